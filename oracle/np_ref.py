@@ -1,0 +1,805 @@
+"""NumPy float64 literal restatement of the STrajNet forward pass + OGMFlow loss.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py): never imported by strajnet_amd.
+PARITY UNPINNED by the reference (no TensorFlow here, no reference tests).
+
+Every function cites the reference file:line it restates (paths relative to
+/root/reference).  Tensors are NHWC like the reference.  The hard-coded
+16/384/64/32 reshapes of the reference are parameterised by the geometry derived
+from cfg['input_size'] so reduced geometries (e.g. 128x128) can be checked fast;
+at cfg-256 / cfg-512 they evaluate to the reference's literals.
+
+Third-party semantics restated from documented behaviour:
+tfa MultiHeadAttention, Keras LayerNormalization/Conv/Dense/UpSampling3D, SAME
+padding, Keras AUC(PR, 100 thresholds, interpolation).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+F64 = np.float64
+
+
+# --------------------------------------------------------------------------- #
+# geometry / parameter registry
+# --------------------------------------------------------------------------- #
+def geometry(cfg, large_ogm=False):
+    """Derived sizes.  modules.py:420-425 (patch grid), :539-556 (stage grids),
+    :582-587,:614-622 (large_ogm pad/crop), :719,:792-794 (decoder dims)."""
+    H, W = cfg['input_size']
+    assert H == W, "reference assumes square inputs (modules.py:583-585,615)"
+    C = cfg['embed_dim']
+    nl = len(cfg['depths'])
+    assert nl == 3, "decoder/FG-MSA hard-code a 3-stage encoder (modules.py:792-801,822)"
+    P = H // 4
+    stage_res = [P // (2 ** i) for i in range(nl)]
+    stage_dim = [C * 2 ** i for i in range(nl)]
+    crop = 2 if large_ogm else 1
+    skip_res = [r // crop for r in stage_res]          # modules.py:617-622
+    hb = skip_res[-1]
+    map_size = H // 2 if large_ogm else H               # modules.py:560-563
+    return dict(H=H, P=P, stage_res=stage_res, stage_dim=stage_dim, skip_res=skip_res,
+                hb=hb, Cb=stage_dim[-1], map_size=map_size, large_ogm=large_ogm,
+                ws=cfg['window_size'], heads=list(cfg['num_heads']), depths=list(cfg['depths']))
+
+
+def param_spec(cfg, fg_msa=True, fg=True):
+    """name -> (shape, kind).  kind in {'glorot','glorot_mha','zeros','ones','rpb','fg_rpe'}.
+    Shapes/layouts = SURVEY.md App. B (Keras layouts: Dense [in,out], Conv HWIO,
+    Conv3D DHWIO, Conv1D [k,in,out], tfa-MHA [H,in,hs] / [H,hs,out])."""
+    C = cfg['embed_dim']
+    ws = cfg['window_size']
+    heads = cfg['num_heads']
+    depths = cfg['depths']
+    sp = OrderedDict()
+
+    def dense(name, i, o, bias=True):
+        sp[name + '/kernel'] = ((i, o), 'glorot')
+        if bias:
+            sp[name + '/bias'] = ((o,), 'zeros')
+
+    def conv(name, kh, kw, i, o, bias=True):
+        sp[name + '/kernel'] = ((kh, kw, i, o), 'glorot')
+        if bias:
+            sp[name + '/bias'] = ((o,), 'zeros')
+
+    def ln(name, c):
+        sp[name + '/gamma'] = ((c,), 'ones')
+        sp[name + '/beta'] = ((c,), 'zeros')
+
+    def mha(name, h, i, hs, o):
+        for k in ('query', 'key', 'value'):
+            sp[f'{name}/{k}_kernel'] = ((h, i, hs), 'glorot_mha')
+        sp[f'{name}/projection_kernel'] = ((h, hs, o), 'glorot_mha')
+        sp[f'{name}/projection_bias'] = ((o,), 'zeros')
+
+    # encoder (modules.py:490-557)
+    for nm, cin in (('patch_embed_vecicle', 11), ('patch_embed_map', 3), ('patch_embed_flow', 2)):
+        conv(nm + '/proj', 4, 4, cin, C)
+        ln(nm + '/norm', C)
+    ln('flow_norm', C)
+    ln('all_patch_norm', C)
+
+    def block(prefix, c, h):
+        ln(prefix + '/norm1', c)
+        dense(prefix + '/attn/qkv', c, 3 * c)
+        sp[prefix + '/attn/relative_position_bias_table'] = (((2 * ws - 1) ** 2, h), 'rpb')
+        dense(prefix + '/attn/proj', c, c)
+        ln(prefix + '/norm2', c)
+        dense(prefix + '/mlp/fc1', c, 4 * c)
+        dense(prefix + '/mlp/fc2', 4 * c, c)
+
+    def merge(prefix, c):
+        ln(prefix + '/downsample/norm', 4 * c)
+        dense(prefix + '/downsample/reduction', 4 * c, 2 * c, bias=False)
+
+    for i in range(depths[0]):
+        block(f'flow_layers0/blocks{i}', C, heads[0])
+    merge('flow_layers0', C)
+    for L in range(3):
+        c = C * 2 ** L
+        for i in range(depths[L]):
+            block(f'layers{L}/blocks{i}', c, heads[L])
+        if L < 2:
+            merge(f'layers{L}', c)
+    Cb = 4 * C
+    # FG-MSA (FG_MSA.py:51-73)
+    if fg_msa:
+        ng, nh = 8, 8
+        nc = Cb
+        gc = nc // ng
+        for p in ('proj_q', 'proj_k', 'proj_v', 'proj_out'):
+            conv('fg_msa/' + p, 1, 1, Cb, nc)
+        conv('fg_msa/conv_offset_0', 3, 3, gc, nc)
+        sp['fg_msa/conv_norm/gamma'] = ((nc,), 'ones')
+        sp['fg_msa/conv_norm/beta'] = ((nc,), 'zeros')
+        conv('fg_msa/conv_offset_proj', 1, 1, gc, 2, bias=False)
+        if fg:
+            conv('fg_msa/conv_offset_proj2', 1, 1, 2, Cb)
+        sp['fg_msa/warp_attn_rel_table'] = (None, 'fg_rpe')   # shape filled from geometry
+    # trajNet (trajNet.py:29-36,65-77,91-120,189-211,256-257)
+    sp['traj_net/traj_encoder/node_feature/kernel'] = ((1, 5, 64), 'glorot')
+    sp['traj_net/traj_encoder/node_feature/bias'] = ((64,), 'zeros')
+    mha('traj_net/traj_encoder/node_attention', 4, 64, 64, 320)
+    dense('traj_net/traj_encoder/vector_feature', 3, 64, bias=False)
+    dense('traj_net/traj_encoder/sublayer', 384, Cb)
+    mha('traj_net/cross_attention/mha', 6, Cb, Cb // 6, Cb)
+    ln('traj_net/cross_attention/norm1', Cb)
+    ln('traj_net/cross_attention/norm2', Cb)
+    dense('traj_net/cross_attention/FFN1', Cb, 4 * Cb)
+    dense('traj_net/cross_attention/FFN2', 4 * Cb, Cb)
+    ln('traj_net/obs_norm', Cb)
+    ln('traj_net/occ_norm', Cb)
+    dense('traj_net/seg_embed', 2, Cb, bias=False)
+    for i in range(8):
+        p = f'cross_attn_obs{i}'
+        mha(p + '/mha', 3, Cb, 128 // 3, 128)
+        ln(p + '/norm1', 128)
+        dense(p + '/FFN1', 128, 512)
+        dense(p + '/FFN2', 512, Cb)
+        ln(p + '/norm2', Cb)
+    # decoder (modules.py:635-730): decode_inds=[3,2,1,0]
+    ch = [48, 96, 128, 192, 384]
+    cin = Cb
+    for i in (3, 2, 1, 0):
+        conv(f'decoder/upconv_{i}_0', 3, 3, cin, ch[i])
+        cin = ch[i]
+    sp['decoder/resconv_3/kernel'] = ((8, 1, 1, 2 * C, ch[3]), 'glorot')
+    sp['decoder/resconv_3/bias'] = ((ch[3],), 'zeros')
+    sp['decoder/resconv_2/kernel'] = ((8, 1, 1, C, ch[2]), 'glorot')
+    sp['decoder/resconv_2/bias'] = ((ch[2],), 'zeros')
+    sp['decoder/resconv_f/kernel'] = ((8, 1, 1, C, 128), 'glorot')
+    sp['decoder/resconv_f/bias'] = ((128,), 'zeros')
+    conv('decoder/upconvf_1_0', 3, 3, 128, ch[1])
+    conv('decoder/upconvf_0_0', 3, 3, ch[1], ch[0])
+    conv('decoder/outconv', 3, 3, ch[0], 2)
+    conv('decoder/outconv_f', 3, 3, ch[0], 2)
+    return sp
+
+
+def make_weights(cfg, seed=0, fg_msa=True, fg=True, large_ogm=False, mode='test', dtype=np.float32):
+    """Seeded weights.  mode='reference': the reference initialisers (glorot-uniform
+    kernels, zero biases, LN gamma=1/beta=0, FG rpe TruncatedNormal(0.01) FG_MSA.py:72),
+    except relative_position_bias_table ~ N(0,0.02) (reference: zeros, modules.py:86) so
+    the bias path is exercised.  mode='test': additionally biases ~N(0,.02),
+    gamma ~ 1+N(0,.05), beta ~ N(0,.02) so bias/affine bugs cannot hide behind zeros."""
+    g = geometry(cfg, large_ogm)
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, (shape, kind) in param_spec(cfg, fg_msa, fg).items():
+        if kind == 'fg_rpe':
+            shape = (2 * g['hb'] - 1, 2 * g['hb'] - 1, 8)
+            w = np.clip(rng.normal(0, 0.01, shape), -0.02, 0.02)
+        elif kind == 'glorot':
+            rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            lim = math.sqrt(6.0 / (shape[-2] * rf + shape[-1] * rf))
+            w = rng.uniform(-lim, lim, shape)
+        elif kind == 'glorot_mha':
+            rf = shape[0]
+            lim = math.sqrt(6.0 / (shape[1] * rf + shape[2] * rf))
+            w = rng.uniform(-lim, lim, shape)
+        elif kind == 'rpb':
+            w = rng.normal(0, 0.02, shape)
+        elif kind == 'zeros':
+            w = rng.normal(0, 0.02, shape) if mode == 'test' else np.zeros(shape)
+        elif kind == 'ones':
+            w = 1.0 + rng.normal(0, 0.05, shape) if mode == 'test' else np.ones(shape)
+        else:
+            raise ValueError(kind)
+        out[name] = np.ascontiguousarray(w, dtype=dtype)
+    return out
+
+
+def make_inputs(cfg, B, seed=1234, large_ogm=False, dtype=np.float32):
+    """Synthetic scene batch of SURVEY.md 8(d) (simplified box model), f32."""
+    g = geometry(cfg, large_ogm)
+    H = g['H']
+    Hm = g['map_size']
+    Hg = 256 if H >= 256 else H          # GT / output grid (decoder always ends at 16*hb)
+    Hg = 16 * g['hb']
+    out = {}
+    ogm = np.zeros((B, H, H, 11, 2), np.float32)
+    flow = np.zeros((B, H, H, 2), np.float32)
+    for b in range(B):
+        rng = np.random.default_rng(seed + b)
+        for _ in range(12):
+            y0, x0 = rng.integers(0, H - 16, 2)
+            vy, vx = rng.integers(-3, 4, 2)
+            hh, ww = (6, 15) if rng.random() < 0.5 else (15, 6)
+            for t in range(11):
+                y, x = int(np.clip(y0 + vy * t, 0, H - hh)), int(np.clip(x0 + vx * t, 0, H - ww))
+                ogm[b, y:y + hh, x:x + ww, t, 0] = 1.0
+                if rng.random() < 0.3:
+                    ogm[b, y:y + hh, x:x + ww, t, 1] = 1.0
+                if t == 10:
+                    flow[b, y:y + hh, x:x + ww] = rng.normal(0, 2.0, 2)
+    rng = np.random.default_rng(seed + 7919)
+    out['ogm'] = ogm
+    out['flow'] = flow
+    out['map_img'] = (rng.integers(-128, 128, (B, Hm, Hm, 3)) / 256.0).astype(np.float32)
+
+    def agents(n):
+        a = np.zeros((B, n, 11, 8), np.float32)
+        a[..., 0:2] = rng.uniform(-40, 40, (B, n, 11, 2))
+        a[..., 2:4] = rng.normal(0, 5, (B, n, 11, 2))
+        a[..., 4] = rng.uniform(-np.pi, np.pi, (B, n, 11))
+        ty = rng.integers(0, 3, (B, n))
+        for k in range(3):
+            a[..., 5 + k] = (ty == k)[..., None]
+        a[:, n - n // 4:] = 0.0                                  # padded agent slots
+        for b in range(B):
+            for i in range(n - n // 4):
+                if rng.random() < 0.25:
+                    a[b, i, :rng.integers(1, 10)] = 0.0           # missing time-step prefix
+        return a
+    out['obs'] = agents(48)
+    out['occ'] = agents(16)
+    out['mapt'] = np.zeros((B, 256, 10, 7), np.float32)
+    gt_obs = (rng.random((B, 8, Hg, Hg, 1)) < 0.02).astype(np.float32)
+    gt_occ = (rng.random((B, 8, Hg, Hg, 1)) < 0.005).astype(np.float32)
+    gt_flow = (rng.normal(0, 3, (B, 8, Hg, Hg, 2)) * np.maximum(gt_obs, gt_occ)).astype(np.float32)
+    origin = (rng.random((B, 8, Hg, Hg, 1)) * (rng.random((B, 8, Hg, Hg, 1)) < 0.03)).astype(np.float32)
+    # keep >=1 positive overlap per waypoint so the use_gt AUC gate never yields sum(res)=0 (App. D-8)
+    origin = np.maximum(origin, 0.9 * np.maximum(gt_obs, gt_occ) * (rng.random((B, 8, Hg, Hg, 1)) < 0.5)).astype(np.float32)
+    out.update(gt_obs=gt_obs, gt_occ=gt_occ, gt_flow=gt_flow, origin_flow=origin)
+    return {k: v.astype(dtype) if v.dtype.kind == 'f' else v for k, v in out.items()}
+
+
+# --------------------------------------------------------------------------- #
+# primitive ops (third-party semantics)
+# --------------------------------------------------------------------------- #
+def gelu(x):
+    """modules.py:18-29 / FG_MSA.py:7-18 (tanh form)."""
+    return x * (0.5 * (1.0 + np.tanh(np.sqrt(2 / np.pi) * (x + 0.044715 * np.power(x, 3)))))
+
+
+def elu(x):
+    """Keras activation='elu', alpha=1 (App. C-6)."""
+    return np.where(x > 0, x, np.expm1(np.minimum(x, 0.0)))
+
+
+def layer_norm(x, gamma, beta, eps):
+    """Keras LayerNormalization over the last axis, biased variance (App. C-2)."""
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + eps) * gamma + beta
+
+
+def softmax(x, axis=-1):
+    m = x.max(axis=axis, keepdims=True)
+    e = np.exp(x - m)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def dense(x, W, b=None):
+    y = x @ W
+    return y if b is None else y + b
+
+
+def conv2d_same(x, W, b=None):
+    """Keras Conv2D stride 1 padding='same', odd kernel; leading dims folded into batch (App. C-3/4)."""
+    kh, kw, cin, cout = W.shape
+    lead = x.shape[:-3]
+    H, Wd = x.shape[-3], x.shape[-2]
+    xx = x.reshape((-1, H, Wd, cin))
+    ph, pw = (kh - 1) // 2, (kw - 1) // 2
+    xp = np.pad(xx, ((0, 0), (ph, kh - 1 - ph), (pw, kw - 1 - pw), (0, 0)))
+    y = np.zeros((xx.shape[0], H, Wd, cout), F64)
+    for i in range(kh):
+        for j in range(kw):
+            y += xp[:, i:i + H, j:j + Wd, :] @ W[i, j]
+    if b is not None:
+        y = y + b
+    return y.reshape(lead + (H, Wd, cout))
+
+
+def conv2d_grouped_same(x, W, b, groups):
+    """Keras Conv2D(groups=g): out channels [g*co,(g+1)*co) read in channels [g*ci,(g+1)*ci) (App. C-3)."""
+    kh, kw, ci, cout = W.shape
+    co = cout // groups
+    ys = [conv2d_same(x[..., g * ci:(g + 1) * ci], W[..., g * co:(g + 1) * co]) for g in range(groups)]
+    return np.concatenate(ys, -1) + b
+
+
+def conv2d_patch(x, W, b, p):
+    """Keras Conv2D kernel=stride=p, padding='valid' (modules.py:430-431)."""
+    B, H, Wd, cin = x.shape
+    xx = x.reshape(B, H // p, p, Wd // p, p, cin).transpose(0, 1, 3, 2, 4, 5).reshape(B, H // p, Wd // p, p * p * cin)
+    return xx @ W.reshape(p * p * cin, -1) + b
+
+
+def conv3d_time_same(x, W, b):
+    """Keras Conv3D kernel (8,1,1) stride 1 padding='same' on [B,T,H,W,C]: even k=8 pads 3 before,
+    4 after: out[t] = sum_j W[j] x[t+j-3] (App. C-4)."""
+    kd = W.shape[0]
+    T = x.shape[1]
+    pb = (kd - 1) // 2
+    y = np.zeros(x.shape[:-1] + (W.shape[-1],), F64)
+    for t in range(T):
+        for j in range(kd):
+            s = t + j - pb
+            if 0 <= s < T:
+                y[:, t] += x[:, s] @ W[j, 0, 0]
+    return y + b
+
+
+def upsample2(x):
+    """UpSampling3D(size=(1,2,2)) = nearest repeat on H,W (App. C-6)."""
+    return np.repeat(np.repeat(x, 2, axis=-3), 2, axis=-2)
+
+
+def tfa_mha(query, key, value, Wq, Wk, Wv, Wo, bo, mask=None):
+    """tensorflow_addons.layers.MultiHeadAttention (un-vendored; App. C-1).  No dropout (eval).
+    The additive mask -10e9*(1-mask) is applied in float32 by the reference, where
+    logit + (-1e10) == -1e10 exactly for |logit| < 512; restated as a select."""
+    hs = Wq.shape[-1]
+    q = np.einsum('...ni,hio->...nho', query, Wq) / np.sqrt(F64(hs))
+    k = np.einsum('...mi,hio->...mho', key, Wk)
+    v = np.einsum('...mi,hio->...mho', value, Wv)
+    logits = np.einsum('...nho,...mho->...hnm', q, k)
+    if mask is not None:
+        m = mask.astype(F64)
+        if m.ndim != logits.ndim:
+            m = np.expand_dims(m, -3)
+        assert np.abs(logits).max() < 512
+        logits = np.where(m != 0, logits, -10e9)
+    coef = softmax(logits, -1)
+    o = np.einsum('...hnm,...mhi->...nhi', coef, v)
+    return np.einsum('...nhi,hio->...no', o, Wo) + bo
+
+
+def interpolate_bilinear_xy(grid, q):
+    """tfa_image.py:87-173 with indexing='xy'.  grid [B,H,W,C], q [B,N,2] = (x,y)."""
+    B, H, Wd, C = grid.shape
+    alphas, floors, ceils = [], [], []
+    for i, dim in enumerate([1, 0]):                       # tfa_image.py:113
+        queries = q[..., dim]
+        size = grid.shape[i + 1]
+        fl = np.minimum(np.maximum(0.0, np.floor(queries)), size - 2)   # :124-128
+        floors.append(fl.astype(np.int32))
+        ceils.append(fl.astype(np.int32) + 1)
+        alphas.append(np.clip(queries - fl, 0.0, 1.0)[..., None])       # :136-139
+    flat = grid.reshape(B * H * Wd, C)
+    boff = (np.arange(B) * H * Wd)[:, None]
+
+    def gather(y, x):
+        return flat[boff + y * Wd + x]
+    tl, tr = gather(floors[0], floors[1]), gather(floors[0], ceils[1])
+    bl, br = gather(ceils[0], floors[1]), gather(ceils[0], ceils[1])
+    top = alphas[1] * (tr - tl) + tl
+    bot = alphas[1] * (br - bl) + bl
+    return alphas[0] * (bot - top) + top
+
+
+def sample(image, warp):
+    """occu_metric.py:345-409 as called with pixel_type=0 (no -0.5 shift, :394), BILINEAR, ZERO border:
+    pad image by 1, warp+1, bilinear with clamped floors/alphas.  warp[...,0]=x (width), [...,1]=y."""
+    img = np.pad(image, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    w = warp + 1
+    flat = w.reshape(w.shape[0], -1, 2)
+    out = interpolate_bilinear_xy(img, flat)
+    return out.reshape(warp.shape[:-1] + (image.shape[-1],))
+
+
+# --------------------------------------------------------------------------- #
+# Swin encoder
+# --------------------------------------------------------------------------- #
+def window_partition(x, ws):
+    """modules.py:49-55."""
+    B, H, W, C = x.shape
+    x = x.reshape(B, H // ws, ws, W // ws, ws, C).transpose(0, 1, 3, 2, 4, 5)
+    return x.reshape(-1, ws, ws, C)
+
+
+def window_reverse(win, ws, H, W, C):
+    """modules.py:58-63."""
+    x = win.reshape(-1, H // ws, W // ws, ws, ws, C).transpose(0, 1, 3, 2, 4, 5)
+    return x.reshape(-1, H, W, C)
+
+
+def relative_position_index(ws):
+    """modules.py:88-98."""
+    coords = np.stack(np.meshgrid(np.arange(ws), np.arange(ws), indexing='ij'))
+    cf = coords.reshape(2, -1)
+    rel = (cf[:, :, None] - cf[:, None, :]).transpose(1, 2, 0).copy()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1).astype(np.int64)
+
+
+def shift_attn_mask(H, W, ws, shift):
+    """modules.py:189-216: [nW, ws*ws, ws*ws] in {0,-100}."""
+    img = np.zeros((1, H, W, 1))
+    cnt = 0
+    for h in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for w in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[:, h, w, :] = cnt
+            cnt += 1
+    mw = window_partition(img, ws).reshape(-1, ws * ws)
+    am = mw[:, None, :] - mw[:, :, None]
+    return np.where(am != 0, -100.0, 0.0)
+
+
+def window_attention(x, p, prefix, ws, heads, mask):
+    """modules.py:103-134 (eval: dropout off)."""
+    B_, N, C = x.shape
+    hd = C // heads
+    qkv = dense(x, p[prefix + '/attn/qkv/kernel'], p[prefix + '/attn/qkv/bias'])
+    qkv = qkv.reshape(B_, N, 3, heads, hd).transpose(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(0, 1, 3, 2)
+    idx = relative_position_index(ws).reshape(-1)
+    rpb = p[prefix + '/attn/relative_position_bias_table'][idx].reshape(N, N, heads).transpose(2, 0, 1)
+    attn = attn + rpb[None]
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = attn.reshape(-1, nW, heads, N, N) + mask[None, :, None]
+        attn = attn.reshape(-1, heads, N, N)
+    attn = softmax(attn, -1)
+    y = (attn @ v).transpose(0, 2, 1, 3).reshape(B_, N, C)
+    return dense(y, p[prefix + '/attn/proj/kernel'], p[prefix + '/attn/proj/bias'])
+
+
+def swin_block(x, p, prefix, res, heads, ws, shift):
+    """modules.py:220-262 (eval: DropPath identity)."""
+    H = W = res
+    if min(res, res) <= ws:            # modules.py:173-175
+        shift, ws = 0, min(res, res)
+    B, L, C = x.shape
+    assert L == H * W
+    sc = x
+    x = layer_norm(x, p[prefix + '/norm1/gamma'], p[prefix + '/norm1/beta'], 1e-5).reshape(B, H, W, C)
+    if shift > 0:
+        x = np.roll(x, (-shift, -shift), (1, 2))
+    xw = window_partition(x, ws).reshape(-1, ws * ws, C)
+    mask = shift_attn_mask(H, W, ws, shift) if shift > 0 else None
+    aw = window_attention(xw, p, prefix, ws, heads, mask).reshape(-1, ws, ws, C)
+    x = window_reverse(aw, ws, H, W, C)
+    if shift > 0:
+        x = np.roll(x, (shift, shift), (1, 2))
+    x = sc + x.reshape(B, H * W, C)
+    h = layer_norm(x, p[prefix + '/norm2/gamma'], p[prefix + '/norm2/beta'], 1e-5)
+    h = gelu(dense(h, p[prefix + '/mlp/fc1/kernel'], p[prefix + '/mlp/fc1/bias']))
+    return x + dense(h, p[prefix + '/mlp/fc2/kernel'], p[prefix + '/mlp/fc2/bias'])
+
+
+def patch_merging(x, p, prefix, res):
+    """modules.py:274-292."""
+    B, L, C = x.shape
+    x = x.reshape(B, res, res, C)
+    x = np.concatenate([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+    x = x.reshape(B, (res // 2) ** 2, 4 * C)
+    x = layer_norm(x, p[prefix + '/downsample/norm/gamma'], p[prefix + '/downsample/norm/beta'], 1e-5)
+    return dense(x, p[prefix + '/downsample/reduction/kernel'])
+
+
+def basic_layer(x, p, prefix, res, depth, heads, ws, downsample):
+    """modules.py:351-364."""
+    for i in range(depth):
+        x = swin_block(x, p, f'{prefix}/blocks{i}', res, heads, ws, 0 if i % 2 == 0 else ws // 2)
+    if downsample:
+        return patch_merging(x, p, prefix, res), x
+    return x, x
+
+
+def patch_embed(x, p, name):
+    """modules.py:437-446."""
+    y = conv2d_patch(x, p[name + '/proj/kernel'], p[name + '/proj/bias'], 4)
+    y = y.reshape(y.shape[0], -1, y.shape[-1])
+    return layer_norm(y, p[name + '/norm/gamma'], p[name + '/norm/beta'], 1e-5)
+
+
+def encoder(p, g, ogm, map_img, flow, taps=None):
+    """SwinTransformerEncoder.forward_features, sep_encode & flow_sep & use_flow branch (modules.py:570-624)."""
+    C = g['stage_dim'][0]
+    P = g['P']
+    vec = ogm[..., 0]                                        # :572 (ped/cyc dropped)
+    fl = patch_embed(flow, p, 'patch_embed_flow')            # :576
+    fl = layer_norm(fl, p['flow_norm/gamma'], p['flow_norm/beta'], 1e-5)
+    flow_x, flow_res = basic_layer(fl, p, 'flow_layers0', P, g['depths'][0], g['heads'][0], g['ws'], True)
+    if not g['large_ogm']:
+        x = patch_embed(vec, p, 'patch_embed_vecicle') + patch_embed(map_img, p, 'patch_embed_map')
+    else:                                                    # :582-587
+        maps = patch_embed(map_img, p, 'patch_embed_map')
+        Pm = g['map_size'] // 4
+        pad = (P - Pm) // 2
+        maps = np.pad(maps.reshape(-1, Pm, Pm, C), ((0, 0), (pad, pad), (pad, pad), (0, 0))).reshape(-1, P * P, C)
+        x = patch_embed(vec, p, 'patch_embed_vecicle') + maps
+    x = layer_norm(x, p['all_patch_norm/gamma'], p['all_patch_norm/beta'], 1e-5)   # :602
+    if taps is not None:
+        taps['stem'] = x
+        taps['flow_res'] = flow_res
+        taps['flow_x'] = flow_x
+    res_list = []
+    for i in range(3):
+        r, c = g['stage_res'][i], g['stage_dim'][i]
+        x, res = basic_layer(x, p, f'layers{i}', r, g['depths'][i], g['heads'][i], g['ws'], i < 2)
+        if i == 2:
+            res = res.reshape(-1, r, r, c)                   # :611
+        if i == 0:
+            x = x + flow_x                                   # :613
+            if g['large_ogm']:                               # :615
+                q = r // 4
+                flow_res = flow_res.reshape(-1, r, r, c)[:, q:q + r // 2, q:q + r // 2].reshape(-1, (r // 2) ** 2, c)
+            res_list.append(flow_res)
+        if g['large_ogm']:                                   # :617-622
+            cb, ce = int(r * 0.25), int(r * 0.75)
+            res = res.reshape(-1, r, r, c)[:, cb:ce, cb:ce].reshape(-1, (r // 2) ** 2, c)
+        res_list.append(res)
+        if taps is not None:
+            taps[f'res{i}'] = res
+    return res_list
+
+
+# --------------------------------------------------------------------------- #
+# FG-MSA
+# --------------------------------------------------------------------------- #
+def ref_points(Hk, Wk, n):
+    """FG_MSA.py:95-104: default 'xy' meshgrid => ref[i,j] = (j, i)."""
+    ry, rx = np.meshgrid(np.arange(Hk), np.arange(Wk))
+    ref = np.stack((ry, rx), -1).astype(F64)
+    return np.repeat(ref[None], n, 0)
+
+
+def fgmsa(p, x, fg=True, n_heads=8, n_groups=8, taps=None):
+    """FGMSA.call (FG_MSA.py:106-183), eval.  Returns (y, pos, flow_hidden|reference)."""
+    B, H, W, C = x.shape
+    nc = C
+    hc = nc // n_heads
+    gc = nc // n_groups
+    gh = n_heads // n_groups
+
+    def c1(t, name, bias=True):
+        k = p[f'fg_msa/{name}/kernel']
+        return dense(t, k.reshape(k.shape[2], k.shape[3]), p[f'fg_msa/{name}/bias'] if bias else None)
+    q = c1(x, 'proj_q')
+    # _get_offset (:84-92)
+    o = conv2d_grouped_same(q, p['fg_msa/conv_offset_0/kernel'], p['fg_msa/conv_offset_0/bias'], n_groups)
+    o = layer_norm(o.reshape(B, H * W, nc), p['fg_msa/conv_norm/gamma'], p['fg_msa/conv_norm/beta'], 1e-3)
+    o = gelu(o.reshape(B, H, W, nc))
+    o = o.reshape(B, H, W, n_groups, gc).transpose(0, 3, 1, 2, 4).reshape(B * n_groups, H, W, gc)
+    offset = c1(o, 'conv_offset_proj', bias=False)                        # [B*g,H,W,2]
+    Hk, Wk = H, W
+    n_sample = Hk * Wk
+    offset = np.tanh(offset) * np.array([Hk / 2, Wk / 2]).reshape(1, 1, 1, 2)   # :115-117
+    flow_hidden = None
+    if fg:                                                                # :120-123
+        flow_hidden = c1(offset.reshape(B, n_groups, Hk, Wk, 2), 'conv_offset_proj2')
+    reference = ref_points(Hk, Wk, B * n_groups)
+    pos = offset + reference                                              # :134
+    # :141-142 the sampled x is dead; K/V come from the unsampled x (App. D-3)
+    x_s = x.reshape(B, n_sample, 1, C)
+    qh = q.reshape(B, H * W, n_heads, hc).transpose(0, 2, 1, 3).reshape(B * n_heads, H * W, hc)
+    kh = c1(x_s, 'proj_k').reshape(B, n_sample, n_heads, hc).transpose(0, 2, 1, 3).reshape(B * n_heads, n_sample, hc)
+    vh = c1(x_s, 'proj_v').reshape(B, n_sample, n_heads, hc).transpose(0, 2, 1, 3).reshape(B * n_heads, n_sample, hc)
+    attn = np.einsum('bqc,bkc->bqk', qh, kh) * hc ** -0.5
+    # rpe bias (:150-172)
+    rpe = np.repeat(p['fg_msa/warp_attn_rel_table'][None], B, 0)
+    q_grid = ref_points(H, W, B * n_groups)
+    disp = q_grid.reshape(B * n_groups, H * W, 2)[:, :, None] - pos.reshape(B * n_groups, n_sample, 2)[:, None]
+    rpe = rpe.reshape(B, 2 * H - 1, 2 * W - 1, n_groups, gh).transpose(0, 3, 1, 2, 4)
+    disp = np.concatenate([disp[..., 1:2], disp[..., 0:1]], -1)
+    bias = sample(rpe.reshape(B * n_groups, 2 * H - 1, 2 * W - 1, gh), disp)
+    bias = bias.reshape(B * n_groups, H * W, n_sample, gh).transpose(0, 3, 1, 2).reshape(B * n_heads, H * W, n_sample)
+    attn = softmax(attn + bias, 2)
+    out = np.einsum('bkv,bvc->bck', attn, vh)                             # :176
+    out = out.reshape(B, C, H, W).transpose(0, 2, 3, 1)                   # :177
+    y = c1(out, 'proj_out')
+    pos = pos.reshape(B, n_groups, Hk, Wk, 2)
+    if taps is not None:
+        taps['fg_offset'] = offset.reshape(B, n_groups, Hk, Wk, 2)
+        taps['fg_bias'] = bias
+        taps['fg_y'] = y
+    if fg:
+        return y, pos, flow_hidden
+    return y, pos, reference.reshape(B, n_groups, Hk, Wk, 2)
+
+
+# --------------------------------------------------------------------------- #
+# trajNet
+# --------------------------------------------------------------------------- #
+def _mha_w(p, name):
+    return (p[name + '/query_kernel'], p[name + '/key_kernel'], p[name + '/value_kernel'],
+            p[name + '/projection_kernel'], p[name + '/projection_bias'])
+
+
+def traj_encoder(p, inputs, mask):
+    """TrajEncoder.call (trajNet.py:38-48), eval.  inputs [B,11,8], mask [B,11] bool."""
+    pre = 'traj_net/traj_encoder'
+    m = mask.astype(np.int32)
+    m2 = m[:, :, None] * m[:, None, :]
+    nodes = elu(dense(inputs[:, :, :5], p[pre + '/node_feature/kernel'][0], p[pre + '/node_feature/bias']))
+    nodes = tfa_mha(nodes, nodes, nodes, *_mha_w(p, pre + '/node_attention'), mask=m2)
+    nodes = nodes.max(axis=1)                                             # GlobalMaxPooling1D
+    vector = dense(inputs[:, 0, 5:], p[pre + '/vector_feature/kernel'])
+    out = np.concatenate([nodes, vector], 1)
+    return elu(dense(out, p[pre + '/sublayer/kernel'], p[pre + '/sublayer/bias']))
+
+
+def cross_attention(p, pre, query, key, mask):
+    """Cross_Attention.call / Cross_AttentionT.call (trajNet.py:79-87, 224-234), eval, sep_actors off."""
+    v = tfa_mha(query, key, key, *_mha_w(p, pre + '/mha'), mask=mask)
+    v = layer_norm(v, p[pre + '/norm1/gamma'], p[pre + '/norm1/beta'], 1e-3)
+    v = elu(dense(v, p[pre + '/FFN1/kernel'], p[pre + '/FFN1/bias']))
+    v = dense(v, p[pre + '/FFN2/kernel'], p[pre + '/FFN2/bias'])
+    return layer_norm(v, p[pre + '/norm2/gamma'], p[pre + '/norm2/beta'], 1e-3)
+
+
+def traj_net(p, obs_traj, occ_traj):
+    """TrajNet.call (trajNet.py:125-187), no_attn=False, double_net=False."""
+    n_obs, n_occ = obs_traj.shape[1], occ_traj.shape[1]
+    obs_mask = (obs_traj != 0)[:, :, :, 0]
+    obs = np.stack([traj_encoder(p, obs_traj[:, i], obs_mask[:, i]) for i in range(n_obs)], 1)
+    occ_mask = (occ_traj != 0)[:, :, :, 0]
+    occ = np.stack([traj_encoder(p, occ_traj[:, i], occ_mask[:, i]) for i in range(n_occ)], 1)
+    bi = np.repeat(np.array([[1, 0], [0, 1]], F64), [n_obs, n_occ], 0)
+    embed = dense(np.repeat(bi[None], obs.shape[0], 0), p['traj_net/seg_embed/kernel'])
+    cmask = (np.concatenate([obs_mask, occ_mask], 1).astype(np.int32).sum(-1) != 0).astype(np.int32)
+    concat = np.concatenate([obs, occ], 1) * cmask[:, :, None].astype(F64)
+    query = concat + embed
+    amask = cmask[:, :, None] * cmask[:, None, :]
+    value = cross_attention(p, 'traj_net/cross_attention', query, concat, amask)
+    obs = obs + value[:, :n_obs]
+    occ = occ + value[:, n_obs:]
+    obs = layer_norm(obs + embed[:, :n_obs], p['traj_net/obs_norm/gamma'], p['traj_net/obs_norm/beta'], 1e-3)
+    occ = layer_norm(occ + embed[:, n_obs:], p['traj_net/occ_norm/gamma'], p['traj_net/occ_norm/beta'], 1e-3)
+    return obs, occ, cmask
+
+
+def traj_cross_attention(p, pic, obs_traj, occ_traj, taps=None):
+    """TrajNetCrossAttention.call (trajNet.py:284-319), actor_only=True, sep_actors=False."""
+    B, T, H, W, C = pic.shape
+    obs, occ, tmask = traj_net(p, obs_traj, occ_traj)
+    flat = pic.reshape(B, 8, H * W, C)
+    pic_mask = np.ones((B, H * W), np.int32)
+    amask = pic_mask[:, :, None] * tmask[:, None, :]
+    key = np.concatenate([obs, occ], 1)
+    if taps is not None:
+        taps['traj_key'] = key
+        taps['traj_mask'] = tmask
+    outs = []
+    for i in range(8):
+        o = cross_attention(p, f'cross_attn_obs{i}', flat[:, i], key, amask)
+        outs.append(o + flat[:, i])
+    return np.stack(outs, 1).reshape(B, 8, H, W, C)
+
+
+# --------------------------------------------------------------------------- #
+# decoder + assembly
+# --------------------------------------------------------------------------- #
+def decoder(p, g, x, res_list, taps=None):
+    """Pyramid3DDecoder.call (modules.py:739-772) with shallow_decode=1, flow_sep_decode=True,
+    use_pyramid=True, rep_res=True, stp_grad=False."""
+    flow_res, res_list = res_list[0], res_list[1:]
+    ind_list = [1, 0]
+    rdim = [g['skip_res'][1], g['skip_res'][0]]
+    names = ['decoder/upconv_3_0', 'decoder/upconv_2_0', 'decoder/upconv_1_0', 'decoder/upconv_0_0']
+    rnames = ['decoder/resconv_3', 'decoder/resconv_2']
+    flow_x = None
+    for i, nm in enumerate(names):
+        x = elu(conv2d_same(upsample2(x), p[nm + '/kernel'], p[nm + '/bias']))
+        if i <= 1:
+            r = res_list[ind_list[i]]
+            rf = np.repeat(r[:, None], 8, 1).reshape(-1, 8, rdim[i], rdim[i], r.shape[-1])
+            x = x + elu(conv3d_time_same(rf, p[rnames[i] + '/kernel'], p[rnames[i] + '/bias']))
+        if i == 1:
+            fr = flow_res.reshape(-1, rdim[1], rdim[1], flow_res.shape[-1])
+            fr = np.repeat(fr[:, None], 8, 1)
+            flow_x = x + elu(conv3d_time_same(fr, p['decoder/resconv_f/kernel'], p['decoder/resconv_f/bias']))
+        if taps is not None:
+            taps[f'dec{i}'] = x
+    y = conv2d_same(x, p['decoder/outconv/kernel'], p['decoder/outconv/bias'])
+    for nm in ('decoder/upconvf_1_0', 'decoder/upconvf_0_0'):
+        flow_x = elu(conv2d_same(upsample2(flow_x), p[nm + '/kernel'], p[nm + '/bias']))
+    fy = conv2d_same(flow_x, p['decoder/outconv_f/kernel'], p['decoder/outconv_f/bias'])
+    return np.concatenate([y, fy], -1)
+
+
+def strajnet_forward(p, cfg, ogm, map_img, obs, occ, flow, fg_msa=True, fg=True, large_ogm=False, taps=None):
+    """STrajNet.call (modules.py:815-839), training=False semantics.  Returns [B,Hg,Hg,32] float64."""
+    p = {k: np.asarray(v, F64) for k, v in p.items()}
+    ogm, map_img, obs, occ, flow = (np.asarray(a, F64) for a in (ogm, map_img, obs, occ, flow))
+    g = geometry(cfg, large_ogm)
+    hb, Cb = g['hb'], g['Cb']
+    res_list = encoder(p, g, ogm, map_img, flow, taps)
+    q = res_list[-1].reshape(-1, hb, hb, Cb)
+    ref = None
+    if fg_msa:
+        res, pos, ref = fgmsa(p, q, fg=fg, taps=taps)
+        q = res + q
+    q = q.reshape(-1, hb * hb, Cb)
+    query = np.repeat(q[:, None], 8, 1)
+    if fg:
+        query = ref.reshape(-1, 8, hb * hb, Cb) + query
+    if taps is not None:
+        taps['query'] = query
+    ov = traj_cross_attention(p, query.reshape(-1, 8, hb, hb, Cb), obs, occ, taps)
+    if taps is not None:
+        taps['obs_value'] = ov
+    y = decoder(p, g, ov, res_list, taps)
+    Hg = y.shape[2]
+    return y.transpose(0, 2, 3, 1, 4).reshape(-1, Hg, Hg, 32)
+
+
+# --------------------------------------------------------------------------- #
+# loss + AUC
+# --------------------------------------------------------------------------- #
+def keras_auc_pr(y_true, y_pred, num_thresholds=100):
+    """tf.keras.metrics.AUC(num_thresholds=100, curve='PR', summation_method='interpolation')
+    (App. C-7; call sites loss.py:41,134-136, occu_metric.py:165-174).  float32 thresholds."""
+    eps = 1e-7
+    thr = np.array([0.0 - eps] + [(i + 1) * 1.0 / (num_thresholds - 1) for i in range(num_thresholds - 2)] + [1.0 + eps],
+                   np.float32)
+    yt = np.asarray(y_true).reshape(-1).astype(bool)
+    yp = np.asarray(y_pred, np.float32).reshape(-1)
+    pos = yp[None, :] > thr[:, None]
+    tp = (pos & yt[None]).sum(1).astype(F64)
+    fp = (pos & ~yt[None]).sum(1).astype(F64)
+    fn = ((~pos) & yt[None]).sum(1).astype(F64)
+
+    def dnn(a, b):
+        return np.where(b != 0, a / np.where(b != 0, b, 1), 0.0)
+    n = num_thresholds
+    dtp = tp[:n - 1] - tp[1:]
+    pp = tp + fp
+    dp = pp[:n - 1] - pp[1:]
+    slope = dnn(dtp, np.maximum(dp, 0))
+    icpt = tp[1:] - slope * pp[1:]
+    ratio = np.where((pp[:n - 1] > 0) & (pp[1:] > 0), dnn(pp[:n - 1], np.maximum(pp[1:], 0)), 1.0)
+    inc = dnn(slope * (dtp + icpt * np.log(ratio)), np.maximum(tp[1:] + fn[1:], 0))
+    return float(inc.sum())
+
+
+def sigmoid_xe(labels, logits):
+    """tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log1p(exp(-|x|))."""
+    return np.maximum(logits, 0) - logits * labels + np.log1p(np.exp(-np.abs(logits)))
+
+
+def ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin_flow, ogm_weight=1000.0, occ_weight=1000.0,
+                  flow_weight=1.0, replica=1.0, flow_origin_weight=1000.0, no_use_warp=False, use_pred=False,
+                  use_focal_loss=False, use_gt=True, return_gates=False):
+    """OGMFlow_loss.__call__ (loss.py:50-170) on the [B,H,W,32] model output with the slicing of
+    train.py:105-140 (channel 4k+{0,1,2:4}; GT [B,8,H,W,*] sliced on axis 1).  Focal branch restated
+    only for use_focal_loss=False (train.py:196)."""
+    assert not use_focal_loss and not use_pred, "oracle restates the train.py:195-196 configuration"
+    logits = np.asarray(logits, F64)
+    gt_obs, gt_occ, gt_flow, origin_flow = (np.asarray(a, F64) for a in (gt_obs, gt_occ, gt_flow, origin_flow))
+    B, H, W, _ = logits.shape
+    hh = np.arange(H, dtype=F64)
+    ww = np.arange(W, dtype=F64)
+    h_idx, w_idx = np.meshgrid(hh, ww)                                   # loss.py:83
+    ident = np.stack((w_idx.T, h_idx.T), -1)                             # :86-90  -> [...,0]=x(col), [...,1]=y(row)
+    d = dict(observed_xe=[], occluded_xe=[], flow=[], flow_warp_xe=[])
+    f_c = []
+    for k in range(8):
+        po, pc, pf = logits[..., 4 * k:4 * k + 1], logits[..., 4 * k + 1:4 * k + 2], logits[..., 4 * k + 2:4 * k + 4]
+        to, tc, tf_, org = gt_obs[:, k], gt_occ[:, k], gt_flow[:, k], origin_flow[:, k]
+        d['observed_xe'].append(ogm_weight * sigmoid_xe(to, po).sum() / (po.size * replica))      # :173-200
+        d['occluded_xe'].append(occ_weight * sigmoid_xe(tc, pc).sum() / (pc.size * replica))      # :202-229
+        true_all = np.clip(to + tc, 0, 1)
+        if use_gt:                                                       # :127-137
+            wp = sample(org, ident[None] + tf_)
+            auc = keras_auc_pr(true_all, wp * true_all)
+            res = float((1 - auc) < 1.0)
+        else:
+            res = 1.0
+        f_c.append(res)
+        # _flow_loss (:273-295), default loss_weight=1 (flow_weight is never applied)
+        exists = ((tf_[..., 0:1] != 0) | (tf_[..., 1:2] != 0)).astype(F64)
+        diff = (tf_ - pf) * exists
+        den = exists.sum() * replica / 2
+        fl = np.abs(diff).sum() / den if den != 0 else 0.0
+        d['flow'].append(res * fl)
+        if not no_use_warp:                                              # :144-158, quirk App. D-8
+            wpo = sample(org, ident[None] + pf)
+            sig = np.clip(1 / (1 + np.exp(-to)) + 1 / (1 + np.exp(-tc)), 0, 1)
+            joint = sig * wpo
+            d['flow_warp_xe'].append(res * flow_origin_weight * sigmoid_xe(true_all, joint).sum() / (true_all.size * replica))
+    out = dict(observed_xe=sum(d['observed_xe']) / 8, occluded_xe=sum(d['occluded_xe']) / 8,
+               flow=sum(d['flow']) / sum(f_c),
+               flow_warp_xe=(sum(d['flow_warp_xe']) / sum(f_c)) if not no_use_warp else 0.0)
+    if return_gates:
+        return out, f_c
+    return out
