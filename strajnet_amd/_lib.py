@@ -1,0 +1,77 @@
+"""ctypes binding of libstrajnet_hip.so (the C-ABI HIP library, see include/strajnet_hip.h).
+
+The product path has NO CPU fallback: if the library is missing this raises, loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libstrajnet_hip.so')
+
+vp, ci, cl, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+
+# name -> argument ctypes (return type is always int except where noted)
+SIGNATURES = {
+    'stj_abi_version': [],
+    'stj_gemm': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci,
+                 cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl,
+                 ci, cf, ci, ci, ci, ci, vp],
+    'stj_colsum': [vp, vp, ci, ci, cl, ci, vp],
+    'stj_cast': [vp, ci, vp, ci, cl, vp],
+    'stj_unary_fwd': [vp, vp, cl, ci, cf, ci, vp],
+    'stj_unary_bwd': [vp, vp, vp, cl, ci, cf, ci, vp],
+    'stj_maxpool_fwd': [vp, vp, vp, cl, ci, ci, ci, vp],
+    'stj_maxpool_bwd': [vp, vp, vp, cl, ci, ci, ci, vp],
+    'stj_layernorm_fwd': [vp, vp, vp, vp, vp, vp, cl, ci, cf, ci, ci, ci, vp],
+    'stj_layernorm_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, ci, vp],
+    'stj_win_attn_fwd': [vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    'stj_win_attn_bwd': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    'stj_softmax_fwd': [vp, vp, vp, vp, vp, cl, ci, ci, ci, ci, vp],
+    'stj_softmax_bwd': [vp, vp, vp, cl, ci, ci, vp],
+    'stj_fg_bias_fwd': [vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    'stj_fg_bias_bwd': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    'stj_upconv_prep': [vp, vp, vp, ci, ci, ci, vp],
+    'stj_upconv_fold': [vp, vp, ci, ci, vp],
+    'stj_upconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
+    'stj_upconv_dgrad': [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    'stj_upconv_wgrad': [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    'stj_outconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
+    'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
+    'stj_im2col_patch': [vp, vp, ci, ci, ci, ci, cl, ci, ci, vp],
+    'stj_im2col3': [vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    'stj_col2im3': [vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    'stj_loss_auc_gate': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp],
+    'stj_loss_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp],
+    'stj_loss_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+}
+
+_lib = None
+
+
+class StjError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the C-ABI library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StjError(f'{LIB_PATH} not found: build it with `python -m strajnet_amd.build` '
+                           '(hipcc --offload-arch=gfx950).  There is no CPU / eager fallback.')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here == header / library mismatch
+            fn.argtypes = args
+            fn.restype = ci
+        L.stj_last_error.argtypes = []
+        L.stj_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise StjError(f'{name} failed ({rc}): {L.stj_last_error().decode()}')

@@ -1,0 +1,192 @@
+// Common device helpers for the STrajNet gfx950 (CDNA4 / MI355X) kernels.
+// Wavefront = 64 lanes.  MFMA tiles used: v_mfma_f32_16x16x32_bf16 (bf16 storage mode)
+// and v_mfma_f32_16x16x4_f32 (exact-f32 parity mode).  C/D fragment map for both:
+//   col = lane & 15, row = (lane >> 4) * 4 + reg.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define STJ_WAVE 64
+
+struct bf16 { uint16_t v; };
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ float bf2f(uint16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                            // RNE
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16>(const bf16* p) { return bf2f(p->v); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float x);
+template <> __device__ __forceinline__ void stf<float>(float* p, float x) { *p = x; }
+template <> __device__ __forceinline__ void stf<bf16>(bf16* p, float x) { p->v = f2bf(x); }
+
+// ---- vector (16-byte) global access converted to/from float ---------------------------
+template <typename T> struct Vec;   // elements per 16 bytes
+template <> struct Vec<float> { static constexpr int N = 4; };
+template <> struct Vec<bf16> { static constexpr int N = 8; };
+
+template <typename T> __device__ __forceinline__ void ld16(const T* p, float* out);
+template <> __device__ __forceinline__ void ld16<float>(const float* p, float* out) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <> __device__ __forceinline__ void ld16<bf16>(const bf16* p, float* out) {
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __uint_as_float(w[i] << 16);
+    out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const float* in);
+template <> __device__ __forceinline__ void st16<float>(float* p, const float* in) {
+  *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
+}
+template <> __device__ __forceinline__ void st16<bf16>(bf16* p, const float* in) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(in[2 * i]) | ((uint32_t)f2bf(in[2 * i + 1]) << 16);
+  *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- activations -----------------------------------------------------------------------
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_ELU = 2 };
+
+__device__ __forceinline__ float gelu_f(float x) {   // tanh form (reference modules.py:18-29)
+  const float k = 0.7978845608028654f;
+  float u = k * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float k = 0.7978845608028654f;
+  float x2 = x * x;
+  float u = k * (x + 0.044715f * x * x2);
+  float t = tanhf(u);
+  float du = k * (1.f + 3.f * 0.044715f * x2);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+}
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float apply_act(float x, int act) {
+  return act == ACT_GELU ? gelu_f(x) : (act == ACT_ELU ? elu_f(x) : x);
+}
+
+// ---- wave reductions (64 lanes) ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- MFMA tile engine ---------------------------------------------------------------------
+// LDS operand tiles are "K-contiguous": A as [m][k], B as [n][k], leading dim `ld` elements.
+// Frag<T>: per-lane operand registers for one 16x16xKSTEP MFMA.
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  // one "step" = 16 k's = 4 x v_mfma_f32_16x16x4_f32.  Lane (row=lane&15, g=lane>>4) supplies k = k0+4g+j to the
+  // j-th MFMA; A and B use the same k mapping, so the contraction is merely visited in a permuted order.
+  static constexpr int KSTEP = 16;
+  typedef f32x4 Frag;
+  __device__ static __forceinline__ Frag load(const float* tile, int ld, int row0, int k0, int lane) {
+    return *reinterpret_cast<const f32x4*>(tile + (row0 + (lane & 15)) * ld + k0 + (lane >> 4) * 4);
+  }
+  // generic strided read: element (row,k) at tile[row*sr + k*sk]
+  __device__ static __forceinline__ Frag load_strided(const float* tile, int sr, int sk, int row0, int k0, int lane) {
+    const float* p = tile + (row0 + (lane & 15)) * sr + (k0 + (lane >> 4) * 4) * sk;
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = p[j * sk];
+    return f;
+  }
+  __device__ static __forceinline__ Frag from_global(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static constexpr int LANE_K = 4;   // consecutive k elements per lane per step
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+  }
+};
+template <> struct Mma<bf16> {
+  static constexpr int KSTEP = 32;
+  typedef s16x8 Frag;
+  // elements (row = lane&15, k = k0 + (lane>>4)*8 .. +8), 16-byte aligned ds_read_b128
+  __device__ static __forceinline__ Frag load(const bf16* tile, int ld, int row0, int k0, int lane) {
+    return *reinterpret_cast<const s16x8*>(tile + (row0 + (lane & 15)) * ld + k0 + (lane >> 4) * 8);
+  }
+  __device__ static __forceinline__ Frag load_strided(const bf16* tile, int sr, int sk, int row0, int k0, int lane) {
+    const uint16_t* p = reinterpret_cast<const uint16_t*>(tile) + (row0 + (lane & 15)) * sr + (k0 + (lane >> 4) * 8) * sk;
+    s16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (short)p[j * sk];
+    return f;
+  }
+  __device__ static __forceinline__ Frag from_global(const bf16* p) { return *reinterpret_cast<const s16x8*>(p); }
+  static constexpr int LANE_K = 8;
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+// accumulate a (FM*16) x (FN*16) wave tile over kk in [0,KT) from K-contiguous LDS tiles
+template <typename T, int FM, int FN>
+__device__ __forceinline__ void mma_tile(const T* As, int lda, const T* Bs, int ldb, int KT, int lane, f32x4 (&acc)[FM][FN]) {
+  for (int k0 = 0; k0 < KT; k0 += Mma<T>::KSTEP) {
+    typename Mma<T>::Frag a[FM], b[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) a[i] = Mma<T>::load(As, lda, i * 16, k0, lane);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b[j] = Mma<T>::load(Bs, ldb, j * 16, k0, lane);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
+  }
+}
+
+// LDS row padding (elements) that keeps 16-byte alignment of rows
+template <typename T> struct LdsPad;
+template <> struct LdsPad<float> { static constexpr int P = 4; };
+template <> struct LdsPad<bf16> { static constexpr int P = 8; };
+
+// ---- zero-padded clamped bilinear sampling (reference occu_metric.py:345-409 + tfa_image.py:87-173) ----
+struct Bil {
+  int y0, x0; float ay, ax; bool gy, gx;   // floor indices in the padded image, alphas, alpha-differentiable flags
+};
+__device__ __forceinline__ Bil bil_setup(float qx, float qy, int Hp, int Wp) {
+  Bil r;
+  float fy = fminf(fmaxf(0.f, floorf(qy)), (float)(Hp - 2));
+  float fx = fminf(fmaxf(0.f, floorf(qx)), (float)(Wp - 2));
+  float ay = qy - fy, ax = qx - fx;
+  r.gy = ay > 0.f && ay < 1.f;
+  r.gx = ax > 0.f && ax < 1.f;
+  r.ay = fminf(fmaxf(ay, 0.f), 1.f);
+  r.ax = fminf(fmaxf(ax, 0.f), 1.f);
+  r.y0 = (int)fy; r.x0 = (int)fx;
+  return r;
+}
+// value of the zero-padded image at padded coords (y,x); img is [H][W] with element stride `es`
+__device__ __forceinline__ float pad_at(const float* img, int H, int W, int es, int y, int x) {
+  return (y >= 1 && y <= H && x >= 1 && x <= W) ? img[((y - 1) * W + (x - 1)) * es] : 0.f;
+}
+
+
+// ---- host-side error plumbing -------------------------------------------------------------
+enum { STJ_OK = 0, STJ_EINVAL = -1, STJ_ELAUNCH = -2, STJ_EUNSUPPORTED = -3 };
+enum { STJ_F32 = 0, STJ_BF16 = 1 };
+void stj_set_error(const char* fmt, ...);
+int stj_check_launch(const char* what);

@@ -1,0 +1,664 @@
+// Decoder convolutions of the FPN / pyramid decoder (reference modules.py:630-772, Pyramid3DDecoder):
+//   UpSampling3D(1,2,2) nearest -> Conv2D 3x3 SAME + bias -> ELU   (modules.py:746-748, 732-735)
+// as an implicit GEMM on MFMA with the 2x nearest upsample FOLDED into the weights: output pixel
+// (2i+a, 2j+b) only ever sees the 2x2 low-res neighbourhood X[i+a-1+r, j+b-1+s], r,s in {0,1}, with
+// summed taps  Weff[a,b,r,s] = sum_{dy in R(a,r)} sum_{dx in R(b,s)} W[dy,dx]
+//   R(0,0)={-1}  R(0,1)={0,+1}  R(1,0)={-1,0}  R(1,1)={+1}
+// (exact algebra, 2.25x fewer MACs than the materialised upsample; SURVEY.md App. C KAT vi).
+// Zero padding at the upsampled border == zero padding of the low-res map, so halo pixels outside the
+// low-res map are staged as zeros.
+//   forward : Y[f,2i+a,2j+b,:] = ELU( sum_{r,s} X[f,i+a-1+r,j+b-1+s,:] . Weff[a,b,r,s] + bias )
+//   dgrad   : dX[f,i,j,:]      = sum_{u,v in -1..2} dP[f,2i+u,2j+v,:] . Weff[a,b,r,s]^T,  a=u&1, r=(2-a-u)/2 (same for v)
+//   wgrad   : dWeff[a,b,r,s]   = sum_{f,i,j} X[f,i+a-1+r,j+b-1+s,:]^T dP[f,2i+a,2j+b,:]  (split over pixel strips, f32 atomics)
+// Also here: the 48->2 output convolutions writing straight into the [B,H,W,32] result layout
+// (modules.py:767-770 + transpose :838), patch im2col for the 4x4/stride-4 patch embeds (modules.py:430-431),
+// and 3x3 im2col / col2im for the small grouped conv of FG-MSA (FG_MSA.py:51).
+#include "common.h"
+
+#define TILE_H 8
+#define TILE_W 16
+#define KC 32
+
+// ---------------------------------------------------------------------------------------------------
+// weight preparation / gradient fold-back
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tap_range(int a, int r, int& lo, int& hi) {   // indices dy+1 in [lo,hi]
+  if (a == 0) { lo = r == 0 ? 0 : 1; hi = r == 0 ? 0 : 2; }
+  else { lo = r == 0 ? 0 : 2; hi = r == 0 ? 1 : 2; }
+}
+__device__ __forceinline__ int tap_of(int a, int dyi) {  // which r of phase a uses tap index dyi (0..2)
+  return a == 0 ? (dyi == 0 ? 0 : 1) : (dyi == 2 ? 1 : 0);
+}
+
+// W [3][3][Cin][Cout] f32 (Keras HWIO) -> Wf [16][Cout][Cin] (forward B operand, K=cin contiguous)
+//                                         Wd [16][Cin][Cout] (dgrad  B operand, K=cout contiguous, indexed (u+1)*4+(v+1))
+template <typename T>
+__global__ __launch_bounds__(256) void upconv_prep_kernel(const float* W, T* Wf, T* Wd, int Cin, int Cout) {
+  const int total = 16 * Cout * Cin;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int ci = idx % Cin, co = (idx / Cin) % Cout, pt = idx / (Cin * Cout);
+    const int a = pt >> 3, b = (pt >> 2) & 1, r = (pt >> 1) & 1, s = pt & 1;
+    int ylo, yhi, xlo, xhi;
+    tap_range(a, r, ylo, yhi);
+    tap_range(b, s, xlo, xhi);
+    float acc = 0.f;
+    for (int y = ylo; y <= yhi; ++y)
+      for (int x = xlo; x <= xhi; ++x) acc += W[((y * 3 + x) * Cin + ci) * Cout + co];
+    stf(Wf + ((long long)pt * Cout + co) * Cin + ci, acc);
+    const int u = 2 - a - 2 * r, v = 2 - b - 2 * s;
+    stf(Wd + ((long long)((u + 1) * 4 + (v + 1)) * Cin + ci) * Cout + co, acc);
+  }
+}
+// dW[dy][dx][ci][co] += sum_{a,b} dWeff[a,b,r(a,dy),s(b,dx)][co][ci]
+__global__ __launch_bounds__(256) void upconv_fold_kernel(const float* dWeff, float* dW, int Cin, int Cout) {
+  const int total = 9 * Cin * Cout;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int co = idx % Cout, ci = (idx / Cout) % Cin, t = idx / (Cin * Cout);
+    const int dyi = t / 3, dxi = t % 3;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int pt = a * 8 + b * 4 + tap_of(a, dyi) * 2 + tap_of(b, dxi);
+        acc += dWeff[((long long)pt * Cout + co) * Cin + ci];
+      }
+    dW[idx] += acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int FN>
+__global__ __launch_bounds__(256) void upconv_fwd_kernel(const T* X, const T* Wf, const float* bias, T* Y,
+                                                         int F, int Hi, int Wi, int Cin, int Cout, int act) {
+  constexpr int BN = FN * 16;
+  constexpr int LDK = KC + LdsPad<T>::P;
+  constexpr int VN = Vec<T>::N, CPR = KC / VN;
+  constexpr int HH = TILE_H + 2, HW = TILE_W + 2;
+  __shared__ __attribute__((aligned(16))) T halo[HH * HW * LDK];
+  __shared__ __attribute__((aligned(16))) T Bs[8 * BN * LDK];   // (phase,tap) slots of one dy group
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tiles_x = (Wi + TILE_W - 1) / TILE_W, tiles_y = (Hi + TILE_H - 1) / TILE_H;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; const int f = bid / tiles_y;
+  const int ty0 = ty * TILE_H, tx0 = tx * TILE_W, n0 = blockIdx.y * BN;
+  const int mf0 = 2 * w;
+
+  f32x4 acc[4][2][FN];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < FN; ++n) acc[p][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const T* Xf = X + (long long)f * Hi * Wi * Cin;
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  for (int c0 = 0; c0 < Cin; c0 += KC) {
+    for (int i = tid; i < HH * HW * CPR; i += 256) {
+      const int px = i / CPR, ch = (i % CPR) * VN;
+      const int gy = ty0 + px / HW - 1, gx = tx0 + px % HW - 1;
+      uint4 v = z4;
+      if (gy >= 0 && gy < Hi && gx >= 0 && gx < Wi && c0 + ch < Cin)
+        v = *reinterpret_cast<const uint4*>(Xf + ((long long)gy * Wi + gx) * Cin + c0 + ch);
+      *reinterpret_cast<uint4*>(halo + px * LDK + ch) = v;
+    }
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi) {
+      // (a,r) pairs with a + r == dyi: dyi=0 -> (0,0); dyi=1 -> (0,1),(1,0); dyi=2 -> (1,1).  slot = al*4 + b*2 + s
+      const int npair = dyi == 1 ? 2 : 1;
+      __syncthreads();               // halo staged (dyi==0) / previous group's B reads finished
+      for (int i = tid; i < npair * 4 * BN * CPR; i += 256) {
+        const int ch = (i % CPR) * VN, n = (i / CPR) % BN, slot = i / (CPR * BN);
+        const int al = slot >> 2, b = (slot >> 1) & 1, s2 = slot & 1;
+        const int a = dyi == 0 ? 0 : (dyi == 2 ? 1 : al);
+        const int r = dyi - a;
+        const int pt = a * 8 + b * 4 + r * 2 + s2;
+        uint4 v = z4;
+        if (n0 + n < Cout && c0 + ch < Cin)
+          v = *reinterpret_cast<const uint4*>(Wf + ((long long)pt * Cout + n0 + n) * Cin + c0 + ch);
+        *reinterpret_cast<uint4*>(Bs + (slot * BN + n) * LDK + ch) = v;
+      }
+      __syncthreads();
+      for (int k0 = 0; k0 < KC; k0 += Mma<T>::KSTEP) {
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+          typename Mma<T>::Frag af[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) af[m] = Mma<T>::load(halo + ((mf0 + m + dyi) * HW + dxi) * LDK, LDK, 0, k0, lane);
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const int r = dyi - a;
+            if (r < 0 || r > 1) continue;
+            const int al = dyi == 1 ? a : 0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const int s2 = dxi - b;
+              if (s2 < 0 || s2 > 1) continue;
+              const int slot = al * 4 + b * 2 + s2;
+#pragma unroll
+              for (int n = 0; n < FN; ++n) {
+                typename Mma<T>::Frag bf = Mma<T>::load(Bs + (slot * BN + n * 16) * LDK, LDK, 0, k0, lane);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[a * 2 + b][m][n] = Mma<T>::mma(af[m], bf, acc[a * 2 + b][m][n]);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  T* Yf = Y + (long long)f * Ho * Wo * Cout;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int a = p >> 1, b = p & 1;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int py = ty0 + mf0 + m;
+      if (py >= Hi) continue;
+#pragma unroll
+      for (int n = 0; n < FN; ++n) {
+        const int col = n0 + n * 16 + (lane & 15);
+        if (col >= Cout) continue;
+        const float bv = bias[col];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int px = tx0 + (lane >> 4) * 4 + rg;
+          if (px >= Wi) continue;
+          stf(Yf + ((long long)(2 * py + a) * Wo + 2 * px + b) * Cout + col, apply_act(acc[p][m][n][rg] + bv, act));
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dgrad
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int FN>
+__global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T* Wd, T* dX, int F, int Hi, int Wi, int Cin, int Cout) {
+  constexpr int BN = FN * 16;
+  constexpr int LDK = KC + LdsPad<T>::P;
+  constexpr int VN = Vec<T>::N, CPR = KC / VN;
+  constexpr int HH = 2 * TILE_H + 2, HW = 2 * TILE_W + 2;
+  __shared__ __attribute__((aligned(16))) T halo[HH * HW * LDK];
+  __shared__ __attribute__((aligned(16))) T Bs[4 * BN * LDK];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tiles_x = (Wi + TILE_W - 1) / TILE_W, tiles_y = (Hi + TILE_H - 1) / TILE_H;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; const int f = bid / tiles_y;
+  const int ty0 = ty * TILE_H, tx0 = tx * TILE_W, n0 = blockIdx.y * BN;
+  const int mf0 = 2 * w;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+
+  f32x4 acc[2][FN];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < FN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const T* Pf = dP + (long long)f * Ho * Wo * Cout;
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  for (int c0 = 0; c0 < Cout; c0 += KC) {
+    for (int i = tid; i < HH * HW * CPR; i += 256) {
+      const int px = i / CPR, ch = (i % CPR) * VN;
+      const int gy = 2 * ty0 + px / HW - 1, gx = 2 * tx0 + px % HW - 1;
+      uint4 v = z4;
+      if (gy >= 0 && gy < Ho && gx >= 0 && gx < Wo && c0 + ch < Cout)
+        v = *reinterpret_cast<const uint4*>(Pf + ((long long)gy * Wo + gx) * Cout + c0 + ch);
+      *reinterpret_cast<uint4*>(halo + px * LDK + ch) = v;
+    }
+    for (int ui = 0; ui < 4; ++ui) {
+      __syncthreads();                 // previous group's B reads finished (and halo staged on ui == 0)
+      for (int i = tid; i < 4 * BN * CPR; i += 256) {
+        const int ch = (i % CPR) * VN, n = (i / CPR) % BN, vi = i / (CPR * BN);
+        uint4 v = z4;
+        if (n0 + n < Cin && c0 + ch < Cout)
+          v = *reinterpret_cast<const uint4*>(Wd + ((long long)(ui * 4 + vi) * Cin + n0 + n) * Cout + c0 + ch);
+        *reinterpret_cast<uint4*>(Bs + (vi * BN + n) * LDK + ch) = v;
+      }
+      __syncthreads();
+      for (int k0 = 0; k0 < KC; k0 += Mma<T>::KSTEP) {
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi) {
+          typename Mma<T>::Frag af[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            af[m] = Mma<T>::load(halo + ((2 * (mf0 + m) + ui) * HW + vi) * LDK, 2 * LDK, 0, k0, lane);
+#pragma unroll
+          for (int n = 0; n < FN; ++n) {
+            typename Mma<T>::Frag bf = Mma<T>::load(Bs + (vi * BN + n * 16) * LDK, LDK, 0, k0, lane);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m][n] = Mma<T>::mma(af[m], bf, acc[m][n]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  T* Xf = dX + (long long)f * Hi * Wi * Cin;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int py = ty0 + mf0 + m;
+    if (py >= Hi) continue;
+#pragma unroll
+    for (int n = 0; n < FN; ++n) {
+      const int col = n0 + n * 16 + (lane & 15);
+      if (col >= Cin) continue;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int px = tx0 + (lane >> 4) * 4 + rg;
+        if (px >= Wi) continue;
+        stf(Xf + ((long long)py * Wi + px) * Cin + col, acc[m][n][rg]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad: block = (pixel strip, phase, cout-tile x cin-tile); wave = tap (r,s); K = pixels in chunks of one
+// low-res row segment of 32 columns.
+// ---------------------------------------------------------------------------------------------------
+#define WG_W 32
+template <typename T, int FO, int FI>
+__global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* dP, float* dWeff, int F, int Hi, int Wi,
+                                                           int Cin, int Cout, int chunks_per_block) {
+  constexpr int BO = FO * 16, BI = FI * 16;
+  constexpr int LDO = BO + LdsPad<T>::P, LDI = BI + LdsPad<T>::P;
+  constexpr int VN = Vec<T>::N;
+  constexpr int XW = WG_W + 2;
+  __shared__ __attribute__((aligned(16))) T dYs[WG_W * LDO];
+  __shared__ __attribute__((aligned(16))) T Xs[2 * XW * LDI];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int a = blockIdx.y >> 1, b = blockIdx.y & 1;
+  const int r = w >> 1, s = w & 1;
+  const int cin_tiles = (Cin + BI - 1) / BI;
+  const int co0 = (blockIdx.z / cin_tiles) * BO, ci0 = (blockIdx.z % cin_tiles) * BI;
+  const int segs = (Wi + WG_W - 1) / WG_W;
+  const long long nchunks = (long long)F * Hi * segs;
+  const long long c_begin = (long long)blockIdx.x * chunks_per_block;
+  const long long c_end = min(nchunks, c_begin + chunks_per_block);
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+
+  f32x4 acc[FO][FI];
+#pragma unroll
+  for (int m = 0; m < FO; ++m)
+#pragma unroll
+    for (int n = 0; n < FI; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+
+  for (long long c = c_begin; c < c_end; ++c) {
+    const int seg = (int)(c % segs); long long t = c / segs;
+    const int i = (int)(t % Hi); const int f = (int)(t / Hi);
+    const int j0 = seg * WG_W;
+    // dP of this phase: pixels (2i+a, 2(j0+cj)+b), cj in [0,32)
+    for (int q = tid; q < WG_W * (BO / VN); q += 256) {
+      const int cj = q / (BO / VN), ch = (q % (BO / VN)) * VN;
+      uint4 v = z4;
+      if (j0 + cj < Wi && co0 + ch < Cout)
+        v = *reinterpret_cast<const uint4*>(dP + (((long long)f * Ho + 2 * i + a) * Wo + 2 * (j0 + cj) + b) * Cout + co0 + ch);
+      *reinterpret_cast<uint4*>(dYs + cj * LDO + ch) = v;
+    }
+    // X rows i+a-1+{0,1}, cols j0+b-1 .. j0+b-1+33
+    for (int q = tid; q < 2 * XW * (BI / VN); q += 256) {
+      const int ch = (q % (BI / VN)) * VN; const int p = q / (BI / VN);
+      const int rr = p / XW, cc = p % XW;
+      const int gy = i + a - 1 + rr, gx = j0 + b - 1 + cc;
+      uint4 v = z4;
+      if (gy >= 0 && gy < Hi && gx >= 0 && gx < Wi && ci0 + ch < Cin)
+        v = *reinterpret_cast<const uint4*>(X + (((long long)f * Hi + gy) * Wi + gx) * Cin + ci0 + ch);
+      *reinterpret_cast<uint4*>(Xs + p * LDI + ch) = v;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < WG_W; k0 += Mma<T>::KSTEP) {
+      typename Mma<T>::Frag af[FO], bf[FI];
+#pragma unroll
+      for (int m = 0; m < FO; ++m) af[m] = Mma<T>::load_strided(dYs, 1, LDO, m * 16, k0, lane);
+#pragma unroll
+      for (int n = 0; n < FI; ++n) bf[n] = Mma<T>::load_strided(Xs + (r * XW + s) * LDI, 1, LDI, n * 16, k0, lane);
+#pragma unroll
+      for (int m = 0; m < FO; ++m)
+#pragma unroll
+        for (int n = 0; n < FI; ++n) acc[m][n] = Mma<T>::mma(af[m], bf[n], acc[m][n]);
+    }
+    __syncthreads();
+  }
+  const int pt = a * 8 + b * 4 + r * 2 + s;
+#pragma unroll
+  for (int m = 0; m < FO; ++m)
+#pragma unroll
+    for (int n = 0; n < FI; ++n) {
+      const int ci = ci0 + n * 16 + (lane & 15);
+      if (ci >= Cin) continue;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = co0 + m * 16 + (lane >> 4) * 4 + rg;
+        if (co < Cout) atomicAdd(dWeff + ((long long)pt * Cout + co) * Cin + ci, acc[m][n][rg]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------------
+extern "C" int stj_upconv_prep(const float* W, void* Wf, void* Wd, int Cin, int Cout, int dtype, hipStream_t stream) {
+  const int g = min(2048, (16 * Cin * Cout + 255) / 256);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(upconv_prep_kernel<bf16>, dim3(g), dim3(256), 0, stream, W, (bf16*)Wf, (bf16*)Wd, Cin, Cout);
+  else hipLaunchKernelGGL(upconv_prep_kernel<float>, dim3(g), dim3(256), 0, stream, W, (float*)Wf, (float*)Wd, Cin, Cout);
+  return stj_check_launch("stj_upconv_prep");
+}
+extern "C" int stj_upconv_fold(const float* dWeff, float* dW, int Cin, int Cout, hipStream_t stream) {
+  const int g = min(2048, (9 * Cin * Cout + 255) / 256);
+  hipLaunchKernelGGL(upconv_fold_kernel, dim3(g), dim3(256), 0, stream, dWeff, dW, Cin, Cout);
+  return stj_check_launch("stj_upconv_fold");
+}
+
+static int upconv_check(int F, int Hi, int Wi, int Cin, int Cout, int dtype) {
+  const int vn = dtype == STJ_BF16 ? 8 : 4;
+  if (F <= 0 || Hi <= 0 || Wi <= 0) { stj_set_error("upconv: empty problem"); return STJ_EINVAL; }
+  if (Cin % vn || Cout % vn) { stj_set_error("upconv: channels must be multiples of %d (Cin=%d Cout=%d)", vn, Cin, Cout); return STJ_EINVAL; }
+  return STJ_OK;
+}
+
+template <typename T>
+static int upconv_fwd_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act, hipStream_t st) {
+  const int tiles = ((Wi + TILE_W - 1) / TILE_W) * ((Hi + TILE_H - 1) / TILE_H) * F;
+  if (Cout % 64 == 0 || Cout > 96) {
+    hipLaunchKernelGGL((upconv_fwd_kernel<T, 4>), dim3(tiles, (Cout + 63) / 64), dim3(256), 0, st, (const T*)X, (const T*)Wf, bias, (T*)Y, F, Hi, Wi, Cin, Cout, act);
+  } else {
+    hipLaunchKernelGGL((upconv_fwd_kernel<T, 3>), dim3(tiles, (Cout + 47) / 48), dim3(256), 0, st, (const T*)X, (const T*)Wf, bias, (T*)Y, F, Hi, Wi, Cin, Cout, act);
+  }
+  return stj_check_launch("stj_upconv_fwd");
+}
+extern "C" int stj_upconv_fwd(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin,
+                              int Cout, int act, int dtype, hipStream_t stream) {
+  int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
+  if (e) return e;
+  return dtype == STJ_BF16 ? upconv_fwd_launch<bf16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream)
+                           : upconv_fwd_launch<float>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream);
+}
+
+template <typename T>
+static int upconv_dgrad_launch(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  const int tiles = ((Wi + TILE_W - 1) / TILE_W) * ((Hi + TILE_H - 1) / TILE_H) * F;
+  if (Cin % 96 == 0 && Cin % 64 != 0) {
+    hipLaunchKernelGGL((upconv_dgrad_kernel<T, 6>), dim3(tiles, Cin / 96), dim3(256), 0, st, (const T*)dP, (const T*)Wd, (T*)dX, F, Hi, Wi, Cin, Cout);
+  } else {
+    hipLaunchKernelGGL((upconv_dgrad_kernel<T, 4>), dim3(tiles, (Cin + 63) / 64), dim3(256), 0, st, (const T*)dP, (const T*)Wd, (T*)dX, F, Hi, Wi, Cin, Cout);
+  }
+  return stj_check_launch("stj_upconv_dgrad");
+}
+extern "C" int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout,
+                                int dtype, hipStream_t stream) {
+  int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
+  if (e) return e;
+  return dtype == STJ_BF16 ? upconv_dgrad_launch<bf16>(dP, Wd, dX, F, Hi, Wi, Cin, Cout, stream)
+                           : upconv_dgrad_launch<float>(dP, Wd, dX, F, Hi, Wi, Cin, Cout, stream);
+}
+
+template <typename T>
+static int upconv_wgrad_launch(const void* X, const void* dP, float* dWeff, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  const long long nchunks = (long long)F * Hi * ((Wi + WG_W - 1) / WG_W);
+  if (Cout <= 48 && Cin <= 96) {
+    const int tiles = 1;
+    int strips = (int)min(nchunks, (long long)(2048 / (4 * tiles)));
+    const int cpb = (int)((nchunks + strips - 1) / strips);
+    strips = (int)((nchunks + cpb - 1) / cpb);
+    hipLaunchKernelGGL((upconv_wgrad_kernel<T, 3, 6>), dim3(strips, 4, tiles), dim3(256), 0, st, (const T*)X, (const T*)dP, dWeff, F, Hi, Wi, Cin, Cout, cpb);
+  } else {
+    const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    int strips = (int)min(nchunks, (long long)max(1, 2048 / (4 * tiles)));
+    const int cpb = (int)((nchunks + strips - 1) / strips);
+    strips = (int)((nchunks + cpb - 1) / cpb);
+    hipLaunchKernelGGL((upconv_wgrad_kernel<T, 4, 4>), dim3(strips, 4, tiles), dim3(256), 0, st, (const T*)X, (const T*)dP, dWeff, F, Hi, Wi, Cin, Cout, cpb);
+  }
+  return stj_check_launch("stj_upconv_wgrad");
+}
+// dWeff: f32 [16][Cout][Cin] scratch, must be zero on entry (caller memsets); fold with stj_upconv_fold afterwards.
+extern "C" int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, int F, int Hi, int Wi, int Cin, int Cout,
+                                int dtype, hipStream_t stream) {
+  int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
+  if (e) return e;
+  return dtype == STJ_BF16 ? upconv_wgrad_launch<bf16>(X, dP, dWeff, F, Hi, Wi, Cin, Cout, stream)
+                           : upconv_wgrad_launch<float>(X, dP, dWeff, F, Hi, Wi, Cin, Cout, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3x3 SAME conv C->2 (no activation), HBM-streaming: each block stages an 18x18 halo of all C channels in LDS
+// (f32), one thread per output pixel.  Output is written with arbitrary pixel/frame strides so the two heads
+// land directly in the [B,H,W,8*4] result (channel 4t + {0,1} / {2,3}).  Y is f32 (model output).
+// ---------------------------------------------------------------------------------------------------
+#define OC_T 16
+template <typename T>
+__global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* X, const float* W, const float* bias, float* Y, int Hh, int Ww,
+                                                          int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LDC = C + 1;
+  float* halo = smem;                       // [18*18][C+1]
+  float* Ws = smem + 18 * 18 * LDC;         // [9][C][2]
+  const int tid = threadIdx.x;
+  const int tiles_x = Ww / OC_T, tiles_y = Hh / OC_T;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; const int f = bid / tiles_y;
+  const T* Xf = X + (long long)f * Hh * Ww * C;
+  for (int i = tid; i < 18 * 18 * C; i += 256) {
+    const int c = i % C, p = i / C;
+    const int gy = ty * OC_T + p / 18 - 1, gx = tx * OC_T + p % 18 - 1;
+    halo[p * LDC + c] = (gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) ? ldf(Xf + ((long long)gy * Ww + gx) * C + c) : 0.f;
+  }
+  for (int i = tid; i < 9 * C * 2; i += 256) Ws[i] = W[i];
+  __syncthreads();
+  const int py = tid / OC_T, px = tid % OC_T;
+  float a0 = bias[0], a1 = bias[1];
+  for (int t = 0; t < 9; ++t) {
+    const float* h = halo + ((py + t / 3) * 18 + px + t % 3) * LDC;
+    const float* wv = Ws + t * C * 2;
+    for (int c = 0; c < C; ++c) { const float x = h[c]; a0 += x * wv[2 * c]; a1 += x * wv[2 * c + 1]; }
+  }
+  const int b = f / Tn, tt = f % Tn;
+  float* dst = Y + b * y_bstride + tt * y_tstride + ((long long)(ty * OC_T + py) * Ww + tx * OC_T + px) * y_pstride;
+  dst[0] = a0; dst[1] = a1;
+}
+
+// backward of the output conv: dX [F,H,W,C] (type T) and dW [3][3][C][2], db [2] (f32 atomics).
+// dY is read with the same strides as Y was written.
+template <typename T>
+__global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* X, const float* W, const float* dY, T* dX, float* dW, float* db,
+                                                          int F, int Hh, int Ww, int C, int Tn, long long y_bstride, long long y_tstride,
+                                                          long long y_pstride) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LDC = C + 1;
+  float* halo = smem;                       // X halo [18*18][C+1]
+  float* Ws = halo + 18 * 18 * LDC;         // [9][C][2]
+  float* dys = Ws + 9 * C * 2;              // dY halo [18*18][2]
+  const int tid = threadIdx.x;
+  const int tiles_x = Ww / OC_T, tiles_y = Hh / OC_T;
+  const int ntiles = F * tiles_x * tiles_y;
+  for (int i = tid; i < 9 * C * 2; i += 256) Ws[i] = W[i];
+  // per-thread dW partials for items i = tid, tid+256, ... (< 9*C <= 4*256)
+  float w0[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f};
+  float b0 = 0.f, b1 = 0.f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; const int f = bid / tiles_y;
+    const int b = f / Tn, tt = f % Tn;
+    const T* Xf = X + (long long)f * Hh * Ww * C;
+    const float* dYf = dY + b * y_bstride + tt * y_tstride;
+    __syncthreads();
+    for (int i = tid; i < 18 * 18 * C; i += 256) {
+      const int c = i % C, p = i / C;
+      const int gy = ty * OC_T + p / 18 - 1, gx = tx * OC_T + p % 18 - 1;
+      halo[p * LDC + c] = (gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) ? ldf(Xf + ((long long)gy * Ww + gx) * C + c) : 0.f;
+    }
+    for (int i = tid; i < 18 * 18; i += 256) {
+      const int gy = ty * OC_T + i / 18 - 1, gx = tx * OC_T + i % 18 - 1;
+      const bool ok = gy >= 0 && gy < Hh && gx >= 0 && gx < Ww;
+      const float* src = dYf + ((long long)gy * Ww + gx) * y_pstride;
+      dys[2 * i] = ok ? src[0] : 0.f;
+      dys[2 * i + 1] = ok ? src[1] : 0.f;
+    }
+    __syncthreads();
+    // dX[p][c] = sum_t sum_o dY[p - off(t)][o] W[t][c][o]   (halo index of p - off(t): (py+2-t/3, px+2-t%3))
+    {
+      const int py = tid / OC_T, px = tid % OC_T;
+      T* dst = dX + (long long)f * Hh * Ww * C + ((long long)(ty * OC_T + py) * Ww + tx * OC_T + px) * C;
+      float g0[9], g1[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int hp = (py + 2 - t / 3) * 18 + px + 2 - t % 3;
+        g0[t] = dys[2 * hp]; g1[t] = dys[2 * hp + 1];
+      }
+      for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc += g0[t] * Ws[(t * C + c) * 2] + g1[t] * Ws[(t * C + c) * 2 + 1];
+        stf(dst + c, acc);
+      }
+      const int hp = (py + 1) * 18 + px + 1;
+      b0 += dys[2 * hp]; b1 += dys[2 * hp + 1];
+    }
+    // dW[t][c][o] += sum_p X[p + off(t)][c] dY[p][o] ; threads over (t,c)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + it * 256;
+      if (i < 9 * C) {
+        const int c = i % C, t = i / C;
+        float s0 = 0.f, s1 = 0.f;
+        for (int p = 0; p < OC_T * OC_T; ++p) {
+          const int py = p / OC_T, px = p % OC_T;
+          const float x = halo[((py + t / 3) * 18 + px + t % 3) * LDC + c];
+          const int hp = (py + 1) * 18 + px + 1;
+          s0 += x * dys[2 * hp]; s1 += x * dys[2 * hp + 1];
+        }
+        w0[it] += s0; w1[it] += s1;
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = tid + it * 256;
+    if (i < 9 * C) { atomicAdd(dW + i * 2, w0[it]); atomicAdd(dW + i * 2 + 1, w1[it]); }
+  }
+  b0 = wave_sum(b0); b1 = wave_sum(b1);
+  if ((tid & 63) == 0) { atomicAdd(db, b0); atomicAdd(db + 1, b1); }
+}
+
+extern "C" int stj_outconv_fwd(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
+                               long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream) {
+  if (Hh % OC_T || Ww % OC_T) { stj_set_error("outconv: H,W must be multiples of 16"); return STJ_EINVAL; }
+  const size_t lds = (size_t)(18 * 18 * (C + 1) + 9 * C * 2) * 4;
+  if (lds > 160 * 1024) { stj_set_error("outconv: C=%d too large for LDS", C); return STJ_EUNSUPPORTED; }
+  const int grid = F * (Hh / OC_T) * (Ww / OC_T);
+  if (dtype == STJ_BF16) {
+    hipFuncSetAttribute((const void*)outconv_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(outconv_fwd_kernel<bf16>, dim3(grid), dim3(256), lds, stream, (const bf16*)X, W, bias, Y, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride);
+  } else {
+    hipFuncSetAttribute((const void*)outconv_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(outconv_fwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)X, W, bias, Y, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride);
+  }
+  return stj_check_launch("stj_outconv_fwd");
+}
+extern "C" int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww,
+                               int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream) {
+  if (Hh % OC_T || Ww % OC_T) { stj_set_error("outconv: H,W must be multiples of 16"); return STJ_EINVAL; }
+  const size_t lds = (size_t)(18 * 18 * (C + 1) + 9 * C * 2 + 18 * 18 * 2) * 4;
+  if (lds > 160 * 1024 || 9 * C > 1024) { stj_set_error("outconv: C=%d too large", C); return STJ_EUNSUPPORTED; }
+  const int grid = min(1024, F * (Hh / OC_T) * (Ww / OC_T));
+  if (dtype == STJ_BF16) {
+    hipFuncSetAttribute((const void*)outconv_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(outconv_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, stream, (const bf16*)X, W, dY, (bf16*)dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride);
+  } else {
+    hipFuncSetAttribute((const void*)outconv_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(outconv_bwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)X, W, dY, (float*)dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride);
+  }
+  return stj_check_launch("stj_outconv_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// im2col helpers (tiny tensors)
+// ---------------------------------------------------------------------------------------------------
+// patch embed: src f32 [B,H,W,*] read as src[((b*H+y)*W+x)*pix_stride + c*ch_stride], dst T [B*(H/4)*(W/4), 16*Cin]
+// with k = (dy*4+dx)*Cin + c  (matches Keras kernel [4,4,Cin,Cout] flattened).  Also performs the f32->T cast and the
+// stride-2 pick of the vehicle channel ogm[...,0] (reference modules.py:572).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const float* src, T* dst, int B, int H, int W, int Cin, long long pix_stride, int ch_stride) {
+  const int K = 16 * Cin, Ph = H / 4, Pw = W / 4;
+  const long long total = (long long)B * Ph * Pw * K;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int k = (int)(i % K); long long m = i / K;
+    const int c = k % Cin, d = k / Cin, dy = d >> 2, dx = d & 3;
+    const int pj = (int)(m % Pw); long long t = m / Pw;
+    const int pi = (int)(t % Ph); const long long b = t / Ph;
+    stf(dst + i, src[((b * H + 4 * pi + dy) * W + 4 * pj + dx) * pix_stride + (long long)c * ch_stride]);
+  }
+}
+extern "C" int stj_im2col_patch(const float* src, void* dst, int B, int H, int W, int Cin, long long pix_stride, int ch_stride, int dtype, hipStream_t stream) {
+  const long long total = (long long)B * (H / 4) * (W / 4) * 16 * Cin;
+  if (total <= 0) return STJ_OK;
+  const int g = (int)min(8192ll, (total + 255) / 256);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(im2col_patch_kernel<bf16>, dim3(g), dim3(256), 0, stream, src, (bf16*)dst, B, H, W, Cin, pix_stride, ch_stride);
+  else hipLaunchKernelGGL(im2col_patch_kernel<float>, dim3(g), dim3(256), 0, stream, src, (float*)dst, B, H, W, Cin, pix_stride, ch_stride);
+  return stj_check_launch("stj_im2col_patch");
+}
+
+// grouped 3x3 SAME: x [N,H,W,G*Cg] -> cols [N*H*W, G, 9*Cg] with k = (dy*3+dx)*Cg + c ; col2im is the adjoint.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3_kernel(const T* x, T* cols, int N, int H, int W, int G, int Cg) {
+  const int K = 9 * Cg; const int C = G * Cg;
+  const long long total = (long long)N * H * W * G * K;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int k = (int)(i % K); long long t = i / K;
+    const int g = (int)(t % G); t /= G;
+    const int xw = (int)(t % W); t /= W;
+    const int yh = (int)(t % H); const long long n = t / H;
+    const int c = k % Cg, d = k / Cg;
+    const int sy = yh + d / 3 - 1, sx = xw + d % 3 - 1;
+    T z; if constexpr (sizeof(T) == 2) z.v = 0; else z = 0.f;
+    cols[i] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[((n * H + sy) * W + sx) * C + g * Cg + c] : z;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void col2im3_kernel(const T* dcols, T* dx, int N, int H, int W, int G, int Cg) {
+  const int K = 9 * Cg; const int C = G * Cg;
+  const long long total = (long long)N * H * W * C;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int ch = (int)(i % C); long long t = i / C;
+    const int xw = (int)(t % W); t /= W;
+    const int yh = (int)(t % H); const long long n = t / H;
+    const int g = ch / Cg, c = ch % Cg;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) {
+      const int oy = yh - (d / 3 - 1), ox = xw - (d % 3 - 1);      // output pixel whose tap d reads (yh,xw)
+      if (oy >= 0 && oy < H && ox >= 0 && ox < W) acc += ldf(dcols + ((((n * H + oy) * W + ox) * G + g) * (long long)K) + d * Cg + c);
+    }
+    stf(dx + i, acc);
+  }
+}
+extern "C" int stj_im2col3(const void* x, void* cols, int N, int H, int W, int G, int Cg, int dtype, hipStream_t stream) {
+  const long long total = (long long)N * H * W * G * 9 * Cg;
+  if (total <= 0) return STJ_OK;
+  const int g = (int)min(8192ll, (total + 255) / 256);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(im2col3_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)x, (bf16*)cols, N, H, W, G, Cg);
+  else hipLaunchKernelGGL(im2col3_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)x, (float*)cols, N, H, W, G, Cg);
+  return stj_check_launch("stj_im2col3");
+}
+extern "C" int stj_col2im3(const void* dcols, void* dx, int N, int H, int W, int G, int Cg, int dtype, hipStream_t stream) {
+  const long long total = (long long)N * H * W * G * Cg;
+  if (total <= 0) return STJ_OK;
+  const int g = (int)min(8192ll, (total + 255) / 256);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(col2im3_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)dcols, (bf16*)dx, N, H, W, G, Cg);
+  else hipLaunchKernelGGL(col2im3_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)dcols, (float*)dx, N, H, W, G, Cg);
+  return stj_check_launch("stj_col2im3");
+}

@@ -1,0 +1,248 @@
+// OGMFlow loss, fused: one streaming pass over the [B,H,W,32] logits + ground truth for the forward sums,
+// one for d(loss)/d(logits).  Restates OGMFlow_loss.__call__ (reference loss.py:50-170) with the flags
+// train.py:195-196 uses (use_focal_loss=False, use_pred=False, no_use_warp=False):
+//   observed_xe / occluded_xe : sigmoid cross entropy sums (loss.py:173-229)
+//   flow                      : masked L1 (loss.py:273-295)
+//   flow_warp_xe              : XE(labels=true_all, logits = clip(sig(gt_obs)+sig(gt_occ),0,1) * warp(origin, id+pred_flow))
+//                               (loss.py:144-158,231-250 -- the quirk of SURVEY App. D-8 is reproduced)
+//   use_gt gate               : res_k = [PR-AUC(true_all, warp(origin, id+gt_flow)*true_all) > 0]  (loss.py:127-137),
+//                               Keras AUC(num_thresholds=100, curve='PR', summation 'interpolation') restated below.
+// Channel slicing of the logits follows train.py:105-123: 4k+0 obs, 4k+1 occ, 4k+2..3 flow (dx,dy).
+#include "common.h"
+
+#define NWP 8
+// per-waypoint accumulator slots
+enum { S_OBS = 0, S_OCC = 1, S_L1 = 2, S_EX = 3, S_WARP = 4, S_N = 5 };
+
+__device__ __forceinline__ float xe_logits(float z, float x) {   // tf.nn.sigmoid_cross_entropy_with_logits
+  return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// bilinear sample of a single-channel [H][W] image at (x,y) (sample(): pad 1, warp+1); optionally d/dx, d/dy
+__device__ __forceinline__ float warp_sample(const float* img, int H, int W, float x, float y, float* ddx, float* ddy) {
+  Bil c = bil_setup(x + 1.f, y + 1.f, H + 2, W + 2);
+  const float tl = pad_at(img, H, W, 1, c.y0, c.x0), tr = pad_at(img, H, W, 1, c.y0, c.x0 + 1);
+  const float bl = pad_at(img, H, W, 1, c.y0 + 1, c.x0), br = pad_at(img, H, W, 1, c.y0 + 1, c.x0 + 1);
+  const float top = c.ax * (tr - tl) + tl, bot = c.ax * (br - bl) + bl;
+  if (ddx) *ddx = c.gx ? (c.ay * (br - bl) + (1.f - c.ay) * (tr - tl)) : 0.f;
+  if (ddy) *ddy = c.gy ? (bot - top) : 0.f;
+  return c.ay * (bot - top) + top;
+}
+
+// ---- AUC gate ----------------------------------------------------------------------------------------
+// hist [NWP][2][101] (int): bucket = #thresholds strictly below pred; class 1 = label true.
+__global__ __launch_bounds__(256) void auc_hist_kernel(const float* gt_obs, const float* gt_occ, const float* gt_flow,
+                                                       const float* origin, int* hist, int B, int H, int W) {
+  __shared__ int sh[2 * 101];
+  const int k = blockIdx.y;
+  for (int i = threadIdx.x; i < 202; i += 256) sh[i] = 0;
+  __syncthreads();
+  const long long npix = (long long)B * H * W;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += gridDim.x * 256ll) {
+    const int x = (int)(i % W); long long t = i / W;
+    const int y = (int)(t % H); const long long b = t / H;
+    const long long g = ((b * NWP + k) * H + y) * W + x;
+    const float ta = fminf(fmaxf(gt_obs[g] + gt_occ[g], 0.f), 1.f);
+    const float* img = origin + (b * NWP + k) * (long long)H * W;
+    const float wp = warp_sample(img, H, W, (float)x + gt_flow[2 * g], (float)y + gt_flow[2 * g + 1], nullptr, nullptr);
+    const float pred = wp * ta;
+    // thresholds: t0 = -1e-7, t_i = i/99 (i=1..98), t_99 = 1+1e-7, as float32
+    int bk = 0;
+    if (pred > -1e-7f) {
+      bk = 1;
+      int j = (int)(pred * 99.f);
+      j = j < 0 ? 0 : (j > 98 ? 98 : j);
+      // count i in 1..98 with t_i < pred, robust to rounding of pred*99
+      int cnt = j;
+      if (cnt >= 1 && !((float)((double)cnt / 99.0) < pred)) cnt -= 1;
+      else if (cnt < 98 && ((float)((double)(cnt + 1) / 99.0) < pred)) cnt += 1;
+      bk += cnt;
+      if (pred > (float)(1.0 + 1e-7)) bk += 1;
+    }
+    atomicAdd(&sh[(ta != 0.f ? 101 : 0) + bk], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 202; i += 256)
+    if (sh[i]) atomicAdd(hist + k * 202 + i, sh[i]);
+}
+// one thread per waypoint: Keras interpolate_pr_auc from the histogram; gate[k] = auc > 0 ; auc_out optional
+__global__ void auc_gate_kernel(const int* hist, float* gate, float* auc_out) {
+  const int k = threadIdx.x;
+  if (k >= NWP) return;
+  const int* hn = hist + k * 202;
+  const int* hp = hn + 101;
+  double tp[100], pp[100];
+  double totp = 0, totn = 0;
+  for (int i = 0; i <= 100; ++i) { totp += hp[i]; totn += hn[i]; }
+  double cp = 0, cn = 0;
+  for (int i = 0; i < 100; ++i) {      // positive at threshold i <=> bucket > i
+    cp += hp[i]; cn += hn[i];
+    tp[i] = totp - cp;
+    pp[i] = tp[i] + (totn - cn);
+  }
+  double auc = 0;
+  for (int i = 0; i < 99; ++i) {
+    const double dtp = tp[i] - tp[i + 1], dp = pp[i] - pp[i + 1];
+    const double den = dp > 0 ? dp : 0;
+    const double slope = den != 0 ? dtp / den : 0;
+    const double icpt = tp[i + 1] - slope * pp[i + 1];
+    double ratio = 1.0;
+    if (pp[i] > 0 && pp[i + 1] > 0) ratio = pp[i] / pp[i + 1];
+    const double d2 = totp > 0 ? totp : 0;    // tp + fn = all positives
+    auc += d2 != 0 ? slope * (dtp + icpt * log(ratio)) / d2 : 0;
+  }
+  gate[k] = ((1.0 - auc) < 1.0) ? 1.f : 0.f;
+  if (auc_out) auc_out[k] = (float)auc;
+}
+
+// ---- forward sums -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* logits, const float* gt_obs, const float* gt_occ,
+                                                       const float* gt_flow, const float* origin, float* sums,
+                                                       int B, int H, int W, int use_warp) {
+  __shared__ float red[4][NWP * S_N];
+  float acc[NWP * S_N];
+#pragma unroll
+  for (int i = 0; i < NWP * S_N; ++i) acc[i] = 0.f;
+  const long long npix = (long long)B * H * W;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += gridDim.x * 256ll) {
+    const int x = (int)(i % W); long long t = i / W;
+    const int y = (int)(t % H); const long long b = t / H;
+    float lg[32];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const float4 q = reinterpret_cast<const float4*>(logits + i * 32)[v];
+      lg[4 * v] = q.x; lg[4 * v + 1] = q.y; lg[4 * v + 2] = q.z; lg[4 * v + 3] = q.w;
+    }
+#pragma unroll
+    for (int k = 0; k < NWP; ++k) {
+      const long long g = ((b * NWP + k) * H + y) * W + x;
+      const float to = gt_obs[g], tc = gt_occ[g];
+      const float fx = gt_flow[2 * g], fy = gt_flow[2 * g + 1];
+      acc[k * S_N + S_OBS] += xe_logits(to, lg[4 * k]);
+      acc[k * S_N + S_OCC] += xe_logits(tc, lg[4 * k + 1]);
+      const float ex = (fx != 0.f || fy != 0.f) ? 1.f : 0.f;
+      acc[k * S_N + S_L1] += (fabsf(fx - lg[4 * k + 2]) + fabsf(fy - lg[4 * k + 3])) * ex;
+      acc[k * S_N + S_EX] += ex;
+      if (use_warp) {
+        const float* img = origin + (b * NWP + k) * (long long)H * W;
+        const float wp = warp_sample(img, H, W, (float)x + lg[4 * k + 2], (float)y + lg[4 * k + 3], nullptr, nullptr);
+        const float sg = fminf(fmaxf(sigmoidf(to) + sigmoidf(tc), 0.f), 1.f);
+        const float ta = fminf(fmaxf(to + tc, 0.f), 1.f);
+        acc[k * S_N + S_WARP] += xe_logits(ta, sg * wp);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NWP * S_N; ++i) {
+    const float s = wave_sum(acc[i]);
+    if (lane == 0) red[w][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NWP * S_N) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+struct LossCfg { float ogm_w, occ_w, fow, replica; int use_warp; };
+
+// loss[4] = observed_xe, occluded_xe, flow, flow_warp_xe ; coef [NWP][4] per-waypoint backward coefficients (before upstream grads)
+__global__ void loss_finalize_kernel(const float* sums, const float* gate, float* loss, float* coef, float npix, LossCfg c) {
+  if (threadIdx.x != 0) return;
+  float so = 0.f, sc = 0.f, sf = 0.f, sw = 0.f, fc = 0.f;
+  for (int k = 0; k < NWP; ++k) fc += gate[k];
+  for (int k = 0; k < NWP; ++k) {
+    const float* s = sums + k * S_N;
+    so += c.ogm_w * s[S_OBS] / (npix * c.replica);
+    sc += c.occ_w * s[S_OCC] / (npix * c.replica);
+    const float den = s[S_EX] * c.replica / 2.f;
+    const float fl = den != 0.f ? s[S_L1] / den : 0.f;
+    sf += gate[k] * fl;
+    sw += gate[k] * c.fow * s[S_WARP] / (npix * c.replica);
+    coef[k * 4 + 0] = c.ogm_w / (npix * c.replica) / NWP;
+    coef[k * 4 + 1] = c.occ_w / (npix * c.replica) / NWP;
+    coef[k * 4 + 2] = den != 0.f ? gate[k] / fc / den : 0.f;
+    coef[k * 4 + 3] = c.use_warp ? gate[k] / fc * c.fow / (npix * c.replica) : 0.f;
+  }
+  loss[0] = so / NWP;
+  loss[1] = sc / NWP;
+  loss[2] = sf / fc;
+  loss[3] = c.use_warp ? sw / fc : 0.f;
+}
+
+// dlogits[B,H,W,32] = sum_j up[j] * d loss_j / d logits
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* logits, const float* gt_obs, const float* gt_occ,
+                                                       const float* gt_flow, const float* origin, const float* coef,
+                                                       const float* up, float* dlogits, int B, int H, int W, int use_warp) {
+  __shared__ float cf[NWP * 4];
+  if (threadIdx.x < NWP * 4) cf[threadIdx.x] = coef[threadIdx.x] * up[threadIdx.x & 3];
+  __syncthreads();
+  const long long npix = (long long)B * H * W;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += gridDim.x * 256ll) {
+    const int x = (int)(i % W); long long t = i / W;
+    const int y = (int)(t % H); const long long b = t / H;
+    float lg[32], dl[32];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const float4 q = reinterpret_cast<const float4*>(logits + i * 32)[v];
+      lg[4 * v] = q.x; lg[4 * v + 1] = q.y; lg[4 * v + 2] = q.z; lg[4 * v + 3] = q.w;
+    }
+#pragma unroll
+    for (int k = 0; k < NWP; ++k) {
+      const long long g = ((b * NWP + k) * H + y) * W + x;
+      const float to = gt_obs[g], tc = gt_occ[g];
+      const float fx = gt_flow[2 * g], fy = gt_flow[2 * g + 1];
+      dl[4 * k] = cf[4 * k] * (sigmoidf(lg[4 * k]) - to);
+      dl[4 * k + 1] = cf[4 * k + 1] * (sigmoidf(lg[4 * k + 1]) - tc);
+      const float ex = (fx != 0.f || fy != 0.f) ? 1.f : 0.f;
+      const float d0 = fx - lg[4 * k + 2], d1 = fy - lg[4 * k + 3];
+      float g2 = -cf[4 * k + 2] * ex * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+      float g3 = -cf[4 * k + 2] * ex * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+      if (use_warp && cf[4 * k + 3] != 0.f) {
+        const float* img = origin + (b * NWP + k) * (long long)H * W;
+        float ddx, ddy;
+        const float wp = warp_sample(img, H, W, (float)x + lg[4 * k + 2], (float)y + lg[4 * k + 3], &ddx, &ddy);
+        const float sg = fminf(fmaxf(sigmoidf(to) + sigmoidf(tc), 0.f), 1.f);
+        const float ta = fminf(fmaxf(to + tc, 0.f), 1.f);
+        const float dj = cf[4 * k + 3] * (sigmoidf(sg * wp) - ta) * sg;
+        g2 += dj * ddx;
+        g3 += dj * ddy;
+      }
+      dl[4 * k + 2] = g2;
+      dl[4 * k + 3] = g3;
+    }
+#pragma unroll
+    for (int v = 0; v < 8; ++v)
+      reinterpret_cast<float4*>(dlogits + i * 32)[v] = make_float4(dl[4 * v], dl[4 * v + 1], dl[4 * v + 2], dl[4 * v + 3]);
+  }
+}
+
+// gate: f32[8] out.  hist: int[8*202] scratch (zeroed here).  auc_out optional f32[8].
+extern "C" int stj_loss_auc_gate(const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
+                                 int* hist, float* gate, float* auc_out, int B, int H, int W, hipStream_t stream) {
+  if (hipMemsetAsync(hist, 0, sizeof(int) * NWP * 202, stream) != hipSuccess) { stj_set_error("loss: memset failed"); return STJ_ELAUNCH; }
+  const long long npix = (long long)B * H * W;
+  const int gx = (int)min(256ll, (npix + 255) / 256);
+  hipLaunchKernelGGL(auc_hist_kernel, dim3(gx, NWP), dim3(256), 0, stream, gt_obs, gt_occ, gt_flow, origin, hist, B, H, W);
+  hipLaunchKernelGGL(auc_gate_kernel, dim3(1), dim3(64), 0, stream, hist, gate, auc_out);
+  return stj_check_launch("stj_loss_auc_gate");
+}
+// sums: f32[40] scratch (zeroed here); loss f32[4]; coef f32[32]
+extern "C" int stj_loss_fwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
+                            const float* gate, float* sums, float* loss, float* coef, int B, int H, int W, float ogm_w, float occ_w,
+                            float flow_origin_w, float replica, int use_warp, hipStream_t stream) {
+  if (((uintptr_t)logits) & 15) { stj_set_error("loss: logits must be 16-byte aligned"); return STJ_EINVAL; }
+  if (hipMemsetAsync(sums, 0, sizeof(float) * NWP * S_N, stream) != hipSuccess) { stj_set_error("loss: memset failed"); return STJ_ELAUNCH; }
+  const long long npix = (long long)B * H * W;
+  const int gx = (int)min(2048ll, (npix + 255) / 256);
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, sums, B, H, W, use_warp);
+  LossCfg c; c.ogm_w = ogm_w; c.occ_w = occ_w; c.fow = flow_origin_w; c.replica = replica; c.use_warp = use_warp;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, gate, loss, coef, (float)npix, c);
+  return stj_check_launch("stj_loss_fwd");
+}
+extern "C" int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
+                            const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int use_warp, hipStream_t stream) {
+  const long long npix = (long long)B * H * W;
+  const int gx = (int)min(4096ll, (npix + 255) / 256);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, coef, upstream, dlogits, B, H, W, use_warp);
+  return stj_check_launch("stj_loss_bwd");
+}

@@ -1,0 +1,132 @@
+// LayerNorm forward / backward, one wavefront per row, reductions by wave shuffles.
+// Keras LayerNormalization semantics (biased variance, eps inside sqrt): reference modules.py:179,184,272,433,
+// 517,557 (eps 1e-5) and FG_MSA.py:52, trajNet.py:72-73,110-111,206-207 (eps 1e-3).
+// Optional fused PatchMerging gather (reference modules.py:282-287): logical row (b,i,j) of width 4*C0 is
+// the concat [x(2i,2j), x(2i+1,2j), x(2i,2j+1), x(2i+1,2j+1)] of a [B,res,res,C0] map -- no concat copy.
+#include "common.h"
+
+__device__ __forceinline__ long long ln_src(long long row, int c, int C, int gres, int C0) {
+  if (gres == 0) return row * C + c;
+  const int half = gres >> 1;
+  const int j = (int)(row % half); const long long t = row / half;
+  const int i = (int)(t % half); const long long b = t / half;
+  const int q = c / C0, cc = c - q * C0;
+  const int di = q & 1, dj = q >> 1;
+  return ((b * gres + 2 * i + di) * gres + 2 * j + dj) * C0 + cc;
+}
+
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
+                                                     float* mean, float* rstd, long long rows, int C, float eps,
+                                                     int gres, int C0) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  for (long long row = wave; row < rows; row += gridDim.x * 4ll) {
+    float v[NPL];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int c = lane + 64 * j;
+      v[j] = c < C ? ldf(x + ln_src(row, c, C, gres, C0)) : 0.f;
+      s += v[j];
+    }
+    const float mu = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int c = lane + 64 * j;
+      const float d = c < C ? v[j] - mu : 0.f;
+      q += d * d;
+    }
+    const float rs = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) stf(y + row * C + c, (v[j] - mu) * rs * gamma[c] + beta[c]);
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  }
+}
+
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+                                                     const float* rstd, T* dx, float* dgamma, float* dbeta,
+                                                     long long rows, int C, int gres, int C0) {
+  __shared__ float red[2][4][64 * NPL];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long wave = blockIdx.x * 4ll + w;
+  float ag[NPL], ab[NPL];
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
+  for (long long row = wave; row < rows; row += gridDim.x * 4ll) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NPL], g[NPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) {
+        const float d = ldf(dy + row * C + c);
+        xh[j] = (ldf(x + ln_src(row, c, C, gres, C0)) - mu) * rs;
+        g[j] = d * gamma[c];
+        ag[j] += d * xh[j];
+        ab[j] += d;
+      } else { xh[j] = 0.f; g[j] = 0.f; }
+      s1 += g[j];
+      s2 += g[j] * xh[j];
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) stf(dx + ln_src(row, c, C, gres, C0), rs * (g[j] - s1 - xh[j] * s2));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) { red[0][w][lane + 64 * j] = ag[j]; red[1][w][lane + 64 * j] = ab[j]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+#define LN_DISPATCH(NPLV)                                                                                         \
+  if (fwd) hipLaunchKernelGGL((ln_fwd_kernel<T, NPLV>), dim3(grid), dim3(256), 0, stream, (const T*)x, gamma, beta, \
+                              (T*)y, mean, rstd, rows, C, eps, gres, C0);                                          \
+  else hipLaunchKernelGGL((ln_bwd_kernel<T, NPLV>), dim3(grid), dim3(256), 0, stream, (const T*)dy, (const T*)x,    \
+                          gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0);
+
+template <typename T>
+static int ln_launch(bool fwd, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                     const void* dy, void* dx, float* dgamma, float* dbeta, long long rows, int C, float eps, int gres,
+                     int C0, hipStream_t stream) {
+  const int npl = (C + 63) / 64;
+  long long want = (rows + 3) / 4;
+  const int cap = fwd ? 4096 : 512;
+  const int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+  if (npl <= 2) { LN_DISPATCH(2) }
+  else if (npl <= 3) { LN_DISPATCH(3) }
+  else if (npl <= 6) { LN_DISPATCH(6) }
+  else if (npl <= 8) { LN_DISPATCH(8) }
+  else if (npl <= 12) { LN_DISPATCH(12) }
+  else if (npl <= 24) { LN_DISPATCH(24) }
+  else { stj_set_error("layernorm: C=%d > 1536 unsupported", C); return STJ_EUNSUPPORTED; }
+  return stj_check_launch("stj_layernorm");
+}
+
+extern "C" int stj_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                 long long rows, int C, float eps, int gather_res, int C0, int dtype, hipStream_t stream) {
+  if (rows <= 0) return STJ_OK;
+  if (gather_res && (C != 4 * C0 || (gather_res & 1))) { stj_set_error("layernorm: bad gather geometry"); return STJ_EINVAL; }
+  if (dtype == STJ_BF16) return ln_launch<bf16>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, stream);
+  return ln_launch<float>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, stream);
+}
+extern "C" int stj_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 void* dx, float* dgamma, float* dbeta, long long rows, int C, int gather_res, int C0,
+                                 int dtype, hipStream_t stream) {
+  if (rows <= 0) return STJ_OK;
+  if (dtype == STJ_BF16) return ln_launch<bf16>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, stream);
+  return ln_launch<float>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, stream);
+}

@@ -1,0 +1,311 @@
+// Fused (shifted-)window multi-head self-attention, forward and backward: one wavefront per
+// (scene, window, head).  Replaces roll -> window_partition -> per-head softmax(q k^T*scale + relpos
+// bias [+ shift mask]) v -> window_reverse -> roll of the reference (modules.py:49-63 window_partition/
+// reverse, :103-134 WindowAttention.call, :189-216 shift mask, :229-255 roll/partition plumbing).
+// The cyclic shift and the window partition are pure index arithmetic on the token map: q/k/v are
+// gathered straight from the [B, res*res, 3C] qkv tensor in original token order and the result is
+// written back in original token order (no rolled / partitioned tensors are materialised).
+// window = 8x8 tokens (64), head_dim = 32:  S = Q K^T is a 64x64x32 MFMA tile, O = P V a 64x32x64 one;
+// softmax row reductions are 16-lane xor shuffles on the MFMA accumulator layout.
+#include "common.h"
+
+#define WS 8
+#define WN 64
+#define HD 32
+
+template <typename T> struct WinCfg;
+template <> struct WinCfg<bf16> { static constexpr int WPB = 4; static constexpr int WPB_BWD = 2; };
+template <> struct WinCfg<float> { static constexpr int WPB = 2; static constexpr int WPB_BWD = 2; };
+
+struct WinGeom {
+  int B, res, heads, shift;
+  long long items;
+};
+
+__device__ __forceinline__ int win_token(int res, int shift, int wy, int wx, int t) {
+  int ry = wy * WS + (t >> 3), rx = wx * WS + (t & 7);
+  int sy = ry + shift; if (sy >= res) sy -= res;
+  int sx = rx + shift; if (sx >= res) sx -= res;
+  return sy * res + sx;
+}
+__device__ __forceinline__ int win_label(int res, int shift, int wy, int wx, int t) {
+  int ry = wy * WS + (t >> 3), rx = wx * WS + (t & 7);
+  int ly = ry < res - WS ? 0 : (ry < res - shift ? 1 : 2);
+  int lx = rx < res - WS ? 0 : (rx < res - shift ? 1 : 2);
+  return ly * 3 + lx;
+}
+
+// load a [64][32] operand (which = 0 q, 1 k, 2 v of qkv; or a plain [B,N,C] tensor when stride3 = 1) into LDS rows
+template <typename T>
+__device__ __forceinline__ void win_load(T* dst, int ld, const T* src, long long tokstride, int coff, const int* tok, int lane) {
+  constexpr int VN = Vec<T>::N;
+  constexpr int CPR = HD / VN;               // 16-byte chunks per token row
+  for (int i = lane; i < WN * CPR; i += 64) {
+    int t = i / CPR, c = (i % CPR) * VN;
+    *reinterpret_cast<uint4*>(dst + t * ld + c) =
+        *reinterpret_cast<const uint4*>(src + (long long)tok[t] * tokstride + coff + c);
+  }
+}
+
+// scores -> probabilities in the accumulator layout.  s[i][j][r]: row = i*16+(lane>>4)*4+r, col = j*16+(lane&15)
+__device__ __forceinline__ void win_softmax(f32x4 (&s)[4][4], const float* tbl, const int* lab, int use_mask, float scale, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i * 16 + (lane >> 4) * 4 + r;
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = j * 16 + (lane & 15);
+        float v = s[i][j][r] * scale + tbl[((row >> 3) - (col >> 3) + WS - 1) * (2 * WS - 1) + ((row & 7) - (col & 7) + WS - 1)];
+        if (use_mask && lab[row] != lab[col]) v += -100.0f;
+        s[i][j][r] = v;
+        m = fmaxf(m, v);
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float e = __expf(s[i][j][r] - m); s[i][j][r] = e; sum += e; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[i][j][r] *= inv;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64 * WinCfg<T>::WPB) void win_attn_fwd_kernel(const T* qkv, const float* table, T* out, WinGeom g) {
+  constexpr int WPB = WinCfg<T>::WPB;
+  constexpr int LQ = HD + LdsPad<T>::P, LP = WN + LdsPad<T>::P;
+  // per wave: Q|K region (reused for P), Vt, table, token ids, labels
+  constexpr int QK_ELEMS = (2 * WN * LQ > WN * LP) ? 2 * WN * LQ : WN * LP;
+  __shared__ __attribute__((aligned(16))) T s_qk[WPB][QK_ELEMS];
+  __shared__ __attribute__((aligned(16))) T s_vt[WPB][HD * LP];
+  __shared__ float s_tbl[WPB][(2 * WS - 1) * (2 * WS - 1)];
+  __shared__ int s_tok[WPB][WN];
+  __shared__ int s_lab[WPB][WN];
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  long long item = blockIdx.x * (long long)WPB + w;
+  const bool live = item < g.items;
+  if (!live) item = g.items - 1;
+  const int C = g.heads * HD;
+  const int nwx = g.res / WS, nW = nwx * nwx;
+  const int h = (int)(item % g.heads);
+  const long long bw = item / g.heads;
+  const int win = (int)(bw % nW);
+  const int b = (int)(bw / nW);
+  const int wy = win / nwx, wx = win % nwx;
+
+  s_tok[w][lane] = win_token(g.res, g.shift, wy, wx, lane);
+  s_lab[w][lane] = win_label(g.res, g.shift, wy, wx, lane);
+  for (int i = lane; i < (2 * WS - 1) * (2 * WS - 1); i += 64) s_tbl[w][i] = table[i * g.heads + h];
+  __syncthreads();
+
+  T* Qs = s_qk[w];
+  T* Ks = s_qk[w] + WN * LQ;
+  T* Vt = s_vt[w];
+  const T* base = qkv + (long long)b * g.res * g.res * 3 * C;
+  win_load<T>(Qs, LQ, base, 3 * C, 0 * C + h * HD, s_tok[w], lane);
+  win_load<T>(Ks, LQ, base, 3 * C, 1 * C + h * HD, s_tok[w], lane);
+  {  // V transposed: Vt[d][tok]
+    constexpr int VN = Vec<T>::N;
+    constexpr int CPR = HD / VN;
+    for (int i = lane; i < WN * CPR; i += 64) {
+      int t = i / CPR, c = (i % CPR) * VN;
+      __attribute__((aligned(16))) T tmp[VN];
+      *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(base + (long long)s_tok[w][t] * 3 * C + 2 * C + h * HD + c);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) Vt[(c + e) * LP + t] = tmp[e];
+    }
+  }
+  __syncthreads();
+
+  f32x4 s[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  mma_tile<T, 4, 4>(Qs, LQ, Ks, LQ, HD, lane, s);
+  win_softmax(s, s_tbl[w], s_lab[w], g.shift > 0, rsqrtf((float)HD), lane);
+  __syncthreads();                       // all Q/K fragment reads done before P overwrites the region
+  T* Ps = s_qk[w];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stf(Ps + (i * 16 + (lane >> 4) * 4 + r) * LP + j * 16 + (lane & 15), s[i][j][r]);
+  __syncthreads();
+
+  f32x4 o[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  mma_tile<T, 4, 2>(Ps, LP, Vt, LP, WN, lane, o);
+  if (live) {
+    T* ob = out + (long long)b * g.res * g.res * C + h * HD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + (lane >> 4) * 4 + r;
+        T* dst = ob + (long long)s_tok[w][row] * C;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) stf(dst + j * 16 + (lane & 15), o[i][j][r]);
+      }
+  }
+}
+
+// Backward.  dqkv [B,N,3C] gets dq,dk,dv;  dtable [225,heads] (f32) accumulated atomically.
+template <typename T>
+__global__ __launch_bounds__(64 * WinCfg<T>::WPB_BWD) void win_attn_bwd_kernel(const T* qkv, const float* table, const T* dout,
+                                                                           T* dqkv, float* dtable, WinGeom g) {
+  constexpr int WPB = WinCfg<T>::WPB_BWD;
+  constexpr int LQ = HD + LdsPad<T>::P, LP = WN + LdsPad<T>::P;
+  __shared__ __attribute__((aligned(16))) T s_q[WPB][WN * LQ];
+  __shared__ __attribute__((aligned(16))) T s_k[WPB][WN * LQ];
+  __shared__ __attribute__((aligned(16))) T s_v[WPB][WN * LQ];
+  __shared__ __attribute__((aligned(16))) T s_do[WPB][WN * LQ];
+  __shared__ __attribute__((aligned(16))) T s_p[WPB][WN * LP];
+  __shared__ __attribute__((aligned(16))) T s_ds[WPB][WN * LP];
+  __shared__ float s_tbl[WPB][(2 * WS - 1) * (2 * WS - 1)];
+  __shared__ float s_dtbl[WPB][(2 * WS - 1) * (2 * WS - 1)];
+  __shared__ int s_tok[WPB][WN];
+  __shared__ int s_lab[WPB][WN];
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  long long item = blockIdx.x * (long long)WPB + w;
+  const bool live = item < g.items;
+  if (!live) item = g.items - 1;
+  const int C = g.heads * HD;
+  const int nwx = g.res / WS, nW = nwx * nwx;
+  const int h = (int)(item % g.heads);
+  const long long bw = item / g.heads;
+  const int win = (int)(bw % nW);
+  const int b = (int)(bw / nW);
+  const int wy = win / nwx, wx = win % nwx;
+  const float scale = rsqrtf((float)HD);
+
+  s_tok[w][lane] = win_token(g.res, g.shift, wy, wx, lane);
+  s_lab[w][lane] = win_label(g.res, g.shift, wy, wx, lane);
+  for (int i = lane; i < (2 * WS - 1) * (2 * WS - 1); i += 64) { s_tbl[w][i] = table[i * g.heads + h]; s_dtbl[w][i] = 0.f; }
+  __syncthreads();
+  const T* base = qkv + (long long)b * g.res * g.res * 3 * C;
+  win_load<T>(s_q[w], LQ, base, 3 * C, 0 * C + h * HD, s_tok[w], lane);
+  win_load<T>(s_k[w], LQ, base, 3 * C, 1 * C + h * HD, s_tok[w], lane);
+  win_load<T>(s_v[w], LQ, base, 3 * C, 2 * C + h * HD, s_tok[w], lane);
+  win_load<T>(s_do[w], LQ, dout + (long long)b * g.res * g.res * C, C, h * HD, s_tok[w], lane);
+  __syncthreads();
+
+  f32x4 p[4][4], dp[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  mma_tile<T, 4, 4>(s_q[w], LQ, s_k[w], LQ, HD, lane, p);
+  win_softmax(p, s_tbl[w], s_lab[w], g.shift > 0, scale, lane);
+  mma_tile<T, 4, 4>(s_do[w], LQ, s_v[w], LQ, HD, lane, dp);        // dP = dO V^T
+  // dS = P * (dP - rowsum(dP*P)); stash P and dS (as T) for the three remaining products
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d += dp[i][j][r] * p[i][j][r];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      const int row = i * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = j * 16 + (lane & 15);
+        const float ds = p[i][j][r] * (dp[i][j][r] - d);
+        stf(s_p[w] + row * LP + col, p[i][j][r]);
+        stf(s_ds[w] + row * LP + col, ds);
+        if (live) atomicAdd(&s_dtbl[w][((row >> 3) - (col >> 3) + WS - 1) * (2 * WS - 1) + ((row & 7) - (col & 7) + WS - 1)], ds);
+      }
+    }
+  }
+  __syncthreads();
+  T* dbase = dqkv + (long long)b * g.res * g.res * 3 * C;
+  f32x4 acc[4][2];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto store = [&](int which, float mul) {
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + (lane >> 4) * 4 + r;
+        T* dst = dbase + (long long)s_tok[w][row] * 3 * C + which * C + h * HD;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) stf(dst + j * 16 + (lane & 15), acc[i][j][r] * mul);
+      }
+  };
+  // generic strided products: out[m][n] = sum_k Aop(m,k) * Bop(k,n)
+  auto prod = [&](const T* Am, int a_sr, int a_sk, const T* Bm, int b_sr, int b_sk) {
+    for (int k0 = 0; k0 < WN; k0 += Mma<T>::KSTEP) {
+      typename Mma<T>::Frag a[4], bb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = Mma<T>::load_strided(Am, a_sr, a_sk, i * 16, k0, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bb[j] = Mma<T>::load_strided(Bm, b_sr, b_sk, j * 16, k0, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma<T>::mma(a[i], bb[j], acc[i][j]);
+    }
+  };
+  // dV[key][d] = sum_q P[q][key] dO[q][d]     A(m=key,k=q) = P[q][key] -> sr=1, sk=LP ; B(n=d,k=q) = dO[q][d] -> sr=1, sk=LQ
+  zero(); prod(s_p[w], 1, LP, s_do[w], 1, LQ); store(2, 1.f);
+  // dQ[q][d] = scale * sum_key dS[q][key] K[key][d]   A(m=q,k=key) -> sr=LP, sk=1 ; B(n=d,k=key) = K[key][d] -> sr=1, sk=LQ
+  zero(); prod(s_ds[w], LP, 1, s_k[w], 1, LQ); store(0, scale);
+  // dK[key][d] = scale * sum_q dS[q][key] Q[q][d]     A(m=key,k=q) -> sr=1, sk=LP ; B(n=d,k=q) = Q[q][d] -> sr=1, sk=LQ
+  zero(); prod(s_ds[w], 1, LP, s_q[w], 1, LQ); store(1, scale);
+  if (live)
+    for (int i = lane; i < (2 * WS - 1) * (2 * WS - 1); i += 64) atomicAdd(dtable + i * g.heads + h, s_dtbl[w][i]);
+}
+
+extern "C" int stj_win_attn_fwd(const void* qkv, const float* table, void* out, int B, int res, int heads, int shift,
+                                int dtype, hipStream_t stream) {
+  if (res % WS != 0 || shift < 0 || shift >= WS) { stj_set_error("win_attn: res %% 8 != 0 or bad shift"); return STJ_EINVAL; }
+  if (((uintptr_t)qkv | (uintptr_t)out) & 15) { stj_set_error("win_attn: unaligned pointers"); return STJ_EINVAL; }
+  WinGeom g; g.B = B; g.res = res; g.heads = heads; g.shift = shift;
+  g.items = (long long)B * (res / WS) * (res / WS) * heads;
+  if (g.items <= 0) return STJ_OK;
+  if (dtype == STJ_BF16) {
+    constexpr int W = WinCfg<bf16>::WPB;
+    hipLaunchKernelGGL(win_attn_fwd_kernel<bf16>, dim3((unsigned)((g.items + W - 1) / W)), dim3(64 * W), 0, stream, (const bf16*)qkv, table, (bf16*)out, g);
+  } else {
+    constexpr int W = WinCfg<float>::WPB;
+    hipLaunchKernelGGL(win_attn_fwd_kernel<float>, dim3((unsigned)((g.items + W - 1) / W)), dim3(64 * W), 0, stream, (const float*)qkv, table, (float*)out, g);
+  }
+  return stj_check_launch("stj_win_attn_fwd");
+}
+
+extern "C" int stj_win_attn_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable,
+                                int B, int res, int heads, int shift, int dtype, hipStream_t stream) {
+  if (res % WS != 0 || shift < 0 || shift >= WS) { stj_set_error("win_attn: res %% 8 != 0 or bad shift"); return STJ_EINVAL; }
+  WinGeom g; g.B = B; g.res = res; g.heads = heads; g.shift = shift;
+  g.items = (long long)B * (res / WS) * (res / WS) * heads;
+  if (g.items <= 0) return STJ_OK;
+  if (dtype == STJ_BF16) {
+    constexpr int W = WinCfg<bf16>::WPB_BWD;
+    hipLaunchKernelGGL(win_attn_bwd_kernel<bf16>, dim3((unsigned)((g.items + W - 1) / W)), dim3(64 * W), 0, stream, (const bf16*)qkv, table, (const bf16*)dout, (bf16*)dqkv, dtable, g);
+  } else {
+    constexpr int W = WinCfg<float>::WPB_BWD;
+    hipLaunchKernelGGL(win_attn_bwd_kernel<float>, dim3((unsigned)((g.items + W - 1) / W)), dim3(64 * W), 0, stream, (const float*)qkv, table, (const float*)dout, (float*)dqkv, dtable, g);
+  }
+  return stj_check_launch("stj_win_attn_bwd");
+}

@@ -1,0 +1,139 @@
+// Error plumbing + streaming elementwise kernels (HBM-bound: 16-byte vector access, grid-stride).
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void stj_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int stj_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    stj_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return STJ_ELAUNCH;
+  }
+  return STJ_OK;
+}
+extern "C" const char* stj_last_error(void) { return g_err; }
+extern "C" int stj_abi_version(void) { return 1; }
+
+static inline int ew_grid(long long n_vec) {
+  long long b = (n_vec + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// ---- dtype cast ---------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* src, TD* dst, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) stf(dst + i, ldf(src + i));
+}
+extern "C" int stj_cast(const void* src, int sdtype, void* dst, int ddtype, long long n, hipStream_t stream) {
+  if (n <= 0) return STJ_OK;
+  int g = ew_grid(n);
+  if (sdtype == STJ_F32 && ddtype == STJ_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(g), dim3(256), 0, stream, (const float*)src, (bf16*)dst, n);
+  else if (sdtype == STJ_BF16 && ddtype == STJ_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(g), dim3(256), 0, stream, (const bf16*)src, (float*)dst, n);
+  else if (sdtype == STJ_F32 && ddtype == STJ_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, stream, (const float*)src, (float*)dst, n);
+  else if (sdtype == STJ_BF16 && ddtype == STJ_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(g), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, n);
+  else { stj_set_error("stj_cast: bad dtypes"); return STJ_EINVAL; }
+  return stj_check_launch("stj_cast");
+}
+
+// ---- unary activations ----------------------------------------------------------------------
+// op: 1 gelu (saved = x), 2 elu (saved = y), 3 tanh*scale (saved = y)
+enum { U_GELU = 1, U_ELU = 2, U_TANHS = 3 };
+
+template <typename T>
+__global__ __launch_bounds__(256) void unary_fwd_kernel(const T* x, T* y, long long n, int op, float p0) {
+  constexpr int VN = Vec<T>::N;
+  const long long nv = n / VN;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += gridDim.x * 256ll) {
+    float v[VN];
+    ld16(x + i * VN, v);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) v[e] = op == U_GELU ? gelu_f(v[e]) : (op == U_ELU ? elu_f(v[e]) : tanhf(v[e]) * p0);
+    st16(y + i * VN, v);
+  }
+  for (long long i = nv * VN + blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+    float v = ldf(x + i);
+    stf(y + i, op == U_GELU ? gelu_f(v) : (op == U_ELU ? elu_f(v) : tanhf(v) * p0));
+  }
+}
+__device__ __forceinline__ float unary_grad(float dy, float s, int op, float p0) {
+  if (op == U_GELU) return dy * gelu_grad_f(s);
+  if (op == U_ELU) return s > 0.f ? dy : dy * (s + 1.f);
+  float t = s / p0;                 // tanh
+  return dy * p0 * (1.f - t * t);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void unary_bwd_kernel(const T* dy, const T* s, T* dx, long long n, int op, float p0) {
+  constexpr int VN = Vec<T>::N;
+  const long long nv = n / VN;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += gridDim.x * 256ll) {
+    float a[VN], b[VN];
+    ld16(dy + i * VN, a);
+    ld16(s + i * VN, b);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) a[e] = unary_grad(a[e], b[e], op, p0);
+    st16(dx + i * VN, a);
+  }
+  for (long long i = nv * VN + blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
+    stf(dx + i, unary_grad(ldf(dy + i), ldf(s + i), op, p0));
+}
+extern "C" int stj_unary_fwd(const void* x, void* y, long long n, int op, float p0, int dtype, hipStream_t stream) {
+  if (n <= 0) return STJ_OK;
+  if (((uintptr_t)x | (uintptr_t)y) & 15) { stj_set_error("stj_unary_fwd: pointers must be 16-byte aligned"); return STJ_EINVAL; }
+  int g = ew_grid(n / 4);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(unary_fwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n, op, p0);
+  else hipLaunchKernelGGL(unary_fwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, n, op, p0);
+  return stj_check_launch("stj_unary_fwd");
+}
+extern "C" int stj_unary_bwd(const void* dy, const void* saved, void* dx, long long n, int op, float p0, int dtype, hipStream_t stream) {
+  if (n <= 0) return STJ_OK;
+  if (((uintptr_t)dy | (uintptr_t)saved | (uintptr_t)dx) & 15) { stj_set_error("stj_unary_bwd: pointers must be 16-byte aligned"); return STJ_EINVAL; }
+  int g = ew_grid(n / 4);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(unary_bwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)saved, (bf16*)dx, n, op, p0);
+  else hipLaunchKernelGGL(unary_bwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)dy, (const float*)saved, (float*)dx, n, op, p0);
+  return stj_check_launch("stj_unary_bwd");
+}
+
+// ---- max over a middle axis: x[outer][T][C] -> y[outer][C], idx (argmax, int8-in-int32) ---------
+// GlobalMaxPooling1D over the 11 time steps (reference trajNet.py:34,44).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* y, int* idx, long long outer, int Tn, int C) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < outer * C; i += gridDim.x * 256ll) {
+    long long o = i / C; int c = (int)(i % C);
+    float best = -INFINITY; int bi = 0;
+    for (int t = 0; t < Tn; ++t) {
+      float v = ldf(x + (o * Tn + t) * C + c);
+      if (v > best) { best = v; bi = t; }
+    }
+    stf(y + i, best);
+    idx[i] = bi;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dy, const int* idx, T* dx, long long outer, int Tn, int C) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < outer * Tn * C; i += gridDim.x * 256ll) {
+    int c = (int)(i % C); long long ot = i / C; int t = (int)(ot % Tn); long long o = ot / Tn;
+    stf(dx + i, idx[o * C + c] == t ? ldf(dy + o * C + c) : 0.f);
+  }
+}
+extern "C" int stj_maxpool_fwd(const void* x, void* y, int* idx, long long outer, int Tn, int C, int dtype, hipStream_t stream) {
+  if (outer <= 0) return STJ_OK;
+  int g = ew_grid(outer * C);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, idx, outer, Tn, C);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, idx, outer, Tn, C);
+  return stj_check_launch("stj_maxpool_fwd");
+}
+extern "C" int stj_maxpool_bwd(const void* dy, const int* idx, void* dx, long long outer, int Tn, int C, int dtype, hipStream_t stream) {
+  if (outer <= 0) return STJ_OK;
+  int g = ew_grid(outer * Tn * C);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, idx, (bf16*)dx, outer, Tn, C);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)dy, idx, (float*)dx, outer, Tn, C);
+  return stj_check_launch("stj_maxpool_bwd");
+}

@@ -1,0 +1,114 @@
+"""OGMFlow_loss -- same constructor / call signature as the reference (loss.py:22-57), HIP-fused inside.
+
+    OGMFlow_loss(config, ogm_weight=1000., occ_weight=1000., flow_weight=1., replica=1., flow_origin_weight=1000.,
+                 no_use_warp=False, use_pred=False, use_focal_loss=True, use_gt=False)
+    loss_fn(pred_waypoint_logits, true_waypoints, curr_ogm) -> {'observed_xe','occluded_xe','flow','flow_warp_xe'}
+
+`pred_waypoint_logits` / `true_waypoints` are WaypointGrids-like objects (.vehicles.observed_occupancy /
+.occluded_occupancy / .flow / .flow_origin_occupancy = lists of 8 tensors [B,H,W,{1,1,2,1}], reference
+train.py:105-140).  The fast path is the packed form: `get_pred_waypoint_logits(model_out)` and
+`warpped_gt(gt_obs, gt_occ, gt_flow, origin_flow)` below build WaypointGrids that remember the packed tensors they
+were sliced from, so the fused kernel reads [B,H,W,32] / [B,8,H,W,*] directly; hand-built lists are packed with
+torch.cat/stack first (autograd carries the gradient back through that packing).
+
+Only the configuration train.py:195-196 uses is built on the GPU: use_focal_loss=False, use_pred=False
+(constructor defaults of the reference differ: use_focal_loss=True -- requesting it raises NotImplementedError).
+"""
+import torch
+
+from . import ops
+
+NUM_PRED_CHANNELS = 4
+
+
+class _Vehicles:
+    def __init__(self):
+        self.observed_occupancy = []
+        self.occluded_occupancy = []
+        self.flow = []
+        self.flow_origin_occupancy = []
+
+
+class WaypointGrids:
+    """Stand-in for waymo_open_dataset.utils.occupancy_flow_grids.WaypointGrids (a plain container)."""
+    def __init__(self):
+        self.vehicles = _Vehicles()
+        self._packed = None
+
+
+class OccupancyFlowTaskConfig:
+    """The three fields of the Waymo proto the hot path reads (loss.py:81-82,95)."""
+    def __init__(self, grid_height_cells=256, grid_width_cells=256, num_waypoints=8):
+        self.grid_height_cells = grid_height_cells
+        self.grid_width_cells = grid_width_cells
+        self.num_waypoints = num_waypoints
+
+
+def get_pred_waypoint_logits(model_outputs, num_waypoints=8):
+    """train.py:105-123: slice [B,H,W,32] into per-waypoint obs/occ/flow views."""
+    g = WaypointGrids()
+    for k in range(num_waypoints):
+        c = k * NUM_PRED_CHANNELS
+        g.vehicles.observed_occupancy.append(model_outputs[..., c:c + 1])
+        g.vehicles.occluded_occupancy.append(model_outputs[..., c + 1:c + 2])
+        g.vehicles.flow.append(model_outputs[..., c + 2:c + 4])
+    g._packed = model_outputs
+    return g
+
+
+def warpped_gt(gt_ogm, gt_occ, gt_flow, origin_flow):
+    """train.py:126-140: GT [B,8,H,W,*] sliced along axis 1."""
+    g = WaypointGrids()
+    for k in range(gt_ogm.shape[1]):
+        g.vehicles.observed_occupancy.append(gt_ogm[:, k])
+        g.vehicles.occluded_occupancy.append(gt_occ[:, k])
+        g.vehicles.flow.append(gt_flow[:, k])
+        g.vehicles.flow_origin_occupancy.append(origin_flow[:, k])
+    g._packed = (gt_ogm, gt_occ, gt_flow, origin_flow)
+    return g
+
+
+class OGMFlow_loss:
+    def __init__(self, config, ogm_weight=1000.0, occ_weight=1000.0, flow_weight=1.0, replica=1.0,
+                 flow_origin_weight=1000.0, no_use_warp=False, use_pred=False, use_focal_loss=True, use_gt=False):
+        if use_focal_loss:
+            raise NotImplementedError('use_focal_loss=True (tfa SigmoidFocalCrossEntropy) is off the timed path '
+                                      '(train.py:196 passes False) and is not built')
+        if use_pred:
+            raise NotImplementedError('use_pred=True is not built (train.py:195 passes False)')
+        self.config = config
+        self.ogm_weight, self.occ_weight = ogm_weight, occ_weight
+        self.flow_weight = flow_weight            # stored but never applied, as in the reference (loss.py:29,141)
+        self.replica = replica
+        self.flow_origin_weight = flow_origin_weight
+        self.no_use_warp, self.use_gt = no_use_warp, use_gt
+
+    def __call__(self, pred_waypoint_logits, true_waypoints, curr_ogm=None):
+        n = self.config.num_waypoints
+        if n != 8:
+            raise NotImplementedError('num_waypoints must be 8')
+        pv, tv = pred_waypoint_logits.vehicles, true_waypoints.vehicles
+        if len(pv.observed_occupancy) != n or len(tv.observed_occupancy) != n:
+            raise ValueError('expected 8 waypoints in both grids')
+        logits = getattr(pred_waypoint_logits, '_packed', None)
+        if logits is None:
+            logits = torch.cat([torch.cat([pv.observed_occupancy[k], pv.occluded_occupancy[k], pv.flow[k]], -1)
+                                for k in range(n)], -1)
+        packed = getattr(true_waypoints, '_packed', None)
+        if packed is None:
+            packed = (torch.stack(tv.observed_occupancy, 1), torch.stack(tv.occluded_occupancy, 1),
+                      torch.stack(tv.flow, 1), torch.stack(tv.flow_origin_occupancy, 1))
+        gt_obs, gt_occ, gt_flow, origin = (t.float().contiguous() for t in packed)
+        B, H, W, Cc = logits.shape
+        if (H, W) != (self.config.grid_height_cells, self.config.grid_width_cells) or Cc != 32:
+            raise ValueError(f'logits must be [B,{self.config.grid_height_cells},{self.config.grid_width_cells},32]')
+        if tuple(gt_obs.shape) != (B, 8, H, W, 1) or tuple(gt_flow.shape) != (B, 8, H, W, 2):
+            raise ValueError('ground truth must be [B,8,H,W,{1,1,2,1}]')
+        if self.use_gt:
+            gate = ops.auc_gate(gt_obs, gt_occ, gt_flow, origin)
+        else:
+            gate = torch.ones(8, dtype=torch.float32, device=logits.device)
+        loss = ops.ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin, gate, self.ogm_weight, self.occ_weight,
+                                 self.flow_origin_weight, self.replica, not self.no_use_warp)
+        return {'observed_xe': loss[0], 'occluded_xe': loss[1], 'flow': loss[2],
+                'flow_warp_xe': loss[3] if not self.no_use_warp else 0.0}

@@ -1,0 +1,462 @@
+"""STrajNet model -- MI355X-native host side, mirroring the reference call surface.
+
+    STrajNet(cfg, model_name='STrajNet', use_pyramid=True, actor_only=True, sep_actors=False, fg_msa=False,
+             use_last_ref=False, fg=False, large_ogm=True)                       # reference modules.py:778-779
+    model(ogm, map_img, training=True, obs=None, occ=None, mapt=None, flow=None, dense_vec=None, dense_map=None)
+        -> [B, Hg, Hg, 32] float32                                              # reference modules.py:815-839
+
+Tensors are torch CUDA (ROCm) tensors, NHWC like the reference.  All math runs in the HIP kernels of
+libstrajnet_hip.so (strajnet_amd/csrc); torch supplies memory, streams and the autograd tape.
+Parameters live in ONE flat f32 buffer (+ a flat f32 gradient buffer that doubles as the data-parallel
+all-reduce bucket, + a bf16 shadow in bf16 mode); names/shapes/layouts follow the reference's Keras variables
+ so a name->array dict (state_dict / load_weights) exchanges weights with the oracle.
+
+Not built (documented gaps): dropout / DropPath randomness (training=True runs the same
+deterministic graph, rates 0), actor_only=False (MapEncoder), sep_actors=True, use_last_ref=True.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import Param, ACT_NONE, ACT_ELU
+
+
+def _param_spec(cfg, hb, fg_msa, fg):
+    """name -> (shape, init).  Keras layouts (Dense [in,out]; Conv HWIO; Conv3D DHWIO; Conv1D [k,in,out];
+    tfa-MHA [H,in,hs]/[H,hs,out]).  init in {'glorot','glorot_mha','zeros','ones','rpb','fg_rpe'}."""
+    C, ws, heads, depths = cfg['embed_dim'], cfg['window_size'], cfg['num_heads'], cfg['depths']
+    sp = OrderedDict()
+
+    def add(name, shape, init):
+        assert name not in sp
+        sp[name] = (tuple(shape), init)
+
+    def dense(n, i, o, bias=True):
+        add(n + '/kernel', (i, o), 'glorot')
+        if bias:
+            add(n + '/bias', (o,), 'zeros')
+
+    def conv(n, kh, kw, i, o, bias=True):
+        add(n + '/kernel', (kh, kw, i, o), 'glorot')
+        if bias:
+            add(n + '/bias', (o,), 'zeros')
+
+    def ln(n, c):
+        add(n + '/gamma', (c,), 'ones')
+        add(n + '/beta', (c,), 'zeros')
+
+    def mha(n, h, i, hs, o):
+        for k in ('query', 'key', 'value'):
+            add(f'{n}/{k}_kernel', (h, i, hs), 'glorot_mha')
+        add(f'{n}/projection_kernel', (h, hs, o), 'glorot_mha')
+        add(f'{n}/projection_bias', (o,), 'zeros')
+
+    for nm, cin in (('patch_embed_vecicle', 11), ('patch_embed_map', 3), ('patch_embed_flow', 2)):   # modules.py:490-537
+        conv(nm + '/proj', 4, 4, cin, C)
+        ln(nm + '/norm', C)
+    ln('flow_norm', C)                                                                                # modules.py:517
+    ln('all_patch_norm', C)                                                                           # modules.py:557
+
+    def block(pre, c, h):                                                                             # modules.py:179-187,76-86
+        ln(pre + '/norm1', c)
+        dense(pre + '/attn/qkv', c, 3 * c)
+        add(pre + '/attn/relative_position_bias_table', ((2 * ws - 1) ** 2, h), 'rpb')
+        dense(pre + '/attn/proj', c, c)
+        ln(pre + '/norm2', c)
+        dense(pre + '/mlp/fc1', c, 4 * c)
+        dense(pre + '/mlp/fc2', 4 * c, c)
+
+    def merge(pre, c):                                                                                # modules.py:270-272
+        ln(pre + '/downsample/norm', 4 * c)
+        dense(pre + '/downsample/reduction', 4 * c, 2 * c, bias=False)
+
+    for i in range(depths[0]):
+        block(f'flow_layers0/blocks{i}', C, heads[0])
+    merge('flow_layers0', C)
+    for L in range(3):
+        for i in range(depths[L]):
+            block(f'layers{L}/blocks{i}', C * 2 ** L, heads[L])
+        if L < 2:
+            merge(f'layers{L}', C * 2 ** L)
+    Cb = 4 * C
+    if fg_msa:                                                                                        # FG_MSA.py:51-73
+        gc = Cb // 8
+        for p in ('proj_q', 'proj_k', 'proj_v', 'proj_out'):
+            conv('fg_msa/' + p, 1, 1, Cb, Cb)
+        conv('fg_msa/conv_offset_0', 3, 3, gc, Cb)
+        ln('fg_msa/conv_norm', Cb)
+        conv('fg_msa/conv_offset_proj', 1, 1, gc, 2, bias=False)
+        if fg:
+            conv('fg_msa/conv_offset_proj2', 1, 1, 2, Cb)
+        add('fg_msa/warp_attn_rel_table', (2 * hb - 1, 2 * hb - 1, 8), 'fg_rpe')
+    add('traj_net/traj_encoder/node_feature/kernel', (1, 5, 64), 'glorot')                           # trajNet.py:32-36
+    add('traj_net/traj_encoder/node_feature/bias', (64,), 'zeros')
+    mha('traj_net/traj_encoder/node_attention', 4, 64, 64, 320)
+    dense('traj_net/traj_encoder/vector_feature', 3, 64, bias=False)
+    dense('traj_net/traj_encoder/sublayer', 384, Cb)
+    mha('traj_net/cross_attention/mha', 6, Cb, Cb // 6, Cb)                                           # trajNet.py:71-76
+    ln('traj_net/cross_attention/norm1', Cb)
+    ln('traj_net/cross_attention/norm2', Cb)
+    dense('traj_net/cross_attention/FFN1', Cb, 4 * Cb)
+    dense('traj_net/cross_attention/FFN2', 4 * Cb, Cb)
+    ln('traj_net/obs_norm', Cb)
+    ln('traj_net/occ_norm', Cb)
+    dense('traj_net/seg_embed', 2, Cb, bias=False)
+    for i in range(8):                                                                                # trajNet.py:195-210,257
+        p = f'cross_attn_obs{i}'
+        mha(p + '/mha', 3, Cb, 128 // 3, 128)
+        ln(p + '/norm1', 128)
+        dense(p + '/FFN1', 128, 512)
+        dense(p + '/FFN2', 512, Cb)
+        ln(p + '/norm2', Cb)
+    ch = [48, 96, 128, 192, 384]                                                                      # modules.py:635-730
+    cin = Cb
+    for i in (3, 2, 1, 0):
+        conv(f'decoder/upconv_{i}_0', 3, 3, cin, ch[i])
+        cin = ch[i]
+    for nm, ci, co in (('resconv_3', 2 * C, ch[3]), ('resconv_2', C, ch[2]), ('resconv_f', C, 128)):
+        add(f'decoder/{nm}/kernel', (8, 1, 1, ci, co), 'glorot')
+        add(f'decoder/{nm}/bias', (co,), 'zeros')
+    conv('decoder/upconvf_1_0', 3, 3, 128, ch[1])
+    conv('decoder/upconvf_0_0', 3, 3, ch[1], ch[0])
+    conv('decoder/outconv', 3, 3, ch[0], 2)
+    conv('decoder/outconv_f', 3, 3, ch[0], 2)
+    return sp
+
+
+def _init_tensor(shape, kind, gen):
+    if kind in ('glorot', 'glorot_mha'):
+        if kind == 'glorot':
+            rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            fi, fo = shape[-2] * rf, shape[-1] * rf
+        else:
+            fi, fo = shape[1] * shape[0], shape[2] * shape[0]
+        lim = math.sqrt(6.0 / (fi + fo))
+        return (torch.rand(shape, generator=gen) * 2 - 1) * lim
+    if kind == 'rpb':        # reference zero-initialises (modules.py:86); N(0,0.02) keeps the bias path live
+        return torch.randn(shape, generator=gen) * 0.02
+    if kind == 'fg_rpe':     # TruncatedNormal(0, 0.01) (FG_MSA.py:72)
+        return (torch.randn(shape, generator=gen) * 0.01).clamp_(-0.02, 0.02)
+    if kind == 'zeros':
+        return torch.zeros(shape)
+    if kind == 'ones':
+        return torch.ones(shape)
+    raise ValueError(kind)
+
+
+class STrajNet:
+    def __init__(self, cfg, model_name='STrajNet', use_pyramid=True, actor_only=True, sep_actors=False,
+                 fg_msa=False, use_last_ref=False, fg=False, large_ogm=True,
+                 device='cuda', dtype=torch.float32, seed=0):
+        if not use_pyramid or not actor_only or sep_actors or use_last_ref:
+            raise NotImplementedError('only use_pyramid=True, actor_only=True, sep_actors=False, use_last_ref=False '
+                                      '(the configuration train.py:194 / modules.py:851 uses) is built')
+        if fg and not fg_msa:
+            raise ValueError('fg=True requires fg_msa=True (modules.py:828-831 reads the FG-MSA output)')
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError('dtype must be torch.float32 (parity mode) or torch.bfloat16 (throughput mode)')
+        H, W = cfg['input_size']
+        if H != W or H % 128 != 0 and H != 128:
+            pass
+        if H != W:
+            raise ValueError('square inputs only (reference modules.py:583-585)')
+        if len(cfg['depths']) != 3 or len(cfg['num_heads']) != 3:
+            raise ValueError('depths/num_heads must have length 3 (reference modules.py:792-801,822)')
+        if cfg['window_size'] != 8 or any(cfg['embed_dim'] * 2 ** i // h != 32 for i, h in enumerate(cfg['num_heads'])):
+            raise NotImplementedError('window kernels are specialised for window_size=8, head_dim=32')
+        if cfg['embed_dim'] != 96:
+            raise NotImplementedError('embed_dim must be 96 (decoder / trajNet hard-code 384, reference modules.py:794,822)')
+        self.cfg = dict(cfg)
+        self.name = model_name
+        self.fg_msa, self.fg, self.large_ogm = fg_msa, fg, large_ogm
+        self.device = torch.device(device)
+        self.dtype = dtype
+        C = cfg['embed_dim']
+        self.P = H // 4
+        self.stage_res = [self.P, self.P // 2, self.P // 4]
+        self.stage_dim = [C, 2 * C, 4 * C]
+        crop = 2 if large_ogm else 1
+        self.skip_res = [r // crop for r in self.stage_res]
+        self.hb = self.skip_res[2]
+        self.map_size = H // 2 if large_ogm else H
+        if self.stage_res[2] % 8 != 0:
+            raise ValueError('input_size must be a multiple of 128')
+
+        spec = _param_spec(cfg, self.hb, fg_msa, fg)
+        total = sum(int(np.prod(s)) for s, _ in spec.values())
+        # 16-byte aligned slots so vector loads of every tensor are legal
+        offs, off = {}, 0
+        for n, (s, _) in spec.items():
+            offs[n] = off
+            off += (int(np.prod(s)) + 7) // 8 * 8
+        self.n_params = total
+        self._flat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self._gflat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self._cflat = self._flat if dtype == torch.float32 else torch.zeros(off, dtype=dtype, device=self.device)
+        gen = torch.Generator().manual_seed(seed)
+        self.params = OrderedDict()
+        for n, (s, kind) in spec.items():
+            k = int(np.prod(s))
+            sl = slice(offs[n], offs[n] + k)
+            self._flat[sl] = _init_tensor(s, kind, gen).reshape(-1).to(self.device)
+            master = self._flat[sl].view(s).requires_grad_(True)
+            grad = self._gflat[sl].view(s)
+            master.grad = grad
+            self.params[n] = Param(n, s, master, self._cflat[sl].view(s), grad)
+        self._sync_compute_weights()
+
+    # ------------------------------------------------------------------ weights
+    def _sync_compute_weights(self):
+        if self.dtype != torch.float32:
+            ops.call('stj_cast', ops._p(self._flat), 0, ops._p(self._cflat), 1, self._flat.numel(), ops._st())
+
+    def state_dict(self):
+        return OrderedDict((n, p.master.detach().cpu().numpy().copy()) for n, p in self.params.items())
+
+    def load_weights(self, weights):
+        """weights: dict name -> array (Keras layouts, App. B names)."""
+        missing = [n for n in self.params if n not in weights]
+        extra = [n for n in weights if n not in self.params]
+        if missing or extra:
+            raise KeyError(f'load_weights: missing {missing[:5]} extra {extra[:5]}')
+        with torch.no_grad():
+            for n, p in self.params.items():
+                w = torch.as_tensor(np.asarray(weights[n]), dtype=torch.float32)
+                if tuple(w.shape) != p.shape:
+                    raise ValueError(f'{n}: shape {tuple(w.shape)} != {p.shape}')
+                p.master.copy_(w.to(self.device))
+        self._sync_compute_weights()
+
+    def trainable_weights(self):
+        return [p.master for p in self.params.values()]
+
+    def parameters(self):
+        return self.trainable_weights()
+
+    def flat_grads(self):
+        """The flat f32 gradient buffer (also the data-parallel all-reduce bucket)."""
+        return self._gflat
+
+    def flat_weights(self):
+        return self._flat
+
+    def zero_grad(self):
+        self._gflat.zero_()
+
+    def grads(self):
+        return OrderedDict((n, p.grad) for n, p in self.params.items())
+
+    # ------------------------------------------------------------------ blocks
+    def _p(self, name):
+        return self.params[name]
+
+    def _ln(self, x, name, eps, gather_res=0):
+        return ops.layernorm(x, self._p(name + '/gamma'), self._p(name + '/beta'), eps, gather_res)
+
+    def _dense(self, x, name, act=ACT_NONE, res=None, bias=True):
+        return ops.linear(x, self._p(name + '/kernel'), self._p(name + '/bias') if bias else None, act, res)
+
+    def _swin_block(self, x, pre, B, res, heads, shift):
+        """SwinTransformerBlock.call (modules.py:220-262); the roll/partition/reverse plumbing lives in the kernel."""
+        if res <= 8:
+            shift = 0                                             # modules.py:173-175
+        h = self._ln(x, pre + '/norm1', 1e-5)
+        qkv = self._dense(h, pre + '/attn/qkv')
+        a = ops.win_attn(qkv, self._p(pre + '/attn/relative_position_bias_table'), B, res, heads, shift)
+        x = self._dense(a, pre + '/attn/proj', res=x)             # shortcut + attn
+        h = self._ln(x, pre + '/norm2', 1e-5)
+        h = ops.gelu(self._dense(h, pre + '/mlp/fc1'))
+        return self._dense(h, pre + '/mlp/fc2', res=x)
+
+    def _basic_layer(self, x, pre, B, res, depth, heads, downsample, add=None):
+        """BasicLayer.call (modules.py:351-364) -> (downsampled, pre-merge tokens)."""
+        for i in range(depth):
+            x = self._swin_block(x, f'{pre}/blocks{i}', B, res, heads, 0 if i % 2 == 0 else 4)
+        if not downsample:
+            return x, x
+        m = self._ln(x, pre + '/downsample/norm', 1e-5, gather_res=res)      # PatchMerging (modules.py:274-292)
+        return self._dense(m, pre + '/downsample/reduction', bias=False, res=add), x
+
+    def _patch_embed(self, src, name, Cin, ch_stride, pix_stride):
+        """PatchEmbed.call (modules.py:437-446): conv4x4/s4 as im2col + dense, then LN(1e-5)."""
+        B, H = src.shape[0], src.shape[1]
+        cols = ops.patch_im2col(src, Cin, ch_stride, pix_stride, self.dtype)
+        y = self._dense(cols, name + '/proj')
+        y = self._ln(y, name + '/norm', 1e-5)
+        return y.view(B, (H // 4) ** 2, -1)
+
+    def _encoder(self, ogm, map_img, flow):
+        """SwinTransformerEncoder.forward_features (modules.py:570-624), sep_encode/flow_sep/use_flow branch."""
+        B = ogm.shape[0]
+        C, P = self.stage_dim[0], self.P
+        depths, heads = self.cfg['depths'], self.cfg['num_heads']
+        fl = self._patch_embed(flow, 'patch_embed_flow', 2, 1, 2)
+        fl = self._ln(fl, 'flow_norm', 1e-5)
+        flow_x, flow_res = self._basic_layer(fl, 'flow_layers0', B, P, depths[0], heads[0], True)
+        vec = self._patch_embed(ogm, 'patch_embed_vecicle', 11, 2, 22)          # ogm[...,0]: stride-2 channel pick (:572)
+        maps = self._patch_embed(map_img, 'patch_embed_map', 3, 1, 3)
+        if self.large_ogm:                                                      # modules.py:582-587
+            Pm = self.map_size // 4
+            pad = (P - Pm) // 2
+            maps = torch.nn.functional.pad(maps.view(B, Pm, Pm, C), (0, 0, pad, pad, pad, pad)).reshape(B, P * P, C)
+        x = self._ln(vec + maps, 'all_patch_norm', 1e-5)
+        res_list = []
+
+        def crop(t, r, c):
+            q = r // 4
+            return t.view(B, r, r, c)[:, q:q + r // 2, q:q + r // 2].reshape(B, (r // 2) ** 2, c)
+        for i in range(3):
+            r, c = self.stage_res[i], self.stage_dim[i]
+            x, res = self._basic_layer(x, f'layers{i}', B, r, depths[i], heads[i], i < 2, add=flow_x if i == 0 else None)
+            if i == 0:
+                res_list.append(crop(flow_res, r, c) if self.large_ogm else flow_res)
+            res_list.append(crop(res, r, c) if self.large_ogm else res)
+        return res_list
+
+    def _fgmsa(self, x):
+        """FGMSA.call (FG_MSA.py:106-183), eval semantics.  x [B,hb,hb,384] -> (y, flow_hidden|None)."""
+        B, Hh, Ww, C = x.shape
+        G = 8
+        gc = C // G
+        HW = Hh * Ww
+        q = self._dense(x, 'fg_msa/proj_q')
+        o = ops.grouped_conv3(q, self._p('fg_msa/conv_offset_0/kernel'), self._p('fg_msa/conv_offset_0/bias'), G)
+        o = ops.gelu(self._ln(o, 'fg_msa/conv_norm', 1e-3))
+        # regroup [B,H,W,G,gc] -> [B,G,HW,gc] then 1x1 conv gc->2 (no bias), tanh * (H/2)
+        o = o.view(B, HW, G, gc).permute(0, 2, 1, 3).contiguous()
+        off = ops.tanh_scale(self._dense(o, 'fg_msa/conv_offset_proj', bias=False), Hh / 2.0)      # [B,G,HW,2]
+        flow_hidden = self._dense(off, 'fg_msa/conv_offset_proj2') if self.fg else None                # [B,G,HW,C]
+        k = self._dense(x, 'fg_msa/proj_k')                                                            # unsampled x (App. D-3)
+        v = self._dense(x, 'fg_msa/proj_v')
+        bias = ops.fg_bias(off, self._p('fg_msa/warp_attn_rel_table'), Hh, Ww)
+        a = ops.mha_core(q.view(B, HW, C), k.view(B, HW, C), v.view(B, HW, C), G, gc, gc ** -0.5, bias=bias)
+        y = self._dense(a.view(B, Hh, Ww, C), 'fg_msa/proj_out')
+        return y, flow_hidden
+
+    def _tfa_mha(self, pre, query, key, H, qvalid, kvalid):
+        """tensorflow_addons MultiHeadAttention with inputs=[query, key] (value=key), eval (trajNet.py:42,80,225)."""
+        pq, pk, pv = self._p(pre + '/query_kernel'), self._p(pre + '/key_kernel'), self._p(pre + '/value_kernel')
+        hs = pq.shape[-1]
+        q = ops.linear_heads_in(query, pq)
+        k = ops.linear_heads_in(key, pk)
+        v = ops.linear_heads_in(key, pv)
+        o = ops.mha_core(q, k, v, H, hs, 1.0 / math.sqrt(hs), qvalid=qvalid, kvalid=kvalid)
+        return ops.linear_heads_out(o, self._p(pre + '/projection_kernel'), self._p(pre + '/projection_bias'))
+
+    def _cross_attention(self, pre, query, key, H, qvalid, kvalid):
+        """Cross_Attention / Cross_AttentionT .call (trajNet.py:79-87,224-234), eval, sep_actors off."""
+        v = self._tfa_mha(pre + '/mha', query, key, H, qvalid, kvalid)
+        v = self._ln(v, pre + '/norm1', 1e-3)
+        v = self._dense(v, pre + '/FFN1', act=ACT_ELU)
+        v = self._dense(v, pre + '/FFN2')
+        return self._ln(v, pre + '/norm2', 1e-3)
+
+    def _traj_net(self, obs, occ):
+        """TrajNet.call (trajNet.py:125-187) with the 64-way TrajEncoder loop batched.  -> key [B,64,384], mask [B,64]."""
+        pre = 'traj_net/traj_encoder'
+        tr = torch.cat([obs, occ], 1).to(torch.float32)                    # [B,64,11,8]
+        B, A, T, _ = tr.shape
+        n_obs = obs.shape[1]
+        valid_t = (tr[..., 0] != 0)                                        # [B,64,11]   (trajNet.py:127,131)
+        vt = valid_t.to(torch.int32).contiguous().view(B * A, T)
+        cm = valid_t.any(-1)                                               # [B,64]      (trajNet.py:138)
+        cmi = cm.to(torch.int32).contiguous()
+        trc = tr.to(self.dtype)
+        nodes = ops.linear(trc[..., :5].contiguous(), self._p(pre + '/node_feature/kernel'),
+                           self._p(pre + '/node_feature/bias'), act=ACT_ELU)               # Conv1D(64,1)+ELU
+        nodes = nodes.view(B * A, T, 64)
+        nodes = self._tfa_mha(pre + '/node_attention', nodes, nodes, 4, vt, vt)           # [B*A,T,320]
+        nodes = ops.maxpool_time(nodes).view(B, A, 320)
+        vec = ops.linear(trc[:, :, 0, 5:].contiguous(), self._p(pre + '/vector_feature/kernel'))
+        enc = ops.linear(torch.cat([nodes, vec], -1), self._p(pre + '/sublayer/kernel'), self._p(pre + '/sublayer/bias'), act=ACT_ELU)
+        onehot = torch.zeros((A, 2), dtype=self.dtype, device=self.device)
+        onehot[:n_obs, 0] = 1
+        onehot[n_obs:, 1] = 1
+        embed = ops.linear(onehot, self._p('traj_net/seg_embed/kernel'))[None]            # [1,64,384]
+        concat = enc * cm[..., None].to(enc.dtype)
+        value = self._cross_attention('traj_net/cross_attention', concat + embed, concat, 6, cmi, cmi)
+        out = enc + value + embed
+        o1 = self._ln(out[:, :n_obs].contiguous(), 'traj_net/obs_norm', 1e-3)
+        o2 = self._ln(out[:, n_obs:].contiguous(), 'traj_net/occ_norm', 1e-3)
+        return torch.cat([o1, o2], 1), cmi
+
+    def _resconv(self, skip, name):
+        """ELU(Conv3D(8,1,1) SAME (tf.repeat(skip, 8))) collapsed exactly to 8 per-time 1x1 GEMMs with summed
+        time taps (modules.py:750-765): W_t = sum_{j=max(0,3-t)}^{min(7,10-t)} W[j]."""
+        pw, pb = self._p(name + '/kernel'), self._p(name + '/bias')
+        Ci, Co = pw.shape[3], pw.shape[4]
+        sel = torch.zeros((8, 8), dtype=torch.float32, device=self.device)
+        for t in range(8):
+            sel[t, max(0, 3 - t):min(7, 10 - t) + 1] = 1
+        wz = (sel @ pw.master.detach().view(8, Ci * Co)).view(8, Ci, Co).to(self.dtype)
+        gwz = torch.zeros((8, Ci, Co), dtype=torch.float32, device=self.device)
+        gbz = torch.zeros((8, Co), dtype=torch.float32, device=self.device)
+        bz = pb.master.detach()[None].expand(8, Co).contiguous()
+        def fold():
+            pw.grad.view(8, Ci * Co).add_(sel.t() @ gwz.view(8, Ci * Co))
+            pb.grad.add_(gbz.sum(0))
+        return ops.linear_z(skip, pw.master, wz, bz, gwz, gbz, act=ACT_ELU, shared_x=True, fold=fold)    # [B,8,HW,Co]
+
+    def _decoder(self, x, res_list, B):
+        """Pyramid3DDecoder.call (modules.py:739-772): shallow_decode=1, flow_sep_decode, use_pyramid, rep_res."""
+        hb = self.hb
+        flow_res, r0, r1 = res_list[0], res_list[1], res_list[2]
+
+        def up(t, name):
+            return ops.upconv(t, self._p(name + '/kernel'), self._p(name + '/bias'))
+        x = x.view(B * 8, hb, hb, -1)
+        x = up(x, 'decoder/upconv_3_0')                                              # [F,2hb,2hb,192]
+        x = x + self._resconv(r1, 'decoder/resconv_3').view(x.shape)
+        x = up(x, 'decoder/upconv_2_0')                                              # [F,4hb,4hb,128]
+        x = x + self._resconv(r0, 'decoder/resconv_2').view(x.shape)
+        fx = x + self._resconv(flow_res, 'decoder/resconv_f').view(x.shape)
+        x = up(up(x, 'decoder/upconv_1_0'), 'decoder/upconv_0_0')
+        fx = up(up(fx, 'decoder/upconvf_1_0'), 'decoder/upconvf_0_0')
+        return ops.outconv_pair(x, fx, self._p('decoder/outconv/kernel'), self._p('decoder/outconv/bias'),
+                                self._p('decoder/outconv_f/kernel'), self._p('decoder/outconv_f/bias'), B, 8)
+
+    # ------------------------------------------------------------------ call
+    def __call__(self, ogm, map_img, training=True, obs=None, occ=None, mapt=None, flow=None, dense_vec=None, dense_map=None):
+        return self.call(ogm, map_img, training, obs, occ, mapt, flow, dense_vec, dense_map)
+
+    def call(self, ogm, map_img, training=True, obs=None, occ=None, mapt=None, flow=None, dense_vec=None, dense_map=None):
+        """STrajNet.call (modules.py:815-839).  mapt is ignored (actor_only=True), as in the reference."""
+        if obs is None or occ is None or flow is None:
+            raise ValueError('obs, occ and flow are required (reference modules.py:818,834)')
+        H = self.cfg['input_size'][0]
+        if ogm.dim() != 5 or tuple(ogm.shape[1:]) != (H, H, 11, 2):
+            raise ValueError(f'ogm must be [B,{H},{H},11,2], got {tuple(ogm.shape)}')
+        B = ogm.shape[0]
+        if tuple(map_img.shape) != (B, self.map_size, self.map_size, 3):
+            raise ValueError(f'map_img must be [B,{self.map_size},{self.map_size},3], got {tuple(map_img.shape)}')
+        if tuple(flow.shape) != (B, H, H, 2):
+            raise ValueError(f'flow must be [B,{H},{H},2], got {tuple(flow.shape)}')
+        if tuple(obs.shape[2:]) != (11, 8) or tuple(occ.shape[2:]) != (11, 8):
+            raise ValueError('obs/occ must be [B,n,11,8]')
+        for t in (ogm, map_img, flow, obs, occ):
+            if not t.is_cuda:
+                raise RuntimeError('inputs must be CUDA (ROCm) tensors: the HIP path has no CPU fallback')
+        self._sync_compute_weights()
+        ogm, map_img, flow = ogm.float().contiguous(), map_img.float().contiguous(), flow.float().contiguous()
+        hb, Cb = self.hb, self.stage_dim[2]
+        res_list = self._encoder(ogm, map_img, flow)
+        q = res_list[-1].reshape(B, hb, hb, Cb)
+        fh = None
+        if self.fg_msa:
+            y, fh = self._fgmsa(q)
+            q = q + y                                                              # modules.py:825
+        query = q.reshape(B, 1, hb * hb, Cb).expand(B, 8, hb * hb, Cb)             # modules.py:827
+        if self.fg:
+            query = query + fh.reshape(B, 8, hb * hb, Cb)                          # modules.py:830-831
+        key, tmask = self._traj_net(obs, occ)
+        outs = []
+        for i in range(8):                                                         # trajNet.py:305-314
+            qi = query[:, i].contiguous()
+            o = self._cross_attention(f'cross_attn_obs{i}', qi, key, 3, None, tmask)
+            outs.append(o + qi)
+        x = torch.stack(outs, 1)                                                   # [B,8,hb*hb,Cb]
+        out = self._decoder(x, res_list, B)
+        return out

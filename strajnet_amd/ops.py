@@ -1,0 +1,612 @@
+"""torch.autograd plumbing around the C-ABI HIP kernels.
+
+PyTorch is used for device memory, streams and the autograd tape only; every FLOP-carrying op below is a
+launch of a hand-written gfx950 kernel from libstrajnet_hip.so.  Weight gradients are accumulated by the
+kernels straight into the model's flat f32 gradient buffer (the DP all-reduce bucket) -- autograd only
+routes activation gradients.
+"""
+import ctypes
+
+import torch
+
+from ._lib import call
+
+ACT_NONE, ACT_GELU, ACT_ELU = 0, 1, 2
+U_GELU, U_ELU, U_TANHS = 1, 2, 3
+vp = ctypes.c_void_p
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return 1
+    if t.dtype == torch.float32:
+        return 0
+    raise TypeError(f'unsupported activation dtype {t.dtype}')
+
+
+def _p(t):
+    return vp(t.data_ptr()) if t is not None else vp(0)
+
+
+def _st():
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('strajnet_amd ops run on the GPU only (HIP kernels); got a CPU tensor. '
+                               'There is no CPU fallback.')
+
+
+class Param:
+    """One trainable tensor: f32 master view, compute-dtype view, f32 gradient view (all slices of flat buffers)."""
+    __slots__ = ('name', 'shape', 'master', 'c', 'grad')
+
+    def __init__(self, name, shape, master, c, grad):
+        self.name, self.shape, self.master, self.c, self.grad = name, tuple(shape), master, c, grad
+
+
+def gemm(A, B, C, M, N, K, sA, sB, sC, dt, bias=None, sBias=(0, 0), res=None, sRes=(0, 0, 0), nb=(1, 1),
+         act=ACT_NONE, alpha=1.0, c_f32=0, accumulate=0, splitk=1):
+    """sA = (b1, b2, m, k) element strides; sB = (b1, b2, k, n); sC = (b1, b2, ldc); sRes = (b1, b2, ld)."""
+    call('stj_gemm', _p(A), _p(B), _p(C), _p(bias), _p(res), M, N, K, nb[0], nb[1],
+         sA[0], sA[1], sA[2], sA[3], sB[0], sB[1], sB[2], sB[3], sC[0], sC[1], sC[2],
+         sBias[0], sBias[1], sRes[0], sRes[1], sRes[2], act, float(alpha), dt, c_f32, accumulate, splitk, _st())
+
+
+def _splitk(M_out, N_out, Kdim):
+    tiles = ((M_out + 63) // 64) * ((N_out + 63) // 64)
+    want = max(1, 512 // max(tiles, 1))
+    return int(max(1, min(want, (Kdim + 255) // 256, 256)))
+
+
+# ----------------------------------------------------------------------------------------------------
+# Dense (+bias, +ELU, +residual)
+# ----------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = act(x @ wc + bias) [+ res].  wc: [K,N] compute-dtype weight; gw: f32 [K,N] gradient accumulation target
+    (or, with `fold`, a scratch gradient is produced and handed to fold(g))."""
+    @staticmethod
+    def forward(ctx, x, trig, wc, gw, bias, gb, act, res, fold):
+        _req_cuda(x)
+        K, N = wc.shape
+        x2 = x.contiguous().view(-1, K)
+        M = x2.shape[0]
+        dt = _dt(x2)
+        if act == ACT_ELU and res is not None:
+            raise RuntimeError('linear: ELU + residual in one op is not supported')
+        if act == ACT_GELU:
+            raise RuntimeError('linear: fused GELU has no backward (use the separate gelu op)')
+        y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+        r2 = res.contiguous().view(M, N) if res is not None else None
+        gemm(x2, wc, y, M, N, K, (0, 0, K, 1), (0, 0, N, 1), (0, 0, N), dt, bias=bias, res=r2, sRes=(0, 0, N), act=act)
+        ctx.wc, ctx.gw, ctx.gb, ctx.act, ctx.has_res, ctx.fold = wc, gw, gb, act, res is not None, fold
+        ctx.xshape = x.shape
+        ctx.save_for_backward(x2, y if act == ACT_ELU else None)
+        return y.view(x.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y = ctx.saved_tensors
+        wc = ctx.wc
+        K, N = wc.shape
+        M = x2.shape[0]
+        dt = _dt(x2)
+        dy2 = dy.contiguous().view(M, N)
+        if ctx.act == ACT_ELU:
+            dpre = torch.empty_like(dy2)
+            call('stj_unary_bwd', _p(dy2), _p(y), _p(dpre), M * N, U_ELU, 0.0, dt, _st())
+        else:
+            dpre = dy2
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            gemm(dpre, wc, dx, M, K, N, (0, 0, N, 1), (0, 0, 1, N), (0, 0, K), dt)        # dx = dpre W^T
+            dx = dx.view(ctx.xshape)
+        gw = ctx.gw if ctx.fold is None else torch.zeros((K, N), dtype=torch.float32, device=x2.device)
+        gemm(x2, dpre, gw, K, N, M, (0, 0, 1, K), (0, 0, N, 1), (0, 0, N), dt, c_f32=1, accumulate=1,
+             splitk=_splitk(K, N, M))                                                    # dW += x^T dpre
+        if ctx.fold is not None:
+            ctx.fold(gw)
+        if ctx.gb is not None:
+            call('stj_colsum', _p(dpre), _p(ctx.gb), M, N, N, dt, _st())
+        dres = dy if ctx.has_res else None
+        return dx, None, None, None, None, None, None, dres, None
+
+
+def linear(x, pw, pb=None, act=ACT_NONE, res=None):
+    """Keras Dense / 1x1 Conv2D / flattened conv kernel: weight [..., K, N] viewed as [prod(...)*K, N]."""
+    N = pw.c.shape[-1]
+    return _Linear.apply(x, pw.master, pw.c.view(-1, N), pw.grad.view(-1, N), pb.master if pb is not None else None,
+                         pb.grad if pb is not None else None, act, res, None)
+
+
+def linear_heads_in(x, pw):
+    """tfa-MHA query/key/value kernel [H, in, hs]: y[..., h*hs+o] = sum_i x[..., i] W[h,i,o] (no bias)."""
+    H, I, hs = pw.c.shape
+    wc = pw.c.permute(1, 0, 2).reshape(I, H * hs)
+
+    def fold(g):
+        pw.grad.add_(g.view(I, H, hs).permute(1, 0, 2))
+    return _Linear.apply(x, pw.master, wc, None, None, None, ACT_NONE, None, fold)
+
+
+def linear_heads_out(x, pw, pb):
+    """tfa-MHA projection kernel [H, hs, out] (+ projection_bias): plain dense on the flattened (h,hs) axis."""
+    H, hs, O = pw.c.shape
+    return _Linear.apply(x, pw.master, pw.c.view(H * hs, O), pw.grad.view(H * hs, O), pb.master, pb.grad, ACT_NONE, None, None)
+
+
+# ----------------------------------------------------------------------------------------------------
+# batched dense: y[b, z, m, :] = act(x[b, (z|shared), m, :] @ W[z] + bias[z])      (z = waypoint / time index)
+# ----------------------------------------------------------------------------------------------------
+class _LinearZ(torch.autograd.Function):
+    """x: [B, Z, M, K] or, with shared_x, [B, M, K] broadcast over z; W: [Z, K, N] (contiguous, compute dtype tensor
+    `wz` derived from a parameter by the caller); bias [Z, N] f32 or None.  Returns y [B, Z, M, N] and accumulates
+    dW into gwz [Z,K,N] f32, db into gbz [Z,N] f32."""
+    @staticmethod
+    def forward(ctx, x, trig, wz, bz, gwz, gbz, act, shared_x, fold):
+        _req_cuda(x)
+        Z, K, N = wz.shape
+        x = x.contiguous()
+        if shared_x:
+            B, M = x.shape[0], x.shape[1]
+            sA = (M * K, 0, K, 1)
+        else:
+            B, M = x.shape[0], x.shape[2]
+            sA = (Z * M * K, M * K, K, 1)
+        dt = _dt(x)
+        y = torch.empty((B, Z, M, N), dtype=x.dtype, device=x.device)
+        gemm(x, wz, y, M, N, K, sA, (0, K * N, N, 1), (Z * M * N, M * N, N), dt, bias=bz, sBias=(0, N), nb=(B, Z), act=act)
+        ctx.dims = (B, Z, M, K, N, sA, shared_x, act)
+        ctx.wz, ctx.gwz, ctx.gbz, ctx.fold = wz, gwz, gbz, fold
+        ctx.save_for_backward(x, y if act == ACT_ELU else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        B, Z, M, K, N, sA, shared_x, act = ctx.dims
+        dt = _dt(x)
+        dy = dy.contiguous()
+        if act == ACT_ELU:
+            dpre = torch.empty_like(dy)
+            call('stj_unary_bwd', _p(dy), _p(y), _p(dpre), dy.numel(), U_ELU, 0.0, dt, _st())
+        else:
+            dpre = dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if shared_x:
+                # dx[b,m,k] = sum_z sum_n dpre[b,z,m,n] W[z,k,n]  -> one GEMM with contraction over (z,n) is not strided-
+                # expressible; accumulate z by z into an f32 buffer, then cast.
+                acc = torch.zeros((B, M, K), dtype=torch.float32, device=x.device)
+                for z in range(Z):
+                    gemm(dpre[:, z], ctx.wz[z], acc, M, K, N, (Z * M * N, 0, N, 1), (0, 0, 1, N), (M * K, 0, K), dt,
+                         nb=(B, 1), c_f32=1, accumulate=1)
+                dx = acc.to(x.dtype)
+            else:
+                dx = torch.empty_like(x)
+                gemm(dpre, ctx.wz, dx, M, K, N, (Z * M * N, M * N, N, 1), (0, K * N, 1, N), (Z * M * K, M * K, K), dt,
+                     nb=(B, Z))
+        # dW[z][k,n] += sum_b sum_m x[b,z,m,k] dpre[b,z,m,n]: batch over z, loop b (contraction over m per launch)
+        for b in range(B):
+            xa = x[b]
+            sAx = (0, 0 if shared_x else M * K, 1, K)
+            gemm(xa, dpre[b], ctx.gwz, K, N, M, sAx, (0, M * N, N, 1), (0, K * N, N), dt, nb=(1, Z), c_f32=1,
+                 accumulate=1, splitk=_splitk(K, N, M) if Z * _splitk(K, N, M) <= 4096 else 1)
+        if ctx.gbz is not None:
+            for z in range(Z):
+                dz = dpre[:, z]
+                call('stj_colsum', _p(dz.contiguous()), _p(ctx.gbz[z]), B * M, N, N, dt, _st())
+        if ctx.fold is not None:
+            ctx.fold()
+        return dx, None, None, None, None, None, None, None, None
+
+
+def linear_z(x, trig, wz, bz, gwz, gbz, act=ACT_NONE, shared_x=False, fold=None):
+    return _LinearZ.apply(x, trig, wz, bz, gwz, gbz, act, shared_x, fold)
+
+
+# ----------------------------------------------------------------------------------------------------
+# unary activations
+# ----------------------------------------------------------------------------------------------------
+class _Unary(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op, p0):
+        _req_cuda(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        call('stj_unary_fwd', _p(x), _p(y), x.numel(), op, float(p0), _dt(x), _st())
+        ctx.op, ctx.p0 = op, p0
+        ctx.save_for_backward(x if op == U_GELU else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (s,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call('stj_unary_bwd', _p(dy), _p(s), _p(dx), dy.numel(), ctx.op, float(ctx.p0), _dt(dy), _st())
+        return dx, None, None
+
+
+def gelu(x):
+    return _Unary.apply(x, U_GELU, 0.0)
+
+
+def elu(x):
+    return _Unary.apply(x, U_ELU, 0.0)
+
+
+def tanh_scale(x, s):
+    return _Unary.apply(x, U_TANHS, s)
+
+
+# ----------------------------------------------------------------------------------------------------
+# LayerNorm (optionally fused with the PatchMerging 2x2 gather)
+# ----------------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g_master, b_master, pg, pb, eps, gather_res):
+        _req_cuda(x)
+        x = x.contiguous()
+        dt = _dt(x)
+        if gather_res:
+            B, L, C0 = x.shape
+            assert L == gather_res * gather_res
+            C = 4 * C0
+            rows = B * (gather_res // 2) ** 2
+            oshape = (B, (gather_res // 2) ** 2, C)
+        else:
+            C0 = 0
+            C = x.shape[-1]
+            rows = x.numel() // C
+            oshape = x.shape
+        y = torch.empty(oshape, dtype=x.dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        call('stj_layernorm_fwd', _p(x), _p(pg.master), _p(pb.master), _p(y), _p(mean), _p(rstd), rows, C, float(eps),
+             gather_res, C0, dt, _st())
+        ctx.pg, ctx.pb, ctx.geo = pg, pb, (rows, C, gather_res, C0)
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        rows, C, gres, C0 = ctx.geo
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        call('stj_layernorm_bwd', _p(dy), _p(x), _p(ctx.pg.master), _p(mean), _p(rstd), _p(dx), _p(ctx.pg.grad),
+             _p(ctx.pb.grad), rows, C, gres, C0, _dt(x), _st())
+        return dx, None, None, None, None, None, None
+
+
+def layernorm(x, pg, pb, eps, gather_res=0):
+    return _LayerNorm.apply(x, pg.master, pb.master, pg, pb, eps, gather_res)
+
+
+# ----------------------------------------------------------------------------------------------------
+# fused (shifted) window attention
+# ----------------------------------------------------------------------------------------------------
+class _WinAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, t_master, pt, B, res, heads, shift):
+        _req_cuda(qkv)
+        qkv = qkv.contiguous()
+        C = heads * 32
+        out = torch.empty((B, res * res, C), dtype=qkv.dtype, device=qkv.device)
+        call('stj_win_attn_fwd', _p(qkv), _p(pt.master), _p(out), B, res, heads, shift, _dt(qkv), _st())
+        ctx.pt, ctx.geo = pt, (B, res, heads, shift)
+        ctx.save_for_backward(qkv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv,) = ctx.saved_tensors
+        B, res, heads, shift = ctx.geo
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        call('stj_win_attn_bwd', _p(qkv), _p(ctx.pt.master), _p(dout), _p(dqkv), _p(ctx.pt.grad), B, res, heads, shift,
+             _dt(qkv), _st())
+        return dqkv, None, None, None, None, None, None
+
+
+def win_attn(qkv, pt, B, res, heads, shift):
+    return _WinAttn.apply(qkv, pt.master, pt, B, res, heads, shift)
+
+
+# ----------------------------------------------------------------------------------------------------
+# global multi-head attention core: softmax(scale * q k^T (+bias) (+mask)) v   (projections are `linear`s)
+# ----------------------------------------------------------------------------------------------------
+class _MhaCore(torch.autograd.Function):
+    """q [Bt,Nq,H*d], k,v [Bt,Nk,H*d]; qvalid [Bt,Nq] / kvalid [Bt,Nk] int32 or None; bias f32 [Bt,H,Nq,Nk] or None.
+    Returns o [Bt,Nq,H*d].  Gradient w.r.t. bias is returned in the activation dtype."""
+    @staticmethod
+    def forward(ctx, q, k, v, bias, H, d, scale, qvalid, kvalid):
+        _req_cuda(q, k, v)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        Bt, Nq, HD = q.shape
+        Nk = k.shape[1]
+        dt = _dt(q)
+        S = torch.empty((Bt, H, Nq, Nk), dtype=torch.float32, device=q.device)
+        # S[b,h] = scale * Q[b,:,h,:] K[b,:,h,:]^T
+        gemm(q, k, S, Nq, Nk, d, (Nq * HD, d, HD, 1), (Nk * HD, d, 1, HD), (H * Nq * Nk, Nq * Nk, Nk), dt, nb=(Bt, H),
+             alpha=scale, c_f32=1)
+        P = torch.empty((Bt, H, Nq, Nk), dtype=q.dtype, device=q.device)
+        if bias is not None:
+            bias = bias.contiguous()
+        call('stj_softmax_fwd', _p(S), _p(P), _p(qvalid), _p(kvalid), _p(bias), Bt, H, Nq, Nk, dt, _st())
+        o = torch.empty_like(q)
+        # O[b,:,h,:] = P[b,h] V[b,:,h,:]
+        gemm(P, v, o, Nq, d, Nk, (H * Nq * Nk, Nq * Nk, Nk, 1), (Nk * HD, d, HD, 1), (Nq * HD, d, HD), dt, nb=(Bt, H))
+        ctx.geo = (Bt, Nq, Nk, H, d, scale, bias is not None)
+        ctx.save_for_backward(q, k, v, P)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, P = ctx.saved_tensors
+        Bt, Nq, Nk, H, d, scale, has_bias = ctx.geo
+        HD = H * d
+        dt = _dt(q)
+        do = do.contiguous()
+        dP = torch.empty((Bt, H, Nq, Nk), dtype=torch.float32, device=q.device)
+        # dP[b,h] = dO[b,:,h,:] V[b,:,h,:]^T
+        gemm(do, v, dP, Nq, Nk, d, (Nq * HD, d, HD, 1), (Nk * HD, d, 1, HD), (H * Nq * Nk, Nq * Nk, Nk), dt, nb=(Bt, H), c_f32=1)
+        dS = torch.empty_like(P)
+        call('stj_softmax_bwd', _p(P), _p(dP), _p(dS), Bt * H * Nq, Nk, dt, _st())
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        # dV[b,:,h,:] = P[b,h]^T dO ; dQ = scale dS K ; dK = scale dS^T Q
+        gemm(P, do, dv, Nk, d, Nq, (H * Nq * Nk, Nq * Nk, 1, Nk), (Nq * HD, d, HD, 1), (Nk * HD, d, HD), dt, nb=(Bt, H))
+        gemm(dS, k, dq, Nq, d, Nk, (H * Nq * Nk, Nq * Nk, Nk, 1), (Nk * HD, d, HD, 1), (Nq * HD, d, HD), dt, nb=(Bt, H), alpha=scale)
+        gemm(dS, q, dk, Nk, d, Nq, (H * Nq * Nk, Nq * Nk, 1, Nk), (Nq * HD, d, HD, 1), (Nk * HD, d, HD), dt, nb=(Bt, H), alpha=scale)
+        return dq, dk, dv, (dS if has_bias else None), None, None, None, None, None
+
+
+def mha_core(q, k, v, H, d, scale, qvalid=None, kvalid=None, bias=None):
+    return _MhaCore.apply(q, k, v, bias, H, d, scale, qvalid, kvalid)
+
+
+class _FgBias(torch.autograd.Function):
+    """off [B,G,HW,2] (activation dtype) + table param [2H-1,2W-1,G] -> f32 bias [B,G,HW,HW]."""
+    @staticmethod
+    def forward(ctx, off, t_master, pt, Hh, Ww):
+        _req_cuda(off)
+        off = off.contiguous()
+        B, G = off.shape[0], off.shape[1]
+        bias = torch.empty((B, G, Hh * Ww, Hh * Ww), dtype=torch.float32, device=off.device)
+        call('stj_fg_bias_fwd', _p(off), _p(pt.master), _p(bias), B, G, Hh, Ww, _dt(off), _st())
+        ctx.pt, ctx.geo = pt, (B, G, Hh, Ww)
+        ctx.save_for_backward(off)
+        return bias
+
+    @staticmethod
+    def backward(ctx, dbias):
+        (off,) = ctx.saved_tensors
+        B, G, Hh, Ww = ctx.geo
+        dbias = dbias.contiguous().to(off.dtype)
+        doff = torch.empty(off.shape, dtype=torch.float32, device=off.device)
+        call('stj_fg_bias_bwd', _p(off), _p(ctx.pt.master), _p(dbias), _p(ctx.pt.grad), _p(doff), B, G, Hh, Ww, _dt(off), _st())
+        return doff.to(off.dtype), None, None, None, None
+
+
+def fg_bias(off, pt, Hh, Ww):
+    return _FgBias.apply(off, pt.master, pt, Hh, Ww)
+
+
+# ----------------------------------------------------------------------------------------------------
+# max over time (GlobalMaxPooling1D)
+# ----------------------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _req_cuda(x)
+        x = x.contiguous()
+        outer, Tn, C = x.shape[:-2].numel(), x.shape[-2], x.shape[-1]
+        y = torch.empty(x.shape[:-2] + (C,), dtype=x.dtype, device=x.device)
+        idx = torch.empty(outer * C, dtype=torch.int32, device=x.device)
+        call('stj_maxpool_fwd', _p(x), _p(y), _p(idx), outer, Tn, C, _dt(x), _st())
+        ctx.geo = (outer, Tn, C, x.shape)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        outer, Tn, C, shape = ctx.geo
+        dy = dy.contiguous()
+        dx = torch.empty(shape, dtype=dy.dtype, device=dy.device)
+        call('stj_maxpool_bwd', _p(dy), _p(idx), _p(dx), outer, Tn, C, _dt(dy), _st())
+        return dx
+
+
+def maxpool_time(x):
+    return _MaxPool.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------------
+# patch embedding conv (4x4 stride 4) = im2col + dense
+# ----------------------------------------------------------------------------------------------------
+def patch_im2col(src, Cin, ch_stride, pix_stride, dtype):
+    """src: f32 tensor viewed as [B,H,W,*]; returns [B*(H/4)*(W/4), 16*Cin] in `dtype` (no grad: inputs are data)."""
+    _req_cuda(src)
+    src = src.contiguous()
+    B, H, W = src.shape[0], src.shape[1], src.shape[2]
+    out = torch.empty((B * (H // 4) * (W // 4), 16 * Cin), dtype=dtype, device=src.device)
+    call('stj_im2col_patch', _p(src), _p(out), B, H, W, Cin, pix_stride, ch_stride, 1 if dtype == torch.bfloat16 else 0, _st())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# grouped 3x3 SAME conv (FG-MSA offsets): im2col -> per-group GEMM
+# ----------------------------------------------------------------------------------------------------
+class _GroupedConv3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_master, b_master, pw, pb, G):
+        _req_cuda(x)
+        x = x.contiguous()
+        N, H, W, C = x.shape
+        Cg = C // G
+        K = 9 * Cg
+        Co = pw.c.shape[-1]
+        cog = Co // G
+        dt = _dt(x)
+        M = N * H * W
+        cols = torch.empty((M, G, K), dtype=x.dtype, device=x.device)
+        call('stj_im2col3', _p(x), _p(cols), N, H, W, G, Cg, dt, _st())
+        y = torch.empty((N, H, W, Co), dtype=x.dtype, device=x.device)
+        # group g: A = cols[:, g, :] ; B[k, n] = W_flat[k, g*cog + n] (row stride Co)
+        gemm(cols, pw.c, y, M, cog, K, (0, K, G * K, 1), (0, cog, Co, 1), (0, cog, Co), dt, bias=pb.master, sBias=(0, cog), nb=(1, G))
+        ctx.pw, ctx.pb, ctx.geo = pw, pb, (N, H, W, G, Cg, K, Co, cog, M)
+        ctx.save_for_backward(cols)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cols,) = ctx.saved_tensors
+        N, H, W, G, Cg, K, Co, cog, M = ctx.geo
+        pw, pb = ctx.pw, ctx.pb
+        dt = _dt(cols)
+        dy = dy.contiguous()
+        dcols = torch.empty_like(cols)
+        # dcols[:, g, k] = sum_n dy[:, g*cog+n] W[k, g*cog+n]
+        gemm(dy, pw.c, dcols, M, K, cog, (0, cog, Co, 1), (0, cog, 1, Co), (0, K, G * K), dt, nb=(1, G))
+        dx = torch.empty((N, H, W, G * Cg), dtype=dy.dtype, device=dy.device)
+        call('stj_col2im3', _p(dcols), _p(dx), N, H, W, G, Cg, dt, _st())
+        # dW[k, g*cog+n] += sum_m cols[m,g,k] dy[m, g*cog+n]
+        gemm(cols, dy, pw.grad, K, cog, M, (0, K, 1, G * K), (0, cog, Co, 1), (0, cog, Co), dt, nb=(1, G), c_f32=1,
+             accumulate=1, splitk=_splitk(K, cog, M))
+        call('stj_colsum', _p(dy), _p(pb.grad), M, Co, Co, dt, _st())
+        return dx, None, None, None, None, None
+
+
+def grouped_conv3(x, pw, pb, G):
+    return _GroupedConv3.apply(x, pw.master, pb.master, pw, pb, G)
+
+
+# ----------------------------------------------------------------------------------------------------
+# decoder: nearest-2x upsample folded 3x3 conv + bias + ELU
+# ----------------------------------------------------------------------------------------------------
+class _UpConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_master, b_master, pw, pb):
+        _req_cuda(x)
+        x = x.contiguous()
+        F_, Hi, Wi, Cin = x.shape
+        Cout = pw.master.shape[-1]
+        dt = _dt(x)
+        wf = torch.empty((16, Cout, Cin), dtype=x.dtype, device=x.device)
+        wd = torch.empty((16, Cin, Cout), dtype=x.dtype, device=x.device)
+        call('stj_upconv_prep', _p(pw.master), _p(wf), _p(wd), Cin, Cout, dt, _st())
+        y = torch.empty((F_, 2 * Hi, 2 * Wi, Cout), dtype=x.dtype, device=x.device)
+        call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
+        ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
+        ctx.save_for_backward(x, y, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, wd = ctx.saved_tensors
+        F_, Hi, Wi, Cin, Cout = ctx.geo
+        dt = _dt(x)
+        dy = dy.contiguous()
+        dpre = torch.empty_like(dy)
+        call('stj_unary_bwd', _p(dy), _p(y), _p(dpre), dy.numel(), U_ELU, 0.0, dt, _st())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), F_, Hi, Wi, Cin, Cout, dt, _st())
+        dweff = torch.zeros((16, Cout, Cin), dtype=torch.float32, device=x.device)
+        call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), F_, Hi, Wi, Cin, Cout, dt, _st())
+        call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
+        call('stj_colsum', _p(dpre), _p(ctx.pb.grad), F_ * 4 * Hi * Wi, Cout, Cout, dt, _st())
+        return dx, None, None, None, None
+
+
+def upconv(x, pw, pb):
+    """x [F,Hi,Wi,Cin] -> ELU(conv3x3(upsample2(x)) + b) [F,2Hi,2Wi,Cout]."""
+    return _UpConv.apply(x, pw.master, pb.master, pw, pb)
+
+
+class _OutConvPair(torch.autograd.Function):
+    """Two 3x3 C->2 heads written straight into the [B,H,W,32] f32 model output (channel 4t+{0,1} and 4t+{2,3})."""
+    @staticmethod
+    def forward(ctx, xo, xf, w1m, b1m, w2m, b2m, p1w, p1b, p2w, p2b, B, Tn):
+        _req_cuda(xo, xf)
+        xo, xf = xo.contiguous(), xf.contiguous()
+        F_, H, W, C = xo.shape
+        out = torch.empty((B, H, W, 4 * Tn), dtype=torch.float32, device=xo.device)
+        dt = _dt(xo)
+        ybs, yts, yps = H * W * 4 * Tn, 4, 4 * Tn
+        call('stj_outconv_fwd', _p(xo), _p(p1w.master), _p(p1b.master), vp(out.data_ptr()), F_, H, W, C, Tn, ybs, yts, yps, dt, _st())
+        call('stj_outconv_fwd', _p(xf), _p(p2w.master), _p(p2b.master), vp(out.data_ptr() + 8), F_, H, W, C, Tn, ybs, yts, yps, dt, _st())
+        ctx.ps = (p1w, p1b, p2w, p2b)
+        ctx.geo = (F_, H, W, C, Tn, ybs, yts, yps)
+        ctx.save_for_backward(xo, xf)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xo, xf = ctx.saved_tensors
+        p1w, p1b, p2w, p2b = ctx.ps
+        F_, H, W, C, Tn, ybs, yts, yps = ctx.geo
+        dout = dout.contiguous().float()
+        dt = _dt(xo)
+        dxo, dxf = torch.empty_like(xo), torch.empty_like(xf)
+        call('stj_outconv_bwd', _p(xo), _p(p1w.master), vp(dout.data_ptr()), _p(dxo), _p(p1w.grad), _p(p1b.grad), F_, H, W, C, Tn,
+             ybs, yts, yps, dt, _st())
+        call('stj_outconv_bwd', _p(xf), _p(p2w.master), vp(dout.data_ptr() + 8), _p(dxf), _p(p2w.grad), _p(p2b.grad), F_, H, W, C, Tn,
+             ybs, yts, yps, dt, _st())
+        return (dxo, dxf) + (None,) * 10
+
+
+def outconv_pair(xo, xf, p1w, p1b, p2w, p2b, B, Tn):
+    return _OutConvPair.apply(xo, xf, p1w.master, p1b.master, p2w.master, p2b.master, p1w, p1b, p2w, p2b, B, Tn)
+
+
+# ----------------------------------------------------------------------------------------------------
+# loss
+# ----------------------------------------------------------------------------------------------------
+class _OgmFlowLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, use_warp):
+        _req_cuda(logits)
+        logits = logits.contiguous().float()
+        B, H, W, _ = logits.shape
+        dev = logits.device
+        sums = torch.empty(40, dtype=torch.float32, device=dev)
+        loss = torch.empty(4, dtype=torch.float32, device=dev)
+        coef = torch.empty(32, dtype=torch.float32, device=dev)
+        call('stj_loss_fwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(sums), _p(loss), _p(coef),
+             B, H, W, float(ogm_w), float(occ_w), float(fow), float(replica), int(use_warp), _st())
+        ctx.geo = (B, H, W, int(use_warp))
+        ctx.save_for_backward(logits, gt_obs, gt_occ, gt_flow, origin, coef)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, gt_obs, gt_occ, gt_flow, origin, coef = ctx.saved_tensors
+        B, H, W, use_warp = ctx.geo
+        up = dloss.contiguous().float()
+        dlogits = torch.empty_like(logits)
+        call('stj_loss_bwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(coef), _p(up), _p(dlogits), B, H, W,
+             use_warp, _st())
+        return (dlogits,) + (None,) * 10
+
+
+def auc_gate(gt_obs, gt_occ, gt_flow, origin, return_auc=False):
+    """res_k of loss.py:127-137 for the 8 waypoints -> f32[8] (no grad)."""
+    _req_cuda(gt_obs)
+    B, _, H, W, _ = gt_obs.shape
+    dev = gt_obs.device
+    hist = torch.empty(8 * 202, dtype=torch.int32, device=dev)
+    gate = torch.empty(8, dtype=torch.float32, device=dev)
+    auc = torch.empty(8, dtype=torch.float32, device=dev)
+    call('stj_loss_auc_gate', _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(hist), _p(gate), _p(auc), B, H, W, _st())
+    return (gate, auc) if return_auc else gate
+
+
+def ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, use_warp):
+    return _OgmFlowLoss.apply(logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, use_warp)

@@ -1,0 +1,119 @@
+"""End-to-end parity of the HIP path (STrajNet(...) call + OGMFlow_loss) against the CPU oracle.
+
+Gate (BASELINE.json north_star): outputs match the reference within 1e-3 abs in the f32-storage parity mode.
+The oracle is the in-repo restatement (PARITY UNPINNED by the reference itself: TensorFlow cannot run here).
+Reduced geometry 128x128 (the oracle finishes in seconds); cfg-256 is covered by the committed golden fixture.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG128 = dict(input_size=(128, 128), window_size=8, embed_dim=96, depths=[2, 2, 2], num_heads=[3, 6, 12])
+ABS_TOL_F32 = 1e-3          # north_star tolerance
+
+
+def _setup(cfg, B, dtype, large_ogm=False, fg_msa=True, fg=True, seed=0):
+    from strajnet_amd import STrajNet
+    from oracle import np_ref
+    w = np_ref.make_weights(cfg, seed, fg_msa=fg_msa, fg=fg, large_ogm=large_ogm)
+    x = np_ref.make_inputs(cfg, B, large_ogm=large_ogm)
+    model = STrajNet(cfg, fg_msa=fg_msa, fg=fg, large_ogm=large_ogm, dtype=dtype)
+    model.load_weights(w)
+    xt = {k: torch.as_tensor(v).cuda() for k, v in x.items()}
+    return model, w, x, xt
+
+
+def _fwd(model, xt):
+    return model(xt['ogm'], xt['map_img'], training=False, obs=xt['obs'], occ=xt['occ'], mapt=xt['mapt'], flow=xt['flow'])
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _lib(lib_built):
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize('fg_msa,fg', [(True, True), (False, False)])
+def test_forward_parity_f32(fg_msa, fg):
+    from oracle import np_ref
+    model, w, x, xt = _setup(CFG128, 2, torch.float32, fg_msa=fg_msa, fg=fg)
+    with torch.no_grad():
+        y = _fwd(model, xt).cpu().numpy()
+    ref = np_ref.strajnet_forward(w, CFG128, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'], fg_msa=fg_msa, fg=fg)
+    err = np.abs(y - ref).max()
+    print(f'fwd f32 max-abs err {err:.3e} (ref scale {np.abs(ref).max():.2f})')
+    assert y.shape == ref.shape == (2, 128, 128, 32)
+    assert err < ABS_TOL_F32
+
+
+def test_forward_parity_large_ogm_f32():
+    """cfg-512 plumbing (map pad + skip centre-crops, modules.py:582-587,614-622) at the reduced 256 -> 128 geometry."""
+    from oracle import np_ref
+    cfg = dict(CFG128, input_size=(256, 256))
+    model, w, x, xt = _setup(cfg, 1, torch.float32, large_ogm=True)
+    with torch.no_grad():
+        y = _fwd(model, xt).cpu().numpy()
+    ref = np_ref.strajnet_forward(w, cfg, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'], large_ogm=True)
+    err = np.abs(y - ref).max()
+    print(f'fwd f32 large_ogm max-abs err {err:.3e}')
+    assert err < ABS_TOL_F32
+
+
+def test_train_step_parity_f32():
+    """Loss dict + gradients of every trainable tensor vs torch autograd on the float64 restatement."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from oracle import torch_ref
+    model, w, x, xt = _setup(CFG128, 2, torch.float32)
+    model.zero_grad()
+    out = _fwd(model, xt)
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(128, 128, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+    d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+    total = sum(d.values())
+    total.backward()
+    pr = torch_ref.to_torch(w, torch.float64, requires_grad=True)
+    xr = torch_ref.to_torch(x, torch.float64)
+    yr = torch_ref.forward(pr, CFG128, xr['ogm'], xr['map_img'], xr['obs'], xr['occ'], xr['flow'])
+    dr = torch_ref.loss(yr, xr['gt_obs'], xr['gt_occ'], xr['gt_flow'], xr['origin_flow'], replica=1.0, use_gt=True)
+    sum(dr.values()).backward()
+    for k in dr:
+        assert abs(float(d[k]) - float(dr[k])) < 1e-4 * abs(float(dr[k])) + 1e-5, (k, float(d[k]), float(dr[k]))
+    bad = []
+    worst = 0.0
+    for n, p in model.params.items():
+        g, gr = p.grad.double().cpu(), pr[n].grad
+        scale = float(gr.abs().max())
+        e = float((g - gr).abs().max()) / (scale + 1e-12)
+        worst = max(worst, e)
+        if e > 2e-3:
+            bad.append((n, e, scale))
+    print(f'worst relative grad error {worst:.3e} over {len(model.params)} tensors')
+    assert not bad, bad[:10]
+
+
+def test_bf16_mode_error_report():
+    """bf16-storage throughput mode: measured error vs the f64 oracle (reported, bounded loosely)."""
+    from oracle import np_ref
+    model, w, x, xt = _setup(CFG128, 2, torch.bfloat16)
+    with torch.no_grad():
+        y = _fwd(model, xt).cpu().numpy()
+    ref = np_ref.strajnet_forward(w, CFG128, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'])
+    err = np.abs(y - ref).max()
+    rms = float(np.sqrt(((y - ref) ** 2).mean()))
+    print(f'fwd bf16 max-abs err {err:.3e}, rms {rms:.3e} (ref scale {np.abs(ref).max():.2f})')
+    assert np.isfinite(y).all()
+    assert rms < 0.1 and err < 1.0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from strajnet_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libstrajnet_hip.so')
+    with pytest.raises(_lib.StjError):
+        _lib.lib()
+
+
+def test_cpu_tensor_rejected():
+    from strajnet_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.gelu(torch.zeros(8))

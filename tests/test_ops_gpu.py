@@ -1,0 +1,363 @@
+"""Per-kernel parity: every HIP op (forward + backward) against a float64 PyTorch-CPU statement of the same op.
+
+Tolerances: f32 mode (exact-f32 MFMA, the parity mode) ~1e-4 relative-to-scale; bf16 mode ~3e-2.
+All calls go through the C-ABI library via strajnet_amd.ops.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return 2e-4 if dt == torch.float32 else 4e-2
+
+
+def rel_err(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((a - ref).abs().max() / (ref.abs().max() + 1e-12))
+
+
+def mk_param(shape, dt, scale=0.1, seed=0):
+    from strajnet_amd.ops import Param
+    g = torch.Generator().manual_seed(seed)
+    m = (torch.randn(shape, generator=g) * scale).cuda().requires_grad_(True)
+    grad = torch.zeros(shape, device='cuda')
+    m.grad = grad
+    c = m.detach() if dt == torch.float32 else m.detach().to(dt)
+    return Param('p', shape, m, c, grad)
+
+
+def rnd(shape, dt, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g) * scale
+    return x.to(dt).cuda()
+
+
+def ref_of(t):
+    """float64 CPU leaf holding exactly the values the kernel saw."""
+    return t.detach().double().cpu().requires_grad_(True)
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _lib(lib_built):
+    assert torch.cuda.is_available()
+    from strajnet_amd import _lib as L
+    L.lib()
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('M,K,N,act,use_res', [(300, 96, 288, 0, False), (1000, 384, 96, 0, True), (77, 5, 64, 2, False),
+                                               (64, 2, 384, 0, False), (513, 384, 126, 0, False), (4096, 96, 48, 2, False)])
+def test_linear(dt, M, K, N, act, use_res):
+    from strajnet_amd import ops
+    pw, pb = mk_param((K, N), dt, 0.2, 1), mk_param((N,), dt, 0.2, 2)
+    x = rnd((M, K), dt, 3).requires_grad_(True)
+    res = rnd((M, N), dt, 4).requires_grad_(True) if use_res else None
+    y = ops.linear(x, pw, pb, act, res)
+    xr, wr, br = ref_of(x), ref_of(pw.c), ref_of(pb.master)
+    yr = xr @ wr + br
+    if act == 2:
+        yr = F.elu(yr)
+    rr = None
+    if use_res:
+        rr = ref_of(res)
+        yr = yr + rr
+    assert rel_err(y, yr) < tol(dt)
+    g = rnd((M, N), dt, 5)
+    y.backward(g)
+    yr.backward(g.double().cpu())
+    assert rel_err(x.grad, xr.grad) < tol(dt)
+    assert rel_err(pw.grad, wr.grad) < tol(dt)
+    assert rel_err(pb.grad, br.grad) < tol(dt)
+    if use_res:
+        assert rel_err(res.grad, rr.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('rows,C,eps', [(1000, 96, 1e-5), (300, 384, 1e-3), (64, 128, 1e-3), (50, 768, 1e-5)])
+def test_layernorm(dt, rows, C, eps):
+    from strajnet_amd import ops
+    pg, pb = mk_param((C,), dt, 0.3, 1), mk_param((C,), dt, 0.3, 2)
+    with torch.no_grad():
+        pg.master.add_(1.0)
+    x = rnd((rows, C), dt, 3, 2.0).requires_grad_(True)
+    y = ops.layernorm(x, pg, pb, eps)
+    xr, gr, br = ref_of(x), ref_of(pg.master), ref_of(pb.master)
+    yr = F.layer_norm(xr, (C,), gr, br, eps)
+    assert rel_err(y, yr) < tol(dt)
+    g = rnd((rows, C), dt, 5)
+    y.backward(g)
+    yr.backward(g.double().cpu())
+    assert rel_err(x.grad, xr.grad) < tol(dt)
+    assert rel_err(pg.grad, gr.grad) < tol(dt)
+    assert rel_err(pb.grad, br.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_layernorm_merge_gather(dt):
+    from strajnet_amd import ops
+    B, res, C0 = 2, 16, 96
+    pg, pb = mk_param((4 * C0,), dt, 0.3, 1), mk_param((4 * C0,), dt, 0.3, 2)
+    x = rnd((B, res * res, C0), dt, 3).requires_grad_(True)
+    y = ops.layernorm(x, pg, pb, 1e-5, gather_res=res)
+    xr, gr, br = ref_of(x), ref_of(pg.master), ref_of(pb.master)
+    xx = xr.view(B, res, res, C0)
+    cat = torch.cat([xx[:, 0::2, 0::2], xx[:, 1::2, 0::2], xx[:, 0::2, 1::2], xx[:, 1::2, 1::2]], -1)   # modules.py:282-286
+    yr = F.layer_norm(cat.reshape(B, -1, 4 * C0), (4 * C0,), gr, br, 1e-5)
+    assert rel_err(y, yr) < tol(dt)
+    g = rnd(tuple(y.shape), dt, 5)
+    y.backward(g)
+    yr.backward(g.double().cpu())
+    assert rel_err(x.grad, xr.grad) < tol(dt)
+    assert rel_err(pg.grad, gr.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_unary(dt):
+    from strajnet_amd import ops
+    for fn, rf in ((ops.gelu, lambda t: F.gelu(t, approximate='tanh')), (ops.elu, F.elu),
+                   (lambda t: ops.tanh_scale(t, 8.0), lambda t: torch.tanh(t) * 8.0)):
+        x = rnd((1000, 37), dt, 1, 2.0).requires_grad_(True)
+        y = fn(x)
+        xr = ref_of(x)
+        yr = rf(xr)
+        assert rel_err(y, yr) < tol(dt)
+        g = rnd((1000, 37), dt, 2)
+        y.backward(g)
+        yr.backward(g.double().cpu())
+        assert rel_err(x.grad, xr.grad) < tol(dt)
+
+
+def _win_ref(qkv, table, B, res, heads, shift):
+    """float64 restatement with the index formulation of oracle/torch_ref.py."""
+    from oracle.torch_ref import _win_index, _region_id
+    C = heads * 32
+    N = 64
+    idx = _win_index(res, 8, shift, qkv.device)
+    nW = idx.shape[0]
+    t = qkv[:, idx].view(B, nW, N, 3, heads, 32)
+    q, k, v = t[..., 0, :, :], t[..., 1, :, :], t[..., 2, :, :]
+    att = torch.einsum('bwnhd,bwmhd->bwhnm', q * 32 ** -0.5, k)
+    c = torch.arange(8)
+    yy, xx = torch.meshgrid(c, c, indexing='ij')
+    yy, xx = yy.reshape(-1), xx.reshape(-1)
+    ridx = (yy[:, None] - yy[None, :] + 7) * 15 + (xx[:, None] - xx[None, :] + 7)
+    att = att + table[ridx].permute(2, 0, 1)
+    if shift > 0:
+        lab = _region_id(res, 8, shift, qkv.device)
+        labw = lab.view(res // 8, 8, res // 8, 8).permute(0, 2, 1, 3).reshape(nW, N)
+        att = att + ((labw[:, :, None] != labw[:, None, :]).double() * -100.0)[None, :, None]
+    o = torch.einsum('bwhnm,bwmhd->bwnhd', att.softmax(-1), v).reshape(B, nW * N, C)
+    return torch.zeros(B, res * res, C, dtype=torch.float64).index_copy(1, idx.reshape(-1), o)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('res,heads,shift', [(16, 3, 0), (16, 3, 4), (32, 6, 4), (8, 12, 0)])
+def test_win_attn(dt, res, heads, shift):
+    from strajnet_amd import ops
+    B, C = 2, heads * 32
+    pt = mk_param((225, heads), dt, 0.5, 1)
+    qkv = rnd((B, res * res, 3 * C), dt, 2).requires_grad_(True)
+    out = ops.win_attn(qkv, pt, B, res, heads, shift)
+    qr, tr = ref_of(qkv), ref_of(pt.master)
+    outr = _win_ref(qr, tr, B, res, heads, shift)
+    assert rel_err(out, outr) < tol(dt)
+    g = rnd(tuple(out.shape), dt, 3)
+    out.backward(g)
+    outr.backward(g.double().cpu())
+    assert rel_err(qkv.grad, qr.grad) < tol(dt)
+    assert rel_err(pt.grad, tr.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('Bt,Nq,Nk,H,d,masks,use_bias', [(6, 11, 11, 4, 64, 'qk', False), (2, 64, 64, 6, 64, 'qk', False),
+                                                        (3, 256, 64, 3, 42, 'k', False), (2, 64, 64, 8, 48, '', True)])
+def test_mha_core(dt, Bt, Nq, Nk, H, d, masks, use_bias):
+    from strajnet_amd import ops
+    q = rnd((Bt, Nq, H * d), dt, 1).requires_grad_(True)
+    k = rnd((Bt, Nk, H * d), dt, 2).requires_grad_(True)
+    v = rnd((Bt, Nk, H * d), dt, 3).requires_grad_(True)
+    g = torch.Generator().manual_seed(4)
+    qv = (torch.rand((Bt, Nq), generator=g) > 0.3).int().cuda() if 'q' in masks else None
+    kv = (torch.rand((Bt, Nk), generator=g) > 0.3).int().cuda() if 'k' in masks else None
+    if kv is not None:
+        kv[0] = 0                                   # one fully masked batch entry -> uniform softmax (tfa -1e10 semantics)
+    bias = (torch.randn((Bt, H, Nq, Nk), generator=g)).cuda().requires_grad_(True) if use_bias else None
+    scale = 1.0 / math.sqrt(d)
+    o = ops.mha_core(q, k, v, H, d, scale, qvalid=qv, kvalid=kv, bias=bias)
+    qr, kr, vr = ref_of(q), ref_of(k), ref_of(v)
+    lg = torch.einsum('bnhd,bmhd->bhnm', qr.view(Bt, Nq, H, d), kr.view(Bt, Nk, H, d)) * scale
+    br = None
+    if use_bias:
+        br = ref_of(bias)
+        lg = lg + br
+    m = torch.ones(Bt, Nq, Nk, dtype=torch.bool)
+    if qv is not None:
+        m &= qv.cpu().bool()[:, :, None]
+    if kv is not None:
+        m &= kv.cpu().bool()[:, None, :]
+    lg = torch.where(m[:, None], lg, torch.full_like(lg, -10e9))
+    orf = torch.einsum('bhnm,bmhd->bnhd', lg.softmax(-1), vr.view(Bt, Nk, H, d)).reshape(Bt, Nq, H * d)
+    assert rel_err(o, orf) < tol(dt)
+    go = rnd(tuple(o.shape), dt, 5)
+    o.backward(go)
+    orf.backward(go.double().cpu())
+    assert rel_err(q.grad, qr.grad) < tol(dt)
+    assert rel_err(k.grad, kr.grad) < tol(dt)
+    assert rel_err(v.grad, vr.grad) < tol(dt)
+    if use_bias:
+        assert rel_err(bias.grad, br.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_fg_bias(dt):
+    from strajnet_amd import ops
+    from oracle.torch_ref import _sample
+    B, G, Hh = 2, 8, 8
+    HW = Hh * Hh
+    pt = mk_param((2 * Hh - 1, 2 * Hh - 1, G), dt, 0.5, 1)
+    off = (rnd((B, G, HW, 2), dt, 2, 3.0)).requires_grad_(True)
+    bias = ops.fg_bias(off, pt, Hh, Hh)
+    offr, tr = ref_of(off), ref_of(pt.master)
+    ii, jj = torch.meshgrid(torch.arange(Hh, dtype=torch.float64), torch.arange(Hh, dtype=torch.float64), indexing='ij')
+    ref = torch.stack((jj, ii), -1).view(1, 1, HW, 2)
+    pos = offr + ref
+    disp = ref.view(1, 1, HW, 1, 2) - pos.view(B, G, 1, HW, 2)
+    warp = torch.stack((disp[..., 1], disp[..., 0]), -1)
+    tab = tr.permute(2, 0, 1)[None].expand(B, -1, -1, -1).reshape(B * G, 2 * Hh - 1, 2 * Hh - 1, 1)
+    br = _sample(tab, warp.reshape(B * G, HW, HW, 2)).view(B, G, HW, HW)
+    assert rel_err(bias, br) < (1e-4 if dt == torch.float32 else 1e-4)
+    g = torch.randn(B, G, HW, HW, generator=torch.Generator().manual_seed(3))
+    bias.backward(g.cuda())
+    br.backward(g.double())
+    assert rel_err(pt.grad, tr.grad) < tol(dt)
+    assert rel_err(off.grad, offr.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('F_,Hi,Cin,Cout', [(2, 8, 384, 192), (2, 16, 192, 128), (1, 32, 128, 96), (1, 32, 96, 48), (3, 16, 96, 48)])
+def test_upconv(dt, F_, Hi, Cin, Cout):
+    from strajnet_amd import ops
+    pw, pb = mk_param((3, 3, Cin, Cout), dt, 0.05, 1), mk_param((Cout,), dt, 0.1, 2)
+    x = rnd((F_, Hi, Hi, Cin), dt, 3).requires_grad_(True)
+    y = ops.upconv(x, pw, pb)
+    xr, wr, br = ref_of(x), ref_of(pw.master), ref_of(pb.master)
+    up = F.interpolate(xr.permute(0, 3, 1, 2), scale_factor=2, mode='nearest')
+    yr = F.elu(F.conv2d(up, wr.permute(3, 2, 0, 1), br, padding=1)).permute(0, 2, 3, 1)
+    assert rel_err(y, yr) < tol(dt)
+    g = rnd(tuple(y.shape), dt, 5)
+    y.backward(g)
+    yr.backward(g.double().cpu())
+    assert rel_err(x.grad, xr.grad) < tol(dt)
+    assert rel_err(pw.grad, wr.grad) < tol(dt)
+    assert rel_err(pb.grad, br.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_outconv_pair(dt):
+    from strajnet_amd import ops
+    B, Tn, H, C = 2, 8, 32, 48
+    ps = [mk_param((3, 3, C, 2), dt, 0.1, 1), mk_param((2,), dt, 0.1, 2), mk_param((3, 3, C, 2), dt, 0.1, 3), mk_param((2,), dt, 0.1, 4)]
+    xo = rnd((B * Tn, H, H, C), dt, 5).requires_grad_(True)
+    xf = rnd((B * Tn, H, H, C), dt, 6).requires_grad_(True)
+    out = ops.outconv_pair(xo, xf, *ps, B, Tn)
+    refs = [ref_of(p.master) for p in ps]
+    xor_, xfr = ref_of(xo), ref_of(xf)
+
+    def cv(t, w, b):
+        return F.conv2d(t.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, padding=1).permute(0, 2, 3, 1)
+    y = torch.cat([cv(xor_, refs[0], refs[1]), cv(xfr, refs[2], refs[3])], -1).view(B, Tn, H, H, 4)
+    outr = y.permute(0, 2, 3, 1, 4).reshape(B, H, H, 4 * Tn)                  # modules.py:838
+    assert rel_err(out, outr) < tol(dt)
+    g = torch.randn(B, H, H, 4 * Tn, generator=torch.Generator().manual_seed(7))
+    out.backward(g.cuda())
+    outr.backward(g.double())
+    assert rel_err(xo.grad, xor_.grad) < tol(dt)
+    assert rel_err(xf.grad, xfr.grad) < tol(dt)
+    for p, r in zip(ps, refs):
+        assert rel_err(p.grad, r.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_grouped_conv3(dt):
+    from strajnet_amd import ops
+    N, H, G, Cg = 2, 16, 8, 48
+    pw, pb = mk_param((3, 3, Cg, G * Cg), dt, 0.05, 1), mk_param((G * Cg,), dt, 0.1, 2)
+    x = rnd((N, H, H, G * Cg), dt, 3).requires_grad_(True)
+    y = ops.grouped_conv3(x, pw, pb, G)
+    xr, wr, br = ref_of(x), ref_of(pw.c), ref_of(pb.master)
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr.permute(3, 2, 0, 1), br, padding=1, groups=G).permute(0, 2, 3, 1)
+    assert rel_err(y, yr) < tol(dt)
+    g = rnd(tuple(y.shape), dt, 5)
+    y.backward(g)
+    yr.backward(g.double().cpu())
+    assert rel_err(x.grad, xr.grad) < tol(dt)
+    assert rel_err(pw.grad, wr.grad) < tol(dt)
+    assert rel_err(pb.grad, br.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_maxpool(dt):
+    from strajnet_amd import ops
+    x = rnd((20, 11, 320), dt, 1).requires_grad_(True)
+    y = ops.maxpool_time(x)
+    xr = ref_of(x)
+    yr = xr.amax(-2)
+    assert rel_err(y, yr) < 1e-6
+    g = rnd((20, 320), dt, 2)
+    y.backward(g)
+    yr.backward(g.double().cpu())
+    assert rel_err(x.grad, xr.grad) < 1e-6
+
+
+def test_patch_im2col():
+    from strajnet_amd import ops
+    B, H = 2, 32
+    ogm = torch.randn(B, H, H, 11, 2).cuda()
+    cols = ops.patch_im2col(ogm, 11, 2, 22, torch.float32)
+    w = torch.randn(4, 4, 11, 96, dtype=torch.float64)
+    ref = F.conv2d(ogm[..., 0].double().cpu().permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), stride=4).permute(0, 2, 3, 1).reshape(-1, 96)
+    got = cols.double().cpu() @ w.reshape(-1, 96)
+    assert rel_err(got, ref) < 1e-6
+
+
+def test_loss_and_gate():
+    """Fused loss (fwd + d/dlogits) and the AUC gate vs the oracle restatements."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from strajnet_amd import ops
+    from oracle import np_ref, torch_ref
+    cfg = dict(input_size=(128, 128), window_size=8, embed_dim=96, depths=[2, 2, 2], num_heads=[3, 6, 12])
+    x = np_ref.make_inputs(cfg, 2)
+    Hg = x['gt_obs'].shape[2]
+    rng = np.random.default_rng(0)
+    logits = rng.normal(0, 2, (2, Hg, Hg, 32)).astype(np.float32)
+    x['gt_obs'][:, 3] = 0
+    x['gt_occ'][:, 3] = 0                        # waypoint 3: no positives -> AUC 0 -> gate 0 (loss.py:137)
+    gt = {k: torch.as_tensor(x[k]).cuda() for k in ('gt_obs', 'gt_occ', 'gt_flow', 'origin_flow')}
+    lt = torch.as_tensor(logits).cuda().requires_grad_(True)
+    for use_gt in (True, False):
+        lt.grad = None
+        loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(Hg, Hg, 8), replica=2.0, use_focal_loss=False, use_gt=use_gt)
+        d = loss_fn(get_pred_waypoint_logits(lt), warpped_gt(gt['gt_obs'], gt['gt_occ'], gt['gt_flow'], gt['origin_flow']), None)
+        ref, gates = np_ref.ogm_flow_loss(logits, x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow'], replica=2.0,
+                                          use_gt=use_gt, return_gates=True)
+        if use_gt:
+            assert gates[3] == 0.0 and sum(gates) == 7.0
+            g, auc = ops.auc_gate(gt['gt_obs'], gt['gt_occ'], gt['gt_flow'], gt['origin_flow'], return_auc=True)
+            assert g.cpu().tolist() == gates
+        for k in ref:
+            assert abs(float(d[k]) - float(ref[k])) <= 2e-5 * abs(float(ref[k])) + 1e-6, (k, float(d[k]), float(ref[k]))
+        sum(d.values()).backward()
+        lr = torch.as_tensor(logits).double().requires_grad_(True)
+        gtr = {k: torch.as_tensor(x[k]).double() for k in gt}
+        dr = torch_ref.loss(lr, gtr['gt_obs'], gtr['gt_occ'], gtr['gt_flow'], gtr['origin_flow'], replica=2.0, use_gt=use_gt)
+        sum(dr.values()).backward()
+        assert rel_err(lt.grad, lr.grad) < 1e-4
