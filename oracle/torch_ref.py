@@ -198,7 +198,9 @@ def _mha(q_in, k_in, p, name, mask):
     v = torch.einsum('...mi,hio->...hmo', k_in, Wv)
     lg = q @ k.transpose(-1, -2)
     if mask is not None:
-        lg = lg.masked_fill(mask.unsqueeze(-3) == 0, -10e9)     # f32 reference: x + (-1e10) == -1e10
+        # reference: logits += -10e9*(1-mask) in f32, where x + (-1e10) == -1e10 exactly (|x| < 512) but the
+        # gradient of the ADD still passes through to x (matters only for fully masked rows).
+        lg = torch.where(mask.unsqueeze(-3) != 0, lg, lg + (-10e9 - lg).detach())
     o = lg.softmax(-1) @ v
     return torch.einsum('...hni,hio->...no', o, Wo) + bo
 

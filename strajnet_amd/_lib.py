@@ -21,7 +21,7 @@ SIGNATURES = {
     'stj_unary_fwd': [vp, vp, cl, ci, cf, ci, vp],
     'stj_unary_bwd': [vp, vp, vp, cl, ci, cf, ci, vp],
     'stj_maxpool_fwd': [vp, vp, vp, cl, ci, ci, ci, vp],
-    'stj_maxpool_bwd': [vp, vp, vp, cl, ci, ci, ci, vp],
+    'stj_maxpool_bwd': [vp, vp, vp, vp, cl, ci, ci, ci, vp],
     'stj_layernorm_fwd': [vp, vp, vp, vp, vp, vp, cl, ci, cf, ci, ci, ci, vp],
     'stj_layernorm_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, ci, vp],
     'stj_win_attn_fwd': [vp, vp, vp, ci, ci, ci, ci, ci, vp],

@@ -172,8 +172,9 @@ __device__ __forceinline__ Bil bil_setup(float qx, float qy, int Hp, int Wp) {
   float fy = fminf(fmaxf(0.f, floorf(qy)), (float)(Hp - 2));
   float fx = fminf(fmaxf(0.f, floorf(qx)), (float)(Wp - 2));
   float ay = qy - fy, ax = qx - fx;
-  r.gy = ay > 0.f && ay < 1.f;
-  r.gx = ax > 0.f && ax < 1.f;
+  // TF clip gradients: max(0,a) passes a's gradient only for a > 0 (ties go to the constant); min(.,1) passes it for a <= 1
+  r.gy = ay > 0.f && ay <= 1.f;
+  r.gx = ax > 0.f && ax <= 1.f;
   r.ay = fminf(fmaxf(ay, 0.f), 1.f);
   r.ax = fminf(fmaxf(ax, 0.f), 1.f);
   r.y0 = (int)fy; r.x0 = (int)fx;

@@ -116,11 +116,16 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* y, int*
     idx[i] = bi;
   }
 }
+// TF reduce_max gradient: split evenly among ties (indicators / num_selected).
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dy, const int* idx, T* dx, long long outer, int Tn, int C) {
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < outer * Tn * C; i += gridDim.x * 256ll) {
-    int c = (int)(i % C); long long ot = i / C; int t = (int)(ot % Tn); long long o = ot / Tn;
-    stf(dx + i, idx[o * C + c] == t ? ldf(dy + o * C + c) : 0.f);
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dy, const T* x, const T* y, T* dx, long long outer, int Tn, int C) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < outer * C; i += gridDim.x * 256ll) {
+    long long o = i / C; int c = (int)(i % C);
+    const float m = ldf(y + i), g = ldf(dy + i);
+    int cnt = 0;
+    for (int t = 0; t < Tn; ++t) cnt += ldf(x + (o * Tn + t) * C + c) == m ? 1 : 0;
+    const float gg = g / (float)(cnt > 0 ? cnt : 1);
+    for (int t = 0; t < Tn; ++t) stf(dx + (o * Tn + t) * C + c, ldf(x + (o * Tn + t) * C + c) == m ? gg : 0.f);
   }
 }
 extern "C" int stj_maxpool_fwd(const void* x, void* y, int* idx, long long outer, int Tn, int C, int dtype, hipStream_t stream) {
@@ -130,10 +135,10 @@ extern "C" int stj_maxpool_fwd(const void* x, void* y, int* idx, long long outer
   else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, idx, outer, Tn, C);
   return stj_check_launch("stj_maxpool_fwd");
 }
-extern "C" int stj_maxpool_bwd(const void* dy, const int* idx, void* dx, long long outer, int Tn, int C, int dtype, hipStream_t stream) {
+extern "C" int stj_maxpool_bwd(const void* dy, const void* x, const void* y, void* dx, long long outer, int Tn, int C, int dtype, hipStream_t stream) {
   if (outer <= 0) return STJ_OK;
-  int g = ew_grid(outer * Tn * C);
-  if (dtype == STJ_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, idx, (bf16*)dx, outer, Tn, C);
-  else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)dy, idx, (float*)dx, outer, Tn, C);
+  int g = ew_grid(outer * C);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, (const bf16*)y, (bf16*)dx, outer, Tn, C);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)dy, (const float*)x, (const float*)y, (float*)dx, outer, Tn, C);
   return stj_check_launch("stj_maxpool_bwd");
 }

@@ -409,16 +409,16 @@ class _MaxPool(torch.autograd.Function):
         idx = torch.empty(outer * C, dtype=torch.int32, device=x.device)
         call('stj_maxpool_fwd', _p(x), _p(y), _p(idx), outer, Tn, C, _dt(x), _st())
         ctx.geo = (outer, Tn, C, x.shape)
-        ctx.save_for_backward(idx)
+        ctx.save_for_backward(x, y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (idx,) = ctx.saved_tensors
+        x, y = ctx.saved_tensors
         outer, Tn, C, shape = ctx.geo
         dy = dy.contiguous()
         dx = torch.empty(shape, dtype=dy.dtype, device=dy.device)
-        call('stj_maxpool_bwd', _p(dy), _p(idx), _p(dx), outer, Tn, C, _dt(dy), _st())
+        call('stj_maxpool_bwd', _p(dy), _p(x), _p(y), _p(dx), outer, Tn, C, _dt(dy), _st())
         return dx
 
 

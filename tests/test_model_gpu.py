@@ -4,11 +4,24 @@ Gate (BASELINE.json north_star): outputs match the reference within 1e-3 abs in 
 The oracle is the in-repo restatement (PARITY UNPINNED by the reference itself: TensorFlow cannot run here).
 Reduced geometry 128x128 (the oracle finishes in seconds); cfg-256 is covered by the committed golden fixture.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+def _report(msg):
+    print(msg)
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'parity_report.txt'), 'a') as f:
+            f.write(msg + '\n')
+    except OSError:
+        pass
+
 
 CFG128 = dict(input_size=(128, 128), window_size=8, embed_dim=96, depths=[2, 2, 2], num_heads=[3, 6, 12])
 ABS_TOL_F32 = 1e-3          # north_star tolerance
@@ -42,7 +55,7 @@ def test_forward_parity_f32(fg_msa, fg):
         y = _fwd(model, xt).cpu().numpy()
     ref = np_ref.strajnet_forward(w, CFG128, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'], fg_msa=fg_msa, fg=fg)
     err = np.abs(y - ref).max()
-    print(f'fwd f32 max-abs err {err:.3e} (ref scale {np.abs(ref).max():.2f})')
+    _report(f'fwd f32 (fg_msa={fg_msa}, fg={fg}) 128x128 B=2: max-abs err {err:.3e} (ref scale {np.abs(ref).max():.2f})')
     assert y.shape == ref.shape == (2, 128, 128, 32)
     assert err < ABS_TOL_F32
 
@@ -56,7 +69,7 @@ def test_forward_parity_large_ogm_f32():
         y = _fwd(model, xt).cpu().numpy()
     ref = np_ref.strajnet_forward(w, cfg, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'], large_ogm=True)
     err = np.abs(y - ref).max()
-    print(f'fwd f32 large_ogm max-abs err {err:.3e}')
+    _report(f'fwd f32 large_ogm 256->128 B=1: max-abs err {err:.3e}')
     assert err < ABS_TOL_F32
 
 
@@ -80,14 +93,18 @@ def test_train_step_parity_f32():
         assert abs(float(d[k]) - float(dr[k])) < 1e-4 * abs(float(dr[k])) + 1e-5, (k, float(d[k]), float(dr[k]))
     bad = []
     worst = 0.0
+    gmax = max(float(pr[n].grad.abs().max()) for n in model.params)
     for n, p in model.params.items():
         g, gr = p.grad.double().cpu(), pr[n].grad
         scale = float(gr.abs().max())
-        e = float((g - gr).abs().max()) / (scale + 1e-12)
+        # tensors whose true gradient is identically zero (e.g. a key bias under softmax) only carry f32 noise:
+        # floor the scale at 1e-6 of the largest gradient in the model
+        e = float((g - gr).abs().max()) / (scale + 1e-6 * gmax)
         worst = max(worst, e)
         if e > 2e-3:
             bad.append((n, e, scale))
-    print(f'worst relative grad error {worst:.3e} over {len(model.params)} tensors')
+    _report(f'train step f32 128x128 B=2: losses ' + ', '.join(f'{k}={float(d[k]):.6f}' for k in d) +
+            f'; worst relative grad error {worst:.3e} over {len(model.params)} tensors')
     assert not bad, bad[:10]
 
 
@@ -100,7 +117,7 @@ def test_bf16_mode_error_report():
     ref = np_ref.strajnet_forward(w, CFG128, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'])
     err = np.abs(y - ref).max()
     rms = float(np.sqrt(((y - ref) ** 2).mean()))
-    print(f'fwd bf16 max-abs err {err:.3e}, rms {rms:.3e} (ref scale {np.abs(ref).max():.2f})')
+    _report(f'fwd bf16 128x128 B=2: max-abs err {err:.3e}, rms {rms:.3e} (ref scale {np.abs(ref).max():.2f})')
     assert np.isfinite(y).all()
     assert rms < 0.1 and err < 1.0
 
