@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py -- scenes/s of the STrajNet train step (fwd + OGMFlow loss + bwd [+ RCCL grad all-reduce]) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): batch 8 per GPU, bf16 storage / f32 accumulate, cfg-256
+(input 256x256x11, window 8, embed 96, depths [2,2,2], heads [3,6,12], fg_msa=True, fg=True, large_ogm=False),
+8 waypoints, observed + occluded + flow heads, synthetic inputs of SURVEY.md 8(d), random-init weights.
+A "step" = model forward, OGMFlow_loss (use_gt AUC gate + flow-warp term), backward into the flat f32 gradient
+buffer, and -- for N>1 -- one RCCL SUM all-reduce of that buffer (loss pre-scaled by 1/N via replica=N, exactly as
+loss.py:200 + MirroredStrategy do).  The optimizer is not part of the metric ("next" item 8f-1).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_GFLOP_FWD_PER_SCENE = 200.7      # SURVEY.md App. E (direct form, 2/MAC)
+ALGO_GFLOP_STEP_PER_SCENE = 602.0     # fwd + dgrad + wgrad
+PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+CFG256 = dict(input_size=(256, 256), window_size=8, embed_dim=96, depths=[2, 2, 2], num_heads=[3, 6, 12])
+
+
+def synth_batch(B, seed, device):
+    """Synthetic scene batch, generated with torch on the host then moved to HBM."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    H = 256
+    ogm = (torch.rand((B, H, H, 11, 2), generator=g) < 0.02).float()
+    flow = torch.randn((B, H, H, 2), generator=g) * 2.0 * ogm[..., 10, 0:1]
+    map_img = torch.randint(-128, 128, (B, H, H, 3), generator=g).float() / 256.0
+
+    def agents(n):
+        a = torch.zeros((B, n, 11, 8))
+        a[..., 0:2] = torch.rand((B, n, 11, 2), generator=g) * 80 - 40
+        a[..., 2:4] = torch.randn((B, n, 11, 2), generator=g) * 5
+        a[..., 4] = torch.rand((B, n, 11), generator=g) * 6.283 - 3.1416
+        ty = torch.randint(0, 3, (B, n), generator=g)
+        for k in range(3):
+            a[..., 5 + k] = (ty == k).float()[..., None]
+        a[:, n - n // 4:] = 0
+        return a
+    obs, occ = agents(48), agents(16)
+    gt_obs = (torch.rand((B, 8, H, H, 1), generator=g) < 0.02).float()
+    gt_occ = (torch.rand((B, 8, H, H, 1), generator=g) < 0.005).float()
+    either = torch.maximum(gt_obs, gt_occ)
+    gt_flow = torch.randn((B, 8, H, H, 2), generator=g) * 3 * either
+    origin = torch.rand((B, 8, H, H, 1), generator=g) * (torch.rand((B, 8, H, H, 1), generator=g) < 0.03).float()
+    origin = torch.maximum(origin, 0.9 * either * (torch.rand((B, 8, H, H, 1), generator=g) < 0.5).float())
+    d = dict(ogm=ogm, flow=flow, map_img=map_img, obs=obs, occ=occ, mapt=torch.zeros((B, 256, 10, 7)),
+             gt_obs=gt_obs, gt_occ=gt_occ, gt_flow=gt_flow, origin_flow=origin)
+    return {k: v.to(device) for k, v in d.items()}
+
+
+def cpu_baseline(max_seconds=30.0):
+    """The oracle's PyTorch-CPU restatement ("port", NOT the TensorFlow reference) timed on this box's host cores:
+    B=1 cfg-256 f32 forward + loss + backward, 1 warm-up + up to 2 timed steps."""
+    import numpy as np
+    import torch
+    from oracle import np_ref, torch_ref
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))          # more threads than this only oversubscribes the small ops of the port
+    torch.set_num_threads(cores)
+    w = np_ref.make_weights(CFG256, 0, mode='reference')
+    x = np_ref.make_inputs(CFG256, 1)
+    p = torch_ref.to_torch(w, torch.float32, requires_grad=True)
+    xt = torch_ref.to_torch(x, torch.float32)
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        y = torch_ref.forward(p, CFG256, xt['ogm'], xt['map_img'], xt['obs'], xt['occ'], xt['flow'])
+        d = torch_ref.loss(y, xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow'])
+        sum(d.values()).backward()
+    t0 = time.time()
+    step()
+    warm = time.time() - t0
+    times = []
+    while len(times) < 2 and (time.time() - t0) < max_seconds:
+        t1 = time.time()
+        step()
+        times.append(time.time() - t1)
+    if not times:
+        times = [warm]
+    sec = float(np.median(times))
+    return {'value': round(1.0 / sec, 4), 'unit': 'scenes/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'B=1 cfg-256 f32 fwd+loss+bwd, oracle/torch_ref.py on CPU (not TensorFlow), 1 warm-up + {len(times)} timed steps, '
+                      f'{sec:.2f} s/step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='scenes per GPU')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from strajnet_amd import STrajNet, OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from strajnet_amd import ops
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        print('bench.py: --gpus N>1 must be launched through torch.distributed.run', file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    model = STrajNet(CFG256, fg_msa=True, fg=True, large_ogm=False, dtype=dtype, device=dev, seed=0)
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(256, 256, 8), ogm_weight=1000.0, occ_weight=1000.0, flow_weight=1.0,
+                           replica=float(world), flow_origin_weight=1000.0, no_use_warp=False, use_pred=False,
+                           use_focal_loss=False, use_gt=True)
+    B = args.batch
+    x = synth_batch(B, 1234 + rank, dev)
+
+    def step():
+        model.zero_grad()
+        out = model(x['ogm'], x['map_img'], training=True, obs=x['obs'], occ=x['occ'], mapt=x['mapt'], flow=x['flow'])
+        d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
+        total = d['observed_xe'] + d['occluded_xe'] + d['flow'] + d['flow_warp_xe']
+        total.backward()
+        if world > 1:
+            dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
+        return total
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not args.no_kernel_timing:
+        ops.prof_enable()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    dt_s = time.perf_counter() - t0
+    prof = ops.prof_disable() if not args.no_kernel_timing else None
+    if world > 1:
+        t = torch.tensor([dt_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_s = float(t.item())
+    loss_val = float(last.detach())
+
+    if rank == 0:
+        scenes = B * world * args.steps
+        value = scenes / dt_s
+        peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+        roof = None
+        kern = {}
+        if prof:
+            for k, evs in prof.items():
+                ms = [a.elapsed_time(b) for a, b, _ in evs]
+                kern[k] = (sum(ms) / len(ms), evs[0][2], sum(ms))
+            dom = max(kern, key=lambda k: kern[k][2])
+            avg_ms, flops, _ = kern[dom]
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(dom)
+                except Exception:
+                    traffic = None
+            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak, 4), 'traffic': traffic, 'avg_launch_ms': round(avg_ms, 4),
+                    'algorithmic_gflop_per_launch': round(flops / 1e9, 2),
+                    'end_to_end_frac': round(value * ALGO_GFLOP_STEP_PER_SCENE / 1e3 / (peak * world), 4)}
+        out = {
+            'metric': 'scenes/sec (fwd+bwd, 256x256 grids)', 'value': round(value, 3), 'unit': 'scenes/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt_s / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'STrajNet cfg-256 train step (fwd+OGMFlow_loss+bwd{"+RCCL grad all-reduce" if world > 1 else ""}), '
+                                   f'batch {B}/GPU, 8 waypoints, obs+occ+flow heads, fg_msa+fg, random-init weights',
+                       'global_batch': B * world, 'grid': '256x256x11', 'parallelism': f'dp{world}',
+                       'optimizer_in_step': False, 'algorithmic_gflop_per_scene_step': ALGO_GFLOP_STEP_PER_SCENE},
+            'loss': round(loss_val, 4),
+            'roofline': roof,
+        }
+        if prof:
+            out['kernel_ms'] = {k: round(v[0], 4) for k, v in sorted(kern.items())}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out['cpu_baseline'] = cpu_baseline()
+            except Exception as e:      # the CPU port is a reported extra, never the product path
+                out['cpu_baseline'] = {'value': None, 'unit': 'scenes/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e}'}
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

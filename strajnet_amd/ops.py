@@ -39,6 +39,38 @@ def _req_cuda(*ts):
                                'There is no CPU fallback.')
 
 
+# ---- optional per-kernel timing (bench.py's live roofline measurement): HIP events recorded on the launch stream
+_PROF = None
+
+
+def prof_enable():
+    global _PROF
+    _PROF = {}
+
+
+def prof_disable():
+    global _PROF
+    p, _PROF = _PROF, None
+    return p
+
+
+class _timed:
+    def __init__(self, key, flops):
+        self.key, self.flops = key, flops
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+
+    def __exit__(self, *a):
+        if _PROF is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream())
+            _PROF.setdefault(self.key, []).append((self.e0, e1, self.flops))
+        return False
+
+
 class Param:
     """One trainable tensor: f32 master view, compute-dtype view, f32 gradient view (all slices of flat buffers)."""
     __slots__ = ('name', 'shape', 'master', 'c', 'grad')
@@ -501,7 +533,9 @@ class _UpConv(torch.autograd.Function):
         wd = torch.empty((16, Cin, Cout), dtype=x.dtype, device=x.device)
         call('stj_upconv_prep', _p(pw.master), _p(wf), _p(wd), Cin, Cout, dt, _st())
         y = torch.empty((F_, 2 * Hi, 2 * Wi, Cout), dtype=x.dtype, device=x.device)
-        call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
+        flops = 2.0 * 9 * Cin * Cout * 4 * Hi * Wi * F_          # algorithmic (direct 9-tap form on the upsampled map)
+        with _timed(f'upconv_fwd[{Hi}x{Wi},{Cin}->{Cout}]', flops):
+            call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
         ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
         ctx.save_for_backward(x, y, wd)
         return y
@@ -514,12 +548,15 @@ class _UpConv(torch.autograd.Function):
         dy = dy.contiguous()
         dpre = torch.empty_like(dy)
         call('stj_unary_bwd', _p(dy), _p(y), _p(dpre), dy.numel(), U_ELU, 0.0, dt, _st())
+        flops = 2.0 * 9 * Cin * Cout * 4 * Hi * Wi * F_
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), F_, Hi, Wi, Cin, Cout, dt, _st())
+            with _timed(f'upconv_dgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
+                call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), F_, Hi, Wi, Cin, Cout, dt, _st())
         dweff = torch.zeros((16, Cout, Cin), dtype=torch.float32, device=x.device)
-        call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), F_, Hi, Wi, Cin, Cout, dt, _st())
+        with _timed(f'upconv_wgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
+            call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), F_, Hi, Wi, Cin, Cout, dt, _st())
         call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
         call('stj_colsum', _p(dpre), _p(ctx.pb.grad), F_ * 4 * Hi * Wi, Cout, Cout, dt, _st())
         return dx, None, None, None, None
