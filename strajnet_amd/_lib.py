@@ -13,7 +13,7 @@ vp, ci, cl, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_floa
 # name -> argument ctypes (return type is always int except where noted)
 SIGNATURES = {
     'stj_abi_version': [],
-    'stj_gemm': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci,
+    'stj_gemm': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci,
                  cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl,
                  ci, cf, ci, ci, ci, ci, vp],
     'stj_colsum': [vp, vp, ci, ci, cl, ci, vp],
@@ -22,8 +22,8 @@ SIGNATURES = {
     'stj_unary_bwd': [vp, vp, vp, cl, ci, cf, ci, vp],
     'stj_maxpool_fwd': [vp, vp, vp, cl, ci, ci, ci, vp],
     'stj_maxpool_bwd': [vp, vp, vp, vp, cl, ci, ci, ci, vp],
-    'stj_layernorm_fwd': [vp, vp, vp, vp, vp, vp, cl, ci, cf, ci, ci, ci, vp],
-    'stj_layernorm_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, ci, vp],
+    'stj_layernorm_fwd': [vp, vp, vp, vp, vp, vp, cl, ci, cf, ci, ci, cl, ci, cl, ci, vp],
+    'stj_layernorm_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, cl, ci, cl, ci, vp],
     'stj_win_attn_fwd': [vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_win_attn_bwd': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_softmax_fwd': [vp, vp, vp, vp, vp, cl, ci, ci, ci, ci, vp],
@@ -34,7 +34,7 @@ SIGNATURES = {
     'stj_upconv_fold': [vp, vp, ci, ci, vp],
     'stj_upconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     'stj_upconv_dgrad': [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
-    'stj_upconv_wgrad': [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    'stj_upconv_wgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
     'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
     'stj_im2col_patch': [vp, vp, ci, ci, ci, ci, cl, ci, ci, vp],

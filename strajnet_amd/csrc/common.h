@@ -16,12 +16,14 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 __device__ __forceinline__ float bf2f(uint16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                            // RNE
-  return (uint16_t)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two f32 -> packed bf16 pair (lo = a, hi = b), round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
@@ -54,10 +56,7 @@ template <> __device__ __forceinline__ void st16<float>(float* p, const float* i
   *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
 }
 template <> __device__ __forceinline__ void st16<bf16>(bf16* p, const float* in) {
-  uint32_t w[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(in[2 * i]) | ((uint32_t)f2bf(in[2 * i + 1]) << 16);
-  *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(in[0], in[1]), pack2bf(in[2], in[3]), pack2bf(in[4], in[5]), pack2bf(in[6], in[7]));
 }
 
 // ---- activations -----------------------------------------------------------------------
@@ -77,6 +76,11 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
 }
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU for bf16-stored results: v_exp_f32 based (abs error ~1e-7 near 0, far below bf16 resolution)
+__device__ __forceinline__ float elu_fast(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+__device__ __forceinline__ float apply_act_fast(float x, int act) {
+  return act == 2 ? elu_fast(x) : (act == 1 ? x * 0.5f * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))) : x);
+}
 __device__ __forceinline__ float apply_act(float x, int act) {
   return act == ACT_GELU ? gelu_f(x) : (act == ACT_ELU ? elu_f(x) : x);
 }

@@ -14,6 +14,7 @@
 // (modules.py:767-770 + transpose :838), patch im2col for the 4x4/stride-4 patch embeds (modules.py:430-431),
 // and 3x3 im2col / col2im for the small grouped conv of FG-MSA (FG_MSA.py:51).
 #include "common.h"
+#include <stdlib.h>
 
 #define TILE_H 8
 #define TILE_W 16
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T*
 // ---------------------------------------------------------------------------------------------------
 #define WG_W 32
 template <typename T, int FO, int FI>
-__global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* dP, float* dWeff, int F, int Hi, int Wi,
+__global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* dP, float* dWeff, float* dbias, int F, int Hi, int Wi,
                                                            int Cin, int Cout, int chunks_per_block) {
   constexpr int BO = FO * 16, BI = FI * 16;
   constexpr int LDO = BO + LdsPad<T>::P, LDI = BI + LdsPad<T>::P;
@@ -295,6 +296,8 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* 
 #pragma unroll
     for (int n = 0; n < FI; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const uint4 z4 = make_uint4(0, 0, 0, 0);
+  const bool do_db = dbias != nullptr && ci0 == 0 && w == 0 && lane < BO;   // fused bias gradient (sum of dP over pixels)
+  float dbacc = 0.f;
 
   for (long long c = c_begin; c < c_end; ++c) {
     const int seg = (int)(c % segs); long long t = c / segs;
@@ -319,6 +322,11 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* 
       *reinterpret_cast<uint4*>(Xs + p * LDI + ch) = v;
     }
     __syncthreads();
+    if (do_db) {
+      float sdb = 0.f;
+      for (int q = 0; q < WG_W; ++q) sdb += ldf(dYs + q * LDO + lane);
+      dbacc += sdb;
+    }
     for (int k0 = 0; k0 < WG_W; k0 += Mma<T>::KSTEP) {
       typename Mma<T>::Frag af[FO], bf[FI];
 #pragma unroll
@@ -332,6 +340,7 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* 
     }
     __syncthreads();
   }
+  if (do_db && co0 + lane < Cout) atomicAdd(dbias + co0 + lane, dbacc);
   const int pt = a * 8 + b * 4 + r * 2 + s;
 #pragma unroll
   for (int m = 0; m < FO; ++m)
@@ -379,10 +388,19 @@ static int upconv_fwd_launch(const void* X, const void* Wf, const float* bias, v
   }
   return stj_check_launch("stj_upconv_fwd");
 }
+bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
+                       hipStream_t st);   // conv_ws.hip
+static bool ws_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("STJ_NO_WS"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
 extern "C" int stj_upconv_fwd(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin,
                               int Cout, int act, int dtype, hipStream_t stream) {
   int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
   if (e) return e;
+  if (dtype == STJ_BF16 && ws_enabled() && upconv_fwd_ws_try(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream))
+    return stj_check_launch("stj_upconv_fwd(ws)");
   return dtype == STJ_BF16 ? upconv_fwd_launch<bf16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream)
                            : upconv_fwd_launch<float>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream);
 }
@@ -406,30 +424,31 @@ extern "C" int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, int F,
 }
 
 template <typename T>
-static int upconv_wgrad_launch(const void* X, const void* dP, float* dWeff, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+static int upconv_wgrad_launch(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   const long long nchunks = (long long)F * Hi * ((Wi + WG_W - 1) / WG_W);
   if (Cout <= 48 && Cin <= 96) {
     const int tiles = 1;
-    int strips = (int)min(nchunks, (long long)(2048 / (4 * tiles)));
+    int strips = (int)min(nchunks, (long long)(1024 / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
-    hipLaunchKernelGGL((upconv_wgrad_kernel<T, 3, 6>), dim3(strips, 4, tiles), dim3(256), 0, st, (const T*)X, (const T*)dP, dWeff, F, Hi, Wi, Cin, Cout, cpb);
+    hipLaunchKernelGGL((upconv_wgrad_kernel<T, 3, 6>), dim3(strips, 4, tiles), dim3(256), 0, st, (const T*)X, (const T*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb);
   } else {
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    int strips = (int)min(nchunks, (long long)max(1, 2048 / (4 * tiles)));
+    int strips = (int)min(nchunks, (long long)max(1, 1024 / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
-    hipLaunchKernelGGL((upconv_wgrad_kernel<T, 4, 4>), dim3(strips, 4, tiles), dim3(256), 0, st, (const T*)X, (const T*)dP, dWeff, F, Hi, Wi, Cin, Cout, cpb);
+    hipLaunchKernelGGL((upconv_wgrad_kernel<T, 4, 4>), dim3(strips, 4, tiles), dim3(256), 0, st, (const T*)X, (const T*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb);
   }
   return stj_check_launch("stj_upconv_wgrad");
 }
 // dWeff: f32 [16][Cout][Cin] scratch, must be zero on entry (caller memsets); fold with stj_upconv_fold afterwards.
-extern "C" int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, int F, int Hi, int Wi, int Cin, int Cout,
+// dbias (optional): f32 [Cout], accumulated with sum over all pixels of dP (the conv bias gradient).
+extern "C" int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout,
                                 int dtype, hipStream_t stream) {
   int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
   if (e) return e;
-  return dtype == STJ_BF16 ? upconv_wgrad_launch<bf16>(X, dP, dWeff, F, Hi, Wi, Cin, Cout, stream)
-                           : upconv_wgrad_launch<float>(X, dP, dWeff, F, Hi, Wi, Cin, Cout, stream);
+  return dtype == STJ_BF16 ? upconv_wgrad_launch<bf16>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream)
+                           : upconv_wgrad_launch<float>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -451,10 +470,21 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* X, const floa
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y; const int f = bid / tiles_y;
   const T* Xf = X + (long long)f * Hh * Ww * C;
-  for (int i = tid; i < 18 * 18 * C; i += 256) {
-    const int c = i % C, p = i / C;
-    const int gy = ty * OC_T + p / 18 - 1, gx = tx * OC_T + p % 18 - 1;
-    halo[p * LDC + c] = (gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) ? ldf(Xf + ((long long)gy * Ww + gx) * C + c) : 0.f;
+  {
+    constexpr int VN = Vec<T>::N;
+    const int cpp = C / VN;                     // 16-byte chunks per pixel (C % VN == 0 checked on the host)
+    for (int i = tid; i < 18 * 18 * cpp; i += 256) {
+      const int c = (i % cpp) * VN, p = i / cpp;
+      const int gy = ty * OC_T + p / 18 - 1, gx = tx * OC_T + p % 18 - 1;
+      float v[VN];
+      if (gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) ld16(Xf + ((long long)gy * Ww + gx) * C + c, v);
+      else {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VN; ++e) halo[p * LDC + c + e] = v[e];
+    }
   }
   for (int i = tid; i < 9 * C * 2; i += 256) Ws[i] = W[i];
   __syncthreads();
@@ -496,10 +526,21 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* X, const floa
     const T* Xf = X + (long long)f * Hh * Ww * C;
     const float* dYf = dY + b * y_bstride + tt * y_tstride;
     __syncthreads();
-    for (int i = tid; i < 18 * 18 * C; i += 256) {
-      const int c = i % C, p = i / C;
-      const int gy = ty * OC_T + p / 18 - 1, gx = tx * OC_T + p % 18 - 1;
-      halo[p * LDC + c] = (gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) ? ldf(Xf + ((long long)gy * Ww + gx) * C + c) : 0.f;
+    {
+      constexpr int VN = Vec<T>::N;
+      const int cpp = C / VN;
+      for (int i = tid; i < 18 * 18 * cpp; i += 256) {
+        const int c = (i % cpp) * VN, p = i / cpp;
+        const int gy = ty * OC_T + p / 18 - 1, gx = tx * OC_T + p % 18 - 1;
+        float v[VN];
+        if (gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) ld16(Xf + ((long long)gy * Ww + gx) * C + c, v);
+        else {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) halo[p * LDC + c + e] = v[e];
+      }
     }
     for (int i = tid; i < 18 * 18; i += 256) {
       const int gy = ty * OC_T + i / 18 - 1, gx = tx * OC_T + i % 18 - 1;
@@ -519,11 +560,17 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* X, const floa
         const int hp = (py + 2 - t / 3) * 18 + px + 2 - t % 3;
         g0[t] = dys[2 * hp]; g1[t] = dys[2 * hp + 1];
       }
-      for (int c = 0; c < C; ++c) {
-        float acc = 0.f;
+      constexpr int VN = Vec<T>::N;
+      for (int c0 = 0; c0 < C; c0 += VN) {
+        float o[VN];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc += g0[t] * Ws[(t * C + c) * 2] + g1[t] * Ws[(t * C + c) * 2 + 1];
-        stf(dst + c, acc);
+        for (int e = 0; e < VN; ++e) {
+          float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc += g0[t] * Ws[(t * C + c0 + e) * 2] + g1[t] * Ws[(t * C + c0 + e) * 2 + 1];
+          o[e] = acc;
+        }
+        st16(dst + c0, o);
       }
       const int hp = (py + 1) * 18 + px + 1;
       b0 += dys[2 * hp]; b1 += dys[2 * hp + 1];
@@ -556,7 +603,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* X, const floa
 
 extern "C" int stj_outconv_fwd(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                                long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream) {
-  if (Hh % OC_T || Ww % OC_T) { stj_set_error("outconv: H,W must be multiples of 16"); return STJ_EINVAL; }
+  if (Hh % OC_T || Ww % OC_T || C % 8) { stj_set_error("outconv: H,W must be multiples of 16 and C of 8"); return STJ_EINVAL; }
   const size_t lds = (size_t)(18 * 18 * (C + 1) + 9 * C * 2) * 4;
   if (lds > 160 * 1024) { stj_set_error("outconv: C=%d too large for LDS", C); return STJ_EUNSUPPORTED; }
   const int grid = F * (Hh / OC_T) * (Ww / OC_T);
@@ -571,7 +618,7 @@ extern "C" int stj_outconv_fwd(const void* X, const float* W, const float* bias,
 }
 extern "C" int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww,
                                int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream) {
-  if (Hh % OC_T || Ww % OC_T) { stj_set_error("outconv: H,W must be multiples of 16"); return STJ_EINVAL; }
+  if (Hh % OC_T || Ww % OC_T || C % 8) { stj_set_error("outconv: H,W must be multiples of 16 and C of 8"); return STJ_EINVAL; }
   const size_t lds = (size_t)(18 * 18 * (C + 1) + 9 * C * 2 + 18 * 18 * 2) * 4;
   if (lds > 160 * 1024 || 9 * C > 1024) { stj_set_error("outconv: C=%d too large", C); return STJ_EUNSUPPORTED; }
   const int grid = min(1024, F * (Hh / OC_T) * (Ww / OC_T));

@@ -1,77 +1,103 @@
 // Batched strided GEMM on MFMA with fused epilogue, plus column-sum (bias gradient).
 //   C[z][m,n] = epi( alpha * sum_k A[z](m,k) * B[z](k,n) )      epi: +bias[n] -> act -> +res[m,n]
-// Serves every Dense / 1x1-conv / tfa-MHA projection of the hot path and their dgrad / wgrad
-// (reference: Keras Dense modules.py:36-37,76-79,270; FG_MSA.py:54-64; trajNet.py:32-36,71-76,195-210;
-//  time-collapsed Conv3D modules.py:693-717 -- SURVEY.md K2-K8,K10).
-// Operands may be given in either orientation through element strides (one of the two strides of
-// each operand must be 1); tiles are staged into K-contiguous LDS images ([m][k], [n][k]) and fed
-// to v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32.  Weight gradients use split-K with f32
-// atomic accumulation straight into the flat gradient buffer.
+// Serves every Dense / 1x1-conv / tfa-MHA projection of the hot path and their dgrad / wgrad, the Q K^T / P V
+// products of the global attentions, and the time-collapsed Conv3D skips
+// (reference: Keras Dense modules.py:36-37,76-79,270; FG_MSA.py:54-64,147,176; trajNet.py:32-36,71-76,195-210;
+//  Conv3D(8,1,1) modules.py:693-717 -- SURVEY.md K2-K8,K10).
+//
+// Operand orientation is given by element strides.  A K-contiguous operand is staged into an LDS image [rows][BK]
+// and read as 16-byte MFMA fragments (ds_read_b128); a row-contiguous ("transposed") operand -- x^T and dY in every
+// weight gradient, W in every forward Dense with Keras [in,out] layout, V in P V -- is staged UN-transposed as
+// [BK][rows] with coalesced 16-byte global reads, and the transposition happens in the fragment read
+// (8 x ds_read_u16 down the k axis; consecutive lanes hit consecutive LDS addresses).  The first version transposed
+// while writing to LDS and lost >10x to 32-way bank conflicts on 2-byte scatter writes (profiles/r01_a_*).
+// The epilogue goes through LDS so that global stores (and residual loads) are full 16-byte row segments.
+// Weight gradients use split-K with f32 atomic accumulation straight into the flat gradient buffer.
 #include "common.h"
 
 struct GemmArgs {
-  const void* A; const void* B; void* C; const float* bias; const void* res;
+  const void* A; const void* B; void* C; const float* bias; const void* res; float* colsum;
   int M, N, K, nb1, nb2;     // batch index z = z1 * nb2 + z2, each operand has a stride per level
   long long sAb1, sAb2, sAm, sAk, sBb1, sBb2, sBk, sBn, sCb1, sCb2, ldc, sBias1, sBias2, sRes1, sRes2, ldres;
   int act, c_f32, accumulate, splitk;
-  int vecA, vecB;   // 16-byte vector path allowed for the contiguous dimension
+  int vecA, vecB, vecC, vecR;   // 16-byte vector paths legal for A / B staging, C stores, residual loads
   float alpha;
 };
 
-// stage a [ROWS][BK] K-contiguous LDS tile from a strided global operand.
-//   element (r,k) at g[r*sR + k*sK];  rows valid: r < nr, k valid: k < nk.
-template <typename T, int ROWS, int BK>
-__device__ __forceinline__ void stage_tile(T* lds, int ld, const T* g, long long sR, long long sK, int nr, int nk,
-                                           int vec, int tid) {
+template <typename T> struct PadT;            // row padding of the un-transposed image: bank-conflict-free strided reads
+template <> struct PadT<bf16> { static constexpr int P = 2; };
+template <> struct PadT<float> { static constexpr int P = 4; };
+
+template <typename T> __device__ __forceinline__ T zero_of() {
+  T z;
+  if constexpr (sizeof(T) == 2) z.v = 0; else z = 0.f;
+  return z;
+}
+
+// K-contiguous image [ROWS][LD]: element (r,k) from g[r*sR + k*sK]
+template <typename T, int ROWS, int BK, int LD>
+__device__ __forceinline__ void stage_kc(T* lds, const T* g, long long sR, long long sK, int nr, int nk, int vec, int tid) {
   constexpr int VN = Vec<T>::N;
-  if (sK == 1) {                                // K contiguous: 16-byte chunks along k
+  if (sK == 1) {
     constexpr int CPR = BK / VN;
     for (int i = tid; i < ROWS * CPR; i += 256) {
-      int r = i / CPR, k = (i % CPR) * VN;
-      T* dst = lds + r * ld + k;
+      const int r = i / CPR, k = (i % CPR) * VN;
+      T* dst = lds + r * LD + k;
       if (r < nr && k + VN <= nk && vec) {
         *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(g + (long long)r * sR + k);
       } else {
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-          T z; if constexpr (sizeof(T) == 2) z.v = 0; else z = 0.f;
-          dst[e] = (r < nr && k + e < nk) ? g[(long long)r * sR + k + e] : z;
-        }
+        for (int e = 0; e < VN; ++e) dst[e] = (r < nr && k + e < nk) ? g[(long long)r * sR + k + e] : zero_of<T>();
       }
     }
-  } else if (sR == 1) {                         // row contiguous (transposed operand): chunks along rows
-    constexpr int CPK = ROWS / VN;
-    for (int i = tid; i < BK * CPK; i += 256) {
-      int k = i / CPK, r = (i % CPK) * VN;
-      __attribute__((aligned(16))) T tmp[VN];
-      if (k < nk && r + VN <= nr && vec) {
-        *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(g + (long long)k * sK + r);
-      } else {
-#pragma unroll
-        for (int e = 0; e < VN; ++e) {
-          T z; if constexpr (sizeof(T) == 2) z.v = 0; else z = 0.f;
-          tmp[e] = (k < nk && r + e < nr) ? g[(long long)k * sK + r + e] : z;
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < VN; ++e) lds[(r + e) * ld + k] = tmp[e];
-    }
-  } else {                                      // general strides
+  } else {
     for (int i = tid; i < ROWS * BK; i += 256) {
-      int r = i / BK, k = i % BK;
-      T z; if constexpr (sizeof(T) == 2) z.v = 0; else z = 0.f;
-      lds[r * ld + k] = (r < nr && k < nk) ? g[(long long)r * sR + (long long)k * sK] : z;
+      const int r = i / BK, k = i % BK;
+      lds[r * LD + k] = (r < nr && k < nk) ? g[(long long)r * sR + (long long)k * sK] : zero_of<T>();
+    }
+  }
+}
+// row-contiguous operand kept un-transposed: image [BK][LDT], element (r,k) from g[r + k*sK]
+template <typename T, int ROWS, int BK, int LDT>
+__device__ __forceinline__ void stage_rc(T* lds, const T* g, long long sK, int nr, int nk, int vec, int tid) {
+  constexpr int VN = Vec<T>::N;
+  constexpr int CPK = ROWS / VN;
+  for (int i = tid; i < BK * CPK; i += 256) {
+    const int k = i / CPK, r = (i % CPK) * VN;
+    T* dst = lds + k * LDT + r;
+    if (k < nk && r + VN <= nr && vec) {
+      const uint4 v = *reinterpret_cast<const uint4*>(g + (long long)k * sK + r);
+      if constexpr (sizeof(T) == 2) {          // rows are only 4-byte aligned (LDT = ROWS + 2)
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      } else {
+        *reinterpret_cast<uint4*>(dst) = v;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VN; ++e) dst[e] = (k < nk && r + e < nr) ? g[(long long)k * sK + r + e] : zero_of<T>();
     }
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   constexpr int BK = 128 / sizeof(T);
   constexpr int LD = BK + LdsPad<T>::P;
+  constexpr int LDTA = BM + PadT<T>::P, LDTB = BN + PadT<T>::P;
   constexpr int FM = BM / (16 * WM), FN = BN / (16 * WN);
-  __shared__ __attribute__((aligned(16))) T As[BM * LD];
-  __shared__ __attribute__((aligned(16))) T Bs[BN * LD];
+  constexpr int A_ELEMS = TA ? BK * LDTA : BM * LD;
+  constexpr int B_ELEMS = ((TB ? BK * LDTB : BN * LD) + 7) / 8 * 8;
+  constexpr int A_ELEMS_AL = (A_ELEMS + 7) / 8 * 8;
+  constexpr int EP_ROWS = BM < 64 ? BM : 64;
+  constexpr int LDC = BN + 4;
+  constexpr int STAGE_BYTES = (A_ELEMS_AL + B_ELEMS) * (int)sizeof(T);
+  constexpr int EPI_BYTES = EP_ROWS * LDC * 4;
+  constexpr int SMEM = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  T* As = reinterpret_cast<T*>(smem);
+  T* Bs = As + A_ELEMS_AL;
+  float* Cs = reinterpret_cast<float*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -83,6 +109,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int ktiles = (p.K + BK - 1) / BK;
   const int kt_per = (ktiles + p.splitk - 1) / p.splitk;
   const int kt0 = ks * kt_per, kt1 = min(ktiles, kt0 + kt_per);
+  if (kt0 >= kt1 && (p.accumulate || ks != 0)) return;
 
   const long long z1 = z / p.nb2, z2 = z % p.nb2;
   const T* A = reinterpret_cast<const T*>(p.A) + z1 * p.sAb1 + z2 * p.sAb2 + (long long)m0 * p.sAm;
@@ -93,63 +120,165 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = p.colsum != nullptr && tm == 0;
+  float cs = 0.f;
 
   for (int kt = kt0; kt < kt1; ++kt) {
     const int k0 = kt * BK;
-    stage_tile<T, BM, BK>(As, LD, A + (long long)k0 * p.sAk, p.sAm, p.sAk, p.M - m0, p.K - k0, p.vecA, tid);
-    stage_tile<T, BN, BK>(Bs, LD, B + (long long)k0 * p.sBk, p.sBn, p.sBk, p.N - n0, p.K - k0, p.vecB, tid);
+    if constexpr (TA) stage_rc<T, BM, BK, LDTA>(As, A + (long long)k0 * p.sAk, p.sAk, p.M - m0, p.K - k0, p.vecA, tid);
+    else stage_kc<T, BM, BK, LD>(As, A + (long long)k0 * p.sAk, p.sAm, p.sAk, p.M - m0, p.K - k0, p.vecA, tid);
+    if constexpr (TB) stage_rc<T, BN, BK, LDTB>(Bs, B + (long long)k0 * p.sBk, p.sBk, p.N - n0, p.K - k0, p.vecB, tid);
+    else stage_kc<T, BN, BK, LD>(Bs, B + (long long)k0 * p.sBk, p.sBn, p.sBk, p.N - n0, p.K - k0, p.vecB, tid);
     __syncthreads();
-    mma_tile<T, FM, FN>(As + (wm * FM * 16) * LD, LD, Bs + (wn * FN * 16) * LD, LD, BK, lane, acc);
+    if (do_cs && tid < BN) {           // fused bias gradient: column sums of the B (= dY) tile over this block's k range
+      float s = 0.f;
+      if constexpr (TB) { for (int k = 0; k < BK; ++k) s += ldf(Bs + k * LDTB + tid); }
+      else { for (int k = 0; k < BK; ++k) s += ldf(Bs + tid * LD + k); }
+      cs += s;
+    }
+    for (int kk = 0; kk < BK; kk += Mma<T>::KSTEP) {
+      typename Mma<T>::Frag a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        if constexpr (TA) a[i] = Mma<T>::load_strided(As, 1, LDTA, (wm * FM + i) * 16, kk, lane);
+        else a[i] = Mma<T>::load(As, LD, (wm * FM + i) * 16, kk, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        if constexpr (TB) b[j] = Mma<T>::load_strided(Bs, 1, LDTB, (wn * FN + j) * 16, kk, lane);
+        else b[j] = Mma<T>::load(Bs, LD, (wn * FN + j) * 16, kk, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
+    }
     __syncthreads();
   }
-  if (kt0 >= kt1 && !(p.accumulate == 0 && ks == 0)) return;
 
-  // epilogue
-  const float* bias = p.bias ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
+  if (do_cs && tid < BN && n0 + tid < p.N) atomicAdd(p.colsum + z1 * p.sBias1 + z2 * p.sBias2 + n0 + tid, cs);
+
+  // ---- epilogue through LDS: EP_ROWS rows per pass, full-row 16-byte global accesses ----
+  const float* bias = (p.bias && ks == 0) ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
   const T* res = p.res ? reinterpret_cast<const T*>(p.res) + z1 * p.sRes1 + z2 * p.sRes2 : nullptr;
   float* Cf = reinterpret_cast<float*>(p.C) + z1 * p.sCb1 + z2 * p.sCb2;
   T* Ct = reinterpret_cast<T*>(p.C) + z1 * p.sCb1 + z2 * p.sCb2;
+  constexpr int WROWS = FM * 16;                 // rows owned by one wave
+  for (int r0 = 0; r0 < BM; r0 += EP_ROWS) {
+    if (wm * WROWS >= r0 && wm * WROWS < r0 + EP_ROWS) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = n0 + (wn * FN + j) * 16 + (lane & 15);
-      if (col >= p.N) continue;
-      const float bv = (bias && ks == 0) ? bias[col] : 0.f;
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + (wm * FM + i) * 16 + (lane >> 4) * 4 + r;
-        if (row >= p.M) continue;
-        float v = acc[i][j][r] * p.alpha + bv;
-        v = apply_act(v, p.act);
-        if (res) v += ldf(res + (long long)row * p.ldres + col);
-        const long long o = (long long)row * p.ldc + col;
-        if (p.accumulate) atomicAdd(Cf + o, v);
-        else if (p.c_f32) Cf[o] = v;
-        else stf(Ct + o, v);
+          for (int r = 0; r < 4; ++r)
+            Cs[(wm * WROWS - r0 + i * 16 + (lane >> 4) * 4 + r) * LDC + (wn * FN + j) * 16 + (lane & 15)] = acc[i][j][r] * p.alpha;
+    }
+    __syncthreads();
+    if (p.accumulate) {
+      for (int i = tid; i < EP_ROWS * BN; i += 256) {
+        const int r = i / BN, c = i % BN;
+        const int row = m0 + r0 + r, col = n0 + c;
+        if (row < p.M && col < p.N) {
+          float v = Cs[r * LDC + c];
+          if (bias) v += bias[col];
+          atomicAdd(Cf + (long long)row * p.ldc + col, v);
+        }
+      }
+    } else if (p.c_f32) {
+      constexpr int CH = BN / 4;
+      for (int i = tid; i < EP_ROWS * CH; i += 256) {
+        const int r = i / CH, c = (i % CH) * 4;
+        const int row = m0 + r0 + r, col = n0 + c;
+        if (row >= p.M || col >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = Cs[r * LDC + c + e];
+          if (bias && col + e < p.N) v[e] += bias[col + e];
+          v[e] = apply_act(v[e], p.act);
+        }
+        float* dst = Cf + (long long)row * p.ldc + col;
+        if (p.vecC && col + 4 <= p.N && !res) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          for (int e = 0; e < 4 && col + e < p.N; ++e) dst[e] = v[e] + (res ? ldf(res + (long long)row * p.ldres + col + e) : 0.f);
+        }
+      }
+    } else {
+      constexpr int VN = Vec<T>::N;
+      constexpr int CH = BN / VN;
+      for (int i = tid; i < EP_ROWS * CH; i += 256) {
+        const int r = i / CH, c = (i % CH) * VN;
+        const int row = m0 + r0 + r, col = n0 + c;
+        if (row >= p.M || col >= p.N) continue;
+        float v[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+          v[e] = Cs[r * LDC + c + e];
+          if (bias && col + e < p.N) v[e] += bias[col + e];
+          v[e] = apply_act(v[e], p.act);
+        }
+        T* dst = Ct + (long long)row * p.ldc + col;
+        if (p.vecC && col + VN <= p.N) {
+          if (res) {
+            float rr[VN];
+            if (p.vecR) ld16(res + (long long)row * p.ldres + col, rr);
+            else {
+#pragma unroll
+              for (int e = 0; e < VN; ++e) rr[e] = ldf(res + (long long)row * p.ldres + col + e);
+            }
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] += rr[e];
+          }
+          st16(dst, v);
+        } else {
+          for (int e = 0; e < VN && col + e < p.N; ++e) stf(dst + e, v[e] + (res ? ldf(res + (long long)row * p.ldres + col + e) : 0.f));
+        }
       }
     }
+    __syncthreads();
   }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static void launch_tile(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
+  dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), p.nb1 * p.nb2 * p.splitk), blk(256);
+  if (ta && tb) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, true, true>), grid, blk, 0, st, p);
+  else if (ta) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, true, false>), grid, blk, 0, st, p);
+  else if (tb) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, false, true>), grid, blk, 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, false, false>), grid, blk, 0, st, p);
 }
 
 template <typename T>
-static int launch_gemm(const GemmArgs& p, hipStream_t st) {
-  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nb1 * p.nb2 * p.splitk;
-  dim3 blk(256);
-  if (p.N > 64 && p.M > 64 && tiles128 >= 128) {
-    dim3 grid(((p.M + 127) / 128) * ((p.N + 127) / 128), p.nb1 * p.nb2 * p.splitk);
-    hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2>), grid, blk, 0, st, p);
-  } else if (p.N <= 64 && p.M >= 4096) {
-    dim3 grid(((p.M + 127) / 128) * ((p.N + 63) / 64), p.nb1 * p.nb2 * p.splitk);
-    hipLaunchKernelGGL((gemm_kernel<T, 128, 64, 4, 1>), grid, blk, 0, st, p);
-  } else {
-    dim3 grid(((p.M + 63) / 64) * ((p.N + 63) / 64), p.nb1 * p.nb2 * p.splitk);
-    hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2>), grid, blk, 0, st, p);
+static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
+  constexpr int BK = 128 / sizeof(T);
+  const long long nb = (long long)p.nb1 * p.nb2;
+  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nb;
+  const long long tiles64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * nb;
+  const int ktiles = (p.K + BK - 1) / BK;
+  int cfg;   // 0: 128x128, 1: 128x64 (narrow N), 2: 64x64
+  if (p.N <= 64 && p.M >= 2048) cfg = 1;
+  else if (p.N > 64 && p.M > 64 && tiles128 >= 192) cfg = 0;
+  else cfg = 2;
+  if (p.splitk == 0) {            // auto split-K (accumulating GEMMs only): aim at ~2 blocks per CU
+    const long long tiles = cfg == 0 ? tiles128 : (cfg == 1 ? (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * nb : tiles64);
+    long long s = (384 + tiles - 1) / tiles;
+    if (s > 48) s = 48;                 // bound same-address atomic contention
+    if (s > ktiles / 2) s = ktiles / 2;
+    if (s < 1) s = 1;
+    if (s * nb > 65535) s = 65535 / nb;
+    p.splitk = (int)s;
   }
+  if (cfg == 0) launch_tile<T, 128, 128, 2, 2>(p, ta, tb, st);
+  else if (cfg == 1) launch_tile<T, 128, 64, 4, 1>(p, ta, tb, st);
+  else launch_tile<T, 64, 64, 2, 2>(p, ta, tb, st);
   return stj_check_launch("stj_gemm");
 }
 
-extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias, const void* res,
+// colsum (optional, f32, accumulate GEMMs only): colsum[z][n] += sum_k B[z](k,n)  -- the bias gradient that goes with
+// a weight gradient dW = x^T dY; addressed with the bias batch strides.
+extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias, const void* res, float* colsum,
                         int M, int N, int K, int nb1, int nb2,
                         long long sAb1, long long sAb2, long long sAm, long long sAk,
                         long long sBb1, long long sBb2, long long sBk, long long sBn,
@@ -157,13 +286,14 @@ extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias
                         long long sBias1, long long sBias2, long long sRes1, long long sRes2, long long ldres,
                         int act, float alpha, int dtype, int c_f32, int accumulate, int splitk, hipStream_t stream) {
   if (M <= 0 || N <= 0 || nb1 <= 0 || nb2 <= 0) return STJ_OK;
-  if (K < 0 || splitk < 1) { stj_set_error("stj_gemm: bad K/splitk"); return STJ_EINVAL; }
+  if (K < 0 || splitk < 0) { stj_set_error("stj_gemm: bad K/splitk"); return STJ_EINVAL; }
   if (accumulate && !c_f32) { stj_set_error("stj_gemm: accumulate requires f32 output"); return STJ_EINVAL; }
-  if (splitk > 1 && !accumulate) { stj_set_error("stj_gemm: splitk>1 requires accumulate"); return STJ_EINVAL; }
-  if (splitk > 1 && (act != ACT_NONE || res)) { stj_set_error("stj_gemm: splitk with nonlinear epilogue"); return STJ_EINVAL; }
-  if ((long long)nb1 * nb2 * splitk > 65535) { stj_set_error("stj_gemm: batch*splitk too large"); return STJ_EINVAL; }
+  if (splitk != 1 && !accumulate) { stj_set_error("stj_gemm: splitk != 1 requires accumulate"); return STJ_EINVAL; }
+  if (colsum && (!accumulate || bias)) { stj_set_error("stj_gemm: colsum needs accumulate and no bias"); return STJ_EINVAL; }
+  if (accumulate && (act != ACT_NONE || res)) { stj_set_error("stj_gemm: accumulate with nonlinear epilogue"); return STJ_EINVAL; }
+  if ((long long)nb1 * nb2 * (splitk > 0 ? splitk : 1) > 65535) { stj_set_error("stj_gemm: batch*splitk too large"); return STJ_EINVAL; }
   GemmArgs p;
-  p.A = A; p.B = B; p.C = C; p.bias = bias; p.res = res;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.res = res; p.colsum = colsum;
   p.M = M; p.N = N; p.K = K; p.nb1 = nb1; p.nb2 = nb2;
   p.sAb1 = sAb1; p.sAb2 = sAb2; p.sAm = sAm; p.sAk = sAk;
   p.sBb1 = sBb1; p.sBb2 = sBb2; p.sBk = sBk; p.sBn = sBn;
@@ -171,41 +301,72 @@ extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias
   p.sBias1 = sBias1; p.sBias2 = sBias2; p.sRes1 = sRes1; p.sRes2 = sRes2; p.ldres = ldres;
   p.act = act; p.c_f32 = c_f32; p.accumulate = accumulate; p.splitk = splitk; p.alpha = alpha;
   const long long es = dtype == STJ_BF16 ? 2 : 4;
-  auto al = [&](const void* ptr, long long s0, long long s1, long long s2) {
-    return ((uintptr_t)ptr % 16 == 0) && ((s0 * es) % 16 == 0) && ((s1 * es) % 16 == 0) && ((s2 * es) % 16 == 0);
+  auto al = [&](const void* ptr, long long esz, long long s0, long long s1, long long s2) {
+    return ((uintptr_t)ptr % 16 == 0) && ((s0 * esz) % 16 == 0) && ((s1 * esz) % 16 == 0) && ((s2 * esz) % 16 == 0);
   };
-  p.vecA = (sAk == 1) ? al(A, sAm, sAb1, sAb2) : (sAm == 1 ? al(A, sAk, sAb1, sAb2) : 0);
-  p.vecB = (sBk == 1) ? al(B, sBn, sBb1, sBb2) : (sBn == 1 ? al(B, sBk, sBb1, sBb2) : 0);
-  if (dtype == STJ_BF16) return launch_gemm<bf16>(p, stream);
-  if (dtype == STJ_F32) return launch_gemm<float>(p, stream);
+  const bool ta = (sAm == 1 && sAk != 1), tb = (sBn == 1 && sBk != 1);
+  p.vecA = ta ? al(A, es, sAk, sAb1, sAb2) : (sAk == 1 ? al(A, es, sAm, sAb1, sAb2) : 0);
+  p.vecB = tb ? al(B, es, sBk, sBb1, sBb2) : (sBk == 1 ? al(B, es, sBn, sBb1, sBb2) : 0);
+  p.vecC = al(C, c_f32 ? 4 : es, ldc, sCb1, sCb2);
+  p.vecR = res ? al(res, es, ldres, sRes1, sRes2) : 0;
+  if (dtype == STJ_BF16) return launch_gemm<bf16>(p, ta, tb, stream);
+  if (dtype == STJ_F32) return launch_gemm<float>(p, ta, tb, stream);
   stj_set_error("stj_gemm: bad dtype %d", dtype);
   return STJ_EINVAL;
 }
 
 // ---- column sums: out[n] += sum_m X[m, n]  (bias gradients; out is f32, accumulated atomically) ----
+// Threads are laid out as (16-byte column vectors) x (row lanes); each block streams a strip of rows with
+// coalesced 16-byte loads, reduces over its row lanes in LDS, then issues one atomic per column.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* X, float* out, int M, int N, long long ld, int rows_per_block) {
-  __shared__ float part[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(M, r0 + rows_per_block);
-  for (int c0 = blockIdx.y * 64; c0 < N; c0 += gridDim.y * 64) {
-    const int c = c0 + cx;
-    float s = 0.f;
-    if (c < N)
-      for (int r = r0 + ry; r < r1; r += 4) s += ldf(X + (long long)r * ld + c);
-    part[ry][cx] = s;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, float* out, int M, int N, long long ld, int rows_per_block, int vec) {
+  constexpr int VN = Vec<T>::N;
+  __shared__ float part[256 * VN];
+  const int cv = (N + VN - 1) / VN;                 // column vectors
+  const int cvb = cv < 256 ? cv : 256;              // column vectors handled per pass
+  const int rl = 256 / cvb;                         // row lanes
+  const int tx = threadIdx.x % cvb, ty = threadIdx.x / cvb;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (int c0 = 0; c0 < cv; c0 += cvb) {
+    const int c = (c0 + tx) * VN;
+    float s[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) s[e] = 0.f;
+    if (ty < rl && c < N) {
+      if (vec && c + VN <= N) {
+        for (int r = r0 + ty; r < r1; r += rl) {
+          float v[VN];
+          ld16(X + (long long)r * ld + c, v);
+#pragma unroll
+          for (int e = 0; e < VN; ++e) s[e] += v[e];
+        }
+      } else {
+        for (int r = r0 + ty; r < r1; r += rl)
+          for (int e = 0; e < VN && c + e < N; ++e) s[e] += ldf(X + (long long)r * ld + c + e);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VN; ++e) part[threadIdx.x * VN + e] = s[e];
     __syncthreads();
-    if (ry == 0 && c < N) atomicAdd(out + c, part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
+    if (ty == 0 && c < N) {
+      for (int e = 0; e < VN && c + e < N; ++e) {
+        float t = 0.f;
+        for (int q = 0; q < rl; ++q) t += part[(q * cvb + tx) * VN + e];
+        atomicAdd(out + c + e, t);
+      }
+    }
     __syncthreads();
   }
 }
 
 extern "C" int stj_colsum(const void* X, float* out, int M, int N, long long ld, int dtype, hipStream_t stream) {
   if (M <= 0 || N <= 0) return STJ_OK;
-  const int rpb = 256;
-  dim3 grid((M + rpb - 1) / rpb, min(8, (N + 63) / 64));
-  if (dtype == STJ_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)X, out, M, N, ld, rpb);
-  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, out, M, N, ld, rpb);
+  const long long es = dtype == STJ_BF16 ? 2 : 4;
+  int rpb = (M + 511) / 512;
+  if (rpb < 64) rpb = 64;
+  const int vec = ((uintptr_t)X % 16 == 0) && ((ld * es) % 16 == 0);
+  dim3 grid((M + rpb - 1) / rpb);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)X, out, M, N, ld, rpb, vec);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, out, M, N, ld, rpb, vec);
   return stj_check_launch("stj_colsum");
 }

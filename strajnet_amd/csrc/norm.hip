@@ -3,6 +3,9 @@
 // 517,557 (eps 1e-5) and FG_MSA.py:52, trajNet.py:72-73,110-111,206-207 (eps 1e-3).
 // Optional fused PatchMerging gather (reference modules.py:282-287): logical row (b,i,j) of width 4*C0 is
 // the concat [x(2i,2j), x(2i+1,2j), x(2i,2j+1), x(2i+1,2j+1)] of a [B,res,res,C0] map -- no concat copy.
+// Parameter groups: rows are cut into runs of `group_rows`; run c uses gamma/beta number (c % ngroups), found at
+// gamma + g * gstride.  This batches the 8 per-waypoint LayerNorms of the time-separated cross-attentions
+// (reference trajNet.py:206-207,257: 8 Cross_AttentionT layers with their own norm1/norm2) into one launch.
 #include "common.h"
 
 __device__ __forceinline__ long long ln_src(long long row, int c, int C, int gres, int C0) {
@@ -15,13 +18,16 @@ __device__ __forceinline__ long long ln_src(long long row, int c, int C, int gre
   return ((b * gres + 2 * i + di) * gres + 2 * j + dj) * C0 + cc;
 }
 
+struct LnGroups { long long group_rows; int ngroups; long long gstride; };
+
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
                                                      float* mean, float* rstd, long long rows, int C, float eps,
-                                                     int gres, int C0) {
+                                                     int gres, int C0, LnGroups G) {
   const int lane = threadIdx.x & 63;
   const long long wave = blockIdx.x * 4ll + (threadIdx.x >> 6);
   for (long long row = wave; row < rows; row += gridDim.x * 4ll) {
+    const long long goff = G.ngroups > 1 ? ((row / G.group_rows) % G.ngroups) * G.gstride : 0;
     float v[NPL];
     float s = 0.f;
 #pragma unroll
@@ -42,70 +48,90 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
       const int c = lane + 64 * j;
-      if (c < C) stf(y + row * C + c, (v[j] - mu) * rs * gamma[c] + beta[c]);
+      if (c < C) stf(y + row * C + c, (v[j] - mu) * rs * gamma[goff + c] + beta[goff + c]);
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
   }
 }
 
+// grid = ngroups * nb blocks: block (g, sub) walks the row runs c with c % ngroups == g, so its per-lane dgamma/dbeta
+// partials belong to one parameter group; one atomic per (block, channel) at the end (nb bounds the contention).
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                      const float* rstd, T* dx, float* dgamma, float* dbeta,
-                                                     long long rows, int C, int gres, int C0) {
+                                                     long long rows, int C, int gres, int C0, LnGroups G, int nb) {
   __shared__ float red[2][4][64 * NPL];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long long wave = blockIdx.x * 4ll + w;
+  const int g = blockIdx.x % G.ngroups, sub = blockIdx.x / G.ngroups;
+  const long long goff = (long long)g * G.gstride;
+  const long long nchunks = (rows + G.group_rows - 1) / G.group_rows;
   float ag[NPL], ab[NPL];
 #pragma unroll
   for (int j = 0; j < NPL; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
-  for (long long row = wave; row < rows; row += gridDim.x * 4ll) {
-    const float mu = mean[row], rs = rstd[row];
-    float xh[NPL], g[NPL];
-    float s1 = 0.f, s2 = 0.f;
+  for (long long chunk = g + (long long)G.ngroups * sub; chunk < nchunks; chunk += (long long)G.ngroups * nb) {
+    const long long rend = min(rows, (chunk + 1) * G.group_rows);
+    for (long long row = chunk * G.group_rows + w; row < rend; row += 4) {
+      const float mu = mean[row], rs = rstd[row];
+      float xh[NPL], gg[NPL];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      const int c = lane + 64 * j;
-      if (c < C) {
-        const float d = ldf(dy + row * C + c);
-        xh[j] = (ldf(x + ln_src(row, c, C, gres, C0)) - mu) * rs;
-        g[j] = d * gamma[c];
-        ag[j] += d * xh[j];
-        ab[j] += d;
-      } else { xh[j] = 0.f; g[j] = 0.f; }
-      s1 += g[j];
-      s2 += g[j] * xh[j];
-    }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
+      for (int j = 0; j < NPL; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) {
+          const float d = ldf(dy + row * C + c);
+          xh[j] = (ldf(x + ln_src(row, c, C, gres, C0)) - mu) * rs;
+          gg[j] = d * gamma[goff + c];
+          ag[j] += d * xh[j];
+          ab[j] += d;
+        } else { xh[j] = 0.f; gg[j] = 0.f; }
+        s1 += gg[j];
+        s2 += gg[j] * xh[j];
+      }
+      s1 = wave_sum(s1) / C;
+      s2 = wave_sum(s2) / C;
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      const int c = lane + 64 * j;
-      if (c < C) stf(dx + ln_src(row, c, C, gres, C0), rs * (g[j] - s1 - xh[j] * s2));
+      for (int j = 0; j < NPL; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) stf(dx + ln_src(row, c, C, gres, C0), rs * (gg[j] - s1 - xh[j] * s2));
+      }
     }
   }
 #pragma unroll
   for (int j = 0; j < NPL; ++j) { red[0][w][lane + 64 * j] = ag[j]; red[1][w][lane + 64 * j] = ab[j]; }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    atomicAdd(dgamma + goff + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + goff + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
   }
 }
 
 #define LN_DISPATCH(NPLV)                                                                                         \
   if (fwd) hipLaunchKernelGGL((ln_fwd_kernel<T, NPLV>), dim3(grid), dim3(256), 0, stream, (const T*)x, gamma, beta, \
-                              (T*)y, mean, rstd, rows, C, eps, gres, C0);                                          \
+                              (T*)y, mean, rstd, rows, C, eps, gres, C0, G);                                       \
   else hipLaunchKernelGGL((ln_bwd_kernel<T, NPLV>), dim3(grid), dim3(256), 0, stream, (const T*)dy, (const T*)x,    \
-                          gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0);
+                          gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0, G, nb);
 
 template <typename T>
 static int ln_launch(bool fwd, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      const void* dy, void* dx, float* dgamma, float* dbeta, long long rows, int C, float eps, int gres,
-                     int C0, hipStream_t stream) {
+                     int C0, LnGroups G, hipStream_t stream) {
   const int npl = (C + 63) / 64;
-  long long want = (rows + 3) / 4;
-  const int cap = fwd ? 4096 : 512;
-  const int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+  int grid, nb = 1;
+  if (fwd) {
+    long long want = (rows + 3) / 4;
+    grid = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  } else {
+    if (G.ngroups <= 1) {              // single parameter set: cut rows into runs so that <= 256 blocks share the atomics
+      G.ngroups = 1; G.gstride = 0;
+      long long gr = (rows + 255) / 256;
+      if (gr < 16) gr = 16;
+      G.group_rows = gr;
+    }
+    const long long nchunks = (rows + G.group_rows - 1) / G.group_rows;
+    long long per_group = (nchunks + G.ngroups - 1) / G.ngroups;
+    nb = (int)(per_group < 1 ? 1 : (per_group > 256 / G.ngroups + 1 ? 256 / G.ngroups + 1 : per_group));
+    grid = G.ngroups * nb;
+  }
   if (npl <= 2) { LN_DISPATCH(2) }
   else if (npl <= 3) { LN_DISPATCH(3) }
   else if (npl <= 6) { LN_DISPATCH(6) }
@@ -116,17 +142,22 @@ static int ln_launch(bool fwd, const void* x, const float* gamma, const float* b
   return stj_check_launch("stj_layernorm");
 }
 
+// group_rows/ngroups/gstride: parameter groups (ngroups <= 1: one gamma/beta for all rows).
 extern "C" int stj_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                                 long long rows, int C, float eps, int gather_res, int C0, int dtype, hipStream_t stream) {
+                                 long long rows, int C, float eps, int gather_res, int C0, long long group_rows, int ngroups,
+                                 long long gstride, int dtype, hipStream_t stream) {
   if (rows <= 0) return STJ_OK;
   if (gather_res && (C != 4 * C0 || (gather_res & 1))) { stj_set_error("layernorm: bad gather geometry"); return STJ_EINVAL; }
-  if (dtype == STJ_BF16) return ln_launch<bf16>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, stream);
-  return ln_launch<float>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, stream);
+  if (ngroups > 1 && group_rows <= 0) { stj_set_error("layernorm: bad group_rows"); return STJ_EINVAL; }
+  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride;
+  if (dtype == STJ_BF16) return ln_launch<bf16>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, G, stream);
+  return ln_launch<float>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, G, stream);
 }
 extern "C" int stj_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                  void* dx, float* dgamma, float* dbeta, long long rows, int C, int gather_res, int C0,
-                                 int dtype, hipStream_t stream) {
+                                 long long group_rows, int ngroups, long long gstride, int dtype, hipStream_t stream) {
   if (rows <= 0) return STJ_OK;
-  if (dtype == STJ_BF16) return ln_launch<bf16>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, stream);
-  return ln_launch<float>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, stream);
+  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride;
+  if (dtype == STJ_BF16) return ln_launch<bf16>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream);
+  return ln_launch<float>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream);
 }

@@ -193,6 +193,12 @@ class STrajNet:
             offs[n] = off
             off += (int(np.prod(s)) + 7) // 8 * 8
         self.n_params = total
+        self._offs = offs
+        self._zstride = offs['cross_attn_obs1/norm1/gamma'] - offs['cross_attn_obs0/norm1/gamma']
+        for n in spec:
+            if n.startswith('cross_attn_obs0/'):
+                for z in range(1, 8):
+                    assert offs[n.replace('obs0', f'obs{z}')] - offs[n] == z * self._zstride
         self._flat = torch.zeros(off, dtype=torch.float32, device=self.device)
         self._gflat = torch.zeros(off, dtype=torch.float32, device=self.device)
         self._cflat = self._flat if dtype == torch.float32 else torch.zeros(off, dtype=dtype, device=self.device)
@@ -393,12 +399,58 @@ class STrajNet:
             sel[t, max(0, 3 - t):min(7, 10 - t) + 1] = 1
         wz = (sel @ pw.master.detach().view(8, Ci * Co)).view(8, Ci, Co).to(self.dtype)
         gwz = torch.zeros((8, Ci, Co), dtype=torch.float32, device=self.device)
-        gbz = torch.zeros((8, Co), dtype=torch.float32, device=self.device)
-        bz = pb.master.detach()[None].expand(8, Co).contiguous()
+
         def fold():
             pw.grad.view(8, Ci * Co).add_(sel.t() @ gwz.view(8, Ci * Co))
-            pb.grad.add_(gbz.sum(0))
-        return ops.linear_z(skip, pw.master, wz, bz, gwz, gbz, act=ACT_ELU, shared_x=True, fold=fold)    # [B,8,HW,Co]
+        return ops.linear_z(skip, pw.master, wz[0], Ci * Co, pb.master.detach(), 0, gwz[0], Ci * Co, pb.grad, 8,
+                            act=ACT_ELU, shared_x=True, fold=fold)    # [B,8,HW,Co]
+
+    # ---- the 8 time-separated cross-attentions, batched over the waypoint axis z (trajNet.py:305-314) ----
+    def _zp(self, suffix):
+        return self._p('cross_attn_obs0/' + suffix)
+
+    def _zheads_in(self, suffix):
+        """[8] x tfa kernel [H,in,hs] -> contiguous [8, in, H*hs] compute copy + gradient fold."""
+        p0 = self._zp(suffix)
+        H, I, hs = p0.shape
+        off = self._offs['cross_attn_obs0/' + suffix]
+        src = torch.as_strided(self._cflat, (8, H, I, hs), (self._zstride, I * hs, hs, 1), off)
+        wz = src.permute(0, 2, 1, 3).reshape(8, I, H * hs).contiguous()
+        gwz = torch.zeros((8, I, H * hs), dtype=torch.float32, device=self.device)
+        gdst = torch.as_strided(self._gflat, (8, H, I, hs), (self._zstride, I * hs, hs, 1), off)
+
+        def fold():
+            gdst.add_(gwz.view(8, I, H, hs).permute(0, 2, 1, 3))
+        return p0, wz, gwz, fold
+
+    def _cross_attention_z(self, query, key, tmask):
+        """8 x Cross_AttentionT (trajNet.py:224-234) + query residual in one batched pass.  query [B,8,HW,Cb], key [B,64,Cb]."""
+        B, Z, HW, Cb = query.shape
+        zs = self._zstride
+        hs = 128 // 3
+
+        def proj_in(x, suffix, shared):
+            p0, wz, gwz, fold = self._zheads_in(suffix)
+            return ops.linear_z(x, p0.master, wz[0], wz.shape[1] * wz.shape[2], None, 0, gwz[0], wz.shape[1] * wz.shape[2], None, 8,
+                                shared_x=shared, fold=fold)
+        q = proj_in(query, 'mha/query_kernel', False)                    # [B,8,HW,126]
+        k = proj_in(key, 'mha/key_kernel', True)                         # [B,8,64,126]
+        v = proj_in(key, 'mha/value_kernel', True)
+        kvalid = tmask[:, None, :].expand(B, Z, tmask.shape[1]).reshape(B * Z, -1).contiguous()
+        o = ops.mha_core(q.view(B * Z, HW, 3 * hs), k.view(B * Z, -1, 3 * hs), v.view(B * Z, -1, 3 * hs), 3, hs,
+                         1.0 / math.sqrt(hs), kvalid=kvalid)
+
+        pw, pb = self._zp('mha/projection_kernel'), self._zp('mha/projection_bias')
+        H_, hs_, O_ = pw.shape
+        v1 = ops.linear_z(o.view(B, Z, HW, 3 * hs), pw.master, pw.c.view(H_ * hs_, O_), zs, pb.master.detach(), zs,
+                          pw.grad.view(H_ * hs_, O_), zs, pb.grad, 8)
+        v1 = ops.layernorm(v1, self._zp('norm1/gamma'), self._zp('norm1/beta'), 1e-3, group_rows=HW, ngroups=8, gstride=zs)
+        pw, pb = self._zp('FFN1/kernel'), self._zp('FFN1/bias')
+        v1 = ops.linear_z(v1, pw.master, pw.c, zs, pb.master.detach(), zs, pw.grad, zs, pb.grad, 8, act=ACT_ELU)
+        pw, pb = self._zp('FFN2/kernel'), self._zp('FFN2/bias')
+        v1 = ops.linear_z(v1, pw.master, pw.c, zs, pb.master.detach(), zs, pw.grad, zs, pb.grad, 8)
+        v1 = ops.layernorm(v1, self._zp('norm2/gamma'), self._zp('norm2/beta'), 1e-3, group_rows=HW, ngroups=8, gstride=zs)
+        return v1 + query
 
     def _decoder(self, x, res_list, B):
         """Pyramid3DDecoder.call (modules.py:739-772): shallow_decode=1, flow_sep_decode, use_pyramid, rep_res."""
@@ -452,11 +504,6 @@ class STrajNet:
         if self.fg:
             query = query + fh.reshape(B, 8, hb * hb, Cb)                          # modules.py:830-831
         key, tmask = self._traj_net(obs, occ)
-        outs = []
-        for i in range(8):                                                         # trajNet.py:305-314
-            qi = query[:, i].contiguous()
-            o = self._cross_attention(f'cross_attn_obs{i}', qi, key, 3, None, tmask)
-            outs.append(o + qi)
-        x = torch.stack(outs, 1)                                                   # [B,8,hb*hb,Cb]
+        x = self._cross_attention_z(query.contiguous(), key, tmask)               # [B,8,hb*hb,Cb]  (trajNet.py:305-317)
         out = self._decoder(x, res_list, B)
         return out

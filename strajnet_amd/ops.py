@@ -25,7 +25,16 @@ def _dt(t):
 
 
 def _p(t):
-    return vp(t.data_ptr()) if t is not None else vp(0)
+    if t is None:
+        return vp(0)
+    if isinstance(t, vp):
+        return t
+    return vp(t.data_ptr())
+
+
+def _poff(t, elems):
+    """raw pointer `elems` elements past the start of tensor t (may point outside t's own view: flat-buffer addressing)."""
+    return vp(t.data_ptr() + elems * t.element_size())
 
 
 def _st():
@@ -80,9 +89,9 @@ class Param:
 
 
 def gemm(A, B, C, M, N, K, sA, sB, sC, dt, bias=None, sBias=(0, 0), res=None, sRes=(0, 0, 0), nb=(1, 1),
-         act=ACT_NONE, alpha=1.0, c_f32=0, accumulate=0, splitk=1):
+         act=ACT_NONE, alpha=1.0, c_f32=0, accumulate=0, splitk=1, colsum=None):
     """sA = (b1, b2, m, k) element strides; sB = (b1, b2, k, n); sC = (b1, b2, ldc); sRes = (b1, b2, ld)."""
-    call('stj_gemm', _p(A), _p(B), _p(C), _p(bias), _p(res), M, N, K, nb[0], nb[1],
+    call('stj_gemm', _p(A), _p(B), _p(C), _p(bias), _p(res), _p(colsum), M, N, K, nb[0], nb[1],
          sA[0], sA[1], sA[2], sA[3], sB[0], sB[1], sB[2], sB[3], sC[0], sC[1], sC[2],
          sBias[0], sBias[1], sRes[0], sRes[1], sRes[2], act, float(alpha), dt, c_f32, accumulate, splitk, _st())
 
@@ -138,11 +147,9 @@ class _Linear(torch.autograd.Function):
             dx = dx.view(ctx.xshape)
         gw = ctx.gw if ctx.fold is None else torch.zeros((K, N), dtype=torch.float32, device=x2.device)
         gemm(x2, dpre, gw, K, N, M, (0, 0, 1, K), (0, 0, N, 1), (0, 0, N), dt, c_f32=1, accumulate=1,
-             splitk=_splitk(K, N, M))                                                    # dW += x^T dpre
+             splitk=0, colsum=ctx.gb)                                     # dW += x^T dpre ; db += 1^T dpre (fused)
         if ctx.fold is not None:
             ctx.fold(gw)
-        if ctx.gb is not None:
-            call('stj_colsum', _p(dpre), _p(ctx.gb), M, N, N, dt, _st())
         dres = dy if ctx.has_res else None
         return dx, None, None, None, None, None, None, dres, None
 
@@ -171,16 +178,16 @@ def linear_heads_out(x, pw, pb):
 
 
 # ----------------------------------------------------------------------------------------------------
-# batched dense: y[b, z, m, :] = act(x[b, (z|shared), m, :] @ W[z] + bias[z])      (z = waypoint / time index)
+# batched dense over a leading "z" axis (8 waypoints / 8 time steps), one launch for all z:
+#   y[b, z, m, :] = act(x[b, (z|shared), m, :] @ W_z + bias_z)
+# W_z lives at w0 + z*wstride (elements), so the 8 per-waypoint weight sets are addressed in place inside the flat
+# parameter buffer (they are laid out with a constant stride), and so are their gradients.
 # ----------------------------------------------------------------------------------------------------
 class _LinearZ(torch.autograd.Function):
-    """x: [B, Z, M, K] or, with shared_x, [B, M, K] broadcast over z; W: [Z, K, N] (contiguous, compute dtype tensor
-    `wz` derived from a parameter by the caller); bias [Z, N] f32 or None.  Returns y [B, Z, M, N] and accumulates
-    dW into gwz [Z,K,N] f32, db into gbz [Z,N] f32."""
     @staticmethod
-    def forward(ctx, x, trig, wz, bz, gwz, gbz, act, shared_x, fold):
+    def forward(ctx, x, trig, w0, wstride, b0, bstride, gw0, gwstride, gb0, Z, act, shared_x, fold):
         _req_cuda(x)
-        Z, K, N = wz.shape
+        K, N = w0.shape
         x = x.contiguous()
         if shared_x:
             B, M = x.shape[0], x.shape[1]
@@ -190,16 +197,16 @@ class _LinearZ(torch.autograd.Function):
             sA = (Z * M * K, M * K, K, 1)
         dt = _dt(x)
         y = torch.empty((B, Z, M, N), dtype=x.dtype, device=x.device)
-        gemm(x, wz, y, M, N, K, sA, (0, K * N, N, 1), (Z * M * N, M * N, N), dt, bias=bz, sBias=(0, N), nb=(B, Z), act=act)
-        ctx.dims = (B, Z, M, K, N, sA, shared_x, act)
-        ctx.wz, ctx.gwz, ctx.gbz, ctx.fold = wz, gwz, gbz, fold
+        gemm(x, w0, y, M, N, K, sA, (0, wstride, N, 1), (Z * M * N, M * N, N), dt, bias=b0, sBias=(0, bstride), nb=(B, Z), act=act)
+        ctx.dims = (B, Z, M, K, N, shared_x, act, wstride, bstride, gwstride)
+        ctx.w0, ctx.gw0, ctx.gb0, ctx.fold = w0, gw0, gb0, fold
         ctx.save_for_backward(x, y if act == ACT_ELU else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
-        B, Z, M, K, N, sA, shared_x, act = ctx.dims
+        B, Z, M, K, N, shared_x, act, wstride, bstride, gwstride = ctx.dims
         dt = _dt(x)
         dy = dy.contiguous()
         if act == ACT_ELU:
@@ -210,34 +217,26 @@ class _LinearZ(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if shared_x:
-                # dx[b,m,k] = sum_z sum_n dpre[b,z,m,n] W[z,k,n]  -> one GEMM with contraction over (z,n) is not strided-
-                # expressible; accumulate z by z into an f32 buffer, then cast.
+                # dx[b,m,:] = sum_z dpre[b,z,m,:] W_z^T : accumulate z by z into f32, then cast
                 acc = torch.zeros((B, M, K), dtype=torch.float32, device=x.device)
                 for z in range(Z):
-                    gemm(dpre[:, z], ctx.wz[z], acc, M, K, N, (Z * M * N, 0, N, 1), (0, 0, 1, N), (M * K, 0, K), dt,
+                    gemm(dpre[:, z], _poff(ctx.w0, z * wstride), acc, M, K, N, (Z * M * N, 0, N, 1), (0, 0, 1, N), (M * K, 0, K), dt,
                          nb=(B, 1), c_f32=1, accumulate=1)
                 dx = acc.to(x.dtype)
             else:
                 dx = torch.empty_like(x)
-                gemm(dpre, ctx.wz, dx, M, K, N, (Z * M * N, M * N, N, 1), (0, K * N, 1, N), (Z * M * K, M * K, K), dt,
-                     nb=(B, Z))
-        # dW[z][k,n] += sum_b sum_m x[b,z,m,k] dpre[b,z,m,n]: batch over z, loop b (contraction over m per launch)
+                gemm(dpre, ctx.w0, dx, M, K, N, (Z * M * N, M * N, N, 1), (0, wstride, 1, N), (Z * M * K, M * K, K), dt, nb=(B, Z))
+        # dW_z += sum_b x[b,z]^T dpre[b,z] ; db_z += column sums (fused): one launch per b, batched over z
         for b in range(B):
-            xa = x[b]
-            sAx = (0, 0 if shared_x else M * K, 1, K)
-            gemm(xa, dpre[b], ctx.gwz, K, N, M, sAx, (0, M * N, N, 1), (0, K * N, N), dt, nb=(1, Z), c_f32=1,
-                 accumulate=1, splitk=_splitk(K, N, M) if Z * _splitk(K, N, M) <= 4096 else 1)
-        if ctx.gbz is not None:
-            for z in range(Z):
-                dz = dpre[:, z]
-                call('stj_colsum', _p(dz.contiguous()), _p(ctx.gbz[z]), B * M, N, N, dt, _st())
+            gemm(x[b], dpre[b], ctx.gw0, K, N, M, (0, 0 if shared_x else M * K, 1, K), (0, M * N, N, 1), (0, gwstride, N), dt,
+                 nb=(1, Z), c_f32=1, accumulate=1, splitk=0, colsum=ctx.gb0, sBias=(0, bstride))
         if ctx.fold is not None:
             ctx.fold()
-        return dx, None, None, None, None, None, None, None, None
+        return (dx,) + (None,) * 12
 
 
-def linear_z(x, trig, wz, bz, gwz, gbz, act=ACT_NONE, shared_x=False, fold=None):
-    return _LinearZ.apply(x, trig, wz, bz, gwz, gbz, act, shared_x, fold)
+def linear_z(x, trig, w0, wstride, b0, bstride, gw0, gwstride, gb0, Z, act=ACT_NONE, shared_x=False, fold=None):
+    return _LinearZ.apply(x, trig, w0, wstride, b0, bstride, gw0, gwstride, gb0, Z, act, shared_x, fold)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -280,7 +279,7 @@ def tanh_scale(x, s):
 # ----------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g_master, b_master, pg, pb, eps, gather_res):
+    def forward(ctx, x, g_master, b_master, pg, pb, eps, gather_res, group_rows, ngroups, gstride):
         _req_cuda(x)
         x = x.contiguous()
         dt = _dt(x)
@@ -299,24 +298,25 @@ class _LayerNorm(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         call('stj_layernorm_fwd', _p(x), _p(pg.master), _p(pb.master), _p(y), _p(mean), _p(rstd), rows, C, float(eps),
-             gather_res, C0, dt, _st())
-        ctx.pg, ctx.pb, ctx.geo = pg, pb, (rows, C, gather_res, C0)
+             gather_res, C0, group_rows, ngroups, gstride, dt, _st())
+        ctx.pg, ctx.pb, ctx.geo = pg, pb, (rows, C, gather_res, C0, group_rows, ngroups, gstride)
         ctx.save_for_backward(x, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd = ctx.saved_tensors
-        rows, C, gres, C0 = ctx.geo
+        rows, C, gres, C0, group_rows, ngroups, gstride = ctx.geo
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         call('stj_layernorm_bwd', _p(dy), _p(x), _p(ctx.pg.master), _p(mean), _p(rstd), _p(dx), _p(ctx.pg.grad),
-             _p(ctx.pb.grad), rows, C, gres, C0, _dt(x), _st())
-        return dx, None, None, None, None, None, None
+             _p(ctx.pb.grad), rows, C, gres, C0, group_rows, ngroups, gstride, _dt(x), _st())
+        return (dx,) + (None,) * 9
 
 
-def layernorm(x, pg, pb, eps, gather_res=0):
-    return _LayerNorm.apply(x, pg.master, pb.master, pg, pb, eps, gather_res)
+def layernorm(x, pg, pb, eps, gather_res=0, group_rows=0, ngroups=1, gstride=0):
+    """pg/pb: Param of gamma/beta (of group 0 when ngroups > 1; group g's live gstride*g elements further)."""
+    return _LayerNorm.apply(x, pg.master, pb.master, pg, pb, eps, gather_res, group_rows, ngroups, gstride)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -509,7 +509,7 @@ class _GroupedConv3(torch.autograd.Function):
         call('stj_col2im3', _p(dcols), _p(dx), N, H, W, G, Cg, dt, _st())
         # dW[k, g*cog+n] += sum_m cols[m,g,k] dy[m, g*cog+n]
         gemm(cols, dy, pw.grad, K, cog, M, (0, K, 1, G * K), (0, cog, Co, 1), (0, cog, Co), dt, nb=(1, G), c_f32=1,
-             accumulate=1, splitk=_splitk(K, cog, M))
+             accumulate=1, splitk=0)
         call('stj_colsum', _p(dy), _p(pb.grad), M, Co, Co, dt, _st())
         return dx, None, None, None, None, None
 
@@ -556,9 +556,8 @@ class _UpConv(torch.autograd.Function):
                 call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), F_, Hi, Wi, Cin, Cout, dt, _st())
         dweff = torch.zeros((16, Cout, Cin), dtype=torch.float32, device=x.device)
         with _timed(f'upconv_wgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
-            call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), F_, Hi, Wi, Cin, Cout, dt, _st())
+            call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(ctx.pb.grad), F_, Hi, Wi, Cin, Cout, dt, _st())
         call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
-        call('stj_colsum', _p(dpre), _p(ctx.pb.grad), F_ * 4 * Hi * Wi, Cout, Cout, dt, _st())
         return dx, None, None, None, None
 
 
