@@ -1,0 +1,132 @@
+/* strajnet_hip.h -- C ABI of libstrajnet_hip.so (MI355X / gfx950 kernels of the STrajNet hot path).
+ *
+ * The reference (georgeliu233/STrajNet) has no FFI / plugin interface: its hot path is TensorFlow ops issued from
+ * Python (modules.py, FG_MSA.py, trajNet.py, loss.py).  This header is therefore the boundary a maintainer would bind
+ * (ctypes stub in INTEGRATION.md); each entry point names the reference op sequence it replaces (file:line relative
+ * to the reference repo).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller (no allocation, no synchronisation inside; every call is
+ *     one or a few stream-ordered launches on `stream` => hipGraph-capturable); 16-byte alignment where noted.
+ *   - dtype: STJ_F32 = 0 (exact-f32 MFMA, parity mode) or STJ_BF16 = 1 (bf16 storage, f32 accumulate) selects the
+ *     activation type `T`; parameters, biases, LN gamma/beta, tables and all gradients of parameters are f32.
+ *   - return 0 on success, negative stj_status otherwise; message via stj_last_error() (thread local).
+ *   - tensors are NHWC / row-major exactly as in the reference.
+ *   - "+=" outputs are ACCUMULATED with f32 atomics (they point into the flat gradient buffer).
+ */
+#ifndef STRAJNET_HIP_H
+#define STRAJNET_HIP_H
+#include <hip/hip_runtime_api.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum stj_status { STJ_OK = 0, STJ_EINVAL = -1, STJ_ELAUNCH = -2, STJ_EUNSUPPORTED = -3 };
+enum stj_dtype { STJ_F32 = 0, STJ_BF16 = 1 };
+enum stj_act { STJ_ACT_NONE = 0, STJ_ACT_GELU = 1, STJ_ACT_ELU = 2 };
+enum stj_unary { STJ_U_GELU = 1, STJ_U_ELU = 2, STJ_U_TANH_SCALE = 3 };
+
+const char* stj_last_error(void);
+int stj_abi_version(void);
+
+/* Batched strided GEMM with fused epilogue:  C[z] = act(alpha * A[z] B[z] + bias[z]) + res[z],  z = z1*nb2 + z2.
+ * Replaces Keras Dense (modules.py:36-37,76-79,270-271), 1x1 Conv2D (FG_MSA.py:54-64), tfa MultiHeadAttention
+ * projections and q k^T / attn v einsums (trajNet.py:33,42,71,80,195,225; FG_MSA.py:147,176), the time-collapsed
+ * Conv3D(8,1,1) skips (modules.py:693-717,750-765) and all their dgrad/wgrad (tape.gradient, train.py:223).
+ * Element strides: A(m,k) at sAm*m + sAk*k (+ batch), B(k,n) at sBk*k + sBn*n; C row-major with ldc.
+ * c_f32: C is f32; accumulate: C += (f32 atomics; splitk may be >1, 0 = auto); colsum (optional): colsum[z][n] +=
+ * sum_k B[z](k,n) (the bias gradient belonging to dW = x^T dY), addressed with the bias batch strides. */
+int stj_gemm(const void* A, const void* B, void* C, const float* bias, const void* res, float* colsum,
+             int M, int N, int K, int nb1, int nb2,
+             long long sAb1, long long sAb2, long long sAm, long long sAk,
+             long long sBb1, long long sBb2, long long sBk, long long sBn,
+             long long sCb1, long long sCb2, long long ldc,
+             long long sBias1, long long sBias2, long long sRes1, long long sRes2, long long ldres,
+             int act, float alpha, int dtype, int c_f32, int accumulate, int splitk, hipStream_t stream);
+/* out[n] += sum_m X[m,n]  (bias gradients of the conv heads). */
+int stj_colsum(const void* X, float* out, int M, int N, long long ld, int dtype, hipStream_t stream);
+/* f32 <-> bf16 copy (bf16 shadow of the flat parameter buffer). */
+int stj_cast(const void* src, int sdtype, void* dst, int ddtype, long long n, hipStream_t stream);
+
+/* Gelu (tanh form, modules.py:18-29 / FG_MSA.py:7-18), ELU (Keras activation='elu'), tanh*scale (FG_MSA.py:116-117).
+ * bwd: saved = x for GELU, y for ELU / tanh. */
+int stj_unary_fwd(const void* x, void* y, long long n, int op, float p0, int dtype, hipStream_t stream);
+int stj_unary_bwd(const void* dy, const void* saved, void* dx, long long n, int op, float p0, int dtype, hipStream_t stream);
+/* GlobalMaxPooling1D over the 11 time steps (trajNet.py:34,44); backward splits ties evenly like tf.reduce_max. */
+int stj_maxpool_fwd(const void* x, void* y, int* idx, long long outer, int Tn, int C, int dtype, hipStream_t stream);
+int stj_maxpool_bwd(const void* dy, const void* x, const void* y, void* dx, long long outer, int Tn, int C, int dtype, hipStream_t stream);
+
+/* Keras LayerNormalization (modules.py:179,184,272,433,517,557 eps 1e-5; FG_MSA.py:52, trajNet.py:72-73,110-111,
+ * 206-207 eps 1e-3).  gather_res != 0 fuses the PatchMerging 2x2 gather-concat (modules.py:282-287): x is
+ * [B,res,res,C0], C = 4*C0.  group_rows/ngroups/gstride: row runs of group_rows rows use parameter set
+ * (run % ngroups) at gamma + g*gstride (the 8 per-waypoint LayerNorms, trajNet.py:257). */
+int stj_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      long long rows, int C, float eps, int gather_res, int C0, long long group_rows, int ngroups,
+                      long long gstride, int dtype, hipStream_t stream);
+int stj_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                      void* dx, float* dgamma, float* dbeta, long long rows, int C, int gather_res, int C0,
+                      long long group_rows, int ngroups, long long gstride, int dtype, hipStream_t stream);
+
+/* Fused (shifted-)window attention, window 8x8, head_dim 32: roll + window_partition + softmax(q k^T*scale +
+ * relative_position_bias[+shift mask]) v + window_reverse + roll (modules.py:49-63,103-134,189-216,229-255).
+ * qkv [B,res*res,3*heads*32] in original token order, table f32 [225,heads], out [B,res*res,heads*32]. */
+int stj_win_attn_fwd(const void* qkv, const float* table, void* out, int B, int res, int heads, int shift,
+                     int dtype, hipStream_t stream);
+int stj_win_attn_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable,
+                     int B, int res, int heads, int shift, int dtype, hipStream_t stream);
+
+/* Row softmax of the global attentions: P = softmax(S + bias + (-10e9 where !(qvalid&kvalid))) (tfa MHA mask
+ * semantics, f32 add); S f32 [batch,H,Nq,Nk] (Nk <= 256).  bwd: dS = P*(dP - sum(P dP)). */
+int stj_softmax_fwd(const float* S, void* P, const int* qvalid, const int* kvalid, const float* bias,
+                    long long batch, int H, int Nq, int Nk, int dtype, hipStream_t stream);
+int stj_softmax_bwd(const void* P, const float* dP, void* dS, long long rows, int Nk, int dtype, hipStream_t stream);
+/* FG-MSA relative-position bias: bilinear `sample` of rpe_table at (query - key - offset) displacements
+ * (FG_MSA.py:150-172 via occu_metric.py:345-409 + tfa_image.py:87-173).  off [B,G,H*W,2], table f32 [2H-1,2W-1,G],
+ * bias f32 [B,G,HW,HW]; bwd: dtable +=, doff f32 [B,G,HW,2] (written). */
+int stj_fg_bias_fwd(const void* off, const float* table, float* bias, int B, int G, int Hh, int Ww, int dtype, hipStream_t stream);
+int stj_fg_bias_bwd(const void* off, const float* table, const void* dbias, float* dtable, float* doff,
+                    int B, int G, int Hh, int Ww, int dtype, hipStream_t stream);
+
+/* Decoder: UpSampling3D(1,2,2) nearest + Conv2D 3x3 SAME + bias + ELU (modules.py:746-748,732-735) with the upsample
+ * folded into 16 effective 2x2-tap matrices.  prep: W f32 [3,3,Cin,Cout] -> Wf [16,Cout,Cin], Wd [16,Cin,Cout] (T).
+ * fwd: X [F,Hi,Wi,Cin] -> Y [F,2Hi,2Wi,Cout].  dgrad: dP (= dY*ELU') -> dX.  wgrad: dWeff f32 [16,Cout,Cin] += (zeroed
+ * by the caller), dbias f32 [Cout] += ; fold: dW [3,3,Cin,Cout] += fold(dWeff). */
+int stj_upconv_prep(const float* W, void* Wf, void* Wd, int Cin, int Cout, int dtype, hipStream_t stream);
+int stj_upconv_fold(const float* dWeff, float* dW, int Cin, int Cout, hipStream_t stream);
+int stj_upconv_fwd(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin,
+                   int Cout, int act, int dtype, hipStream_t stream);
+int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout,
+                     int dtype, hipStream_t stream);
+int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout,
+                     int dtype, hipStream_t stream);
+/* Output heads: Conv2D 3x3 SAME C->2, no activation (modules.py:767-770), written with strides straight into the
+ * [B,H,W,32] f32 model output (concat + transpose of modules.py:770,838).  Y element (b,t,y,x,o) at
+ * Y + b*y_bstride + t*y_tstride + (y*W+x)*y_pstride + o. */
+int stj_outconv_fwd(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
+                    long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream);
+int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww,
+                    int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream);
+/* PatchEmbed Conv2D k=4 s=4 VALID as im2col (+ f32->T cast, + stride-2 pick of ogm[...,0]; modules.py:430-431,572). */
+int stj_im2col_patch(const float* src, void* dst, int B, int H, int W, int Cin, long long pix_stride, int ch_stride,
+                     int dtype, hipStream_t stream);
+/* grouped 3x3 SAME conv of FG-MSA (FG_MSA.py:51) as im2col / col2im around the batched GEMM. */
+int stj_im2col3(const void* x, void* cols, int N, int H, int W, int G, int Cg, int dtype, hipStream_t stream);
+int stj_col2im3(const void* dcols, void* dx, int N, int H, int W, int G, int Cg, int dtype, hipStream_t stream);
+
+/* OGMFlow_loss (loss.py:50-170 with train.py:195-196 flags).  All tensors f32: logits [B,H,W,32] (channel 4k+{0,1,2,3},
+ * train.py:105-123), gt_obs/gt_occ/origin [B,8,H,W,1], gt_flow [B,8,H,W,2].
+ * auc_gate: res_k = [Keras PR-AUC(true_all, warp(origin, id+gt_flow)*true_all) > 0] (loss.py:127-137); hist int[8*202] scratch.
+ * fwd: sums f32[40] scratch, loss f32[4] = observed_xe, occluded_xe, flow, flow_warp_xe; coef f32[32] for bwd.
+ * bwd: dlogits = sum_j upstream[j] * dloss_j/dlogits. */
+int stj_loss_auc_gate(const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
+                      int* hist, float* gate, float* auc_out, int B, int H, int W, hipStream_t stream);
+int stj_loss_fwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
+                 const float* gate, float* sums, float* loss, float* coef, int B, int H, int W, float ogm_w, float occ_w,
+                 float flow_origin_w, float replica, int use_warp, hipStream_t stream);
+int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
+                 const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int use_warp, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

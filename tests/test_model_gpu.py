@@ -134,3 +134,25 @@ def test_cpu_tensor_rejected():
     from strajnet_amd import ops
     with pytest.raises(RuntimeError):
         ops.gelu(torch.zeros(8))
+
+
+def test_golden_cfg256_f32():
+    """Full-size cfg-256 (BASELINE configs[0] geometry) against the committed golden fixture (tests/golden, made by the
+    oracle): logits subsample, per-row checksums and the 4 loss scalars."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'strajnet_256_b1.npz'))
+    cfg = dict(CFG128, input_size=(256, 256))
+    model, w, x, xt = _setup(cfg, 1, torch.float32, seed=int(g['weight_seed']))
+    with torch.no_grad():
+        out = _fwd(model, xt)
+        loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(256, 256, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+        d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+    y = out.cpu().numpy().astype(np.float64)
+    err = np.abs(y[0, ::4, ::4, :] - g['logits_sub']).max()
+    rs = np.abs(y[0].sum((1, 2)) - g['logits_rowsum']).max()
+    _report(f'golden cfg-256 B=1 f32: max-abs err on subsample {err:.3e}, row-checksum err {rs:.3e} '
+            f'(|logit| max {float(g["logits_abs_max"]):.2f})')
+    assert err < ABS_TOL_F32
+    assert rs < 256 * 32 * 1e-4
+    for i, k in enumerate(('observed_xe', 'occluded_xe', 'flow', 'flow_warp_xe')):
+        assert abs(float(d[k]) - float(g['loss'][i])) < 1e-4 * abs(float(g['loss'][i])) + 1e-5
