@@ -390,6 +390,11 @@ static int upconv_fwd_launch(const void* X, const void* Wf, const float* bias, v
 }
 bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        hipStream_t st);   // conv_ws.hip
+bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
+bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
+                          long long y_bs, long long y_ts, long long y_ps, hipStream_t st);
+bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
+                          int Tn, long long y_bs, long long y_ts, long long y_ps, hipStream_t st);
 static bool ws_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("STJ_NO_WS"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -447,6 +452,8 @@ extern "C" int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, flo
                                 int dtype, hipStream_t stream) {
   int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
   if (e) return e;
+  if (dtype == STJ_BF16 && ws_enabled() && upconv_wgrad_tr_try(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream))
+    return stj_check_launch("stj_upconv_wgrad(tr)");
   return dtype == STJ_BF16 ? upconv_wgrad_launch<bf16>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream)
                            : upconv_wgrad_launch<float>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream);
 }
@@ -604,6 +611,8 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* X, const floa
 extern "C" int stj_outconv_fwd(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                                long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream) {
   if (Hh % OC_T || Ww % OC_T || C % 8) { stj_set_error("outconv: H,W must be multiples of 16 and C of 8"); return STJ_EINVAL; }
+  if (dtype == STJ_BF16 && ws_enabled() && outconv_fwd_mfma_try(X, W, bias, Y, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, stream))
+    return stj_check_launch("stj_outconv_fwd(mfma)");
   const size_t lds = (size_t)(18 * 18 * (C + 1) + 9 * C * 2) * 4;
   if (lds > 160 * 1024) { stj_set_error("outconv: C=%d too large for LDS", C); return STJ_EUNSUPPORTED; }
   const int grid = F * (Hh / OC_T) * (Ww / OC_T);
@@ -619,6 +628,8 @@ extern "C" int stj_outconv_fwd(const void* X, const float* W, const float* bias,
 extern "C" int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww,
                                int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream) {
   if (Hh % OC_T || Ww % OC_T || C % 8) { stj_set_error("outconv: H,W must be multiples of 16 and C of 8"); return STJ_EINVAL; }
+  if (dtype == STJ_BF16 && ws_enabled() && outconv_bwd_mfma_try(X, W, dY, dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, stream))
+    return stj_check_launch("stj_outconv_bwd(mfma)");
   const size_t lds = (size_t)(18 * 18 * (C + 1) + 9 * C * 2 + 18 * 18 * 2) * 4;
   if (lds > 160 * 1024 || 9 * C > 1024) { stj_set_error("outconv: C=%d too large", C); return STJ_EUNSUPPORTED; }
   const int grid = min(1024, F * (Hh / OC_T) * (Ww / OC_T));

@@ -191,3 +191,398 @@ bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y
   if (Cin == 128) return variant == 0 ? ws_launch<4, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st) : ws_launch<4, 2, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
   return false;
 }
+
+// =====================================================================================================
+// Weight gradient, v2 (bf16): output-stationary, both operands read with ds_read_b64_tr_b16.
+//   dWeff[a,b,r,s][co][ci] = sum_{f,i,j} dP[f,2i+a,2j+b,co] * X[f,i+a-1+r,j+b-1+s,ci]
+// MFMA view: D[m=co][n=ci] += A[m][k=pixel] B[k=pixel][n].  Both operands have the contraction (pixel) axis as the
+// SLOW axis of their natural [pixel][channel] LDS tiles; the gfx950 LDS transpose read delivers, per lane (channel
+// l&15), 4 consecutive pixels -- two of them form one 16x16x32 fragment (probe: tools/probes/tr16_probe.hip).
+// The v1 kernel assembled fragments from 8 ds_read_u16 each and was LDS-bound (PMC: LDS active 184M cycles,
+// 45 % conflicts vs 151M MFMA-busy cycles).  One block = (pixel strip, output phase, cout tile x cin tile), one wave =
+// one of the phase's 4 taps; chunks of 4 low-res rows x 32 columns per barrier pair, next chunk prefetched in registers.
+// =====================================================================================================
+typedef __attribute__((ext_vector_type(4))) short ws_s16x4;
+__device__ __forceinline__ ws_s16x4 lds_tr16(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws_s16x4*)(p));
+}
+__device__ __forceinline__ s16x8 tr_frag(const bf16* p0, const bf16* p1) {
+  const ws_s16x4 lo = lds_tr16(p0), hi = lds_tr16(p1);
+  return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+#define WG2_ROWS 4
+#define WG2_W 32
+template <int FO, int FI>
+__global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dP,
+                                                              float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin,
+                                                              int Cout, int chunks_per_block) {
+  constexpr int BO = FO * 16, BI = FI * 16;
+  constexpr int LDO = BO + 8, LDI = BI + 8;
+  constexpr int XW = WG2_W + 2, XR = WG2_ROWS + 1;
+  constexpr int NPX = WG2_ROWS * WG2_W;
+  constexpr int DY_CH = NPX * (BO / 8), X_CH = XR * XW * (BI / 8);
+  constexpr int NCH = (DY_CH + X_CH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf16 dYs[NPX * LDO];
+  __shared__ __attribute__((aligned(16))) bf16 Xs[XR * XW * LDI];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int a = blockIdx.y >> 1, b = blockIdx.y & 1;
+  const int r = w >> 1, s = w & 1;
+  const int g = lane >> 4, p = lane & 15;
+  const int cin_tiles = (Cin + BI - 1) / BI;
+  const int co0 = (blockIdx.z / cin_tiles) * BO, ci0 = (blockIdx.z % cin_tiles) * BI;
+  const int segs = Wi / WG2_W, rgs = Hi / WG2_ROWS;
+  const long long nchunks = (long long)F * rgs * segs;
+  const long long c_begin = (long long)blockIdx.x * chunks_per_block;
+  const long long c_end = min(nchunks, c_begin + chunks_per_block);
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+
+  f32x4 acc[FO][FI];
+#pragma unroll
+  for (int m = 0; m < FO; ++m)
+#pragma unroll
+    for (int n = 0; n < FI; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_db = dbias != nullptr && ci0 == 0 && lane < BO;
+  float dbacc = 0.f;
+
+  uint4 pre[NCH];
+  auto prefetch = [&](long long c) {
+    const int seg = (int)(c % segs); long long t = c / segs;
+    const int i0 = (int)(t % rgs) * WG2_ROWS; const int f = (int)(t / rgs);
+    const int j0 = seg * WG2_W;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int q = tid + u * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < DY_CH) {
+        const int px = q / (BO / 8), ch = (q % (BO / 8)) * 8;
+        const int ri = px / WG2_W, cj = px % WG2_W;
+        if (co0 + ch < Cout)
+          v = *reinterpret_cast<const uint4*>(dP + (((long long)f * Ho + 2 * (i0 + ri) + a) * Wo + 2 * (j0 + cj) + b) * Cout + co0 + ch);
+      } else if (q < DY_CH + X_CH) {
+        const int q2 = q - DY_CH;
+        const int px = q2 / (BI / 8), ch = (q2 % (BI / 8)) * 8;
+        const int gy = i0 + a - 1 + px / XW, gx = j0 + b - 1 + px % XW;
+        if (gy >= 0 && gy < Hi && gx >= 0 && gx < Wi && ci0 + ch < Cin)
+          v = *reinterpret_cast<const uint4*>(X + (((long long)f * Hi + gy) * Wi + gx) * Cin + ci0 + ch);
+      }
+      pre[u] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int q = tid + u * 256;
+      if (q < DY_CH) *reinterpret_cast<uint4*>(dYs + (q / (BO / 8)) * LDO + (q % (BO / 8)) * 8) = pre[u];
+      else if (q < DY_CH + X_CH) { const int q2 = q - DY_CH; *reinterpret_cast<uint4*>(Xs + (q2 / (BI / 8)) * LDI + (q2 % (BI / 8)) * 8) = pre[u]; }
+    }
+  };
+
+  if (c_begin < c_end) { prefetch(c_begin); commit(); }
+  __syncthreads();
+  // per-lane tr-read bases: lane p of group g addresses pixel (8g + p/4 [+4]) and channels 4*(p%4).. of a 16-channel block
+  const int kpx = 8 * g + (p >> 2), kch = 4 * (p & 3);
+  for (long long c = c_begin; c < c_end; ++c) {
+    if (c + 1 < c_end) prefetch(c + 1);
+#pragma unroll
+    for (int rr = 0; rr < WG2_ROWS; ++rr) {
+      s16x8 af[FO], bfr[FI];
+      const bf16* ab = dYs + (rr * WG2_W + kpx) * LDO + kch;
+#pragma unroll
+      for (int m = 0; m < FO; ++m) af[m] = tr_frag(ab + m * 16, ab + 4 * LDO + m * 16);
+      const bf16* bb = Xs + ((rr + r) * XW + kpx + s) * LDI + kch;
+#pragma unroll
+      for (int n = 0; n < FI; ++n) bfr[n] = tr_frag(bb + n * 16, bb + 4 * LDI + n * 16);
+#pragma unroll
+      for (int m = 0; m < FO; ++m)
+#pragma unroll
+        for (int n = 0; n < FI; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[m]), __builtin_bit_cast(bf16x8_t, bfr[n]), acc[m][n], 0, 0, 0);
+    }
+    if (do_db) {                       // wave w sums row w of the chunk
+      float sdb = 0.f;
+      for (int q = 0; q < WG2_W; ++q) sdb += bf2f(dYs[(w * WG2_W + q) * LDO + lane].v);
+      dbacc += sdb;
+    }
+    __syncthreads();
+    if (c + 1 < c_end) commit();
+    __syncthreads();
+  }
+  if (do_db && co0 + lane < Cout) atomicAdd(dbias + co0 + lane, dbacc);
+  const int pt = a * 8 + b * 4 + r * 2 + s;
+#pragma unroll
+  for (int m = 0; m < FO; ++m)
+#pragma unroll
+    for (int n = 0; n < FI; ++n) {
+      const int ci = ci0 + n * 16 + p;
+      if (ci >= Cin) continue;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = co0 + m * 16 + g * 4 + rg;
+        if (co < Cout) atomicAdd(dWeff + ((long long)pt * Cout + co) * Cin + ci, acc[m][n][rg]);
+      }
+    }
+}
+
+// returns true when handled (bf16, Wi % 32 == 0, Hi % 4 == 0, channels % 8 == 0)
+bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  if (Wi % WG2_W || Hi % WG2_ROWS || Cin % 8 || Cout % 8) return false;
+  const long long nchunks = (long long)F * (Hi / WG2_ROWS) * (Wi / WG2_W);
+  if (Cout <= 48 && Cin <= 96) {
+    int strips = (int)min(nchunks, (long long)256);
+    const int cpb = (int)((nchunks + strips - 1) / strips);
+    strips = (int)((nchunks + cpb - 1) / cpb);
+    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6>), dim3(strips, 4, 1), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb);
+  } else {
+    const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    int strips = (int)min(nchunks, (long long)max(1, 1024 / (4 * tiles)));
+    const int cpb = (int)((nchunks + strips - 1) / strips);
+    strips = (int)((nchunks + cpb - 1) / cpb);
+    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<4, 4>), dim3(strips, 4, tiles), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb);
+  }
+  return true;
+}
+
+// =====================================================================================================
+// Output heads on MFMA (bf16): Conv2D 3x3 SAME 48 -> 2 (reference modules.py:767-770) written straight into the
+// [B,H,W,32] f32 result, and its backward.  N = 2 is far too narrow for a GEMM tile, so the 2 output channels ride in
+// rows 0..1 of a 16-row MFMA A operand that stays in registers (9 taps x (one 16x16x32 + one 16x16x16 step = 48
+// channels exactly)); pixels are the N dimension and come from an 18x18 halo tile in LDS.  HBM-bound by design:
+// 403 MB read per head at B=8.  The first (VALU) version ran at 0.48 ms fwd / 1.2 ms bwd per head (profiles/r01_b_*).
+// =====================================================================================================
+#define OCM_T 16
+#define OCM_H 18
+template <int C>
+__global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const bf16* __restrict__ X, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, float* __restrict__ Y, int F, int Hh,
+                                                               int Ww, int Tn, long long y_bs, long long y_ts, long long y_ps) {
+  static_assert(C == 48, "specialised for 48 input channels (32 + 16)");
+  constexpr int LDH = C + 8;
+  constexpr int CPP = C / 8, NCH = (OCM_H * OCM_H * CPP + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf16 halo[OCM_H * OCM_H * LDH + 64];   // pads + tail stay zero (read by the padded 2nd k-step)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
+  // stationary weights: row m = ln is output channel o (only o < 2 non-zero)
+  s16x8 a32[9];
+  s16x8 a16[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float v[8], u[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ln < 2 ? W[(t * C + 8 * g + j) * 2 + ln] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] = (ln < 2 && g < 2) ? W[(t * C + 32 + 8 * g + j) * 2 + ln] : 0.f;   // channels 32..47, rest zero
+    const uint32_t p0 = pack2bf(v[0], v[1]), p1 = pack2bf(v[2], v[3]), p2 = pack2bf(v[4], v[5]), p3 = pack2bf(v[6], v[7]);
+    a32[t] = __builtin_bit_cast(s16x8, make_uint4(p0, p1, p2, p3));
+    a16[t] = __builtin_bit_cast(s16x8, make_uint4(pack2bf(u[0], u[1]), pack2bf(u[2], u[3]), pack2bf(u[4], u[5]), pack2bf(u[6], u[7])));
+  }
+  const float b0 = bias[0], b1 = bias[1];
+  const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T, ntiles = F * tiles_x * tiles_y;
+  uint4 pre[NCH];
+  auto prefetch = [&](int tile) {
+    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, f = t2 / tiles_y;
+    const bf16* Xf = X + (long long)f * Hh * Ww * C;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int q = tid + u * 256;
+      const int px = q / CPP, ch = (q % CPP) * 8;
+      const int gy = ty * OCM_T + px / OCM_H - 1, gx = tx * OCM_T + px % OCM_H - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < OCM_H * OCM_H * CPP && gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) v = *reinterpret_cast<const uint4*>(Xf + ((long long)gy * Ww + gx) * C + ch);
+      pre[u] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int q = tid + u * 256;
+      if (q < OCM_H * OCM_H * CPP) *reinterpret_cast<uint4*>(halo + (q / CPP) * LDH + (q % CPP) * 8) = pre[u];
+    }
+  };
+  for (int i = tid; i < OCM_H * OCM_H * LDH + 64; i += 256) halo[i].v = 0;
+  __syncthreads();
+  int tile = blockIdx.x;
+  if (tile < ntiles) { prefetch(tile); commit(); }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) prefetch(next);
+    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, f = t2 / tiles_y;
+    const int bb = f / Tn, tt = f % Tn;
+    float* Yb = Y + bb * y_bs + tt * y_ts;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = 4 * w + rr;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const bf16* hp = halo + ((row + t / 3) * OCM_H + ln + t % 3) * LDH;
+        const s16x8 x32 = *reinterpret_cast<const s16x8*>(hp + 8 * g);
+        const s16x8 x16 = *reinterpret_cast<const s16x8*>(hp + 32 + 8 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a32[t]), __builtin_bit_cast(bf16x8_t, x32), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a16[t]), __builtin_bit_cast(bf16x8_t, x16), acc, 0, 0, 0);
+      }
+      if (g == 0) {
+        float* dst = Yb + ((long long)(ty * OCM_T + row) * Ww + tx * OCM_T + ln) * y_ps;
+        *reinterpret_cast<float2*>(dst) = make_float2(acc[0] + b0, acc[1] + b1);
+      }
+    }
+    __syncthreads();
+    if (next < ntiles) commit();
+    __syncthreads();
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __restrict__ X, const float* __restrict__ W,
+                                                               const float* __restrict__ dY, bf16* __restrict__ dX, float* dW, float* db,
+                                                               int F, int Hh, int Ww, int Tn, long long y_bs, long long y_ts, long long y_ps) {
+  static_assert(C == 48, "specialised for 48 channels");
+  constexpr int LDH = C + 8;
+  constexpr int CPP = C / 8, NCH = (OCM_H * OCM_H * CPP + 255) / 256;
+  constexpr int NDY = (OCM_H * OCM_H + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf16 halo[OCM_H * OCM_H * LDH];
+  __shared__ __attribute__((aligned(16))) float dys[OCM_H * OCM_H * 2];
+  __shared__ __attribute__((aligned(16))) bf16 dyb[OCM_T * OCM_T * 16];      // [pixel][16] bf16, columns 0..1 = dY, rest 0 (B operand of dW)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
+  // dX weights: A[m = c][k = (tap, o)], k = 2*tap + o < 18 ; lane row c = mf*16 + ln, k = 8g + j
+  s16x8 ax[3];
+#pragma unroll
+  for (int mf = 0; mf < 3; ++mf) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; v[j] = k < 18 ? W[((k >> 1) * C + mf * 16 + ln) * 2 + (k & 1)] : 0.f; }
+    ax[mf] = __builtin_bit_cast(s16x8, make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])));
+  }
+  f32x4 wacc[9][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mf = 0; mf < 3; ++mf) wacc[t][mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float db0 = 0.f, db1 = 0.f;
+  for (int i = tid; i < OCM_T * OCM_T * 16; i += 256) dyb[i].v = 0;
+  const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T, ntiles = F * tiles_x * tiles_y;
+  uint4 pre[NCH];
+  float2 pdy[NDY];
+  auto prefetch = [&](int tile) {
+    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, f = t2 / tiles_y;
+    const bf16* Xf = X + (long long)f * Hh * Ww * C;
+    const float* dYf = dY + (f / Tn) * y_bs + (f % Tn) * y_ts;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int q = tid + u * 256;
+      const int px = q / CPP, ch = (q % CPP) * 8;
+      const int gy = ty * OCM_T + px / OCM_H - 1, gx = tx * OCM_T + px % OCM_H - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < OCM_H * OCM_H * CPP && gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) v = *reinterpret_cast<const uint4*>(Xf + ((long long)gy * Ww + gx) * C + ch);
+      pre[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int q = tid + u * 256;
+      const int gy = ty * OCM_T + q / OCM_H - 1, gx = tx * OCM_T + q % OCM_H - 1;
+      float2 v = make_float2(0.f, 0.f);
+      if (q < OCM_H * OCM_H && gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) v = *reinterpret_cast<const float2*>(dYf + ((long long)gy * Ww + gx) * y_ps);
+      pdy[u] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int q = tid + u * 256;
+      if (q < OCM_H * OCM_H * CPP) *reinterpret_cast<uint4*>(halo + (q / CPP) * LDH + (q % CPP) * 8) = pre[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int q = tid + u * 256;
+      if (q < OCM_H * OCM_H) {
+        *reinterpret_cast<float2*>(dys + 2 * q) = pdy[u];
+        const int hy = q / OCM_H, hx = q % OCM_H;
+        if (hy >= 1 && hy <= OCM_T && hx >= 1 && hx <= OCM_T)
+          *reinterpret_cast<uint32_t*>(dyb + ((hy - 1) * OCM_T + hx - 1) * 16) = pack2bf(pdy[u].x, pdy[u].y);
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) { prefetch(tile); commit(); }
+  __syncthreads();
+  const int kpx = 8 * (g & 1) + (ln >> 2), kch = 4 * (ln & 3);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) prefetch(next);
+    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, f = t2 / tiles_y;
+    bf16* dXf = dX + (long long)f * Hh * Ww * C;
+    // ---- dX rows 4w .. 4w+3 ----
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = 4 * w + rr;
+      // B[k = 2*tap + o][n = pixel ln] = dY[(row,ln) - off(tap)][o]; this lane supplies taps 4g .. 4g+3
+      float2 d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = 4 * g + j;
+        d[j] = t < 9 ? *reinterpret_cast<const float2*>(dys + 2 * ((row + 2 - t / 3) * OCM_H + ln + 2 - t % 3)) : make_float2(0.f, 0.f);
+      }
+      const s16x8 bx = __builtin_bit_cast(s16x8, make_uint4(pack2bf(d[0].x, d[0].y), pack2bf(d[1].x, d[1].y), pack2bf(d[2].x, d[2].y), pack2bf(d[3].x, d[3].y)));
+#pragma unroll
+      for (int mf = 0; mf < 3; ++mf) {
+        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax[mf]), __builtin_bit_cast(bf16x8_t, bx), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        *reinterpret_cast<uint2*>(dXf + ((long long)(ty * OCM_T + row) * Ww + tx * OCM_T + ln) * C + mf * 16 + 4 * g) =
+            make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+      }
+    }
+    // ---- dW: this wave's 4 rows = 2 k-steps of 32 pixels (rows y, y+1) ----
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int y = 4 * w + 2 * kk + (g >> 1);          // tile row of this lane's k group
+      // B[k = pixel][n = o]: lane n = ln reads dyb[pixel 8g'+j][n]
+      const bf16* bp = dyb + ((4 * w + 2 * kk) * OCM_T + 8 * g) * 16 + ln;       // pixels (row y0, 8g..) linear index = y0*16 + 8g + j (g>=2 -> next row)
+      s16x8 bw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bw[j] = (short)bp[j * 16].v;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const bf16* ap = halo + ((y + t / 3) * OCM_H + kpx + t % 3) * LDH + kch;
+#pragma unroll
+        for (int mf = 0; mf < 3; ++mf) {
+          const s16x8 aw = tr_frag(ap + mf * 16, ap + 4 * LDH + mf * 16);
+          wacc[t][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), __builtin_bit_cast(bf16x8_t, bw), wacc[t][mf], 0, 0, 0);
+        }
+      }
+    }
+    {
+      const int py = tid / OCM_T, px = tid % OCM_T;
+      const float2 v = *reinterpret_cast<const float2*>(dys + 2 * ((py + 1) * OCM_H + px + 1));
+      db0 += v.x; db1 += v.y;
+    }
+    __syncthreads();
+    if (next < ntiles) commit();
+    __syncthreads();
+  }
+  // D[m = c][n = o]: lanes with ln < 2 hold dW[t][mf*16 + 4g + r][ln]
+  if (ln < 2) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int mf = 0; mf < 3; ++mf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(dW + (t * C + mf * 16 + 4 * g + r) * 2 + ln, wacc[t][mf][r]);
+  }
+  db0 = wave_sum(db0); db1 = wave_sum(db1);
+  if (lane == 0) { atomicAdd(db, db0); atomicAdd(db + 1, db1); }
+}
+
+bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
+                          long long y_bs, long long y_ts, long long y_ps, hipStream_t st) {
+  if (C != 48 || Hh % OCM_T || Ww % OCM_T || (y_ps & 1) || (((uintptr_t)Y) & 7)) return false;
+  const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
+  hipLaunchKernelGGL(outconv_fwd_mfma_kernel<48>, dim3(min(ntiles, 1024)), dim3(256), 0, st, (const bf16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
+  return true;
+}
+bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
+                          int Tn, long long y_bs, long long y_ts, long long y_ps, hipStream_t st) {
+  if (C != 48 || Hh % OCM_T || Ww % OCM_T || (y_ps & 1) || (((uintptr_t)dY) & 7)) return false;
+  const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
+  hipLaunchKernelGGL(outconv_bwd_mfma_kernel<48>, dim3(min(ntiles, 512)), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, dW, db, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
+  return true;
+}
