@@ -106,42 +106,50 @@ __global__ __launch_bounds__(256) void fg_bias_fwd_kernel(const T* off, const fl
   }
 }
 
-// dbias (type T, = dS of the attention) -> dtable (f32 atomics), doff [B,G,HW,2] (f32 atomics)
+// dbias (type T, = dS of the attention) -> dtable (f32 atomics), doff [B,G,HW,2] (f32, written).
+// One workgroup per (b,g); thread = key k, loop over queries q: dbias[q][k] is read coalesced across threads, the
+// per-key offset gradient accumulates in registers (no cross-lane reduction), the table gradient in an LDS copy of the
+// (2H-1)x(2W-1) table that is flushed with one global atomic per entry.  (v1 swept q across lanes with stride-HW reads:
+// 0.94 ms at B=8.)
 template <typename T>
 __global__ __launch_bounds__(256) void fg_bias_bwd_kernel(const T* off, const float* table, const T* dbias, float* dtable,
                                                           float* doff, int B, int G, int Hh, int Ww) {
+  extern __shared__ float fg_lds[];
   const int HW = Hh * Ww, TH = 2 * Hh - 1, TW = 2 * Ww - 1;
-  // one wave per (b,g,k): lanes sweep q, reduce doff over q
-  const int lane = threadIdx.x & 63;
-  const long long total = (long long)B * G * HW;
-  for (long long i = blockIdx.x * 4ll + (threadIdx.x >> 6); i < total; i += gridDim.x * 4ll) {
-    const int k = (int)(i % HW); long long t = i / HW;
-    const int g = (int)(t % G); const int b = (int)(t / G);
-    const float off0 = ldf(off + i * 2), off1 = ldf(off + i * 2 + 1);
-    const float* img = table + g;
+  float* tbl = fg_lds;                 // table_g values
+  float* dtb = fg_lds + TH * TW;       // gradient accumulator
+  const int bg = blockIdx.x, g = bg % G;
+  for (int i = threadIdx.x; i < TH * TW; i += 256) { tbl[i] = table[i * G + g]; dtb[i] = 0.f; }
+  __syncthreads();
+  for (int k = threadIdx.x; k < HW; k += 256) {
+    const long long ok = ((long long)bg * HW + k) * 2;
+    const float off0 = ldf(off + ok), off1 = ldf(off + ok + 1);
+    const int ik = k / Ww, jk = k % Ww;
     float d0 = 0.f, d1 = 0.f;
-    for (int q = lane; q < HW; q += 64) {
-      const float go = ldf(dbias + (((long long)b * G + g) * HW + q) * HW + k);
-      const float x = (float)(q / Ww - k / Ww) - off1 + 1.f;
-      const float y = (float)(q % Ww - k % Ww) - off0 + 1.f;
+    for (int q = 0; q < HW; ++q) {
+      const float go = ldf(dbias + ((long long)bg * HW + q) * HW + k);
+      const float x = (float)(q / Ww - ik) - off1 + 1.f;
+      const float y = (float)(q % Ww - jk) - off0 + 1.f;
       Bil c = bil_setup(x, y, TH + 2, TW + 2);
-      const float tl = pad_at(img, TH, TW, G, c.y0, c.x0), tr = pad_at(img, TH, TW, G, c.y0, c.x0 + 1);
-      const float bl = pad_at(img, TH, TW, G, c.y0 + 1, c.x0), br = pad_at(img, TH, TW, G, c.y0 + 1, c.x0 + 1);
+      const float tl = pad_at(tbl, TH, TW, 1, c.y0, c.x0), tr = pad_at(tbl, TH, TW, 1, c.y0, c.x0 + 1);
+      const float bl = pad_at(tbl, TH, TW, 1, c.y0 + 1, c.x0), br = pad_at(tbl, TH, TW, 1, c.y0 + 1, c.x0 + 1);
       const float top = c.ax * (tr - tl) + tl, bot = c.ax * (br - bl) + bl;
-      if (c.gy) d0 += -go * (bot - top);                                       // d/dy * dy/doff0 (= -1)
-      if (c.gx) d1 += -go * (c.ay * (br - bl) + (1.f - c.ay) * (tr - tl));     // d/dx * dx/doff1 (= -1)
+      if (c.gy) d0 -= go * (bot - top);
+      if (c.gx) d1 -= go * (c.ay * (br - bl) + (1.f - c.ay) * (tr - tl));
       if (go != 0.f) {
         const float w[4] = {(1.f - c.ay) * (1.f - c.ax), (1.f - c.ay) * c.ax, c.ay * (1.f - c.ax), c.ay * c.ax};
         const int yy[4] = {c.y0, c.y0, c.y0 + 1, c.y0 + 1}, xx[4] = {c.x0, c.x0 + 1, c.x0, c.x0 + 1};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (yy[e] >= 1 && yy[e] <= TH && xx[e] >= 1 && xx[e] <= TW && w[e] != 0.f)
-            atomicAdd(dtable + ((yy[e] - 1) * TW + (xx[e] - 1)) * G + g, go * w[e]);
+            atomicAdd(&dtb[(yy[e] - 1) * TW + (xx[e] - 1)], go * w[e]);
       }
     }
-    d0 = wave_sum(d0); d1 = wave_sum(d1);
-    if (lane == 0) { doff[i * 2] = d0; doff[i * 2 + 1] = d1; }
+    doff[ok] = d0; doff[ok + 1] = d1;
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TH * TW; i += 256)
+    if (dtb[i] != 0.f) atomicAdd(dtable + i * G + g, dtb[i]);
 }
 
 extern "C" int stj_fg_bias_fwd(const void* off, const float* table, float* bias, int B, int G, int Hh, int Ww, int dtype, hipStream_t stream) {
@@ -154,10 +162,10 @@ extern "C" int stj_fg_bias_fwd(const void* off, const float* table, float* bias,
 }
 extern "C" int stj_fg_bias_bwd(const void* off, const float* table, const void* dbias, float* dtable, float* doff,
                                int B, int G, int Hh, int Ww, int dtype, hipStream_t stream) {
-  const long long total = (long long)B * G * Hh * Ww;
-  if (total <= 0) return STJ_OK;
-  const int grid = (int)((total + 3) / 4);
-  if (dtype == STJ_BF16) hipLaunchKernelGGL(fg_bias_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)off, table, (const bf16*)dbias, dtable, doff, B, G, Hh, Ww);
-  else hipLaunchKernelGGL(fg_bias_bwd_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)off, table, (const float*)dbias, dtable, doff, B, G, Hh, Ww);
+  if (B * G <= 0) return STJ_OK;
+  const int grid = B * G;
+  const size_t lds = (size_t)(2 * Hh - 1) * (2 * Ww - 1) * 2 * sizeof(float);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(fg_bias_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, stream, (const bf16*)off, table, (const bf16*)dbias, dtable, doff, B, G, Hh, Ww);
+  else hipLaunchKernelGGL(fg_bias_bwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)off, table, (const float*)dbias, dtable, doff, B, G, Hh, Ww);
   return stj_check_launch("stj_fg_bias_bwd");
 }

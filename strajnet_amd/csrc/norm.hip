@@ -18,7 +18,7 @@ __device__ __forceinline__ long long ln_src(long long row, int c, int C, int gre
   return ((b * gres + 2 * i + di) * gres + 2 * j + dj) * C0 + cc;
 }
 
-struct LnGroups { long long group_rows; int ngroups; long long gstride; };
+struct LnGroups { long long group_rows; int ngroups; long long gstride; int S; long long L; };   // S sub-runs of L rows per run (bwd)
 
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
@@ -64,35 +64,59 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = blockIdx.x % G.ngroups, sub = blockIdx.x / G.ngroups;
   const long long goff = (long long)g * G.gstride;
-  const long long nchunks = (rows + G.group_rows - 1) / G.group_rows;
+  const long long nruns = (rows + G.group_rows - 1) / G.group_rows;
+  const long long nr_g = (nruns - g + G.ngroups - 1) / G.ngroups;      // runs of this group
   float ag[NPL], ab[NPL];
 #pragma unroll
   for (int j = 0; j < NPL; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
-  for (long long chunk = g + (long long)G.ngroups * sub; chunk < nchunks; chunk += (long long)G.ngroups * nb) {
-    const long long rend = min(rows, (chunk + 1) * G.group_rows);
-    for (long long row = chunk * G.group_rows + w; row < rend; row += 4) {
-      const float mu = mean[row], rs = rstd[row];
-      float xh[NPL], gg[NPL];
-      float s1 = 0.f, s2 = 0.f;
+  for (long long jj = sub; jj < nr_g * G.S; jj += nb) {
+    const long long run = g + (long long)G.ngroups * (jj / G.S);
+    const long long part = jj % G.S;
+    const long long chunk_begin = run * G.group_rows + part * G.L;
+    const long long rend = min(rows, run * G.group_rows + min(G.group_rows, (part + 1) * G.L));
+    // RI rows in flight per wave: all loads of the RI rows are issued before any reduction (memory-level parallelism;
+    // one row per iteration was latency-bound at ~1 us per row)
+    constexpr int RI = NPL <= 3 ? 4 : (NPL <= 6 ? 2 : 1);
+    for (long long row0 = chunk_begin + w * RI; row0 < rend; row0 += 4 * RI) {
+      float dv[RI][NPL], xv[RI][NPL], mu[RI], rs[RI];
 #pragma unroll
-      for (int j = 0; j < NPL; ++j) {
-        const int c = lane + 64 * j;
-        if (c < C) {
-          const float d = ldf(dy + row * C + c);
-          xh[j] = (ldf(x + ln_src(row, c, C, gres, C0)) - mu) * rs;
-          gg[j] = d * gamma[goff + c];
-          ag[j] += d * xh[j];
-          ab[j] += d;
-        } else { xh[j] = 0.f; gg[j] = 0.f; }
-        s1 += gg[j];
-        s2 += gg[j] * xh[j];
+      for (int u = 0; u < RI; ++u) {
+        const long long row = row0 + u;
+        const bool ok = row < rend;
+        mu[u] = ok ? mean[row] : 0.f; rs[u] = ok ? rstd[row] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+          const int c = lane + 64 * j;
+          const bool in = ok && c < C;
+          dv[u][j] = in ? ldf(dy + row * C + c) : 0.f;
+          xv[u][j] = in ? ldf(x + ln_src(row, c, C, gres, C0)) : 0.f;
+        }
       }
-      s1 = wave_sum(s1) / C;
-      s2 = wave_sum(s2) / C;
 #pragma unroll
-      for (int j = 0; j < NPL; ++j) {
-        const int c = lane + 64 * j;
-        if (c < C) stf(dx + ln_src(row, c, C, gres, C0), rs * (gg[j] - s1 - xh[j] * s2));
+      for (int u = 0; u < RI; ++u) {
+        const long long row = row0 + u;
+        if (row >= rend) continue;
+        float xh[NPL], gg[NPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+          const int c = lane + 64 * j;
+          if (c < C) {
+            xh[j] = (xv[u][j] - mu[u]) * rs[u];
+            gg[j] = dv[u][j] * gamma[goff + c];
+            ag[j] += dv[u][j] * xh[j];
+            ab[j] += dv[u][j];
+          } else { xh[j] = 0.f; gg[j] = 0.f; }
+          s1 += gg[j];
+          s2 += gg[j] * xh[j];
+        }
+        s1 = wave_sum(s1) / C;
+        s2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+          const int c = lane + 64 * j;
+          if (c < C) stf(dx + ln_src(row, c, C, gres, C0), rs[u] * (gg[j] - s1 - xh[j] * s2));
+        }
       }
     }
   }
@@ -121,15 +145,18 @@ static int ln_launch(bool fwd, const void* x, const float* gamma, const float* b
     long long want = (rows + 3) / 4;
     grid = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
   } else {
-    if (G.ngroups <= 1) {              // single parameter set: cut rows into runs so that <= 256 blocks share the atomics
-      G.ngroups = 1; G.gstride = 0;
-      long long gr = (rows + 255) / 256;
-      if (gr < 16) gr = 16;
-      G.group_rows = gr;
-    }
-    const long long nchunks = (rows + G.group_rows - 1) / G.group_rows;
-    long long per_group = (nchunks + G.ngroups - 1) / G.ngroups;
-    nb = (int)(per_group < 1 ? 1 : (per_group > 256 / G.ngroups + 1 ? 256 / G.ngroups + 1 : per_group));
+    if (G.ngroups <= 1) { G.ngroups = 1; G.gstride = 0; G.group_rows = rows; }
+    // <= ~256 blocks in total share the dgamma/dbeta atomics; every run is cut into S sub-runs of L rows
+    const long long nruns = (rows + G.group_rows - 1) / G.group_rows;
+    const long long nr = (nruns + G.ngroups - 1) / G.ngroups;
+    long long nbt = (rows / G.ngroups + 15) / 16;
+    if (nbt > 256 / G.ngroups) nbt = 256 / G.ngroups;
+    if (nbt < 1) nbt = 1;
+    long long S = (nbt + nr - 1) / nr;
+    if (S < 1) S = 1;
+    G.S = (int)S;
+    G.L = (G.group_rows + S - 1) / S;
+    nb = (int)(nbt < nr * S ? nbt : nr * S);
     grid = G.ngroups * nb;
   }
   if (npl <= 2) { LN_DISPATCH(2) }
@@ -149,7 +176,7 @@ extern "C" int stj_layernorm_fwd(const void* x, const float* gamma, const float*
   if (rows <= 0) return STJ_OK;
   if (gather_res && (C != 4 * C0 || (gather_res & 1))) { stj_set_error("layernorm: bad gather geometry"); return STJ_EINVAL; }
   if (ngroups > 1 && group_rows <= 0) { stj_set_error("layernorm: bad group_rows"); return STJ_EINVAL; }
-  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride;
+  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride; G.S = 1; G.L = G.group_rows;
   if (dtype == STJ_BF16) return ln_launch<bf16>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, G, stream);
   return ln_launch<float>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, G, stream);
 }
@@ -157,7 +184,7 @@ extern "C" int stj_layernorm_bwd(const void* dy, const void* x, const float* gam
                                  void* dx, float* dgamma, float* dbeta, long long rows, int C, int gather_res, int C0,
                                  long long group_rows, int ngroups, long long gstride, int dtype, hipStream_t stream) {
   if (rows <= 0) return STJ_OK;
-  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride;
+  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride; G.S = 1; G.L = G.group_rows;
   if (dtype == STJ_BF16) return ln_launch<bf16>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream);
   return ln_launch<float>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream);
 }

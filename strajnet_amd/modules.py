@@ -403,7 +403,7 @@ class STrajNet:
         def fold():
             pw.grad.view(8, Ci * Co).add_(sel.t() @ gwz.view(8, Ci * Co))
         return ops.linear_z(skip, pw.master, wz[0], Ci * Co, pb.master.detach(), 0, gwz[0], Ci * Co, pb.grad, 8,
-                            act=ACT_ELU, shared_x=True, fold=fold)    # [B,8,HW,Co]
+                            act=ACT_ELU, shared_x=True, fold=fold)    # [8, B*HW, Co]  (time-major)
 
     # ---- the 8 time-separated cross-attentions, batched over the waypoint axis z (trajNet.py:305-314) ----
     def _zp(self, suffix):
@@ -424,33 +424,34 @@ class STrajNet:
         return p0, wz, gwz, fold
 
     def _cross_attention_z(self, query, key, tmask):
-        """8 x Cross_AttentionT (trajNet.py:224-234) + query residual in one batched pass.  query [B,8,HW,Cb], key [B,64,Cb]."""
-        B, Z, HW, Cb = query.shape
+        """8 x Cross_AttentionT (trajNet.py:224-234) + query residual in one batched pass, waypoint-major:
+        query [8,B,HW,Cb], key [B,64,Cb] -> [8,B,HW,Cb]."""
+        Z, B, HW, Cb = query.shape
         zs = self._zstride
         hs = 128 // 3
+        A = key.shape[1]
 
         def proj_in(x, suffix, shared):
             p0, wz, gwz, fold = self._zheads_in(suffix)
             return ops.linear_z(x, p0.master, wz[0], wz.shape[1] * wz.shape[2], None, 0, gwz[0], wz.shape[1] * wz.shape[2], None, 8,
                                 shared_x=shared, fold=fold)
-        q = proj_in(query, 'mha/query_kernel', False)                    # [B,8,HW,126]
-        k = proj_in(key, 'mha/key_kernel', True)                         # [B,8,64,126]
+        q = proj_in(query, 'mha/query_kernel', False)                    # [8, B*HW, 126]
+        k = proj_in(key, 'mha/key_kernel', True)                         # [8, B*64, 126]
         v = proj_in(key, 'mha/value_kernel', True)
-        kvalid = tmask[:, None, :].expand(B, Z, tmask.shape[1]).reshape(B * Z, -1).contiguous()
-        o = ops.mha_core(q.view(B * Z, HW, 3 * hs), k.view(B * Z, -1, 3 * hs), v.view(B * Z, -1, 3 * hs), 3, hs,
+        kvalid = tmask[None].expand(Z, B, A).reshape(Z * B, A).contiguous()
+        o = ops.mha_core(q.view(Z * B, HW, 3 * hs), k.view(Z * B, A, 3 * hs), v.view(Z * B, A, 3 * hs), 3, hs,
                          1.0 / math.sqrt(hs), kvalid=kvalid)
-
         pw, pb = self._zp('mha/projection_kernel'), self._zp('mha/projection_bias')
         H_, hs_, O_ = pw.shape
-        v1 = ops.linear_z(o.view(B, Z, HW, 3 * hs), pw.master, pw.c.view(H_ * hs_, O_), zs, pb.master.detach(), zs,
+        v1 = ops.linear_z(o.view(Z, B * HW, 3 * hs), pw.master, pw.c.view(H_ * hs_, O_), zs, pb.master.detach(), zs,
                           pw.grad.view(H_ * hs_, O_), zs, pb.grad, 8)
-        v1 = ops.layernorm(v1, self._zp('norm1/gamma'), self._zp('norm1/beta'), 1e-3, group_rows=HW, ngroups=8, gstride=zs)
+        v1 = ops.layernorm(v1, self._zp('norm1/gamma'), self._zp('norm1/beta'), 1e-3, group_rows=B * HW, ngroups=8, gstride=zs)
         pw, pb = self._zp('FFN1/kernel'), self._zp('FFN1/bias')
         v1 = ops.linear_z(v1, pw.master, pw.c, zs, pb.master.detach(), zs, pw.grad, zs, pb.grad, 8, act=ACT_ELU)
         pw, pb = self._zp('FFN2/kernel'), self._zp('FFN2/bias')
         v1 = ops.linear_z(v1, pw.master, pw.c, zs, pb.master.detach(), zs, pw.grad, zs, pb.grad, 8)
-        v1 = ops.layernorm(v1, self._zp('norm2/gamma'), self._zp('norm2/beta'), 1e-3, group_rows=HW, ngroups=8, gstride=zs)
-        return v1 + query
+        v1 = ops.layernorm(v1, self._zp('norm2/gamma'), self._zp('norm2/beta'), 1e-3, group_rows=B * HW, ngroups=8, gstride=zs)
+        return v1.view(Z, B, HW, Cb) + query
 
     def _decoder(self, x, res_list, B):
         """Pyramid3DDecoder.call (modules.py:739-772): shallow_decode=1, flow_sep_decode, use_pyramid, rep_res."""
@@ -459,7 +460,7 @@ class STrajNet:
 
         def up(t, name):
             return ops.upconv(t, self._p(name + '/kernel'), self._p(name + '/bias'))
-        x = x.view(B * 8, hb, hb, -1)
+        x = x.view(8 * B, hb, hb, -1)                                                # frames are TIME-major: f = t*B + b
         x = up(x, 'decoder/upconv_3_0')                                              # [F,2hb,2hb,192]
         x = x + self._resconv(r1, 'decoder/resconv_3').view(x.shape)
         x = up(x, 'decoder/upconv_2_0')                                              # [F,4hb,4hb,128]
@@ -468,7 +469,7 @@ class STrajNet:
         x = up(up(x, 'decoder/upconv_1_0'), 'decoder/upconv_0_0')
         fx = up(up(fx, 'decoder/upconvf_1_0'), 'decoder/upconvf_0_0')
         return ops.outconv_pair(x, fx, self._p('decoder/outconv/kernel'), self._p('decoder/outconv/bias'),
-                                self._p('decoder/outconv_f/kernel'), self._p('decoder/outconv_f/bias'), B, 8)
+                                self._p('decoder/outconv_f/kernel'), self._p('decoder/outconv_f/bias'), B, 8, t_major=True)
 
     # ------------------------------------------------------------------ call
     def __call__(self, ogm, map_img, training=True, obs=None, occ=None, mapt=None, flow=None, dense_vec=None, dense_map=None):
@@ -500,10 +501,12 @@ class STrajNet:
         if self.fg_msa:
             y, fh = self._fgmsa(q)
             q = q + y                                                              # modules.py:825
-        query = q.reshape(B, 1, hb * hb, Cb).expand(B, 8, hb * hb, Cb)             # modules.py:827
+        # waypoint-major [8,B,HW,Cb] (the reference's [B,8,...] transposed): every per-waypoint product downstream is then a
+        # plain batched GEMM and the decoder frames are t-major; the output kernel undoes it when writing [B,H,W,32]
+        query = q.reshape(1, B, hb * hb, Cb).expand(8, B, hb * hb, Cb)             # modules.py:827
         if self.fg:
-            query = query + fh.reshape(B, 8, hb * hb, Cb)                          # modules.py:830-831
+            query = query + fh.reshape(B, 8, hb * hb, Cb).permute(1, 0, 2, 3)      # modules.py:830-831
         key, tmask = self._traj_net(obs, occ)
-        x = self._cross_attention_z(query.contiguous(), key, tmask)               # [B,8,hb*hb,Cb]  (trajNet.py:305-317)
+        x = self._cross_attention_z(query.contiguous(), key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
         out = self._decoder(x, res_list, B)
         return out

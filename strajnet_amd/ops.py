@@ -178,10 +178,11 @@ def linear_heads_out(x, pw, pb):
 
 
 # ----------------------------------------------------------------------------------------------------
-# batched dense over a leading "z" axis (8 waypoints / 8 time steps), one launch for all z:
-#   y[b, z, m, :] = act(x[b, (z|shared), m, :] @ W_z + bias_z)
-# W_z lives at w0 + z*wstride (elements), so the 8 per-waypoint weight sets are addressed in place inside the flat
-# parameter buffer (they are laid out with a constant stride), and so are their gradients.
+# batched dense over a LEADING "z" axis (8 waypoints / 8 time steps), one launch for all z:
+#   y[z, r, :] = act(x[(z|shared), r, :] @ W_z + bias_z)          x: [Z, R, K] or shared [R, K];  y: [Z, R, N]
+# z-major layout makes every product a plain batched GEMM (rows (scene, token) of one z are contiguous): forward,
+# dgrad and wgrad are ONE launch each.  W_z lives at w0 + z*wstride (elements): the 8 per-waypoint weight sets are
+# addressed in place inside the flat parameter buffer (constant stride), and so are their gradients.
 # ----------------------------------------------------------------------------------------------------
 class _LinearZ(torch.autograd.Function):
     @staticmethod
@@ -189,16 +190,12 @@ class _LinearZ(torch.autograd.Function):
         _req_cuda(x)
         K, N = w0.shape
         x = x.contiguous()
-        if shared_x:
-            B, M = x.shape[0], x.shape[1]
-            sA = (M * K, 0, K, 1)
-        else:
-            B, M = x.shape[0], x.shape[2]
-            sA = (Z * M * K, M * K, K, 1)
+        R = x.numel() // K if shared_x else x.numel() // (K * Z)
         dt = _dt(x)
-        y = torch.empty((B, Z, M, N), dtype=x.dtype, device=x.device)
-        gemm(x, w0, y, M, N, K, sA, (0, wstride, N, 1), (Z * M * N, M * N, N), dt, bias=b0, sBias=(0, bstride), nb=(B, Z), act=act)
-        ctx.dims = (B, Z, M, K, N, shared_x, act, wstride, bstride, gwstride)
+        y = torch.empty((Z, R, N), dtype=x.dtype, device=x.device)
+        gemm(x, w0, y, R, N, K, (0, 0 if shared_x else R * K, K, 1), (0, wstride, N, 1), (0, R * N, N), dt, bias=b0,
+             sBias=(0, bstride), nb=(1, Z), act=act)
+        ctx.dims = (Z, R, K, N, shared_x, act, wstride, bstride, gwstride, x.shape)
         ctx.w0, ctx.gw0, ctx.gb0, ctx.fold = w0, gw0, gb0, fold
         ctx.save_for_backward(x, y if act == ACT_ELU else None)
         return y
@@ -206,7 +203,7 @@ class _LinearZ(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
-        B, Z, M, K, N, shared_x, act, wstride, bstride, gwstride = ctx.dims
+        Z, R, K, N, shared_x, act, wstride, bstride, gwstride, xshape = ctx.dims
         dt = _dt(x)
         dy = dy.contiguous()
         if act == ACT_ELU:
@@ -216,20 +213,16 @@ class _LinearZ(torch.autograd.Function):
             dpre = dy
         dx = None
         if ctx.needs_input_grad[0]:
-            if shared_x:
-                # dx[b,m,:] = sum_z dpre[b,z,m,:] W_z^T : accumulate z by z into f32, then cast
-                acc = torch.zeros((B, M, K), dtype=torch.float32, device=x.device)
-                for z in range(Z):
-                    gemm(dpre[:, z], _poff(ctx.w0, z * wstride), acc, M, K, N, (Z * M * N, 0, N, 1), (0, 0, 1, N), (M * K, 0, K), dt,
-                         nb=(B, 1), c_f32=1, accumulate=1)
-                dx = acc.to(x.dtype)
+            if shared_x:       # dx[r,:] = sum_z dpre[z,r,:] W_z^T : all z accumulate (f32 atomics) into one buffer
+                acc = torch.zeros((R, K), dtype=torch.float32, device=x.device)
+                gemm(dpre, ctx.w0, acc, R, K, N, (0, R * N, N, 1), (0, wstride, 1, N), (0, 0, K), dt, nb=(1, Z), c_f32=1, accumulate=1)
+                dx = acc.to(x.dtype).view(xshape)
             else:
                 dx = torch.empty_like(x)
-                gemm(dpre, ctx.w0, dx, M, K, N, (Z * M * N, M * N, N, 1), (0, wstride, 1, N), (Z * M * K, M * K, K), dt, nb=(B, Z))
-        # dW_z += sum_b x[b,z]^T dpre[b,z] ; db_z += column sums (fused): one launch per b, batched over z
-        for b in range(B):
-            gemm(x[b], dpre[b], ctx.gw0, K, N, M, (0, 0 if shared_x else M * K, 1, K), (0, M * N, N, 1), (0, gwstride, N), dt,
-                 nb=(1, Z), c_f32=1, accumulate=1, splitk=0, colsum=ctx.gb0, sBias=(0, bstride))
+                gemm(dpre, ctx.w0, dx, R, K, N, (0, R * N, N, 1), (0, wstride, 1, N), (0, R * K, K), dt, nb=(1, Z))
+        # dW_z += x_z^T dpre_z ; db_z += column sums (fused)
+        gemm(x, dpre, ctx.gw0, K, N, R, (0, 0 if shared_x else R * K, 1, K), (0, R * N, N, 1), (0, gwstride, N), dt,
+             nb=(1, Z), c_f32=1, accumulate=1, splitk=0, colsum=ctx.gb0, sBias=(0, bstride))
         if ctx.fold is not None:
             ctx.fold()
         return (dx,) + (None,) * 12
@@ -569,17 +562,20 @@ def upconv(x, pw, pb):
 class _OutConvPair(torch.autograd.Function):
     """Two 3x3 C->2 heads written straight into the [B,H,W,32] f32 model output (channel 4t+{0,1} and 4t+{2,3})."""
     @staticmethod
-    def forward(ctx, xo, xf, w1m, b1m, w2m, b2m, p1w, p1b, p2w, p2b, B, Tn):
+    def forward(ctx, xo, xf, w1m, b1m, w2m, b2m, p1w, p1b, p2w, p2b, B, Tn, t_major):
         _req_cuda(xo, xf)
         xo, xf = xo.contiguous(), xf.contiguous()
         F_, H, W, C = xo.shape
         out = torch.empty((B, H, W, 4 * Tn), dtype=torch.float32, device=xo.device)
         dt = _dt(xo)
         ybs, yts, yps = H * W * 4 * Tn, 4, 4 * Tn
-        call('stj_outconv_fwd', _p(xo), _p(p1w.master), _p(p1b.master), vp(out.data_ptr()), F_, H, W, C, Tn, ybs, yts, yps, dt, _st())
-        call('stj_outconv_fwd', _p(xf), _p(p2w.master), _p(p2b.master), vp(out.data_ptr() + 8), F_, H, W, C, Tn, ybs, yts, yps, dt, _st())
+        inner = Tn
+        if t_major:            # frames ordered f = t*B + b: the kernel's (f / inner, f % inner) split then yields (t, b)
+            ybs, yts, inner = 4, H * W * 4 * Tn, B
+        call('stj_outconv_fwd', _p(xo), _p(p1w.master), _p(p1b.master), vp(out.data_ptr()), F_, H, W, C, inner, ybs, yts, yps, dt, _st())
+        call('stj_outconv_fwd', _p(xf), _p(p2w.master), _p(p2b.master), vp(out.data_ptr() + 8), F_, H, W, C, inner, ybs, yts, yps, dt, _st())
         ctx.ps = (p1w, p1b, p2w, p2b)
-        ctx.geo = (F_, H, W, C, Tn, ybs, yts, yps)
+        ctx.geo = (F_, H, W, C, inner, ybs, yts, yps)
         ctx.save_for_backward(xo, xf)
         return out
 
@@ -595,11 +591,11 @@ class _OutConvPair(torch.autograd.Function):
              ybs, yts, yps, dt, _st())
         call('stj_outconv_bwd', _p(xf), _p(p2w.master), vp(dout.data_ptr() + 8), _p(dxf), _p(p2w.grad), _p(p2b.grad), F_, H, W, C, Tn,
              ybs, yts, yps, dt, _st())
-        return (dxo, dxf) + (None,) * 10
+        return (dxo, dxf) + (None,) * 11
 
 
-def outconv_pair(xo, xf, p1w, p1b, p2w, p2b, B, Tn):
-    return _OutConvPair.apply(xo, xf, p1w.master, p1b.master, p2w.master, p2b.master, p1w, p1b, p2w, p2b, B, Tn)
+def outconv_pair(xo, xf, p1w, p1b, p2w, p2b, B, Tn, t_major=False):
+    return _OutConvPair.apply(xo, xf, p1w.master, p1b.master, p2w.master, p2b.master, p1w, p1b, p2w, p2b, B, Tn, t_major)
 
 
 # ----------------------------------------------------------------------------------------------------
