@@ -34,51 +34,53 @@ template <typename T> __device__ __forceinline__ T zero_of() {
   return z;
 }
 
-// K-contiguous image [ROWS][LD]: element (r,k) from g[r*sR + k*sK]
-template <typename T, int ROWS, int BK, int LD>
-__device__ __forceinline__ void stage_kc(T* lds, const T* g, long long sR, long long sK, int nr, int nk, int vec, int tid) {
-  constexpr int VN = Vec<T>::N;
-  if (sK == 1) {
-    constexpr int CPR = BK / VN;
-    for (int i = tid; i < ROWS * CPR; i += 256) {
-      const int r = i / CPR, k = (i % CPR) * VN;
-      T* dst = lds + r * LD + k;
-      if (r < nr && k + VN <= nk && vec) {
-        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(g + (long long)r * sR + k);
-      } else {
+// ---- operand staging, split into "global -> registers" (issued one k-tile ahead, so the loads fly while the MFMAs of
+// the current tile run) and "registers -> LDS".  A thread owns NCH 16-byte chunks of the ROWS x BK tile.
+//   RC = false: K-contiguous operand, image [ROWS][LD], chunk = VN consecutive k of one row
+//   RC = true : row-contiguous operand kept un-transposed, image [BK][LDT], chunk = VN consecutive rows of one k
+template <typename T, int ROWS, int BK, bool RC>
+struct Stage {
+  static constexpr int VN = Vec<T>::N;
+  static constexpr int NCH = ROWS * BK / VN / 256;
+  static constexpr int CPR = RC ? ROWS / VN : BK / VN;      // chunks along the contiguous axis
+  static_assert(ROWS * BK / VN % 256 == 0, "tile must split evenly over 256 threads");
+
+  __device__ static __forceinline__ void load(uint4 (&reg)[NCH], const T* g, long long sR, long long sK, int nr, int nk, int vec, int tid) {
 #pragma unroll
-        for (int e = 0; e < VN; ++e) dst[e] = (r < nr && k + e < nk) ? g[(long long)r * sR + k + e] : zero_of<T>();
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + i * 256;
+      const int a = idx / CPR, c = (idx % CPR) * VN;         // KC: (row a, k c)   RC: (k a, row c)
+      const int r = RC ? c : a, k = RC ? a : c;
+      const bool full = RC ? (k < nk && r + VN <= nr) : (r < nr && k + VN <= nk);
+      if (full && vec) {
+        reg[i] = *reinterpret_cast<const uint4*>(g + (long long)r * sR + (long long)k * sK);
+      } else {
+        __attribute__((aligned(16))) T tmp[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+          const int rr = RC ? r + e : r, kk = RC ? k : k + e;
+          tmp[e] = (rr < nr && kk < nk) ? g[(long long)rr * sR + (long long)kk * sK] : zero_of<T>();
+        }
+        reg[i] = *reinterpret_cast<const uint4*>(tmp);
       }
     }
-  } else {
-    for (int i = tid; i < ROWS * BK; i += 256) {
-      const int r = i / BK, k = i % BK;
-      lds[r * LD + k] = (r < nr && k < nk) ? g[(long long)r * sR + (long long)k * sK] : zero_of<T>();
-    }
   }
-}
-// row-contiguous operand kept un-transposed: image [BK][LDT], element (r,k) from g[r + k*sK]
-template <typename T, int ROWS, int BK, int LDT>
-__device__ __forceinline__ void stage_rc(T* lds, const T* g, long long sK, int nr, int nk, int vec, int tid) {
-  constexpr int VN = Vec<T>::N;
-  constexpr int CPK = ROWS / VN;
-  for (int i = tid; i < BK * CPK; i += 256) {
-    const int k = i / CPK, r = (i % CPK) * VN;
-    T* dst = lds + k * LDT + r;
-    if (k < nk && r + VN <= nr && vec) {
-      const uint4 v = *reinterpret_cast<const uint4*>(g + (long long)k * sK + r);
-      if constexpr (sizeof(T) == 2) {          // rows are only 4-byte aligned (LDT = ROWS + 2)
+  template <int LDX>
+  __device__ static __forceinline__ void commit(T* lds, const uint4 (&reg)[NCH], int tid) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + i * 256;
+      const int a = idx / CPR, c = (idx % CPR) * VN;
+      T* dst = lds + a * LDX + c;
+      if constexpr (RC && sizeof(T) == 2) {                  // rows only 4-byte aligned (LDT = ROWS + 2)
         uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        d[0] = reg[i].x; d[1] = reg[i].y; d[2] = reg[i].z; d[3] = reg[i].w;
       } else {
-        *reinterpret_cast<uint4*>(dst) = v;
+        *reinterpret_cast<uint4*>(dst) = reg[i];
       }
-    } else {
-#pragma unroll
-      for (int e = 0; e < VN; ++e) dst[e] = (k < nk && r + e < nr) ? g[(long long)k * sK + r + e] : zero_of<T>();
     }
   }
-}
+};
 
 template <typename T, int BM, int BN, int WM, int WN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
@@ -123,13 +125,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const bool do_cs = p.colsum != nullptr && tm == 0;
   float cs = 0.f;
 
+  typedef Stage<T, BM, BK, TA> SA;
+  typedef Stage<T, BN, BK, TB> SB;
+  uint4 ra[SA::NCH], rb[SB::NCH];
+  const long long a_sR = TA ? 1 : p.sAm, b_sR = TB ? 1 : p.sBn;
+  if (kt0 < kt1) {
+    SA::load(ra, A + (long long)kt0 * BK * p.sAk, a_sR, p.sAk, p.M - m0, p.K - kt0 * BK, p.vecA, tid);
+    SB::load(rb, B + (long long)kt0 * BK * p.sBk, b_sR, p.sBk, p.N - n0, p.K - kt0 * BK, p.vecB, tid);
+  }
   for (int kt = kt0; kt < kt1; ++kt) {
-    const int k0 = kt * BK;
-    if constexpr (TA) stage_rc<T, BM, BK, LDTA>(As, A + (long long)k0 * p.sAk, p.sAk, p.M - m0, p.K - k0, p.vecA, tid);
-    else stage_kc<T, BM, BK, LD>(As, A + (long long)k0 * p.sAk, p.sAm, p.sAk, p.M - m0, p.K - k0, p.vecA, tid);
-    if constexpr (TB) stage_rc<T, BN, BK, LDTB>(Bs, B + (long long)k0 * p.sBk, p.sBk, p.N - n0, p.K - k0, p.vecB, tid);
-    else stage_kc<T, BN, BK, LD>(Bs, B + (long long)k0 * p.sBk, p.sBn, p.sBk, p.N - n0, p.K - k0, p.vecB, tid);
+    SA::template commit<TA ? LDTA : LD>(As, ra, tid);
+    SB::template commit<TB ? LDTB : LD>(Bs, rb, tid);
     __syncthreads();
+    if (kt + 1 < kt1) {                 // next tile's global loads overlap this tile's MFMAs
+      const int k1 = (kt + 1) * BK;
+      SA::load(ra, A + (long long)k1 * p.sAk, a_sR, p.sAk, p.M - m0, p.K - k1, p.vecA, tid);
+      SB::load(rb, B + (long long)k1 * p.sBk, b_sR, p.sBk, p.N - n0, p.K - k1, p.vecB, tid);
+    }
     if (do_cs && tid < BN) {           // fused bias gradient: column sums of the B (= dY) tile over this block's k range
       float s = 0.f;
       if constexpr (TB) { for (int k = 0; k < BK; ++k) s += ldf(Bs + k * LDTB + tid); }
