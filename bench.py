@@ -109,6 +109,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying the captured hipGraph')
     args = ap.parse_args()
 
     import torch
@@ -146,6 +147,24 @@ def main():
             dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
         return total
 
+    graphed = None
+    if not args.no_graph:
+        try:
+            from strajnet_amd.graph import GraphedTrainStep
+            graphed = GraphedTrainStep(model, loss_fn, x)
+        except Exception as e:           # capture is an optimisation, never a requirement
+            print(f'bench.py: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
+            graphed = None
+    eager_step = step
+
+    def step_graph():
+        losses = graphed()
+        if world > 1:
+            dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
+        return losses.sum()
+    if graphed is not None:
+        step = step_graph
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -154,14 +173,20 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    if not args.no_kernel_timing:
-        ops.prof_enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
     barrier()
     dt_s = time.perf_counter() - t0
-    prof = ops.prof_disable() if not args.no_kernel_timing else None
+    # per-kernel HIP-event timing of the conv kernels (roofline of the dominant one): the same launches, issued eagerly
+    # with events recorded on the launch stream -- under graph replay individual launches cannot carry events
+    prof = None
+    if not args.no_kernel_timing:
+        ops.prof_enable()
+        for _ in range(min(args.steps, 3)):
+            eager_step()
+        barrier()
+        prof = ops.prof_disable()
     if world > 1:
         t = torch.tensor([dt_s], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,7 +223,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'STrajNet cfg-256 train step (fwd+OGMFlow_loss+bwd{"+RCCL grad all-reduce" if world > 1 else ""}), '
                                    f'batch {B}/GPU, 8 waypoints, obs+occ+flow heads, fg_msa+fg, random-init weights',
-                       'global_batch': B * world, 'grid': '256x256x11', 'parallelism': f'dp{world}',
+                       'global_batch': B * world, 'grid': '256x256x11', 'parallelism': f'dp{world}', 'hipgraph': graphed is not None,
                        'optimizer_in_step': False, 'algorithmic_gflop_per_scene_step': ALGO_GFLOP_STEP_PER_SCENE},
             'loss': round(loss_val, 4),
             'roofline': roof,

@@ -216,22 +216,21 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* logits, cons
   }
 }
 
-// gate: f32[8] out.  hist: int[8*202] scratch (zeroed here).  auc_out optional f32[8].
+// gate: f32[8] out.  hist: int[8*202] scratch, MUST BE ZERO on entry (no memset node here: hipMemsetAsync inside a captured
+// hipGraph replayed with stale contents on ROCm 7.2 -- tools/probes/dbg_graph2.py).  auc_out optional f32[8].
 extern "C" int stj_loss_auc_gate(const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                                  int* hist, float* gate, float* auc_out, int B, int H, int W, hipStream_t stream) {
-  if (hipMemsetAsync(hist, 0, sizeof(int) * NWP * 202, stream) != hipSuccess) { stj_set_error("loss: memset failed"); return STJ_ELAUNCH; }
   const long long npix = (long long)B * H * W;
   const int gx = (int)min(256ll, (npix + 255) / 256);
   hipLaunchKernelGGL(auc_hist_kernel, dim3(gx, NWP), dim3(256), 0, stream, gt_obs, gt_occ, gt_flow, origin, hist, B, H, W);
   hipLaunchKernelGGL(auc_gate_kernel, dim3(1), dim3(64), 0, stream, hist, gate, auc_out);
   return stj_check_launch("stj_loss_auc_gate");
 }
-// sums: f32[40] scratch (zeroed here); loss f32[4]; coef f32[32]
+// sums: f32[40] scratch, MUST BE ZERO on entry; loss f32[4]; coef f32[32]
 extern "C" int stj_loss_fwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                             const float* gate, float* sums, float* loss, float* coef, int B, int H, int W, float ogm_w, float occ_w,
                             float flow_origin_w, float replica, int use_warp, hipStream_t stream) {
   if (((uintptr_t)logits) & 15) { stj_set_error("loss: logits must be 16-byte aligned"); return STJ_EINVAL; }
-  if (hipMemsetAsync(sums, 0, sizeof(float) * NWP * S_N, stream) != hipSuccess) { stj_set_error("loss: memset failed"); return STJ_ELAUNCH; }
   const long long npix = (long long)B * H * W;
   const int gx = (int)min(2048ll, (npix + 255) / 256);
   hipLaunchKernelGGL(loss_fwd_kernel, dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, sums, B, H, W, use_warp);

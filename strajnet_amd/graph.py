@@ -1,0 +1,52 @@
+"""hipGraph capture of the whole train step (forward + OGMFlow_loss + backward into the flat gradient bucket).
+
+The step is ~650 stream-ordered kernel launches with static shapes, no host synchronisation and no allocation outside
+torch's graph-private pool (every kernel of libstrajnet_hip.so launches on the current stream and never allocates), so
+it is capturable as ONE graph; replaying it removes the Python / launch overhead (~10 ms per step, measured with B=1).
+New data is fed by copying into the static input tensors; weights are read in place (the bf16 shadow cast is part of
+the graph), gradients land in model.flat_grads().  The data-parallel all-reduce stays outside the graph.
+"""
+import torch
+
+from .loss import get_pred_waypoint_logits, warpped_gt
+
+
+class GraphedTrainStep:
+    def __init__(self, model, loss_fn, batch, warmup=2):
+        self.model, self.loss_fn = model, loss_fn
+        self.static = {k: v.clone() for k, v in batch.items()}
+        self.graph = None
+        self.losses = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.losses = self._eager()
+        self.graph = g
+
+    def _eager(self):
+        x, m = self.static, self.model
+        m.zero_grad()
+        out = m(x['ogm'], x['map_img'], training=True, obs=x['obs'], occ=x['occ'], mapt=x.get('mapt'), flow=x['flow'])
+        d = self.loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
+        total = d['observed_xe'] + d['occluded_xe'] + d['flow'] + d['flow_warp_xe']
+        total.backward()
+        return torch.stack([d['observed_xe'].detach(), d['occluded_xe'].detach(), d['flow'].detach(),
+                            d['flow_warp_xe'].detach() if torch.is_tensor(d['flow_warp_xe']) else torch.zeros((), device=out.device)])
+
+    def load(self, batch):
+        """Copy a new batch into the static input tensors (stream-ordered device copies)."""
+        for k, v in batch.items():
+            if k in self.static:
+                self.static[k].copy_(v, non_blocking=True)
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            self.load(batch)
+        self.graph.replay()
+        return self.losses          # [observed_xe, occluded_xe, flow, flow_warp_xe]; gradients in model.flat_grads()

@@ -608,7 +608,7 @@ class _OgmFlowLoss(torch.autograd.Function):
         logits = logits.contiguous().float()
         B, H, W, _ = logits.shape
         dev = logits.device
-        sums = torch.empty(40, dtype=torch.float32, device=dev)
+        sums = torch.zeros(40, dtype=torch.float32, device=dev)
         loss = torch.empty(4, dtype=torch.float32, device=dev)
         coef = torch.empty(32, dtype=torch.float32, device=dev)
         call('stj_loss_fwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(sums), _p(loss), _p(coef),
@@ -633,7 +633,7 @@ def auc_gate(gt_obs, gt_occ, gt_flow, origin, return_auc=False):
     _req_cuda(gt_obs)
     B, _, H, W, _ = gt_obs.shape
     dev = gt_obs.device
-    hist = torch.empty(8 * 202, dtype=torch.int32, device=dev)
+    hist = torch.zeros(8 * 202, dtype=torch.int32, device=dev)
     gate = torch.empty(8, dtype=torch.float32, device=dev)
     auc = torch.empty(8, dtype=torch.float32, device=dev)
     call('stj_loss_auc_gate', _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(hist), _p(gate), _p(auc), B, H, W, _st())
