@@ -395,6 +395,7 @@ bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, floa
                           long long y_bs, long long y_ts, long long y_ps, hipStream_t st);
 bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
                           int Tn, long long y_bs, long long y_ts, long long y_ps, hipStream_t st);
+bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
 static bool ws_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("STJ_NO_WS"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -424,6 +425,8 @@ extern "C" int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, int F,
                                 int dtype, hipStream_t stream) {
   int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
   if (e) return e;
+  if (dtype == STJ_BF16 && ws_enabled() && upconv_dgrad_ws_try(dP, Wd, dX, F, Hi, Wi, Cin, Cout, stream))
+    return stj_check_launch("stj_upconv_dgrad(ws)");
   return dtype == STJ_BF16 ? upconv_dgrad_launch<bf16>(dP, Wd, dX, F, Hi, Wi, Cin, Cout, stream)
                            : upconv_dgrad_launch<float>(dP, Wd, dX, F, Hi, Wi, Cin, Cout, stream);
 }

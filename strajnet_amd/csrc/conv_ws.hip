@@ -586,3 +586,167 @@ bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* 
   hipLaunchKernelGGL(outconv_bwd_mfma_kernel<48>, dim3(min(ntiles, 512)), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, dW, db, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
   return true;
 }
+
+// =====================================================================================================
+// Input gradient of the folded up-conv, v2 (bf16): weight-stationary per INPUT phase + LDS reduction.
+//   dX[f,i,j,:] = sum_{a,b} sum_{r,s} dP[f, 2i+u, 2j+v, :] . Weff[a,b,r,s]^T ,  u = 2-a-2r, v = 2-b-2s
+// Wave (a,b) keeps Weff[a,b,*,*]^T (Cin-tile x Cout) in VGPRs as MFMA A fragments and consumes only the hi-res pixels of
+// parity (a,b) from an 18 x 34 halo tile of dP in LDS; the four per-phase partial tiles are summed through LDS (f32)
+// and leave as coalesced 8-byte segments.  v1 (conv.hip) re-staged 16 tap matrices through LDS per tile: 0.59 ms for
+// 96<-48 @128x128 (profiles/r01_b_*).
+// =====================================================================================================
+template <int KS, int NFI>
+__global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ Wd,
+                                                                 bf16* __restrict__ dX, int F, int Hi, int Wi, int Cin, int Cout,
+                                                                 int ntiles) {
+  constexpr int LDK = KS * 32 + 8;                 // halo pixel stride (elements); channels >= Cout stay zero
+  constexpr int HH = 2 * WS_TH + 2, HW = 2 * WS_TW + 2, HPIX = HH * HW;
+  constexpr int CT = NFI * 16;                     // cin tile of this workgroup
+  constexpr int LDR = CT + 4;                      // reduction row stride (floats)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16* halo = reinterpret_cast<bf16*>(smem_raw);                         // [HPIX][LDK] (+64 tail)
+  float* red = reinterpret_cast<float*>(smem_raw + (size_t)(HPIX * LDK + 64) * 2);   // [4 waves][2 rows][16 px][LDR]
+  const int CPP = Cout / 8;                        // 16-byte chunks per halo pixel (runtime: Cout <= KS*32)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int a = w >> 1, b = w & 1;
+  const int g = lane >> 4, ln = lane & 15;
+  const int n0 = blockIdx.y * CT;
+  const int tiles_x = (Wi + WS_TW - 1) / WS_TW, tiles_y = (Hi + WS_TH - 1) / WS_TH;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+
+  // stationary weights: A[m = cin][k = cout] = Wd[(u+1)*4 + (v+1)][cin][cout]
+  s16x8 wd[4][NFI][KS];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = t >> 1, s = t & 1;
+    const int uv = (2 - a - 2 * r + 1) * 4 + (2 - b - 2 * s + 1);
+#pragma unroll
+    for (int n = 0; n < NFI; ++n) {
+      const int ci = n0 + n * 16 + ln;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int co = ks * 32 + g * 8;
+        if (ci < Cin && co < Cout) wd[t][n][ks] = *reinterpret_cast<const s16x8*>(Wd + ((long long)uv * Cin + ci) * Cout + co);
+        else wd[t][n][ks] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  }
+  for (int i = tid; i < (HPIX * LDK + 64) / 2; i += 256) reinterpret_cast<uint32_t*>(halo)[i] = 0u;
+  __syncthreads();
+
+  constexpr int NCH_MAX = (HPIX * (KS * 4) + 255) / 256;     // Cout/8 <= KS*4 chunks per pixel
+  uint4 pre[NCH_MAX];
+  auto tile_coords = [&](int tile, int& f, int& ty0, int& tx0) {
+    const int tx = tile % tiles_x; const int t2 = tile / tiles_x;
+    ty0 = (t2 % tiles_y) * WS_TH; f = t2 / tiles_y; tx0 = tx * WS_TW;
+  };
+  auto prefetch = [&](int tile) {
+    int f, ty0, tx0;
+    tile_coords(tile, f, ty0, tx0);
+    const bf16* Pf = dP + (long long)f * Ho * Wo * Cout;
+#pragma unroll
+    for (int i = 0; i < NCH_MAX; ++i) {
+      const int q = tid + i * 256;
+      const int px = q / CPP, ch = (q % CPP) * 8;
+      const int gy = 2 * ty0 + px / HW - 1, gx = 2 * tx0 + px % HW - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < HPIX * CPP && gy >= 0 && gy < Ho && gx >= 0 && gx < Wo) v = *reinterpret_cast<const uint4*>(Pf + ((long long)gy * Wo + gx) * Cout + ch);
+      pre[i] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH_MAX; ++i) {
+      const int q = tid + i * 256;
+      if (q < HPIX * CPP) *reinterpret_cast<uint4*>(halo + (q / CPP) * LDK + (q % CPP) * 8) = pre[i];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) { prefetch(tile); commit(); }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) prefetch(next);
+    int f, ty0, tx0;
+    tile_coords(tile, f, ty0, tx0);
+    bf16* Xf = dX + (long long)f * Hi * Wi * Cin;
+#pragma unroll 1
+    for (int mf = 0; mf < WS_TH; mf += 2) {
+      f32x4 acc[2][NFI];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NFI; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int u1 = 2 - a - 2 * r + 1, v1 = 2 - b - 2 * s + 1;      // halo offsets (u+1, v+1)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            s16x8 xb[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+              xb[m] = *reinterpret_cast<const s16x8*>(halo + ((2 * (mf + m) + u1) * HW + 2 * ln + v1) * LDK + ks * 32 + g * 8);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int n = 0; n < NFI; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wd[r * 2 + s][n][ks]),
+                                                                    __builtin_bit_cast(bf16x8_t, xb[m]), acc[m][n], 0, 0, 0);
+          }
+        }
+      // partial tile of this phase -> LDS: lane holds cins n*16 + g*4 + 0..3 of pixel (mf+m, ln)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NFI; ++n)
+          *reinterpret_cast<float4*>(red + ((w * 2 + m) * 16 + ln) * LDR + n * 16 + g * 4) = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+      __syncthreads();
+      // sum the 4 phases, 4 channels per thread-iteration, coalesced 8-byte stores
+      for (int q = tid; q < 2 * 16 * (CT / 4); q += 256) {
+        const int c4 = (q % (CT / 4)) * 4, p = q / (CT / 4);      // p = m*16 + px
+        const int m = p >> 4, px = p & 15;
+        const float* rp = red + p * LDR + c4;
+        float4 s0 = *reinterpret_cast<const float4*>(rp);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+          const float4 t4 = *reinterpret_cast<const float4*>(rp + ww * 2 * 16 * LDR);
+          s0.x += t4.x; s0.y += t4.y; s0.z += t4.z; s0.w += t4.w;
+        }
+        const int oy = ty0 + mf + m, ox = tx0 + px, ci = n0 + c4;
+        if (oy < Hi && ox < Wi && ci < Cin)
+          *reinterpret_cast<uint2*>(Xf + ((long long)oy * Wi + ox) * Cin + ci) = make_uint2(pack2bf(s0.x, s0.y), pack2bf(s0.z, s0.w));
+      }
+      __syncthreads();
+    }
+    if (next < ntiles) commit();
+    __syncthreads();
+  }
+}
+
+template <int KS, int NFI>
+static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  constexpr int LDK = KS * 32 + 8, HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), CT = NFI * 16, LDR = CT + 4;
+  const size_t lds = (size_t)(HPIX * LDK + 64) * 2 + (size_t)4 * 2 * 16 * LDR * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)upconv_dgrad_ws_kernel<KS, NFI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    attr_set = true;
+  }
+  const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
+  const int ct = (Cin + CT - 1) / CT;
+  int nblk = 256 / ct;
+  if (nblk > ntiles) nblk = ntiles;
+  if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL((upconv_dgrad_ws_kernel<KS, NFI>), dim3(nblk, ct), dim3(256), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX,
+                     F, Hi, Wi, Cin, Cout, ntiles);
+  return true;
+}
+bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  if (Cout % 8 || Cin % 4) return false;
+  if (Cout == 48 && Cin == 96) return dgrad_ws_launch<2, 6>(dP, Wd, dX, F, Hi, Wi, Cin, Cout, st);
+  if (Cout == 96 && Cin == 128) return dgrad_ws_launch<3, 4>(dP, Wd, dX, F, Hi, Wi, Cin, Cout, st);
+  return false;
+}
