@@ -56,12 +56,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
 
 // grid = ngroups * nb blocks: block (g, sub) walks the row runs c with c % ngroups == g, so its per-lane dgamma/dbeta
 // partials belong to one parameter group; one atomic per (block, channel) at the end (nb bounds the contention).
+#define LNB_WAVES 16
 template <typename T, int NPL>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                      const float* rstd, T* dx, float* dgamma, float* dbeta,
                                                      long long rows, int C, int gres, int C0, LnGroups G, int nb) {
-  __shared__ float red[2][4][64 * NPL];
+  __shared__ float red[2][64 * NPL];     // block-level dgamma/dbeta partials (LDS atomics), then ONE global atomic per channel
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < 2 * 64 * NPL; c += 64 * LNB_WAVES) (&red[0][0])[c] = 0.f;
+  __syncthreads();
   const int g = blockIdx.x % G.ngroups, sub = blockIdx.x / G.ngroups;
   const long long goff = (long long)g * G.gstride;
   const long long nruns = (rows + G.group_rows - 1) / G.group_rows;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
     // RI rows in flight per wave: all loads of the RI rows are issued before any reduction (memory-level parallelism;
     // one row per iteration was latency-bound at ~1 us per row)
     constexpr int RI = NPL <= 3 ? 4 : (NPL <= 6 ? 2 : 1);
-    for (long long row0 = chunk_begin + w * RI; row0 < rend; row0 += 4 * RI) {
+    for (long long row0 = chunk_begin + w * RI; row0 < rend; row0 += LNB_WAVES * RI) {
       float dv[RI][NPL], xv[RI][NPL], mu[RI], rs[RI];
 #pragma unroll
       for (int u = 0; u < RI; ++u) {
@@ -121,18 +124,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
     }
   }
 #pragma unroll
-  for (int j = 0; j < NPL; ++j) { red[0][w][lane + 64 * j] = ag[j]; red[1][w][lane + 64 * j] = ab[j]; }
+  for (int j = 0; j < NPL; ++j) { atomicAdd(&red[0][lane + 64 * j], ag[j]); atomicAdd(&red[1][lane + 64 * j], ab[j]); }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + goff + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta + goff + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  for (int c = threadIdx.x; c < C; c += 64 * LNB_WAVES) {
+    atomicAdd(dgamma + goff + c, red[0][c]);
+    atomicAdd(dbeta + goff + c, red[1][c]);
   }
 }
 
 #define LN_DISPATCH(NPLV)                                                                                         \
   if (fwd) hipLaunchKernelGGL((ln_fwd_kernel<T, NPLV>), dim3(grid), dim3(256), 0, stream, (const T*)x, gamma, beta, \
                               (T*)y, mean, rstd, rows, C, eps, gres, C0, G);                                       \
-  else hipLaunchKernelGGL((ln_bwd_kernel<T, NPLV>), dim3(grid), dim3(256), 0, stream, (const T*)dy, (const T*)x,    \
+  else hipLaunchKernelGGL((ln_bwd_kernel<T, NPLV>), dim3(grid), dim3(64 * LNB_WAVES), 0, stream, (const T*)dy, (const T*)x,    \
                           gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0, G, nb);
 
 template <typename T>
@@ -146,10 +149,11 @@ static int ln_launch(bool fwd, const void* x, const float* gamma, const float* b
     grid = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
   } else {
     if (G.ngroups <= 1) { G.ngroups = 1; G.gstride = 0; G.group_rows = rows; }
-    // <= ~256 blocks in total share the dgamma/dbeta atomics; every run is cut into S sub-runs of L rows
+    // <= ~64 blocks (of 16 waves) in total share the dgamma/dbeta global atomics (same-address atomics serialise: 256
+    // contending blocks cost ~25 us per launch); every run is cut into S sub-runs of L rows
     const long long nruns = (rows + G.group_rows - 1) / G.group_rows;
     const long long nr = (nruns + G.ngroups - 1) / G.ngroups;
-    long long nbt = (rows / G.ngroups + 15) / 16;
+    long long nbt = (rows / G.ngroups + 63) / 64;
     if (nbt > 256 / G.ngroups) nbt = 256 / G.ngroups;
     if (nbt < 1) nbt = 1;
     long long S = (nbt + nr - 1) / nr;
