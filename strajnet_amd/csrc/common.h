@@ -117,6 +117,9 @@ template <> struct Mma<float> {
     for (int j = 0; j < 4; ++j) f[j] = p[j * sk];
     return f;
   }
+  __device__ static __forceinline__ Frag load_tr(const float* tile, int ldt, int row0, int k0, int lane) {
+    return load_strided(tile, 1, ldt, row0, k0, lane);
+  }
   __device__ static __forceinline__ Frag from_global(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
   static constexpr int LANE_K = 4;   // consecutive k elements per lane per step
   __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
@@ -138,6 +141,17 @@ template <> struct Mma<bf16> {
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (short)p[j * sk];
     return f;
+  }
+  // fragment of an operand stored UN-transposed as [k][rows] (rows contiguous, row stride ldt elements, 8-byte aligned):
+  // two ds_read_b64_tr_b16 (gfx950 LDS transpose read; semantics probed in tools/probes/tr16_probe.hip): lane p of a
+  // 16-lane group reads 4 consecutive rows 4*(p%4).. of k-row (p/4); the hardware hands lane l row (l&15), k-rows 0..3.
+  __device__ static __forceinline__ Frag load_tr(const bf16* tile, int ldt, int row0, int k0, int lane) {
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    const int g = lane >> 4, p = lane & 15;
+    const bf16* a = tile + (k0 + 8 * g + (p >> 2)) * ldt + row0 + 4 * (p & 3);
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a + 4 * ldt));
+    return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   }
   __device__ static __forceinline__ Frag from_global(const bf16* p) { return *reinterpret_cast<const s16x8*>(p); }
   static constexpr int LANE_K = 8;

@@ -9,7 +9,7 @@
 // and read as 16-byte MFMA fragments (ds_read_b128); a row-contiguous ("transposed") operand -- x^T and dY in every
 // weight gradient, W in every forward Dense with Keras [in,out] layout, V in P V -- is staged UN-transposed as
 // [BK][rows] with coalesced 16-byte global reads, and the transposition happens in the fragment read
-// (8 x ds_read_u16 down the k axis; consecutive lanes hit consecutive LDS addresses).  The first version transposed
+// (two ds_read_b64_tr_b16 LDS transpose reads per fragment).  The first version transposed
 // while writing to LDS and lost >10x to 32-way bank conflicts on 2-byte scatter writes (profiles/r01_a_*).
 // The epilogue goes through LDS so that global stores (and residual loads) are full 16-byte row segments.
 // Weight gradients use split-K with f32 atomic accumulation straight into the flat gradient buffer.
@@ -25,7 +25,7 @@ struct GemmArgs {
 };
 
 template <typename T> struct PadT;            // row padding of the un-transposed image: bank-conflict-free strided reads
-template <> struct PadT<bf16> { static constexpr int P = 2; };
+template <> struct PadT<bf16> { static constexpr int P = 4; };   // rows 8-byte aligned for ds_read_b64_tr_b16
 template <> struct PadT<float> { static constexpr int P = 4; };
 
 template <typename T> __device__ __forceinline__ T zero_of() {
@@ -72,9 +72,9 @@ struct Stage {
       const int idx = tid + i * 256;
       const int a = idx / CPR, c = (idx % CPR) * VN;
       T* dst = lds + a * LDX + c;
-      if constexpr (RC && sizeof(T) == 2) {                  // rows only 4-byte aligned (LDT = ROWS + 2)
-        uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-        d[0] = reg[i].x; d[1] = reg[i].y; d[2] = reg[i].z; d[3] = reg[i].w;
+      if constexpr (RC && sizeof(T) == 2) {                  // rows only 8-byte aligned (LDT = ROWS + 4)
+        uint2* d = reinterpret_cast<uint2*>(dst);
+        d[0] = make_uint2(reg[i].x, reg[i].y); d[1] = make_uint2(reg[i].z, reg[i].w);
       } else {
         *reinterpret_cast<uint4*>(dst) = reg[i];
       }
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   constexpr int EPI_BYTES = EP_ROWS * LDC * 4;
   constexpr int SMEM = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  __shared__ float bias_s[BN];            // bias of this column tile: ONE coalesced load instead of per-element global loads in the epilogue
   T* As = reinterpret_cast<T*>(smem);
   T* Bs = As + A_ELEMS_AL;
   float* Cs = reinterpret_cast<float*>(smem);
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool do_cs = p.colsum != nullptr && tm == 0;
   float cs = 0.f;
+  if (tid < BN) bias_s[tid] = (p.bias && ks == 0 && n0 + tid < p.N) ? p.bias[z1 * p.sBias1 + z2 * p.sBias2 + n0 + tid] : 0.f;
 
   typedef Stage<T, BM, BK, TA> SA;
   typedef Stage<T, BN, BK, TB> SB;
@@ -152,12 +154,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       typename Mma<T>::Frag a[FM], b[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        if constexpr (TA) a[i] = Mma<T>::load_strided(As, 1, LDTA, (wm * FM + i) * 16, kk, lane);
+        if constexpr (TA) a[i] = Mma<T>::load_tr(As, LDTA, (wm * FM + i) * 16, kk, lane);
         else a[i] = Mma<T>::load(As, LD, (wm * FM + i) * 16, kk, lane);
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        if constexpr (TB) b[j] = Mma<T>::load_strided(Bs, 1, LDTB, (wn * FN + j) * 16, kk, lane);
+        if constexpr (TB) b[j] = Mma<T>::load_tr(Bs, LDTB, (wn * FN + j) * 16, kk, lane);
         else b[j] = Mma<T>::load(Bs, LD, (wn * FN + j) * 16, kk, lane);
       }
 #pragma unroll
@@ -171,7 +173,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   if (do_cs && tid < BN && n0 + tid < p.N) atomicAdd(p.colsum + z1 * p.sBias1 + z2 * p.sBias2 + n0 + tid, cs);
 
   // ---- epilogue through LDS: EP_ROWS rows per pass, full-row 16-byte global accesses ----
-  const float* bias = (p.bias && ks == 0) ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
   const T* res = p.res ? reinterpret_cast<const T*>(p.res) + z1 * p.sRes1 + z2 * p.sRes2 : nullptr;
   float* Cf = reinterpret_cast<float*>(p.C) + z1 * p.sCb1 + z2 * p.sCb2;
   T* Ct = reinterpret_cast<T*>(p.C) + z1 * p.sCb1 + z2 * p.sCb2;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         const int row = m0 + r0 + r, col = n0 + c;
         if (row < p.M && col < p.N) {
           float v = Cs[r * LDC + c];
-          if (bias) v += bias[col];
+          v += bias_s[c];
           atomicAdd(Cf + (long long)row * p.ldc + col, v);
         }
       }
@@ -206,9 +207,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = Cs[r * LDC + c + e];
-          if (bias && col + e < p.N) v[e] += bias[col + e];
-          v[e] = apply_act(v[e], p.act);
+          v[e] = apply_act(Cs[r * LDC + c + e] + bias_s[c + e], p.act);
         }
         float* dst = Cf + (long long)row * p.ldc + col;
         if (p.vecC && col + 4 <= p.N && !res) {
@@ -227,9 +226,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         float v[VN];
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
-          v[e] = Cs[r * LDC + c + e];
-          if (bias && col + e < p.N) v[e] += bias[col + e];
-          v[e] = apply_act(v[e], p.act);
+          v[e] = apply_act(Cs[r * LDC + c + e] + bias_s[c + e], p.act);
         }
         T* dst = Ct + (long long)row * p.ldc + col;
         if (p.vecC && col + VN <= p.N) {
