@@ -14,6 +14,7 @@
 // The epilogue goes through LDS so that global stores (and residual loads) are full 16-byte row segments.
 // Weight gradients use split-K with f32 atomic accumulation straight into the flat gradient buffer.
 #include "common.h"
+#include <stdlib.h>
 
 struct GemmArgs {
   const void* A; const void* B; void* C; const float* bias; const void* res; float* colsum;
@@ -266,10 +267,14 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nb;
   const long long tiles64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * nb;
   const int ktiles = (p.K + BK - 1) / BK;
+  // Tile choice.  The hot-path GEMMs are skinny (K <= 1536, mostly 96..384) and latency / memory-parallelism bound, not
+  // MFMA bound: measured on every Dense shape of the model, 64x64 tiles (4x the workgroups in flight) beat 128x128 by
+  // 1.3-1.8x (profiles/r01_c_gemm_tiles.txt), so 64x64 is the default; 128x128 only pays for genuinely large problems.
   int cfg;   // 0: 128x128, 1: 128x64 (narrow N), 2: 64x64
-  if (p.N <= 64 && p.M >= 2048) cfg = 1;
-  else if (p.N > 64 && p.M > 64 && tiles128 >= 192) cfg = 0;
+  const double flops = 2.0 * p.M * p.N * (double)p.K * nb;
+  if (p.N > 64 && p.M > 64 && tiles128 >= 1024 && p.K >= 1024 && flops > 2e11) cfg = 0;
   else cfg = 2;
+  { static int f = -2; if (f == -2) { const char* e = getenv("STJ_GEMM_CFG"); f = e ? atoi(e) : -1; } if (f >= 0 && !p.accumulate) cfg = f; }
   if (p.splitk == 0) {            // auto split-K (accumulating GEMMs only): aim at ~2 blocks per CU
     const long long tiles = cfg == 0 ? tiles128 : (cfg == 1 ? (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * nb : tiles64);
     long long s = (384 + tiles - 1) / tiles;
