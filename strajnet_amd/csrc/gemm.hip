@@ -277,8 +277,10 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   { static int f = -2; if (f == -2) { const char* e = getenv("STJ_GEMM_CFG"); f = e ? atoi(e) : -1; } if (f >= 0 && !p.accumulate) cfg = f; }
   if (p.splitk == 0) {            // auto split-K (accumulating GEMMs only): aim at ~2 blocks per CU
     const long long tiles = cfg == 0 ? tiles128 : (cfg == 1 ? (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * nb : tiles64);
-    long long s = (384 + tiles - 1) / tiles;
-    if (s > 48) s = 48;                 // bound same-address atomic contention
+    static int tgt = -1, cap = -1;
+    if (tgt < 0) { const char* e = getenv("STJ_SPLITK_TGT"); tgt = e ? atoi(e) : 768; e = getenv("STJ_SPLITK_CAP"); cap = e ? atoi(e) : 96; }
+    long long s = (tgt + tiles - 1) / tiles;
+    if (s > cap) s = cap;                 // bound same-address atomic contention
     if (s > ktiles / 2) s = ktiles / 2;
     if (s < 1) s = 1;
     if (s * nb > 65535) s = 65535 / nb;
