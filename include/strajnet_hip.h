@@ -101,11 +101,12 @@ int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, 
                      int dtype, hipStream_t stream);
 /* Output heads: Conv2D 3x3 SAME C->2, no activation (modules.py:767-770), written with strides straight into the
  * [B,H,W,32] f32 model output (concat + transpose of modules.py:770,838).  Y element (b,t,y,x,o) at
- * Y + b*y_bstride + t*y_tstride + (y*W+x)*y_pstride + o. */
+ * Y + b*y_bstride + t*y_tstride + (y*W+x)*y_pstride + o.  bwd with elu_in != 0: X is an ELU output, dX is multiplied by
+ * ELU'(x) (gradient w.r.t. the producing conv's pre-activation; the producer then skips its own ELU' pass). */
 int stj_outconv_fwd(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                     long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream);
 int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww,
-                    int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream);
+                    int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int elu_in, int dtype, hipStream_t stream);
 /* PatchEmbed Conv2D k=4 s=4 VALID as im2col (+ f32->T cast, + stride-2 pick of ogm[...,0]; modules.py:430-431,572). */
 int stj_im2col_patch(const float* src, void* dst, int B, int H, int W, int Cin, long long pix_stride, int ch_stride,
                      int dtype, hipStream_t stream);

@@ -36,7 +36,7 @@ SIGNATURES = {
     'stj_upconv_dgrad': [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_upconv_wgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
-    'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
+    'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, ci, vp],
     'stj_im2col_patch': [vp, vp, ci, ci, ci, ci, cl, ci, ci, vp],
     'stj_im2col3': [vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_col2im3': [vp, vp, ci, ci, ci, ci, ci, ci, vp],

@@ -394,7 +394,7 @@ bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbi
 bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                           long long y_bs, long long y_ts, long long y_ps, hipStream_t st);
 bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
-                          int Tn, long long y_bs, long long y_ts, long long y_ps, hipStream_t st);
+                          int Tn, long long y_bs, long long y_ts, long long y_ps, int elu_in, hipStream_t st);
 bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
 static bool ws_enabled() {
   static int v = -1;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* X, const floa
 template <typename T>
 __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* X, const float* W, const float* dY, T* dX, float* dW, float* db,
                                                           int F, int Hh, int Ww, int C, int Tn, long long y_bstride, long long y_tstride,
-                                                          long long y_pstride) {
+                                                          long long y_pstride, int elu_in) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LDC = C + 1;
   float* halo = smem;                       // X halo [18*18][C+1]
@@ -578,6 +578,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* X, const floa
           float acc = 0.f;
 #pragma unroll
           for (int t = 0; t < 9; ++t) acc += g0[t] * Ws[(t * C + c0 + e) * 2] + g1[t] * Ws[(t * C + c0 + e) * 2 + 1];
+          if (elu_in) { const float xv = halo[((py + 1) * 18 + px + 1) * LDC + c0 + e]; acc *= xv > 0.f ? 1.f : xv + 1.f; }
           o[e] = acc;
         }
         st16(dst + c0, o);
@@ -628,20 +629,23 @@ extern "C" int stj_outconv_fwd(const void* X, const float* W, const float* bias,
   }
   return stj_check_launch("stj_outconv_fwd");
 }
+// elu_in != 0: X is the output of an ELU (the producing up-conv); dX is then multiplied by ELU'(x) = (x > 0 ? 1 : x + 1), i.e. the
+// gradient w.r.t. the producer's PRE-activation is returned and the producer skips its own ELU' pass.
 extern "C" int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww,
-                               int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream) {
+                               int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int elu_in, int dtype,
+                               hipStream_t stream) {
   if (Hh % OC_T || Ww % OC_T || C % 8) { stj_set_error("outconv: H,W must be multiples of 16 and C of 8"); return STJ_EINVAL; }
-  if (dtype == STJ_BF16 && ws_enabled() && outconv_bwd_mfma_try(X, W, dY, dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, stream))
+  if (dtype == STJ_BF16 && ws_enabled() && outconv_bwd_mfma_try(X, W, dY, dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, elu_in, stream))
     return stj_check_launch("stj_outconv_bwd(mfma)");
   const size_t lds = (size_t)(18 * 18 * (C + 1) + 9 * C * 2 + 18 * 18 * 2) * 4;
   if (lds > 160 * 1024 || 9 * C > 1024) { stj_set_error("outconv: C=%d too large", C); return STJ_EUNSUPPORTED; }
   const int grid = min(1024, F * (Hh / OC_T) * (Ww / OC_T));
   if (dtype == STJ_BF16) {
     hipFuncSetAttribute((const void*)outconv_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(outconv_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, stream, (const bf16*)X, W, dY, (bf16*)dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride);
+    hipLaunchKernelGGL(outconv_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, stream, (const bf16*)X, W, dY, (bf16*)dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, elu_in);
   } else {
     hipFuncSetAttribute((const void*)outconv_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(outconv_bwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)X, W, dY, (float*)dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride);
+    hipLaunchKernelGGL(outconv_bwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)X, W, dY, (float*)dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, elu_in);
   }
   return stj_check_launch("stj_outconv_bwd");
 }

@@ -436,7 +436,8 @@ __global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const bf16* __res
 template <int C>
 __global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __restrict__ X, const float* __restrict__ W,
                                                                const float* __restrict__ dY, bf16* __restrict__ dX, float* dW, float* db,
-                                                               int F, int Hh, int Ww, int Tn, long long y_bs, long long y_ts, long long y_ps) {
+                                                               int F, int Hh, int Ww, int Tn, long long y_bs, long long y_ts, long long y_ps,
+                                                               int elu_in) {
   static_assert(C == 48, "specialised for 48 channels");
   constexpr int LDH = C + 8;
   constexpr int CPP = C / 8, NCH = (OCM_H * OCM_H * CPP + 255) / 256;
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __res
   __shared__ __attribute__((aligned(16))) bf16 halo[OCM_H * OCM_H * LDH];
   __shared__ __attribute__((aligned(16))) float dys[OCM_H * OCM_H * 2];
   __shared__ __attribute__((aligned(16))) bf16 dyb[OCM_T * OCM_T * 16];      // [pixel][16] bf16, columns 0..1 = dY, rest 0 (B operand of dW)
+  __shared__ __attribute__((aligned(16))) bf16 ostg[OCM_T * OCM_T * LDH];     // dX tile staged for coalesced 16-byte stores
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
   // dX weights: A[m = c][k = (tap, o)], k = 2*tap + o < 18 ; lane row c = mf*16 + ln, k = 8g + j
   s16x8 ax[3];
@@ -527,8 +529,14 @@ __global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __res
 #pragma unroll
       for (int mf = 0; mf < 3; ++mf) {
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax[mf]), __builtin_bit_cast(bf16x8_t, bx), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        *reinterpret_cast<uint2*>(dXf + ((long long)(ty * OCM_T + row) * Ww + tx * OCM_T + ln) * C + mf * 16 + 4 * g) =
-            make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+        if (elu_in) {        // X is the ELU output of the producing conv: fold ELU'(x) = (x > 0 ? 1 : x + 1) into the input gradient
+          const uint2 xv = *reinterpret_cast<const uint2*>(halo + ((row + 1) * OCM_H + ln + 1) * LDH + mf * 16 + 4 * g);
+          const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
+          const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
+          acc[0] *= x0 > 0.f ? 1.f : x0 + 1.f; acc[1] *= x1 > 0.f ? 1.f : x1 + 1.f;
+          acc[2] *= x2 > 0.f ? 1.f : x2 + 1.f; acc[3] *= x3 > 0.f ? 1.f : x3 + 1.f;
+        }
+        *reinterpret_cast<uint2*>(ostg + (row * OCM_T + ln) * LDH + mf * 16 + 4 * g) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
       }
     }
     // ---- dW: this wave's 4 rows = 2 k-steps of 32 pixels (rows y, y+1) ----
@@ -557,6 +565,11 @@ __global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __res
     }
     __syncthreads();
     if (next < ntiles) commit();
+    for (int q = tid; q < OCM_T * OCM_T * (C / 8); q += 256) {       // coalesced 16-byte stores of the dX tile
+      const int px = q / (C / 8), ch = (q % (C / 8)) * 8;
+      *reinterpret_cast<uint4*>(dXf + ((long long)(ty * OCM_T + px / OCM_T) * Ww + tx * OCM_T + px % OCM_T) * C + ch) =
+          *reinterpret_cast<const uint4*>(ostg + px * LDH + ch);
+    }
     __syncthreads();
   }
   // D[m = c][n = o]: lanes with ln < 2 hold dW[t][mf*16 + 4g + r][ln]
@@ -580,10 +593,10 @@ bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, floa
   return true;
 }
 bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
-                          int Tn, long long y_bs, long long y_ts, long long y_ps, hipStream_t st) {
+                          int Tn, long long y_bs, long long y_ts, long long y_ps, int elu_in, hipStream_t st) {
   if (C != 48 || Hh % OCM_T || Ww % OCM_T || (y_ps & 1) || (((uintptr_t)dY) & 7)) return false;
   const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
-  hipLaunchKernelGGL(outconv_bwd_mfma_kernel<48>, dim3(min(ntiles, 512)), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, dW, db, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
+  hipLaunchKernelGGL(outconv_bwd_mfma_kernel<48>, dim3(min(ntiles, 512)), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, dW, db, F, Hh, Ww, Tn, y_bs, y_ts, y_ps, elu_in);
   return true;
 }
 

@@ -516,7 +516,7 @@ def grouped_conv3(x, pw, pb, G):
 # ----------------------------------------------------------------------------------------------------
 class _UpConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_master, b_master, pw, pb):
+    def forward(ctx, x, w_master, b_master, pw, pb, grad_is_pre):
         _req_cuda(x)
         x = x.contiguous()
         F_, Hi, Wi, Cin = x.shape
@@ -530,6 +530,7 @@ class _UpConv(torch.autograd.Function):
         with _timed(f'upconv_fwd[{Hi}x{Wi},{Cin}->{Cout}]', flops):
             call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
         ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
+        ctx.grad_is_pre = grad_is_pre
         ctx.save_for_backward(x, y, wd)
         return y
 
@@ -539,8 +540,11 @@ class _UpConv(torch.autograd.Function):
         F_, Hi, Wi, Cin, Cout = ctx.geo
         dt = _dt(x)
         dy = dy.contiguous()
-        dpre = torch.empty_like(dy)
-        call('stj_unary_bwd', _p(dy), _p(y), _p(dpre), dy.numel(), U_ELU, 0.0, dt, _st())
+        if ctx.grad_is_pre:          # the consumer already folded ELU'(y) into the gradient it returned
+            dpre = dy
+        else:
+            dpre = torch.empty_like(dy)
+            call('stj_unary_bwd', _p(dy), _p(y), _p(dpre), dy.numel(), U_ELU, 0.0, dt, _st())
         flops = 2.0 * 9 * Cin * Cout * 4 * Hi * Wi * F_
         dx = None
         if ctx.needs_input_grad[0]:
@@ -551,18 +555,20 @@ class _UpConv(torch.autograd.Function):
         with _timed(f'upconv_wgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
             call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(ctx.pb.grad), F_, Hi, Wi, Cin, Cout, dt, _st())
         call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def upconv(x, pw, pb):
-    """x [F,Hi,Wi,Cin] -> ELU(conv3x3(upsample2(x)) + b) [F,2Hi,2Wi,Cout]."""
-    return _UpConv.apply(x, pw.master, pb.master, pw, pb)
+def upconv(x, pw, pb, grad_is_pre=False):
+    """x [F,Hi,Wi,Cin] -> ELU(conv3x3(upsample2(x)) + b) [F,2Hi,2Wi,Cout].
+    grad_is_pre=True: contract with the (single) consumer of the output -- it returns the gradient already multiplied by
+    ELU'(y) (outconv_pair(x_is_elu_out=True)), so the separate ELU' pass over the largest tensors is skipped."""
+    return _UpConv.apply(x, pw.master, pb.master, pw, pb, grad_is_pre)
 
 
 class _OutConvPair(torch.autograd.Function):
     """Two 3x3 C->2 heads written straight into the [B,H,W,32] f32 model output (channel 4t+{0,1} and 4t+{2,3})."""
     @staticmethod
-    def forward(ctx, xo, xf, w1m, b1m, w2m, b2m, p1w, p1b, p2w, p2b, B, Tn, t_major):
+    def forward(ctx, xo, xf, w1m, b1m, w2m, b2m, p1w, p1b, p2w, p2b, B, Tn, t_major, x_is_elu_out):
         _req_cuda(xo, xf)
         xo, xf = xo.contiguous(), xf.contiguous()
         F_, H, W, C = xo.shape
@@ -576,6 +582,7 @@ class _OutConvPair(torch.autograd.Function):
         call('stj_outconv_fwd', _p(xf), _p(p2w.master), _p(p2b.master), vp(out.data_ptr() + 8), F_, H, W, C, inner, ybs, yts, yps, dt, _st())
         ctx.ps = (p1w, p1b, p2w, p2b)
         ctx.geo = (F_, H, W, C, inner, ybs, yts, yps)
+        ctx.elu_in = int(bool(x_is_elu_out))
         ctx.save_for_backward(xo, xf)
         return out
 
@@ -588,14 +595,14 @@ class _OutConvPair(torch.autograd.Function):
         dt = _dt(xo)
         dxo, dxf = torch.empty_like(xo), torch.empty_like(xf)
         call('stj_outconv_bwd', _p(xo), _p(p1w.master), vp(dout.data_ptr()), _p(dxo), _p(p1w.grad), _p(p1b.grad), F_, H, W, C, Tn,
-             ybs, yts, yps, dt, _st())
+             ybs, yts, yps, ctx.elu_in, dt, _st())
         call('stj_outconv_bwd', _p(xf), _p(p2w.master), vp(dout.data_ptr() + 8), _p(dxf), _p(p2w.grad), _p(p2b.grad), F_, H, W, C, Tn,
-             ybs, yts, yps, dt, _st())
-        return (dxo, dxf) + (None,) * 11
+             ybs, yts, yps, ctx.elu_in, dt, _st())
+        return (dxo, dxf) + (None,) * 12
 
 
-def outconv_pair(xo, xf, p1w, p1b, p2w, p2b, B, Tn, t_major=False):
-    return _OutConvPair.apply(xo, xf, p1w.master, p1b.master, p2w.master, p2b.master, p1w, p1b, p2w, p2b, B, Tn, t_major)
+def outconv_pair(xo, xf, p1w, p1b, p2w, p2b, B, Tn, t_major=False, x_is_elu_out=False):
+    return _OutConvPair.apply(xo, xf, p1w.master, p1b.master, p2w.master, p2b.master, p1w, p1b, p2w, p2b, B, Tn, t_major, x_is_elu_out)
 
 
 # ----------------------------------------------------------------------------------------------------
