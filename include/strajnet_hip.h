@@ -89,13 +89,14 @@ int stj_fg_bias_bwd(const void* off, const float* table, const void* dbias, floa
 
 /* Decoder: UpSampling3D(1,2,2) nearest + Conv2D 3x3 SAME + bias + ELU (modules.py:746-748,732-735) with the upsample
  * folded into 16 effective 2x2-tap matrices.  prep: W f32 [3,3,Cin,Cout] -> Wf [16,Cout,Cin], Wd [16,Cin,Cout] (T).
- * fwd: X [F,Hi,Wi,Cin] -> Y [F,2Hi,2Wi,Cout].  dgrad: dP (= dY*ELU') -> dX.  wgrad: dWeff f32 [16,Cout,Cin] += (zeroed
+ * fwd: X [F,Hi,Wi,Cin] -> Y [F,2Hi,2Wi,Cout].  dgrad: dP (= dY*ELU') -> dX (times ELU'(Xelu) when Xelu != NULL:
+ * the layer input is itself an ELU output and its producer skips its own ELU' pass).  wgrad: dWeff f32 [16,Cout,Cin] += (zeroed
  * by the caller), dbias f32 [Cout] += ; fold: dW [3,3,Cin,Cout] += fold(dWeff). */
 int stj_upconv_prep(const float* W, void* Wf, void* Wd, int Cin, int Cout, int dtype, hipStream_t stream);
 int stj_upconv_fold(const float* dWeff, float* dW, int Cin, int Cout, hipStream_t stream);
 int stj_upconv_fwd(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin,
                    int Cout, int act, int dtype, hipStream_t stream);
-int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout,
+int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout,
                      int dtype, hipStream_t stream);
 int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout,
                      int dtype, hipStream_t stream);

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const T* X, const T* Wf
 // dgrad
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int FN>
-__global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T* Wd, T* dX, int F, int Hi, int Wi, int Cin, int Cout) {
+__global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T* Wd, T* dX, const T* Xelu, int F, int Hi, int Wi, int Cin, int Cout) {
   constexpr int BN = FN * 16;
   constexpr int LDK = KC + LdsPad<T>::P;
   constexpr int VN = Vec<T>::N, CPR = KC / VN;
@@ -258,7 +258,10 @@ __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T*
       for (int rg = 0; rg < 4; ++rg) {
         const int px = tx0 + (lane >> 4) * 4 + rg;
         if (px >= Wi) continue;
-        stf(Xf + ((long long)py * Wi + px) * Cin + col, acc[m][n][rg]);
+        const long long o = ((long long)py * Wi + px) * Cin + col;
+        float v = acc[m][n][rg];
+        if (Xelu) { const float xv = ldf(Xelu + (long long)f * Hi * Wi * Cin + o); v *= xv > 0.f ? 1.f : xv + 1.f; }
+        stf(Xf + o, v);
       }
     }
   }
@@ -395,7 +398,7 @@ bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, floa
                           long long y_bs, long long y_ts, long long y_ps, hipStream_t st);
 bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
                           int Tn, long long y_bs, long long y_ts, long long y_ps, int elu_in, hipStream_t st);
-bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
+bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
 static bool ws_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("STJ_NO_WS"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -412,23 +415,24 @@ extern "C" int stj_upconv_fwd(const void* X, const void* Wf, const float* bias, 
 }
 
 template <typename T>
-static int upconv_dgrad_launch(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+static int upconv_dgrad_launch(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   const int tiles = ((Wi + TILE_W - 1) / TILE_W) * ((Hi + TILE_H - 1) / TILE_H) * F;
   if (Cin % 96 == 0 && Cin % 64 != 0) {
-    hipLaunchKernelGGL((upconv_dgrad_kernel<T, 6>), dim3(tiles, Cin / 96), dim3(256), 0, st, (const T*)dP, (const T*)Wd, (T*)dX, F, Hi, Wi, Cin, Cout);
+    hipLaunchKernelGGL((upconv_dgrad_kernel<T, 6>), dim3(tiles, Cin / 96), dim3(256), 0, st, (const T*)dP, (const T*)Wd, (T*)dX, (const T*)Xelu, F, Hi, Wi, Cin, Cout);
   } else {
-    hipLaunchKernelGGL((upconv_dgrad_kernel<T, 4>), dim3(tiles, (Cin + 63) / 64), dim3(256), 0, st, (const T*)dP, (const T*)Wd, (T*)dX, F, Hi, Wi, Cin, Cout);
+    hipLaunchKernelGGL((upconv_dgrad_kernel<T, 4>), dim3(tiles, (Cin + 63) / 64), dim3(256), 0, st, (const T*)dP, (const T*)Wd, (T*)dX, (const T*)Xelu, F, Hi, Wi, Cin, Cout);
   }
   return stj_check_launch("stj_upconv_dgrad");
 }
-extern "C" int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout,
+// Xelu (nullable): the layer input X when it is itself an ELU output; dX is then multiplied by ELU'(x) = (x > 0 ? 1 : x + 1).
+extern "C" int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout,
                                 int dtype, hipStream_t stream) {
   int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
   if (e) return e;
-  if (dtype == STJ_BF16 && ws_enabled() && upconv_dgrad_ws_try(dP, Wd, dX, F, Hi, Wi, Cin, Cout, stream))
+  if (dtype == STJ_BF16 && ws_enabled() && upconv_dgrad_ws_try(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream))
     return stj_check_launch("stj_upconv_dgrad(ws)");
-  return dtype == STJ_BF16 ? upconv_dgrad_launch<bf16>(dP, Wd, dX, F, Hi, Wi, Cin, Cout, stream)
-                           : upconv_dgrad_launch<float>(dP, Wd, dX, F, Hi, Wi, Cin, Cout, stream);
+  return dtype == STJ_BF16 ? upconv_dgrad_launch<bf16>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream)
+                           : upconv_dgrad_launch<float>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream);
 }
 
 template <typename T>

@@ -610,8 +610,8 @@ bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* 
 // =====================================================================================================
 template <int KS, int NFI>
 __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ Wd,
-                                                                 bf16* __restrict__ dX, int F, int Hi, int Wi, int Cin, int Cout,
-                                                                 int ntiles) {
+                                                                 bf16* __restrict__ dX, const bf16* __restrict__ Xelu, int F, int Hi,
+                                                                 int Wi, int Cin, int Cout, int ntiles) {
   constexpr int LDK = KS * 32 + 8;                 // halo pixel stride (elements); channels >= Cout stay zero
   constexpr int HH = 2 * WS_TH + 2, HW = 2 * WS_TW + 2, HPIX = HH * HW;
   constexpr int CT = NFI * 16;                     // cin tile of this workgroup
@@ -729,8 +729,17 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
           s0.x += t4.x; s0.y += t4.y; s0.z += t4.z; s0.w += t4.w;
         }
         const int oy = ty0 + mf + m, ox = tx0 + px, ci = n0 + c4;
-        if (oy < Hi && ox < Wi && ci < Cin)
-          *reinterpret_cast<uint2*>(Xf + ((long long)oy * Wi + ox) * Cin + ci) = make_uint2(pack2bf(s0.x, s0.y), pack2bf(s0.z, s0.w));
+        if (oy < Hi && ox < Wi && ci < Cin) {
+          const long long o = ((long long)oy * Wi + ox) * Cin + ci;
+          if (Xelu) {      // layer input is an ELU output: return the gradient w.r.t. the producer's pre-activation
+            const uint2 xv = *reinterpret_cast<const uint2*>(Xelu + (long long)f * Hi * Wi * Cin + o);
+            const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
+            const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
+            s0.x *= x0 > 0.f ? 1.f : x0 + 1.f; s0.y *= x1 > 0.f ? 1.f : x1 + 1.f;
+            s0.z *= x2 > 0.f ? 1.f : x2 + 1.f; s0.w *= x3 > 0.f ? 1.f : x3 + 1.f;
+          }
+          *reinterpret_cast<uint2*>(Xf + o) = make_uint2(pack2bf(s0.x, s0.y), pack2bf(s0.z, s0.w));
+        }
       }
       __syncthreads();
     }
@@ -740,7 +749,7 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
 }
 
 template <int KS, int NFI>
-static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   constexpr int LDK = KS * 32 + 8, HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), CT = NFI * 16, LDR = CT + 4;
   const size_t lds = (size_t)(HPIX * LDK + 64) * 2 + (size_t)4 * 2 * 16 * LDR * 4;
   static bool attr_set = false;
@@ -754,12 +763,12 @@ static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, int F, int
   if (nblk > ntiles) nblk = ntiles;
   if (nblk < 1) nblk = 1;
   hipLaunchKernelGGL((upconv_dgrad_ws_kernel<KS, NFI>), dim3(nblk, ct), dim3(256), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX,
-                     F, Hi, Wi, Cin, Cout, ntiles);
+                     (const bf16*)Xelu, F, Hi, Wi, Cin, Cout, ntiles);
   return true;
 }
-bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   if (Cout % 8 || Cin % 4) return false;
-  if (Cout == 48 && Cin == 96) return dgrad_ws_launch<2, 6>(dP, Wd, dX, F, Hi, Wi, Cin, Cout, st);
-  if (Cout == 96 && Cin == 128) return dgrad_ws_launch<3, 4>(dP, Wd, dX, F, Hi, Wi, Cin, Cout, st);
+  if (Cout == 48 && Cin == 96) return dgrad_ws_launch<2, 6>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
+  if (Cout == 96 && Cin == 128) return dgrad_ws_launch<3, 4>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
   return false;
 }

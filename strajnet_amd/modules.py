@@ -458,17 +458,17 @@ class STrajNet:
         hb = self.hb
         flow_res, r0, r1 = res_list[0], res_list[1], res_list[2]
 
-        def up(t, name, grad_is_pre=False):
-            return ops.upconv(t, self._p(name + '/kernel'), self._p(name + '/bias'), grad_is_pre)
+        def up(t, name, grad_is_pre=False, x_is_elu_out=False):
+            return ops.upconv(t, self._p(name + '/kernel'), self._p(name + '/bias'), grad_is_pre, x_is_elu_out)
         x = x.view(8 * B, hb, hb, -1)                                                # frames are TIME-major: f = t*B + b
         x = up(x, 'decoder/upconv_3_0')                                              # [F,2hb,2hb,192]
         x = x + self._resconv(r1, 'decoder/resconv_3').view(x.shape)
         x = up(x, 'decoder/upconv_2_0')                                              # [F,4hb,4hb,128]
         x = x + self._resconv(r0, 'decoder/resconv_2').view(x.shape)
         fx = x + self._resconv(flow_res, 'decoder/resconv_f').view(x.shape)
-        # the 256x256x48 tensors feed only the output heads, whose backward folds ELU' into the gradient it returns
-        x = up(up(x, 'decoder/upconv_1_0'), 'decoder/upconv_0_0', grad_is_pre=True)
-        fx = up(up(fx, 'decoder/upconvf_1_0'), 'decoder/upconvf_0_0', grad_is_pre=True)
+        # the last two levels of each branch have a single consumer, whose backward folds ELU' into the gradient it returns
+        x = up(up(x, 'decoder/upconv_1_0', grad_is_pre=True), 'decoder/upconv_0_0', grad_is_pre=True, x_is_elu_out=True)
+        fx = up(up(fx, 'decoder/upconvf_1_0', grad_is_pre=True), 'decoder/upconvf_0_0', grad_is_pre=True, x_is_elu_out=True)
         return ops.outconv_pair(x, fx, self._p('decoder/outconv/kernel'), self._p('decoder/outconv/bias'),
                                 self._p('decoder/outconv_f/kernel'), self._p('decoder/outconv_f/bias'), B, 8, t_major=True, x_is_elu_out=True)
 

@@ -516,7 +516,7 @@ def grouped_conv3(x, pw, pb, G):
 # ----------------------------------------------------------------------------------------------------
 class _UpConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_master, b_master, pw, pb, grad_is_pre):
+    def forward(ctx, x, w_master, b_master, pw, pb, grad_is_pre, x_is_elu_out):
         _req_cuda(x)
         x = x.contiguous()
         F_, Hi, Wi, Cin = x.shape
@@ -530,7 +530,7 @@ class _UpConv(torch.autograd.Function):
         with _timed(f'upconv_fwd[{Hi}x{Wi},{Cin}->{Cout}]', flops):
             call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
         ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
-        ctx.grad_is_pre = grad_is_pre
+        ctx.grad_is_pre, ctx.x_is_elu_out = grad_is_pre, x_is_elu_out
         ctx.save_for_backward(x, y, wd)
         return y
 
@@ -550,19 +550,20 @@ class _UpConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with _timed(f'upconv_dgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
-                call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), F_, Hi, Wi, Cin, Cout, dt, _st())
+                call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), _p(x) if ctx.x_is_elu_out else None, F_, Hi, Wi, Cin, Cout, dt, _st())
         dweff = torch.zeros((16, Cout, Cin), dtype=torch.float32, device=x.device)
         with _timed(f'upconv_wgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
             call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(ctx.pb.grad), F_, Hi, Wi, Cin, Cout, dt, _st())
         call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
-def upconv(x, pw, pb, grad_is_pre=False):
+def upconv(x, pw, pb, grad_is_pre=False, x_is_elu_out=False):
     """x [F,Hi,Wi,Cin] -> ELU(conv3x3(upsample2(x)) + b) [F,2Hi,2Wi,Cout].
     grad_is_pre=True: contract with the (single) consumer of the output -- it returns the gradient already multiplied by
-    ELU'(y) (outconv_pair(x_is_elu_out=True)), so the separate ELU' pass over the largest tensors is skipped."""
-    return _UpConv.apply(x, pw.master, pb.master, pw, pb, grad_is_pre)
+    ELU'(y) (outconv_pair / upconv with x_is_elu_out=True), so the separate ELU' pass over the largest tensors is skipped.
+    x_is_elu_out=True: x is the ELU output of a producer called with grad_is_pre=True; dx is returned times ELU'(x)."""
+    return _UpConv.apply(x, pw.master, pb.master, pw, pb, grad_is_pre, x_is_elu_out)
 
 
 class _OutConvPair(torch.autograd.Function):

@@ -288,6 +288,41 @@ def test_outconv_pair(dt):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
+def test_decoder_tail_fused_elu_bwd(dt):
+    """up(128->96) -> up(96->48) -> output heads with the ELU' passes folded into the consumers' backward kernels
+    (grad_is_pre / x_is_elu_out, t-major frames) == the unfused chain in f64 (modules.py:746-748,767-770,838)."""
+    from strajnet_amd import ops
+    B, Tn, H0 = 1, 8, 8
+    p1 = [mk_param((3, 3, 128, 96), dt, 0.05, 1), mk_param((96,), dt, 0.1, 2)]
+    p0 = [mk_param((3, 3, 96, 48), dt, 0.05, 3), mk_param((48,), dt, 0.1, 4)]
+    po = [mk_param((3, 3, 48, 2), dt, 0.1, 5), mk_param((2,), dt, 0.1, 6), mk_param((3, 3, 48, 2), dt, 0.1, 7), mk_param((2,), dt, 0.1, 8)]
+    xs = [rnd((Tn * B, H0, H0, 128), dt, 9 + i).requires_grad_(True) for i in range(2)]
+    hs = [ops.upconv(ops.upconv(x, *p1, True, False), *p0, True, True) for x in xs]
+    out = ops.outconv_pair(hs[0], hs[1], *po, B, Tn, t_major=True, x_is_elu_out=True)
+
+    def upr(t, w, b):
+        u = F.interpolate(t.permute(0, 3, 1, 2), scale_factor=2, mode='nearest')
+        return F.elu(F.conv2d(u, w.permute(3, 2, 0, 1), b, padding=1)).permute(0, 2, 3, 1)
+
+    def cv(t, w, b):
+        return F.conv2d(t.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, padding=1).permute(0, 2, 3, 1)
+    r1, r0, ro = [ref_of(p.master) for p in p1], [ref_of(p.master) for p in p0], [ref_of(p.master) for p in po]
+    xr = [ref_of(x) for x in xs]
+    hr = [upr(upr(x, *r1), *r0) for x in xr]
+    H = 4 * H0
+    y = torch.cat([cv(hr[0], ro[0], ro[1]), cv(hr[1], ro[2], ro[3])], -1).view(Tn, B, H, H, 4)      # frames t-major
+    outr = y.permute(1, 2, 3, 0, 4).reshape(B, H, H, 4 * Tn)
+    assert rel_err(out, outr) < tol(dt)
+    g = torch.randn(B, H, H, 4 * Tn, generator=torch.Generator().manual_seed(7))
+    out.backward(g.cuda())
+    outr.backward(g.double())
+    for x, r in zip(xs, xr):
+        assert rel_err(x.grad, r.grad) < 2 * tol(dt)
+    for p, r in zip(p1 + p0 + po, r1 + r0 + ro):
+        assert rel_err(p.grad, r.grad) < 2 * tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
 def test_grouped_conv3(dt):
     from strajnet_amd import ops
     N, H, G, Cg = 2, 16, 8, 48
