@@ -107,7 +107,9 @@ int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, 
 int stj_outconv_fwd(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                     long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream);
 int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww,
-                    int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int elu_in, int dtype, hipStream_t stream);
+                    int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int elu_in, void* ws,
+                    long long ws_bytes, int dtype, hipStream_t stream);
+long long stj_outconv_bwd_workspace_bytes(void);   /* size of the caller-owned scratch `ws` (not zeroed; may be NULL: slower path) */
 /* PatchEmbed Conv2D k=4 s=4 VALID as im2col (+ f32->T cast, + stride-2 pick of ogm[...,0]; modules.py:430-431,572). */
 int stj_im2col_patch(const float* src, void* dst, int B, int H, int W, int Cin, long long pix_stride, int ch_stride,
                      int dtype, hipStream_t stream);

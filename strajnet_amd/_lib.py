@@ -36,7 +36,8 @@ SIGNATURES = {
     'stj_upconv_dgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_upconv_wgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
-    'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, ci, vp],
+    'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp, cl, ci, vp],
+    'stj_outconv_bwd_workspace_bytes': [],
     'stj_im2col_patch': [vp, vp, ci, ci, ci, ci, cl, ci, ci, vp],
     'stj_im2col3': [vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_col2im3': [vp, vp, ci, ci, ci, ci, ci, ci, vp],
@@ -64,6 +65,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError here == header / library mismatch
             fn.argtypes = args
             fn.restype = ci
+        L.stj_outconv_bwd_workspace_bytes.restype = ctypes.c_longlong
         L.stj_last_error.argtypes = []
         L.stj_last_error.restype = ctypes.c_char_p
         _lib = L

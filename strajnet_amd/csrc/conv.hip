@@ -397,7 +397,8 @@ bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbi
 bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                           long long y_bs, long long y_ts, long long y_ps, hipStream_t st);
 bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
-                          int Tn, long long y_bs, long long y_ts, long long y_ps, int elu_in, hipStream_t st);
+                          int Tn, long long y_bs, long long y_ts, long long y_ps, int elu_in, void* ws, long long ws_bytes, hipStream_t st);
+long long outconv_bwd_ws_bytes();
 bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
 static bool ws_enabled() {
   static int v = -1;
@@ -633,13 +634,16 @@ extern "C" int stj_outconv_fwd(const void* X, const float* W, const float* bias,
   }
   return stj_check_launch("stj_outconv_fwd");
 }
+// ws: caller-owned scratch of stj_outconv_bwd_workspace_bytes() bytes (need not be zeroed; per-block dW/db partials of the bf16
+// path live there between its two kernels); without it the slower generic kernel runs.
+extern "C" long long stj_outconv_bwd_workspace_bytes() { return outconv_bwd_ws_bytes(); }
 // elu_in != 0: X is the output of an ELU (the producing up-conv); dX is then multiplied by ELU'(x) = (x > 0 ? 1 : x + 1), i.e. the
 // gradient w.r.t. the producer's PRE-activation is returned and the producer skips its own ELU' pass.
 extern "C" int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww,
-                               int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int elu_in, int dtype,
-                               hipStream_t stream) {
+                               int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int elu_in, void* ws,
+                               long long ws_bytes, int dtype, hipStream_t stream) {
   if (Hh % OC_T || Ww % OC_T || C % 8) { stj_set_error("outconv: H,W must be multiples of 16 and C of 8"); return STJ_EINVAL; }
-  if (dtype == STJ_BF16 && ws_enabled() && outconv_bwd_mfma_try(X, W, dY, dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, elu_in, stream))
+  if (dtype == STJ_BF16 && ws_enabled() && outconv_bwd_mfma_try(X, W, dY, dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, elu_in, ws, ws_bytes, stream))
     return stj_check_launch("stj_outconv_bwd(mfma)");
   const size_t lds = (size_t)(18 * 18 * (C + 1) + 9 * C * 2 + 18 * 18 * 2) * 4;
   if (lds > 160 * 1024 || 9 * C > 1024) { stj_set_error("outconv: C=%d too large", C); return STJ_EUNSUPPORTED; }

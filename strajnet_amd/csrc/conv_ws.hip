@@ -433,19 +433,25 @@ __global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const bf16* __res
   }
 }
 
+// Backward.  Occupancy is what matters here (the first MFMA version held all 27 (tap, channel-block) dW accumulators in every
+// wave: 332 VGPRs, one wave per SIMD, and 1.8 M same-address f32 atomics for dW -- 0.5-0.6 ms per head).  Now: wave w owns 7 of
+// the 27 dW accumulators and walks all 16 rows of the tile, so a block needs 168 VGPRs and 39 KB LDS -> 3 blocks per CU (0.28 ms per head); dW/db
+// partials leave as plain stores into a caller-provided workspace [blocks][866] and a small second kernel sums them.
+#define OCB_PART (9 * 48 * 2 + 2)
+#define OCB_MAXBLK 768
 template <int C>
-__global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __restrict__ X, const float* __restrict__ W,
-                                                               const float* __restrict__ dY, bf16* __restrict__ dX, float* dW, float* db,
-                                                               int F, int Hh, int Ww, int Tn, long long y_bs, long long y_ts, long long y_ps,
-                                                               int elu_in) {
+__global__ __launch_bounds__(256, 3) void outconv_bwd_mfma_kernel(const bf16* __restrict__ X, const float* __restrict__ W,
+                                                                  const float* __restrict__ dY, bf16* __restrict__ dX,
+                                                                  float* __restrict__ part, int F, int Hh, int Ww, int Tn,
+                                                                  long long y_bs, long long y_ts, long long y_ps, int elu_in) {
   static_assert(C == 48, "specialised for 48 channels");
   constexpr int LDH = C + 8;
   constexpr int CPP = C / 8, NCH = (OCM_H * OCM_H * CPP + 255) / 256;
   constexpr int NDY = (OCM_H * OCM_H + 255) / 256;
+  constexpr int NACC = 7;                          // ceil(27 / 4) accumulators per wave
   __shared__ __attribute__((aligned(16))) bf16 halo[OCM_H * OCM_H * LDH];
   __shared__ __attribute__((aligned(16))) float dys[OCM_H * OCM_H * 2];
-  __shared__ __attribute__((aligned(16))) bf16 dyb[OCM_T * OCM_T * 16];      // [pixel][16] bf16, columns 0..1 = dY, rest 0 (B operand of dW)
-  __shared__ __attribute__((aligned(16))) bf16 ostg[OCM_T * OCM_T * LDH];     // dX tile staged for coalesced 16-byte stores
+  __shared__ float dbs[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
   // dX weights: A[m = c][k = (tap, o)], k = 2*tap + o < 18 ; lane row c = mf*16 + ln, k = 8g + j
   s16x8 ax[3];
@@ -456,13 +462,17 @@ __global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __res
     for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; v[j] = k < 18 ? W[((k >> 1) * C + mf * 16 + ln) * 2 + (k & 1)] : 0.f; }
     ax[mf] = __builtin_bit_cast(s16x8, make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])));
   }
-  f32x4 wacc[9][3];
+  // dW accumulators of this wave: combo c = 7w + i  ->  tap t = c / 3, channel block mf = c % 3
+  f32x4 wacc[NACC];
+  int aoff[NACC];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int mf = 0; mf < 3; ++mf) wacc[t][mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NACC; ++i) {
+    wacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int c = min(NACC * w + i, 26), t = c / 3, mf = c % 3;
+    aoff[i] = ((t / 3) * OCM_H + t % 3) * LDH + mf * 16;
+  }
   float db0 = 0.f, db1 = 0.f;
-  for (int i = tid; i < OCM_T * OCM_T * 16; i += 256) dyb[i].v = 0;
+  if (tid < 2) dbs[tid] = 0.f;
   const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T, ntiles = F * tiles_x * tiles_y;
   uint4 pre[NCH];
   float2 pdy[NDY];
@@ -497,12 +507,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __res
 #pragma unroll
     for (int u = 0; u < NDY; ++u) {
       const int q = tid + u * 256;
-      if (q < OCM_H * OCM_H) {
-        *reinterpret_cast<float2*>(dys + 2 * q) = pdy[u];
-        const int hy = q / OCM_H, hx = q % OCM_H;
-        if (hy >= 1 && hy <= OCM_T && hx >= 1 && hx <= OCM_T)
-          *reinterpret_cast<uint32_t*>(dyb + ((hy - 1) * OCM_T + hx - 1) * 16) = pack2bf(pdy[u].x, pdy[u].y);
-      }
+      if (q < OCM_H * OCM_H) *reinterpret_cast<float2*>(dys + 2 * q) = pdy[u];
     }
   };
   int tile = blockIdx.x;
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __res
     const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, f = t2 / tiles_y;
     bf16* dXf = dX + (long long)f * Hh * Ww * C;
     // ---- dX rows 4w .. 4w+3 ----
-#pragma unroll
+#pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
       const int row = 4 * w + rr;
       // B[k = 2*tap + o][n = pixel ln] = dY[(row,ln) - off(tap)][o]; this lane supplies taps 4g .. 4g+3
@@ -526,6 +531,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __res
         d[j] = t < 9 ? *reinterpret_cast<const float2*>(dys + 2 * ((row + 2 - t / 3) * OCM_H + ln + 2 - t % 3)) : make_float2(0.f, 0.f);
       }
       const s16x8 bx = __builtin_bit_cast(s16x8, make_uint4(pack2bf(d[0].x, d[0].y), pack2bf(d[1].x, d[1].y), pack2bf(d[2].x, d[2].y), pack2bf(d[3].x, d[3].y)));
+      bf16* orow = dXf + ((long long)(ty * OCM_T + row) * Ww + tx * OCM_T + ln) * C + 4 * g;
 #pragma unroll
       for (int mf = 0; mf < 3; ++mf) {
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax[mf]), __builtin_bit_cast(bf16x8_t, bx), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -536,26 +542,24 @@ __global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __res
           acc[0] *= x0 > 0.f ? 1.f : x0 + 1.f; acc[1] *= x1 > 0.f ? 1.f : x1 + 1.f;
           acc[2] *= x2 > 0.f ? 1.f : x2 + 1.f; acc[3] *= x3 > 0.f ? 1.f : x3 + 1.f;
         }
-        *reinterpret_cast<uint2*>(ostg + (row * OCM_T + ln) * LDH + mf * 16 + 4 * g) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+        // the three stores of a row fill whole 96-byte pixels back to back; L2 merges them into full lines
+        *reinterpret_cast<uint2*>(orow + mf * 16) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
       }
     }
-    // ---- dW: this wave's 4 rows = 2 k-steps of 32 pixels (rows y, y+1) ----
+    // ---- dW: k-step kk = tile rows 2kk, 2kk+1 (32 pixels); every wave walks all 8 k-steps for its own accumulators ----
+#pragma unroll 1
+    for (int kk = 0; kk < OCM_T / 2; ++kk) {
+      // B[k = pixel][n = o]: lane (g, ln) supplies pixels 8g .. 8g+7 of the k-step for output channel ln (0 beyond the 2 real ones)
+      const float* dp = dys + 2 * ((2 * kk + (g >> 1) + 1) * OCM_H + 8 * (g & 1) + 1) + (ln & 1);
+      float dv[8];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int y = 4 * w + 2 * kk + (g >> 1);          // tile row of this lane's k group
-      // B[k = pixel][n = o]: lane n = ln reads dyb[pixel 8g'+j][n]
-      const bf16* bp = dyb + ((4 * w + 2 * kk) * OCM_T + 8 * g) * 16 + ln;       // pixels (row y0, 8g..) linear index = y0*16 + 8g + j (g>=2 -> next row)
-      s16x8 bw;
+      for (int j = 0; j < 8; ++j) dv[j] = ln < 2 ? dp[2 * j] : 0.f;
+      const s16x8 bw = __builtin_bit_cast(s16x8, make_uint4(pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3]), pack2bf(dv[4], dv[5]), pack2bf(dv[6], dv[7])));
+      const bf16* ap = halo + ((2 * kk + (g >> 1)) * OCM_H + kpx) * LDH + kch;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bw[j] = (short)bp[j * 16].v;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const bf16* ap = halo + ((y + t / 3) * OCM_H + kpx + t % 3) * LDH + kch;
-#pragma unroll
-        for (int mf = 0; mf < 3; ++mf) {
-          const s16x8 aw = tr_frag(ap + mf * 16, ap + 4 * LDH + mf * 16);
-          wacc[t][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), __builtin_bit_cast(bf16x8_t, bw), wacc[t][mf], 0, 0, 0);
-        }
+      for (int i = 0; i < NACC; ++i) {
+        const s16x8 aw = tr_frag(ap + aoff[i], ap + aoff[i] + 4 * LDH);
+        wacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), __builtin_bit_cast(bf16x8_t, bw), wacc[i], 0, 0, 0);
       }
     }
     {
@@ -565,24 +569,33 @@ __global__ __launch_bounds__(256) void outconv_bwd_mfma_kernel(const bf16* __res
     }
     __syncthreads();
     if (next < ntiles) commit();
-    for (int q = tid; q < OCM_T * OCM_T * (C / 8); q += 256) {       // coalesced 16-byte stores of the dX tile
-      const int px = q / (C / 8), ch = (q % (C / 8)) * 8;
-      *reinterpret_cast<uint4*>(dXf + ((long long)(ty * OCM_T + px / OCM_T) * Ww + tx * OCM_T + px % OCM_T) * C + ch) =
-          *reinterpret_cast<const uint4*>(ostg + px * LDH + ch);
-    }
     __syncthreads();
   }
-  // D[m = c][n = o]: lanes with ln < 2 hold dW[t][mf*16 + 4g + r][ln]
+  // partials: D[m = c][n = o] -> lanes with ln < 2 hold dW[t][mf*16 + 4g + r][ln]
+  float* mypart = part + (long long)blockIdx.x * OCB_PART;
   if (ln < 2) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int i = 0; i < NACC; ++i) {
+      const int c = NACC * w + i, t = c / 3, mf = c % 3;
+      if (c < 27) {
 #pragma unroll
-      for (int mf = 0; mf < 3; ++mf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(dW + (t * C + mf * 16 + 4 * g + r) * 2 + ln, wacc[t][mf][r]);
+        for (int r = 0; r < 4; ++r) mypart[(t * C + mf * 16 + 4 * g + r) * 2 + ln] = wacc[i][r];
+      }
+    }
   }
   db0 = wave_sum(db0); db1 = wave_sum(db1);
-  if (lane == 0) { atomicAdd(db, db0); atomicAdd(db + 1, db1); }
+  if (lane == 0) { atomicAdd(&dbs[0], db0); atomicAdd(&dbs[1], db1); }
+  __syncthreads();
+  if (tid < 2) mypart[9 * C * 2 + tid] = dbs[tid];
+}
+
+// sums the per-block partials: grid (ceil(866 / 64), 16 row groups) x 64 threads
+__global__ __launch_bounds__(64) void outconv_bwd_reduce_kernel(const float* __restrict__ part, int nblk, float* dW, float* db) {
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  if (idx >= OCB_PART) return;
+  float s = 0.f;
+  for (int r = blockIdx.y; r < nblk; r += gridDim.y) s += part[(long long)r * OCB_PART + idx];
+  atomicAdd(idx < OCB_PART - 2 ? dW + idx : db + (idx - (OCB_PART - 2)), s);
 }
 
 bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
@@ -592,11 +605,16 @@ bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, floa
   hipLaunchKernelGGL(outconv_fwd_mfma_kernel<48>, dim3(min(ntiles, 1024)), dim3(256), 0, st, (const bf16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
   return true;
 }
+long long outconv_bwd_ws_bytes() { return (long long)OCB_MAXBLK * OCB_PART * sizeof(float); }
 bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
-                          int Tn, long long y_bs, long long y_ts, long long y_ps, int elu_in, hipStream_t st) {
+                          int Tn, long long y_bs, long long y_ts, long long y_ps, int elu_in, void* ws, long long ws_bytes, hipStream_t st) {
   if (C != 48 || Hh % OCM_T || Ww % OCM_T || (y_ps & 1) || (((uintptr_t)dY) & 7)) return false;
+  if (!ws || ws_bytes < outconv_bwd_ws_bytes()) return false;
   const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
-  hipLaunchKernelGGL(outconv_bwd_mfma_kernel<48>, dim3(min(ntiles, 512)), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, dW, db, F, Hh, Ww, Tn, y_bs, y_ts, y_ps, elu_in);
+  const int nblk = min(ntiles, OCB_MAXBLK);          // 3 resident blocks per CU (168 VGPRs, 39 KB LDS): measured best of 512/768/1024
+  hipLaunchKernelGGL(outconv_bwd_mfma_kernel<48>, dim3(nblk), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, (float*)ws, F, Hh, Ww, Tn,
+                     y_bs, y_ts, y_ps, elu_in);
+  hipLaunchKernelGGL(outconv_bwd_reduce_kernel, dim3((OCB_PART + 63) / 64, 16), dim3(64), 0, st, (const float*)ws, nblk, dW, db);
   return true;
 }
 
@@ -686,6 +704,20 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
     bf16* Xf = dX + (long long)f * Hi * Wi * Cin;
 #pragma unroll 1
     for (int mf = 0; mf < WS_TH; mf += 2) {
+      // ELU' operand of the epilogue (layer input x): issued before the MFMA work so its latency is hidden
+      constexpr int NEP = (2 * 16 * (CT / 4) + 255) / 256;
+      uint2 xin[NEP];
+      if (Xelu) {
+#pragma unroll
+        for (int i = 0; i < NEP; ++i) {
+          const int q = tid + i * 256;
+          const int c4 = (q % (CT / 4)) * 4, p = q / (CT / 4);
+          const int oy = ty0 + mf + (p >> 4), ox = tx0 + (p & 15), ci = n0 + c4;
+          xin[i] = make_uint2(0x3f803f80u, 0x3f803f80u);
+          if (q < 2 * 16 * (CT / 4) && oy < Hi && ox < Wi && ci < Cin)
+            xin[i] = *reinterpret_cast<const uint2*>(Xelu + ((long long)f * Hi * Wi + (long long)oy * Wi + ox) * Cin + ci);
+        }
+      }
       f32x4 acc[2][NFI];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -718,7 +750,10 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
           *reinterpret_cast<float4*>(red + ((w * 2 + m) * 16 + ln) * LDR + n * 16 + g * 4) = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
       __syncthreads();
       // sum the 4 phases, 4 channels per thread-iteration, coalesced 8-byte stores
-      for (int q = tid; q < 2 * 16 * (CT / 4); q += 256) {
+#pragma unroll
+      for (int i = 0; i < NEP; ++i) {
+        const int q = tid + i * 256;
+        if (q >= 2 * 16 * (CT / 4)) break;
         const int c4 = (q % (CT / 4)) * 4, p = q / (CT / 4);      // p = m*16 + px
         const int m = p >> 4, px = p & 15;
         const float* rp = red + p * LDR + c4;
@@ -730,15 +765,14 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
         }
         const int oy = ty0 + mf + m, ox = tx0 + px, ci = n0 + c4;
         if (oy < Hi && ox < Wi && ci < Cin) {
-          const long long o = ((long long)oy * Wi + ox) * Cin + ci;
           if (Xelu) {      // layer input is an ELU output: return the gradient w.r.t. the producer's pre-activation
-            const uint2 xv = *reinterpret_cast<const uint2*>(Xelu + (long long)f * Hi * Wi * Cin + o);
+            const uint2 xv = xin[i];
             const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
             const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
             s0.x *= x0 > 0.f ? 1.f : x0 + 1.f; s0.y *= x1 > 0.f ? 1.f : x1 + 1.f;
             s0.z *= x2 > 0.f ? 1.f : x2 + 1.f; s0.w *= x3 > 0.f ? 1.f : x3 + 1.f;
           }
-          *reinterpret_cast<uint2*>(Xf + o) = make_uint2(pack2bf(s0.x, s0.y), pack2bf(s0.z, s0.w));
+          *reinterpret_cast<uint2*>(Xf + ((long long)oy * Wi + ox) * Cin + ci) = make_uint2(pack2bf(s0.x, s0.y), pack2bf(s0.z, s0.w));
         }
       }
       __syncthreads();

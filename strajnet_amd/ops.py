@@ -566,6 +566,18 @@ def upconv(x, pw, pb, grad_is_pre=False, x_is_elu_out=False):
     return _UpConv.apply(x, pw.master, pb.master, pw, pb, grad_is_pre, x_is_elu_out)
 
 
+_OUTCONV_WS = {}
+
+
+def _outconv_workspace(device):
+    """Caller-owned scratch of stj_outconv_bwd (per-block dW/db partials; never zeroed, reused by both heads in stream order)."""
+    ws = _OUTCONV_WS.get(device)
+    if ws is None:
+        from ._lib import lib
+        ws = _OUTCONV_WS[device] = torch.empty(int(lib().stj_outconv_bwd_workspace_bytes()), dtype=torch.uint8, device=device)
+    return ws
+
+
 class _OutConvPair(torch.autograd.Function):
     """Two 3x3 C->2 heads written straight into the [B,H,W,32] f32 model output (channel 4t+{0,1} and 4t+{2,3})."""
     @staticmethod
@@ -595,10 +607,11 @@ class _OutConvPair(torch.autograd.Function):
         dout = dout.contiguous().float()
         dt = _dt(xo)
         dxo, dxf = torch.empty_like(xo), torch.empty_like(xf)
+        ws = _outconv_workspace(xo.device)
         call('stj_outconv_bwd', _p(xo), _p(p1w.master), vp(dout.data_ptr()), _p(dxo), _p(p1w.grad), _p(p1b.grad), F_, H, W, C, Tn,
-             ybs, yts, yps, ctx.elu_in, dt, _st())
+             ybs, yts, yps, ctx.elu_in, _p(ws), ws.numel(), dt, _st())
         call('stj_outconv_bwd', _p(xf), _p(p2w.master), vp(dout.data_ptr() + 8), _p(dxf), _p(p2w.grad), _p(p2b.grad), F_, H, W, C, Tn,
-             ybs, yts, yps, ctx.elu_in, dt, _st())
+             ybs, yts, yps, ctx.elu_in, _p(ws), ws.numel(), dt, _st())
         return (dxo, dxf) + (None,) * 12
 
 

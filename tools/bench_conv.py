@@ -43,5 +43,6 @@ for li, (F, Hi, Cin, Cout) in enumerate(LAYERS):
         ms = e0.elapsed_time(e1) / a.iters
         print(f'{name:6s} [{Hi}x{Hi},{Cin}->{Cout}] {ms*1e3:9.1f} us  algorithmic {flops/ms/1e9:8.1f} TFLOP/s  executed(folded) {flops/2.25/ms/1e9:8.1f} TFLOP/s')
     run('fwd', lambda: call('stj_upconv_fwd', _p(x), _p(wf), _p(b), _p(y), F, Hi, Hi, Cin, Cout, 2, dt, _st()))
-    run('dgrad', lambda: call('stj_upconv_dgrad', _p(dp), _p(wd), _p(dx), F, Hi, Hi, Cin, Cout, dt, _st()))
+    run('dgrad', lambda: call('stj_upconv_dgrad', _p(dp), _p(wd), _p(dx), None, F, Hi, Hi, Cin, Cout, dt, _st()))
+    run('dgradE', lambda: call('stj_upconv_dgrad', _p(dp), _p(wd), _p(dx), _p(x), F, Hi, Hi, Cin, Cout, dt, _st()))
     run('wgrad', lambda: call('stj_upconv_wgrad', _p(x), _p(dp), _p(dweff), _p(db), F, Hi, Hi, Cin, Cout, dt, _st()))
