@@ -110,6 +110,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying the captured hipGraph')
+    ap.add_argument('--gemm-trace', action='store_true', help='print per-shape GEMM launch times (HIP events) to stderr')
     args = ap.parse_args()
 
     import torch
@@ -182,6 +183,7 @@ def main():
     # with events recorded on the launch stream -- under graph replay individual launches cannot carry events
     prof = None
     if not args.no_kernel_timing:
+        ops.PROF_GEMM = args.gemm_trace
         ops.prof_enable()
         for _ in range(min(args.steps, 3)):
             eager_step()
@@ -203,6 +205,14 @@ def main():
             for k, evs in prof.items():
                 ms = [a.elapsed_time(b) for a, b, _ in evs]
                 kern[k] = (sum(ms) / len(ms), evs[0][2], sum(ms))
+            if args.gemm_trace:
+                tot = sum(v[2] for k, v in kern.items() if k.startswith('gemm')) / min(args.steps, 3)
+                print(f'# GEMM launches by shape: {tot:.3f} ms/step', file=sys.stderr)
+                for k in sorted((k for k in kern if k.startswith('gemm')), key=lambda k: -kern[k][2]):
+                    n = len(prof[k]) / min(args.steps, 3)
+                    print(f'{kern[k][2] / min(args.steps, 3) * 1e3:9.1f} us/step  {n:5.1f} x {kern[k][0] * 1e3:7.1f} us  '
+                          f'{kern[k][1] / kern[k][0] / 1e9:7.1f} TF/s  {k}', file=sys.stderr)
+                kern = {k: v for k, v in kern.items() if not k.startswith('gemm')}
             dom = max(kern, key=lambda k: kern[k][2])
             avg_ms, flops, _ = kern[dom]
             ach = flops / (avg_ms * 1e-3) / 1e12

@@ -130,6 +130,20 @@ int stj_loss_fwd(const float* logits, const float* gt_obs, const float* gt_occ, 
 int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                  const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int use_warp, hipStream_t stream);
 
+/* Training-time randomness.  Keras Dropout / tfa-MHA attention dropout (trajNet.py:33,71,75,77,195,209,211) and DropPath
+ * (modules.py:137-151) share one rule: y = [res +] keep(draw) * x / (1 - p), keep = U[0,1) >= p, draw(i) = i / inner
+ * (inner = 1: per element; inner = elements per sample: DropPath with p = drop_prob).  U comes from Philox-4x32-10 keyed by
+ * state = device int64[2] {seed, step} and `site`; backward calls stj_dropout on dY with the same (state, site).
+ * stj_dropout_mask writes the keep bytes of the first ndraw draws (test hook: the oracle is fed the same masks). */
+int stj_rng_advance(long long* state, hipStream_t stream);
+int stj_dropout(const void* x, const void* res, void* y, long long n, long long inner, float p, const long long* state,
+                int site, int dtype, hipStream_t stream);
+int stj_dropout_mask(unsigned char* mask, long long ndraw, float p, const long long* state, int site, hipStream_t stream);
+/* Keras Nadam (train.py:197,224) over flat f32 buffers: one fused pass.  Host-side scalars:
+ * cg = (1-mu_t)/(1-prod_t), cm = mu_{t+1}/(1-prod_{t+1}), vhat_scale = 1/(1-b2^t); g is multiplied by gscale first. */
+int stj_nadam_step(float* w, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                   float cg, float cm, float vhat_scale, float gscale, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -329,8 +329,75 @@ def upsample2(x):
     return np.repeat(np.repeat(x, 2, axis=-3), 2, axis=-2)
 
 
-def tfa_mha(query, key, value, Wq, Wk, Wv, Wo, bo, mask=None):
-    """tensorflow_addons.layers.MultiHeadAttention (un-vendored; App. C-1).  No dropout (eval).
+# Training-time randomness.  The reference draws from TF's global generator (Keras Dropout: x * 1/(1-rate) * (U >= rate);
+# drop_path, modules.py:137-151: x / keep * floor(keep + U)); those streams cannot be reproduced, so the oracle takes the
+# 0/1 KEEP masks as an input (`masks`, name -> array) and applies the reference's arithmetic to them.  masks=None == eval.
+_MASKS = None
+
+
+def keras_dropout(x, name, rate, index=None):
+    """tf.keras.layers.Dropout(rate)(x, training=True) with the keep mask masks[name] (optionally masks[name][:, index])."""
+    if _MASKS is None or name not in _MASKS:
+        return x
+    m = np.asarray(_MASKS[name], F64)
+    if index is not None:
+        m = m[:, index]
+    assert m.shape == x.shape, (name, m.shape, x.shape)
+    return x * (1.0 / (1.0 - rate)) * m
+
+
+def drop_path(x, name, drop_prob):
+    """modules.py:137-151 with binary_tensor = masks[name] ([B])."""
+    if _MASKS is None or name not in _MASKS or drop_prob == 0.0:
+        return x
+    m = np.asarray(_MASKS[name], F64).reshape((x.shape[0],) + (1,) * (x.ndim - 1))
+    return x / (1.0 - drop_prob) * m
+
+
+def drop_path_rates(depths, rate=0.1):
+    """modules.py:507,527,548: block prefix -> DropPath probability."""
+    dpr = np.linspace(0.0, rate, sum(depths))
+    out = {}
+    for i, d in enumerate(depths):
+        for j in range(d):
+            out[f'layers{i}/blocks{j}'] = float(dpr[sum(depths[:i]) + j])
+    for j in range(depths[0]):
+        out[f'flow_layers0/blocks{j}'] = float(dpr[j])
+    return out
+
+
+_DPR = {}
+
+
+def dropout_sites(cfg, B, large_ogm=False, n_actors=64):
+    """name -> (draw shape, drop rate) of every stochastic site of a training=True forward (oracle naming)."""
+    g = geometry(cfg, large_ogm)
+    HW = g['hb'] * g['hb']
+    sites = {}
+    for pre, r in drop_path_rates(cfg['depths']).items():
+        if r > 0.0:
+            sites[pre + '/drop_path_attn'] = ((B,), r)
+            sites[pre + '/drop_path_mlp'] = ((B,), r)
+    sites['traj_net/traj_encoder/node_attention/dropout'] = ((B, n_actors, 4, 11, 11), 0.1)
+    sites['traj_net/cross_attention/mha/dropout'] = ((B, 6, n_actors, n_actors), 0.1)
+    sites['traj_net/cross_attention/dropout1'] = ((B, n_actors, 1536), 0.1)
+    sites['traj_net/cross_attention/dropout2'] = ((B, n_actors, 384), 0.1)
+    for i in range(8):
+        sites[f'cross_attn_obs{i}/mha/dropout'] = ((B, 3, HW, n_actors), 0.1)
+        sites[f'cross_attn_obs{i}/dropout1'] = ((B, HW, 512), 0.1)
+        sites[f'cross_attn_obs{i}/dropout2'] = ((B, HW, 384), 0.1)
+    return sites
+
+
+def make_masks(cfg, B, seed=7, large_ogm=False):
+    """Seeded keep masks (uint8) for every site: U[0,1) >= rate, the Keras / drop_path rule."""
+    rng = np.random.default_rng(seed)
+    return {k: (rng.random(shape) >= r).astype(np.uint8) for k, (shape, r) in dropout_sites(cfg, B, large_ogm).items()}
+
+
+def tfa_mha(query, key, value, Wq, Wk, Wv, Wo, bo, mask=None, drop=None):
+    """tensorflow_addons.layers.MultiHeadAttention (un-vendored; App. C-1).  drop = (mask name, actor index or None):
+    dropout(0.1) on the attention coefficients when training masks are supplied.
     The additive mask -10e9*(1-mask) is applied in float32 by the reference, where
     logit + (-1e10) == -1e10 exactly for |logit| < 512; restated as a select."""
     hs = Wq.shape[-1]
@@ -345,6 +412,8 @@ def tfa_mha(query, key, value, Wq, Wk, Wv, Wo, bo, mask=None):
         assert np.abs(logits).max() < 512
         logits = np.where(m != 0, logits, -10e9)
     coef = softmax(logits, -1)
+    if drop is not None:
+        coef = keras_dropout(coef, drop[0], 0.1, drop[1])
     o = np.einsum('...hnm,...mhi->...nhi', coef, v)
     return np.einsum('...nhi,hio->...no', o, Wo) + bo
 
@@ -443,7 +512,8 @@ def window_attention(x, p, prefix, ws, heads, mask):
 
 
 def swin_block(x, p, prefix, res, heads, ws, shift):
-    """modules.py:220-262 (eval: DropPath identity)."""
+    """modules.py:220-262 (DropPath: identity unless training masks are supplied)."""
+    dp = _DPR.get(prefix, 0.0)
     H = W = res
     if min(res, res) <= ws:            # modules.py:173-175
         shift, ws = 0, min(res, res)
@@ -459,10 +529,10 @@ def swin_block(x, p, prefix, res, heads, ws, shift):
     x = window_reverse(aw, ws, H, W, C)
     if shift > 0:
         x = np.roll(x, (shift, shift), (1, 2))
-    x = sc + x.reshape(B, H * W, C)
+    x = sc + drop_path(x.reshape(B, H * W, C), prefix + '/drop_path_attn', dp)               # :258
     h = layer_norm(x, p[prefix + '/norm2/gamma'], p[prefix + '/norm2/beta'], 1e-5)
     h = gelu(dense(h, p[prefix + '/mlp/fc1/kernel'], p[prefix + '/mlp/fc1/bias']))
-    return x + dense(h, p[prefix + '/mlp/fc2/kernel'], p[prefix + '/mlp/fc2/bias'])
+    return x + drop_path(dense(h, p[prefix + '/mlp/fc2/kernel'], p[prefix + '/mlp/fc2/bias']), prefix + '/drop_path_mlp', dp)   # :260
 
 
 def patch_merging(x, p, prefix, res):
@@ -605,13 +675,14 @@ def _mha_w(p, name):
             p[name + '/projection_kernel'], p[name + '/projection_bias'])
 
 
-def traj_encoder(p, inputs, mask):
-    """TrajEncoder.call (trajNet.py:38-48), eval.  inputs [B,11,8], mask [B,11] bool."""
+def traj_encoder(p, inputs, mask, actor=None):
+    """TrajEncoder.call (trajNet.py:38-48).  inputs [B,11,8], mask [B,11] bool; actor = index into the [B,64,...] dropout mask."""
     pre = 'traj_net/traj_encoder'
     m = mask.astype(np.int32)
     m2 = m[:, :, None] * m[:, None, :]
     nodes = elu(dense(inputs[:, :, :5], p[pre + '/node_feature/kernel'][0], p[pre + '/node_feature/bias']))
-    nodes = tfa_mha(nodes, nodes, nodes, *_mha_w(p, pre + '/node_attention'), mask=m2)
+    nodes = tfa_mha(nodes, nodes, nodes, *_mha_w(p, pre + '/node_attention'), mask=m2,
+                    drop=(pre + '/node_attention/dropout', actor))
     nodes = nodes.max(axis=1)                                             # GlobalMaxPooling1D
     vector = dense(inputs[:, 0, 5:], p[pre + '/vector_feature/kernel'])
     out = np.concatenate([nodes, vector], 1)
@@ -620,10 +691,10 @@ def traj_encoder(p, inputs, mask):
 
 def cross_attention(p, pre, query, key, mask):
     """Cross_Attention.call / Cross_AttentionT.call (trajNet.py:79-87, 224-234), eval, sep_actors off."""
-    v = tfa_mha(query, key, key, *_mha_w(p, pre + '/mha'), mask=mask)
+    v = tfa_mha(query, key, key, *_mha_w(p, pre + '/mha'), mask=mask, drop=(pre + '/mha/dropout', None))
     v = layer_norm(v, p[pre + '/norm1/gamma'], p[pre + '/norm1/beta'], 1e-3)
-    v = elu(dense(v, p[pre + '/FFN1/kernel'], p[pre + '/FFN1/bias']))
-    v = dense(v, p[pre + '/FFN2/kernel'], p[pre + '/FFN2/bias'])
+    v = keras_dropout(elu(dense(v, p[pre + '/FFN1/kernel'], p[pre + '/FFN1/bias'])), pre + '/dropout1', 0.1)
+    v = keras_dropout(dense(v, p[pre + '/FFN2/kernel'], p[pre + '/FFN2/bias']), pre + '/dropout2', 0.1)
     return layer_norm(v, p[pre + '/norm2/gamma'], p[pre + '/norm2/beta'], 1e-3)
 
 
@@ -631,9 +702,9 @@ def traj_net(p, obs_traj, occ_traj):
     """TrajNet.call (trajNet.py:125-187), no_attn=False, double_net=False."""
     n_obs, n_occ = obs_traj.shape[1], occ_traj.shape[1]
     obs_mask = (obs_traj != 0)[:, :, :, 0]
-    obs = np.stack([traj_encoder(p, obs_traj[:, i], obs_mask[:, i]) for i in range(n_obs)], 1)
+    obs = np.stack([traj_encoder(p, obs_traj[:, i], obs_mask[:, i], i) for i in range(n_obs)], 1)
     occ_mask = (occ_traj != 0)[:, :, :, 0]
-    occ = np.stack([traj_encoder(p, occ_traj[:, i], occ_mask[:, i]) for i in range(n_occ)], 1)
+    occ = np.stack([traj_encoder(p, occ_traj[:, i], occ_mask[:, i], n_obs + i) for i in range(n_occ)], 1)
     bi = np.repeat(np.array([[1, 0], [0, 1]], F64), [n_obs, n_occ], 0)
     embed = dense(np.repeat(bi[None], obs.shape[0], 0), p['traj_net/seg_embed/kernel'])
     cmask = (np.concatenate([obs_mask, occ_mask], 1).astype(np.int32).sum(-1) != 0).astype(np.int32)
@@ -697,8 +768,18 @@ def decoder(p, g, x, res_list, taps=None):
     return np.concatenate([y, fy], -1)
 
 
-def strajnet_forward(p, cfg, ogm, map_img, obs, occ, flow, fg_msa=True, fg=True, large_ogm=False, taps=None):
-    """STrajNet.call (modules.py:815-839), training=False semantics.  Returns [B,Hg,Hg,32] float64."""
+def strajnet_forward(p, cfg, ogm, map_img, obs, occ, flow, fg_msa=True, fg=True, large_ogm=False, taps=None, masks=None):
+    """STrajNet.call (modules.py:815-839).  masks=None: training=False; masks = {site: 0/1 keep mask}: training=True with
+    those Dropout / DropPath draws (site names and shapes: see keras_dropout / drop_path call sites).  Returns [B,Hg,Hg,32] f64."""
+    global _MASKS, _DPR
+    _MASKS, _DPR = masks, (drop_path_rates(cfg['depths']) if masks is not None else {})
+    try:
+        return _strajnet_forward(p, cfg, ogm, map_img, obs, occ, flow, fg_msa, fg, large_ogm, taps)
+    finally:
+        _MASKS, _DPR = None, {}
+
+
+def _strajnet_forward(p, cfg, ogm, map_img, obs, occ, flow, fg_msa, fg, large_ogm, taps):
     p = {k: np.asarray(v, F64) for k, v in p.items()}
     ogm, map_img, obs, occ, flow = (np.asarray(a, F64) for a in (ogm, map_img, obs, occ, flow))
     g = geometry(cfg, large_ogm)

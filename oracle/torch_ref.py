@@ -65,7 +65,25 @@ def _region_id(res, ws, shift, device):
     return lab[:, None] * 3 + lab[None, :]
 
 
+_MASKS, _DPR = None, {}
+
+
+def _dropout(x, name, rate, index=None):
+    """Keras Dropout with a supplied 0/1 keep mask (see np_ref.keras_dropout); identity when no masks are set."""
+    if _MASKS is None or name not in _MASKS:
+        return x
+    m = _MASKS[name] if index is None else _MASKS[name][index]
+    return x * (1.0 / (1.0 - rate)) * m.to(x.dtype).reshape(x.shape)
+
+
+def _drop_path(x, name, prob):
+    if _MASKS is None or name not in _MASKS or prob == 0.0:
+        return x
+    return x / (1.0 - prob) * _MASKS[name].to(x.dtype).view(-1, *([1] * (x.dim() - 1)))
+
+
 def _swin_block(x, p, pre, res, heads, ws, shift):
+    dp = _DPR.get(pre, 0.0)
     if res <= ws:
         shift, ws = 0, res
     B, L, C = x.shape
@@ -94,10 +112,10 @@ def _swin_block(x, p, pre, res, heads, ws, shift):
     o = torch.einsum('bwhnm,bwmhd->bwnhd', att, v).reshape(B, nW * N, C)
     o = _lin(o, p, pre + '/attn/proj')
     out = torch.zeros_like(x).index_copy(1, idx.reshape(-1), o)
-    x = x + out
+    x = x + _drop_path(out, pre + '/drop_path_attn', dp)
     h = _ln(x, p, pre + '/norm2', 1e-5)
     h = F.gelu(_lin(h, p, pre + '/mlp/fc1'), approximate='tanh')
-    return x + _lin(h, p, pre + '/mlp/fc2')
+    return x + _drop_path(_lin(h, p, pre + '/mlp/fc2'), pre + '/drop_path_mlp', dp)
 
 
 def _merge(x, p, pre, res):
@@ -189,7 +207,7 @@ def _fgmsa(p, x, fg):
     return c1(out, 'proj_out'), pos, flow_hidden
 
 
-def _mha(q_in, k_in, p, name, mask):
+def _mha(q_in, k_in, p, name, mask, drop=None):
     Wq, Wk, Wv = p[name + '/query_kernel'], p[name + '/key_kernel'], p[name + '/value_kernel']
     Wo, bo = p[name + '/projection_kernel'], p[name + '/projection_bias']
     hs = Wq.shape[-1]
@@ -201,15 +219,18 @@ def _mha(q_in, k_in, p, name, mask):
         # reference: logits += -10e9*(1-mask) in f32, where x + (-1e10) == -1e10 exactly (|x| < 512) but the
         # gradient of the ADD still passes through to x (matters only for fully masked rows).
         lg = torch.where(mask.unsqueeze(-3) != 0, lg, lg + (-10e9 - lg).detach())
-    o = lg.softmax(-1) @ v
+    coef = lg.softmax(-1)
+    if drop is not None:
+        coef = _dropout(coef, drop, 0.1)
+    o = coef @ v
     return torch.einsum('...hni,hio->...no', o, Wo) + bo
 
 
 def _xattn(p, pre, query, key, mask):
-    v = _mha(query, key, p, pre + '/mha', mask)
+    v = _mha(query, key, p, pre + '/mha', mask, pre + '/mha/dropout')
     v = _ln(v, p, pre + '/norm1', 1e-3)
-    v = F.elu(_lin(v, p, pre + '/FFN1'))
-    v = _lin(v, p, pre + '/FFN2')
+    v = _dropout(F.elu(_lin(v, p, pre + '/FFN1')), pre + '/dropout1', 0.1)
+    v = _dropout(_lin(v, p, pre + '/FFN2'), pre + '/dropout2', 0.1)
     return _ln(v, p, pre + '/norm2', 1e-3)
 
 
@@ -220,7 +241,7 @@ def _traj(p, obs_traj, occ_traj):
     m = (tr[..., 0] != 0)
     m2 = (m[..., :, None] & m[..., None, :])
     nodes = F.elu(F.linear(tr[..., :5], p[pre + '/node_feature/kernel'][0].t(), p[pre + '/node_feature/bias']))
-    nodes = _mha(nodes, nodes, p, pre + '/node_attention', m2).amax(-2)
+    nodes = _mha(nodes, nodes, p, pre + '/node_attention', m2, pre + '/node_attention/dropout').amax(-2)
     vec = F.linear(tr[..., 0, 5:], p[pre + '/vector_feature/kernel'].t())
     enc = F.elu(_lin(torch.cat([nodes, vec], -1), p, pre + '/sublayer'))
     seg = p['traj_net/seg_embed/kernel']
@@ -253,8 +274,20 @@ def _resconv(skip, p, name, r):
     return F.elu(F.conv3d(x, w, p[name + '/bias'])).permute(0, 2, 3, 4, 1)
 
 
-def forward(p, cfg, ogm, map_img, obs, occ, flow, fg_msa=True, fg=True, large_ogm=False):
-    """STrajNet.call, training=False.  p: dict name->torch tensor (Keras layouts)."""
+def forward(p, cfg, ogm, map_img, obs, occ, flow, fg_msa=True, fg=True, large_ogm=False, masks=None):
+    """STrajNet.call.  p: dict name->torch tensor (Keras layouts).  masks=None: training=False; otherwise the 0/1 keep masks
+    of every Dropout / DropPath site (same names and shapes as np_ref.strajnet_forward) -> training=True with those draws."""
+    global _MASKS, _DPR
+    from . import np_ref
+    _MASKS = None if masks is None else {k: torch.as_tensor(v) for k, v in masks.items()}
+    _DPR = np_ref.drop_path_rates(cfg['depths']) if masks is not None else {}
+    try:
+        return _forward(p, cfg, ogm, map_img, obs, occ, flow, fg_msa, fg, large_ogm)
+    finally:
+        _MASKS, _DPR = None, {}
+
+
+def _forward(p, cfg, ogm, map_img, obs, occ, flow, fg_msa, fg, large_ogm):
     g = _geom(cfg, large_ogm)
     hb, Cb = g['hb'], g['dim'][2]
     res_list = _encoder(p, g, ogm, map_img, flow)

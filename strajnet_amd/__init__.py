@@ -7,3 +7,4 @@ The math runs in hand-written HIP kernels (strajnet_amd/csrc -> libstrajnet_hip.
 from .modules import STrajNet            # noqa: F401
 from .loss import (OGMFlow_loss, WaypointGrids, OccupancyFlowTaskConfig,     # noqa: F401
                    get_pred_waypoint_logits, warpped_gt)
+from .optim import Nadam                # noqa: F401

@@ -18,6 +18,10 @@ SIGNATURES = {
                  ci, cf, ci, ci, ci, ci, vp],
     'stj_colsum': [vp, vp, ci, ci, cl, ci, vp],
     'stj_cast': [vp, ci, vp, ci, cl, vp],
+    'stj_rng_advance': [vp, vp],
+    'stj_dropout': [vp, vp, vp, cl, cl, cf, vp, ci, ci, vp],
+    'stj_dropout_mask': [vp, cl, cf, vp, ci, vp],
+    'stj_nadam_step': [vp, vp, vp, vp, cl, cf, cf, cf, cf, cf, cf, cf, cf, vp],
     'stj_unary_fwd': [vp, vp, cl, ci, cf, ci, vp],
     'stj_unary_bwd': [vp, vp, vp, cl, ci, cf, ci, vp],
     'stj_maxpool_fwd': [vp, vp, vp, cl, ci, ci, ci, vp],

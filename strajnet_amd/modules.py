@@ -11,8 +11,12 @@ Parameters live in ONE flat f32 buffer (+ a flat f32 gradient buffer that double
 all-reduce bucket, + a bf16 shadow in bf16 mode); names/shapes/layouts follow the reference's Keras variables
  so a name->array dict (state_dict / load_weights) exchanges weights with the oracle.
 
-Not built (documented gaps): dropout / DropPath randomness (training=True runs the same
-deterministic graph, rates 0), actor_only=False (MapEncoder), sep_actors=True, use_last_ref=True.
+training=True draws the reference's stochastic regularisers -- DropPath linspace(0, .1, 6) over the Swin blocks
+(modules.py:507,258-260), dropout .1 on every tfa-MHA's attention coefficients and after FFN1/FFN2 of the
+cross-attention blocks (trajNet.py:33,71-77,195-211) -- from a counter-based RNG inside the kernels (csrc/rng.hip);
+training=False is the deterministic graph.
+
+Not built (documented gaps): actor_only=False (MapEncoder), sep_actors=True, use_last_ref=True.
 """
 import math
 from collections import OrderedDict
@@ -203,6 +207,16 @@ class STrajNet:
         self._gflat = torch.zeros(off, dtype=torch.float32, device=self.device)
         self._cflat = self._flat if dtype == torch.float32 else torch.zeros(off, dtype=dtype, device=self.device)
         gen = torch.Generator().manual_seed(seed)
+        # DropPath schedule (modules.py:507,527,548): rates linspace(0, .1, sum(depths)); the flow stage reuses the first depths[0]
+        dpr = np.linspace(0.0, 0.1, sum(cfg['depths']))
+        self.drop_path_rate = {}
+        for i, d in enumerate(cfg['depths']):
+            for j in range(d):
+                self.drop_path_rate[f'layers{i}/blocks{j}'] = float(dpr[sum(cfg['depths'][:i]) + j])
+        for j in range(cfg['depths'][0]):
+            self.drop_path_rate[f'flow_layers0/blocks{j}'] = float(dpr[j])
+        self.dropctx = ops.DropCtx(self.device, seed)
+        self._dctx = None
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():
             k = int(np.prod(s))
@@ -269,13 +283,22 @@ class STrajNet:
         """SwinTransformerBlock.call (modules.py:220-262); the roll/partition/reverse plumbing lives in the kernel."""
         if res <= 8:
             shift = 0                                             # modules.py:173-175
+        dpr = self.drop_path_rate.get(pre, 0.0) if self._dctx is not None else 0.0
         h = self._ln(x, pre + '/norm1', 1e-5)
         qkv = self._dense(h, pre + '/attn/qkv')
         a = ops.win_attn(qkv, self._p(pre + '/attn/relative_position_bias_table'), B, res, heads, shift)
-        x = self._dense(a, pre + '/attn/proj', res=x)             # shortcut + attn
+        if dpr == 0.0:
+            x = self._dense(a, pre + '/attn/proj', res=x)         # shortcut + attn
+            h = self._ln(x, pre + '/norm2', 1e-5)
+            h = ops.gelu(self._dense(h, pre + '/mlp/fc1'))
+            return self._dense(h, pre + '/mlp/fc2', res=x)
+        # training: shortcut + DropPath(branch), one Bernoulli(keep) draw per sample and branch (modules.py:137-151,258,260)
+        a = self._dense(a, pre + '/attn/proj').view(B, -1)
+        x = ops.dropout(a, dpr, self._dctx, pre + '/drop_path_attn', res=x.view(B, -1), per_sample=True).view(x.shape)
         h = self._ln(x, pre + '/norm2', 1e-5)
         h = ops.gelu(self._dense(h, pre + '/mlp/fc1'))
-        return self._dense(h, pre + '/mlp/fc2', res=x)
+        h = self._dense(h, pre + '/mlp/fc2').view(B, -1)
+        return ops.dropout(h, dpr, self._dctx, pre + '/drop_path_mlp', res=x.view(B, -1), per_sample=True).view(x.shape)
 
     def _basic_layer(self, x, pre, B, res, depth, heads, downsample, add=None):
         """BasicLayer.call (modules.py:351-364) -> (downsampled, pre-merge tokens)."""
@@ -349,15 +372,26 @@ class STrajNet:
         q = ops.linear_heads_in(query, pq)
         k = ops.linear_heads_in(key, pk)
         v = ops.linear_heads_in(key, pv)
-        o = ops.mha_core(q, k, v, H, hs, 1.0 / math.sqrt(hs), qvalid=qvalid, kvalid=kvalid)
+        o = ops.mha_core(q, k, v, H, hs, 1.0 / math.sqrt(hs), qvalid=qvalid, kvalid=kvalid,
+                         drop=self._attn_drop(pre + '/dropout', (q.shape[0], H, q.shape[1], k.shape[1])))
         return ops.linear_heads_out(o, self._p(pre + '/projection_kernel'), self._p(pre + '/projection_bias'))
+
+    def _attn_drop(self, name, shape, p=0.1):
+        """tfa-MHA dropout=0.1 on the attention coefficients (trajNet.py:33,71,195) when training."""
+        if self._dctx is None:
+            return None
+        return (p, self._dctx.snap, self._dctx.site(name, shape, p))
+
+    def _drop(self, x, name, p=0.1):
+        """tf.keras.layers.Dropout(0.1) (trajNet.py:75,77,209,211) when training."""
+        return x if self._dctx is None else ops.dropout(x, p, self._dctx, name)
 
     def _cross_attention(self, pre, query, key, H, qvalid, kvalid):
         """Cross_Attention / Cross_AttentionT .call (trajNet.py:79-87,224-234), eval, sep_actors off."""
         v = self._tfa_mha(pre + '/mha', query, key, H, qvalid, kvalid)
         v = self._ln(v, pre + '/norm1', 1e-3)
-        v = self._dense(v, pre + '/FFN1', act=ACT_ELU)
-        v = self._dense(v, pre + '/FFN2')
+        v = self._drop(self._dense(v, pre + '/FFN1', act=ACT_ELU), pre + '/dropout1')
+        v = self._drop(self._dense(v, pre + '/FFN2'), pre + '/dropout2')
         return self._ln(v, pre + '/norm2', 1e-3)
 
     def _traj_net(self, obs, occ):
@@ -440,16 +474,18 @@ class STrajNet:
         v = proj_in(key, 'mha/value_kernel', True)
         kvalid = tmask[None].expand(Z, B, A).reshape(Z * B, A).contiguous()
         o = ops.mha_core(q.view(Z * B, HW, 3 * hs), k.view(Z * B, A, 3 * hs), v.view(Z * B, A, 3 * hs), 3, hs,
-                         1.0 / math.sqrt(hs), kvalid=kvalid)
+                         1.0 / math.sqrt(hs), kvalid=kvalid, drop=self._attn_drop('cross_attn_obs/mha/dropout', (Z, B, 3, HW, A)))
         pw, pb = self._zp('mha/projection_kernel'), self._zp('mha/projection_bias')
         H_, hs_, O_ = pw.shape
         v1 = ops.linear_z(o.view(Z, B * HW, 3 * hs), pw.master, pw.c.view(H_ * hs_, O_), zs, pb.master.detach(), zs,
                           pw.grad.view(H_ * hs_, O_), zs, pb.grad, 8)
         v1 = ops.layernorm(v1, self._zp('norm1/gamma'), self._zp('norm1/beta'), 1e-3, group_rows=B * HW, ngroups=8, gstride=zs)
         pw, pb = self._zp('FFN1/kernel'), self._zp('FFN1/bias')
-        v1 = ops.linear_z(v1, pw.master, pw.c, zs, pb.master.detach(), zs, pw.grad, zs, pb.grad, 8, act=ACT_ELU)
+        v1 = self._drop(ops.linear_z(v1, pw.master, pw.c, zs, pb.master.detach(), zs, pw.grad, zs, pb.grad, 8, act=ACT_ELU),
+                        'cross_attn_obs/dropout1')                                   # draws laid out [8, B*HW, 512]
         pw, pb = self._zp('FFN2/kernel'), self._zp('FFN2/bias')
-        v1 = ops.linear_z(v1, pw.master, pw.c, zs, pb.master.detach(), zs, pw.grad, zs, pb.grad, 8)
+        v1 = self._drop(ops.linear_z(v1, pw.master, pw.c, zs, pb.master.detach(), zs, pw.grad, zs, pb.grad, 8),
+                        'cross_attn_obs/dropout2')
         v1 = ops.layernorm(v1, self._zp('norm2/gamma'), self._zp('norm2/beta'), 1e-3, group_rows=B * HW, ngroups=8, gstride=zs)
         return v1.view(Z, B, HW, Cb) + query
 
@@ -494,6 +530,10 @@ class STrajNet:
             if not t.is_cuda:
                 raise RuntimeError('inputs must be CUDA (ROCm) tensors: the HIP path has no CPU fallback')
         self._sync_compute_weights()
+        self._dctx = None
+        if training:                     # Dropout / DropPath draws of this step (reference: training=True, train.py:218)
+            self.dropctx.begin()
+            self._dctx = self.dropctx
         ogm, map_img, flow = ogm.float().contiguous(), map_img.float().contiguous(), flow.float().contiguous()
         hb, Cb = self.hb, self.stage_dim[2]
         res_list = self._encoder(ogm, map_img, flow)

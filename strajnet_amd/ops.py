@@ -50,6 +50,7 @@ def _req_cuda(*ts):
 
 # ---- optional per-kernel timing (bench.py's live roofline measurement): HIP events recorded on the launch stream
 _PROF = None
+PROF_GEMM = False
 
 
 def prof_enable():
@@ -91,6 +92,15 @@ class Param:
 def gemm(A, B, C, M, N, K, sA, sB, sC, dt, bias=None, sBias=(0, 0), res=None, sRes=(0, 0, 0), nb=(1, 1),
          act=ACT_NONE, alpha=1.0, c_f32=0, accumulate=0, splitk=1, colsum=None):
     """sA = (b1, b2, m, k) element strides; sB = (b1, b2, k, n); sC = (b1, b2, ldc); sRes = (b1, b2, ld)."""
+    if _PROF is not None and PROF_GEMM:      # per-shape GEMM timing (tools/bench --gemm-trace); off in the normal kernel-timing pass
+        key = f'gemm[{M}x{N}x{K} b{nb[0] * nb[1]} {"T" if sA[3] != 1 else "N"}{"T" if sB[3] != 1 else "N"}{" f32out" if c_f32 else ""}]'
+        with _timed(key, 2.0 * M * N * K * nb[0] * nb[1]):
+            _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum)
+        return
+    _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum)
+
+
+def _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum):
     call('stj_gemm', _p(A), _p(B), _p(C), _p(bias), _p(res), _p(colsum), M, N, K, nb[0], nb[1],
          sA[0], sA[1], sA[2], sA[3], sB[0], sB[1], sB[2], sB[3], sC[0], sC[1], sC[2],
          sBias[0], sBias[1], sRes[0], sRes[1], sRes[2], act, float(alpha), dt, c_f32, accumulate, splitk, _st())
@@ -349,7 +359,7 @@ class _MhaCore(torch.autograd.Function):
     """q [Bt,Nq,H*d], k,v [Bt,Nk,H*d]; qvalid [Bt,Nq] / kvalid [Bt,Nk] int32 or None; bias f32 [Bt,H,Nq,Nk] or None.
     Returns o [Bt,Nq,H*d].  Gradient w.r.t. bias is returned in the activation dtype."""
     @staticmethod
-    def forward(ctx, q, k, v, bias, H, d, scale, qvalid, kvalid):
+    def forward(ctx, q, k, v, bias, H, d, scale, qvalid, kvalid, drop):
         _req_cuda(q, k, v)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         Bt, Nq, HD = q.shape
@@ -363,16 +373,24 @@ class _MhaCore(torch.autograd.Function):
         if bias is not None:
             bias = bias.contiguous()
         call('stj_softmax_fwd', _p(S), _p(P), _p(qvalid), _p(kvalid), _p(bias), Bt, H, Nq, Nk, dt, _st())
+        Pd = P
+        if drop is not None:            # tfa-MHA: dropout on the attention coefficients, after the softmax (App. C-1)
+            p_drop, state, site = drop
+            Pd = torch.empty_like(P)
+            call('stj_dropout', _p(P), None, _p(Pd), P.numel(), 1, float(p_drop), _p(state), site, dt, _st())
         o = torch.empty_like(q)
         # O[b,:,h,:] = P[b,h] V[b,:,h,:]
-        gemm(P, v, o, Nq, d, Nk, (H * Nq * Nk, Nq * Nk, Nk, 1), (Nk * HD, d, HD, 1), (Nq * HD, d, HD), dt, nb=(Bt, H))
+        gemm(Pd, v, o, Nq, d, Nk, (H * Nq * Nk, Nq * Nk, Nk, 1), (Nk * HD, d, HD, 1), (Nq * HD, d, HD), dt, nb=(Bt, H))
         ctx.geo = (Bt, Nq, Nk, H, d, scale, bias is not None)
-        ctx.save_for_backward(q, k, v, P)
+        ctx.drop = drop
+        ctx.save_for_backward(q, k, v, P, Pd if drop is not None else None)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, P = ctx.saved_tensors
+        q, k, v, P, Pd = ctx.saved_tensors
+        if Pd is None:
+            Pd = P
         Bt, Nq, Nk, H, d, scale, has_bias = ctx.geo
         HD = H * d
         dt = _dt(q)
@@ -380,18 +398,83 @@ class _MhaCore(torch.autograd.Function):
         dP = torch.empty((Bt, H, Nq, Nk), dtype=torch.float32, device=q.device)
         # dP[b,h] = dO[b,:,h,:] V[b,:,h,:]^T
         gemm(do, v, dP, Nq, Nk, d, (Nq * HD, d, HD, 1), (Nk * HD, d, 1, HD), (H * Nq * Nk, Nq * Nk, Nk), dt, nb=(Bt, H), c_f32=1)
+        if ctx.drop is not None:        # same mask, re-derived from (state, site); dP is f32
+            p_drop, state, site = ctx.drop
+            call('stj_dropout', _p(dP), None, _p(dP), dP.numel(), 1, float(p_drop), _p(state), site, 0, _st())
         dS = torch.empty_like(P)
         call('stj_softmax_bwd', _p(P), _p(dP), _p(dS), Bt * H * Nq, Nk, dt, _st())
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         # dV[b,:,h,:] = P[b,h]^T dO ; dQ = scale dS K ; dK = scale dS^T Q
-        gemm(P, do, dv, Nk, d, Nq, (H * Nq * Nk, Nq * Nk, 1, Nk), (Nq * HD, d, HD, 1), (Nk * HD, d, HD), dt, nb=(Bt, H))
+        gemm(Pd, do, dv, Nk, d, Nq, (H * Nq * Nk, Nq * Nk, 1, Nk), (Nq * HD, d, HD, 1), (Nk * HD, d, HD), dt, nb=(Bt, H))
         gemm(dS, k, dq, Nq, d, Nk, (H * Nq * Nk, Nq * Nk, Nk, 1), (Nk * HD, d, HD, 1), (Nq * HD, d, HD), dt, nb=(Bt, H), alpha=scale)
         gemm(dS, q, dk, Nk, d, Nq, (H * Nq * Nk, Nq * Nk, 1, Nk), (Nq * HD, d, HD, 1), (Nk * HD, d, HD), dt, nb=(Bt, H), alpha=scale)
-        return dq, dk, dv, (dS if has_bias else None), None, None, None, None, None
+        return dq, dk, dv, (dS if has_bias else None), None, None, None, None, None, None
 
 
-def mha_core(q, k, v, H, d, scale, qvalid=None, kvalid=None, bias=None):
-    return _MhaCore.apply(q, k, v, bias, H, d, scale, qvalid, kvalid)
+def mha_core(q, k, v, H, d, scale, qvalid=None, kvalid=None, bias=None, drop=None):
+    """drop = (p, state, site) applies attention dropout to the softmax output (training)."""
+    return _MhaCore.apply(q, k, v, bias, H, d, scale, qvalid, kvalid, drop)
+
+
+# ----------------------------------------------------------------------------------------------------
+# Dropout / DropPath (+ fused residual)
+# ----------------------------------------------------------------------------------------------------
+class DropCtx:
+    """Random-stream bookkeeping of one model: device state {seed, step}, a per-forward snapshot that the backward kernels
+    re-derive their masks from, and the registry name -> (site id, draw shape, p) of the current forward."""
+
+    def __init__(self, device, seed=0):
+        self.state = torch.tensor([int(seed), 0], dtype=torch.int64, device=device)
+        self.snap, self.n, self.sites = None, 0, {}
+
+    def begin(self):
+        call('stj_rng_advance', _p(self.state), _st())
+        self.snap = self.state.clone()          # backward of THIS forward keeps reading this step, whatever runs in between
+        self.n, self.sites = 0, {}
+
+    def site(self, name, shape, p):
+        sid = self.n
+        self.n += 1
+        self.sites[name] = (sid, tuple(shape), float(p), self.snap)
+        return sid
+
+    def mask(self, name):
+        """Keep mask (uint8, draw shape) of a site of the last forward -- test hook."""
+        sid, shape, p, snap = self.sites[name]
+        n = 1
+        for d in shape:
+            n *= d
+        m = torch.empty(n, dtype=torch.uint8, device=snap.device)
+        call('stj_dropout_mask', _p(m), n, p, _p(snap), sid, _st())
+        return m.view(shape)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, p, inner, state, site):
+        _req_cuda(x)
+        x = x.contiguous()
+        r = res.contiguous() if res is not None else None
+        y = torch.empty_like(x)
+        call('stj_dropout', _p(x), _p(r), _p(y), x.numel(), inner, float(p), _p(state), site, _dt(x), _st())
+        ctx.args = (float(p), inner, state, site, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, inner, state, site, has_res = ctx.args
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call('stj_dropout', _p(dy), None, _p(dx), dy.numel(), inner, p, _p(state), site, _dt(dy), _st())
+        return dx, (dy if has_res else None), None, None, None, None
+
+
+def dropout(x, p, dctx, name, res=None, per_sample=False):
+    """Keras Dropout(p) (per element) or DropPath(p) (per_sample: one draw per x[0] slice), optionally + res."""
+    inner = x[0].numel() if per_sample else 1
+    shape = (x.shape[0],) if per_sample else tuple(x.shape)
+    site = dctx.site(name, shape, p)
+    return _Dropout.apply(x, res, p, inner, dctx.snap, site)
 
 
 class _FgBias(torch.autograd.Function):

@@ -34,7 +34,7 @@ def test_header_argument_counts_match_binding():
     hdr = open(os.path.join(ROOT, 'include', 'strajnet_hip.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
     for name, args in _lib.SIGNATURES.items():
-        m = re.search(r'\bint\s+' + name + r'\s*\((.*?)\)\s*;', hdr, flags=re.S)
+        m = re.search(r'\b(?:int|long long)\s+' + name + r'\s*\((.*?)\)\s*;', hdr, flags=re.S)
         assert m, name
         params = [p for p in m.group(1).split(',') if p.strip() and p.strip() != 'void']
         assert len(params) == len(args), (name, len(params), len(args))

@@ -108,6 +108,71 @@ def test_train_step_parity_f32():
     assert not bad, bad[:10]
 
 
+def _oracle_masks(model, B):
+    """Keep masks of the model's last training=True forward, exported by stj_dropout_mask and renamed / reshaped to the
+    oracle's site list (np_ref.dropout_sites): the 8 cross-attentions and the 64 actor encoders are batched in the HIP path."""
+    out = {}
+    for name in model.dropctx.sites:
+        m = model.dropctx.mask(name).cpu().numpy()
+        if name.startswith('cross_attn_obs/'):
+            suffix = name[len('cross_attn_obs/'):]
+            for i in range(8):
+                mi = m[i]
+                out[f'cross_attn_obs{i}/{suffix}'] = mi if suffix == 'mha/dropout' else mi.reshape(B, -1, mi.shape[-1])
+        elif name == 'traj_net/traj_encoder/node_attention/dropout':
+            out[name] = m.reshape(B, -1, *m.shape[1:])
+        else:
+            out[name] = m
+    return out
+
+
+def test_train_step_parity_training_true_f32():
+    """training=True: DropPath + attention / FFN dropout drawn inside the HIP kernels; the oracle is fed the exported keep
+    masks (the reference's own TF random stream cannot be reproduced).  Logits, losses and all gradients must match."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from oracle import np_ref, torch_ref
+    B = 2
+    model, w, x, xt = _setup(CFG128, B, torch.float32)
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(128, 128, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+    model.zero_grad()
+    out = model(xt['ogm'], xt['map_img'], training=True, obs=xt['obs'], occ=xt['occ'], mapt=xt['mapt'], flow=xt['flow'])
+    d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+    sum(d.values()).backward()
+    masks = _oracle_masks(model, B)
+    want = np_ref.dropout_sites(CFG128, B)
+    assert set(masks) == set(want)
+    for k, (shape, rate) in want.items():
+        assert masks[k].shape == shape, (k, masks[k].shape, shape)
+    big = np.concatenate([masks[f'cross_attn_obs{i}/dropout1'].ravel() for i in range(8)])
+    assert abs(big.mean() - 0.9) < 0.01                                 # keep probability 1 - rate
+    ref = np_ref.strajnet_forward(w, CFG128, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'], masks=masks)
+    err = np.abs(out.detach().cpu().numpy() - ref).max()
+    ref_eval = np_ref.strajnet_forward(w, CFG128, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'])
+    assert np.abs(ref - ref_eval).max() > 1e-2                          # the masks do change the result
+    assert err < ABS_TOL_F32
+    pr = torch_ref.to_torch(w, torch.float64, requires_grad=True)
+    xr = torch_ref.to_torch(x, torch.float64)
+    yr = torch_ref.forward(pr, CFG128, xr['ogm'], xr['map_img'], xr['obs'], xr['occ'], xr['flow'], masks=masks)
+    dr = torch_ref.loss(yr, xr['gt_obs'], xr['gt_occ'], xr['gt_flow'], xr['origin_flow'], replica=1.0, use_gt=True)
+    sum(dr.values()).backward()
+    gmax = max(float(pr[n].grad.abs().max()) for n in model.params)
+    worst, bad = 0.0, []
+    for n, p in model.params.items():
+        g, gr = p.grad.double().cpu(), pr[n].grad
+        e = float((g - gr).abs().max()) / (float(gr.abs().max()) + 1e-6 * gmax)
+        worst = max(worst, e)
+        if e > 2e-3:
+            bad.append((n, e))
+    _report(f'train step f32 training=True (exported masks) 128x128 B=2: fwd max-abs err {err:.3e}; worst relative grad error {worst:.3e}')
+    assert not bad, bad[:10]
+    # a second step draws different masks; the same step re-derives identical ones
+    m1 = model.dropctx.mask('cross_attn_obs/dropout1').clone()
+    assert torch.equal(m1, model.dropctx.mask('cross_attn_obs/dropout1'))
+    with torch.no_grad():
+        model(xt['ogm'], xt['map_img'], training=True, obs=xt['obs'], occ=xt['occ'], mapt=xt['mapt'], flow=xt['flow'])
+    assert not torch.equal(m1, model.dropctx.mask('cross_attn_obs/dropout1'))
+
+
 def test_bf16_mode_error_report():
     """bf16-storage throughput mode: measured error vs the f64 oracle (reported, bounded loosely)."""
     from oracle import np_ref

@@ -397,3 +397,61 @@ def test_loss_and_gate():
         dr = torch_ref.loss(lr, gtr['gt_obs'], gtr['gt_occ'], gtr['gt_flow'], gtr['origin_flow'], replica=2.0, use_gt=use_gt)
         sum(dr.values()).backward()
         assert rel_err(lt.grad, lr.grad) < 1e-4
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_dropout_op(dt):
+    """stj_dropout: y = [res +] keep * x / (1 - p); per-element and per-sample (DropPath) draws; backward re-derives the mask;
+    stj_dropout_mask exports exactly the mask the forward used."""
+    from strajnet_amd import ops
+    dctx = ops.DropCtx('cuda', seed=5)
+    dctx.begin()
+    x = rnd((6, 37, 50), dt, 1).requires_grad_(True)
+    r = rnd((6, 37, 50), dt, 2).requires_grad_(True)
+    y = ops.dropout(x, 0.1, dctx, 'a')
+    m = dctx.mask('a').double().cpu()
+    assert m.shape == (6, 37, 50) and abs(float(m.mean()) - 0.9) < 0.02
+    assert rel_err(y, ref_of(x).detach() * m / 0.9) < (1e-6 if dt == torch.float32 else 5e-3)
+    y2 = ops.dropout(x, 0.3, dctx, 'b', res=r, per_sample=True)
+    m2 = dctx.mask('b').double().cpu()
+    assert m2.shape == (6,)
+    assert rel_err(y2, ref_of(r).detach() + ref_of(x).detach() * m2.view(6, 1, 1) / 0.7) < (1e-6 if dt == torch.float32 else 5e-3)
+    g = rnd((6, 37, 50), dt, 3)
+    (y.float() * g.float()).sum().backward()
+    assert rel_err(x.grad, g.double().cpu() * m / 0.9) < (1e-6 if dt == torch.float32 else 5e-3)
+    x.grad = None
+    (y2.float() * g.float()).sum().backward()
+    assert rel_err(x.grad, g.double().cpu() * m2.view(6, 1, 1) / 0.7) < (1e-6 if dt == torch.float32 else 5e-3)
+    assert rel_err(r.grad, g.double().cpu()) < 1e-6
+    # streams: another site or another step gives another mask, the same (step, site) the same one
+    ma = dctx.mask('a').clone()
+    dctx.begin()
+    ops.dropout(x, 0.1, dctx, 'a')
+    assert not torch.equal(ma, dctx.mask('a'))
+    # per-sample draws over many samples follow the rate
+    xs = torch.ones(4096, 8, device='cuda', dtype=dt)
+    ops.dropout(xs, 0.25, dctx, 'c', per_sample=True)
+    assert abs(float(dctx.mask('c').double().mean()) - 0.75) < 0.03
+
+
+def test_nadam_step_matches_keras_formula():
+    """stj_nadam_step vs the Keras Nadam recurrences in float64 over three steps."""
+    from strajnet_amd.optim import Nadam
+    torch.manual_seed(0)
+    n = 1003
+    w = torch.randn(n, device='cuda')
+    w0 = w.double().cpu().clone()
+    g = torch.zeros(n, device='cuda')
+    opt = Nadam(w, g, lr=1e-2)
+    m = torch.zeros(n, dtype=torch.float64); v = torch.zeros(n, dtype=torch.float64); wr = w0.clone()
+    b1, b2, eps, prod = 0.9, 0.999, 1e-7, 1.0
+    for t in range(1, 4):
+        gt = torch.randn(n, device='cuda')
+        g.copy_(gt)
+        opt.step()
+        gd = gt.double().cpu()
+        mu_t = b1 * (1 - 0.5 * 0.96 ** (0.004 * t)); mu_n = b1 * (1 - 0.5 * 0.96 ** (0.004 * (t + 1)))
+        prod_t = prod * mu_t; prod_n = prod_t * mu_n; prod = prod_t
+        m = b1 * m + (1 - b1) * gd; v = b2 * v + (1 - b2) * gd * gd
+        wr = wr - 1e-2 * ((1 - mu_t) * gd / (1 - prod_t) + mu_n * m / (1 - prod_n)) / ((v / (1 - b2 ** t)).sqrt() + eps)
+    assert rel_err(w, wr) < 1e-5
