@@ -60,6 +60,34 @@ __global__ __launch_bounds__(256) void dropout_group_kernel(const T* __restrict_
     stf(y + i, v);
   }
 }
+// 16-byte vector path (n, inner multiples of the vector width, 16-byte aligned pointers): a thread owns VN consecutive
+// elements = VN / 4 Philox blocks (per-element draws) or one shared draw (per-sample draws)
+template <typename T, bool GROUP>
+__global__ __launch_bounds__(256) void dropout_vec_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                          long long n, long long inner, float p, float scale,
+                                                          const long long* __restrict__ state, int site) {
+  constexpr int VN = Vec<T>::N;
+  const long long nv = n / VN;
+  for (long long vi = blockIdx.x * 256ll + threadIdx.x; vi < nv; vi += gridDim.x * 256ll) {
+    float v[VN], r[VN];
+    ld16(x + vi * VN, v);
+    if (res) ld16(res + vi * VN, r);
+    bool k[VN];
+    if constexpr (GROUP) {
+      const long long d = vi * VN / inner;
+      bool k4[4];
+      keep4(state, site, d >> 2, p, k4);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) k[e] = k4[d & 3];
+    } else {
+#pragma unroll
+      for (int q = 0; q < VN / 4; ++q) keep4(state, site, vi * (VN / 4) + q, p, k + 4 * q);
+    }
+#pragma unroll
+    for (int e = 0; e < VN; ++e) v[e] = (k[e] ? v[e] * scale : 0.f) + (res ? r[e] : 0.f);
+    st16(y + vi * VN, v);
+  }
+}
 __global__ __launch_bounds__(256) void dropout_mask_kernel(unsigned char* mask, long long ndraw, float p, const long long* state, int site) {
   const long long ng = (ndraw + 3) / 4;
   for (long long gi = blockIdx.x * 256ll + threadIdx.x; gi < ng; gi += gridDim.x * 256ll) {
@@ -87,7 +115,15 @@ extern "C" int stj_dropout(const void* x, const void* res, void* y, long long n,
   if (n <= 0) return STJ_OK;
   if (!(p >= 0.f && p < 1.f) || inner < 1 || !state) { stj_set_error("stj_dropout: need 0 <= p < 1, inner >= 1, state != NULL"); return STJ_EINVAL; }
   const float scale = 1.0f / (1.0f - p);
-  if (inner == 1) {
+  const int vn = dtype == STJ_BF16 ? 8 : 4;
+  const bool vec = n % vn == 0 && (inner == 1 || inner % vn == 0) && !((((uintptr_t)x) | ((uintptr_t)res) | ((uintptr_t)y)) & 15);
+  if (vec) {
+    const int g = rng_grid(n / vn);
+    if (dtype == STJ_BF16 && inner == 1) hipLaunchKernelGGL((dropout_vec_kernel<bf16, false>), dim3(g), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, (bf16*)y, n, inner, p, scale, state, site);
+    else if (dtype == STJ_BF16) hipLaunchKernelGGL((dropout_vec_kernel<bf16, true>), dim3(g), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, (bf16*)y, n, inner, p, scale, state, site);
+    else if (inner == 1) hipLaunchKernelGGL((dropout_vec_kernel<float, false>), dim3(g), dim3(256), 0, stream, (const float*)x, (const float*)res, (float*)y, n, inner, p, scale, state, site);
+    else hipLaunchKernelGGL((dropout_vec_kernel<float, true>), dim3(g), dim3(256), 0, stream, (const float*)x, (const float*)res, (float*)y, n, inner, p, scale, state, site);
+  } else if (inner == 1) {
     const int g = rng_grid((n + 3) / 4);
     if (dtype == STJ_BF16) hipLaunchKernelGGL(dropout_elem_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, (bf16*)y, n, p, scale, state, site);
     else hipLaunchKernelGGL(dropout_elem_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)x, (const float*)res, (float*)y, n, p, scale, state, site);

@@ -5,6 +5,7 @@ torch's graph-private pool (every kernel of libstrajnet_hip.so launches on the c
 it is capturable as ONE graph; replaying it removes the Python / launch overhead (~10 ms per step, measured with B=1).
 New data is fed by copying into the static input tensors; weights are read in place (the bf16 shadow cast is part of
 the graph), gradients land in model.flat_grads().  The data-parallel all-reduce stays outside the graph.
+The Dropout / DropPath stream advances inside the graph (stj_rng_advance bumps a device counter), so every replay draws new masks.
 """
 import torch
 
@@ -12,8 +13,8 @@ from .loss import get_pred_waypoint_logits, warpped_gt
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fn, batch, warmup=2):
-        self.model, self.loss_fn = model, loss_fn
+    def __init__(self, model, loss_fn, batch, warmup=2, training=True):
+        self.model, self.loss_fn, self.training = model, loss_fn, training
         self.static = {k: v.clone() for k, v in batch.items()}
         self.graph = None
         self.losses = None
@@ -32,7 +33,7 @@ class GraphedTrainStep:
     def _eager(self):
         x, m = self.static, self.model
         m.zero_grad()
-        out = m(x['ogm'], x['map_img'], training=True, obs=x['obs'], occ=x['occ'], mapt=x.get('mapt'), flow=x['flow'])
+        out = m(x['ogm'], x['map_img'], training=self.training, obs=x['obs'], occ=x['occ'], mapt=x.get('mapt'), flow=x['flow'])
         d = self.loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
         total = d['observed_xe'] + d['occluded_xe'] + d['flow'] + d['flow_warp_xe']
         total.backward()

@@ -173,6 +173,36 @@ def test_train_step_parity_training_true_f32():
     assert not torch.equal(m1, model.dropctx.mask('cross_attn_obs/dropout1'))
 
 
+def test_graph_replay_matches_eager_and_redraws_masks():
+    """hipGraph replay of the whole train step: same losses / gradients as the eager step (training=False, deterministic graph);
+    with training=True every replay advances the device RNG counter and draws new masks."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from strajnet_amd.graph import GraphedTrainStep
+    model, w, x, xt = _setup(CFG128, 2, torch.float32)
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(128, 128, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+    model.zero_grad()
+    out = _fwd(model, xt)
+    d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+    sum(d.values()).backward()
+    g_eager = model.flat_grads().clone()
+    l_eager = torch.stack([d[k].detach() for k in ('observed_xe', 'occluded_xe', 'flow', 'flow_warp_xe')])
+    step = GraphedTrainStep(model, loss_fn, xt, training=False)
+    for _ in range(2):
+        losses = step()
+    torch.cuda.synchronize()
+    assert torch.allclose(losses, l_eager, rtol=1e-5, atol=1e-6)
+    denom = float(g_eager.abs().max())
+    assert float((model.flat_grads() - g_eager).abs().max()) < 1e-4 * denom       # f32 atomics: order differs, values do not
+    step_t = GraphedTrainStep(model, loss_fn, xt, training=True)
+    c0 = int(model.dropctx.state[1])
+    l1 = step_t().clone()
+    l2 = step_t().clone()
+    torch.cuda.synchronize()
+    assert int(model.dropctx.state[1]) == c0 + 2
+    assert not torch.equal(l1, l2)
+    assert torch.isfinite(l1).all() and torch.isfinite(l2).all()
+
+
 def test_bf16_mode_error_report():
     """bf16-storage throughput mode: measured error vs the f64 oracle (reported, bounded loosely)."""
     from oracle import np_ref
