@@ -69,7 +69,9 @@ def lib():
             fn = getattr(L, name)          # AttributeError here == header / library mismatch
             fn.argtypes = args
             fn.restype = ci
-        L.stj_outconv_bwd_workspace_bytes.restype = ctypes.c_longlong
+        for name in SIGNATURES:
+            if name.endswith('_workspace_bytes'):
+                getattr(L, name).restype = ctypes.c_longlong
         L.stj_last_error.argtypes = []
         L.stj_last_error.restype = ctypes.c_char_p
         _lib = L

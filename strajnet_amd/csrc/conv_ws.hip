@@ -626,7 +626,7 @@ bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* 
 // and leave as coalesced 8-byte segments.  v1 (conv.hip) re-staged 16 tap matrices through LDS per tile: 0.59 ms for
 // 96<-48 @128x128 (profiles/r01_b_*).
 // =====================================================================================================
-template <int KS, int NFI>
+template <int KS, int NFI, bool ELU>
 __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ Wd,
                                                                  bf16* __restrict__ dX, const bf16* __restrict__ Xelu, int F, int Hi,
                                                                  int Wi, int Cin, int Cout, int ntiles) {
@@ -706,8 +706,8 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
     for (int mf = 0; mf < WS_TH; mf += 2) {
       // ELU' operand of the epilogue (layer input x): issued before the MFMA work so its latency is hidden
       constexpr int NEP = (2 * 16 * (CT / 4) + 255) / 256;
-      uint2 xin[NEP];
-      if (Xelu) {
+      uint2 xin[ELU ? NEP : 1];
+      if constexpr (ELU) {
 #pragma unroll
         for (int i = 0; i < NEP; ++i) {
           const int q = tid + i * 256;
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
         }
         const int oy = ty0 + mf + m, ox = tx0 + px, ci = n0 + c4;
         if (oy < Hi && ox < Wi && ci < Cin) {
-          if (Xelu) {      // layer input is an ELU output: return the gradient w.r.t. the producer's pre-activation
+          if constexpr (ELU) {      // layer input is an ELU output: return the gradient w.r.t. the producer's pre-activation
             const uint2 xv = xin[i];
             const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
             const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
@@ -782,13 +782,13 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
   }
 }
 
-template <int KS, int NFI>
-static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+template <int KS, int NFI, bool ELU>
+static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   constexpr int LDK = KS * 32 + 8, HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), CT = NFI * 16, LDR = CT + 4;
   const size_t lds = (size_t)(HPIX * LDK + 64) * 2 + (size_t)4 * 2 * 16 * LDR * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)upconv_dgrad_ws_kernel<KS, NFI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)upconv_dgrad_ws_kernel<KS, NFI, ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
   }
   const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
@@ -796,9 +796,14 @@ static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, const void
   int nblk = 256 / ct;
   if (nblk > ntiles) nblk = ntiles;
   if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL((upconv_dgrad_ws_kernel<KS, NFI>), dim3(nblk, ct), dim3(256), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX,
+  hipLaunchKernelGGL((upconv_dgrad_ws_kernel<KS, NFI, ELU>), dim3(nblk, ct), dim3(256), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX,
                      (const bf16*)Xelu, F, Hi, Wi, Cin, Cout, ntiles);
   return true;
+}
+template <int KS, int NFI>
+static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  return Xelu ? dgrad_ws_launch2<KS, NFI, true>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st)
+              : dgrad_ws_launch2<KS, NFI, false>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
 }
 bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   if (Cout % 8 || Cin % 4) return false;

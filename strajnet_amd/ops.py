@@ -81,6 +81,20 @@ class _timed:
         return False
 
 
+_WS = {}
+
+
+def _workspace(device, size_fn):
+    """Caller-owned kernel scratch, allocated once per (device, kernel family) and ZEROED once (arrival counters re-arm
+    themselves); launches on one stream reuse it in stream order."""
+    key = (str(device), size_fn)
+    ws = _WS.get(key)
+    if ws is None:
+        from ._lib import lib
+        ws = _WS[key] = torch.zeros(int(getattr(lib(), size_fn)()), dtype=torch.uint8, device=device)
+    return ws
+
+
 class Param:
     """One trainable tensor: f32 master view, compute-dtype view, f32 gradient view (all slices of flat buffers)."""
     __slots__ = ('name', 'shape', 'master', 'c', 'grad')
@@ -649,16 +663,9 @@ def upconv(x, pw, pb, grad_is_pre=False, x_is_elu_out=False):
     return _UpConv.apply(x, pw.master, pb.master, pw, pb, grad_is_pre, x_is_elu_out)
 
 
-_OUTCONV_WS = {}
-
-
 def _outconv_workspace(device):
-    """Caller-owned scratch of stj_outconv_bwd (per-block dW/db partials; never zeroed, reused by both heads in stream order)."""
-    ws = _OUTCONV_WS.get(device)
-    if ws is None:
-        from ._lib import lib
-        ws = _OUTCONV_WS[device] = torch.empty(int(lib().stj_outconv_bwd_workspace_bytes()), dtype=torch.uint8, device=device)
-    return ws
+    """Caller-owned scratch of stj_outconv_bwd (per-block dW/db partials; reused by both heads in stream order)."""
+    return _workspace(device, 'stj_outconv_bwd_workspace_bytes')
 
 
 class _OutConvPair(torch.autograd.Function):
