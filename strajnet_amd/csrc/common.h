@@ -78,6 +78,11 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
 // ELU for bf16-stored results: v_exp_f32 based (abs error ~1e-7 near 0, far below bf16 resolution)
 __device__ __forceinline__ float elu_fast(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+// branch-free ELU for MFMA epilogues: v_min, v_mul, v_exp, v_add, v_cmp, v_cndmask (exp2 of a non-positive argument needs no range fix-up)
+__device__ __forceinline__ float elu_bf(float x) {
+  const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.4426950408889634f) - 1.f;
+  return x > 0.f ? x : e;
+}
 __device__ __forceinline__ float apply_act_fast(float x, int act) {
   return act == 2 ? elu_fast(x) : (act == 1 ? x * 0.5f * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))) : x);
 }

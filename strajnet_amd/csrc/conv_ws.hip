@@ -137,8 +137,10 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
-          const uint32_t p0 = pack2bf(apply_act_fast(acc[m][n][0] + bv[n][0], act), apply_act_fast(acc[m][n][1] + bv[n][1], act));
-          const uint32_t p1 = pack2bf(apply_act_fast(acc[m][n][2] + bv[n][2], act), apply_act_fast(acc[m][n][3] + bv[n][3], act));
+          // ELU only (the launcher routes other activations to the generic kernel): 6 VALU ops per value, no branches --
+          // the runtime-selected activation cost ~7000 instructions per tile, more than the 288 MFMAs
+          const uint32_t p0 = pack2bf(elu_bf(acc[m][n][0] + bv[n][0]), elu_bf(acc[m][n][1] + bv[n][1]));
+          const uint32_t p1 = pack2bf(elu_bf(acc[m][n][2] + bv[n][2]), elu_bf(acc[m][n][3] + bv[n][3]));
           *reinterpret_cast<uint2*>(ostage + ((2 * (mf + m) + a) * (2 * WS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
         }
     }
@@ -183,7 +185,7 @@ static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y,
 // returns true when the weight-stationary kernel handles this shape (bf16, Cin in {96,128}, Cout multiple of 4)
 bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        hipStream_t st) {
-  if (Cout % 4) return false;
+  if (Cout % 4 || act != ACT_ELU) return false;
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("STJ_WS_VARIANT"); variant = e ? atoi(e) : 1; }
   // Cin=96: the 2-waves-per-SIMD variant spills (144 weight VGPRs + prefetch); one wave per SIMD measured faster (386 vs 432 us)

@@ -51,3 +51,34 @@ class GraphedTrainStep:
             self.load(batch)
         self.graph.replay()
         return self.losses          # [observed_xe, occluded_xe, flow, flow_warp_xe]; gradients in model.flat_grads()
+
+
+class GraphedForward:
+    """hipGraph capture of the inference forward (training=False, no autograd): BASELINE config 4 (batch 32, one MI355X).
+    __call__(batch) copies the batch into the static inputs, replays, and returns the static [B,Hg,Hg,32] f32 output."""
+
+    def __init__(self, model, batch, warmup=2):
+        self.model = model
+        self.static = {k: v.clone() for k, v in batch.items() if k in ('ogm', 'map_img', 'obs', 'occ', 'flow')}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = self._eager()
+
+    def _eager(self):
+        x = self.static
+        return self.model(x['ogm'], x['map_img'], training=False, obs=x['obs'], occ=x['occ'], mapt=None, flow=x['flow'])
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            for k, v in batch.items():
+                if k in self.static:
+                    self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.out

@@ -203,6 +203,44 @@ def test_graph_replay_matches_eager_and_redraws_masks():
     assert torch.isfinite(l1).all() and torch.isfinite(l2).all()
 
 
+def test_config4_inference_graph_b32_bf16():
+    """BASELINE config 4: inference-only batch 32 on one GPU, hipGraph-captured forward (bf16 MFMA path; the build has no fp16
+    storage mode).  The replay must reproduce the eager forward bit for bit (the forward has no atomics) and follow new inputs."""
+    from strajnet_amd.graph import GraphedForward
+    from oracle import np_ref
+    cfg = dict(CFG128, input_size=(256, 256))
+    model, w, x, xt = _setup(cfg, 1, torch.bfloat16)
+    xs = np_ref.make_inputs(cfg, 4, seed=77)
+    big = {k: torch.as_tensor(np.concatenate([v] * 8, 0)).cuda() for k, v in xs.items()}          # B = 32
+    with torch.no_grad():
+        eager = model(big['ogm'], big['map_img'], training=False, obs=big['obs'], occ=big['occ'], mapt=None, flow=big['flow']).clone()
+    gf = GraphedForward(model, big)
+    out = gf().clone()
+    assert out.shape == (32, 256, 256, 32) and torch.isfinite(out).all()
+    assert torch.equal(out, eager)
+    assert torch.equal(out[:4], out[4:8])                        # replicated scenes -> identical rows (batch independence)
+    big2 = {k: torch.roll(v, 1, 0) for k, v in big.items()}
+    out2 = gf(big2)
+    assert torch.equal(out2, torch.roll(eager, 1, 0))
+
+
+def test_config5_cfg512_deeper_stage_f32():
+    """BASELINE config 5: 512x512 grid (large_ogm=True: 256^2 map, skips centre-cropped), window 8, deeper last Swin stage
+    depths=[2,2,6], B=1, against the differentiable restatement in float64 at FULL size."""
+    from oracle import np_ref, torch_ref
+    cfg = dict(input_size=(512, 512), window_size=8, embed_dim=96, depths=[2, 2, 6], num_heads=[3, 6, 12])
+    model, w, x, xt = _setup(cfg, 1, torch.float32, large_ogm=True)
+    assert model.n_params == 20386444                          # 13 277 788 + 4 more 32x32x384 blocks
+    with torch.no_grad():
+        y = _fwd(model, xt)
+        p, xr = torch_ref.to_torch(w), torch_ref.to_torch(x)
+        ref = torch_ref.forward(p, cfg, xr['ogm'], xr['map_img'], xr['obs'], xr['occ'], xr['flow'], large_ogm=True)
+    assert tuple(y.shape) == tuple(ref.shape) == (1, 256, 256, 32)
+    err = float((y.double().cpu() - ref).abs().max())
+    _report(f'fwd f32 cfg-512 depths [2,2,6] large_ogm B=1 (full size, vs torch_ref f64): max-abs err {err:.3e} (ref scale {float(ref.abs().max()):.2f}), {model.n_params} parameters')
+    assert err < ABS_TOL_F32
+
+
 def test_bf16_mode_error_report():
     """bf16-storage throughput mode: measured error vs the f64 oracle (reported, bounded loosely)."""
     from oracle import np_ref
