@@ -251,6 +251,148 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
+// =====================================================================================================
+// Row-streaming linear kernel (bf16): Y[M,N] = epi(X[M,K] W) for the token-major Dense layers with M >> N,K
+// (Swin qkv/proj/fc1/fc2 and their input gradients at 32768 / 8192 tokens, the per-waypoint 1x1 skips).
+// The generic tile kernel above spends its time on per-tile fixed costs there (two staged operands, 2-4 barriers and an
+// LDS epilogue for 12 MFMAs per wave).  Here the WEIGHT tile (NC output columns x all of K) is staged in LDS once per
+// block and is the MFMA A operand (m = output column); the activations never touch LDS: a lane loads its MFMA B
+// fragment (row = lane&15, 8 consecutive k) straight from global memory with one 16-byte load per k-step, for the whole K
+// up front.  D[m = column 4g+r][n = row] leaves each lane with 4 consecutive output columns of one row -> 8-byte stores
+// (+bias, ELU, residual) directly from the accumulators.  One barrier per block; 128 rows x NC columns per block.
+// =====================================================================================================
+template <int KS, int NC, bool TB>
+__global__ __launch_bounds__(256, 3) void linear_rs_kernel(GemmArgs p) {
+  constexpr int K = KS * 32;
+  constexpr int LDW = TB ? NC + 4 : K + 8;        // TB: image [K][NC+4] (n contiguous, as stored); else [NC][K+8]
+  constexpr int NJ = NC / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+  bf16* Ws = reinterpret_cast<bf16*>(rs_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ln = lane & 15;
+  const int z = blockIdx.z;
+  const long long z1 = z / p.nb2, z2 = z % p.nb2;
+  const int n0 = blockIdx.y * NC;
+  const int m0 = blockIdx.x * 128 + wave * 32;
+  const bf16* A = reinterpret_cast<const bf16*>(p.A) + z1 * p.sAb1 + z2 * p.sAb2;
+  const bf16* B = reinterpret_cast<const bf16*>(p.B) + z1 * p.sBb1 + z2 * p.sBb2;
+
+  // activations: B fragments of this wave's 32 rows, all k-steps (loads in flight while the weight tile is staged)
+  s16x8 xa[2][KS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + 16 * i + ln;
+    const bf16* ap = A + (long long)row * p.sAm + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (row < p.M) xa[i][ks] = *reinterpret_cast<const s16x8*>(ap + ks * 32);
+      else xa[i][ks] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  // weight tile -> LDS
+  if constexpr (TB) {           // W[k][n], n contiguous: chunk = 8 consecutive n of one k
+    constexpr int CPR = NC / 8;
+    for (int q = tid; q < K * CPR; q += 256) {
+      const int k = q / CPR, c = (q % CPR) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n0 + c < p.N) v = *reinterpret_cast<const uint4*>(B + (long long)k * p.sBk + n0 + c);     // N % 8 == 0 (dispatch)
+      uint2* d = reinterpret_cast<uint2*>(Ws + k * LDW + c);
+      d[0] = make_uint2(v.x, v.y); d[1] = make_uint2(v.z, v.w);
+    }
+  } else {                      // W^T[n][k], k contiguous
+    constexpr int CPR = K / 8;
+    for (int q = tid; q < NC * CPR; q += 256) {
+      const int n = q / CPR, c = (q % CPR) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n0 + n < p.N) v = *reinterpret_cast<const uint4*>(B + (long long)(n0 + n) * p.sBn + c);
+      *reinterpret_cast<uint4*>(Ws + n * LDW + c) = v;
+    }
+  }
+  __syncthreads();
+  if (m0 >= p.M) return;
+
+  f32x4 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      s16x8 wf;
+      if constexpr (TB) wf = Mma<bf16>::load_tr(Ws, LDW, j * 16, ks * 32, lane);
+      else wf = Mma<bf16>::load(Ws, LDW, j * 16, ks * 32, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = Mma<bf16>::mma(wf, xa[i][ks], acc[i][j]);
+    }
+
+  // epilogue from the accumulators: lane = 4 consecutive columns (n0 + 16 j + 4 g ..) of row (m0 + 16 i + ln)
+  const float* bias = p.bias ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
+  const bf16* res = p.res ? reinterpret_cast<const bf16*>(p.res) + z1 * p.sRes1 + z2 * p.sRes2 : nullptr;
+  bf16* C = reinterpret_cast<bf16*>(p.C) + z1 * p.sCb1 + z2 * p.sCb2;
+  const bool elu = p.act == ACT_ELU;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = n0 + 16 * j + 4 * g;
+    if (col >= p.N) continue;                    // N % 4 == 0 (dispatch)
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m0 + 16 * i + ln;
+      if (row >= p.M) continue;
+      float v0 = acc[i][j][0] * p.alpha + bv.x, v1 = acc[i][j][1] * p.alpha + bv.y;
+      float v2 = acc[i][j][2] * p.alpha + bv.z, v3 = acc[i][j][3] * p.alpha + bv.w;
+      if (elu) { v0 = elu_bf(v0); v1 = elu_bf(v1); v2 = elu_bf(v2); v3 = elu_bf(v3); }
+      if (res) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(res + (long long)row * p.ldres + col);
+        v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xffff0000u);
+        v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xffff0000u);
+      }
+      *reinterpret_cast<uint2*>(C + (long long)row * p.ldc + col) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+    }
+  }
+}
+
+template <int KS, int NC, bool TB>
+static bool rs_launch2(const GemmArgs& p, hipStream_t st) {
+  constexpr int K = KS * 32;
+  constexpr size_t lds = (size_t)(TB ? K * (NC + 4) : NC * (K + 8)) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)linear_rs_kernel<KS, NC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    attr_set = true;
+  }
+  dim3 grid((p.M + 127) / 128, (p.N + NC - 1) / NC, p.nb1 * p.nb2);
+  hipLaunchKernelGGL((linear_rs_kernel<KS, NC, TB>), grid, dim3(256), lds, st, p);
+  return true;
+}
+template <int KS, int NC>
+static bool rs_launch(const GemmArgs& p, bool tb, hipStream_t st) {
+  return tb ? rs_launch2<KS, NC, true>(p, st) : rs_launch2<KS, NC, false>(p, st);
+}
+// true when the row-streaming kernel took the problem
+static bool linear_rs_try(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
+  static int enabled = -1;
+  static int rs_min_m = 16384;     // measured: wins at 32768 tokens (1.3-1.7x), loses at <= 8192 (too few 128-row blocks for 256 CUs)
+  if (enabled < 0) { const char* e = getenv("STJ_NO_RS"); enabled = !(e && atoi(e)); e = getenv("STJ_RS_MIN_M"); if (e) rs_min_m = atoi(e); }
+  if (!enabled || ta || p.c_f32 || p.accumulate || p.splitk != 1 || p.colsum) return false;
+  if (p.M < rs_min_m || p.K % 32 || p.N % 8 || p.sAk != 1 || !p.vecA || !p.vecB || !p.vecC) return false;
+  if (p.act != ACT_NONE && p.act != ACT_ELU) return false;
+  if (p.res && (!p.vecR)) return false;
+  if (p.bias && (((uintptr_t)p.bias) % 16 || p.sBias1 % 4 || p.sBias2 % 4)) return false;
+  if (!tb && p.sBk != 1) return false;
+  if ((long long)p.nb1 * p.nb2 > 65535) return false;
+  switch (p.K) {
+    case 96: return rs_launch<3, 128>(p, tb, st);
+    case 128: return rs_launch<4, 128>(p, tb, st);
+    case 192: return rs_launch<6, 128>(p, tb, st);
+    case 288: return rs_launch<9, 64>(p, tb, st);
+    case 384: return rs_launch<12, 64>(p, tb, st);
+    default: return false;
+  }
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 static void launch_tile(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), p.nb1 * p.nb2 * p.splitk), blk(256);
@@ -262,6 +404,9 @@ static void launch_tile(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
 
 template <typename T>
 static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (linear_rs_try(p, ta, tb, st)) return stj_check_launch("stj_gemm(rs)");
+  }
   constexpr int BK = 128 / sizeof(T);
   const long long nb = (long long)p.nb1 * p.nb2;
   const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nb;

@@ -215,6 +215,13 @@ class STrajNet:
                 self.drop_path_rate[f'layers{i}/blocks{j}'] = float(dpr[sum(cfg['depths'][:i]) + j])
         for j in range(cfg['depths'][0]):
             self.drop_path_rate[f'flow_layers0/blocks{j}'] = float(dpr[j])
+        # constants of the graph, built once: which of the 8 Conv3D time taps see real (non-padded) frames for output time t
+        # (SAME padding 3 before / 4 after), and the obs/occ segment one-hots (trajNet.py:119-120)
+        sel = torch.zeros((8, 8), dtype=torch.float32)
+        for t in range(8):
+            sel[t, max(0, 3 - t):min(7, 10 - t) + 1] = 1
+        self._time_sel = sel.to(self.device)
+        self._seg_onehot = {}
         self.dropctx = ops.DropCtx(self.device, seed)
         self._dctx = None
         self.params = OrderedDict()
@@ -412,9 +419,12 @@ class STrajNet:
         nodes = ops.maxpool_time(nodes).view(B, A, 320)
         vec = ops.linear(trc[:, :, 0, 5:].contiguous(), self._p(pre + '/vector_feature/kernel'))
         enc = ops.linear(torch.cat([nodes, vec], -1), self._p(pre + '/sublayer/kernel'), self._p(pre + '/sublayer/bias'), act=ACT_ELU)
-        onehot = torch.zeros((A, 2), dtype=self.dtype, device=self.device)
-        onehot[:n_obs, 0] = 1
-        onehot[n_obs:, 1] = 1
+        onehot = self._seg_onehot.get((A, n_obs))
+        if onehot is None:
+            onehot = torch.zeros((A, 2), dtype=self.dtype, device=self.device)
+            onehot[:n_obs, 0] = 1
+            onehot[n_obs:, 1] = 1
+            self._seg_onehot[(A, n_obs)] = onehot
         embed = ops.linear(onehot, self._p('traj_net/seg_embed/kernel'))[None]            # [1,64,384]
         concat = enc * cm[..., None].to(enc.dtype)
         value = self._cross_attention('traj_net/cross_attention', concat + embed, concat, 6, cmi, cmi)
@@ -428,9 +438,7 @@ class STrajNet:
         time taps (modules.py:750-765): W_t = sum_{j=max(0,3-t)}^{min(7,10-t)} W[j]."""
         pw, pb = self._p(name + '/kernel'), self._p(name + '/bias')
         Ci, Co = pw.shape[3], pw.shape[4]
-        sel = torch.zeros((8, 8), dtype=torch.float32, device=self.device)
-        for t in range(8):
-            sel[t, max(0, 3 - t):min(7, 10 - t) + 1] = 1
+        sel = self._time_sel
         wz = (sel @ pw.master.detach().view(8, Ci * Co)).view(8, Ci, Co).to(self.dtype)
         gwz = torch.zeros((8, Ci, Co), dtype=torch.float32, device=self.device)
 

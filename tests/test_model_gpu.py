@@ -42,6 +42,19 @@ def _fwd(model, xt):
     return model(xt['ogm'], xt['map_img'], training=False, obs=xt['obs'], occ=xt['occ'], mapt=xt['mapt'], flow=xt['flow'])
 
 
+def _auc_delta(y, ref, x):
+    """occ-AUC parity (BASELINE metric): max over the 8 waypoints and both occupancy heads of
+    |PR-AUC(gt, sigmoid(kernel logits)) - PR-AUC(gt, sigmoid(oracle logits))| with the Keras AUC(PR, 100 thresholds)."""
+    from oracle import np_ref
+    sig = lambda a: 1.0 / (1.0 + np.exp(-a))
+    worst = 0.0
+    for t in range(8):
+        for ch, gt in ((0, x['gt_obs']), (1, x['gt_occ'])):
+            g = gt[:, t, :, :, 0]
+            worst = max(worst, abs(np_ref.keras_auc_pr(g, sig(y[..., 4 * t + ch])) - np_ref.keras_auc_pr(g, sig(ref[..., 4 * t + ch]))))
+    return worst
+
+
 @pytest.fixture(scope='module', autouse=True)
 def _lib(lib_built):
     assert torch.cuda.is_available()
@@ -55,9 +68,11 @@ def test_forward_parity_f32(fg_msa, fg):
         y = _fwd(model, xt).cpu().numpy()
     ref = np_ref.strajnet_forward(w, CFG128, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'], fg_msa=fg_msa, fg=fg)
     err = np.abs(y - ref).max()
-    _report(f'fwd f32 (fg_msa={fg_msa}, fg={fg}) 128x128 B=2: max-abs err {err:.3e} (ref scale {np.abs(ref).max():.2f})')
+    dauc = _auc_delta(y, ref, x)
+    _report(f'fwd f32 (fg_msa={fg_msa}, fg={fg}) 128x128 B=2: max-abs err {err:.3e} (ref scale {np.abs(ref).max():.2f}), |dPR-AUC| {dauc:.2e}')
     assert y.shape == ref.shape == (2, 128, 128, 32)
     assert err < ABS_TOL_F32
+    assert dauc < 1e-5
 
 
 def test_forward_parity_large_ogm_f32():
@@ -250,7 +265,9 @@ def test_bf16_mode_error_report():
     ref = np_ref.strajnet_forward(w, CFG128, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'])
     err = np.abs(y - ref).max()
     rms = float(np.sqrt(((y - ref) ** 2).mean()))
-    _report(f'fwd bf16 128x128 B=2: max-abs err {err:.3e}, rms {rms:.3e} (ref scale {np.abs(ref).max():.2f})')
+    dauc = _auc_delta(y, ref, x)
+    _report(f'fwd bf16 128x128 B=2: max-abs err {err:.3e}, rms {rms:.3e} (ref scale {np.abs(ref).max():.2f}), |dPR-AUC| {dauc:.2e}')
+    assert dauc < 2e-2
     assert np.isfinite(y).all()
     assert rms < 0.1 and err < 1.0
 

@@ -55,7 +55,11 @@ def _lib(lib_built):
 
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('M,K,N,act,use_res', [(300, 96, 288, 0, False), (1000, 384, 96, 0, True), (77, 5, 64, 2, False),
-                                               (64, 2, 384, 0, False), (513, 384, 126, 0, False), (4096, 96, 48, 2, False)])
+                                               (64, 2, 384, 0, False), (513, 384, 126, 0, False), (4096, 96, 48, 2, False),
+                                               # row-streaming kernel (bf16, M >= 2048, K in {96,128,192,288,384}): fwd [K,N] and dgrad [N,K] forms,
+                                               # ragged row tail, partial last column chunk, bias+ELU, residual
+                                               (2100, 96, 288, 0, True), (4133, 384, 96, 2, False), (2048, 192, 136, 0, False),
+                                               (2050, 288, 96, 0, True), (2304, 128, 384, 2, False)])
 def test_linear(dt, M, K, N, act, use_res):
     from strajnet_amd import ops
     pw, pb = mk_param((K, N), dt, 0.2, 1), mk_param((N,), dt, 0.2, 2)
