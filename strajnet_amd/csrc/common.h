@@ -184,7 +184,10 @@ __device__ __forceinline__ void mma_tile(const T* As, int lda, const T* Bs, int 
 // LDS row padding (elements) that keeps 16-byte alignment of rows
 template <typename T> struct LdsPad;
 template <> struct LdsPad<float> { static constexpr int P = 4; };
-template <> struct LdsPad<bf16> { static constexpr int P = 8; };
+// 16 elements = 32 bytes: rows of (multiple of 64 B) + 32 B put consecutive rows 2 (mod 4) 16-byte slots apart, the only
+// row strides for which the four 16-lane groups of a ds_read_b128 fragment read (rows = lane&15, +16 B per lane>>4) are
+// conflict-free on gfx950 (MI355X_MICROARCH.md LDS table; +16-byte padding measured 48 % conflict cycles in the conv kernels)
+template <> struct LdsPad<bf16> { static constexpr int P = 16; };
 
 // ---- zero-padded clamped bilinear sampling (reference occu_metric.py:345-409 + tfa_image.py:87-173) ----
 struct Bil {

@@ -33,6 +33,10 @@ __device__ __forceinline__ int tap_of(int a, int dyi) {  // which r of phase a u
 
 // W [3][3][Cin][Cout] f32 (Keras HWIO) -> Wf [16][Cout][Cin] (forward B operand, K=cin contiguous)
 //                                         Wd [16][Cin][Cout] (dgrad  B operand, K=cout contiguous, indexed (u+1)*4+(v+1))
+// LDS row padding of the generic (v1) conv kernels: 16 bytes.  (The 32-byte LdsPad that makes b128 fragment reads conflict-free
+// costs these kernels a resident block per CU: measured 0.31 -> 0.47 ms on the two small decoder layers.)
+template <typename T> struct ConvPad { static constexpr int P = 16 / sizeof(T); };
+
 template <typename T>
 __global__ __launch_bounds__(256) void upconv_prep_kernel(const float* W, T* Wf, T* Wd, int Cin, int Cout) {
   const int total = 16 * Cout * Cin;
@@ -75,7 +79,7 @@ template <typename T, int FN>
 __global__ __launch_bounds__(256) void upconv_fwd_kernel(const T* X, const T* Wf, const float* bias, T* Y,
                                                          int F, int Hi, int Wi, int Cin, int Cout, int act) {
   constexpr int BN = FN * 16;
-  constexpr int LDK = KC + LdsPad<T>::P;
+  constexpr int LDK = KC + ConvPad<T>::P;
   constexpr int VN = Vec<T>::N, CPR = KC / VN;
   constexpr int HH = TILE_H + 2, HW = TILE_W + 2;
   __shared__ __attribute__((aligned(16))) T halo[HH * HW * LDK];
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const T* X, const T* Wf
 template <typename T, int FN>
 __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T* Wd, T* dX, const T* Xelu, int F, int Hi, int Wi, int Cin, int Cout) {
   constexpr int BN = FN * 16;
-  constexpr int LDK = KC + LdsPad<T>::P;
+  constexpr int LDK = KC + ConvPad<T>::P;
   constexpr int VN = Vec<T>::N, CPR = KC / VN;
   constexpr int HH = 2 * TILE_H + 2, HW = 2 * TILE_W + 2;
   __shared__ __attribute__((aligned(16))) T halo[HH * HW * LDK];
@@ -276,7 +280,7 @@ template <typename T, int FO, int FI>
 __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* dP, float* dWeff, float* dbias, int F, int Hi, int Wi,
                                                            int Cin, int Cout, int chunks_per_block) {
   constexpr int BO = FO * 16, BI = FI * 16;
-  constexpr int LDO = BO + LdsPad<T>::P, LDI = BI + LdsPad<T>::P;
+  constexpr int LDO = BO + ConvPad<T>::P, LDI = BI + ConvPad<T>::P;
   constexpr int VN = Vec<T>::N;
   constexpr int XW = WG_W + 2;
   __shared__ __attribute__((aligned(16))) T dYs[WG_W * LDO];

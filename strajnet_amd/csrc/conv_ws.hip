@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
                                                                const float* __restrict__ bias, bf16* __restrict__ Y,
                                                                int F, int Hi, int Wi, int Cout, int act, int ntiles) {
   constexpr int CIN = KS * 32;
-  constexpr int LDK = CIN + 8;                     // halo pixel stride (elements)
+  constexpr int LDK = CIN + 16;                    // halo pixel stride (elements): 2 (mod 4) 16-byte slots -> conflict-free b128 fragment reads
   constexpr int CT = NF * 16;                      // cout tile of this workgroup
   constexpr int LDO = CT + 4;                      // output-stage pixel stride (elements), 8-byte aligned
   constexpr int HPIX = WS_HH * WS_HW;              // 180 halo pixels
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
 
 template <int KS, int NF, int NW>
 static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, int act, hipStream_t st) {
-  constexpr int CIN = KS * 32, LDK = CIN + 8, CT = NF * 16, LDO = CT + 4;
+  constexpr int CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 4;
   const size_t lds = (size_t)(2 * WS_HH * WS_HW * LDK + 2 * WS_TH * 2 * WS_TW * LDO) * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -218,7 +218,7 @@ __device__ __forceinline__ s16x8 tr_frag(const bf16* p0, const bf16* p1) {
 template <int FO, int FI>
 __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dP,
                                                               float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin,
-                                                              int Cout, int chunks_per_block) {
+                                                              int Cout, int chunks_per_block, int nstrips, int ntiles) {
   constexpr int BO = FO * 16, BI = FI * 16;
   constexpr int LDO = BO + 8, LDI = BI + 8;
   constexpr int XW = WG2_W + 2, XR = WG2_ROWS + 1;
@@ -229,14 +229,22 @@ __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __rest
   __shared__ __attribute__((aligned(16))) bf16 Xs[XR * XW * LDI];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int a = blockIdx.y >> 1, b = blockIdx.y & 1;
+  // XCD-aware work map (1-D grid): workgroup L runs on XCD L % 8 (round-robin dispatch); the 4 output phases and the channel
+  // tiles of ONE pixel strip read the same X rows and the same dP cache lines, so they get consecutive slots of the SAME
+  // XCD and share them through that XCD's L2.  Before (phase = blockIdx.y): 1.68 GB fetched per launch for 0.60 GB of
+  // operands (rocprofv3 FETCH_SIZE, profiles/r01_e_pmc_conv.txt) -- every phase streamed X and both dP column parities again.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int inner = 4 * ntiles;
+  const int strip = (slot / inner) * 8 + xcd, phase = (slot % inner) & 3, ctile = (slot % inner) >> 2;
+  if (strip >= nstrips) return;
+  const int a = phase >> 1, b = phase & 1;
   const int r = w >> 1, s = w & 1;
   const int g = lane >> 4, p = lane & 15;
   const int cin_tiles = (Cin + BI - 1) / BI;
-  const int co0 = (blockIdx.z / cin_tiles) * BO, ci0 = (blockIdx.z % cin_tiles) * BI;
+  const int co0 = (ctile / cin_tiles) * BO, ci0 = (ctile % cin_tiles) * BI;
   const int segs = Wi / WG2_W, rgs = Hi / WG2_ROWS;
   const long long nchunks = (long long)F * rgs * segs;
-  const long long c_begin = (long long)blockIdx.x * chunks_per_block;
+  const long long c_begin = (long long)strip * chunks_per_block;
   const long long c_end = min(nchunks, c_begin + chunks_per_block);
   const int Ho = 2 * Hi, Wo = 2 * Wi;
 
@@ -335,13 +343,13 @@ bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbi
     int strips = (int)min(nchunks, (long long)256);
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
-    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6>), dim3(strips, 4, 1), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb);
+    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6>), dim3((strips + 7) / 8 * 8 * 4), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb, strips, 1);
   } else {
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     int strips = (int)min(nchunks, (long long)max(1, 1024 / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
-    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<4, 4>), dim3(strips, 4, tiles), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb);
+    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<4, 4>), dim3((strips + 7) / 8 * 8 * 4 * tiles), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb, strips, tiles);
   }
   return true;
 }
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const bf16* __res
                                                                const float* __restrict__ bias, float* __restrict__ Y, int F, int Hh,
                                                                int Ww, int Tn, long long y_bs, long long y_ts, long long y_ps) {
   static_assert(C == 48, "specialised for 48 input channels (32 + 16)");
-  constexpr int LDH = C + 8;
+  constexpr int LDH = C + 32;                      // 160-byte pixels: conflict-free b128 fragment reads
   constexpr int CPP = C / 8, NCH = (OCM_H * OCM_H * CPP + 255) / 256;
   __shared__ __attribute__((aligned(16))) bf16 halo[OCM_H * OCM_H * LDH + 64];   // pads + tail stay zero (read by the padded 2nd k-step)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
@@ -632,7 +640,7 @@ template <int KS, int NFI, bool ELU>
 __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ Wd,
                                                                  bf16* __restrict__ dX, const bf16* __restrict__ Xelu, int F, int Hi,
                                                                  int Wi, int Cin, int Cout, int ntiles) {
-  constexpr int LDK = KS * 32 + 8;                 // halo pixel stride (elements); channels >= Cout stay zero
+  constexpr int LDK = KS * 32 + (KS == 3 ? 8 : 16);   // halo pixel stride; +16 = conflict-free b128 reads (KS = 3: only +8 fits in 160 KB); channels >= Cout stay zero
   constexpr int HH = 2 * WS_TH + 2, HW = 2 * WS_TW + 2, HPIX = HH * HW;
   constexpr int CT = NFI * 16;                     // cin tile of this workgroup
   constexpr int LDR = CT + 4;                      // reduction row stride (floats)
@@ -786,7 +794,7 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
 
 template <int KS, int NFI, bool ELU>
 static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
-  constexpr int LDK = KS * 32 + 8, HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), CT = NFI * 16, LDR = CT + 4;
+  constexpr int LDK = KS * 32 + (KS == 3 ? 8 : 16), HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), CT = NFI * 16, LDR = CT + 4;
   const size_t lds = (size_t)(HPIX * LDK + 64) * 2 + (size_t)4 * 2 * 16 * LDR * 4;
   static bool attr_set = false;
   if (!attr_set) {

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 template <int KS, int NC, bool TB>
 __global__ __launch_bounds__(256, 3) void linear_rs_kernel(GemmArgs p) {
   constexpr int K = KS * 32;
-  constexpr int LDW = TB ? NC + 4 : K + 8;        // TB: image [K][NC+4] (n contiguous, as stored); else [NC][K+8]
+  constexpr int LDW = TB ? NC + 4 : K + 16;       // TB: image [K][NC+4] (n contiguous, as stored); else [NC][K+16]
   constexpr int NJ = NC / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
   bf16* Ws = reinterpret_cast<bf16*>(rs_smem);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 3) void linear_rs_kernel(GemmArgs p) {
 template <int KS, int NC, bool TB>
 static bool rs_launch2(const GemmArgs& p, hipStream_t st) {
   constexpr int K = KS * 32;
-  constexpr size_t lds = (size_t)(TB ? K * (NC + 4) : NC * (K + 8)) * 2;
+  constexpr size_t lds = (size_t)(TB ? K * (NC + 4) : NC * (K + 16)) * 2;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)linear_rs_kernel<KS, NC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
