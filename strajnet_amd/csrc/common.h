@@ -59,6 +59,15 @@ template <> __device__ __forceinline__ void st16<bf16>(bf16* p, const float* in)
   *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(in[0], in[1]), pack2bf(in[2], in[3]), pack2bf(in[4], in[5]), pack2bf(in[6], in[7]));
 }
 
+// 4 consecutive elements (8 bytes of bf16 / 16 bytes of f32)
+__device__ __forceinline__ void st4(bf16* p, const float* v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])); }
+__device__ __forceinline__ void st4(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void ld4(const bf16* p, float* v) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u); v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+__device__ __forceinline__ void ld4(const float* p, float* v) { const float4 u = *reinterpret_cast<const float4*>(p); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; }
+
 // ---- activations -----------------------------------------------------------------------
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_ELU = 2 };
 

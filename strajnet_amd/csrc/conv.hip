@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const T* X, const T* Wf
               for (int n = 0; n < FN; ++n) {
                 typename Mma<T>::Frag bf = Mma<T>::load(Bs + (slot * BN + n * 16) * LDK, LDK, 0, k0, lane);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[a * 2 + b][m][n] = Mma<T>::mma(af[m], bf, acc[a * 2 + b][m][n]);
+                for (int m = 0; m < 2; ++m) acc[a * 2 + b][m][n] = Mma<T>::mma(bf, af[m], acc[a * 2 + b][m][n]);   // D[m = cout][n = pixel]
               }
             }
           }
@@ -158,26 +158,34 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const T* X, const T* Wf
     }
     __syncthreads();
   }
+  // epilogue: weights are the MFMA A operand, so a lane holds 4 CONSECUTIVE couts (n0 + 16 n + 4 (lane>>4) ..) of pixel
+  // (row mf0 + m, column lane & 15) -> one 8/16-byte store per fragment (v0 of this kernel stored single elements and
+  // picked the activation per element at run time: ~5000 instructions per tile)
   const int Ho = 2 * Hi, Wo = 2 * Wi;
   T* Yf = Y + (long long)f * Ho * Wo * Cout;
+  const int g4 = (lane >> 4) * 4, px = tx0 + (lane & 15);
+  const bool elu = act == ACT_ELU;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int a = p >> 1, b = p & 1;
+  for (int n = 0; n < FN; ++n) {
+    const int col = n0 + n * 16 + g4;
+    if (col >= Cout) continue;                       // Cout % 4 == 0 (checked by the launcher)
+    const float4 bv = *reinterpret_cast<const float4*>(bias + col);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int py = ty0 + mf0 + m;
-      if (py >= Hi) continue;
+    for (int p = 0; p < 4; ++p) {
+      const int a = p >> 1, b = p & 1;
 #pragma unroll
-      for (int n = 0; n < FN; ++n) {
-        const int col = n0 + n * 16 + (lane & 15);
-        if (col >= Cout) continue;
-        const float bv = bias[col];
+      for (int m = 0; m < 2; ++m) {
+        const int py = ty0 + mf0 + m;
+        if (py >= Hi || px >= Wi) continue;
+        float v[4] = {acc[p][m][n][0] + bv.x, acc[p][m][n][1] + bv.y, acc[p][m][n][2] + bv.z, acc[p][m][n][3] + bv.w};
+        if (elu) {
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int px = tx0 + (lane >> 4) * 4 + rg;
-          if (px >= Wi) continue;
-          stf(Yf + ((long long)(2 * py + a) * Wo + 2 * px + b) * Cout + col, apply_act(acc[p][m][n][rg] + bv, act));
+          for (int e = 0; e < 4; ++e) v[e] = elu_bf(v[e]);
+        } else if (act != ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
         }
+        st4(Yf + ((long long)(2 * py + a) * Wo + 2 * px + b) * Cout + col, v);
       }
     }
   }
@@ -242,31 +250,33 @@ __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T*
           for (int n = 0; n < FN; ++n) {
             typename Mma<T>::Frag bf = Mma<T>::load(Bs + (vi * BN + n * 16) * LDK, LDK, 0, k0, lane);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) acc[m][n] = Mma<T>::mma(af[m], bf, acc[m][n]);
+            for (int m = 0; m < 2; ++m) acc[m][n] = Mma<T>::mma(bf, af[m], acc[m][n]);   // D[m = cin][n = pixel]
           }
         }
       }
     }
     __syncthreads();
   }
+  // lane = 4 consecutive cins (n0 + 16 n + 4 (lane>>4) ..) of pixel (row mf0 + m, column lane & 15)
   T* Xf = dX + (long long)f * Hi * Wi * Cin;
+  const int g4 = (lane >> 4) * 4, px = tx0 + (lane & 15);
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const int py = ty0 + mf0 + m;
-    if (py >= Hi) continue;
+    if (py >= Hi || px >= Wi) continue;
 #pragma unroll
     for (int n = 0; n < FN; ++n) {
-      const int col = n0 + n * 16 + (lane & 15);
-      if (col >= Cin) continue;
+      const int col = n0 + n * 16 + g4;
+      if (col >= Cin) continue;                      // Cin % 4 == 0 (checked by the launcher)
+      const long long o = ((long long)py * Wi + px) * Cin + col;
+      float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+      if (Xelu) {
+        float xv[4];
+        ld4(Xelu + (long long)f * Hi * Wi * Cin + o, xv);
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int px = tx0 + (lane >> 4) * 4 + rg;
-        if (px >= Wi) continue;
-        const long long o = ((long long)py * Wi + px) * Cin + col;
-        float v = acc[m][n][rg];
-        if (Xelu) { const float xv = ldf(Xelu + (long long)f * Hi * Wi * Cin + o); v *= xv > 0.f ? 1.f : xv + 1.f; }
-        stf(Xf + o, v);
+        for (int e = 0; e < 4; ++e) v[e] *= xv[e] > 0.f ? 1.f : xv[e] + 1.f;
       }
+      st4(Xf + o, v);
     }
   }
 }
