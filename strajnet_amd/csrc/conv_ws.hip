@@ -213,12 +213,12 @@ __device__ __forceinline__ s16x8 tr_frag(const bf16* p0, const bf16* p1) {
   return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-#define WG2_ROWS 4
-#define WG2_W 32
-template <int FO, int FI>
+// chunk = CR rows x CW columns of low-res pixels with CR * CW = 128; CW = 32 (wide layers) or 16 (the 16x16 bottleneck layer)
+template <int FO, int FI, int CW>
 __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dP,
                                                               float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin,
                                                               int Cout, int chunks_per_block, int nstrips, int ntiles) {
+  constexpr int WG2_W = CW, WG2_ROWS = 128 / CW, KROWS = 32 / CW;      // KROWS: chunk rows per 32-pixel k-step
   constexpr int BO = FO * 16, BI = FI * 16;
   constexpr int LDO = BO + 8, LDI = BI + 8;
   constexpr int XW = WG2_W + 2, XR = WG2_ROWS + 1;
@@ -296,12 +296,12 @@ __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __rest
   for (long long c = c_begin; c < c_end; ++c) {
     if (c + 1 < c_end) prefetch(c + 1);
 #pragma unroll
-    for (int rr = 0; rr < WG2_ROWS; ++rr) {
+    for (int rr = 0; rr < 4; ++rr) {              // k-step rr = pixels 32 rr .. 32 rr + 31 of the chunk (row-major)
       s16x8 af[FO], bfr[FI];
-      const bf16* ab = dYs + (rr * WG2_W + kpx) * LDO + kch;
+      const bf16* ab = dYs + (rr * 32 + kpx) * LDO + kch;
 #pragma unroll
       for (int m = 0; m < FO; ++m) af[m] = tr_frag(ab + m * 16, ab + 4 * LDO + m * 16);
-      const bf16* bb = Xs + ((rr + r) * XW + kpx + s) * LDI + kch;
+      const bf16* bb = Xs + ((rr * KROWS + kpx / CW + r) * XW + kpx % CW + s) * LDI + kch;
 #pragma unroll
       for (int n = 0; n < FI; ++n) bfr[n] = tr_frag(bb + n * 16, bb + 4 * LDI + n * 16);
 #pragma unroll
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __rest
     }
     if (do_db) {                       // wave w sums row w of the chunk
       float sdb = 0.f;
-      for (int q = 0; q < WG2_W; ++q) sdb += bf2f(dYs[(w * WG2_W + q) * LDO + lane].v);
+      for (int q = 0; q < 32; ++q) sdb += bf2f(dYs[(w * 32 + q) * LDO + lane].v);
       dbacc += sdb;
     }
     __syncthreads();
@@ -335,23 +335,30 @@ __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __rest
     }
 }
 
-// returns true when handled (bf16, Wi % 32 == 0, Hi % 4 == 0, channels % 8 == 0)
-bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
-  if (Wi % WG2_W || Hi % WG2_ROWS || Cin % 8 || Cout % 8) return false;
-  const long long nchunks = (long long)F * (Hi / WG2_ROWS) * (Wi / WG2_W);
+// returns true when handled (bf16; Wi % 32 == 0 and Hi % 4 == 0, or Wi % 16 == 0 and Hi % 8 == 0; channels % 8 == 0)
+template <int CW>
+static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  constexpr int CR = 128 / CW;
+  const long long nchunks = (long long)F * (Hi / CR) * (Wi / CW);
   if (Cout <= 48 && Cin <= 96) {
     int strips = (int)min(nchunks, (long long)256);
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
-    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6>), dim3((strips + 7) / 8 * 8 * 4), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb, strips, 1);
+    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6, CW>), dim3((strips + 7) / 8 * 8 * 4), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb, strips, 1);
   } else {
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     int strips = (int)min(nchunks, (long long)max(1, 1024 / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
-    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<4, 4>), dim3((strips + 7) / 8 * 8 * 4 * tiles), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb, strips, tiles);
+    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<4, 4, CW>), dim3((strips + 7) / 8 * 8 * 4 * tiles), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb, strips, tiles);
   }
   return true;
+}
+bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  if (Cin % 8 || Cout % 8) return false;
+  if (Wi % 32 == 0 && Hi % 4 == 0) return wgrad_tr_launch<32>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, st);
+  if (Wi % 16 == 0 && Hi % 8 == 0) return wgrad_tr_launch<16>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, st);
+  return false;
 }
 
 // =====================================================================================================
