@@ -132,6 +132,182 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dy, con
   }
 }
 
+// =====================================================================================================
+// v2 (16-byte vector) kernels.  v1 above reads 2-byte elements (lane = column), one row per wave at a time: backward ran at
+// 0.5-1 TB/s, spilled for C >= 384 (1024-thread blocks cap a wave at 128 VGPRs) and cost ~40 us even for 128 rows.
+// v2: a row is covered by LPR lanes x NCHK 16-byte chunks (C = 96: 12 of 16 lanes busy, 4 rows per wave pass; 384: 48 of 64
+// lanes), U passes are in flight per wave, row reductions are xor-shuffles inside the LPR-lane group, 256-thread blocks.
+// =====================================================================================================
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// source offset of the VN-element chunk starting at logical column c (a chunk never straddles PatchMerging quadrants: C0 % VN == 0)
+template <typename T, int LPR, int NCHK>
+__global__ __launch_bounds__(256) void ln_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                      long long rows, int C, float eps, int gres, int C0, LnGroups G) {
+  constexpr int VN = Vec<T>::N, RPW = 64 / LPR;
+  constexpr int U = NCHK == 1 ? 4 : (NCHK == 2 ? 2 : 1);
+  const int lane = threadIdx.x & 63, sl = lane % LPR, rsub = lane / LPR;
+  const long long wave = blockIdx.x * 4ll + (threadIdx.x >> 6), nwaves = gridDim.x * 4ll;
+  const float invC = 1.f / C;
+  for (long long row0 = wave * (U * RPW); row0 < rows; row0 += nwaves * (U * RPW)) {
+    float v[U][NCHK][VN];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long row = row0 + u * RPW + rsub;
+#pragma unroll
+      for (int k = 0; k < NCHK; ++k) {
+        const int c = (sl + LPR * k) * VN;
+        if (row < rows && c < C) ld16(x + ln_src(row, c, C, gres, C0), v[u][k]);
+        else {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[u][k][e] = 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long row = row0 + u * RPW + rsub;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCHK; ++k)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) s += v[u][k][e];
+      const float mu = group_sum<LPR>(s) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCHK; ++k) {
+        const int c = (sl + LPR * k) * VN;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { const float d = c < C ? v[u][k][e] - mu : 0.f; q += d * d; }
+      }
+      const float rs = rsqrtf(group_sum<LPR>(q) * invC + eps);
+      if (row >= rows) continue;
+      const long long goff = G.ngroups > 1 ? ((row / G.group_rows) % G.ngroups) * G.gstride : 0;
+#pragma unroll
+      for (int k = 0; k < NCHK; ++k) {
+        const int c = (sl + LPR * k) * VN;
+        if (c >= C) continue;
+        float o[VN];
+#pragma unroll
+        for (int e = 0; e < VN; e += 4) {
+          const float4 gv = *reinterpret_cast<const float4*>(gamma + goff + c + e), bv = *reinterpret_cast<const float4*>(beta + goff + c + e);
+          o[e] = (v[u][k][e] - mu) * rs * gv.x + bv.x; o[e + 1] = (v[u][k][e + 1] - mu) * rs * gv.y + bv.y;
+          o[e + 2] = (v[u][k][e + 2] - mu) * rs * gv.z + bv.z; o[e + 3] = (v[u][k][e + 3] - mu) * rs * gv.w + bv.w;
+        }
+        st16(y + row * C + c, o);
+      }
+      if (sl == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+  }
+}
+
+template <typename T, int LPR, int NCHK>
+__global__ __launch_bounds__(256) void ln_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
+                                                      float* dgamma, float* dbeta, long long rows, int C, int gres, int C0, LnGroups G, int nb) {
+  constexpr int VN = Vec<T>::N, RPW = 64 / LPR;
+  constexpr int U = NCHK == 1 ? 4 : (NCHK == 2 ? 2 : 1);
+  __shared__ float red[2][LPR * NCHK * VN];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sl = lane % LPR, rsub = lane / LPR;
+  for (int c = threadIdx.x; c < 2 * LPR * NCHK * VN; c += 256) (&red[0][0])[c] = 0.f;
+  __syncthreads();
+  const int g = blockIdx.x % G.ngroups, sub = blockIdx.x / G.ngroups;
+  const long long goff = (long long)g * G.gstride;
+  const long long nruns = (rows + G.group_rows - 1) / G.group_rows;
+  const long long nr_g = (nruns - g + G.ngroups - 1) / G.ngroups;
+  const float invC = 1.f / C;
+  float gam[NCHK][VN], ag[NCHK][VN], ab[NCHK][VN];
+#pragma unroll
+  for (int k = 0; k < NCHK; ++k) {
+    const int c = (sl + LPR * k) * VN;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { gam[k][e] = c < C ? gamma[goff + c + e] : 0.f; ag[k][e] = 0.f; ab[k][e] = 0.f; }
+  }
+  for (long long jj = sub; jj < nr_g * G.S; jj += nb) {
+    const long long run = g + (long long)G.ngroups * (jj / G.S);
+    const long long part = jj % G.S;
+    const long long chunk_begin = run * G.group_rows + part * G.L;
+    const long long rend = min(rows, run * G.group_rows + min(G.group_rows, (part + 1) * G.L));
+    for (long long row0 = chunk_begin + (long long)w * (U * RPW); row0 < rend; row0 += 4 * (U * RPW)) {
+      float dv[U][NCHK][VN], xv[U][NCHK][VN], mu[U], rs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long row = row0 + u * RPW + rsub;
+        const bool ok = row < rend;
+        mu[u] = ok ? mean[row] : 0.f; rs[u] = ok ? rstd[row] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NCHK; ++k) {
+          const int c = (sl + LPR * k) * VN;
+          if (ok && c < C) { ld16(dy + row * C + c, dv[u][k]); ld16(x + ln_src(row, c, C, gres, C0), xv[u][k]); }
+          else {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) { dv[u][k][e] = 0.f; xv[u][k][e] = 0.f; }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long row = row0 + u * RPW + rsub;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCHK; ++k) {
+          const int c = (sl + LPR * k) * VN;
+#pragma unroll
+          for (int e = 0; e < VN; ++e) {
+            const float xh = c < C ? (xv[u][k][e] - mu[u]) * rs[u] : 0.f;      // rs = 0 on rows past the end
+            const float gg = dv[u][k][e] * gam[k][e];
+            ag[k][e] += dv[u][k][e] * xh;
+            ab[k][e] += dv[u][k][e];
+            xv[u][k][e] = xh; dv[u][k][e] = gg;
+            s1 += gg; s2 += gg * xh;
+          }
+        }
+        s1 = group_sum<LPR>(s1) * invC;
+        s2 = group_sum<LPR>(s2) * invC;
+        if (row >= rend) continue;
+#pragma unroll
+        for (int k = 0; k < NCHK; ++k) {
+          const int c = (sl + LPR * k) * VN;
+          if (c >= C) continue;
+          float o[VN];
+#pragma unroll
+          for (int e = 0; e < VN; ++e) o[e] = rs[u] * (dv[u][k][e] - s1 - xv[u][k][e] * s2);
+          st16(dx + ln_src(row, c, C, gres, C0), o);
+        }
+      }
+    }
+  }
+  // dgamma / dbeta: sum the RPW row sub-groups of the wave, then the 4 waves through LDS, then one atomic per column and block
+#pragma unroll
+  for (int k = 0; k < NCHK; ++k)
+#pragma unroll
+    for (int e = 0; e < VN; ++e) {
+      float a = ag[k][e], b = ab[k][e];
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+      if (rsub == 0) { atomicAdd(&red[0][(sl + LPR * k) * VN + e], a); atomicAdd(&red[1][(sl + LPR * k) * VN + e], b); }
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + goff + c, red[0][c]);
+    atomicAdd(dbeta + goff + c, red[1][c]);
+  }
+}
+
+// LPR lanes x NCHK chunks cover a row of C / VN 16-byte chunks
+template <typename T, int LPR, int NCHK>
+static void ln2_launch(bool fwd, int grid, hipStream_t stream, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                       float* rstd, const void* dy, void* dx, float* dgamma, float* dbeta, long long rows, int C, float eps, int gres, int C0,
+                       LnGroups G, int nb) {
+  if (fwd) hipLaunchKernelGGL((ln_fwd2_kernel<T, LPR, NCHK>), dim3(grid), dim3(256), 0, stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, gres, C0, G);
+  else hipLaunchKernelGGL((ln_bwd2_kernel<T, LPR, NCHK>), dim3(grid), dim3(256), 0, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0, G, nb);
+}
+
 #define LN_DISPATCH(NPLV)                                                                                         \
   if (fwd) hipLaunchKernelGGL((ln_fwd_kernel<T, NPLV>), dim3(grid), dim3(256), 0, stream, (const T*)x, gamma, beta, \
                               (T*)y, mean, rstd, rows, C, eps, gres, C0, G);                                       \
@@ -144,6 +320,45 @@ static int ln_launch(bool fwd, const void* x, const float* gamma, const float* b
                      int C0, LnGroups G, hipStream_t stream) {
   const int npl = (C + 63) / 64;
   int grid, nb = 1;
+  {
+    // v2 path: whole 16-byte chunks, aligned rows, gather quadrants a multiple of the chunk, parameter sets 16-byte aligned
+    constexpr int VN = Vec<T>::N;
+    static int v2 = -1;
+    if (v2 < 0) { const char* e = getenv("STJ_LN_V1"); v2 = !(e && atoi(e)); }
+    const int chunks = C / VN;
+    const bool al = ((uintptr_t)x % 16 == 0) && (!fwd || (uintptr_t)y % 16 == 0) && (fwd || ((uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0)) &&
+                    ((uintptr_t)gamma % 16 == 0) && (fwd ? (uintptr_t)beta % 16 == 0 : true) && (G.gstride % 4 == 0);
+    if (v2 && C % VN == 0 && (gres == 0 || C0 % VN == 0) && chunks <= 192 && al) {
+      LnGroups G2 = G;
+      if (fwd) {
+        const int lpr = chunks <= 16 ? 16 : (chunks <= 32 ? 32 : 64);
+        const int rows_per_wave = (64 / lpr) * (chunks <= 64 ? 4 : (chunks <= 128 ? 2 : 1));
+        long long want = (rows + 4ll * rows_per_wave - 1) / (4ll * rows_per_wave);
+        grid = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+      } else {
+        if (G2.ngroups <= 1) { G2.ngroups = 1; G2.gstride = 0; G2.group_rows = rows; }
+        const long long nruns = (rows + G2.group_rows - 1) / G2.group_rows;
+        const long long nr = (nruns + G2.ngroups - 1) / G2.ngroups;
+        long long nbt = (rows / G2.ngroups + 63) / 64;                 // >= 64 rows per block
+        if (nbt > 512 / G2.ngroups) nbt = 512 / G2.ngroups;            // <= 512 blocks share the dgamma/dbeta atomics
+        if (nbt < 1) nbt = 1;
+        long long S = (nbt + nr - 1) / nr;
+        if (S < 1) S = 1;
+        G2.S = (int)S;
+        G2.L = (G2.group_rows + S - 1) / S;
+        nb = (int)(nbt < nr * S ? nbt : nr * S);
+        grid = G2.ngroups * nb;
+      }
+#define LN2(LPRV, NCHKV) ln2_launch<T, LPRV, NCHKV>(fwd, grid, stream, x, gamma, beta, y, mean, rstd, dy, dx, dgamma, dbeta, rows, C, eps, gres, C0, G2, nb)
+      if (chunks <= 16) LN2(16, 1);
+      else if (chunks <= 32) LN2(32, 1);
+      else if (chunks <= 64) LN2(64, 1);
+      else if (chunks <= 128) LN2(64, 2);
+      else LN2(64, 3);
+#undef LN2
+      return stj_check_launch("stj_layernorm(v2)");
+    }
+  }
   if (fwd) {
     long long want = (rows + 3) / 4;
     grid = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
