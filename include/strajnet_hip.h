@@ -82,7 +82,7 @@ int stj_softmax_fwd(const float* S, void* P, const int* qvalid, const int* kvali
 int stj_softmax_bwd(const void* P, const float* dP, void* dS, long long rows, int Nk, int dtype, hipStream_t stream);
 /* FG-MSA relative-position bias: bilinear `sample` of rpe_table at (query - key - offset) displacements
  * (FG_MSA.py:150-172 via occu_metric.py:345-409 + tfa_image.py:87-173).  off [B,G,H*W,2], table f32 [2H-1,2W-1,G],
- * bias f32 [B,G,HW,HW]; bwd: dtable +=, doff f32 [B,G,HW,2] (written). */
+ * bias f32 [B,G,HW,HW]; bwd: dtable +=, doff f32 [B,G,HW,2] += (zeroed by the caller: query slices accumulate). */
 int stj_fg_bias_fwd(const void* off, const float* table, float* bias, int B, int G, int Hh, int Ww, int dtype, hipStream_t stream);
 int stj_fg_bias_bwd(const void* off, const float* table, const void* dbias, float* dtable, float* doff,
                     int B, int G, int Hh, int Ww, int dtype, hipStream_t stream);

@@ -113,12 +113,15 @@ __global__ __launch_bounds__(256) void fg_bias_fwd_kernel(const T* off, const fl
 // 0.94 ms at B=8.)
 template <typename T>
 __global__ __launch_bounds__(256) void fg_bias_bwd_kernel(const T* off, const float* table, const T* dbias, float* dtable,
-                                                          float* doff, int B, int G, int Hh, int Ww) {
+                                                          float* doff, int B, int G, int Hh, int Ww, int QS) {
   extern __shared__ float fg_lds[];
   const int HW = Hh * Ww, TH = 2 * Hh - 1, TW = 2 * Ww - 1;
   float* tbl = fg_lds;                 // table_g values
   float* dtb = fg_lds + TH * TW;       // gradient accumulator
-  const int bg = blockIdx.x, g = bg % G;
+  // block = (b, g, query slice): B*G alone is 64 blocks on 256 CUs; the QS slices of the query range add their offset
+  // gradients with f32 atomics (doff is zeroed by the caller)
+  const int bg = blockIdx.x / QS, qs = blockIdx.x % QS, g = bg % G;
+  const int q_lo = (int)((long long)HW * qs / QS), q_hi = (int)((long long)HW * (qs + 1) / QS);
   for (int i = threadIdx.x; i < TH * TW; i += 256) { tbl[i] = table[i * G + g]; dtb[i] = 0.f; }
   __syncthreads();
   for (int k = threadIdx.x; k < HW; k += 256) {
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void fg_bias_bwd_kernel(const T* off, const fl
     const float off0 = ldf(off + ok), off1 = ldf(off + ok + 1);
     const int ik = k / Ww, jk = k % Ww;
     float d0 = 0.f, d1 = 0.f;
-    for (int q = 0; q < HW; ++q) {
+    for (int q = q_lo; q < q_hi; ++q) {
       const float go = ldf(dbias + ((long long)bg * HW + q) * HW + k);
       const float x = (float)(q / Ww - ik) - off1 + 1.f;
       const float y = (float)(q % Ww - jk) - off0 + 1.f;
@@ -145,7 +148,8 @@ __global__ __launch_bounds__(256) void fg_bias_bwd_kernel(const T* off, const fl
             atomicAdd(&dtb[(yy[e] - 1) * TW + (xx[e] - 1)], go * w[e]);
       }
     }
-    doff[ok] = d0; doff[ok + 1] = d1;
+    if (QS == 1) { doff[ok] = d0; doff[ok + 1] = d1; }
+    else { atomicAdd(doff + ok, d0); atomicAdd(doff + ok + 1, d1); }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < TH * TW; i += 256)
@@ -163,9 +167,13 @@ extern "C" int stj_fg_bias_fwd(const void* off, const float* table, float* bias,
 extern "C" int stj_fg_bias_bwd(const void* off, const float* table, const void* dbias, float* dtable, float* doff,
                                int B, int G, int Hh, int Ww, int dtype, hipStream_t stream) {
   if (B * G <= 0) return STJ_OK;
-  const int grid = B * G;
+  // doff (f32 [B,G,HW,2]) MUST BE ZERO on entry: query slices accumulate into it
+  int QS = 512 / (B * G);
+  if (QS < 1) QS = 1;
+  if (QS > 8) QS = 8;
+  const int grid = B * G * QS;
   const size_t lds = (size_t)(2 * Hh - 1) * (2 * Ww - 1) * 2 * sizeof(float);
-  if (dtype == STJ_BF16) hipLaunchKernelGGL(fg_bias_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, stream, (const bf16*)off, table, (const bf16*)dbias, dtable, doff, B, G, Hh, Ww);
-  else hipLaunchKernelGGL(fg_bias_bwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)off, table, (const float*)dbias, dtable, doff, B, G, Hh, Ww);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(fg_bias_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, stream, (const bf16*)off, table, (const bf16*)dbias, dtable, doff, B, G, Hh, Ww, QS);
+  else hipLaunchKernelGGL(fg_bias_bwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)off, table, (const float*)dbias, dtable, doff, B, G, Hh, Ww, QS);
   return stj_check_launch("stj_fg_bias_bwd");
 }

@@ -175,7 +175,6 @@ __global__ __launch_bounds__(64 * WinCfg<T>::WPB_BWD) void win_attn_bwd_kernel(c
   __shared__ __attribute__((aligned(16))) T s_p[WPB][WN * LP];
   __shared__ __attribute__((aligned(16))) T s_ds[WPB][WN * LP];
   __shared__ float s_tbl[WPB][(2 * WS - 1) * (2 * WS - 1)];
-  __shared__ float s_dtbl[WPB][(2 * WS - 1) * (2 * WS - 1)];
   __shared__ int s_tok[WPB][WN];
   __shared__ int s_lab[WPB][WN];
 
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(64 * WinCfg<T>::WPB_BWD) void win_attn_bwd_kernel(c
 
   s_tok[w][lane] = win_token(g.res, g.shift, wy, wx, lane);
   s_lab[w][lane] = win_label(g.res, g.shift, wy, wx, lane);
-  for (int i = lane; i < (2 * WS - 1) * (2 * WS - 1); i += 64) { s_tbl[w][i] = table[i * g.heads + h]; s_dtbl[w][i] = 0.f; }
+  for (int i = lane; i < (2 * WS - 1) * (2 * WS - 1); i += 64) s_tbl[w][i] = table[i * g.heads + h];
   __syncthreads();
   const T* base = qkv + (long long)b * g.res * g.res * 3 * C;
   win_load<T>(s_q[w], LQ, base, 3 * C, 0 * C + h * HD, s_tok[w], lane);
@@ -228,7 +227,6 @@ __global__ __launch_bounds__(64 * WinCfg<T>::WPB_BWD) void win_attn_bwd_kernel(c
         const float ds = p[i][j][r] * (dp[i][j][r] - d);
         stf(s_p[w] + row * LP + col, p[i][j][r]);
         stf(s_ds[w] + row * LP + col, ds);
-        if (live) atomicAdd(&s_dtbl[w][((row >> 3) - (col >> 3) + WS - 1) * (2 * WS - 1) + ((row & 7) - (col & 7) + WS - 1)], ds);
       }
     }
   }
@@ -241,40 +239,54 @@ __global__ __launch_bounds__(64 * WinCfg<T>::WPB_BWD) void win_attn_bwd_kernel(c
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
+  // operands are swapped in the MFMA (A = the d-side operand), so a lane ends up with 4 CONSECUTIVE d of one token:
+  // out^T[m = d 16 j + 4 (lane>>4) + r][n = token 16 i + (lane&15)] -> one 8/16-byte global store per fragment
   auto store = [&](int which, float mul) {
     if (!live) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      T* dst = dbase + (long long)s_tok[w][i * 16 + (lane & 15)] * 3 * C + which * C + h * HD + (lane >> 4) * 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = i * 16 + (lane >> 4) * 4 + r;
-        T* dst = dbase + (long long)s_tok[w][row] * 3 * C + which * C + h * HD;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) stf(dst + j * 16 + (lane & 15), acc[i][j][r] * mul);
+      for (int j = 0; j < 2; ++j) {
+        const float v[4] = {acc[i][j][0] * mul, acc[i][j][1] * mul, acc[i][j][2] * mul, acc[i][j][3] * mul};
+        st4(dst + j * 16, v);
       }
+    }
   };
-  // generic strided products: out[m][n] = sum_k Aop(m,k) * Bop(k,n)
-  auto prod = [&](const T* Am, int a_sr, int a_sk, const T* Bm, int b_sr, int b_sk) {
+  // out[tok][d] = sum_k Aop(tok,k) * Bop(k,d).  ATR: Aop is stored [k][tok] (read with the LDS transpose read), else [tok][k];
+  // Bop is always stored [k][d] (q, k, v, dO tiles are token-major) -> transpose read.  (v0 assembled every fragment from 8
+  // ds_read_u16: 288 2-byte LDS reads per lane for the three products.)
+  auto prod = [&](const T* Am, int lda, bool atr, const T* Bm) {
     for (int k0 = 0; k0 < WN; k0 += Mma<T>::KSTEP) {
       typename Mma<T>::Frag a[4], bb[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = Mma<T>::load_strided(Am, a_sr, a_sk, i * 16, k0, lane);
+      for (int i = 0; i < 4; ++i) a[i] = atr ? Mma<T>::load_tr(Am, lda, i * 16, k0, lane) : Mma<T>::load(Am, lda, i * 16, k0, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bb[j] = Mma<T>::load_strided(Bm, b_sr, b_sk, j * 16, k0, lane);
+      for (int j = 0; j < 2; ++j) bb[j] = Mma<T>::load_tr(Bm, LQ, j * 16, k0, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = Mma<T>::mma(a[i], bb[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma<T>::mma(bb[j], a[i], acc[i][j]);
     }
   };
-  // dV[key][d] = sum_q P[q][key] dO[q][d]     A(m=key,k=q) = P[q][key] -> sr=1, sk=LP ; B(n=d,k=q) = dO[q][d] -> sr=1, sk=LQ
-  zero(); prod(s_p[w], 1, LP, s_do[w], 1, LQ); store(2, 1.f);
-  // dQ[q][d] = scale * sum_key dS[q][key] K[key][d]   A(m=q,k=key) -> sr=LP, sk=1 ; B(n=d,k=key) = K[key][d] -> sr=1, sk=LQ
-  zero(); prod(s_ds[w], LP, 1, s_k[w], 1, LQ); store(0, scale);
-  // dK[key][d] = scale * sum_q dS[q][key] Q[q][d]     A(m=key,k=q) -> sr=1, sk=LP ; B(n=d,k=q) = Q[q][d] -> sr=1, sk=LQ
-  zero(); prod(s_ds[w], 1, LP, s_q[w], 1, LQ); store(1, scale);
-  if (live)
-    for (int i = lane; i < (2 * WS - 1) * (2 * WS - 1); i += 64) atomicAdd(dtable + i * g.heads + h, s_dtbl[w][i]);
+  // dV[key][d] = sum_q P[q][key] dO[q][d]             A(tok=key, k=q) = s_p [q][key]  -> transposed read
+  zero(); prod(s_p[w], LP, true, s_do[w]); store(2, 1.f);
+  // dQ[q][d] = scale * sum_key dS[q][key] K[key][d]   A(tok=q, k=key) = s_ds [q][key] -> plain read
+  zero(); prod(s_ds[w], LP, false, s_k[w]); store(0, scale);
+  // dK[key][d] = scale * sum_q dS[q][key] Q[q][d]     A(tok=key, k=q) = s_ds [q][key] -> transposed read
+  zero(); prod(s_ds[w], LP, true, s_q[w]); store(1, scale);
+  // relative-position-bias gradient: bin (dy, dx) collects dS[(ry,rx)][(ry-dy, rx-dx)] over the window.  Gathered from the
+  // stashed dS tile (<= 64 plain LDS reads per bin) instead of 4096 LDS atomics per window that serialised on 225 bins.
+  if (live) {
+    for (int bin = lane; bin < (2 * WS - 1) * (2 * WS - 1); bin += 64) {
+      const int dy = bin / (2 * WS - 1) - (WS - 1), dx = bin % (2 * WS - 1) - (WS - 1);
+      float sacc = 0.f;
+      for (int ry = max(0, dy); ry <= min(WS - 1, WS - 1 + dy); ++ry)
+        for (int rx = max(0, dx); rx <= min(WS - 1, WS - 1 + dx); ++rx)
+          sacc += ldf(s_ds[w] + (ry * WS + rx) * LP + (ry - dy) * WS + (rx - dx));
+      atomicAdd(dtable + bin * g.heads + h, sacc);
+    }
+  }
 }
 
 extern "C" int stj_win_attn_fwd(const void* qkv, const float* table, void* out, int B, int res, int heads, int shift,

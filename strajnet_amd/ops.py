@@ -509,7 +509,7 @@ class _FgBias(torch.autograd.Function):
         (off,) = ctx.saved_tensors
         B, G, Hh, Ww = ctx.geo
         dbias = dbias.contiguous().to(off.dtype)
-        doff = torch.empty(off.shape, dtype=torch.float32, device=off.device)
+        doff = torch.zeros(off.shape, dtype=torch.float32, device=off.device)     # accumulated by the kernel's query slices
         call('stj_fg_bias_bwd', _p(off), _p(ctx.pt.master), _p(dbias), _p(ctx.pt.grad), _p(doff), B, G, Hh, Ww, _dt(off), _st())
         return doff.to(off.dtype), None, None, None, None
 
