@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * WinCfg<T>::WPB) void win_attn_fwd_kernel(const
   // per wave: Q|K region (reused for P), Vt, table, token ids, labels
   constexpr int QK_ELEMS = (2 * WN * LQ > WN * LP) ? 2 * WN * LQ : WN * LP;
   __shared__ __attribute__((aligned(16))) T s_qk[WPB][QK_ELEMS];
-  __shared__ __attribute__((aligned(16))) T s_vt[WPB][HD * LP];
+  __shared__ __attribute__((aligned(16))) T s_vt[WPB][WN * LQ];
   __shared__ float s_tbl[WPB][(2 * WS - 1) * (2 * WS - 1)];
   __shared__ int s_tok[WPB][WN];
   __shared__ int s_lab[WPB][WN];
@@ -112,17 +112,7 @@ __global__ __launch_bounds__(64 * WinCfg<T>::WPB) void win_attn_fwd_kernel(const
   const T* base = qkv + (long long)b * g.res * g.res * 3 * C;
   win_load<T>(Qs, LQ, base, 3 * C, 0 * C + h * HD, s_tok[w], lane);
   win_load<T>(Ks, LQ, base, 3 * C, 1 * C + h * HD, s_tok[w], lane);
-  {  // V transposed: Vt[d][tok]
-    constexpr int VN = Vec<T>::N;
-    constexpr int CPR = HD / VN;
-    for (int i = lane; i < WN * CPR; i += 64) {
-      int t = i / CPR, c = (i % CPR) * VN;
-      __attribute__((aligned(16))) T tmp[VN];
-      *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(base + (long long)s_tok[w][t] * 3 * C + 2 * C + h * HD + c);
-#pragma unroll
-      for (int e = 0; e < VN; ++e) Vt[(c + e) * LP + t] = tmp[e];
-    }
-  }
+  win_load<T>(Vt, LQ, base, 3 * C, 2 * C + h * HD, s_tok[w], lane);     // V token-major [key][d]; transposed in the fragment read
   __syncthreads();
 
   f32x4 s[4][4];
@@ -147,18 +137,30 @@ __global__ __launch_bounds__(64 * WinCfg<T>::WPB) void win_attn_fwd_kernel(const
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) o[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  mma_tile<T, 4, 2>(Ps, LP, Vt, LP, WN, lane, o);
-  if (live) {
-    T* ob = out + (long long)b * g.res * g.res * C + h * HD;
+  // O^T[m = d][n = query] = sum_key V[key][d] P[query][key]: V^T fragments by LDS transpose read, P fragments plain; the lane
+  // then owns 4 consecutive d of query (16 i + lane&15) -> one vector store per fragment
+  for (int k0 = 0; k0 < WN; k0 += Mma<T>::KSTEP) {
+    typename Mma<T>::Frag pf[4], vf[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[i] = Mma<T>::load(Ps, LP, i * 16, k0, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) vf[j] = Mma<T>::load_tr(Vt, LQ, j * 16, k0, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = i * 16 + (lane >> 4) * 4 + r;
-        T* dst = ob + (long long)s_tok[w][row] * C;
+      for (int j = 0; j < 2; ++j) o[i][j] = Mma<T>::mma(vf[j], pf[i], o[i][j]);
+  }
+  if (live) {
+    T* ob = out + (long long)b * g.res * g.res * C + h * HD + (lane >> 4) * 4;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) stf(dst + j * 16 + (lane & 15), o[i][j][r]);
+    for (int i = 0; i < 4; ++i) {
+      T* dst = ob + (long long)s_tok[w][i * 16 + (lane & 15)] * C;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float v[4] = {o[i][j][0], o[i][j][1], o[i][j][2], o[i][j][3]};
+        st4(dst + j * 16, v);
       }
+    }
   }
 }
 
