@@ -207,8 +207,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         if (row >= p.M || col >= p.N) continue;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = apply_act(Cs[r * LDC + c + e] + bias_s[c + e], p.act);
+        for (int e = 0; e < 4; ++e) v[e] = Cs[r * LDC + c + e] + bias_s[c + e];
+        if (p.act == ACT_ELU) {          // uniform branch, hoisted out of the per-element work
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = elu_f(v[e]);
+        } else if (p.act == ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
         }
         float* dst = Cf + (long long)row * p.ldc + col;
         if (p.vecC && col + 4 <= p.N && !res) {
@@ -226,8 +231,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         if (row >= p.M || col >= p.N) continue;
         float v[VN];
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-          v[e] = apply_act(Cs[r * LDC + c + e] + bias_s[c + e], p.act);
+        for (int e = 0; e < VN; ++e) v[e] = Cs[r * LDC + c + e] + bias_s[c + e];
+        if (p.act == ACT_ELU) {          // uniform branch, hoisted out of the per-element work
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[e] = sizeof(T) == 2 ? elu_bf(v[e]) : elu_f(v[e]);
+        } else if (p.act == ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[e] = gelu_f(v[e]);
         }
         T* dst = Ct + (long long)row * p.ldc + col;
         if (p.vecC && col + VN <= p.N) {

@@ -47,57 +47,81 @@ extern "C" int stj_cast(const void* src, int sdtype, void* dst, int ddtype, long
 // op: 1 gelu (saved = x), 2 elu (saved = y), 3 tanh*scale (saved = y)
 enum { U_GELU = 1, U_ELU = 2, U_TANHS = 3 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void unary_fwd_kernel(const T* x, T* y, long long n, int op, float p0) {
+// The op is a template parameter (no per-element selection) and the bf16 kernels use a v_exp_f32 based tanh (abs error ~2e-7,
+// two decades below bf16 resolution); the f32 parity mode keeps libm tanhf / expm1f.
+template <bool FAST> __device__ __forceinline__ float tanh_sel(float u) {
+  if constexpr (FAST) {
+    const float e = __builtin_amdgcn_exp2f(fminf(u, 15.f) * 2.885390081777927f);       // e^(2u), clamped: tanh(15) == 1 in f32
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  } else return tanhf(u);
+}
+template <int OP, bool FAST> __device__ __forceinline__ float unary_f(float x, float p0) {
+  if constexpr (OP == U_GELU) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.f + tanh_sel<FAST>(u));
+  } else if constexpr (OP == U_ELU) return FAST ? elu_bf(x) : elu_f(x);
+  else return tanh_sel<FAST>(x) * p0;
+}
+template <int OP, bool FAST> __device__ __forceinline__ float unary_g(float dy, float s, float p0) {
+  if constexpr (OP == U_GELU) {
+    const float k = 0.7978845608028654f, x2 = s * s;
+    const float t = tanh_sel<FAST>(k * (s + 0.044715f * s * x2));
+    return dy * (0.5f * (1.f + t) + 0.5f * s * (1.f - t * t) * (k * (1.f + 3.f * 0.044715f * x2)));
+  } else if constexpr (OP == U_ELU) return s > 0.f ? dy : dy * (s + 1.f);
+  else { const float t = s / p0; return dy * p0 * (1.f - t * t); }
+}
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void unary_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float p0) {
   constexpr int VN = Vec<T>::N;
+  constexpr bool FAST = sizeof(T) == 2;
   const long long nv = n / VN;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += gridDim.x * 256ll) {
     float v[VN];
     ld16(x + i * VN, v);
 #pragma unroll
-    for (int e = 0; e < VN; ++e) v[e] = op == U_GELU ? gelu_f(v[e]) : (op == U_ELU ? elu_f(v[e]) : tanhf(v[e]) * p0);
+    for (int e = 0; e < VN; ++e) v[e] = unary_f<OP, FAST>(v[e], p0);
     st16(y + i * VN, v);
   }
-  for (long long i = nv * VN + blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
-    float v = ldf(x + i);
-    stf(y + i, op == U_GELU ? gelu_f(v) : (op == U_ELU ? elu_f(v) : tanhf(v) * p0));
-  }
+  for (long long i = nv * VN + blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) stf(y + i, unary_f<OP, FAST>(ldf(x + i), p0));
 }
-__device__ __forceinline__ float unary_grad(float dy, float s, int op, float p0) {
-  if (op == U_GELU) return dy * gelu_grad_f(s);
-  if (op == U_ELU) return s > 0.f ? dy : dy * (s + 1.f);
-  float t = s / p0;                 // tanh
-  return dy * p0 * (1.f - t * t);
-}
-template <typename T>
-__global__ __launch_bounds__(256) void unary_bwd_kernel(const T* dy, const T* s, T* dx, long long n, int op, float p0) {
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void unary_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s, T* __restrict__ dx, long long n, float p0) {
   constexpr int VN = Vec<T>::N;
+  constexpr bool FAST = sizeof(T) == 2;
   const long long nv = n / VN;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += gridDim.x * 256ll) {
     float a[VN], b[VN];
     ld16(dy + i * VN, a);
     ld16(s + i * VN, b);
 #pragma unroll
-    for (int e = 0; e < VN; ++e) a[e] = unary_grad(a[e], b[e], op, p0);
+    for (int e = 0; e < VN; ++e) a[e] = unary_g<OP, FAST>(a[e], b[e], p0);
     st16(dx + i * VN, a);
   }
   for (long long i = nv * VN + blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll)
-    stf(dx + i, unary_grad(ldf(dy + i), ldf(s + i), op, p0));
+    stf(dx + i, unary_g<OP, FAST>(ldf(dy + i), ldf(s + i), p0));
 }
+#define UNARY_LAUNCH(KERN, TT, ...)                                                                              \
+  do {                                                                                                           \
+    if (op == U_GELU) hipLaunchKernelGGL((KERN<TT, U_GELU>), dim3(g), dim3(256), 0, stream, __VA_ARGS__);        \
+    else if (op == U_ELU) hipLaunchKernelGGL((KERN<TT, U_ELU>), dim3(g), dim3(256), 0, stream, __VA_ARGS__);     \
+    else hipLaunchKernelGGL((KERN<TT, U_TANHS>), dim3(g), dim3(256), 0, stream, __VA_ARGS__);                    \
+  } while (0)
 extern "C" int stj_unary_fwd(const void* x, void* y, long long n, int op, float p0, int dtype, hipStream_t stream) {
   if (n <= 0) return STJ_OK;
+  if (op < U_GELU || op > U_TANHS) { stj_set_error("stj_unary_fwd: bad op %d", op); return STJ_EINVAL; }
   if (((uintptr_t)x | (uintptr_t)y) & 15) { stj_set_error("stj_unary_fwd: pointers must be 16-byte aligned"); return STJ_EINVAL; }
-  int g = ew_grid(n / 4);
-  if (dtype == STJ_BF16) hipLaunchKernelGGL(unary_fwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n, op, p0);
-  else hipLaunchKernelGGL(unary_fwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, n, op, p0);
+  int g = ew_grid(n / 8);
+  if (dtype == STJ_BF16) UNARY_LAUNCH(unary_fwd_kernel, bf16, (const bf16*)x, (bf16*)y, n, p0);
+  else UNARY_LAUNCH(unary_fwd_kernel, float, (const float*)x, (float*)y, n, p0);
   return stj_check_launch("stj_unary_fwd");
 }
 extern "C" int stj_unary_bwd(const void* dy, const void* saved, void* dx, long long n, int op, float p0, int dtype, hipStream_t stream) {
   if (n <= 0) return STJ_OK;
+  if (op < U_GELU || op > U_TANHS) { stj_set_error("stj_unary_bwd: bad op %d", op); return STJ_EINVAL; }
   if (((uintptr_t)dy | (uintptr_t)saved | (uintptr_t)dx) & 15) { stj_set_error("stj_unary_bwd: pointers must be 16-byte aligned"); return STJ_EINVAL; }
-  int g = ew_grid(n / 4);
-  if (dtype == STJ_BF16) hipLaunchKernelGGL(unary_bwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)saved, (bf16*)dx, n, op, p0);
-  else hipLaunchKernelGGL(unary_bwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)dy, (const float*)saved, (float*)dx, n, op, p0);
+  int g = ew_grid(n / 8);
+  if (dtype == STJ_BF16) UNARY_LAUNCH(unary_bwd_kernel, bf16, (const bf16*)dy, (const bf16*)saved, (bf16*)dx, n, p0);
+  else UNARY_LAUNCH(unary_bwd_kernel, float, (const float*)dy, (const float*)saved, (float*)dx, n, p0);
   return stj_check_launch("stj_unary_bwd");
 }
 
