@@ -66,23 +66,25 @@ __global__ __launch_bounds__(256) void auc_hist_kernel(const float* gt_obs, cons
   for (int i = threadIdx.x; i < 202; i += 256)
     if (sh[i]) atomicAdd(hist + k * 202 + i, sh[i]);
 }
-// one thread per waypoint: Keras interpolate_pr_auc from the histogram; gate[k] = auc > 0 ; auc_out optional
-__global__ void auc_gate_kernel(const int* hist, float* gate, float* auc_out) {
-  const int k = threadIdx.x;
-  if (k >= NWP) return;
-  const int* hn = hist + k * 202;
-  const int* hp = hn + 101;
-  double tp[100], pp[100];
+// one 128-thread block per waypoint, thread i = threshold i: Keras interpolate_pr_auc from the histogram; gate[k] = auc > 0;
+// auc_out optional.  (v0 ran the whole recurrence in ONE thread per waypoint with 1.6 KB of f64 scratch arrays: 82 us.)
+__global__ __launch_bounds__(128) void auc_gate_kernel(const int* hist, float* gate, float* auc_out) {
+  __shared__ int hn[101], hp[101];
+  __shared__ double tp[100], pp[100], part[128];
+  const int k = blockIdx.x, i = threadIdx.x;
+  if (i <= 100) { hn[i] = hist[k * 202 + i]; hp[i] = hist[k * 202 + 101 + i]; }
+  __syncthreads();
   double totp = 0, totn = 0;
-  for (int i = 0; i <= 100; ++i) { totp += hp[i]; totn += hn[i]; }
-  double cp = 0, cn = 0;
-  for (int i = 0; i < 100; ++i) {      // positive at threshold i <=> bucket > i
-    cp += hp[i]; cn += hn[i];
+  for (int j = 0; j <= 100; ++j) { totp += hp[j]; totn += hn[j]; }
+  if (i < 100) {                       // positive at threshold i <=> bucket > i
+    double cp = 0, cn = 0;
+    for (int j = 0; j <= i; ++j) { cp += hp[j]; cn += hn[j]; }
     tp[i] = totp - cp;
     pp[i] = tp[i] + (totn - cn);
   }
-  double auc = 0;
-  for (int i = 0; i < 99; ++i) {
+  __syncthreads();
+  double term = 0;
+  if (i < 99) {
     const double dtp = tp[i] - tp[i + 1], dp = pp[i] - pp[i + 1];
     const double den = dp > 0 ? dp : 0;
     const double slope = den != 0 ? dtp / den : 0;
@@ -90,10 +92,16 @@ __global__ void auc_gate_kernel(const int* hist, float* gate, float* auc_out) {
     double ratio = 1.0;
     if (pp[i] > 0 && pp[i + 1] > 0) ratio = pp[i] / pp[i + 1];
     const double d2 = totp > 0 ? totp : 0;    // tp + fn = all positives
-    auc += d2 != 0 ? slope * (dtp + icpt * log(ratio)) / d2 : 0;
+    term = d2 != 0 ? slope * (dtp + icpt * log(ratio)) / d2 : 0;
   }
-  gate[k] = ((1.0 - auc) < 1.0) ? 1.f : 0.f;
-  if (auc_out) auc_out[k] = (float)auc;
+  part[i] = term;
+  __syncthreads();
+  if (i == 0) {
+    double auc = 0;
+    for (int j = 0; j < 99; ++j) auc += part[j];          // same summation order as the serial recurrence
+    gate[k] = ((1.0 - auc) < 1.0) ? 1.f : 0.f;
+    if (auc_out) auc_out[k] = (float)auc;
+  }
 }
 
 // ---- forward sums -------------------------------------------------------------------------------------
@@ -223,7 +231,7 @@ extern "C" int stj_loss_auc_gate(const float* gt_obs, const float* gt_occ, const
   const long long npix = (long long)B * H * W;
   const int gx = (int)min(256ll, (npix + 255) / 256);
   hipLaunchKernelGGL(auc_hist_kernel, dim3(gx, NWP), dim3(256), 0, stream, gt_obs, gt_occ, gt_flow, origin, hist, B, H, W);
-  hipLaunchKernelGGL(auc_gate_kernel, dim3(1), dim3(64), 0, stream, hist, gate, auc_out);
+  hipLaunchKernelGGL(auc_gate_kernel, dim3(NWP), dim3(128), 0, stream, hist, gate, auc_out);
   return stj_check_launch("stj_loss_auc_gate");
 }
 // sums: f32[40] scratch, MUST BE ZERO on entry; loss f32[4]; coef f32[32]
