@@ -35,14 +35,17 @@ int stj_abi_version(void);
  * Conv3D(8,1,1) skips (modules.py:693-717,750-765) and all their dgrad/wgrad (tape.gradient, train.py:223).
  * Element strides: A(m,k) at sAm*m + sAk*k (+ batch), B(k,n) at sBk*k + sBn*n; C row-major with ldc.
  * c_f32: C is f32; accumulate: C += (f32 atomics; splitk may be >1, 0 = auto); colsum (optional): colsum[z][n] +=
- * sum_k B[z](k,n) (the bias gradient belonging to dW = x^T dY), addressed with the bias batch strides. */
+ * sum_k B[z](k,n) (the bias gradient belonging to dW = x^T dY), addressed with the bias batch strides.
+ * nkb >= 1 K segments: the contraction also runs over nkb segments of A / B that lie sAkb / sBkb elements apart (the input
+ * gradient of a layer applied with 8 per-waypoint weight sets to ONE shared input is a single GEMM with K' = 8 K). */
 int stj_gemm(const void* A, const void* B, void* C, const float* bias, const void* res, float* colsum,
              int M, int N, int K, int nb1, int nb2,
              long long sAb1, long long sAb2, long long sAm, long long sAk,
              long long sBb1, long long sBb2, long long sBk, long long sBn,
              long long sCb1, long long sCb2, long long ldc,
              long long sBias1, long long sBias2, long long sRes1, long long sRes2, long long ldres,
-             int act, float alpha, int dtype, int c_f32, int accumulate, int splitk, hipStream_t stream);
+             int act, float alpha, int dtype, int c_f32, int accumulate, int splitk,
+             int nkb, long long sAkb, long long sBkb, hipStream_t stream);
 /* out[n] += sum_m X[m,n]  (bias gradients of the conv heads). */
 int stj_colsum(const void* X, float* out, int M, int N, long long ld, int dtype, hipStream_t stream);
 /* f32 <-> bf16 copy (bf16 shadow of the flat parameter buffer). */

@@ -15,7 +15,7 @@ SIGNATURES = {
     'stj_abi_version': [],
     'stj_gemm': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci,
                  cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl,
-                 ci, cf, ci, ci, ci, ci, vp],
+                 ci, cf, ci, ci, ci, ci, ci, cl, cl, vp],
     'stj_colsum': [vp, vp, ci, ci, cl, ci, vp],
     'stj_cast': [vp, ci, vp, ci, cl, vp],
     'stj_rng_advance': [vp, vp],

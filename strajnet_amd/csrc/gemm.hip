@@ -23,6 +23,10 @@ struct GemmArgs {
   int act, c_f32, accumulate, splitk;
   int vecA, vecB, vecC, vecR;   // 16-byte vector paths legal for A / B staging, C stores, residual loads
   float alpha;
+  // K segments: the contraction runs over nkb segments of K elements; segment s of A / B starts sAkb / sBkb elements further.
+  // (sum over the 8 waypoint weight sets of a shared input's gradient = ONE GEMM with K' = 8 K instead of 8 atomically
+  // accumulated ones)
+  int nkb; long long sAkb, sBkb;
 };
 
 template <typename T> struct PadT;            // row padding of the un-transposed image: bank-conflict-free strided reads
@@ -110,7 +114,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int z = blockIdx.y / p.splitk, ks = blockIdx.y % p.splitk;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const int ktiles = (p.K + BK - 1) / BK;
+  const int ktiles_seg = (p.K + BK - 1) / BK;       // k-tiles per K segment
+  const int ktiles = ktiles_seg * p.nkb;
   const int kt_per = (ktiles + p.splitk - 1) / p.splitk;
   const int kt0 = ks * kt_per, kt1 = min(ktiles, kt0 + kt_per);
   if (kt0 >= kt1 && (p.accumulate || ks != 0)) return;
@@ -132,19 +137,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   typedef Stage<T, BN, BK, TB> SB;
   uint4 ra[SA::NCH], rb[SB::NCH];
   const long long a_sR = TA ? 1 : p.sAm, b_sR = TB ? 1 : p.sBn;
-  if (kt0 < kt1) {
-    SA::load(ra, A + (long long)kt0 * BK * p.sAk, a_sR, p.sAk, p.M - m0, p.K - kt0 * BK, p.vecA, tid);
-    SB::load(rb, B + (long long)kt0 * BK * p.sBk, b_sR, p.sBk, p.N - n0, p.K - kt0 * BK, p.vecB, tid);
-  }
+  auto issue = [&](int kt) {
+    const int seg = kt / ktiles_seg, k1 = (kt - seg * ktiles_seg) * BK;
+    SA::load(ra, A + seg * p.sAkb + (long long)k1 * p.sAk, a_sR, p.sAk, p.M - m0, p.K - k1, p.vecA, tid);
+    SB::load(rb, B + seg * p.sBkb + (long long)k1 * p.sBk, b_sR, p.sBk, p.N - n0, p.K - k1, p.vecB, tid);
+  };
+  if (kt0 < kt1) issue(kt0);
   for (int kt = kt0; kt < kt1; ++kt) {
     SA::template commit<TA ? LDTA : LD>(As, ra, tid);
     SB::template commit<TB ? LDTB : LD>(Bs, rb, tid);
     __syncthreads();
-    if (kt + 1 < kt1) {                 // next tile's global loads overlap this tile's MFMAs
-      const int k1 = (kt + 1) * BK;
-      SA::load(ra, A + (long long)k1 * p.sAk, a_sR, p.sAk, p.M - m0, p.K - k1, p.vecA, tid);
-      SB::load(rb, B + (long long)k1 * p.sBk, b_sR, p.sBk, p.N - n0, p.K - k1, p.vecB, tid);
-    }
+    if (kt + 1 < kt1) issue(kt + 1);    // next tile's global loads overlap this tile's MFMAs
     if (do_cs && tid < BN) {           // fused bias gradient: column sums of the B (= dY) tile over this block's k range
       float s = 0.f;
       if constexpr (TB) { for (int k = 0; k < BK; ++k) s += ldf(Bs + k * LDTB + tid); }
@@ -386,7 +389,7 @@ static bool linear_rs_try(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   static int enabled = -1;
   static int rs_min_m = 16384;     // measured: wins at 32768 tokens (1.3-1.7x), loses at <= 8192 (too few 128-row blocks for 256 CUs)
   if (enabled < 0) { const char* e = getenv("STJ_NO_RS"); enabled = !(e && atoi(e)); e = getenv("STJ_RS_MIN_M"); if (e) rs_min_m = atoi(e); }
-  if (!enabled || ta || p.c_f32 || p.accumulate || p.splitk != 1 || p.colsum) return false;
+  if (!enabled || ta || p.c_f32 || p.accumulate || p.splitk != 1 || p.colsum || p.nkb != 1) return false;
   if (p.M < rs_min_m || p.K % 32 || p.N % 8 || p.sAk != 1 || !p.vecA || !p.vecB || !p.vecC) return false;
   if (p.act != ACT_NONE && p.act != ACT_ELU) return false;
   if (p.res && (!p.vecR)) return false;
@@ -421,7 +424,7 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   const long long nb = (long long)p.nb1 * p.nb2;
   const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nb;
   const long long tiles64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * nb;
-  const int ktiles = (p.K + BK - 1) / BK;
+  const int ktiles = ((p.K + BK - 1) / BK) * p.nkb;
   // Tile choice.  The hot-path GEMMs are skinny (K <= 1536, mostly 96..384) and latency / memory-parallelism bound, not
   // MFMA bound: measured on every Dense shape of the model, 64x64 tiles (4x the workgroups in flight) beat 128x128 by
   // 1.3-1.8x (profiles/r01_c_gemm_tiles.txt), so 64x64 is the default; 128x128 only pays for genuinely large problems.
@@ -455,9 +458,10 @@ extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias
                         long long sBb1, long long sBb2, long long sBk, long long sBn,
                         long long sCb1, long long sCb2, long long ldc,
                         long long sBias1, long long sBias2, long long sRes1, long long sRes2, long long ldres,
-                        int act, float alpha, int dtype, int c_f32, int accumulate, int splitk, hipStream_t stream) {
+                        int act, float alpha, int dtype, int c_f32, int accumulate, int splitk,
+                        int nkb, long long sAkb, long long sBkb, hipStream_t stream) {
   if (M <= 0 || N <= 0 || nb1 <= 0 || nb2 <= 0) return STJ_OK;
-  if (K < 0 || splitk < 0) { stj_set_error("stj_gemm: bad K/splitk"); return STJ_EINVAL; }
+  if (K < 0 || splitk < 0 || nkb < 1) { stj_set_error("stj_gemm: bad K/splitk/nkb"); return STJ_EINVAL; }
   if (accumulate && !c_f32) { stj_set_error("stj_gemm: accumulate requires f32 output"); return STJ_EINVAL; }
   if (splitk != 1 && !accumulate) { stj_set_error("stj_gemm: splitk != 1 requires accumulate"); return STJ_EINVAL; }
   if (colsum && (!accumulate || bias)) { stj_set_error("stj_gemm: colsum needs accumulate and no bias"); return STJ_EINVAL; }
@@ -471,6 +475,7 @@ extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias
   p.sCb1 = sCb1; p.sCb2 = sCb2; p.ldc = ldc;
   p.sBias1 = sBias1; p.sBias2 = sBias2; p.sRes1 = sRes1; p.sRes2 = sRes2; p.ldres = ldres;
   p.act = act; p.c_f32 = c_f32; p.accumulate = accumulate; p.splitk = splitk; p.alpha = alpha;
+  p.nkb = nkb; p.sAkb = sAkb; p.sBkb = sBkb;
   const long long es = dtype == STJ_BF16 ? 2 : 4;
   auto al = [&](const void* ptr, long long esz, long long s0, long long s1, long long s2) {
     return ((uintptr_t)ptr % 16 == 0) && ((s0 * esz) % 16 == 0) && ((s1 * esz) % 16 == 0) && ((s2 * esz) % 16 == 0);
@@ -478,6 +483,7 @@ extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias
   const bool ta = (sAm == 1 && sAk != 1), tb = (sBn == 1 && sBk != 1);
   p.vecA = ta ? al(A, es, sAk, sAb1, sAb2) : (sAk == 1 ? al(A, es, sAm, sAb1, sAb2) : 0);
   p.vecB = tb ? al(B, es, sBk, sBb1, sBb2) : (sBk == 1 ? al(B, es, sBn, sBb1, sBb2) : 0);
+  if (nkb > 1) { p.vecA = p.vecA && (sAkb * es) % 16 == 0; p.vecB = p.vecB && (sBkb * es) % 16 == 0; }
   p.vecC = al(C, c_f32 ? 4 : es, ldc, sCb1, sCb2);
   p.vecR = res ? al(res, es, ldres, sRes1, sRes2) : 0;
   if (dtype == STJ_BF16) return launch_gemm<bf16>(p, ta, tb, stream);

@@ -104,20 +104,22 @@ class Param:
 
 
 def gemm(A, B, C, M, N, K, sA, sB, sC, dt, bias=None, sBias=(0, 0), res=None, sRes=(0, 0, 0), nb=(1, 1),
-         act=ACT_NONE, alpha=1.0, c_f32=0, accumulate=0, splitk=1, colsum=None):
-    """sA = (b1, b2, m, k) element strides; sB = (b1, b2, k, n); sC = (b1, b2, ldc); sRes = (b1, b2, ld)."""
+         act=ACT_NONE, alpha=1.0, c_f32=0, accumulate=0, splitk=1, colsum=None, kseg=(1, 0, 0)):
+    """sA = (b1, b2, m, k) element strides; sB = (b1, b2, k, n); sC = (b1, b2, ldc); sRes = (b1, b2, ld);
+    kseg = (n, sA, sB): the contraction also runs over n K-segments of A / B that lie sA / sB elements apart."""
     if _PROF is not None and PROF_GEMM:      # per-shape GEMM timing (tools/bench --gemm-trace); off in the normal kernel-timing pass
         key = f'gemm[{M}x{N}x{K} b{nb[0] * nb[1]} {"T" if sA[3] != 1 else "N"}{"T" if sB[3] != 1 else "N"}{" f32out" if c_f32 else ""}]'
         with _timed(key, 2.0 * M * N * K * nb[0] * nb[1]):
-            _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum)
+            _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum, kseg)
         return
-    _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum)
+    _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum, kseg)
 
 
-def _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum):
+def _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum, kseg):
     call('stj_gemm', _p(A), _p(B), _p(C), _p(bias), _p(res), _p(colsum), M, N, K, nb[0], nb[1],
          sA[0], sA[1], sA[2], sA[3], sB[0], sB[1], sB[2], sB[3], sC[0], sC[1], sC[2],
-         sBias[0], sBias[1], sRes[0], sRes[1], sRes[2], act, float(alpha), dt, c_f32, accumulate, splitk, _st())
+         sBias[0], sBias[1], sRes[0], sRes[1], sRes[2], act, float(alpha), dt, c_f32, accumulate, splitk,
+         kseg[0], kseg[1], kseg[2], _st())
 
 
 def _splitk(M_out, N_out, Kdim):
@@ -237,7 +239,11 @@ class _LinearZ(torch.autograd.Function):
             dpre = dy
         dx = None
         if ctx.needs_input_grad[0]:
-            if shared_x:       # dx[r,:] = sum_z dpre[z,r,:] W_z^T : all z accumulate (f32 atomics) into one buffer
+            if shared_x and R >= 4096:
+                # dx[r,:] = sum_z dpre[z,r,:] W_z^T : ONE GEMM whose contraction runs over the Z segments (z, n) -- no atomics
+                dx = torch.empty(xshape, dtype=x.dtype, device=x.device)
+                gemm(dpre, ctx.w0, dx, R, K, N, (0, 0, N, 1), (0, 0, 1, N), (0, 0, K), dt, kseg=(Z, R * N, wstride))
+            elif shared_x:     # few rows: Z independent launches-in-one fill the GPU better; all z accumulate with f32 atomics
                 acc = torch.zeros((R, K), dtype=torch.float32, device=x.device)
                 gemm(dpre, ctx.w0, acc, R, K, N, (0, R * N, N, 1), (0, wstride, 1, N), (0, 0, K), dt, nb=(1, Z), c_f32=1, accumulate=1)
                 dx = acc.to(x.dtype).view(xshape)
