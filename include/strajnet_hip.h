@@ -133,6 +133,15 @@ int stj_loss_fwd(const float* logits, const float* gt_obs, const float* gt_occ, 
 int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                  const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int use_warp, hipStream_t stream);
 
+/* Evaluation metrics (occu_metric.py:26-140, evaluated every train / validation step: train.py:243-249,280-282): observed and
+ * occluded PR-AUC + soft IoU, flow EPE, flow-warped occupancy AUC + IoU, means over the 8 waypoints.  pred [B,H,W,32]
+ * (channel 4k+{obs,occ,flow_x,flow_y}); pred_is_logits: sigmoid is applied to the occupancy channels (train.py:142-154).
+ * hist int[8*3*202] and sums f32[8*11] MUST BE ZERO on entry; auc f32[24] scratch; out f32[7] in the order of the proto
+ * fields at occu_metric.py:130-139. */
+int stj_metrics(const float* pred, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
+                int* hist, float* sums, float* auc, float* out, int B, int H, int W, int pred_is_logits, int use_warp,
+                hipStream_t stream);
+
 /* Training-time randomness.  Keras Dropout / tfa-MHA attention dropout (trajNet.py:33,71,75,77,195,209,211) and DropPath
  * (modules.py:137-151) share one rule: y = [res +] keep(draw) * x / (1 - p), keep = U[0,1) >= p, draw(i) = i / inner
  * (inner = 1: per element; inner = elements per sample: DropPath with p = drop_prob).  U comes from Philox-4x32-10 keyed by

@@ -884,3 +884,49 @@ def ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin_flow, ogm_weight=1000.
     if return_gates:
         return out, f_c
     return out
+
+
+# --------------------------------------------------------------------------- #
+# evaluation metrics (occu_metric.py:26-317)
+# --------------------------------------------------------------------------- #
+def soft_iou(true_occ, pred_occ):
+    """_compute_occupancy_soft_iou (occu_metric.py:177-201): means, divide_no_nan."""
+    t, p = np.asarray(true_occ, F64).reshape(-1), np.asarray(pred_occ, F64).reshape(-1)
+    inter = (p * t).mean()
+    den = p.mean() + t.mean() - inter
+    return float(inter / den) if den != 0 else 0.0
+
+
+def flow_epe(true_flow, pred_flow):
+    """_compute_flow_epe (occu_metric.py:204-252)."""
+    tf_, pf = np.asarray(true_flow, F64), np.asarray(pred_flow, F64)
+    exists = ((tf_[..., 0:1] != 0) | (tf_[..., 1:2] != 0)).astype(F64)
+    epe = np.sqrt((((tf_ - pf) * exists) ** 2).sum(-1))
+    return float(epe.sum() / exists.sum()) if exists.sum() != 0 else 0.0
+
+
+def occupancy_flow_metrics(model_out, gt_obs, gt_occ, gt_flow, origin_flow, pred_is_logits=True, no_warp=False):
+    """compute_occupancy_flow_metrics (occu_metric.py:26-140) on the packed tensors: model_out [B,H,W,32] (channel 4k+{obs,occ,
+    flow_x,flow_y}, train.py:105-123; occupancy logits get tf.sigmoid as in train.py:142-154), GT [B,8,H,W,{1,1,2,1}].
+    Returns the 7 means in the order of the proto fields set at occu_metric.py:130-139."""
+    y = np.asarray(model_out, F64)
+    B, H, W, _ = y.shape
+    ident = np.stack(np.meshgrid(np.arange(W, dtype=F64), np.arange(H, dtype=F64), indexing='xy'), -1)[None]     # (x, y)
+    out = {k: [] for k in ('obs_auc', 'occ_auc', 'obs_iou', 'occ_iou', 'epe', 'warp_auc', 'warp_iou')}
+    for k in range(8):
+        po, pc, pf = y[..., 4 * k:4 * k + 1], y[..., 4 * k + 1:4 * k + 2], y[..., 4 * k + 2:4 * k + 4]
+        if pred_is_logits:
+            po, pc = 1.0 / (1.0 + np.exp(-po)), 1.0 / (1.0 + np.exp(-pc))
+        to, tc, tfl, org = (np.asarray(a, F64)[:, k] for a in (gt_obs, gt_occ, gt_flow, origin_flow))
+        out['obs_auc'].append(keras_auc_pr(to, po)); out['obs_iou'].append(soft_iou(to, po))
+        out['occ_auc'].append(keras_auc_pr(tc, pc)); out['occ_iou'].append(soft_iou(tc, pc))
+        out['epe'].append(flow_epe(tfl, pf))
+        if not no_warp:
+            true_all = np.clip(to + tc, 0, 1)
+            pred_all = np.clip(po + pc, 0, 1)
+            warped = sample(org, ident + pf)                         # occu_metric.py:289-311, pixel_type=0
+            grounded = pred_all * warped
+            out['warp_auc'].append(keras_auc_pr(grounded, true_all))   # argument order as at occu_metric.py:120-123
+            out['warp_iou'].append(soft_iou(grounded, true_all))
+    mean = lambda v: float(np.mean(v)) if v else 0.0
+    return [mean(out[k]) for k in ('obs_auc', 'occ_auc', 'obs_iou', 'occ_iou', 'epe', 'warp_auc', 'warp_iou')]

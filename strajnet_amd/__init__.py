@@ -8,3 +8,4 @@ from .modules import STrajNet            # noqa: F401
 from .loss import (OGMFlow_loss, WaypointGrids, OccupancyFlowTaskConfig,     # noqa: F401
                    get_pred_waypoint_logits, warpped_gt)
 from .optim import Nadam                # noqa: F401
+from .metrics import compute_occupancy_flow_metrics, apply_sigmoid_to_occupancy_logits, OccupancyFlowMetrics     # noqa: F401

@@ -30,6 +30,24 @@ __device__ __forceinline__ float warp_sample(const float* img, int H, int W, flo
   return c.ay * (bot - top) + top;
 }
 
+// Keras AUC bucket of a prediction: the number of thresholds strictly below it, thresholds t0 = -1e-7, t_i = i/99 (i = 1..98),
+// t_99 = 1 + 1e-7 as float32 (tf.keras.metrics.AUC(num_thresholds=100))
+__device__ __forceinline__ int auc_bucket(float pred) {
+  int bk = 0;
+  if (pred > -1e-7f) {
+    bk = 1;
+    int j = (int)(pred * 99.f);
+    j = j < 0 ? 0 : (j > 98 ? 98 : j);
+    // count i in 1..98 with t_i < pred, robust to rounding of pred*99
+    int cnt = j;
+    if (cnt >= 1 && !((float)((double)cnt / 99.0) < pred)) cnt -= 1;
+    else if (cnt < 98 && ((float)((double)(cnt + 1) / 99.0) < pred)) cnt += 1;
+    bk += cnt;
+    if (pred > (float)(1.0 + 1e-7)) bk += 1;
+  }
+  return bk;
+}
+
 // ---- AUC gate ----------------------------------------------------------------------------------------
 // hist [NWP][2][101] (int): bucket = #thresholds strictly below pred; class 1 = label true.
 __global__ __launch_bounds__(256) void auc_hist_kernel(const float* gt_obs, const float* gt_occ, const float* gt_flow,
@@ -47,19 +65,7 @@ __global__ __launch_bounds__(256) void auc_hist_kernel(const float* gt_obs, cons
     const float* img = origin + (b * NWP + k) * (long long)H * W;
     const float wp = warp_sample(img, H, W, (float)x + gt_flow[2 * g], (float)y + gt_flow[2 * g + 1], nullptr, nullptr);
     const float pred = wp * ta;
-    // thresholds: t0 = -1e-7, t_i = i/99 (i=1..98), t_99 = 1+1e-7, as float32
-    int bk = 0;
-    if (pred > -1e-7f) {
-      bk = 1;
-      int j = (int)(pred * 99.f);
-      j = j < 0 ? 0 : (j > 98 ? 98 : j);
-      // count i in 1..98 with t_i < pred, robust to rounding of pred*99
-      int cnt = j;
-      if (cnt >= 1 && !((float)((double)cnt / 99.0) < pred)) cnt -= 1;
-      else if (cnt < 98 && ((float)((double)(cnt + 1) / 99.0) < pred)) cnt += 1;
-      bk += cnt;
-      if (pred > (float)(1.0 + 1e-7)) bk += 1;
-    }
+    const int bk = auc_bucket(pred);
     atomicAdd(&sh[(ta != 0.f ? 101 : 0) + bk], 1);
   }
   __syncthreads();
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void auc_hist_kernel(const float* gt_obs, cons
 }
 // one 128-thread block per waypoint, thread i = threshold i: Keras interpolate_pr_auc from the histogram; gate[k] = auc > 0;
 // auc_out optional.  (v0 ran the whole recurrence in ONE thread per waypoint with 1.6 KB of f64 scratch arrays: 82 us.)
-__global__ __launch_bounds__(128) void auc_gate_kernel(const int* hist, float* gate, float* auc_out) {
+__global__ __launch_bounds__(128) void auc_gate_kernel(const int* hist, float* gate, float* auc_out) {   // gate may be NULL
   __shared__ int hn[101], hp[101];
   __shared__ double tp[100], pp[100], part[128];
   const int k = blockIdx.x, i = threadIdx.x;
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(128) void auc_gate_kernel(const int* hist, float* g
   if (i == 0) {
     double auc = 0;
     for (int j = 0; j < 99; ++j) auc += part[j];          // same summation order as the serial recurrence
-    gate[k] = ((1.0 - auc) < 1.0) ? 1.f : 0.f;
+    if (gate) gate[k] = ((1.0 - auc) < 1.0) ? 1.f : 0.f;
     if (auc_out) auc_out[k] = (float)auc;
   }
 }
@@ -252,4 +258,93 @@ extern "C" int stj_loss_bwd(const float* logits, const float* gt_obs, const floa
   const int gx = (int)min(4096ll, (npix + 255) / 256);
   hipLaunchKernelGGL(loss_bwd_kernel, dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, coef, upstream, dlogits, B, H, W, use_warp);
   return stj_check_launch("stj_loss_bwd");
+}
+
+
+// =====================================================================================================
+// Evaluation metrics on device (reference occu_metric.py:26-140 compute_occupancy_flow_metrics, called every train and
+// validation step: train.py:243-249,280-282): per waypoint k
+//   observed / occluded PR-AUC(true, pred) and soft IoU (occu_metric.py:152-201), flow EPE (:204-252),
+//   flow-warped occupancy: warped = sample(flow_origin_k, identity + pred_flow_k) (:255-317), grounded = clip(pred_obs +
+//   pred_occ, 0, 1) * warped; AUC(y_true = grounded, y_pred = true_all) and IoU(grounded, true_all) -- the reference passes
+//   the prediction in the y_true slot (:120-126); Keras casts y_true to bool (grounded != 0).
+// One streaming pass accumulates 3 histograms + 10 sums per waypoint; stj_metrics_finalize turns them into the 7 means.
+// pred is the model output [B,H,W,32]; pred_is_logits: occupancy channels are logits (sigmoid applied here, as
+// _apply_sigmoid_to_occupancy_logits train.py:142-154 does) or already probabilities.
+// =====================================================================================================
+enum { M_IO = 0, M_TO, M_PO, M_IC, M_TC, M_PC, M_EPE, M_EX, M_IW, M_TW, M_PW, M_N };
+__global__ __launch_bounds__(256) void metrics_kernel(const float* pred, const float* gt_obs, const float* gt_occ, const float* gt_flow,
+                                                      const float* origin, int* hist, float* sums, int B, int H, int W,
+                                                      int pred_is_logits, int use_warp) {
+  __shared__ int sh[3 * 202];
+  __shared__ float red[4][M_N];
+  const int k = blockIdx.y;
+  for (int i = threadIdx.x; i < 3 * 202; i += 256) sh[i] = 0;
+  __syncthreads();
+  float acc[M_N];
+#pragma unroll
+  for (int i = 0; i < M_N; ++i) acc[i] = 0.f;
+  const long long npix = (long long)B * H * W;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += gridDim.x * 256ll) {
+    const int x = (int)(i % W); long long t = i / W;
+    const int y = (int)(t % H); const long long b = t / H;
+    const float4 q = reinterpret_cast<const float4*>(pred + i * 32)[k];
+    const float po = pred_is_logits ? sigmoidf(q.x) : q.x, pc = pred_is_logits ? sigmoidf(q.y) : q.y;
+    const long long g = ((b * NWP + k) * H + y) * W + x;
+    const float to = gt_obs[g], tc = gt_occ[g];
+    const float fx = gt_flow[2 * g], fy = gt_flow[2 * g + 1];
+    atomicAdd(&sh[0 * 202 + (to != 0.f ? 101 : 0) + auc_bucket(po)], 1);
+    atomicAdd(&sh[1 * 202 + (tc != 0.f ? 101 : 0) + auc_bucket(pc)], 1);
+    acc[M_IO] += po * to; acc[M_TO] += to; acc[M_PO] += po;
+    acc[M_IC] += pc * tc; acc[M_TC] += tc; acc[M_PC] += pc;
+    const float ex = (fx != 0.f || fy != 0.f) ? 1.f : 0.f;
+    const float dx = (fx - q.z) * ex, dy = (fy - q.w) * ex;
+    acc[M_EPE] += sqrtf(dx * dx + dy * dy);
+    acc[M_EX] += ex;
+    if (use_warp) {
+      const float* img = origin + (b * NWP + k) * (long long)H * W;
+      const float wp = warp_sample(img, H, W, (float)x + q.z, (float)y + q.w, nullptr, nullptr);
+      const float ta = fminf(fmaxf(to + tc, 0.f), 1.f);
+      const float fg = fminf(fmaxf(po + pc, 0.f), 1.f) * wp;
+      atomicAdd(&sh[2 * 202 + (fg != 0.f ? 101 : 0) + auc_bucket(ta)], 1);     // y_true = grounded prediction, y_pred = true_all
+      acc[M_IW] += ta * fg; acc[M_TW] += fg; acc[M_PW] += ta;
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < M_N; ++i) {
+    const float s = wave_sum(acc[i]);
+    if (lane == 0) red[w][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < M_N) atomicAdd(sums + k * M_N + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  for (int i = threadIdx.x; i < 3 * 202; i += 256)
+    if (sh[i]) atomicAdd(hist + (k * 3 + i / 202) * 202 + i % 202, sh[i]);
+}
+// out[7] = observed_auc, occluded_auc, observed_iou, occluded_iou, flow_epe, flow_warped_occupancy_auc, flow_warped_occupancy_iou
+__global__ void metrics_finalize_kernel(const float* auc, const float* sums, float* out, int use_warp) {
+  if (threadIdx.x != 0) return;
+  float m[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < NWP; ++k) {
+    const float* s = sums + k * M_N;
+    auto iou = [](float i, float t, float p) { const float d = p + t - i; return d != 0.f ? i / d : 0.f; };   // divide_no_nan
+    m[0] += auc[k * 3 + 0]; m[1] += auc[k * 3 + 1];
+    m[2] += iou(s[M_IO], s[M_TO], s[M_PO]); m[3] += iou(s[M_IC], s[M_TC], s[M_PC]);
+    m[4] += s[M_EX] != 0.f ? s[M_EPE] / s[M_EX] : 0.f;
+    if (use_warp) { m[5] += auc[k * 3 + 2]; m[6] += iou(s[M_IW], s[M_TW], s[M_PW]); }
+  }
+  for (int i = 0; i < 7; ++i) out[i] = m[i] / NWP;
+}
+// hist: int[8*3*202], sums: f32[8*11], auc: f32[24] scratch -- hist and sums MUST BE ZERO on entry.  out: f32[7].
+extern "C" int stj_metrics(const float* pred, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
+                           int* hist, float* sums, float* auc, float* out, int B, int H, int W, int pred_is_logits, int use_warp,
+                           hipStream_t stream) {
+  if (((uintptr_t)pred) & 15) { stj_set_error("metrics: pred must be 16-byte aligned"); return STJ_EINVAL; }
+  const long long npix = (long long)B * H * W;
+  if (npix <= 0) return STJ_OK;
+  const int gx = (int)min(256ll, (npix + 255) / 256);
+  hipLaunchKernelGGL(metrics_kernel, dim3(gx, NWP), dim3(256), 0, stream, pred, gt_obs, gt_occ, gt_flow, origin, hist, sums, B, H, W, pred_is_logits, use_warp);
+  hipLaunchKernelGGL(auc_gate_kernel, dim3(NWP * 3), dim3(128), 0, stream, hist, (float*)nullptr, auc);
+  hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(64), 0, stream, auc, sums, out, use_warp);
+  return stj_check_launch("stj_metrics");
 }

@@ -256,6 +256,42 @@ def test_config5_cfg512_deeper_stage_f32():
     assert err < ABS_TOL_F32
 
 
+def test_device_metrics_match_oracle():
+    """compute_occupancy_flow_metrics (occu_metric.py:26-140) on device vs the oracle restatement, on the model's
+    own output and the synthetic ground truth; packed fast path, hand-built WaypointGrids, probabilities and no_warp."""
+    from strajnet_amd import (OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt, compute_occupancy_flow_metrics,
+                              apply_sigmoid_to_occupancy_logits)
+    from strajnet_amd.loss import WaypointGrids
+    from oracle import np_ref
+    model, w, x, xt = _setup(CFG128, 2, torch.float32)
+    with torch.no_grad():
+        out = _fwd(model, xt)
+    cfg = OccupancyFlowTaskConfig(128, 128, 8)
+    true_wp = warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow'])
+    pred_wp = apply_sigmoid_to_occupancy_logits(get_pred_waypoint_logits(out))
+    m = compute_occupancy_flow_metrics(cfg, true_wp, pred_wp)
+    ref = np_ref.occupancy_flow_metrics(out.cpu().numpy(), x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow'])
+    got = [m.vehicles_observed_auc, m.vehicles_occluded_auc, m.vehicles_observed_iou, m.vehicles_occluded_iou, m.vehicles_flow_epe,
+           m.vehicles_flow_warped_occupancy_auc, m.vehicles_flow_warped_occupancy_iou]
+    _report('device metrics 128x128 B=2: ' + ', '.join(f'{a:.6f}/{b:.6f}' for a, b in zip(got, ref)) + ' (device/oracle)')
+    for a, b in zip(got, ref):
+        assert abs(a - b) < 1e-4 * max(1.0, abs(b)), (got, ref)
+    # hand-built grids of probabilities (no packed tensors): same numbers
+    hand = WaypointGrids()
+    hand.vehicles.observed_occupancy = [t.clone() for t in pred_wp.vehicles.observed_occupancy]
+    hand.vehicles.occluded_occupancy = [t.clone() for t in pred_wp.vehicles.occluded_occupancy]
+    hand.vehicles.flow = [t.clone() for t in pred_wp.vehicles.flow]
+    th = WaypointGrids()
+    th.vehicles.observed_occupancy = [xt['gt_obs'][:, k] for k in range(8)]
+    th.vehicles.occluded_occupancy = [xt['gt_occ'][:, k] for k in range(8)]
+    th.vehicles.flow = [xt['gt_flow'][:, k] for k in range(8)]
+    th.vehicles.flow_origin_occupancy = [xt['origin_flow'][:, k] for k in range(8)]
+    m2 = compute_occupancy_flow_metrics(cfg, th, hand)
+    assert torch.allclose(m2.values, m.values, atol=2e-6)
+    m3 = compute_occupancy_flow_metrics(cfg, true_wp, pred_wp, no_warp=True)
+    assert m3.vehicles_flow_warped_occupancy_auc == 0.0 and abs(m3.vehicles_flow_epe - m.vehicles_flow_epe) < 1e-7
+
+
 def test_bf16_mode_error_report():
     """bf16-storage throughput mode: measured error vs the f64 oracle (reported, bounded loosely)."""
     from oracle import np_ref

@@ -126,3 +126,31 @@ def test_param_count_matches_survey():
     assert n == 13277788
     n2 = sum(int(np.prod(s)) for s, k in R.param_spec(cfg, fg_msa=False, fg=False).values())
     assert n2 == 12510452
+
+
+def test_metrics_kats():
+    """occu_metric.py: soft IoU of identical binary maps is 1 and 0 for empty truth (divide_no_nan); EPE counts only cells with
+    ground-truth flow; the packed metric function reproduces the hand computation on a 2x2 toy and obeys no_warp."""
+    from oracle import np_ref as R
+    a = np.array([[1.0, 0.0], [0.0, 1.0]])
+    assert abs(R.soft_iou(a, a) - 1.0) < 1e-12
+    assert R.soft_iou(np.zeros((2, 2)), np.zeros((2, 2))) == 0.0
+    assert abs(R.soft_iou(a, 0.5 * np.ones((2, 2))) - (0.25 / (0.5 + 0.5 - 0.25))) < 1e-12
+    tf_ = np.zeros((1, 2, 2, 2)); tf_[0, 0, 0] = (3.0, 4.0)
+    pf = np.zeros((1, 2, 2, 2)); pf[0, 1, 1] = (100.0, 100.0)          # error where no GT flow exists does not count
+    assert abs(R.flow_epe(tf_, pf) - 5.0) < 1e-12
+    assert R.flow_epe(np.zeros((1, 2, 2, 2)), pf) == 0.0
+    rng = np.random.default_rng(0)
+    y = rng.normal(size=(1, 8, 8, 32))
+    go = (rng.random((1, 8, 8, 8, 1)) < 0.3).astype(np.float64); gc = (rng.random((1, 8, 8, 8, 1)) < 0.1).astype(np.float64)
+    gf = rng.normal(size=(1, 8, 8, 8, 2)) * go; org = rng.random((1, 8, 8, 8, 1))
+    m = R.occupancy_flow_metrics(y, go, gc, gf, org)
+    m2 = R.occupancy_flow_metrics(y, go, gc, gf, org, no_warp=True)
+    assert len(m) == 7 and all(np.isfinite(m)) and m2[5] == 0.0 and m2[6] == 0.0 and m[:5] == m2[:5]
+    sig = 1 / (1 + np.exp(-y))
+    ious = [R.soft_iou(go[:, k], sig[..., 4 * k:4 * k + 1]) for k in range(8)]
+    assert abs(m[2] - np.mean(ious)) < 1e-12
+    # probabilities in, same answer
+    yp = y.copy(); yp[..., 0::4] = sig[..., 0::4]; yp[..., 1::4] = sig[..., 1::4]
+    m3 = R.occupancy_flow_metrics(yp, go, gc, gf, org, pred_is_logits=False)
+    assert np.allclose(m, m3, atol=1e-12)
