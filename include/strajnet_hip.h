@@ -133,6 +133,12 @@ int stj_loss_fwd(const float* logits, const float* gt_obs, const float* gt_occ, 
 int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                  const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int use_warp, hipStream_t stream);
 
+/* TFRecord feature decode (train.py:87-103, inference.py:84-96 _parse_image_function: tf.io.decode_raw + reshape + centre crop
+ * + cast).  src: the raw feature bytes of a batch, [n_outer][H][W][C] elements of kind 0 bool/uint8 (v != 0), 1 int8,
+ * 2 float32, 3 float64; dst f32 [n_outer][Ho][Wo][C] = scale * src[:, y0:y0+Ho, x0:x0+Wo, :]. */
+int stj_decode_raw(const void* src, int kind, float* dst, long long n_outer, int H, int W, int C, int y0, int x0, int Ho,
+                   int Wo, float scale, hipStream_t stream);
+
 /* Evaluation metrics (occu_metric.py:26-140, evaluated every train / validation step: train.py:243-249,280-282): observed and
  * occluded PR-AUC + soft IoU, flow EPE, flow-warped occupancy AUC + IoU, means over the 8 waypoints.  pred [B,H,W,32]
  * (channel 4k+{obs,occ,flow_x,flow_y}); pred_is_logits: sigmoid is applied to the occupancy channels (train.py:142-154).

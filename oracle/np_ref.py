@@ -930,3 +930,28 @@ def occupancy_flow_metrics(model_out, gt_obs, gt_occ, gt_flow, origin_flow, pred
             out['warp_iou'].append(soft_iou(grounded, true_all))
     mean = lambda v: float(np.mean(v)) if v else 0.0
     return [mean(out[k]) for k in ('obs_auc', 'occ_auc', 'obs_iou', 'occ_iou', 'epe', 'warp_auc', 'warp_iou')]
+
+
+# --------------------------------------------------------------------------- #
+# input records (train.py:87-103)
+# --------------------------------------------------------------------------- #
+def parse_image_function(d, grid=512, out=256, test=False):
+    """_parse_image_function (train.py:87-103; inference.py:84-96 with test=True) on a dict of raw feature bytes:
+    decode_raw + reshape + crop [128:384] + cast, float32 results."""
+    c0 = (grid - out) // 2
+    f = lambda name, dt: np.frombuffer(bytes(d[name]), dtype=dt)
+    r = {
+        'centerlines': f('centerlines', np.float64).reshape(256, 10, 7).astype(np.float32),
+        'actors': f('actors', np.float64).reshape(48, 11, 8).astype(np.float32),
+        'occl_actors': f('occl_actors', np.float64).reshape(16, 11, 8).astype(np.float32),
+        'ogm': f('ogm', np.bool_).astype(np.float32).reshape(grid, grid, 11, 2),
+        'map_image': f('map_image', np.int8).reshape(out, out, 3).astype(np.float32) / 256,
+        'vec_flow': f('vec_flow', np.float32).reshape(grid, grid, 2),
+    }
+    if not test:
+        sl = slice(c0, c0 + out)
+        r['gt_flow'] = f('gt_flow', np.float32).reshape(8, grid, grid, 2)[:, sl, sl, :]
+        r['origin_flow'] = f('origin_flow', np.float32).reshape(8, grid, grid, 1)[:, sl, sl, :]
+        r['gt_obs_ogm'] = f('gt_obs_ogm', np.bool_).astype(np.float32).reshape(8, grid, grid, 1)[:, sl, sl, :]
+        r['gt_occ_ogm'] = f('gt_occ_ogm', np.bool_).astype(np.float32).reshape(8, grid, grid, 1)[:, sl, sl, :]
+    return r

@@ -166,3 +166,36 @@ extern "C" int stj_maxpool_bwd(const void* dy, const void* x, const void* y, voi
   else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)dy, (const float*)x, (const float*)y, (float*)dx, outer, Tn, C);
   return stj_check_launch("stj_maxpool_bwd");
 }
+
+// ---- raw record decode (reference train.py:87-103 / inference.py:84-96 _parse_image_function: tf.io.decode_raw + reshape +
+// centre crop + cast, per feature) --------------------------------------------------------------------------------------
+// src: [n_outer][H][W][C] elements of `kind` exactly as the bytes sit in the TFRecord feature (0: bool / uint8 -> (v != 0),
+// 1: int8, 2: float32, 3: float64); dst f32 [n_outer][Ho][Wo][C] = scale * src[:, y0:y0+Ho, x0:x0+Wo, :].
+template <int KIND>
+__global__ __launch_bounds__(256) void decode_raw_kernel(const void* __restrict__ src, float* __restrict__ dst, long long n_out, int H, int W,
+                                                         int C, int y0, int x0, int Ho, int Wo, float scale) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n_out; i += gridDim.x * 256ll) {
+    const int c = (int)(i % C); long long t = i / C;
+    const int x = (int)(t % Wo); t /= Wo;
+    const int y = (int)(t % Ho); const long long n = t / Ho;
+    const long long s = ((n * H + y0 + y) * W + x0 + x) * C + c;
+    float v;
+    if constexpr (KIND == 0) v = reinterpret_cast<const unsigned char*>(src)[s] != 0 ? 1.f : 0.f;
+    else if constexpr (KIND == 1) v = (float)reinterpret_cast<const signed char*>(src)[s];
+    else if constexpr (KIND == 2) v = reinterpret_cast<const float*>(src)[s];
+    else v = (float)reinterpret_cast<const double*>(src)[s];
+    dst[i] = v * scale;
+  }
+}
+extern "C" int stj_decode_raw(const void* src, int kind, float* dst, long long n_outer, int H, int W, int C, int y0, int x0, int Ho,
+                              int Wo, float scale, hipStream_t stream) {
+  if (n_outer <= 0) return STJ_OK;
+  if (kind < 0 || kind > 3 || y0 < 0 || x0 < 0 || y0 + Ho > H || x0 + Wo > W || C <= 0) { stj_set_error("stj_decode_raw: bad kind / crop"); return STJ_EINVAL; }
+  const long long n_out = n_outer * Ho * Wo * C;
+  const int g = ew_grid(n_out);
+  if (kind == 0) hipLaunchKernelGGL(decode_raw_kernel<0>, dim3(g), dim3(256), 0, stream, src, dst, n_out, H, W, C, y0, x0, Ho, Wo, scale);
+  else if (kind == 1) hipLaunchKernelGGL(decode_raw_kernel<1>, dim3(g), dim3(256), 0, stream, src, dst, n_out, H, W, C, y0, x0, Ho, Wo, scale);
+  else if (kind == 2) hipLaunchKernelGGL(decode_raw_kernel<2>, dim3(g), dim3(256), 0, stream, src, dst, n_out, H, W, C, y0, x0, Ho, Wo, scale);
+  else hipLaunchKernelGGL(decode_raw_kernel<3>, dim3(g), dim3(256), 0, stream, src, dst, n_out, H, W, C, y0, x0, Ho, Wo, scale);
+  return stj_check_launch("stj_decode_raw");
+}
