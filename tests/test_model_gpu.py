@@ -292,6 +292,33 @@ def test_device_metrics_match_oracle():
     assert m3.vehicles_flow_warped_occupancy_auc == 0.0 and abs(m3.vehicles_flow_epe - m.vehicles_flow_epe) < 1e-7
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_train_loop_nadam_reduces_loss(dtype):
+    """The pieces of train.py:199-249 together: model(training=True) -> OGMFlow_loss -> backward -> fused Nadam on the flat
+    buffers -> device metrics.  Eight steps on one synthetic batch must lower the loss (and keep everything finite)."""
+    from strajnet_amd import (OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt, Nadam,
+                              compute_occupancy_flow_metrics, apply_sigmoid_to_occupancy_logits)
+    model, w, x, xt = _setup(CFG128, 2, dtype)
+    cfg = OccupancyFlowTaskConfig(128, 128, 8)
+    loss_fn = OGMFlow_loss(cfg, replica=1.0, use_focal_loss=False, use_gt=True)
+    opt = Nadam.for_model(model, lr=2e-4)
+    true_wp = warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow'])
+    hist = []
+    for _ in range(8):
+        model.zero_grad()
+        out = model(xt['ogm'], xt['map_img'], training=True, obs=xt['obs'], occ=xt['occ'], mapt=xt['mapt'], flow=xt['flow'])
+        logits = get_pred_waypoint_logits(out)
+        d = loss_fn(logits, true_wp, None)
+        total = sum(d.values())
+        total.backward()
+        opt.step()
+        m = compute_occupancy_flow_metrics(cfg, true_wp, apply_sigmoid_to_occupancy_logits(logits))
+        hist.append(float(total.detach()))
+        assert np.isfinite(hist[-1]) and np.isfinite(m.vehicles_flow_epe)
+    _report(f'train loop {dtype}: total loss over 8 Nadam steps (lr 2e-4) ' + ' -> '.join(f'{v:.1f}' for v in hist))
+    assert hist[-1] < 0.8 * hist[0] and min(hist) < 0.6 * hist[0]
+
+
 def test_bf16_mode_error_report():
     """bf16-storage throughput mode: measured error vs the f64 oracle (reported, bounded loosely)."""
     from oracle import np_ref
