@@ -124,21 +124,8 @@ def test_train_step_parity_f32():
 
 
 def _oracle_masks(model, B):
-    """Keep masks of the model's last training=True forward, exported by stj_dropout_mask and renamed / reshaped to the
-    oracle's site list (np_ref.dropout_sites): the 8 cross-attentions and the 64 actor encoders are batched in the HIP path."""
-    out = {}
-    for name in model.dropctx.sites:
-        m = model.dropctx.mask(name).cpu().numpy()
-        if name.startswith('cross_attn_obs/'):
-            suffix = name[len('cross_attn_obs/'):]
-            for i in range(8):
-                mi = m[i]
-                out[f'cross_attn_obs{i}/{suffix}'] = mi if suffix == 'mha/dropout' else mi.reshape(B, -1, mi.shape[-1])
-        elif name == 'traj_net/traj_encoder/node_attention/dropout':
-            out[name] = m.reshape(B, -1, *m.shape[1:])
-        else:
-            out[name] = m
-    return out
+    from oracle.masks import masks_from_model
+    return masks_from_model(model, B)
 
 
 def test_train_step_parity_training_true_f32():
