@@ -124,11 +124,17 @@ def main():
     if args.gpus > 1 and world == 1:
         print('bench.py: --gpus N>1 must be launched through torch.distributed.run', file=sys.stderr)
         sys.exit(2)
-    dev = torch.device('cuda', local_rank)
+    # STJ_BENCH_SHARE_GPU=1 (test hook): all ranks on cuda:0 with the gloo backend -- exercises the multi-process code path of
+    # this file on a 1-GPU box (RCCL refuses two ranks on one device); never set for real measurements
+    share = os.environ.get('STJ_BENCH_SHARE_GPU') == '1'
+    dev = torch.device('cuda', 0 if share else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     model = STrajNet(CFG256, fg_msa=True, fg=True, large_ogm=False, dtype=dtype, device=dev, seed=0)
