@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
 template <typename T, int NPL>
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                      const float* rstd, T* dx, float* dgamma, float* dbeta,
-                                                     long long rows, int C, int gres, int C0, LnGroups G, int nb) {
+                                                     long long rows, int C, int gres, int C0, LnGroups G, int nb, const T* dres) {
   __shared__ float red[2][64 * NPL];     // block-level dgamma/dbeta partials (LDS atomics), then ONE global atomic per channel
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int c = threadIdx.x; c < 2 * 64 * NPL; c += 64 * LNB_WAVES) (&red[0][0])[c] = 0.f;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dy, con
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
           const int c = lane + 64 * j;
-          if (c < C) stf(dx + ln_src(row, c, C, gres, C0), rs[u] * (gg[j] - s1 - xh[j] * s2));
+          if (c < C) stf(dx + ln_src(row, c, C, gres, C0), rs[u] * (gg[j] - s1 - xh[j] * s2) + (dres ? ldf(dres + row * C + c) : 0.f));
         }
       }
     }
@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void ln_fwd2_kernel(const T* __restrict__ x, c
 template <typename T, int LPR, int NCHK>
 __global__ __launch_bounds__(256) void ln_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
-                                                      float* dgamma, float* dbeta, long long rows, int C, int gres, int C0, LnGroups G, int nb) {
+                                                      float* dgamma, float* dbeta, long long rows, int C, int gres, int C0, LnGroups G, int nb,
+                                                      const T* __restrict__ dres) {
   constexpr int VN = Vec<T>::N, RPW = 64 / LPR;
   constexpr int U = NCHK == 1 ? 4 : (NCHK == 2 ? 2 : 1);
   __shared__ float red[2][LPR * NCHK * VN];
@@ -277,6 +278,12 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const T* __restrict__ dy, 
           float o[VN];
 #pragma unroll
           for (int e = 0; e < VN; ++e) o[e] = rs[u] * (dv[u][k][e] - s1 - xv[u][k][e] * s2);
+          if (dres) {              // gradient arriving over the residual connection that bypasses this LayerNorm (fused add)
+            float rr[VN];
+            ld16(dres + row * C + c, rr);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[e] += rr[e];
+          }
           st16(dx + ln_src(row, c, C, gres, C0), o);
         }
       }
@@ -303,21 +310,21 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const T* __restrict__ dy, 
 template <typename T, int LPR, int NCHK>
 static void ln2_launch(bool fwd, int grid, hipStream_t stream, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                        float* rstd, const void* dy, void* dx, float* dgamma, float* dbeta, long long rows, int C, float eps, int gres, int C0,
-                       LnGroups G, int nb) {
+                       LnGroups G, int nb, const void* dres) {
   if (fwd) hipLaunchKernelGGL((ln_fwd2_kernel<T, LPR, NCHK>), dim3(grid), dim3(256), 0, stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, gres, C0, G);
-  else hipLaunchKernelGGL((ln_bwd2_kernel<T, LPR, NCHK>), dim3(grid), dim3(256), 0, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0, G, nb);
+  else hipLaunchKernelGGL((ln_bwd2_kernel<T, LPR, NCHK>), dim3(grid), dim3(256), 0, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0, G, nb, (const T*)dres);
 }
 
 #define LN_DISPATCH(NPLV)                                                                                         \
   if (fwd) hipLaunchKernelGGL((ln_fwd_kernel<T, NPLV>), dim3(grid), dim3(256), 0, stream, (const T*)x, gamma, beta, \
                               (T*)y, mean, rstd, rows, C, eps, gres, C0, G);                                       \
   else hipLaunchKernelGGL((ln_bwd_kernel<T, NPLV>), dim3(grid), dim3(64 * LNB_WAVES), 0, stream, (const T*)dy, (const T*)x,    \
-                          gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0, G, nb);
+                          gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0, G, nb, (const T*)dres);
 
 template <typename T>
 static int ln_launch(bool fwd, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      const void* dy, void* dx, float* dgamma, float* dbeta, long long rows, int C, float eps, int gres,
-                     int C0, LnGroups G, hipStream_t stream) {
+                     int C0, LnGroups G, hipStream_t stream, const void* dres = nullptr) {
   const int npl = (C + 63) / 64;
   int grid, nb = 1;
   {
@@ -326,7 +333,7 @@ static int ln_launch(bool fwd, const void* x, const float* gamma, const float* b
     static int v2 = -1;
     if (v2 < 0) { const char* e = getenv("STJ_LN_V1"); v2 = !(e && atoi(e)); }
     const int chunks = C / VN;
-    const bool al = ((uintptr_t)x % 16 == 0) && (!fwd || (uintptr_t)y % 16 == 0) && (fwd || ((uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0)) &&
+    const bool al = ((uintptr_t)x % 16 == 0) && (!fwd || (uintptr_t)y % 16 == 0) && (fwd || ((uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)dres % 16 == 0)) &&
                     ((uintptr_t)gamma % 16 == 0) && (fwd ? (uintptr_t)beta % 16 == 0 : true) && (G.gstride % 4 == 0);
     if (v2 && C % VN == 0 && (gres == 0 || C0 % VN == 0) && chunks <= 192 && al) {
       LnGroups G2 = G;
@@ -349,7 +356,7 @@ static int ln_launch(bool fwd, const void* x, const float* gamma, const float* b
         nb = (int)(nbt < nr * S ? nbt : nr * S);
         grid = G2.ngroups * nb;
       }
-#define LN2(LPRV, NCHKV) ln2_launch<T, LPRV, NCHKV>(fwd, grid, stream, x, gamma, beta, y, mean, rstd, dy, dx, dgamma, dbeta, rows, C, eps, gres, C0, G2, nb)
+#define LN2(LPRV, NCHKV) ln2_launch<T, LPRV, NCHKV>(fwd, grid, stream, x, gamma, beta, y, mean, rstd, dy, dx, dgamma, dbeta, rows, C, eps, gres, C0, G2, nb, dres)
       if (chunks <= 16) LN2(16, 1);
       else if (chunks <= 32) LN2(32, 1);
       else if (chunks <= 64) LN2(64, 1);
@@ -401,9 +408,10 @@ extern "C" int stj_layernorm_fwd(const void* x, const float* gamma, const float*
 }
 extern "C" int stj_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                  void* dx, float* dgamma, float* dbeta, long long rows, int C, int gather_res, int C0,
-                                 long long group_rows, int ngroups, long long gstride, int dtype, hipStream_t stream) {
+                                 long long group_rows, int ngroups, long long gstride, const void* dres, int dtype, hipStream_t stream) {
   if (rows <= 0) return STJ_OK;
+  if (dres && gather_res) { stj_set_error("layernorm_bwd: dres with the PatchMerging gather is not supported"); return STJ_EINVAL; }
   LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride; G.S = 1; G.L = G.group_rows;
-  if (dtype == STJ_BF16) return ln_launch<bf16>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream);
-  return ln_launch<float>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream);
+  if (dtype == STJ_BF16) return ln_launch<bf16>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream, dres);
+  return ln_launch<float>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream, dres);
 }

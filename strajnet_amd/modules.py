@@ -283,6 +283,10 @@ class STrajNet:
     def _ln(self, x, name, eps, gather_res=0):
         return ops.layernorm(x, self._p(name + '/gamma'), self._p(name + '/beta'), eps, gather_res)
 
+    def _ln_skip(self, x, name, eps):
+        """(LayerNorm(x), x) -- x for the residual that bypasses the norm (gradient accumulation fused into the LN backward)."""
+        return ops.layernorm_skip(x, self._p(name + '/gamma'), self._p(name + '/beta'), eps)
+
     def _dense(self, x, name, act=ACT_NONE, res=None, bias=True):
         return ops.linear(x, self._p(name + '/kernel'), self._p(name + '/bias') if bias else None, act, res)
 
@@ -291,18 +295,18 @@ class STrajNet:
         if res <= 8:
             shift = 0                                             # modules.py:173-175
         dpr = self.drop_path_rate.get(pre, 0.0) if self._dctx is not None else 0.0
-        h = self._ln(x, pre + '/norm1', 1e-5)
+        h, x = self._ln_skip(x, pre + '/norm1', 1e-5)
         qkv = self._dense(h, pre + '/attn/qkv')
         a = ops.win_attn(qkv, self._p(pre + '/attn/relative_position_bias_table'), B, res, heads, shift)
         if dpr == 0.0:
             x = self._dense(a, pre + '/attn/proj', res=x)         # shortcut + attn
-            h = self._ln(x, pre + '/norm2', 1e-5)
+            h, x = self._ln_skip(x, pre + '/norm2', 1e-5)
             h = ops.gelu(self._dense(h, pre + '/mlp/fc1'))
             return self._dense(h, pre + '/mlp/fc2', res=x)
         # training: shortcut + DropPath(branch), one Bernoulli(keep) draw per sample and branch (modules.py:137-151,258,260)
         a = self._dense(a, pre + '/attn/proj').view(B, -1)
         x = ops.dropout(a, dpr, self._dctx, pre + '/drop_path_attn', res=x.view(B, -1), per_sample=True).view(x.shape)
-        h = self._ln(x, pre + '/norm2', 1e-5)
+        h, x = self._ln_skip(x, pre + '/norm2', 1e-5)
         h = ops.gelu(self._dense(h, pre + '/mlp/fc1'))
         h = self._dense(h, pre + '/mlp/fc2').view(B, -1)
         return ops.dropout(h, dpr, self._dctx, pre + '/drop_path_mlp', res=x.view(B, -1), per_sample=True).view(x.shape)

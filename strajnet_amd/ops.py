@@ -302,7 +302,7 @@ def tanh_scale(x, s):
 # ----------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g_master, b_master, pg, pb, eps, gather_res, group_rows, ngroups, gstride):
+    def forward(ctx, x, g_master, b_master, pg, pb, eps, gather_res, group_rows, ngroups, gstride, with_skip):
         _req_cuda(x)
         x = x.contiguous()
         dt = _dt(x)
@@ -324,22 +324,33 @@ class _LayerNorm(torch.autograd.Function):
              gather_res, C0, group_rows, ngroups, gstride, dt, _st())
         ctx.pg, ctx.pb, ctx.geo = pg, pb, (rows, C, gather_res, C0, group_rows, ngroups, gstride)
         ctx.save_for_backward(x, mean, rstd)
+        if with_skip:           # second output: x itself, for the residual connection that bypasses the norm
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, mean, rstd = ctx.saved_tensors
         rows, C, gres, C0, group_rows, ngroups, gstride = ctx.geo
+        if dy is None:          # only the skip output was used
+            return (dskip,) + (None,) * 10
         dy = dy.contiguous()
         dx = torch.empty_like(x)
+        dres = dskip.contiguous() if dskip is not None else None
         call('stj_layernorm_bwd', _p(dy), _p(x), _p(ctx.pg.master), _p(mean), _p(rstd), _p(dx), _p(ctx.pg.grad),
-             _p(ctx.pb.grad), rows, C, gres, C0, group_rows, ngroups, gstride, _dt(x), _st())
-        return (dx,) + (None,) * 9
+             _p(ctx.pb.grad), rows, C, gres, C0, group_rows, ngroups, gstride, _p(dres), _dt(x), _st())
+        return (dx,) + (None,) * 10
 
 
 def layernorm(x, pg, pb, eps, gather_res=0, group_rows=0, ngroups=1, gstride=0):
     """pg/pb: Param of gamma/beta (of group 0 when ngroups > 1; group g's live gstride*g elements further)."""
-    return _LayerNorm.apply(x, pg.master, pb.master, pg, pb, eps, gather_res, group_rows, ngroups, gstride)
+    return _LayerNorm.apply(x, pg.master, pb.master, pg, pb, eps, gather_res, group_rows, ngroups, gstride, False)
+
+
+def layernorm_skip(x, pg, pb, eps):
+    """-> (LayerNorm(x), x).  Use the second output for the residual branch `x + f(LayerNorm(x))`: both gradients then arrive
+    in ONE backward call and the kernel adds the skip gradient while writing dx (no separate accumulation pass)."""
+    return _LayerNorm.apply(x, pg.master, pb.master, pg, pb, eps, 0, 0, 1, 0, True)
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -276,7 +276,7 @@ def test_device_metrics_match_oracle():
     m2 = compute_occupancy_flow_metrics(cfg, th, hand)
     assert torch.allclose(m2.values, m.values, atol=2e-6)
     m3 = compute_occupancy_flow_metrics(cfg, true_wp, pred_wp, no_warp=True)
-    assert m3.vehicles_flow_warped_occupancy_auc == 0.0 and abs(m3.vehicles_flow_epe - m.vehicles_flow_epe) < 1e-7
+    assert m3.vehicles_flow_warped_occupancy_auc == 0.0 and abs(m3.vehicles_flow_epe - m.vehicles_flow_epe) < 1e-5      # f32 atomics: summation order varies
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

@@ -404,6 +404,31 @@ def test_loss_and_gate():
 
 
 @pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('rows,C', [(1000, 96), (257, 384), (64, 100)])
+def test_layernorm_skip(dt, rows, C):
+    """(LayerNorm(x), x): the gradient of the skip output is added inside the LN backward kernel (v2 and v1 paths)."""
+    from strajnet_amd import ops
+    pg, pb = mk_param((C,), dt, 0.3, 1), mk_param((C,), dt, 0.3, 2)
+    with torch.no_grad():
+        pg.master.add_(1.0)
+    x = rnd((rows, C), dt, 3, 2.0).requires_grad_(True)
+    y, xs = ops.layernorm_skip(x, pg, pb, 1e-5)
+    assert torch.equal(xs, x)
+    xr, gr, br = ref_of(x), ref_of(pg.master), ref_of(pb.master)
+    yr = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    g1, g2 = rnd((rows, C), dt, 5), rnd((rows, C), dt, 6)
+    ((y.float() * g1.float()).sum() + (xs.float() * g2.float()).sum()).backward()
+    ((yr * g1.double().cpu()).sum() + (xr * g2.double().cpu()).sum()).backward()
+    assert rel_err(x.grad, xr.grad) < tol(dt)
+    assert rel_err(pg.grad, gr.grad) < tol(dt)
+    # only the skip output used: LayerNorm contributes nothing
+    x2 = rnd((rows, C), dt, 7).requires_grad_(True)
+    _, xs2 = ops.layernorm_skip(x2, pg, pb, 1e-5)
+    (xs2.float() * g2.float()).sum().backward()
+    assert rel_err(x2.grad, g2.double().cpu()) < 1e-6
+
+
+@pytest.mark.parametrize('dt', DTYPES)
 def test_dropout_op(dt):
     """stj_dropout: y = [res +] keep * x / (1 - p); per-element and per-sample (DropPath) draws; backward re-derives the mask;
     stj_dropout_mask exports exactly the mask the forward used."""

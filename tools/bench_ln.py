@@ -25,4 +25,4 @@ for rows, C in [(32768, 96), (8192, 192), (2048, 384), (16384, 384), (16384, 128
         ms = e0.elapsed_time(e1) / a.iters
         print(f'{name} [{rows}x{C}] {ms*1e3:8.1f} us  {nbytes/ms/1e9:6.2f} TB/s', flush=True)
     run('ln_fwd', lambda: call('stj_layernorm_fwd', _p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), rows, C, 1e-5, 0, 0, 0, 1, 0, 1, _st()), rows * C * 4)
-    run('ln_bwd', lambda: call('stj_layernorm_bwd', _p(dy), _p(x), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, C, 0, 0, 0, 1, 0, 1, _st()), rows * C * 6)
+    run('ln_bwd', lambda: call('stj_layernorm_bwd', _p(dy), _p(x), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, C, 0, 0, 0, 1, 0, None, 1, _st()), rows * C * 6)
