@@ -110,8 +110,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-  const int z = blockIdx.y / p.splitk, ks = blockIdx.y % p.splitk;
+  // Work map.  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  For split-K GEMMs
+  // (weight gradients: 64x64 output tiles, every k-slice of X and dY is needed by ALL tiles) the tiles of one k-slice are
+  // therefore given consecutive slots of the SAME XCD, so a slice is fetched into one L2 once instead of by every XCD.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.splitk > 1 && (gridDim.y & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, slot = lin >> 3;
+    bx = slot % gridDim.x;
+    by = (slot / gridDim.x) * 8 + xcd;
+  }
+  const int tm = bx / tiles_n, tn = bx % tiles_n;
+  const int z = by / p.splitk, ks = by % p.splitk;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int ktiles_seg = (p.K + BK - 1) / BK;       // k-tiles per K segment
@@ -442,6 +452,7 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
     if (s > ktiles / 2) s = ktiles / 2;
     if (s < 1) s = 1;
     if (s * nb > 65535) s = 65535 / nb;
+    if (s >= 8 && nb == 1) s = s / 8 * 8;      // multiple of 8: enables the XCD-aware work map
     p.splitk = (int)s;
   }
   if (cfg == 0) launch_tile<T, 128, 128, 2, 2>(p, ta, tb, st);
