@@ -224,6 +224,8 @@ class STrajNet:
         self._seg_onehot = {}
         self.dropctx = ops.DropCtx(self.device, seed)
         self._dctx = None
+        import os as _os
+        self._side = torch.cuda.Stream(self.device) if (self.device.type == 'cuda' and _os.environ.get('STJ_NO_SIDE_STREAM') != '1') else None
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():
             k = int(np.prod(s))
@@ -548,6 +550,16 @@ class STrajNet:
             self._dctx = self.dropctx
         ogm, map_img, flow = ogm.float().contiguous(), map_img.float().contiguous(), flow.float().contiguous()
         hb, Cb = self.hb, self.stage_dim[2]
+        # The agent branch (trajNet: ~45 small launches that occupy a few CUs each) is independent of the raster encoder up to the
+        # cross-attention: it is forked onto a side stream here and joined there, so it overlaps with the Swin stages; autograd
+        # replays the fork / join in backward and a hipGraph capture records both branches.
+        if self._side is not None:
+            main = torch.cuda.current_stream(self.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                key, tmask = self._traj_net(obs, occ)
+        else:
+            key, tmask = self._traj_net(obs, occ)
         res_list = self._encoder(ogm, map_img, flow)
         q = res_list[-1].reshape(B, hb, hb, Cb)
         fh = None
@@ -559,7 +571,10 @@ class STrajNet:
         query = q.reshape(1, B, hb * hb, Cb).expand(8, B, hb * hb, Cb)             # modules.py:827
         if self.fg:
             query = query + fh.reshape(B, 8, hb * hb, Cb).permute(1, 0, 2, 3)      # modules.py:830-831
-        key, tmask = self._traj_net(obs, occ)
+        if self._side is not None:       # join the agent branch
+            main.wait_stream(self._side)
+            key.record_stream(main)
+            tmask.record_stream(main)
         x = self._cross_attention_z(query.contiguous(), key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
         out = self._decoder(x, res_list, B)
         return out
