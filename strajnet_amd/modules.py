@@ -226,6 +226,7 @@ class STrajNet:
         self._dctx = None
         import os as _os
         self._side = torch.cuda.Stream(self.device) if (self.device.type == 'cuda' and _os.environ.get('STJ_NO_SIDE_STREAM') != '1') else None
+        self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and _os.environ.get('STJ_NO_SIDE_STREAM2') != '1') else None
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():
             k = int(np.prod(s))
@@ -320,6 +321,8 @@ class STrajNet:
         if not downsample:
             return x, x
         m = self._ln(x, pre + '/downsample/norm', 1e-5, gather_res=res)      # PatchMerging (modules.py:274-292)
+        if callable(add):
+            add = add()                                                      # join point of a branch computed on a side stream
         return self._dense(m, pre + '/downsample/reduction', bias=False, res=add), x
 
     def _patch_embed(self, src, name, Cin, ch_stride, pix_stride):
@@ -335,9 +338,27 @@ class STrajNet:
         B = ogm.shape[0]
         C, P = self.stage_dim[0], self.P
         depths, heads = self.cfg['depths'], self.cfg['num_heads']
-        fl = self._patch_embed(flow, 'patch_embed_flow', 2, 1, 2)
-        fl = self._ln(fl, 'flow_norm', 1e-5)
-        flow_x, flow_res = self._basic_layer(fl, 'flow_layers0', B, P, depths[0], heads[0], True)
+        def flow_branch():
+            fl = self._patch_embed(flow, 'patch_embed_flow', 2, 1, 2)
+            fl = self._ln(fl, 'flow_norm', 1e-5)
+            return self._basic_layer(fl, 'flow_layers0', B, P, depths[0], heads[0], True)
+        # the flow stage (2 Swin blocks at 64x64 tokens) and the vehicle/map stage 0 are independent until stage 0's PatchMerging
+        # adds flow_x (modules.py:576-578,596-605): side stream, joined right before that GEMM
+        side = self._side2
+        if side is not None:
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                flow_x, flow_res = flow_branch()
+
+            def joined_flow_x():
+                main.wait_stream(side)
+                flow_x.record_stream(main)
+                flow_res.record_stream(main)
+                return flow_x
+        else:
+            flow_x, flow_res = flow_branch()
+            joined_flow_x = flow_x
         vec = self._patch_embed(ogm, 'patch_embed_vecicle', 11, 2, 22)          # ogm[...,0]: stride-2 channel pick (:572)
         maps = self._patch_embed(map_img, 'patch_embed_map', 3, 1, 3)
         if self.large_ogm:                                                      # modules.py:582-587
@@ -352,7 +373,7 @@ class STrajNet:
             return t.view(B, r, r, c)[:, q:q + r // 2, q:q + r // 2].reshape(B, (r // 2) ** 2, c)
         for i in range(3):
             r, c = self.stage_res[i], self.stage_dim[i]
-            x, res = self._basic_layer(x, f'layers{i}', B, r, depths[i], heads[i], i < 2, add=flow_x if i == 0 else None)
+            x, res = self._basic_layer(x, f'layers{i}', B, r, depths[i], heads[i], i < 2, add=joined_flow_x if i == 0 else None)
             if i == 0:
                 res_list.append(crop(flow_res, r, c) if self.large_ogm else flow_res)
             res_list.append(crop(res, r, c) if self.large_ogm else res)
@@ -503,7 +524,7 @@ class STrajNet:
         v1 = ops.layernorm(v1, self._zp('norm2/gamma'), self._zp('norm2/beta'), 1e-3, group_rows=B * HW, ngroups=8, gstride=zs)
         return v1.view(Z, B, HW, Cb) + query
 
-    def _decoder(self, x, res_list, B):
+    def _decoder(self, x, res_list, B, skips=None):
         """Pyramid3DDecoder.call (modules.py:739-772): shallow_decode=1, flow_sep_decode, use_pyramid, rep_res."""
         hb = self.hb
         flow_res, r0, r1 = res_list[0], res_list[1], res_list[2]
@@ -512,10 +533,19 @@ class STrajNet:
             return ops.upconv(t, self._p(name + '/kernel'), self._p(name + '/bias'), grad_is_pre, x_is_elu_out)
         x = x.view(8 * B, hb, hb, -1)                                                # frames are TIME-major: f = t*B + b
         x = up(x, 'decoder/upconv_3_0')                                              # [F,2hb,2hb,192]
-        x = x + self._resconv(r1, 'decoder/resconv_3').view(x.shape)
+        if skips is not None:                                                        # computed on the side stream: join
+            main = torch.cuda.current_stream(self.device)
+            main.wait_stream(self._side2)
+            for t in skips:
+                t.record_stream(main)
+            s3, s2, sf = skips
+        else:
+            s3, s2, sf = (self._resconv(r1, 'decoder/resconv_3'), self._resconv(r0, 'decoder/resconv_2'),
+                          self._resconv(flow_res, 'decoder/resconv_f'))
+        x = x + s3.view(x.shape)
         x = up(x, 'decoder/upconv_2_0')                                              # [F,4hb,4hb,128]
-        x = x + self._resconv(r0, 'decoder/resconv_2').view(x.shape)
-        fx = x + self._resconv(flow_res, 'decoder/resconv_f').view(x.shape)
+        x = x + s2.view(x.shape)
+        fx = x + sf.view(x.shape)
         # the last two levels of each branch have a single consumer, whose backward folds ELU' into the gradient it returns
         x = up(up(x, 'decoder/upconv_1_0', grad_is_pre=True), 'decoder/upconv_0_0', grad_is_pre=True, x_is_elu_out=True)
         fx = up(up(fx, 'decoder/upconvf_1_0', grad_is_pre=True), 'decoder/upconvf_0_0', grad_is_pre=True, x_is_elu_out=True)
@@ -561,6 +591,17 @@ class STrajNet:
         else:
             key, tmask = self._traj_net(obs, occ)
         res_list = self._encoder(ogm, map_img, flow)
+        # the three time-kernel skips (Conv3D collapsed to per-waypoint 1x1 GEMMs) only need the encoder outputs: side stream,
+        # overlapping FG-MSA / the cross-attentions / the first up-convs; joined in the decoder where they are added
+        skips = None
+        if self._side2 is not None:
+            main2 = torch.cuda.current_stream(self.device)
+            self._side2.wait_stream(main2)
+            for t in res_list[:3]:
+                t.record_stream(self._side2)
+            with torch.cuda.stream(self._side2):
+                skips = (self._resconv(res_list[2], 'decoder/resconv_3'), self._resconv(res_list[1], 'decoder/resconv_2'),
+                         self._resconv(res_list[0], 'decoder/resconv_f'))
         q = res_list[-1].reshape(B, hb, hb, Cb)
         fh = None
         if self.fg_msa:
@@ -576,5 +617,5 @@ class STrajNet:
             key.record_stream(main)
             tmask.record_stream(main)
         x = self._cross_attention_z(query.contiguous(), key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
-        out = self._decoder(x, res_list, B)
+        out = self._decoder(x, res_list, B, skips)
         return out
