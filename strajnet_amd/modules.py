@@ -547,8 +547,18 @@ class STrajNet:
         x = x + s2.view(x.shape)
         fx = x + sf.view(x.shape)
         # the last two levels of each branch have a single consumer, whose backward folds ELU' into the gradient it returns
-        x = up(up(x, 'decoder/upconv_1_0', grad_is_pre=True), 'decoder/upconv_0_0', grad_is_pre=True, x_is_elu_out=True)
-        fx = up(up(fx, 'decoder/upconvf_1_0', grad_is_pre=True), 'decoder/upconvf_0_0', grad_is_pre=True, x_is_elu_out=True)
+        if self._side2 is not None:      # the observed-occupancy and flow branches of the last two levels are independent
+            main = torch.cuda.current_stream(self.device)
+            self._side2.wait_stream(main)
+            fx.record_stream(self._side2)
+            with torch.cuda.stream(self._side2):
+                fx = up(up(fx, 'decoder/upconvf_1_0', grad_is_pre=True), 'decoder/upconvf_0_0', grad_is_pre=True, x_is_elu_out=True)
+            x = up(up(x, 'decoder/upconv_1_0', grad_is_pre=True), 'decoder/upconv_0_0', grad_is_pre=True, x_is_elu_out=True)
+            main.wait_stream(self._side2)
+            fx.record_stream(main)
+        else:
+            x = up(up(x, 'decoder/upconv_1_0', grad_is_pre=True), 'decoder/upconv_0_0', grad_is_pre=True, x_is_elu_out=True)
+            fx = up(up(fx, 'decoder/upconvf_1_0', grad_is_pre=True), 'decoder/upconvf_0_0', grad_is_pre=True, x_is_elu_out=True)
         return ops.outconv_pair(x, fx, self._p('decoder/outconv/kernel'), self._p('decoder/outconv/bias'),
                                 self._p('decoder/outconv_f/kernel'), self._p('decoder/outconv_f/bias'), B, 8, t_major=True, x_is_elu_out=True)
 
