@@ -110,6 +110,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying the captured hipGraph')
+    ap.add_argument('--serial', action='store_true', help='no side streams: every kernel runs alone (the mode the roofline kernel timings are taken in)')
     ap.add_argument('--gemm-trace', action='store_true', help='print per-shape GEMM launch times (HIP events) to stderr')
     args = ap.parse_args()
 
@@ -141,6 +142,7 @@ def main():
     loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(256, 256, 8), ogm_weight=1000.0, occ_weight=1000.0, flow_weight=1.0,
                            replica=float(world), flow_origin_weight=1000.0, no_use_warp=False, use_pred=False,
                            use_focal_loss=False, use_gt=True)
+    model.serial = args.serial
     B = args.batch
     x = synth_batch(B, 1234 + rank, dev)
 
@@ -187,14 +189,26 @@ def main():
     dt_s = time.perf_counter() - t0
     # per-kernel HIP-event timing of the conv kernels (roofline of the dominant one): the same launches, issued eagerly
     # with events recorded on the launch stream -- under graph replay individual launches cannot carry events
-    prof = None
+    prof = prof_conc = None
     if not args.no_kernel_timing:
+        # (a) kernels ALONE: side streams off, so an event pair brackets exactly one kernel -- the roofline figures
+        model.serial = True
         ops.PROF_GEMM = args.gemm_trace
+        eager_step()
         ops.prof_enable()
         for _ in range(min(args.steps, 3)):
             eager_step()
         barrier()
         prof = ops.prof_disable()
+        # (b) as scheduled in the measured step (branches on concurrent streams share the GPU): reported next to (a)
+        model.serial = args.serial
+        ops.PROF_GEMM = False
+        eager_step()
+        ops.prof_enable()
+        for _ in range(min(args.steps, 3)):
+            eager_step()
+        barrier()
+        prof_conc = ops.prof_disable()
     if world > 1:
         t = torch.tensor([dt_s], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -229,8 +243,12 @@ def main():
                     traffic = json.load(open(tpath)).get(dom)
                 except Exception:
                     traffic = None
+            conc = prof_conc.get(dom) if prof_conc else None
+            conc_ms = sum(a.elapsed_time(b) for a, b, _ in conc) / len(conc) if conc else None
             roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'avg_launch_ms': round(avg_ms, 4),
+                    'timing': 'kernel alone on the GPU (side streams off, eager pass after the timed region)',
+                    'avg_launch_ms_in_step': round(conc_ms, 4) if conc_ms else None,
                     'algorithmic_gflop_per_launch': round(flops / 1e9, 2),
                     'end_to_end_frac': round(value * ALGO_GFLOP_STEP_PER_SCENE / 1e3 / (peak * world), 4)}
         out = {
@@ -239,7 +257,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'STrajNet cfg-256 train step (fwd+OGMFlow_loss+bwd{"+RCCL grad all-reduce" if world > 1 else ""}), '
                                    f'batch {B}/GPU, 8 waypoints, obs+occ+flow heads, fg_msa+fg, random-init weights',
-                       'global_batch': B * world, 'grid': '256x256x11', 'parallelism': f'dp{world}', 'hipgraph': graphed is not None,
+                       'global_batch': B * world, 'grid': '256x256x11', 'parallelism': f'dp{world}', 'hipgraph': graphed is not None, 'concurrent_branch_streams': not args.serial,
                        'optimizer_in_step': False, 'algorithmic_gflop_per_scene_step': ALGO_GFLOP_STEP_PER_SCENE},
             'loss': round(loss_val, 4),
             'roofline': roof,

@@ -227,6 +227,8 @@ class STrajNet:
         import os as _os
         self._side = torch.cuda.Stream(self.device) if (self.device.type == 'cuda' and _os.environ.get('STJ_NO_SIDE_STREAM') != '1') else None
         self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and _os.environ.get('STJ_NO_SIDE_STREAM2') != '1') else None
+        self._streams = (self._side, self._side2)
+        self.serial = False              # True: everything on the current stream (per-kernel timing, debugging)
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():
             k = int(np.prod(s))
@@ -583,6 +585,8 @@ class STrajNet:
         for t in (ogm, map_img, flow, obs, occ):
             if not t.is_cuda:
                 raise RuntimeError('inputs must be CUDA (ROCm) tensors: the HIP path has no CPU fallback')
+        self._side, self._side2 = (None, None) if self.serial else self._streams
+        ops.set_serial(self.serial)
         self._sync_compute_weights()
         self._dctx = None
         if training:                     # Dropout / DropPath draws of this step (reference: training=True, train.py:218)

@@ -110,6 +110,15 @@ _WG = {}
 _WG_MODE = int(os.environ.get('STJ_WGRAD_STREAM', '2'))
 
 
+_SERIAL = False
+
+
+def set_serial(flag):
+    """True: weight-gradient launches stay on the current stream (per-kernel timing with HIP events needs kernels to run alone)."""
+    global _SERIAL
+    _SERIAL = bool(flag)
+
+
 class _NullCtx:
     def __enter__(self):
         return self
@@ -127,7 +136,7 @@ def _wgrad_join(key):
 
 def wgrad_stream(kind, *operands):
     """Context manager: kernels launched inside run on the weight-gradient side stream of the operands' device."""
-    if not (_WG_MODE & kind):
+    if _SERIAL or not (_WG_MODE & kind):
         return _NullCtx()
     dev = operands[0].device
     key = dev.index if dev.index is not None else torch.cuda.current_device()
