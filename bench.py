@@ -24,19 +24,21 @@ if ROOT not in sys.path:
 
 ALGO_GFLOP_FWD_PER_SCENE = 200.7      # SURVEY.md App. E (direct form, 2/MAC)
 ALGO_GFLOP_STEP_PER_SCENE = 602.0     # fwd + dgrad + wgrad
+ALGO_GFLOP_STEP_PER_SCENE_512 = 3 * 240.9   # cfg-512 with depths [2,2,6]
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 
 CFG256 = dict(input_size=(256, 256), window_size=8, embed_dim=96, depths=[2, 2, 2], num_heads=[3, 6, 12])
 
 
-def synth_batch(B, seed, device):
-    """Synthetic scene batch, generated with torch on the host then moved to HBM."""
+def synth_batch(B, seed, device, grid=256):
+    """Synthetic scene batch, generated with torch on the host then moved to HBM.  grid = 512: the cfg-512
+    geometry (512^2 ogm / flow rasters, 256^2 map image, 256^2 ground truth)."""
     import torch
     g = torch.Generator().manual_seed(seed)
     H = 256
-    ogm = (torch.rand((B, H, H, 11, 2), generator=g) < 0.02).float()
-    flow = torch.randn((B, H, H, 2), generator=g) * 2.0 * ogm[..., 10, 0:1]
+    ogm = (torch.rand((B, grid, grid, 11, 2), generator=g) < 0.02).float()
+    flow = torch.randn((B, grid, grid, 2), generator=g) * 2.0 * ogm[..., 10, 0:1]
     map_img = torch.randint(-128, 128, (B, H, H, 3), generator=g).float() / 256.0
 
     def agents(n):
@@ -110,6 +112,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying the captured hipGraph')
+    ap.add_argument('--cfg512', action='store_true', help='BASELINE config 5 instead of the metric config: 512x512 rasters, large_ogm, depths [2,2,6] (extra measurement, not the headline)')
     ap.add_argument('--serial', action='store_true', help='no side streams: every kernel runs alone (the mode the roofline kernel timings are taken in)')
     ap.add_argument('--gemm-trace', action='store_true', help='print per-shape GEMM launch times (HIP events) to stderr')
     args = ap.parse_args()
@@ -138,13 +141,14 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    model = STrajNet(CFG256, fg_msa=True, fg=True, large_ogm=False, dtype=dtype, device=dev, seed=0)
+    cfg = dict(CFG256, input_size=(512, 512), depths=[2, 2, 6]) if args.cfg512 else CFG256
+    model = STrajNet(cfg, fg_msa=True, fg=True, large_ogm=args.cfg512, dtype=dtype, device=dev, seed=0)
     loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(256, 256, 8), ogm_weight=1000.0, occ_weight=1000.0, flow_weight=1.0,
                            replica=float(world), flow_origin_weight=1000.0, no_use_warp=False, use_pred=False,
                            use_focal_loss=False, use_gt=True)
     model.serial = args.serial
     B = args.batch
-    x = synth_batch(B, 1234 + rank, dev)
+    x = synth_batch(B, 1234 + rank, dev, 512 if args.cfg512 else 256)
 
     def step():
         model.zero_grad()
@@ -217,6 +221,7 @@ def main():
 
     if rank == 0:
         scenes = B * world * args.steps
+        algo_step = ALGO_GFLOP_STEP_PER_SCENE_512 if args.cfg512 else ALGO_GFLOP_STEP_PER_SCENE
         value = scenes / dt_s
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         roof = None
@@ -250,21 +255,21 @@ def main():
                     'timing': 'kernel alone on the GPU (side streams off, eager pass after the timed region)',
                     'avg_launch_ms_in_step': round(conc_ms, 4) if conc_ms else None,
                     'algorithmic_gflop_per_launch': round(flops / 1e9, 2),
-                    'end_to_end_frac': round(value * ALGO_GFLOP_STEP_PER_SCENE / 1e3 / (peak * world), 4)}
+                    'end_to_end_frac': round(value * algo_step / 1e3 / (peak * world), 4)}
         out = {
             'metric': 'scenes/sec (fwd+bwd, 256x256 grids)', 'value': round(value, 3), 'unit': 'scenes/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt_s / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'STrajNet cfg-256 train step (fwd+OGMFlow_loss+bwd{"+RCCL grad all-reduce" if world > 1 else ""}), '
+            'config': {'workload': f'STrajNet {"cfg-512 (large_ogm, depths [2,2,6])" if args.cfg512 else "cfg-256"} train step (fwd+OGMFlow_loss+bwd{"+RCCL grad all-reduce" if world > 1 else ""}), '
                                    f'batch {B}/GPU, 8 waypoints, obs+occ+flow heads, fg_msa+fg, random-init weights',
                        'global_batch': B * world, 'grid': '256x256x11', 'parallelism': f'dp{world}', 'hipgraph': graphed is not None, 'concurrent_branch_streams': not args.serial,
-                       'optimizer_in_step': False, 'algorithmic_gflop_per_scene_step': ALGO_GFLOP_STEP_PER_SCENE},
+                       'optimizer_in_step': False, 'algorithmic_gflop_per_scene_step': algo_step},
             'loss': round(loss_val, 4),
             'roofline': roof,
         }
         if prof:
             out['kernel_ms'] = {k: round(v[0], 4) for k, v in sorted(kern.items())}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.cfg512:
             try:
                 out['cpu_baseline'] = cpu_baseline()
             except Exception as e:      # the CPU port is a reported extra, never the product path
