@@ -632,4 +632,4 @@ class STrajNet:
             tmask.record_stream(main)
         x = self._cross_attention_z(query.contiguous(), key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
         out = self._decoder(x, res_list, B, skips)
-        return out
+        return ops.join_after_backward(out, (self._side, self._side2))

@@ -152,6 +152,35 @@ def wgrad_stream(kind, *operands):
     return torch.cuda.stream(st['side'])
 
 
+class _JoinAfterBackward(torch.autograd.Function):
+    """Identity on the model output.  Its backward is the FIRST node the engine runs; it queues a callback that makes the
+    stream backward was called from wait for the model's side streams once the whole pass has been enqueued -- gradients
+    written by side-stream kernels straight into the flat buffer (no AccumulateGrad node the engine could track) are then
+    ordered before whatever the caller enqueues next (optimizer, all-reduce, end of a graph capture)."""
+    @staticmethod
+    def forward(ctx, out, streams):
+        ctx.streams = streams
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        streams = ctx.streams
+        main = torch.cuda.current_stream(g.device)
+
+        def join():
+            for s in streams:
+                main.wait_stream(s)
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+        return g, None
+
+
+def join_after_backward(out, streams):
+    streams = [s for s in streams if s is not None]
+    if not streams or not out.requires_grad:
+        return out
+    return _JoinAfterBackward.apply(out, streams)
+
+
 class Param:
     """One trainable tensor: f32 master view, compute-dtype view, f32 gradient view (all slices of flat buffers)."""
     __slots__ = ('name', 'shape', 'master', 'c', 'grad')

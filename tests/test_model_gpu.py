@@ -306,6 +306,31 @@ def test_train_loop_nadam_reduces_loss(dtype):
     assert hist[-1] < 0.8 * hist[0] and min(hist) < 0.6 * hist[0]
 
 
+def test_side_streams_are_joined_after_backward():
+    """Branches run on side streams and write their weight gradients straight into the flat buffer; work enqueued on the caller's
+    stream right after backward() (here: a clone of the gradients) must already see all of it, and serial mode must agree."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    model, w, x, xt = _setup(CFG128, 2, torch.float32)
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(128, 128, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+
+    def step():
+        model.zero_grad()
+        out = _fwd(model, xt)
+        d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+        sum(d.values()).backward()
+        return model.flat_grads().clone()           # enqueued on the current stream immediately, no synchronize
+    assert model._streams[0] is not None and model._streams[1] is not None
+    for _ in range(3):
+        g_now = step()
+        torch.cuda.synchronize()
+        g_late = model.flat_grads().clone()
+        assert torch.equal(g_now, g_late)
+    model.serial = True
+    g_serial = step()
+    torch.cuda.synchronize()
+    assert float((g_serial - g_late).abs().max()) < 1e-4 * float(g_late.abs().max())
+
+
 def test_bf16_mode_error_report():
     """bf16-storage throughput mode: measured error vs the f64 oracle (reported, bounded loosely)."""
     from oracle import np_ref
