@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void upconv_fold_kernel(const float* dWeff, fl
 // forward
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int FN>
-__global__ __launch_bounds__(256) void upconv_fwd_kernel(const T* X, const T* Wf, const float* bias, T* Y,
+__global__ __launch_bounds__(256, 2) void upconv_fwd_kernel(const T* X, const T* Wf, const float* bias, T* Y,
                                                          int F, int Hi, int Wi, int Cin, int Cout, int act) {
   constexpr int BN = FN * 16;
   constexpr int LDK = KC + ConvPad<T>::P;
