@@ -721,18 +721,20 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
     bf16* Xf = dX + (long long)f * Hi * Wi * Cin;
 #pragma unroll 1
     for (int mf = 0; mf < WS_TH; mf += 2) {
-      // ELU' operand of the epilogue (layer input x): issued before the MFMA work so its latency is hidden
-      constexpr int NEP = (2 * 16 * (CT / 4) + 255) / 256;
-      uint2 xin[ELU ? NEP : 1];
+      // ELU' operand of the epilogue (layer input x): issued before the MFMA work so its latency is hidden.  The epilogue works
+      // in 8-channel (16-byte) items: 2 rows x 16 pixels x CT/8 of them per pass
+      constexpr int NIT = 2 * 16 * (CT / 8);
+      constexpr int NEP = (NIT + 255) / 256;
+      uint4 xin[ELU ? NEP : 1];
       if constexpr (ELU) {
 #pragma unroll
         for (int i = 0; i < NEP; ++i) {
           const int q = tid + i * 256;
-          const int c4 = (q % (CT / 4)) * 4, p = q / (CT / 4);
-          const int oy = ty0 + mf + (p >> 4), ox = tx0 + (p & 15), ci = n0 + c4;
-          xin[i] = make_uint2(0x3f803f80u, 0x3f803f80u);
-          if (q < 2 * 16 * (CT / 4) && oy < Hi && ox < Wi && ci < Cin)
-            xin[i] = *reinterpret_cast<const uint2*>(Xelu + ((long long)f * Hi * Wi + (long long)oy * Wi + ox) * Cin + ci);
+          const int c8 = (q % (CT / 8)) * 8, p = q / (CT / 8);
+          const int oy = ty0 + mf + (p >> 4), ox = tx0 + (p & 15), ci = n0 + c8;
+          xin[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+          if (q < NIT && oy < Hi && ox < Wi && ci < Cin)
+            xin[i] = *reinterpret_cast<const uint4*>(Xelu + ((long long)f * Hi * Wi + (long long)oy * Wi + ox) * Cin + ci);
         }
       }
       f32x4 acc[2][NFI];
@@ -766,30 +768,37 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
         for (int n = 0; n < NFI; ++n)
           *reinterpret_cast<float4*>(red + ((w * 2 + m) * 16 + ln) * LDR + n * 16 + g * 4) = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
       __syncthreads();
-      // sum the 4 phases, 4 channels per thread-iteration, coalesced 8-byte stores
+      // sum the 4 phases, 8 channels per thread-iteration, coalesced 16-byte stores
 #pragma unroll
       for (int i = 0; i < NEP; ++i) {
         const int q = tid + i * 256;
-        if (q >= 2 * 16 * (CT / 4)) break;
-        const int c4 = (q % (CT / 4)) * 4, p = q / (CT / 4);      // p = m*16 + px
+        if (q >= NIT) break;
+        const int c8 = (q % (CT / 8)) * 8, p = q / (CT / 8);      // p = m*16 + px
         const int m = p >> 4, px = p & 15;
-        const float* rp = red + p * LDR + c4;
-        float4 s0 = *reinterpret_cast<const float4*>(rp);
+        const float* rp = red + p * LDR + c8;
+        float v[8];
+        {
+          const float4 a0 = *reinterpret_cast<const float4*>(rp), a1 = *reinterpret_cast<const float4*>(rp + 4);
+          v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        }
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) {
-          const float4 t4 = *reinterpret_cast<const float4*>(rp + ww * 2 * 16 * LDR);
-          s0.x += t4.x; s0.y += t4.y; s0.z += t4.z; s0.w += t4.w;
+          const float4 t0 = *reinterpret_cast<const float4*>(rp + ww * 2 * 16 * LDR), t1 = *reinterpret_cast<const float4*>(rp + ww * 2 * 16 * LDR + 4);
+          v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
         }
-        const int oy = ty0 + mf + m, ox = tx0 + px, ci = n0 + c4;
-        if (oy < Hi && ox < Wi && ci < Cin) {
+        const int oy = ty0 + mf + m, ox = tx0 + px, ci = n0 + c8;
+        if (oy < Hi && ox < Wi && ci < Cin) {             // Cin % 8 == 0 (dispatch)
           if constexpr (ELU) {      // layer input is an ELU output: return the gradient w.r.t. the producer's pre-activation
-            const uint2 xv = xin[i];
-            const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
-            const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
-            s0.x *= x0 > 0.f ? 1.f : x0 + 1.f; s0.y *= x1 > 0.f ? 1.f : x1 + 1.f;
-            s0.z *= x2 > 0.f ? 1.f : x2 + 1.f; s0.w *= x3 > 0.f ? 1.f : x3 + 1.f;
+            const uint32_t xw[4] = {xin[i].x, xin[i].y, xin[i].z, xin[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
+              v[2 * e] *= x0 > 0.f ? 1.f : x0 + 1.f;
+              v[2 * e + 1] *= x1 > 0.f ? 1.f : x1 + 1.f;
+            }
           }
-          *reinterpret_cast<uint2*>(Xf + ((long long)oy * Wi + ox) * Cin + ci) = make_uint2(pack2bf(s0.x, s0.y), pack2bf(s0.z, s0.w));
+          *reinterpret_cast<uint4*>(Xf + ((long long)oy * Wi + ox) * Cin + ci) =
+              make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
         }
       }
       __syncthreads();
@@ -823,7 +832,7 @@ static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, const void
               : dgrad_ws_launch2<KS, NFI, false>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
 }
 bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
-  if (Cout % 8 || Cin % 4) return false;
+  if (Cout % 8 || Cin % 8) return false;
   if (Cout == 48 && Cin == 96) return dgrad_ws_launch<2, 6>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
   if (Cout == 96 && Cin == 128) return dgrad_ws_launch<3, 4>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
   return false;
