@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
   constexpr int CIN = KS * 32;
   constexpr int LDK = CIN + 16;                    // halo pixel stride (elements): 2 (mod 4) 16-byte slots -> conflict-free b128 fragment reads
   constexpr int CT = NF * 16;                      // cout tile of this workgroup
-  constexpr int LDO = CT + 4;                      // output-stage pixel stride (elements), 8-byte aligned
+  constexpr int LDO = CT + 8;                      // output-stage pixel stride (elements), 16-byte aligned rows
   constexpr int HPIX = WS_HH * WS_HW;              // 180 halo pixels
   constexpr int CPP = CIN / 8;                     // 16-byte chunks per halo pixel
   constexpr int NT = 256 * NW;                     // threads: NW waves per output phase, each owning WS_TH/NW tile rows
@@ -148,14 +148,14 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
     __syncthreads();
     // ---- coalesced store of the 16 x 32 x CT output tile (8-byte segments) ----
     {
-      constexpr int SEG = CT / 4;                  // 8-byte segments per pixel
+      constexpr int SEG = CT / 8;                  // 16-byte segments per pixel
       bf16* Yf = Y + (long long)f * Ho * Wo * Cout;
       for (int q = tid; q < 2 * WS_TH * 2 * WS_TW * SEG; q += NT) {
         const int sg = q % SEG, p = q / SEG;
         const int hr = p / (2 * WS_TW), hc = p % (2 * WS_TW);
-        const int oy = 2 * ty0 + hr, ox = 2 * tx0 + hc, co = n0 + sg * 4;
-        if (oy < Ho && ox < Wo && co < Cout)
-          *reinterpret_cast<uint2*>(Yf + ((long long)oy * Wo + ox) * Cout + co) = *reinterpret_cast<const uint2*>(ostage + p * LDO + sg * 4);
+        const int oy = 2 * ty0 + hr, ox = 2 * tx0 + hc, co = n0 + sg * 8;
+        if (oy < Ho && ox < Wo && co < Cout)         // Cout % 8 == 0 (dispatch)
+          *reinterpret_cast<uint4*>(Yf + ((long long)oy * Wo + ox) * Cout + co) = *reinterpret_cast<const uint4*>(ostage + p * LDO + sg * 8);
       }
     }
     __syncthreads();
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
 
 template <int KS, int NF, int NW>
 static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, int act, hipStream_t st) {
-  constexpr int CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 4;
+  constexpr int CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 8;
   const size_t lds = (size_t)(2 * WS_HH * WS_HW * LDK + 2 * WS_TH * 2 * WS_TW * LDO) * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -185,7 +185,7 @@ static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y,
 // returns true when the weight-stationary kernel handles this shape (bf16, Cin in {96,128}, Cout multiple of 4)
 bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        hipStream_t st) {
-  if (Cout % 4 || act != ACT_ELU) return false;
+  if (Cout % 8 || act != ACT_ELU) return false;
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("STJ_WS_VARIANT"); variant = e ? atoi(e) : 1; }
   // Cin=96: the 2-waves-per-SIMD variant spills (144 weight VGPRs + prefetch); one wave per SIMD measured faster (386 vs 432 us)
