@@ -140,6 +140,12 @@ int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, 
 int stj_decode_raw(const void* src, int kind, float* dst, long long n_outer, int H, int W, int C, int y0, int x0, int Ho,
                    int Wo, float scale, hipStream_t stream);
 
+/* Host-side CRC-32C (Castagnoli) for the two TensorFlow file formats on either side of the hot path: TFRecord framing
+ * (train.py:75-78) and the checkpoint bundle written / read by save_weights / load_weights (train.py:358,366,372;
+ * inference.py:283).  *crc is the running, unmasked CRC: 0 before the first chunk, the checksum after the last.  Runs on the
+ * calling thread; touches no device state. */
+int stj_crc32c(const void* data, long long n, unsigned int* crc);
+
 /* Evaluation metrics (occu_metric.py:26-140, evaluated every train / validation step: train.py:243-249,280-282): observed and
  * occluded PR-AUC + soft IoU, flow EPE, flow-warped occupancy AUC + IoU, means over the 8 waypoints.  pred [B,H,W,32]
  * (channel 4k+{obs,occ,flow_x,flow_y}); pred_is_logits: sigmoid is applied to the occupancy channels (train.py:142-154).

@@ -18,6 +18,7 @@ SIGNATURES = {
                  ci, cf, ci, ci, ci, ci, ci, cl, cl, vp],
     'stj_colsum': [vp, vp, ci, ci, cl, ci, vp],
     'stj_cast': [vp, ci, vp, ci, cl, vp],
+    'stj_crc32c': [vp, cl, vp],
     'stj_decode_raw': [vp, ci, vp, cl, ci, ci, ci, ci, ci, ci, ci, cf, vp],
     'stj_metrics': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_rng_advance': [vp, vp],

@@ -10,6 +10,7 @@ Device side: `decode_batch` uploads the raw feature bytes of a batch and expands
 
 A writer (`write_tfrecord`, `serialize_example`) exists for tests and synthetic data; it produces the same bytes TF reads.
 """
+import ctypes
 import struct
 
 import numpy as np
@@ -57,11 +58,33 @@ def _crc_table():
 _TABLE = _crc_table()
 
 
-def crc32c(data):
-    c = 0xFFFFFFFF
-    for b in data:
+def _crc32c_py(data, crc=0):
+    c = crc ^ 0xFFFFFFFF
+    for b in bytes(data):
         c = _TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
     return c ^ 0xFFFFFFFF
+
+
+_FAST = None
+
+
+def crc32c(data, crc=0):
+    """CRC-32C of `data` (bytes-like or ndarray), continuing from `crc`.  Uses the host routine of libstrajnet_hip.so
+    (`stj_crc32c`, slice-by-8); the byte loop above is what it is tested against and what runs if the library is not built."""
+    global _FAST
+    if _FAST is None:
+        try:
+            from . import _lib
+            _FAST = _lib.lib().stj_crc32c
+        except Exception:
+            _FAST = False
+    if not _FAST:
+        return _crc32c_py(data, crc)
+    a = np.ascontiguousarray(data).reshape(-1).view(np.uint8) if isinstance(data, np.ndarray) else np.frombuffer(data, np.uint8)
+    c = ctypes.c_uint(crc)
+    if _FAST(a.ctypes.data if a.size else None, a.size, ctypes.byref(c)) != 0:
+        raise RuntimeError('stj_crc32c failed')
+    return c.value
 
 
 def masked_crc(data):

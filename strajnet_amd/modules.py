@@ -19,6 +19,7 @@ training=False is the deterministic graph.
 Not built (documented gaps): actor_only=False (MapEncoder), sep_actors=True, use_last_ref=True.
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -248,8 +249,18 @@ class STrajNet:
     def state_dict(self):
         return OrderedDict((n, p.master.detach().cpu().numpy().copy()) for n, p in self.params.items())
 
+    def save_weights(self, path):
+        """`model.save_weights(path)` (train.py:358,366): a TF-format checkpoint (`path.index` + `path.data-00000-of-00001`)
+        keyed by the reference's object-graph paths -- see strajnet_amd.checkpoint."""
+        from . import checkpoint
+        checkpoint.save_tf_checkpoint(path, self.state_dict(), self.cfg, self.fg_msa, self.fg)
+
     def load_weights(self, weights):
-        """weights: dict name -> array (Keras layouts, App. B names)."""
+        """`model.load_weights(path)` (train.py:372, inference.py:283): `weights` is the prefix of a TF-format checkpoint
+        written by the reference (or by save_weights), or a dict name -> array (Keras layouts, App. B names)."""
+        if isinstance(weights, (str, os.PathLike)):
+            from . import checkpoint
+            weights = checkpoint.load_tf_checkpoint(os.fspath(weights), self.cfg, self.fg_msa, self.fg)
         missing = [n for n in self.params if n not in weights]
         extra = [n for n in weights if n not in self.params]
         if missing or extra:

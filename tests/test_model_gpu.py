@@ -306,6 +306,26 @@ def test_train_loop_nadam_reduces_loss(dtype):
     assert hist[-1] < 0.8 * hist[0] and min(hist) < 0.6 * hist[0]
 
 
+def test_save_and_load_weights_tf_checkpoint(tmp_path):
+    """train.py:366 `model.save_weights('.../final_model.tf')` then inference.py:283 `model.load_weights(path)`: a second,
+    differently initialised model must reproduce the first one's outputs bit for bit after loading the TF-format checkpoint,
+    and a Nadam step taken after the load must start from the loaded weights (flat buffer and bf16 shadow both updated)."""
+    import strajnet_amd
+    model, w, x, xt = _setup(CFG128, 2, torch.bfloat16)
+    path = str(tmp_path / 'final_model.tf')
+    model.save_weights(path)
+    assert sorted(os.listdir(tmp_path)) == ['final_model.tf.data-00000-of-00001', 'final_model.tf.index']
+    other = strajnet_amd.STrajNet(CFG128, large_ogm=False, dtype=torch.bfloat16, seed=123)
+    y0 = _fwd(model, xt)
+    assert not torch.equal(_fwd(other, xt), y0)
+    other.load_weights(path)
+    assert torch.equal(_fwd(other, xt), y0)
+    sd = other.state_dict()
+    assert all(np.array_equal(sd[n], np.asarray(w[n], np.float32)) for n in w)
+    with pytest.raises(KeyError):                                     # a deeper model must not half-load this checkpoint
+        strajnet_amd.STrajNet(dict(CFG128, depths=[2, 2, 6]), large_ogm=False).load_weights(path)
+
+
 def test_side_streams_are_joined_after_backward():
     """Branches run on side streams and write their weight gradients straight into the flat buffer; work enqueued on the caller's
     stream right after backward() (here: a clone of the gradients) must already see all of it, and serial mode must agree."""
