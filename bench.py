@@ -63,6 +63,47 @@ def synth_batch(B, seed, device, grid=256):
     return {k: v.to(device) for k, v in d.items()}
 
 
+def bench_infer(args, model, x, world, rank, dist):
+    """BASELINE config 4: replicas only (no collective), one hipGraph replay of the eval forward per step."""
+    import torch
+    from strajnet_amd.graph import GraphedForward
+    gf = None if args.no_graph else GraphedForward(model, x)
+
+    def step():
+        if gf is not None:
+            return gf()
+        with torch.no_grad():
+            return model(x['ogm'], x['map_img'], training=False, obs=x['obs'], occ=x['occ'], mapt=None, flow=x['flow'])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt_s = time.perf_counter() - t0
+    t = torch.tensor([dt_s], device=out.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_s = float(t)
+    if rank == 0:
+        B = args.batch
+        print(json.dumps({
+            'metric': 'scenes/sec (inference forward, 256x256 grids)', 'value': round(B * world * args.steps / dt_s, 3), 'unit': 'scenes/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt_s / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'STrajNet {"cfg-512" if args.cfg512 else "cfg-256"} inference forward (BASELINE config 4: extra measurement, not the headline metric), '
+                                   f'batch {B}/GPU, fg_msa+fg, random-init weights', 'global_batch': B * world, 'parallelism': f'replicas x{world}',
+                       'hipgraph': gf is not None, 'finite': bool(torch.isfinite(out).all())}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def cpu_baseline(max_seconds=30.0):
     """The oracle's PyTorch-CPU restatement ("port", NOT the TensorFlow reference) timed on this box's host cores:
     B=1 cfg-256 f32 forward + loss + backward, 1 warm-up, then timed steps until ~12 s of CPU work (bounded by max_seconds)."""
@@ -108,11 +149,12 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32', 'f16'], help='default bf16 (train step) / f16 (--infer)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying the captured hipGraph')
     ap.add_argument('--cfg512', action='store_true', help='BASELINE config 5 instead of the metric config: 512x512 rasters, large_ogm, depths [2,2,6] (extra measurement, not the headline)')
+    ap.add_argument('--infer', action='store_true', help='BASELINE config 4 instead of the metric config: inference-only forward, batch 32/GPU, fp16 MFMA path, hipGraph replay (extra measurement, not the headline)')
     ap.add_argument('--serial', action='store_true', help='no side streams: every kernel runs alone (the mode the roofline kernel timings are taken in)')
     ap.add_argument('--gemm-trace', action='store_true', help='print per-shape GEMM launch times (HIP events) to stderr')
     args = ap.parse_args()
@@ -140,15 +182,24 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
 
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    if args.dtype is None:
+        args.dtype = 'f16' if args.infer else 'bf16'
+    if args.dtype == 'f16' and not args.infer:
+        print('bench.py: fp16 is the inference mode (no loss scaling); use --infer', file=sys.stderr)
+        sys.exit(2)
+    dtype = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f16': torch.float16}[args.dtype]
     cfg = dict(CFG256, input_size=(512, 512), depths=[2, 2, 6]) if args.cfg512 else CFG256
     model = STrajNet(cfg, fg_msa=True, fg=True, large_ogm=args.cfg512, dtype=dtype, device=dev, seed=0)
     loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(256, 256, 8), ogm_weight=1000.0, occ_weight=1000.0, flow_weight=1.0,
                            replica=float(world), flow_origin_weight=1000.0, no_use_warp=False, use_pred=False,
                            use_focal_loss=False, use_gt=True)
     model.serial = args.serial
+    if args.infer and args.batch == 8:
+        args.batch = 32
     B = args.batch
     x = synth_batch(B, 1234 + rank, dev, 512 if args.cfg512 else 256)
+    if args.infer:
+        return bench_infer(args, model, x, world, rank, dist)
 
     def step():
         model.zero_grad()

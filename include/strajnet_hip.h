@@ -8,8 +8,9 @@
  * Conventions
  *   - all pointers are DEVICE pointers owned by the caller (no allocation, no synchronisation inside; every call is
  *     one or a few stream-ordered launches on `stream` => hipGraph-capturable); 16-byte alignment where noted.
- *   - dtype: STJ_F32 = 0 (exact-f32 MFMA, parity mode) or STJ_BF16 = 1 (bf16 storage, f32 accumulate) selects the
- *     activation type `T`; parameters, biases, LN gamma/beta, tables and all gradients of parameters are f32.
+ *   - dtype: STJ_F32 = 0 (exact-f32 MFMA, parity mode), STJ_BF16 = 1 (bf16 storage, f32 accumulate: the training throughput
+ *     mode) or STJ_F16 = 2 (fp16 storage, f32 accumulate: the inference mode of BASELINE config 4; every entry point accepts it,
+ *     the backward ones without any loss scaling and through the generic conv kernels) selects the activation type `T`; parameters, biases, LN gamma/beta, tables and all gradients of parameters are f32.
  *   - return 0 on success, negative stj_status otherwise; message via stj_last_error() (thread local).
  *   - tensors are NHWC / row-major exactly as in the reference.
  *   - "+=" outputs are ACCUMULATED with f32 atomics (they point into the flat gradient buffer).
@@ -22,7 +23,7 @@ extern "C" {
 #endif
 
 enum stj_status { STJ_OK = 0, STJ_EINVAL = -1, STJ_ELAUNCH = -2, STJ_EUNSUPPORTED = -3 };
-enum stj_dtype { STJ_F32 = 0, STJ_BF16 = 1 };
+enum stj_dtype { STJ_F32 = 0, STJ_BF16 = 1, STJ_F16 = 2 };
 enum stj_act { STJ_ACT_NONE = 0, STJ_ACT_GELU = 1, STJ_ACT_ELU = 2 };
 enum stj_unary { STJ_U_GELU = 1, STJ_U_ELU = 2, STJ_U_TANH_SCALE = 3 };
 
@@ -48,7 +49,7 @@ int stj_gemm(const void* A, const void* B, void* C, const float* bias, const voi
              int nkb, long long sAkb, long long sBkb, hipStream_t stream);
 /* out[n] += sum_m X[m,n]  (bias gradients of the conv heads). */
 int stj_colsum(const void* X, float* out, int M, int N, long long ld, int dtype, hipStream_t stream);
-/* f32 <-> bf16 copy (bf16 shadow of the flat parameter buffer). */
+/* f32 <-> bf16 / fp16 copy (16-bit compute copy of the flat parameter buffer). */
 int stj_cast(const void* src, int sdtype, void* dst, int ddtype, long long n, hipStream_t stream);
 
 /* Gelu (tanh form, modules.py:18-29 / FG_MSA.py:7-18), ELU (Keras activation='elu'), tanh*scale (FG_MSA.py:116-117).

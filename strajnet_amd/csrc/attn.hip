@@ -69,6 +69,7 @@ extern "C" int stj_softmax_fwd(const float* S, void* P, const int* qvalid, const
   if (rows <= 0) return STJ_OK;
   const int grid = (int)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(softmax_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, stream, S, (bf16*)P, qvalid, kvalid, bias, rows, H, Nq, Nk);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(softmax_fwd_kernel<f16>, dim3(grid), dim3(256), 0, stream, S, (f16*)P, qvalid, kvalid, bias, rows, H, Nq, Nk);
   else hipLaunchKernelGGL(softmax_fwd_kernel<float>, dim3(grid), dim3(256), 0, stream, S, (float*)P, qvalid, kvalid, bias, rows, H, Nq, Nk);
   return stj_check_launch("stj_softmax_fwd");
 }
@@ -77,6 +78,7 @@ extern "C" int stj_softmax_bwd(const void* P, const float* dP, void* dS, long lo
   if (rows <= 0) return STJ_OK;
   const int grid = (int)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(softmax_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)P, dP, (bf16*)dS, rows, Nk);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(softmax_bwd_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)P, dP, (f16*)dS, rows, Nk);
   else hipLaunchKernelGGL(softmax_bwd_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)P, dP, (float*)dS, rows, Nk);
   return stj_check_launch("stj_softmax_bwd");
 }
@@ -161,6 +163,7 @@ extern "C" int stj_fg_bias_fwd(const void* off, const float* table, float* bias,
   if (total <= 0) return STJ_OK;
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(fg_bias_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)off, table, bias, B, G, Hh, Ww);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(fg_bias_fwd_kernel<f16>, dim3(grid), dim3(256), 0, stream, (const f16*)off, table, bias, B, G, Hh, Ww);
   else hipLaunchKernelGGL(fg_bias_fwd_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)off, table, bias, B, G, Hh, Ww);
   return stj_check_launch("stj_fg_bias_fwd");
 }
@@ -174,6 +177,7 @@ extern "C" int stj_fg_bias_bwd(const void* off, const float* table, const void* 
   const int grid = B * G * QS;
   const size_t lds = (size_t)(2 * Hh - 1) * (2 * Ww - 1) * 2 * sizeof(float);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(fg_bias_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, stream, (const bf16*)off, table, (const bf16*)dbias, dtable, doff, B, G, Hh, Ww, QS);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(fg_bias_bwd_kernel<f16>, dim3(grid), dim3(256), lds, stream, (const f16*)off, table, (const f16*)dbias, dtable, doff, B, G, Hh, Ww, QS);
   else hipLaunchKernelGGL(fg_bias_bwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)off, table, (const float*)dbias, dtable, doff, B, G, Hh, Ww, QS);
   return stj_check_launch("stj_fg_bias_bwd");
 }

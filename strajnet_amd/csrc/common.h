@@ -1,6 +1,6 @@
 // Common device helpers for the STrajNet gfx950 (CDNA4 / MI355X) kernels.
-// Wavefront = 64 lanes.  MFMA tiles used: v_mfma_f32_16x16x32_bf16 (bf16 storage mode)
-// and v_mfma_f32_16x16x4_f32 (exact-f32 parity mode).  C/D fragment map for both:
+// Wavefront = 64 lanes.  MFMA tiles used: v_mfma_f32_16x16x32_bf16 (bf16 storage mode), v_mfma_f32_16x16x32_f16 (fp16
+// storage mode: the inference path of BASELINE config 4) and v_mfma_f32_16x16x4_f32 (exact-f32 parity mode).  C/D fragment map for both:
 //   col = lane & 15, row = (lane >> 4) * 4 + reg.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -9,9 +9,13 @@
 #define STJ_WAVE 64
 
 struct bf16 { uint16_t v; };
+struct f16 { uint16_t v; };    // IEEE binary16 storage; same fragment layouts as bf16, f32 accumulation
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -24,18 +28,40 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.f) & 0xffffu); }
+// fp16 counterparts (round-to-nearest-even v_cvt_f16_f32; values beyond 65504 become inf, as in any fp16 pipeline)
+__device__ __forceinline__ float h2f(uint16_t x) { return (float)__builtin_bit_cast(_Float16, x); }
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// the two 16-bit storage types through one name: pack two f32 / unpack a 32-bit pair
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b);
+template <> __device__ __forceinline__ uint32_t pack2<bf16>(float a, float b) { return pack2bf(a, b); }
+template <> __device__ __forceinline__ uint32_t pack2<f16>(float a, float b) { return pack2h(a, b); }
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack2<bf16>(uint32_t w, float& lo, float& hi) {
+  lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16>(uint32_t w, float& lo, float& hi) {
+  const f16x2_t h = __builtin_bit_cast(f16x2_t, w);
+  lo = (float)h[0]; hi = (float)h[1];
+}
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16>(const bf16* p) { return bf2f(p->v); }
+template <> __device__ __forceinline__ float ldf<f16>(const f16* p) { return h2f(p->v); }
 template <typename T> __device__ __forceinline__ void stf(T* p, float x);
 template <> __device__ __forceinline__ void stf<float>(float* p, float x) { *p = x; }
 template <> __device__ __forceinline__ void stf<bf16>(bf16* p, float x) { p->v = f2bf(x); }
+template <> __device__ __forceinline__ void stf<f16>(f16* p, float x) { p->v = f2h(x); }
 
 // ---- vector (16-byte) global access converted to/from float ---------------------------
 template <typename T> struct Vec;   // elements per 16 bytes
 template <> struct Vec<float> { static constexpr int N = 4; };
 template <> struct Vec<bf16> { static constexpr int N = 8; };
+template <> struct Vec<f16> { static constexpr int N = 8; };
 
 template <typename T> __device__ __forceinline__ void ld16(const T* p, float* out);
 template <> __device__ __forceinline__ void ld16<float>(const float* p, float* out) {
@@ -51,6 +77,11 @@ template <> __device__ __forceinline__ void ld16<bf16>(const bf16* p, float* out
     out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
   }
 }
+template <> __device__ __forceinline__ void ld16<f16>(const f16* p, float* out) {
+  const f32x8_t v = __builtin_convertvector(__builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(p)), f32x8_t);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = v[i];
+}
 template <typename T> __device__ __forceinline__ void st16(T* p, const float* in);
 template <> __device__ __forceinline__ void st16<float>(float* p, const float* in) {
   *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
@@ -58,13 +89,21 @@ template <> __device__ __forceinline__ void st16<float>(float* p, const float* i
 template <> __device__ __forceinline__ void st16<bf16>(bf16* p, const float* in) {
   *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(in[0], in[1]), pack2bf(in[2], in[3]), pack2bf(in[4], in[5]), pack2bf(in[6], in[7]));
 }
+template <> __device__ __forceinline__ void st16<f16>(f16* p, const float* in) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack2h(in[0], in[1]), pack2h(in[2], in[3]), pack2h(in[4], in[5]), pack2h(in[6], in[7]));
+}
 
-// 4 consecutive elements (8 bytes of bf16 / 16 bytes of f32)
+// 4 consecutive elements (8 bytes of bf16 / fp16, 16 bytes of f32)
 __device__ __forceinline__ void st4(bf16* p, const float* v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])); }
 __device__ __forceinline__ void st4(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void ld4(const bf16* p, float* v) {
   const uint2 u = *reinterpret_cast<const uint2*>(p);
   v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u); v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(f16* p, const float* v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3])); }
+__device__ __forceinline__ void ld4(const f16* p, float* v) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  unpack2<f16>(u.x, v[0], v[1]); unpack2<f16>(u.y, v[2], v[3]);
 }
 __device__ __forceinline__ void ld4(const float* p, float* v) { const float4 u = *reinterpret_cast<const float4*>(p); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; }
 
@@ -142,14 +181,15 @@ template <> struct Mma<float> {
     return c;
   }
 };
-template <> struct Mma<bf16> {
+// 16-bit storage types share the operand layout (8 consecutive k per lane); only the MFMA opcode differs
+template <typename T> struct Mma16 {
   static constexpr int KSTEP = 32;
   typedef s16x8 Frag;
   // elements (row = lane&15, k = k0 + (lane>>4)*8 .. +8), 16-byte aligned ds_read_b128
-  __device__ static __forceinline__ Frag load(const bf16* tile, int ld, int row0, int k0, int lane) {
+  __device__ static __forceinline__ Frag load(const T* tile, int ld, int row0, int k0, int lane) {
     return *reinterpret_cast<const s16x8*>(tile + (row0 + (lane & 15)) * ld + k0 + (lane >> 4) * 8);
   }
-  __device__ static __forceinline__ Frag load_strided(const bf16* tile, int sr, int sk, int row0, int k0, int lane) {
+  __device__ static __forceinline__ Frag load_strided(const T* tile, int sr, int sk, int row0, int k0, int lane) {
     const uint16_t* p = reinterpret_cast<const uint16_t*>(tile) + (row0 + (lane & 15)) * sr + (k0 + (lane >> 4) * 8) * sk;
     s16x8 f;
 #pragma unroll
@@ -159,18 +199,25 @@ template <> struct Mma<bf16> {
   // fragment of an operand stored UN-transposed as [k][rows] (rows contiguous, row stride ldt elements, 8-byte aligned):
   // two ds_read_b64_tr_b16 (gfx950 LDS transpose read; semantics probed in tools/probes/tr16_probe.hip): lane p of a
   // 16-lane group reads 4 consecutive rows 4*(p%4).. of k-row (p/4); the hardware hands lane l row (l&15), k-rows 0..3.
-  __device__ static __forceinline__ Frag load_tr(const bf16* tile, int ldt, int row0, int k0, int lane) {
+  __device__ static __forceinline__ Frag load_tr(const T* tile, int ldt, int row0, int k0, int lane) {
     typedef __attribute__((ext_vector_type(4))) short s4;
     const int g = lane >> 4, p = lane & 15;
-    const bf16* a = tile + (k0 + 8 * g + (p >> 2)) * ldt + row0 + 4 * (p & 3);
+    const T* a = tile + (k0 + 8 * g + (p >> 2)) * ldt + row0 + 4 * (p & 3);
     const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a));
     const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a + 4 * ldt));
     return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   }
-  __device__ static __forceinline__ Frag from_global(const bf16* p) { return *reinterpret_cast<const s16x8*>(p); }
+  __device__ static __forceinline__ Frag from_global(const T* p) { return *reinterpret_cast<const s16x8*>(p); }
   static constexpr int LANE_K = 8;
+};
+template <> struct Mma<bf16> : Mma16<bf16> {
   __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<f16> : Mma16<f16> {
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };
 
@@ -197,6 +244,7 @@ template <> struct LdsPad<float> { static constexpr int P = 4; };
 // row strides for which the four 16-lane groups of a ds_read_b128 fragment read (rows = lane&15, +16 B per lane>>4) are
 // conflict-free on gfx950 (MI355X_MICROARCH.md LDS table; +16-byte padding measured 48 % conflict cycles in the conv kernels)
 template <> struct LdsPad<bf16> { static constexpr int P = 16; };
+template <> struct LdsPad<f16> { static constexpr int P = 16; };
 
 // ---- zero-padded clamped bilinear sampling (reference occu_metric.py:345-409 + tfa_image.py:87-173) ----
 struct Bil {
@@ -223,6 +271,8 @@ __device__ __forceinline__ float pad_at(const float* img, int H, int W, int es, 
 
 // ---- host-side error plumbing -------------------------------------------------------------
 enum { STJ_OK = 0, STJ_EINVAL = -1, STJ_ELAUNCH = -2, STJ_EUNSUPPORTED = -3 };
-enum { STJ_F32 = 0, STJ_BF16 = 1 };
+enum { STJ_F32 = 0, STJ_BF16 = 1, STJ_F16 = 2 };
+static inline bool stj_is16(int dtype) { return dtype == STJ_BF16 || dtype == STJ_F16; }
+static inline bool stj_dtype_ok(int dtype) { return dtype == STJ_F32 || dtype == STJ_BF16 || dtype == STJ_F16; }
 void stj_set_error(const char* fmt, ...);
 int stj_check_launch(const char* what);

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* 
 extern "C" int stj_upconv_prep(const float* W, void* Wf, void* Wd, int Cin, int Cout, int dtype, hipStream_t stream) {
   const int g = min(2048, (16 * Cin * Cout + 255) / 256);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(upconv_prep_kernel<bf16>, dim3(g), dim3(256), 0, stream, W, (bf16*)Wf, (bf16*)Wd, Cin, Cout);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(upconv_prep_kernel<f16>, dim3(g), dim3(256), 0, stream, W, (f16*)Wf, (f16*)Wd, Cin, Cout);
   else hipLaunchKernelGGL(upconv_prep_kernel<float>, dim3(g), dim3(256), 0, stream, W, (float*)Wf, (float*)Wd, Cin, Cout);
   return stj_check_launch("stj_upconv_prep");
 }
@@ -389,7 +390,7 @@ extern "C" int stj_upconv_fold(const float* dWeff, float* dW, int Cin, int Cout,
 }
 
 static int upconv_check(int F, int Hi, int Wi, int Cin, int Cout, int dtype) {
-  const int vn = dtype == STJ_BF16 ? 8 : 4;
+  const int vn = stj_is16(dtype) ? 8 : 4;
   if (F <= 0 || Hi <= 0 || Wi <= 0) { stj_set_error("upconv: empty problem"); return STJ_EINVAL; }
   if (Cin % vn || Cout % vn) { stj_set_error("upconv: channels must be multiples of %d (Cin=%d Cout=%d)", vn, Cin, Cout); return STJ_EINVAL; }
   return STJ_OK;
@@ -406,10 +407,10 @@ static int upconv_fwd_launch(const void* X, const void* Wf, const float* bias, v
   return stj_check_launch("stj_upconv_fwd");
 }
 bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
-                       hipStream_t st);   // conv_ws.hip
+                       int dtype, hipStream_t st);   // conv_ws.hip
 bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
 bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
-                          long long y_bs, long long y_ts, long long y_ps, hipStream_t st);
+                          long long y_bs, long long y_ts, long long y_ps, int dtype, hipStream_t st);
 bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
                           int Tn, long long y_bs, long long y_ts, long long y_ps, int elu_in, void* ws, long long ws_bytes, hipStream_t st);
 long long outconv_bwd_ws_bytes();
@@ -423,8 +424,9 @@ extern "C" int stj_upconv_fwd(const void* X, const void* Wf, const float* bias, 
                               int Cout, int act, int dtype, hipStream_t stream) {
   int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
   if (e) return e;
-  if (dtype == STJ_BF16 && ws_enabled() && upconv_fwd_ws_try(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream))
+  if (stj_is16(dtype) && ws_enabled() && upconv_fwd_ws_try(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, dtype, stream))
     return stj_check_launch("stj_upconv_fwd(ws)");
+  if (dtype == STJ_F16) return upconv_fwd_launch<f16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream);
   return dtype == STJ_BF16 ? upconv_fwd_launch<bf16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream)
                            : upconv_fwd_launch<float>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream);
 }
@@ -446,6 +448,7 @@ extern "C" int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, const 
   if (e) return e;
   if (dtype == STJ_BF16 && ws_enabled() && upconv_dgrad_ws_try(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream))
     return stj_check_launch("stj_upconv_dgrad(ws)");
+  if (dtype == STJ_F16) return upconv_dgrad_launch<f16>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream);
   return dtype == STJ_BF16 ? upconv_dgrad_launch<bf16>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream)
                            : upconv_dgrad_launch<float>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream);
 }
@@ -476,6 +479,7 @@ extern "C" int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, flo
   if (e) return e;
   if (dtype == STJ_BF16 && ws_enabled() && upconv_wgrad_tr_try(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream))
     return stj_check_launch("stj_upconv_wgrad(tr)");
+  if (dtype == STJ_F16) return upconv_wgrad_launch<f16>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream);
   return dtype == STJ_BF16 ? upconv_wgrad_launch<bf16>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream)
                            : upconv_wgrad_launch<float>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream);
 }
@@ -634,7 +638,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* X, const floa
 extern "C" int stj_outconv_fwd(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                                long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream) {
   if (Hh % OC_T || Ww % OC_T || C % 8) { stj_set_error("outconv: H,W must be multiples of 16 and C of 8"); return STJ_EINVAL; }
-  if (dtype == STJ_BF16 && ws_enabled() && outconv_fwd_mfma_try(X, W, bias, Y, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, stream))
+  if (stj_is16(dtype) && ws_enabled() && outconv_fwd_mfma_try(X, W, bias, Y, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, dtype, stream))
     return stj_check_launch("stj_outconv_fwd(mfma)");
   const size_t lds = (size_t)(18 * 18 * (C + 1) + 9 * C * 2) * 4;
   if (lds > 160 * 1024) { stj_set_error("outconv: C=%d too large for LDS", C); return STJ_EUNSUPPORTED; }
@@ -642,6 +646,9 @@ extern "C" int stj_outconv_fwd(const void* X, const float* W, const float* bias,
   if (dtype == STJ_BF16) {
     hipFuncSetAttribute((const void*)outconv_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(outconv_fwd_kernel<bf16>, dim3(grid), dim3(256), lds, stream, (const bf16*)X, W, bias, Y, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride);
+  } else if (dtype == STJ_F16) {
+    hipFuncSetAttribute((const void*)outconv_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(outconv_fwd_kernel<f16>, dim3(grid), dim3(256), lds, stream, (const f16*)X, W, bias, Y, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride);
   } else {
     hipFuncSetAttribute((const void*)outconv_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(outconv_fwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)X, W, bias, Y, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride);
@@ -665,6 +672,9 @@ extern "C" int stj_outconv_bwd(const void* X, const float* W, const float* dY, v
   if (dtype == STJ_BF16) {
     hipFuncSetAttribute((const void*)outconv_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(outconv_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, stream, (const bf16*)X, W, dY, (bf16*)dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, elu_in);
+  } else if (dtype == STJ_F16) {
+    hipFuncSetAttribute((const void*)outconv_bwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(outconv_bwd_kernel<f16>, dim3(grid), dim3(256), lds, stream, (const f16*)X, W, dY, (f16*)dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, elu_in);
   } else {
     hipFuncSetAttribute((const void*)outconv_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(outconv_bwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)X, W, dY, (float*)dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, elu_in);
@@ -695,6 +705,7 @@ extern "C" int stj_im2col_patch(const float* src, void* dst, int B, int H, int W
   if (total <= 0) return STJ_OK;
   const int g = (int)min(8192ll, (total + 255) / 256);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(im2col_patch_kernel<bf16>, dim3(g), dim3(256), 0, stream, src, (bf16*)dst, B, H, W, Cin, pix_stride, ch_stride);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(im2col_patch_kernel<f16>, dim3(g), dim3(256), 0, stream, src, (f16*)dst, B, H, W, Cin, pix_stride, ch_stride);
   else hipLaunchKernelGGL(im2col_patch_kernel<float>, dim3(g), dim3(256), 0, stream, src, (float*)dst, B, H, W, Cin, pix_stride, ch_stride);
   return stj_check_launch("stj_im2col_patch");
 }
@@ -738,6 +749,7 @@ extern "C" int stj_im2col3(const void* x, void* cols, int N, int H, int W, int G
   if (total <= 0) return STJ_OK;
   const int g = (int)min(8192ll, (total + 255) / 256);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(im2col3_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)x, (bf16*)cols, N, H, W, G, Cg);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(im2col3_kernel<f16>, dim3(g), dim3(256), 0, stream, (const f16*)x, (f16*)cols, N, H, W, G, Cg);
   else hipLaunchKernelGGL(im2col3_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)x, (float*)cols, N, H, W, G, Cg);
   return stj_check_launch("stj_im2col3");
 }
@@ -746,6 +758,7 @@ extern "C" int stj_col2im3(const void* dcols, void* dx, int N, int H, int W, int
   if (total <= 0) return STJ_OK;
   const int g = (int)min(8192ll, (total + 255) / 256);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(col2im3_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)dcols, (bf16*)dx, N, H, W, G, Cg);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(col2im3_kernel<f16>, dim3(g), dim3(256), 0, stream, (const f16*)dcols, (f16*)dx, N, H, W, G, Cg);
   else hipLaunchKernelGGL(col2im3_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)dcols, (float*)dx, N, H, W, G, Cg);
   return stj_check_launch("stj_col2im3");
 }

@@ -19,9 +19,9 @@
 #define WS_HW (WS_TW + 2)
 #define WS_HH (WS_TH + 2)
 
-template <int KS, int NF, int NW>
-__global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wf,
-                                                               const float* __restrict__ bias, bf16* __restrict__ Y,
+template <typename T, int KS, int NF, int NW>
+__global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
+                                                               const float* __restrict__ bias, T* __restrict__ Y,
                                                                int F, int Hi, int Wi, int Cout, int act, int ntiles) {
   constexpr int CIN = KS * 32;
   constexpr int LDK = CIN + 16;                    // halo pixel stride (elements): 2 (mod 4) 16-byte slots -> conflict-free b128 fragment reads
@@ -32,9 +32,9 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
   constexpr int NT = 256 * NW;                     // threads: NW waves per output phase, each owning WS_TH/NW tile rows
   constexpr int NCH = (HPIX * CPP + NT - 1) / NT;  // chunks per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16* halo0 = reinterpret_cast<bf16*>(smem_raw);
-  bf16* halo1 = halo0 + HPIX * LDK;
-  bf16* ostage = halo1 + HPIX * LDK;               // [16][32][LDO]
+  T* halo0 = reinterpret_cast<T*>(smem_raw);
+  T* halo1 = halo0 + HPIX * LDK;
+  T* ostage = halo1 + HPIX * LDK;               // [16][32][LDO]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int a = (w & 3) >> 1, b = w & 1;           // this wave's output phase
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
   auto prefetch = [&](int tile) {                  // global -> registers (asynchronous until first use)
     int f, ty0, tx0;
     tile_coords(tile, f, ty0, tx0);
-    const bf16* Xf = X + (long long)f * Hi * Wi * CIN;
+    const T* Xf = X + (long long)f * Hi * Wi * CIN;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int q = tid + i * NT;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
       pre[i] = v;
     }
   };
-  auto commit = [&](bf16* halo) {                  // registers -> LDS
+  auto commit = [&](T* halo) {                  // registers -> LDS
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int q = tid + i * NT;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += gridDim.x) {
-    const bf16* halo = buf ? halo1 : halo0;
+    const T* halo = buf ? halo1 : halo0;
     const int next = tile + gridDim.x;
     if (next < ntiles) prefetch(next);
     int f, ty0, tx0;
@@ -129,8 +129,7 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
             for (int m = 0; m < 2; ++m)
 #pragma unroll
               for (int n = 0; n < NF; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[r * 2 + s][n][ks]),
-                                                                    __builtin_bit_cast(bf16x8_t, xb[m]), acc[m][n], 0, 0, 0);
+                acc[m][n] = Mma<T>::mma(wf[r * 2 + s][n][ks], xb[m], acc[m][n]);
           }
       // epilogue into the LDS stage: lane holds couts g*4..g*4+3 of pixel (2(mf+m)+a, 2 ln + b)
 #pragma unroll
@@ -139,8 +138,8 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
         for (int n = 0; n < NF; ++n) {
           // ELU only (the launcher routes other activations to the generic kernel): 6 VALU ops per value, no branches --
           // the runtime-selected activation cost ~7000 instructions per tile, more than the 288 MFMAs
-          const uint32_t p0 = pack2bf(elu_bf(acc[m][n][0] + bv[n][0]), elu_bf(acc[m][n][1] + bv[n][1]));
-          const uint32_t p1 = pack2bf(elu_bf(acc[m][n][2] + bv[n][2]), elu_bf(acc[m][n][3] + bv[n][3]));
+          const uint32_t p0 = pack2<T>(elu_bf(acc[m][n][0] + bv[n][0]), elu_bf(acc[m][n][1] + bv[n][1]));
+          const uint32_t p1 = pack2<T>(elu_bf(acc[m][n][2] + bv[n][2]), elu_bf(acc[m][n][3] + bv[n][3]));
           *reinterpret_cast<uint2*>(ostage + ((2 * (mf + m) + a) * (2 * WS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
         }
     }
@@ -149,7 +148,7 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
     // ---- coalesced store of the 16 x 32 x CT output tile (8-byte segments) ----
     {
       constexpr int SEG = CT / 8;                  // 16-byte segments per pixel
-      bf16* Yf = Y + (long long)f * Ho * Wo * Cout;
+      T* Yf = Y + (long long)f * Ho * Wo * Cout;
       for (int q = tid; q < 2 * WS_TH * 2 * WS_TW * SEG; q += NT) {
         const int sg = q % SEG, p = q / SEG;
         const int hr = p / (2 * WS_TW), hc = p % (2 * WS_TW);
@@ -163,13 +162,13 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const bf16*
   }
 }
 
-template <int KS, int NF, int NW>
+template <typename T, int KS, int NF, int NW>
 static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, int act, hipStream_t st) {
   constexpr int CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 8;
   const size_t lds = (size_t)(2 * WS_HH * WS_HW * LDK + 2 * WS_TH * 2 * WS_TW * LDO) * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)upconv_fwd_ws_kernel<KS, NF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)upconv_fwd_ws_kernel<T, KS, NF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
   }
   const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
@@ -177,21 +176,27 @@ static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y,
   int nblk = 256 / ct;
   if (nblk > ntiles) nblk = ntiles;
   if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL((upconv_fwd_ws_kernel<KS, NF, NW>), dim3(nblk, ct), dim3(256 * NW), lds, st, (const bf16*)X, (const bf16*)Wf, bias, (bf16*)Y,
+  hipLaunchKernelGGL((upconv_fwd_ws_kernel<T, KS, NF, NW>), dim3(nblk, ct), dim3(256 * NW), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y,
                      F, Hi, Wi, Cout, act, ntiles);
   return true;
 }
 
-// returns true when the weight-stationary kernel handles this shape (bf16, Cin in {96,128}, Cout multiple of 4)
-bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
+// returns true when the weight-stationary kernel handles this shape (bf16 / fp16, Cin in {96,128}, Cout multiple of 8)
+template <typename T>
+static bool upconv_fwd_ws_try_t(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        hipStream_t st) {
   if (Cout % 8 || act != ACT_ELU) return false;
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("STJ_WS_VARIANT"); variant = e ? atoi(e) : 1; }
   // Cin=96: the 2-waves-per-SIMD variant spills (144 weight VGPRs + prefetch); one wave per SIMD measured faster (386 vs 432 us)
-  if (Cin == 96) return variant == 2 ? ws_launch<3, 3, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st) : ws_launch<3, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
-  if (Cin == 128) return variant == 0 ? ws_launch<4, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st) : ws_launch<4, 2, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
+  if (Cin == 96) return variant == 2 ? ws_launch<T, 3, 3, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st) : ws_launch<T, 3, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
+  if (Cin == 128) return variant == 0 ? ws_launch<T, 4, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st) : ws_launch<T, 4, 2, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
   return false;
+}
+bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
+                       int dtype, hipStream_t st) {
+  return dtype == STJ_F16 ? upconv_fwd_ws_try_t<f16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, st)
+                          : upconv_fwd_ws_try_t<bf16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, st);
 }
 
 // =====================================================================================================
@@ -370,14 +375,14 @@ bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbi
 // =====================================================================================================
 #define OCM_T 16
 #define OCM_H 18
-template <int C>
-__global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const bf16* __restrict__ X, const float* __restrict__ W,
+template <typename T, int C>
+__global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const T* __restrict__ X, const float* __restrict__ W,
                                                                const float* __restrict__ bias, float* __restrict__ Y, int F, int Hh,
                                                                int Ww, int Tn, long long y_bs, long long y_ts, long long y_ps) {
   static_assert(C == 48, "specialised for 48 input channels (32 + 16)");
   constexpr int LDH = C + 32;                      // 160-byte pixels: conflict-free b128 fragment reads
   constexpr int CPP = C / 8, NCH = (OCM_H * OCM_H * CPP + 255) / 256;
-  __shared__ __attribute__((aligned(16))) bf16 halo[OCM_H * OCM_H * LDH + 64];   // pads + tail stay zero (read by the padded 2nd k-step)
+  __shared__ __attribute__((aligned(16))) T halo[OCM_H * OCM_H * LDH + 64];   // pads + tail stay zero (read by the padded 2nd k-step)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
   // stationary weights: row m = ln is output channel o (only o < 2 non-zero)
   s16x8 a32[9];
@@ -389,16 +394,16 @@ __global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const bf16* __res
     for (int j = 0; j < 8; ++j) v[j] = ln < 2 ? W[(t * C + 8 * g + j) * 2 + ln] : 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) u[j] = (ln < 2 && g < 2) ? W[(t * C + 32 + 8 * g + j) * 2 + ln] : 0.f;   // channels 32..47, rest zero
-    const uint32_t p0 = pack2bf(v[0], v[1]), p1 = pack2bf(v[2], v[3]), p2 = pack2bf(v[4], v[5]), p3 = pack2bf(v[6], v[7]);
+    const uint32_t p0 = pack2<T>(v[0], v[1]), p1 = pack2<T>(v[2], v[3]), p2 = pack2<T>(v[4], v[5]), p3 = pack2<T>(v[6], v[7]);
     a32[t] = __builtin_bit_cast(s16x8, make_uint4(p0, p1, p2, p3));
-    a16[t] = __builtin_bit_cast(s16x8, make_uint4(pack2bf(u[0], u[1]), pack2bf(u[2], u[3]), pack2bf(u[4], u[5]), pack2bf(u[6], u[7])));
+    a16[t] = __builtin_bit_cast(s16x8, make_uint4(pack2<T>(u[0], u[1]), pack2<T>(u[2], u[3]), pack2<T>(u[4], u[5]), pack2<T>(u[6], u[7])));
   }
   const float b0 = bias[0], b1 = bias[1];
   const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T, ntiles = F * tiles_x * tiles_y;
   uint4 pre[NCH];
   auto prefetch = [&](int tile) {
     const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, f = t2 / tiles_y;
-    const bf16* Xf = X + (long long)f * Hh * Ww * C;
+    const T* Xf = X + (long long)f * Hh * Ww * C;
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
       const int q = tid + u * 256;
@@ -433,11 +438,11 @@ __global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const bf16* __res
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const bf16* hp = halo + ((row + t / 3) * OCM_H + ln + t % 3) * LDH;
+        const T* hp = halo + ((row + t / 3) * OCM_H + ln + t % 3) * LDH;
         const s16x8 x32 = *reinterpret_cast<const s16x8*>(hp + 8 * g);
         const s16x8 x16 = *reinterpret_cast<const s16x8*>(hp + 32 + 8 * g);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a32[t]), __builtin_bit_cast(bf16x8_t, x32), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a16[t]), __builtin_bit_cast(bf16x8_t, x16), acc, 0, 0, 0);
+        acc = Mma<T>::mma(a32[t], x32, acc);
+        acc = Mma<T>::mma(a16[t], x16, acc);
       }
       if (g == 0) {
         float* dst = Yb + ((long long)(ty * OCM_T + row) * Ww + tx * OCM_T + ln) * y_ps;
@@ -616,10 +621,13 @@ __global__ __launch_bounds__(64) void outconv_bwd_reduce_kernel(const float* __r
 }
 
 bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
-                          long long y_bs, long long y_ts, long long y_ps, hipStream_t st) {
+                          long long y_bs, long long y_ts, long long y_ps, int dtype, hipStream_t st) {
   if (C != 48 || Hh % OCM_T || Ww % OCM_T || (y_ps & 1) || (((uintptr_t)Y) & 7)) return false;
   const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
-  hipLaunchKernelGGL(outconv_fwd_mfma_kernel<48>, dim3(min(ntiles, 1024)), dim3(256), 0, st, (const bf16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
+  if (dtype == STJ_F16)
+    hipLaunchKernelGGL((outconv_fwd_mfma_kernel<f16, 48>), dim3(min(ntiles, 1024)), dim3(256), 0, st, (const f16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
+  else
+    hipLaunchKernelGGL((outconv_fwd_mfma_kernel<bf16, 48>), dim3(min(ntiles, 1024)), dim3(256), 0, st, (const bf16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
   return true;
 }
 long long outconv_bwd_ws_bytes() { return (long long)OCB_MAXBLK * OCB_PART * sizeof(float); }

@@ -31,6 +31,7 @@ struct GemmArgs {
 
 template <typename T> struct PadT;            // row padding of the un-transposed image: bank-conflict-free strided reads
 template <> struct PadT<bf16> { static constexpr int P = 4; };   // rows 8-byte aligned for ds_read_b64_tr_b16
+template <> struct PadT<f16> { static constexpr int P = 4; };
 template <> struct PadT<float> { static constexpr int P = 4; };
 
 template <typename T> __device__ __forceinline__ T zero_of() {
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? 5 :
 }
 
 // =====================================================================================================
-// Row-streaming linear kernel (bf16): Y[M,N] = epi(X[M,K] W) for the token-major Dense layers with M >> N,K
+// Row-streaming linear kernel (bf16 / fp16): Y[M,N] = epi(X[M,K] W) for the token-major Dense layers with M >> N,K
 // (Swin qkv/proj/fc1/fc2 and their input gradients at 32768 / 8192 tokens, the per-waypoint 1x1 skips).
 // The generic tile kernel above spends its time on per-tile fixed costs there (two staged operands, 2-4 barriers and an
 // LDS epilogue for 12 MFMAs per wave).  Here the WEIGHT tile (NC output columns x all of K) is staged in LDS once per
@@ -284,27 +285,27 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? 5 :
 // up front.  D[m = column 4g+r][n = row] leaves each lane with 4 consecutive output columns of one row -> 8-byte stores
 // (+bias, ELU, residual) directly from the accumulators.  One barrier per block; 128 rows x NC columns per block.
 // =====================================================================================================
-template <int KS, int NC, bool TB>
+template <typename T, int KS, int NC, bool TB>
 __global__ __launch_bounds__(256, 3) void linear_rs_kernel(GemmArgs p) {
   constexpr int K = KS * 32;
   constexpr int LDW = TB ? NC + 4 : K + 16;       // TB: image [K][NC+4] (n contiguous, as stored); else [NC][K+16]
   constexpr int NJ = NC / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
-  bf16* Ws = reinterpret_cast<bf16*>(rs_smem);
+  T* Ws = reinterpret_cast<T*>(rs_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ln = lane & 15;
   const int z = blockIdx.z;
   const long long z1 = z / p.nb2, z2 = z % p.nb2;
   const int n0 = blockIdx.y * NC;
   const int m0 = blockIdx.x * 128 + wave * 32;
-  const bf16* A = reinterpret_cast<const bf16*>(p.A) + z1 * p.sAb1 + z2 * p.sAb2;
-  const bf16* B = reinterpret_cast<const bf16*>(p.B) + z1 * p.sBb1 + z2 * p.sBb2;
+  const T* A = reinterpret_cast<const T*>(p.A) + z1 * p.sAb1 + z2 * p.sAb2;
+  const T* B = reinterpret_cast<const T*>(p.B) + z1 * p.sBb1 + z2 * p.sBb2;
 
   // activations: B fragments of this wave's 32 rows, all k-steps (loads in flight while the weight tile is staged)
   s16x8 xa[2][KS];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = m0 + 16 * i + ln;
-    const bf16* ap = A + (long long)row * p.sAm + 8 * g;
+    const T* ap = A + (long long)row * p.sAm + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (row < p.M) xa[i][ks] = *reinterpret_cast<const s16x8*>(ap + ks * 32);
@@ -343,16 +344,16 @@ __global__ __launch_bounds__(256, 3) void linear_rs_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       s16x8 wf;
-      if constexpr (TB) wf = Mma<bf16>::load_tr(Ws, LDW, j * 16, ks * 32, lane);
-      else wf = Mma<bf16>::load(Ws, LDW, j * 16, ks * 32, lane);
+      if constexpr (TB) wf = Mma<T>::load_tr(Ws, LDW, j * 16, ks * 32, lane);
+      else wf = Mma<T>::load(Ws, LDW, j * 16, ks * 32, lane);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = Mma<bf16>::mma(wf, xa[i][ks], acc[i][j]);
+      for (int i = 0; i < 2; ++i) acc[i][j] = Mma<T>::mma(wf, xa[i][ks], acc[i][j]);
     }
 
   // epilogue from the accumulators: lane = 4 consecutive columns (n0 + 16 j + 4 g ..) of row (m0 + 16 i + ln)
   const float* bias = p.bias ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
-  const bf16* res = p.res ? reinterpret_cast<const bf16*>(p.res) + z1 * p.sRes1 + z2 * p.sRes2 : nullptr;
-  bf16* C = reinterpret_cast<bf16*>(p.C) + z1 * p.sCb1 + z2 * p.sCb2;
+  const T* res = p.res ? reinterpret_cast<const T*>(p.res) + z1 * p.sRes1 + z2 * p.sRes2 : nullptr;
+  T* C = reinterpret_cast<T*>(p.C) + z1 * p.sCb1 + z2 * p.sCb2;
   const bool elu = p.act == ACT_ELU;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -369,32 +370,34 @@ __global__ __launch_bounds__(256, 3) void linear_rs_kernel(GemmArgs p) {
       if (elu) { v0 = elu_bf(v0); v1 = elu_bf(v1); v2 = elu_bf(v2); v3 = elu_bf(v3); }
       if (res) {
         const uint2 rv = *reinterpret_cast<const uint2*>(res + (long long)row * p.ldres + col);
-        v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xffff0000u);
-        v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xffff0000u);
+        float r0, r1, r2, r3;
+        unpack2<T>(rv.x, r0, r1); unpack2<T>(rv.y, r2, r3);
+        v0 += r0; v1 += r1; v2 += r2; v3 += r3;
       }
-      *reinterpret_cast<uint2*>(C + (long long)row * p.ldc + col) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+      *reinterpret_cast<uint2*>(C + (long long)row * p.ldc + col) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
     }
   }
 }
 
-template <int KS, int NC, bool TB>
+template <typename T, int KS, int NC, bool TB>
 static bool rs_launch2(const GemmArgs& p, hipStream_t st) {
   constexpr int K = KS * 32;
   constexpr size_t lds = (size_t)(TB ? K * (NC + 4) : NC * (K + 16)) * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)linear_rs_kernel<KS, NC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)linear_rs_kernel<T, KS, NC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
   }
   dim3 grid((p.M + 127) / 128, (p.N + NC - 1) / NC, p.nb1 * p.nb2);
-  hipLaunchKernelGGL((linear_rs_kernel<KS, NC, TB>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((linear_rs_kernel<T, KS, NC, TB>), grid, dim3(256), lds, st, p);
   return true;
 }
-template <int KS, int NC>
+template <typename T, int KS, int NC>
 static bool rs_launch(const GemmArgs& p, bool tb, hipStream_t st) {
-  return tb ? rs_launch2<KS, NC, true>(p, st) : rs_launch2<KS, NC, false>(p, st);
+  return tb ? rs_launch2<T, KS, NC, true>(p, st) : rs_launch2<T, KS, NC, false>(p, st);
 }
 // true when the row-streaming kernel took the problem
+template <typename T>
 static bool linear_rs_try(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   static int enabled = -1;
   static int rs_min_m = 16384;     // measured: wins at 32768 tokens (1.3-1.7x), loses at <= 8192 (too few 128-row blocks for 256 CUs)
@@ -407,11 +410,11 @@ static bool linear_rs_try(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   if (!tb && p.sBk != 1) return false;
   if ((long long)p.nb1 * p.nb2 > 65535) return false;
   switch (p.K) {
-    case 96: return rs_launch<3, 128>(p, tb, st);
-    case 128: return rs_launch<4, 128>(p, tb, st);
-    case 192: return rs_launch<6, 128>(p, tb, st);
-    case 288: return rs_launch<9, 64>(p, tb, st);
-    case 384: return rs_launch<12, 64>(p, tb, st);
+    case 96: return rs_launch<T, 3, 128>(p, tb, st);
+    case 128: return rs_launch<T, 4, 128>(p, tb, st);
+    case 192: return rs_launch<T, 6, 128>(p, tb, st);
+    case 288: return rs_launch<T, 9, 64>(p, tb, st);
+    case 384: return rs_launch<T, 12, 64>(p, tb, st);
     default: return false;
   }
 }
@@ -428,7 +431,7 @@ static void launch_tile(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
 template <typename T>
 static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
-    if (linear_rs_try(p, ta, tb, st)) return stj_check_launch("stj_gemm(rs)");
+    if (linear_rs_try<T>(p, ta, tb, st)) return stj_check_launch("stj_gemm(rs)");
   }
   constexpr int BK = 128 / sizeof(T);
   const long long nb = (long long)p.nb1 * p.nb2;
@@ -487,7 +490,7 @@ extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias
   p.sBias1 = sBias1; p.sBias2 = sBias2; p.sRes1 = sRes1; p.sRes2 = sRes2; p.ldres = ldres;
   p.act = act; p.c_f32 = c_f32; p.accumulate = accumulate; p.splitk = splitk; p.alpha = alpha;
   p.nkb = nkb; p.sAkb = sAkb; p.sBkb = sBkb;
-  const long long es = dtype == STJ_BF16 ? 2 : 4;
+  const long long es = stj_is16(dtype) ? 2 : 4;
   auto al = [&](const void* ptr, long long esz, long long s0, long long s1, long long s2) {
     return ((uintptr_t)ptr % 16 == 0) && ((s0 * esz) % 16 == 0) && ((s1 * esz) % 16 == 0) && ((s2 * esz) % 16 == 0);
   };
@@ -498,6 +501,7 @@ extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias
   p.vecC = al(C, c_f32 ? 4 : es, ldc, sCb1, sCb2);
   p.vecR = res ? al(res, es, ldres, sRes1, sRes2) : 0;
   if (dtype == STJ_BF16) return launch_gemm<bf16>(p, ta, tb, stream);
+  if (dtype == STJ_F16) return launch_gemm<f16>(p, ta, tb, stream);
   if (dtype == STJ_F32) return launch_gemm<float>(p, ta, tb, stream);
   stj_set_error("stj_gemm: bad dtype %d", dtype);
   return STJ_EINVAL;
@@ -549,12 +553,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, float* out, int
 
 extern "C" int stj_colsum(const void* X, float* out, int M, int N, long long ld, int dtype, hipStream_t stream) {
   if (M <= 0 || N <= 0) return STJ_OK;
-  const long long es = dtype == STJ_BF16 ? 2 : 4;
+  if (!stj_dtype_ok(dtype)) { stj_set_error("stj_colsum: bad dtype %d", dtype); return STJ_EINVAL; }
+  const long long es = stj_is16(dtype) ? 2 : 4;
   int rpb = (M + 511) / 512;
   if (rpb < 64) rpb = 64;
   const int vec = ((uintptr_t)X % 16 == 0) && ((ld * es) % 16 == 0);
   dim3 grid((M + rpb - 1) / rpb);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)X, out, M, N, ld, rpb, vec);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(colsum_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)X, out, M, N, ld, rpb, vec);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, out, M, N, ld, rpb, vec);
   return stj_check_launch("stj_colsum");
 }

@@ -115,21 +115,24 @@ extern "C" int stj_dropout(const void* x, const void* res, void* y, long long n,
   if (n <= 0) return STJ_OK;
   if (!(p >= 0.f && p < 1.f) || inner < 1 || !state) { stj_set_error("stj_dropout: need 0 <= p < 1, inner >= 1, state != NULL"); return STJ_EINVAL; }
   const float scale = 1.0f / (1.0f - p);
-  const int vn = dtype == STJ_BF16 ? 8 : 4;
+  const int vn = stj_is16(dtype) ? 8 : 4;
   const bool vec = n % vn == 0 && (inner == 1 || inner % vn == 0) && !((((uintptr_t)x) | ((uintptr_t)res) | ((uintptr_t)y)) & 15);
   if (vec) {
     const int g = rng_grid(n / vn);
     if (dtype == STJ_BF16 && inner == 1) hipLaunchKernelGGL((dropout_vec_kernel<bf16, false>), dim3(g), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, (bf16*)y, n, inner, p, scale, state, site);
     else if (dtype == STJ_BF16) hipLaunchKernelGGL((dropout_vec_kernel<bf16, true>), dim3(g), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, (bf16*)y, n, inner, p, scale, state, site);
+    else if (dtype == STJ_F16) hipLaunchKernelGGL((dropout_vec_kernel<f16, true>), dim3(g), dim3(256), 0, stream, (const f16*)x, (const f16*)res, (f16*)y, n, inner, p, scale, state, site);
     else if (inner == 1) hipLaunchKernelGGL((dropout_vec_kernel<float, false>), dim3(g), dim3(256), 0, stream, (const float*)x, (const float*)res, (float*)y, n, inner, p, scale, state, site);
     else hipLaunchKernelGGL((dropout_vec_kernel<float, true>), dim3(g), dim3(256), 0, stream, (const float*)x, (const float*)res, (float*)y, n, inner, p, scale, state, site);
   } else if (inner == 1) {
     const int g = rng_grid((n + 3) / 4);
     if (dtype == STJ_BF16) hipLaunchKernelGGL(dropout_elem_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, (bf16*)y, n, p, scale, state, site);
+    else if (dtype == STJ_F16) hipLaunchKernelGGL(dropout_elem_kernel<f16>, dim3(g), dim3(256), 0, stream, (const f16*)x, (const f16*)res, (f16*)y, n, p, scale, state, site);
     else hipLaunchKernelGGL(dropout_elem_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)x, (const float*)res, (float*)y, n, p, scale, state, site);
   } else {
     const int g = rng_grid(n);
     if (dtype == STJ_BF16) hipLaunchKernelGGL(dropout_group_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, (bf16*)y, n, inner, p, scale, state, site);
+    else if (dtype == STJ_F16) hipLaunchKernelGGL(dropout_group_kernel<f16>, dim3(g), dim3(256), 0, stream, (const f16*)x, (const f16*)res, (f16*)y, n, inner, p, scale, state, site);
     else hipLaunchKernelGGL(dropout_group_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)x, (const float*)res, (float*)y, n, inner, p, scale, state, site);
   }
   return stj_check_launch("stj_dropout");

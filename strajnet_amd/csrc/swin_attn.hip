@@ -15,6 +15,7 @@
 
 template <typename T> struct WinCfg;
 template <> struct WinCfg<bf16> { static constexpr int WPB = 4; static constexpr int WPB_BWD = 1; };   // bwd: 46 KB of LDS per wave -> 3 resident waves per CU (2 with WPB_BWD = 2)
+template <> struct WinCfg<f16> { static constexpr int WPB = 4; static constexpr int WPB_BWD = 1; };
 template <> struct WinCfg<float> { static constexpr int WPB = 2; static constexpr int WPB_BWD = 2; };
 
 struct WinGeom {
@@ -304,6 +305,9 @@ extern "C" int stj_win_attn_fwd(const void* qkv, const float* table, void* out, 
   if (dtype == STJ_BF16) {
     constexpr int W = WinCfg<bf16>::WPB;
     hipLaunchKernelGGL(win_attn_fwd_kernel<bf16>, dim3((unsigned)((g.items + W - 1) / W)), dim3(64 * W), 0, stream, (const bf16*)qkv, table, (bf16*)out, g);
+  } else if (dtype == STJ_F16) {
+    constexpr int W = WinCfg<f16>::WPB;
+    hipLaunchKernelGGL(win_attn_fwd_kernel<f16>, dim3((unsigned)((g.items + W - 1) / W)), dim3(64 * W), 0, stream, (const f16*)qkv, table, (f16*)out, g);
   } else {
     constexpr int W = WinCfg<float>::WPB;
     hipLaunchKernelGGL(win_attn_fwd_kernel<float>, dim3((unsigned)((g.items + W - 1) / W)), dim3(64 * W), 0, stream, (const float*)qkv, table, (float*)out, g);
@@ -320,6 +324,9 @@ extern "C" int stj_win_attn_bwd(const void* qkv, const float* table, const void*
   if (dtype == STJ_BF16) {
     constexpr int W = WinCfg<bf16>::WPB_BWD;
     hipLaunchKernelGGL(win_attn_bwd_kernel<bf16>, dim3((unsigned)((g.items + W - 1) / W)), dim3(64 * W), 0, stream, (const bf16*)qkv, table, (const bf16*)dout, (bf16*)dqkv, dtable, g);
+  } else if (dtype == STJ_F16) {
+    constexpr int W = WinCfg<f16>::WPB_BWD;
+    hipLaunchKernelGGL(win_attn_bwd_kernel<f16>, dim3((unsigned)((g.items + W - 1) / W)), dim3(64 * W), 0, stream, (const f16*)qkv, table, (const f16*)dout, (f16*)dqkv, dtable, g);
   } else {
     constexpr int W = WinCfg<float>::WPB_BWD;
     hipLaunchKernelGGL(win_attn_bwd_kernel<float>, dim3((unsigned)((g.items + W - 1) / W)), dim3(64 * W), 0, stream, (const float*)qkv, table, (const float*)dout, (float*)dqkv, dtable, g);

@@ -40,6 +40,9 @@ extern "C" int stj_cast(const void* src, int sdtype, void* dst, int ddtype, long
   else if (sdtype == STJ_BF16 && ddtype == STJ_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(g), dim3(256), 0, stream, (const bf16*)src, (float*)dst, n);
   else if (sdtype == STJ_F32 && ddtype == STJ_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, stream, (const float*)src, (float*)dst, n);
   else if (sdtype == STJ_BF16 && ddtype == STJ_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(g), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, n);
+  else if (sdtype == STJ_F32 && ddtype == STJ_F16) hipLaunchKernelGGL((cast_kernel<float, f16>), dim3(g), dim3(256), 0, stream, (const float*)src, (f16*)dst, n);
+  else if (sdtype == STJ_F16 && ddtype == STJ_F32) hipLaunchKernelGGL((cast_kernel<f16, float>), dim3(g), dim3(256), 0, stream, (const f16*)src, (float*)dst, n);
+  else if (sdtype == STJ_F16 && ddtype == STJ_F16) hipLaunchKernelGGL((cast_kernel<f16, f16>), dim3(g), dim3(256), 0, stream, (const f16*)src, (f16*)dst, n);
   else { stj_set_error("stj_cast: bad dtypes"); return STJ_EINVAL; }
   return stj_check_launch("stj_cast");
 }
@@ -113,6 +116,7 @@ extern "C" int stj_unary_fwd(const void* x, void* y, long long n, int op, float 
   if (((uintptr_t)x | (uintptr_t)y) & 15) { stj_set_error("stj_unary_fwd: pointers must be 16-byte aligned"); return STJ_EINVAL; }
   int g = ew_grid(n / 8);
   if (dtype == STJ_BF16) UNARY_LAUNCH(unary_fwd_kernel, bf16, (const bf16*)x, (bf16*)y, n, p0);
+  else if (dtype == STJ_F16) UNARY_LAUNCH(unary_fwd_kernel, f16, (const f16*)x, (f16*)y, n, p0);
   else UNARY_LAUNCH(unary_fwd_kernel, float, (const float*)x, (float*)y, n, p0);
   return stj_check_launch("stj_unary_fwd");
 }
@@ -122,6 +126,7 @@ extern "C" int stj_unary_bwd(const void* dy, const void* saved, void* dx, long l
   if (((uintptr_t)dy | (uintptr_t)saved | (uintptr_t)dx) & 15) { stj_set_error("stj_unary_bwd: pointers must be 16-byte aligned"); return STJ_EINVAL; }
   int g = ew_grid(n / 8);
   if (dtype == STJ_BF16) UNARY_LAUNCH(unary_bwd_kernel, bf16, (const bf16*)dy, (const bf16*)saved, (bf16*)dx, n, p0);
+  else if (dtype == STJ_F16) UNARY_LAUNCH(unary_bwd_kernel, f16, (const f16*)dy, (const f16*)saved, (f16*)dx, n, p0);
   else UNARY_LAUNCH(unary_bwd_kernel, float, (const float*)dy, (const float*)saved, (float*)dx, n, p0);
   return stj_check_launch("stj_unary_bwd");
 }
@@ -157,6 +162,7 @@ extern "C" int stj_maxpool_fwd(const void* x, void* y, int* idx, long long outer
   if (outer <= 0) return STJ_OK;
   int g = ew_grid(outer * C);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, idx, outer, Tn, C);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(maxpool_fwd_kernel<f16>, dim3(g), dim3(256), 0, stream, (const f16*)x, (f16*)y, idx, outer, Tn, C);
   else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, idx, outer, Tn, C);
   return stj_check_launch("stj_maxpool_fwd");
 }
@@ -164,6 +170,7 @@ extern "C" int stj_maxpool_bwd(const void* dy, const void* x, const void* y, voi
   if (outer <= 0) return STJ_OK;
   int g = ew_grid(outer * C);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, (const bf16*)y, (bf16*)dx, outer, Tn, C);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, dim3(g), dim3(256), 0, stream, (const f16*)dy, (const f16*)x, (const f16*)y, (f16*)dx, outer, Tn, C);
   else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)dy, (const float*)x, (const float*)y, (float*)dx, outer, Tn, C);
   return stj_check_launch("stj_maxpool_bwd");
 }

@@ -161,8 +161,9 @@ class STrajNet:
                                       '(the configuration train.py:194 / modules.py:851 uses) is built')
         if fg and not fg_msa:
             raise ValueError('fg=True requires fg_msa=True (modules.py:828-831 reads the FG-MSA output)')
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError('dtype must be torch.float32 (parity mode) or torch.bfloat16 (throughput mode)')
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError('dtype must be torch.float32 (parity mode), torch.bfloat16 (throughput mode) or torch.float16 '
+                             '(inference mode: no loss scaling is applied to gradients)')
         H, W = cfg['input_size']
         if H != W or H % 128 != 0 and H != 128:
             pass
@@ -244,7 +245,7 @@ class STrajNet:
     # ------------------------------------------------------------------ weights
     def _sync_compute_weights(self):
         if self.dtype != torch.float32:
-            ops.call('stj_cast', ops._p(self._flat), 0, ops._p(self._cflat), 1, self._flat.numel(), ops._st())
+            ops.call('stj_cast', ops._p(self._flat), 0, ops._p(self._cflat), ops.DTYPE_CODE[self.dtype], self._flat.numel(), ops._st())
 
     def state_dict(self):
         return OrderedDict((n, p.master.detach().cpu().numpy().copy()) for n, p in self.params.items())
@@ -267,7 +268,7 @@ class STrajNet:
             raise KeyError(f'load_weights: missing {missing[:5]} extra {extra[:5]}')
         with torch.no_grad():
             for n, p in self.params.items():
-                w = torch.as_tensor(np.asarray(weights[n]), dtype=torch.float32)
+                w = torch.from_numpy(np.array(weights[n], dtype=np.float32))       # (copy: checkpoint arrays are read-only maps)
                 if tuple(w.shape) != p.shape:
                     raise ValueError(f'{n}: shape {tuple(w.shape)} != {p.shape}')
                 p.master.copy_(w.to(self.device))

@@ -18,12 +18,14 @@ U_GELU, U_ELU, U_TANHS = 1, 2, 3
 vp = ctypes.c_void_p
 
 
+DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}      # STJ_F32 / STJ_BF16 / STJ_F16 (strajnet_hip.h)
+
+
 def _dt(t):
-    if t.dtype == torch.bfloat16:
-        return 1
-    if t.dtype == torch.float32:
-        return 0
-    raise TypeError(f'unsupported activation dtype {t.dtype}')
+    try:
+        return DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise TypeError(f'unsupported activation dtype {t.dtype}') from None
 
 
 def _p(t):
@@ -662,7 +664,7 @@ def patch_im2col(src, Cin, ch_stride, pix_stride, dtype):
     src = src.contiguous()
     B, H, W = src.shape[0], src.shape[1], src.shape[2]
     out = torch.empty((B * (H // 4) * (W // 4), 16 * Cin), dtype=dtype, device=src.device)
-    call('stj_im2col_patch', _p(src), _p(out), B, H, W, Cin, pix_stride, ch_stride, 1 if dtype == torch.bfloat16 else 0, _st())
+    call('stj_im2col_patch', _p(src), _p(out), B, H, W, Cin, pix_stride, ch_stride, DTYPE_CODE[dtype], _st())
     return out
 
 
