@@ -126,14 +126,16 @@ int stj_col2im3(const void* dcols, void* dx, int N, int H, int W, int G, int Cg,
  * train.py:105-123), gt_obs/gt_occ/origin [B,8,H,W,1], gt_flow [B,8,H,W,2].
  * auc_gate: res_k = [Keras PR-AUC(true_all, warp(origin, id+gt_flow)*true_all) > 0] (loss.py:127-137); hist int[8*202] scratch, zero on entry.
  * fwd: sums f32[40] scratch (zero on entry), loss f32[4] = observed_xe, occluded_xe, flow, flow_warp_xe; coef f32[32] for bwd.
- * bwd: dlogits = sum_j upstream[j] * dloss_j/dlogits. */
+ * bwd: dlogits = sum_j upstream[j] * dloss_j/dlogits.
+ * flags: bit 0 = flow-warp term on (not no_use_warp), bit 1 = use_focal_loss (tfa SigmoidFocalCrossEntropy added to the three
+ * occupancy terms, loss.py:183-190,212-219,244-245), bit 2 = use_pred (loss.py:151-154,253-268); the same value goes to fwd and bwd. */
 int stj_loss_auc_gate(const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                       int* hist, float* gate, float* auc_out, int B, int H, int W, hipStream_t stream);
 int stj_loss_fwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                  const float* gate, float* sums, float* loss, float* coef, int B, int H, int W, float ogm_w, float occ_w,
-                 float flow_origin_w, float replica, int use_warp, hipStream_t stream);
+                 float flow_origin_w, float replica, int flags, hipStream_t stream);
 int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
-                 const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int use_warp, hipStream_t stream);
+                 const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int flags, hipStream_t stream);
 
 /* TFRecord feature decode (train.py:87-103, inference.py:84-96 _parse_image_function: tf.io.decode_raw + reshape + centre crop
  * + cast).  src: the raw feature bytes of a batch, [n_outer][H][W][C] elements of kind 0 bool/uint8 (v != 0), 1 int8,

@@ -838,13 +838,38 @@ def sigmoid_xe(labels, logits):
     return np.maximum(logits, 0) - logits * labels + np.log1p(np.exp(-np.abs(logits)))
 
 
+_EPS = float(np.float32(1e-7))                       # Keras backend epsilon, as the float32 the reference computes in
+_HI = float(np.float32(1.0) - np.float32(1e-7))
+
+
+def bce_prob(y, q):
+    """K.binary_crossentropy(target, output, from_logits=False): clip to [eps, 1-eps], then -(y log(q+eps) + (1-y) log(1-q+eps))."""
+    qc = np.clip(q, _EPS, _HI)
+    return -(y * np.log(qc + _EPS) + (1 - y) * np.log(1 - qc + _EPS))
+
+
+def _focal(y, prob, ce, alpha=0.25, gamma=2.0):
+    """tfa sigmoid_focal_crossentropy per element (the caller sums): alpha_t * (1 - p_t)^gamma * ce."""
+    p_t = y * prob + (1 - y) * (1 - prob)
+    return (y * alpha + (1 - y) * (1 - alpha)) * (1 - p_t) ** gamma * ce
+
+
+def focal_logits(y, x):
+    return _focal(y, 1 / (1 + np.exp(-x)), sigmoid_xe(y, x))
+
+
+def focal_prob(y, q):
+    return _focal(y, q, bce_prob(y, q))
+
+
 def ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin_flow, ogm_weight=1000.0, occ_weight=1000.0,
                   flow_weight=1.0, replica=1.0, flow_origin_weight=1000.0, no_use_warp=False, use_pred=False,
                   use_focal_loss=False, use_gt=True, return_gates=False):
     """OGMFlow_loss.__call__ (loss.py:50-170) on the [B,H,W,32] model output with the slicing of
-    train.py:105-140 (channel 4k+{0,1,2:4}; GT [B,8,H,W,*] sliced on axis 1).  Focal branch restated
-    only for use_focal_loss=False (train.py:196)."""
-    assert not use_focal_loss and not use_pred, "oracle restates the train.py:195-196 configuration"
+    train.py:105-140 (channel 4k+{0,1,2:4}; GT [B,8,H,W,*] sliced on axis 1).  Defaults here are the
+    train.py:195-196 flags; use_focal_loss / use_pred follow loss.py:183-190,212-219,244-245,253-268 with
+    tfa.losses.SigmoidFocalCrossEntropy (alpha .25, gamma 2, per-sample SUM) and Keras BinaryCrossentropy
+    (from_logits=False, reduction NONE = per-sample MEAN) restated in focal_logits / bce_prob / focal_prob."""
     logits = np.asarray(logits, F64)
     gt_obs, gt_occ, gt_flow, origin_flow = (np.asarray(a, F64) for a in (gt_obs, gt_occ, gt_flow, origin_flow))
     B, H, W, _ = logits.shape
@@ -857,8 +882,11 @@ def ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin_flow, ogm_weight=1000.
     for k in range(8):
         po, pc, pf = logits[..., 4 * k:4 * k + 1], logits[..., 4 * k + 1:4 * k + 2], logits[..., 4 * k + 2:4 * k + 4]
         to, tc, tf_, org = gt_obs[:, k], gt_occ[:, k], gt_flow[:, k], origin_flow[:, k]
-        d['observed_xe'].append(ogm_weight * sigmoid_xe(to, po).sum() / (po.size * replica))      # :173-200
-        d['occluded_xe'].append(occ_weight * sigmoid_xe(tc, pc).sum() / (pc.size * replica))      # :202-229
+        xo, xc = sigmoid_xe(to, po).sum(), sigmoid_xe(tc, pc).sum()
+        if use_focal_loss:                                               # :183-190, :212-219: focal SUM + XE sum
+            xo, xc = xo + focal_logits(to, po).sum(), xc + focal_logits(tc, pc).sum()
+        d['observed_xe'].append(ogm_weight * xo / (po.size * replica))   # :173-200
+        d['occluded_xe'].append(occ_weight * xc / (pc.size * replica))   # :202-229
         true_all = np.clip(to + tc, 0, 1)
         if use_gt:                                                       # :127-137
             wp = sample(org, ident[None] + tf_)
@@ -875,9 +903,17 @@ def ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin_flow, ogm_weight=1000.
         d['flow'].append(res * fl)
         if not no_use_warp:                                              # :144-158, quirk App. D-8
             wpo = sample(org, ident[None] + pf)
-            sig = np.clip(1 / (1 + np.exp(-to)) + 1 / (1 + np.exp(-tc)), 0, 1)
+            a, b = (po, pc) if use_pred else (to, tc)                    # :151-158: predicted logits or (quirk) GT occupancies
+            sig = np.clip(1 / (1 + np.exp(-a)) + 1 / (1 + np.exp(-b)), 0, 1)
             joint = sig * wpo
-            d['flow_warp_xe'].append(res * flow_origin_weight * sigmoid_xe(true_all, joint).sum() / (true_all.size * replica))
+            bce_mean = bce_prob(true_all, joint).reshape(B, -1).mean(-1).sum()   # Keras BinaryCrossentropy, reduction NONE -> [B]
+            if use_pred:
+                xw = bce_mean                                            # :265 overwrites whatever :261-264 computed
+            elif use_focal_loss:
+                xw = focal_prob(true_all, joint).sum() + bce_mean        # :244-245
+            else:
+                xw = sigmoid_xe(true_all, joint).sum()                   # :247
+            d['flow_warp_xe'].append(res * flow_origin_weight * xw / (true_all.size * replica))
     out = dict(observed_xe=sum(d['observed_xe']) / 8, occluded_xe=sum(d['occluded_xe']) / 8,
                flow=sum(d['flow']) / sum(f_c),
                flow_warp_xe=(sum(d['flow_warp_xe']) / sum(f_c)) if not no_use_warp else 0.0)

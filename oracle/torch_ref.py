@@ -340,9 +340,25 @@ def auc_pr_bucketised(y_true, y_pred, n=100):
     return float(dnn(slope * (dtp + icpt * torch.log(ratio)), (tp[1:] + fn[1:]).clamp(min=0)).sum())
 
 
+_EPS = float(np.float32(1e-7))
+_HI = float(np.float32(1.0) - np.float32(1e-7))
+
+
+def _bce_prob(y, q):
+    qc = q.clamp(_EPS, _HI)                       # torch.clamp, like tf.clip_by_value, passes the gradient on [min, max]
+    return -(y * torch.log(qc + _EPS) + (1 - y) * torch.log(1 - qc + _EPS))
+
+
+def _focal(y, prob, ce):
+    p_t = y * prob + (1 - y) * (1 - prob)
+    return (y * 0.25 + (1 - y) * 0.75) * (1 - p_t) ** 2 * ce
+
+
 def loss(logits, gt_obs, gt_occ, gt_flow, origin_flow, replica=1.0, use_gt=True,
-         ogm_weight=1000.0, occ_weight=1000.0, flow_origin_weight=1000.0):
-    """OGMFlow_loss with train.py:195-196 flags (use_focal_loss=False, use_pred=False, no_use_warp=False)."""
+         ogm_weight=1000.0, occ_weight=1000.0, flow_origin_weight=1000.0, use_focal_loss=False, use_pred=False,
+         no_use_warp=False):
+    """OGMFlow_loss (loss.py:50-170); the defaults are the train.py:195-196 flags.  Differentiable twin of
+    np_ref.ogm_flow_loss, independently written."""
     B, H, W, _ = logits.shape
     yy, xx = torch.meshgrid(torch.arange(H, dtype=logits.dtype), torch.arange(W, dtype=logits.dtype), indexing='ij')
     ident = torch.stack((xx, yy), -1)[None]
@@ -352,8 +368,13 @@ def loss(logits, gt_obs, gt_occ, gt_flow, origin_flow, replica=1.0, use_gt=True,
         po, pc, pf = logits[..., 4 * k:4 * k + 1], logits[..., 4 * k + 1:4 * k + 2], logits[..., 4 * k + 2:4 * k + 4]
         to, tc, tf_, org = gt_obs[:, k], gt_occ[:, k], gt_flow[:, k], origin_flow[:, k]
         n = po.numel() * replica
-        tot['observed_xe'] = tot['observed_xe'] + ogm_weight * F.binary_cross_entropy_with_logits(po, to, reduction='sum') / n
-        tot['occluded_xe'] = tot['occluded_xe'] + occ_weight * F.binary_cross_entropy_with_logits(pc, tc, reduction='sum') / n
+        xo = F.binary_cross_entropy_with_logits(po, to, reduction='sum')
+        xc = F.binary_cross_entropy_with_logits(pc, tc, reduction='sum')
+        if use_focal_loss:
+            xo = xo + _focal(to, torch.sigmoid(po), F.binary_cross_entropy_with_logits(po, to, reduction='none')).sum()
+            xc = xc + _focal(tc, torch.sigmoid(pc), F.binary_cross_entropy_with_logits(pc, tc, reduction='none')).sum()
+        tot['observed_xe'] = tot['observed_xe'] + ogm_weight * xo / n
+        tot['occluded_xe'] = tot['occluded_xe'] + occ_weight * xc / n
         ta = (to + tc).clamp(0, 1)
         res = 1.0
         if use_gt:
@@ -365,12 +386,21 @@ def loss(logits, gt_obs, gt_occ, gt_flow, origin_flow, replica=1.0, use_gt=True,
         den = ex.sum() * replica / 2
         fl = ((tf_ - pf) * ex).abs().sum() / den if float(den) != 0 else 0.0
         tot['flow'] = tot['flow'] + res * fl
+        if no_use_warp:
+            continue
         wpo = _sample(org, ident + pf)
-        joint = (torch.sigmoid(to) + torch.sigmoid(tc)).clamp(0, 1) * wpo
-        tot['flow_warp_xe'] = tot['flow_warp_xe'] + res * flow_origin_weight * \
-            F.binary_cross_entropy_with_logits(joint, ta, reduction='sum') / (ta.numel() * replica)
+        a, b = (po, pc) if use_pred else (to, tc)
+        joint = (torch.sigmoid(a) + torch.sigmoid(b)).clamp(0, 1) * wpo
+        bce_mean = _bce_prob(ta, joint).reshape(B, -1).mean(-1).sum()
+        if use_pred:
+            xw = bce_mean
+        elif use_focal_loss:
+            xw = _focal(ta, joint, _bce_prob(ta, joint)).sum() + bce_mean
+        else:
+            xw = F.binary_cross_entropy_with_logits(joint, ta, reduction='sum')
+        tot['flow_warp_xe'] = tot['flow_warp_xe'] + res * flow_origin_weight * xw / (ta.numel() * replica)
     return dict(observed_xe=tot['observed_xe'] / 8, occluded_xe=tot['occluded_xe'] / 8,
-                flow=tot['flow'] / fc, flow_warp_xe=tot['flow_warp_xe'] / fc)
+                flow=tot['flow'] / fc, flow_warp_xe=(tot['flow_warp_xe'] / fc) if not no_use_warp else 0.0)
 
 
 def to_torch(d, dtype=torch.float64, requires_grad=False):

@@ -1,5 +1,5 @@
 // OGMFlow loss, fused: one streaming pass over the [B,H,W,32] logits + ground truth for the forward sums,
-// one for d(loss)/d(logits).  Restates OGMFlow_loss.__call__ (reference loss.py:50-170) with the flags
+// one for d(loss)/d(logits).  Restates OGMFlow_loss.__call__ (reference loss.py:50-170).  With the flags
 // train.py:195-196 uses (use_focal_loss=False, use_pred=False, no_use_warp=False):
 //   observed_xe / occluded_xe : sigmoid cross entropy sums (loss.py:173-229)
 //   flow                      : masked L1 (loss.py:273-295)
@@ -7,6 +7,12 @@
 //                               (loss.py:144-158,231-250 -- the quirk of SURVEY App. D-8 is reproduced)
 //   use_gt gate               : res_k = [PR-AUC(true_all, warp(origin, id+gt_flow)*true_all) > 0]  (loss.py:127-137),
 //                               Keras AUC(num_thresholds=100, curve='PR', summation 'interpolation') restated below.
+// The constructor defaults (use_focal_loss=True) and use_pred=True are template variants of the same two kernels:
+//   focal (loss.py:183-190,212-219): obs/occ pixel term = XE + tfa sigmoid_focal_crossentropy(from_logits, alpha .25, gamma 2);
+//   focal warp (loss.py:244-245)   : focal on PROBABILITIES q (Keras backend BCE, q clipped to [1e-7, 1-1e-7]) summed over
+//                                    pixels + Keras BinaryCrossentropy = per-sample MEAN over pixels, summed over the batch;
+//   use_pred (loss.py:253-268)     : q = clip(sig(pred_obs)+sig(pred_occ),0,1) * warp, and only the per-sample-mean BCE
+//                                    survives (loss.py:265 overwrites xe_sum); gradients reach obs, occ and flow logits.
 // Channel slicing of the logits follows train.py:105-123: 4k+0 obs, 4k+1 occ, 4k+2..3 flow (dx,dy).
 #include "common.h"
 
@@ -18,6 +24,49 @@ __device__ __forceinline__ float xe_logits(float z, float x) {   // tf.nn.sigmoi
   return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+// XE + tfa focal term on a logit x with label y; *d = derivative w.r.t. x when d != NULL
+__device__ __forceinline__ float xe_focal_logits(float y, float x, float* d) {
+  const float ce = xe_logits(y, x), p = sigmoidf(x);
+  const float pt = y * p + (1.f - y) * (1.f - p), at = y * 0.25f + (1.f - y) * 0.75f, om = 1.f - pt;
+  if (d) {
+    const float dce = p - y, dpt = (2.f * y - 1.f) * p * (1.f - p);
+    *d = dce + at * (om * om * dce - 2.f * om * dpt * ce);
+  }
+  return ce + at * om * om * ce;
+}
+// Keras backend binary_crossentropy(from_logits=False): clip to [eps, 1-eps], -(y log(q+eps) + (1-y) log(1-q+eps));
+// tf.clip_by_value passes the gradient for eps <= q <= 1-eps (bounds included)
+__device__ __forceinline__ float bce_prob(float y, float q, float* d) {
+  const float eps = 1e-7f, hi = 1.f - 1e-7f;
+  const float qc = fminf(fmaxf(q, eps), hi);
+  if (d) *d = (q >= eps && q <= hi) ? (1.f - y) / (1.f - qc + eps) - y / (qc + eps) : 0.f;
+  return -(y * logf(qc + eps) + (1.f - y) * logf(1.f - qc + eps));
+}
+// tfa focal term on a probability q (pred_prob = q unclipped, ce = bce_prob)
+__device__ __forceinline__ float focal_prob(float y, float q, float* d) {
+  float dce;
+  const float ce = bce_prob(y, q, &dce);
+  const float pt = y * q + (1.f - y) * (1.f - q), at = y * 0.25f + (1.f - y) * 0.75f, om = 1.f - pt;
+  if (d) *d = at * (om * om * dce - 2.f * om * (2.f * y - 1.f) * ce);
+  return at * om * om * ce;
+}
+// the warp-consistency pixel term on the joint probability q with label ta; inv_hw = 1 / (H*W)
+template <bool FOCAL, bool PRED>
+__device__ __forceinline__ float warp_term(float ta, float q, float inv_hw, float* d) {
+  if (PRED) {
+    const float v = bce_prob(ta, q, d);
+    if (d) *d *= inv_hw;
+    return v * inv_hw;
+  }
+  if (FOCAL) {
+    float d0, d1;
+    const float v = focal_prob(ta, q, &d0) + bce_prob(ta, q, &d1) * inv_hw;
+    if (d) *d = d0 + d1 * inv_hw;
+    return v;
+  }
+  if (d) *d = sigmoidf(q) - ta;
+  return xe_logits(ta, q);
+}
 
 // bilinear sample of a single-channel [H][W] image at (x,y) (sample(): pad 1, warp+1); optionally d/dx, d/dy
 __device__ __forceinline__ float warp_sample(const float* img, int H, int W, float x, float y, float* ddx, float* ddy) {
@@ -111,10 +160,12 @@ __global__ __launch_bounds__(128) void auc_gate_kernel(const int* hist, float* g
 }
 
 // ---- forward sums -------------------------------------------------------------------------------------
+template <bool FOCAL, bool PRED>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* logits, const float* gt_obs, const float* gt_occ,
                                                        const float* gt_flow, const float* origin, float* sums,
                                                        int B, int H, int W, int use_warp) {
   __shared__ float red[4][NWP * S_N];
+  const float inv_hw = 1.f / ((float)H * (float)W);
   float acc[NWP * S_N];
 #pragma unroll
   for (int i = 0; i < NWP * S_N; ++i) acc[i] = 0.f;
@@ -133,17 +184,18 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* logits, cons
       const long long g = ((b * NWP + k) * H + y) * W + x;
       const float to = gt_obs[g], tc = gt_occ[g];
       const float fx = gt_flow[2 * g], fy = gt_flow[2 * g + 1];
-      acc[k * S_N + S_OBS] += xe_logits(to, lg[4 * k]);
-      acc[k * S_N + S_OCC] += xe_logits(tc, lg[4 * k + 1]);
+      acc[k * S_N + S_OBS] += FOCAL ? xe_focal_logits(to, lg[4 * k], nullptr) : xe_logits(to, lg[4 * k]);
+      acc[k * S_N + S_OCC] += FOCAL ? xe_focal_logits(tc, lg[4 * k + 1], nullptr) : xe_logits(tc, lg[4 * k + 1]);
       const float ex = (fx != 0.f || fy != 0.f) ? 1.f : 0.f;
       acc[k * S_N + S_L1] += (fabsf(fx - lg[4 * k + 2]) + fabsf(fy - lg[4 * k + 3])) * ex;
       acc[k * S_N + S_EX] += ex;
       if (use_warp) {
         const float* img = origin + (b * NWP + k) * (long long)H * W;
         const float wp = warp_sample(img, H, W, (float)x + lg[4 * k + 2], (float)y + lg[4 * k + 3], nullptr, nullptr);
-        const float sg = fminf(fmaxf(sigmoidf(to) + sigmoidf(tc), 0.f), 1.f);
+        const float sg = PRED ? fminf(fmaxf(sigmoidf(lg[4 * k]) + sigmoidf(lg[4 * k + 1]), 0.f), 1.f)
+                              : fminf(fmaxf(sigmoidf(to) + sigmoidf(tc), 0.f), 1.f);
         const float ta = fminf(fmaxf(to + tc, 0.f), 1.f);
-        acc[k * S_N + S_WARP] += xe_logits(ta, sg * wp);
+        acc[k * S_N + S_WARP] += warp_term<FOCAL, PRED>(ta, sg * wp, inv_hw, nullptr);
       }
     }
   }
@@ -184,6 +236,7 @@ __global__ void loss_finalize_kernel(const float* sums, const float* gate, float
 }
 
 // dlogits[B,H,W,32] = sum_j up[j] * d loss_j / d logits
+template <bool FOCAL, bool PRED>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* logits, const float* gt_obs, const float* gt_occ,
                                                        const float* gt_flow, const float* origin, const float* coef,
                                                        const float* up, float* dlogits, int B, int H, int W, int use_warp) {
@@ -191,6 +244,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* logits, cons
   if (threadIdx.x < NWP * 4) cf[threadIdx.x] = coef[threadIdx.x] * up[threadIdx.x & 3];
   __syncthreads();
   const long long npix = (long long)B * H * W;
+  const float inv_hw = 1.f / ((float)H * (float)W);
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += gridDim.x * 256ll) {
     const int x = (int)(i % W); long long t = i / W;
     const int y = (int)(t % H); const long long b = t / H;
@@ -205,8 +259,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* logits, cons
       const long long g = ((b * NWP + k) * H + y) * W + x;
       const float to = gt_obs[g], tc = gt_occ[g];
       const float fx = gt_flow[2 * g], fy = gt_flow[2 * g + 1];
-      dl[4 * k] = cf[4 * k] * (sigmoidf(lg[4 * k]) - to);
-      dl[4 * k + 1] = cf[4 * k + 1] * (sigmoidf(lg[4 * k + 1]) - tc);
+      float g0, g1;
+      if (FOCAL) { xe_focal_logits(to, lg[4 * k], &g0); xe_focal_logits(tc, lg[4 * k + 1], &g1); }
+      else { g0 = sigmoidf(lg[4 * k]) - to; g1 = sigmoidf(lg[4 * k + 1]) - tc; }
+      g0 *= cf[4 * k]; g1 *= cf[4 * k + 1];
       const float ex = (fx != 0.f || fy != 0.f) ? 1.f : 0.f;
       const float d0 = fx - lg[4 * k + 2], d1 = fy - lg[4 * k + 3];
       float g2 = -cf[4 * k + 2] * ex * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
@@ -215,12 +271,22 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* logits, cons
         const float* img = origin + (b * NWP + k) * (long long)H * W;
         float ddx, ddy;
         const float wp = warp_sample(img, H, W, (float)x + lg[4 * k + 2], (float)y + lg[4 * k + 3], &ddx, &ddy);
-        const float sg = fminf(fmaxf(sigmoidf(to) + sigmoidf(tc), 0.f), 1.f);
+        const float sa = sigmoidf(PRED ? lg[4 * k] : to), sb = sigmoidf(PRED ? lg[4 * k + 1] : tc);
+        const float ssum = sa + sb;
+        const float sg = fminf(fmaxf(ssum, 0.f), 1.f);
         const float ta = fminf(fmaxf(to + tc, 0.f), 1.f);
-        const float dj = cf[4 * k + 3] * (sigmoidf(sg * wp) - ta) * sg;
-        g2 += dj * ddx;
-        g3 += dj * ddy;
+        float dq;
+        warp_term<FOCAL, PRED>(ta, sg * wp, inv_hw, &dq);
+        dq *= cf[4 * k + 3];
+        g2 += dq * sg * ddx;
+        g3 += dq * sg * ddy;
+        if (PRED && ssum <= 1.f) {          // clip_by_value passes the gradient inside [0, 1] (sum of two sigmoids > 0)
+          g0 += dq * wp * sa * (1.f - sa);
+          g1 += dq * wp * sb * (1.f - sb);
+        }
       }
+      dl[4 * k] = g0;
+      dl[4 * k + 1] = g1;
       dl[4 * k + 2] = g2;
       dl[4 * k + 3] = g3;
     }
@@ -243,20 +309,28 @@ extern "C" int stj_loss_auc_gate(const float* gt_obs, const float* gt_occ, const
 // sums: f32[40] scratch, MUST BE ZERO on entry; loss f32[4]; coef f32[32]
 extern "C" int stj_loss_fwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                             const float* gate, float* sums, float* loss, float* coef, int B, int H, int W, float ogm_w, float occ_w,
-                            float flow_origin_w, float replica, int use_warp, hipStream_t stream) {
+                            float flow_origin_w, float replica, int flags, hipStream_t stream) {
   if (((uintptr_t)logits) & 15) { stj_set_error("loss: logits must be 16-byte aligned"); return STJ_EINVAL; }
+  if (flags & ~7) { stj_set_error("loss: unknown flag bits %d", flags); return STJ_EINVAL; }
   const long long npix = (long long)B * H * W;
   const int gx = (int)min(2048ll, (npix + 255) / 256);
-  hipLaunchKernelGGL(loss_fwd_kernel, dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, sums, B, H, W, use_warp);
+  const int use_warp = flags & 1, focal = (flags >> 1) & 1, pred = (flags >> 2) & 1;
+#define LOSS_FWD(FO, PR) hipLaunchKernelGGL((loss_fwd_kernel<FO, PR>), dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, sums, B, H, W, use_warp)
+  if (focal && pred) LOSS_FWD(true, true); else if (focal) LOSS_FWD(true, false); else if (pred) LOSS_FWD(false, true); else LOSS_FWD(false, false);
+#undef LOSS_FWD
   LossCfg c; c.ogm_w = ogm_w; c.occ_w = occ_w; c.fow = flow_origin_w; c.replica = replica; c.use_warp = use_warp;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, gate, loss, coef, (float)npix, c);
   return stj_check_launch("stj_loss_fwd");
 }
 extern "C" int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
-                            const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int use_warp, hipStream_t stream) {
+                            const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int flags, hipStream_t stream) {
+  if (flags & ~7) { stj_set_error("loss: unknown flag bits %d", flags); return STJ_EINVAL; }
   const long long npix = (long long)B * H * W;
   const int gx = (int)min(4096ll, (npix + 255) / 256);
-  hipLaunchKernelGGL(loss_bwd_kernel, dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, coef, upstream, dlogits, B, H, W, use_warp);
+  const int use_warp = flags & 1, focal = (flags >> 1) & 1, pred = (flags >> 2) & 1;
+#define LOSS_BWD(FO, PR) hipLaunchKernelGGL((loss_bwd_kernel<FO, PR>), dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, coef, upstream, dlogits, B, H, W, use_warp)
+  if (focal && pred) LOSS_BWD(true, true); else if (focal) LOSS_BWD(true, false); else if (pred) LOSS_BWD(false, true); else LOSS_BWD(false, false);
+#undef LOSS_BWD
   return stj_check_launch("stj_loss_bwd");
 }
 

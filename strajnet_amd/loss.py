@@ -71,12 +71,8 @@ def warpped_gt(gt_ogm, gt_occ, gt_flow, origin_flow):
 class OGMFlow_loss:
     def __init__(self, config, ogm_weight=1000.0, occ_weight=1000.0, flow_weight=1.0, replica=1.0,
                  flow_origin_weight=1000.0, no_use_warp=False, use_pred=False, use_focal_loss=True, use_gt=False):
-        if use_focal_loss:
-            raise NotImplementedError('use_focal_loss=True (tfa SigmoidFocalCrossEntropy) is off the timed path '
-                                      '(train.py:196 passes False) and is not built')
-        if use_pred:
-            raise NotImplementedError('use_pred=True is not built (train.py:195 passes False)')
         self.config = config
+        self.use_focal_loss, self.use_pred = bool(use_focal_loss), bool(use_pred)
         self.ogm_weight, self.occ_weight = ogm_weight, occ_weight
         self.flow_weight = flow_weight            # stored but never applied, as in the reference (loss.py:29,141)
         self.replica = replica
@@ -109,6 +105,7 @@ class OGMFlow_loss:
         else:
             gate = torch.ones(8, dtype=torch.float32, device=logits.device)
         loss = ops.ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin, gate, self.ogm_weight, self.occ_weight,
-                                 self.flow_origin_weight, self.replica, not self.no_use_warp)
+                                 self.flow_origin_weight, self.replica,
+                                 (0 if self.no_use_warp else 1) | (2 if self.use_focal_loss else 0) | (4 if self.use_pred else 0))
         return {'observed_xe': loss[0], 'occluded_xe': loss[1], 'flow': loss[2],
                 'flow_warp_xe': loss[3] if not self.no_use_warp else 0.0}

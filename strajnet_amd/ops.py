@@ -822,7 +822,7 @@ def outconv_pair(xo, xf, p1w, p1b, p2w, p2b, B, Tn, t_major=False, x_is_elu_out=
 # ----------------------------------------------------------------------------------------------------
 class _OgmFlowLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, use_warp):
+    def forward(ctx, logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, flags):
         _req_cuda(logits)
         logits = logits.contiguous().float()
         B, H, W, _ = logits.shape
@@ -831,19 +831,19 @@ class _OgmFlowLoss(torch.autograd.Function):
         loss = torch.empty(4, dtype=torch.float32, device=dev)
         coef = torch.empty(32, dtype=torch.float32, device=dev)
         call('stj_loss_fwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(sums), _p(loss), _p(coef),
-             B, H, W, float(ogm_w), float(occ_w), float(fow), float(replica), int(use_warp), _st())
-        ctx.geo = (B, H, W, int(use_warp))
+             B, H, W, float(ogm_w), float(occ_w), float(fow), float(replica), int(flags), _st())
+        ctx.geo = (B, H, W, int(flags))
         ctx.save_for_backward(logits, gt_obs, gt_occ, gt_flow, origin, coef)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         logits, gt_obs, gt_occ, gt_flow, origin, coef = ctx.saved_tensors
-        B, H, W, use_warp = ctx.geo
+        B, H, W, flags = ctx.geo
         up = dloss.contiguous().float()
         dlogits = torch.empty_like(logits)
         call('stj_loss_bwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(coef), _p(up), _p(dlogits), B, H, W,
-             use_warp, _st())
+             flags, _st())
         return (dlogits,) + (None,) * 10
 
 

@@ -379,28 +379,40 @@ def test_loss_and_gate():
     Hg = x['gt_obs'].shape[2]
     rng = np.random.default_rng(0)
     logits = rng.normal(0, 2, (2, Hg, Hg, 32)).astype(np.float32)
+    # predicted flow on a 1/16 lattice (never an integer): sample coordinates and bilinear weights are then exact in float32, so
+    # the float64 oracle sees the same joint probability q -- the BCE-on-probabilities gradients go like 1/q and would otherwise
+    # carry the 1 % coordinate rounding of q ~ 1e-5 pixels, which is float32 arithmetic (the reference's too), not the formula
+    fl = logits.reshape(2, Hg, Hg, 8, 4)[..., 2:]
+    fl[...] = (np.round(fl * 8) + 0.5) / 8
     x['gt_obs'][:, 3] = 0
     x['gt_occ'][:, 3] = 0                        # waypoint 3: no positives -> AUC 0 -> gate 0 (loss.py:137)
     gt = {k: torch.as_tensor(x[k]).cuda() for k in ('gt_obs', 'gt_occ', 'gt_flow', 'origin_flow')}
     lt = torch.as_tensor(logits).cuda().requires_grad_(True)
-    for use_gt in (True, False):
-        lt.grad = None
-        loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(Hg, Hg, 8), replica=2.0, use_focal_loss=False, use_gt=use_gt)
-        d = loss_fn(get_pred_waypoint_logits(lt), warpped_gt(gt['gt_obs'], gt['gt_occ'], gt['gt_flow'], gt['origin_flow']), None)
-        ref, gates = np_ref.ogm_flow_loss(logits, x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow'], replica=2.0,
-                                          use_gt=use_gt, return_gates=True)
-        if use_gt:
-            assert gates[3] == 0.0 and sum(gates) == 7.0
-            g, auc = ops.auc_gate(gt['gt_obs'], gt['gt_occ'], gt['gt_flow'], gt['origin_flow'], return_auc=True)
-            assert g.cpu().tolist() == gates
-        for k in ref:
-            assert abs(float(d[k]) - float(ref[k])) <= 2e-5 * abs(float(ref[k])) + 1e-6, (k, float(d[k]), float(ref[k]))
-        sum(d.values()).backward()
-        lr = torch.as_tensor(logits).double().requires_grad_(True)
-        gtr = {k: torch.as_tensor(x[k]).double() for k in gt}
-        dr = torch_ref.loss(lr, gtr['gt_obs'], gtr['gt_occ'], gtr['gt_flow'], gtr['origin_flow'], replica=2.0, use_gt=use_gt)
-        sum(dr.values()).backward()
-        assert rel_err(lt.grad, lr.grad) < 1e-4
+    # flags: the train.py:195-196 set, the constructor defaults (focal), use_pred with and without focal, no_use_warp
+    combos = [dict(use_focal_loss=False), dict(use_focal_loss=True), dict(use_focal_loss=False, use_pred=True),
+              dict(use_focal_loss=True, use_pred=True), dict(use_focal_loss=True, no_use_warp=True)]
+    for flags in combos:
+        for use_gt in (True, False):
+            lt.grad = None
+            loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(Hg, Hg, 8), replica=2.0, use_gt=use_gt, **flags)
+            d = loss_fn(get_pred_waypoint_logits(lt), warpped_gt(gt['gt_obs'], gt['gt_occ'], gt['gt_flow'], gt['origin_flow']), None)
+            ref, gates = np_ref.ogm_flow_loss(logits, x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow'], replica=2.0,
+                                              use_gt=use_gt, return_gates=True, **flags)
+            if use_gt:
+                assert gates[3] == 0.0 and sum(gates) == 7.0
+                g, auc = ops.auc_gate(gt['gt_obs'], gt['gt_occ'], gt['gt_flow'], gt['origin_flow'], return_auc=True)
+                assert g.cpu().tolist() == gates
+            for k in ref:
+                v = float(d[k].detach()) if torch.is_tensor(d[k]) else float(d[k])
+                assert abs(v - float(ref[k])) <= 3e-5 * abs(float(ref[k])) + 1e-6, (flags, k, v, float(ref[k]))
+            sum(d.values()).backward()
+            lr = torch.as_tensor(logits).double().requires_grad_(True)
+            gtr = {k: torch.as_tensor(x[k]).double() for k in gt}
+            dr = torch_ref.loss(lr, gtr['gt_obs'], gtr['gt_occ'], gtr['gt_flow'], gtr['origin_flow'], replica=2.0, use_gt=use_gt, **flags)
+            sum(dr.values()).backward()
+            assert rel_err(lt.grad, lr.grad) < 1e-4, flags
+    d0 = OGMFlow_loss(OccupancyFlowTaskConfig(Hg, Hg, 8))                  # the reference's own defaults construct and run
+    assert d0.use_focal_loss and not d0.use_gt and not d0.use_pred
 
 
 @pytest.mark.parametrize('dt', DTYPES)

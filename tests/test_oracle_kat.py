@@ -154,3 +154,22 @@ def test_metrics_kats():
     yp = y.copy(); yp[..., 0::4] = sig[..., 0::4]; yp[..., 1::4] = sig[..., 1::4]
     m3 = R.occupancy_flow_metrics(yp, go, gc, gf, org, pred_is_logits=False)
     assert np.allclose(m, m3, atol=1e-12)
+
+
+def test_focal_and_keras_bce_known_answers():
+    """tfa sigmoid_focal_crossentropy (alpha .25, gamma 2) and Keras backend BCE on probabilities, by hand."""
+    from oracle import np_ref as R
+    ln2 = np.log(2.0)
+    # y=1, logit 0: ce = ln 2, p_t = .5, alpha_t = .25, (1-p_t)^2 = .25
+    assert abs(float(R.focal_logits(np.array(1.0), np.array(0.0))) - 0.25 * 0.25 * ln2) < 1e-12
+    # y=0, logit 0: alpha_t = .75
+    assert abs(float(R.focal_logits(np.array(0.0), np.array(0.0))) - 0.75 * 0.25 * ln2) < 1e-12
+    # confident and right -> modulating factor kills the term; confident and wrong -> ~alpha_t * ce
+    assert float(R.focal_logits(np.array(1.0), np.array(20.0))) < 1e-20
+    assert abs(float(R.focal_logits(np.array(1.0), np.array(-20.0))) - 0.25 * 20.0) < 1e-6
+    eps = float(np.float32(1e-7))
+    assert abs(float(R.bce_prob(np.array(1.0), np.array(0.5))) + np.log(0.5 + eps)) < 1e-15
+    assert abs(float(R.bce_prob(np.array(1.0), np.array(0.0))) + np.log(2 * eps)) < 1e-12          # clipped to eps, + eps
+    assert abs(float(R.bce_prob(np.array(0.0), np.array(0.0))) + np.log(1 - eps + eps)) < 1e-12    # == 0 up to rounding
+    # probability form of the focal term: y=1, q=.5 -> .25 * .25 * bce
+    assert abs(float(R.focal_prob(np.array(1.0), np.array(0.5))) - 0.0625 * float(R.bce_prob(np.array(1.0), np.array(0.5)))) < 1e-15
