@@ -155,6 +155,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying the captured hipGraph')
     ap.add_argument('--cfg512', action='store_true', help='BASELINE config 5 instead of the metric config: 512x512 rasters, large_ogm, depths [2,2,6] (extra measurement, not the headline)')
     ap.add_argument('--infer', action='store_true', help='BASELINE config 4 instead of the metric config: inference-only forward, batch 32/GPU, fp16 MFMA path, hipGraph replay (extra measurement, not the headline)')
+    ap.add_argument('--no-optimizer', action='store_true', help='time fwd + loss + bwd (+ all-reduce) only, without the fused Keras-Nadam update (train.py:197,224) that the default step ends with')
     ap.add_argument('--serial', action='store_true', help='no side streams: every kernel runs alone (the mode the roofline kernel timings are taken in)')
     ap.add_argument('--gemm-trace', action='store_true', help='print per-shape GEMM launch times (HIP events) to stderr')
     args = ap.parse_args()
@@ -201,14 +202,23 @@ def main():
     if args.infer:
         return bench_infer(args, model, x, world, rank, dist)
 
+    from strajnet_amd import Nadam
+    opt = None if args.no_optimizer else Nadam.for_model(model, lr=1e-4)        # train.py:197
+
+    def finish_step():
+        # the exchange step of data parallelism (one SUM all-reduce of the flat f32 gradient bucket), then the optimizer on it
+        if world > 1:
+            dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
+        if opt is not None:
+            opt.step()
+
     def step():
         model.zero_grad()
         out = model(x['ogm'], x['map_img'], training=True, obs=x['obs'], occ=x['occ'], mapt=x['mapt'], flow=x['flow'])
         d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
         total = d['observed_xe'] + d['occluded_xe'] + d['flow'] + d['flow_warp_xe']
         total.backward()
-        if world > 1:
-            dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
+        finish_step()
         return total
 
     graphed = None
@@ -223,8 +233,7 @@ def main():
 
     def step_graph():
         losses = graphed()
-        if world > 1:
-            dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
+        finish_step()
         return losses.sum()
     if graphed is not None:
         step = step_graph
@@ -242,6 +251,23 @@ def main():
         last = step()
     barrier()
     dt_s = time.perf_counter() - t0
+    # the exchange step on its own (measured all-reduce time next to the ring model), outside the timed region
+    allreduce = None
+    if world > 1:
+        g = model.flat_grads()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        barrier()
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        nbytes = g.numel() * 4
+        allreduce = {'ms': round(ms, 4), 'mbytes': round(nbytes / 1e6, 1), 'collective': 'all_reduce(sum, f32), one bucket after backward',
+                     'busbw_GBps': round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1),
+                     'frac_of_step': round(ms / (dt_s / args.steps * 1e3), 4)}
     # per-kernel HIP-event timing of the conv kernels (roofline of the dominant one): the same launches, issued eagerly
     # with events recorded on the launch stream -- under graph replay individual launches cannot carry events
     prof = prof_conc = None
@@ -311,11 +337,12 @@ def main():
             'metric': 'scenes/sec (fwd+bwd, 256x256 grids)', 'value': round(value, 3), 'unit': 'scenes/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt_s / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'STrajNet {"cfg-512 (large_ogm, depths [2,2,6])" if args.cfg512 else "cfg-256"} train step (fwd+OGMFlow_loss+bwd{"+RCCL grad all-reduce" if world > 1 else ""}), '
+            'config': {'workload': f'STrajNet {"cfg-512 (large_ogm, depths [2,2,6])" if args.cfg512 else "cfg-256"} train step (fwd+OGMFlow_loss+bwd{"+RCCL grad all-reduce" if world > 1 else ""}{"+Nadam" if opt is not None else ""}), '
                                    f'batch {B}/GPU, 8 waypoints, obs+occ+flow heads, fg_msa+fg, random-init weights',
                        'global_batch': B * world, 'grid': '256x256x11', 'parallelism': f'dp{world}', 'hipgraph': graphed is not None, 'concurrent_branch_streams': not args.serial,
-                       'optimizer_in_step': False, 'algorithmic_gflop_per_scene_step': algo_step},
+                       'optimizer_in_step': opt is not None, 'algorithmic_gflop_per_scene_step': algo_step},
             'loss': round(loss_val, 4),
+            'allreduce': allreduce,
             'roofline': roof,
         }
         if prof:
