@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libstrajnet_hip.so')
+LIB_PATH = os.environ.get('STJ_LIB_PATH') or os.path.join(_HERE, 'libstrajnet_hip.so')     # override: A/B runs of two builds
 
 vp, ci, cl, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
 

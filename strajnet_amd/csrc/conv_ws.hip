@@ -248,9 +248,9 @@ __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __rest
   const int cin_tiles = (Cin + BI - 1) / BI;
   const int co0 = (ctile / cin_tiles) * BO, ci0 = (ctile % cin_tiles) * BI;
   const int segs = Wi / WG2_W, rgs = Hi / WG2_ROWS;
-  const long long nchunks = (long long)F * rgs * segs;
-  const long long c_begin = (long long)strip * chunks_per_block;
-  const long long c_end = min(nchunks, c_begin + chunks_per_block);
+  const int nchunks = F * rgs * segs;              // 32-bit on purpose: the per-chunk div / mod below is not free in 64 bits
+  const int c_begin = strip * chunks_per_block;
+  const int c_end = min(nchunks, c_begin + chunks_per_block);
   const int Ho = 2 * Hi, Wo = 2 * Wi;
 
   f32x4 acc[FO][FI];
@@ -262,9 +262,9 @@ __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __rest
   float dbacc = 0.f;
 
   uint4 pre[NCH];
-  auto prefetch = [&](long long c) {
-    const int seg = (int)(c % segs); long long t = c / segs;
-    const int i0 = (int)(t % rgs) * WG2_ROWS; const int f = (int)(t / rgs);
+  auto prefetch = [&](int c) {
+    const int seg = c % segs, t = c / segs;
+    const int i0 = (t % rgs) * WG2_ROWS, f = t / rgs;
     const int j0 = seg * WG2_W;
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __rest
   __syncthreads();
   // per-lane tr-read bases: lane p of group g addresses pixel (8g + p/4 [+4]) and channels 4*(p%4).. of a 16-channel block
   const int kpx = 8 * g + (p >> 2), kch = 4 * (p & 3);
-  for (long long c = c_begin; c < c_end; ++c) {
+  for (int c = c_begin; c < c_end; ++c) {
     if (c + 1 < c_end) prefetch(c + 1);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {              // k-step rr = pixels 32 rr .. 32 rr + 31 of the chunk (row-major)
@@ -651,10 +651,12 @@ bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* 
 // and leave as coalesced 8-byte segments.  v1 (conv.hip) re-staged 16 tap matrices through LDS per tile: 0.59 ms for
 // 96<-48 @128x128 (profiles/r01_b_*).
 // =====================================================================================================
-template <int KS, int NFI, bool ELU>
+template <int KS, int NFI, bool ELU, int COUT>
 __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ Wd,
                                                                  bf16* __restrict__ dX, const bf16* __restrict__ Xelu, int F, int Hi,
-                                                                 int Wi, int Cin, int Cout, int ntiles) {
+                                                                 int Wi, int Cin, int ntiles) {
+  constexpr int Cout = COUT;                       // compile time: the halo loader divides by Cout / 8 forty times per tile (a runtime
+                                                   // divisor cost ~1400 VALU instructions per tile, a quarter of the tile's time)
   constexpr int LDK = KS * 32 + (KS == 3 ? 8 : 16);   // halo pixel stride; +16 = conflict-free b128 reads (KS = 3: only +8 fits in 160 KB); channels >= Cout stay zero
   constexpr int HH = 2 * WS_TH + 2, HW = 2 * WS_TW + 2, HPIX = HH * HW;
   constexpr int CT = NFI * 16;                     // cin tile of this workgroup
@@ -662,7 +664,8 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16* halo = reinterpret_cast<bf16*>(smem_raw);                         // [HPIX][LDK] (+64 tail)
   float* red = reinterpret_cast<float*>(smem_raw + (size_t)(HPIX * LDK + 64) * 2);   // [4 waves][2 rows][16 px][LDR]
-  const int CPP = Cout / 8;                        // 16-byte chunks per halo pixel (runtime: Cout <= KS*32)
+  constexpr int CPP = Cout / 8;                    // 16-byte chunks per halo pixel (Cout <= KS*32)
+  static_assert(COUT % 8 == 0 && COUT <= KS * 32, "halo pixel holds KS*32 channels");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int a = w >> 1, b = w & 1;
   const int g = lane >> 4, ln = lane & 15;
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
   for (int i = tid; i < (HPIX * LDK + 64) / 2; i += 256) reinterpret_cast<uint32_t*>(halo)[i] = 0u;
   __syncthreads();
 
-  constexpr int NCH_MAX = (HPIX * (KS * 4) + 255) / 256;     // Cout/8 <= KS*4 chunks per pixel
+  constexpr int NCH_MAX = (HPIX * CPP + 255) / 256;
   uint4 pre[NCH_MAX];
   auto tile_coords = [&](int tile, int& f, int& ty0, int& tx0) {
     const int tx = tile % tiles_x; const int t2 = tile / tiles_x;
@@ -816,13 +819,13 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
   }
 }
 
-template <int KS, int NFI, bool ELU>
+template <int KS, int NFI, bool ELU, int COUT>
 static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   constexpr int LDK = KS * 32 + (KS == 3 ? 8 : 16), HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), CT = NFI * 16, LDR = CT + 4;
   const size_t lds = (size_t)(HPIX * LDK + 64) * 2 + (size_t)4 * 2 * 16 * LDR * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)upconv_dgrad_ws_kernel<KS, NFI, ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)upconv_dgrad_ws_kernel<KS, NFI, ELU, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
   }
   const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
@@ -830,18 +833,18 @@ static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const voi
   int nblk = 256 / ct;
   if (nblk > ntiles) nblk = ntiles;
   if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL((upconv_dgrad_ws_kernel<KS, NFI, ELU>), dim3(nblk, ct), dim3(256), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX,
-                     (const bf16*)Xelu, F, Hi, Wi, Cin, Cout, ntiles);
+  hipLaunchKernelGGL((upconv_dgrad_ws_kernel<KS, NFI, ELU, COUT>), dim3(nblk, ct), dim3(256), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX,
+                     (const bf16*)Xelu, F, Hi, Wi, Cin, ntiles);
   return true;
 }
-template <int KS, int NFI>
+template <int KS, int NFI, int COUT>
 static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
-  return Xelu ? dgrad_ws_launch2<KS, NFI, true>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st)
-              : dgrad_ws_launch2<KS, NFI, false>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
+  return Xelu ? dgrad_ws_launch2<KS, NFI, true, COUT>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st)
+              : dgrad_ws_launch2<KS, NFI, false, COUT>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
 }
 bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   if (Cout % 8 || Cin % 8) return false;
-  if (Cout == 48 && Cin == 96) return dgrad_ws_launch<2, 6>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
-  if (Cout == 96 && Cin == 128) return dgrad_ws_launch<3, 4>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
+  if (Cout == 48 && Cin == 96) return dgrad_ws_launch<2, 6, 48>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
+  if (Cout == 96 && Cin == 128) return dgrad_ws_launch<3, 4, 96>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
   return false;
 }
