@@ -151,7 +151,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU')
     ap.add_argument('--dtype', default=None, choices=['bf16', 'f32', 'f16'], help='default bf16 (train step) / f16 (--infer)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true', help='skip every extra pass after the timed region (per-kernel HIP-event timing, the optimizer-free repeat): the run then executes exactly warmup + steps steps (+ 2 capture warm-ups), which is what the rocprofv3 summaries divide by')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying the captured hipGraph')
     ap.add_argument('--cfg512', action='store_true', help='BASELINE config 5 instead of the metric config: 512x512 rasters, large_ogm, depths [2,2,6] (extra measurement, not the headline)')
     ap.add_argument('--infer', action='store_true', help='BASELINE config 4 instead of the metric config: inference-only forward, batch 32/GPU, fp16 MFMA path, hipGraph replay (extra measurement, not the headline)')
@@ -254,7 +254,7 @@ def main():
     # SURVEY 8(d) words the metric as fwd + loss + bwd (+ all-reduce) WITHOUT the optimizer: the same K steps again with the
     # Nadam launch left out, reported next to the headline (which includes it)
     fwd_bwd_only = None
-    if opt is not None:
+    if opt is not None and not args.no_kernel_timing:
         held, opt = opt, None
         step()
         barrier()
