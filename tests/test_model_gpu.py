@@ -427,6 +427,37 @@ def test_cpu_tensor_rejected():
         ops.gelu(torch.zeros(8))
 
 
+def test_golden_train_step_gradients_f32():
+    """One f32 train step of the HIP path against the committed gradient fixture (tests/golden/strajnet_128_b2_grads.npz, made by
+    make_golden_grads.py from the float64 oracle): the four losses, the L2 norm of each of the 299 gradient tensors and eight
+    small gradients element by element."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from oracle import np_ref
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'strajnet_128_b2_grads.npz'))
+    model, w, x, xt = _setup(CFG128, 2, torch.float32, seed=int(g['weight_seed']))
+    x2 = np_ref.make_inputs(CFG128, 2, seed=int(g['input_seed']))
+    assert all(np.array_equal(x[k], x2[k]) for k in x)               # _setup's default input seed is the fixture's
+    model.zero_grad()
+    out = _fwd(model, xt)
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(128, 128, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+    d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+    sum(d.values()).backward()
+    for i, k in enumerate(('observed_xe', 'occluded_xe', 'flow', 'flow_warp_xe')):
+        assert abs(float(d[k].detach()) - float(g['loss'][i])) < 1e-4 * abs(float(g['loss'][i])) + 1e-5, k
+    ref = dict(zip([str(n) for n in g['names']], g['grad_l2']))
+    gmax = float(g['grad_l2'].max())
+    worst = 0.0
+    for n, p in model.params.items():
+        e = abs(float(p.grad.double().norm()) - ref[n]) / (ref[n] + 1e-6 * gmax)
+        worst = max(worst, e)
+        assert e < 2e-3, (n, e)
+    for k in g.files:
+        if k.startswith('full:'):
+            got, want = model.params[k[5:]].grad.double().cpu().numpy(), g[k]
+            assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 1e-9, k
+    _report(f'golden train step 128x128 B=2 f32: worst relative error of the 299 gradient L2 norms {worst:.3e}')
+
+
 def test_golden_cfg256_f32():
     """Full-size cfg-256 (BASELINE configs[0] geometry) against the committed golden fixture (tests/golden, made by the
     oracle): logits subsample, per-row checksums and the 4 loss scalars."""
