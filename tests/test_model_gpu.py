@@ -427,6 +427,54 @@ def test_cpu_tensor_rejected():
         ops.gelu(torch.zeros(8))
 
 
+def test_bench_config_batch_permutation_bf16():
+    """Size-independent property at the bench configuration (cfg-256, B=8, bf16): scenes are independent units, so
+    permuting the batch permutes the outputs, leaves the (batch-mean) losses unchanged and leaves every gradient unchanged up to
+    the order of f32 accumulation."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from oracle import np_ref
+    cfg = dict(CFG128, input_size=(256, 256))
+    model, w, x, xt = _setup(cfg, 8, torch.bfloat16)
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(256, 256, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device='cuda')
+
+    def run(t):
+        model.zero_grad()
+        out = _fwd(model, t)
+        d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(t['gt_obs'], t['gt_occ'], t['gt_flow'], t['origin_flow']), None)
+        sum(d.values()).backward()
+        return out.detach().clone(), {k: float(v.detach()) for k, v in d.items()}, model.flat_grads().clone()
+    o1, l1, g1 = run(xt)
+    o2, l2, g2 = run({k: v[perm].contiguous() for k, v in xt.items()})
+    assert torch.equal(o1[perm], o2)                                   # per-scene work is identical wherever the scene sits
+    for k in l1:
+        assert abs(l1[k] - l2[k]) <= 1e-5 * abs(l1[k]) + 1e-6, (k, l1[k], l2[k])
+    assert float((g1 - g2).abs().max()) <= 2e-3 * float(g1.abs().max())
+    _report(f'batch permutation cfg-256 B=8 bf16: outputs identical, losses equal, max grad diff '
+            f'{float((g1 - g2).abs().max()):.2e} (|grad| max {float(g1.abs().max()):.2e})')
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The multi-process path of bench.py (rendezvous, replica-scaled loss, gradient all-reduce, Nadam, max-over-ranks timing, the
+    all-reduce probe) end to end with two ranks sharing this GPU over gloo (STJ_BENCH_SHARE_GPU test hook; RCCL needs one device
+    per rank).  Not a measurement -- it guards the driver's N>1 run against plumbing errors."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, STJ_BENCH_SHARE_GPU='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+           '--no-kernel-timing', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                           # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
+    assert d['value'] > 0 and np.isfinite(d['loss']) and d['allreduce']['ms'] > 0 and d['allreduce']['mbytes'] > 50
+    assert d['config']['optimizer_in_step'] and d['scaling'] == 'weak'
+
+
 def test_golden_train_step_gradients_f32():
     """One f32 train step of the HIP path against the committed gradient fixture (tests/golden/strajnet_128_b2_grads.npz, made by
     make_golden_grads.py from the float64 oracle): the four losses, the L2 norm of each of the 299 gradient tensors and eight
