@@ -26,7 +26,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: calls that are illegal during capture only count against THIS thread -- a process-group watchdog thread
+        # (RCCL, data parallel runs) querying its events must not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             self.losses = self._eager()
         self.graph = g
 
@@ -68,7 +70,7 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.out = self._eager()
 
     def _eager(self):
