@@ -77,8 +77,10 @@ int stj_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
  * qkv [B,res*res,3*heads*32] in original token order, table f32 [225,heads], out [B,res*res,heads*32]. */
 int stj_win_attn_fwd(const void* qkv, const float* table, void* out, int B, int res, int heads, int shift,
                      int dtype, hipStream_t stream);
-int stj_win_attn_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable,
+int stj_win_attn_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, int nparts,
                      int B, int res, int heads, int shift, int dtype, hipStream_t stream);
+/* bwd: dtable f32 [nparts][225,heads], "+=": workgroup i adds the bias-table gradient of its window into copy i % nparts and the
+ * caller sums the copies (one copy = hundreds of same-address atomics per table entry on the 64x64 stage; nparts = 1 is valid). */
 
 /* Row softmax of the global attentions: P = softmax(S + bias + (-10e9 where !(qvalid&kvalid))) (tfa MHA mask
  * semantics, f32 add); S f32 [batch,H,Nq,Nk] (Nk <= 256).  bwd: dS = P*(dP - sum(P dP)). */

@@ -21,6 +21,7 @@ template <> struct WinCfg<float> { static constexpr int WPB = 2; static constexp
 struct WinGeom {
   int B, res, heads, shift;
   long long items;
+  int nparts;      // backward: number of partial dtable copies the blocks spread their atomics over
 };
 
 __device__ __forceinline__ int win_token(int res, int shift, int wy, int wx, int t) {
@@ -165,7 +166,9 @@ __global__ __launch_bounds__(64 * WinCfg<T>::WPB) void win_attn_fwd_kernel(const
   }
 }
 
-// Backward.  dqkv [B,N,3C] gets dq,dk,dv;  dtable [225,heads] (f32) accumulated atomically.
+// Backward.  dqkv [B,N,3C] gets dq,dk,dv;  dtable [nparts][225,heads] (f32) accumulated atomically: block i adds into copy
+// i % nparts and the caller sums the copies.  With ONE copy the 1536 blocks of a 64x64 stage queue 512 same-address atomics on
+// each of the 675 table entries -- 34 of the kernel's 80 us (ablation, tools/probes/win_bwd_ablate.py).
 template <typename T>
 __global__ __launch_bounds__(64 * WinCfg<T>::WPB_BWD) void win_attn_bwd_kernel(const T* qkv, const float* table, const T* dout,
                                                                            T* dqkv, float* dtable, WinGeom g) {
@@ -281,17 +284,33 @@ __global__ __launch_bounds__(64 * WinCfg<T>::WPB_BWD) void win_attn_bwd_kernel(c
   zero(); prod(s_ds[w], LP, false, s_k[w]); store(0, scale);
   // dK[key][d] = scale * sum_q dS[q][key] Q[q][d]     A(tok=key, k=q) = s_ds [q][key] -> transposed read
   zero(); prod(s_ds[w], LP, true, s_q[w]); store(1, scale);
-  // relative-position-bias gradient: bin (dy, dx) collects dS[(ry,rx)][(ry-dy, rx-dx)] over the window.  Gathered from the
-  // stashed dS tile (<= 64 plain LDS reads per bin) instead of 4096 LDS atomics per window that serialised on 225 bins.
-  if (live) {
-    for (int bin = lane; bin < (2 * WS - 1) * (2 * WS - 1); bin += 64) {
-      const int dy = bin / (2 * WS - 1) - (WS - 1), dx = bin % (2 * WS - 1) - (WS - 1);
-      float sacc = 0.f;
-      for (int ry = max(0, dy); ry <= min(WS - 1, WS - 1 + dy); ++ry)
-        for (int rx = max(0, dx); rx <= min(WS - 1, WS - 1 + dx); ++rx)
-          sacc += ldf(s_ds[w] + (ry * WS + rx) * LP + (ry - dy) * WS + (rx - dx));
-      atomicAdd(dtable + bin * g.heads + h, sacc);
+  // relative-position-bias gradient: bin (dy, dx) collects dS[(ry,rx)][(ry-dy, rx-dx)] over the window.  Lane l owns the 8 x 8
+  // block (query row ry = l / 8, key row ky = l % 8) of the stashed dS tile: all of it has dy = ry - ky, and its 15 diagonals are
+  // the dx bins -- eight 16-byte LDS reads and 64 adds in registers, then 15 LDS adds into the (now dead) bias-table slot and one
+  // global atomic per bin.  (v0: 4096 LDS atomics per window; v1: <= 64 dependent 2-byte reads per bin in a rolled loop, a
+  // quarter of the kernel's time.)
+  {
+    const int ry = lane >> 3, ky = lane & 7;
+    float dacc[2 * WS - 1];
+#pragma unroll
+    for (int d = 0; d < 2 * WS - 1; ++d) dacc[d] = 0.f;
+#pragma unroll
+    for (int rx = 0; rx < WS; ++rx) {
+      const T* src = s_ds[w] + (ry * WS + rx) * LP + ky * WS;
+      float v[WS];
+      if constexpr (Vec<T>::N == 8) ld16(src, v);
+      else { ld16(src, v); ld16(src + 4, v + 4); }
+#pragma unroll
+      for (int kx = 0; kx < WS; ++kx) dacc[rx - kx + WS - 1] += v[kx];
     }
+    for (int i = lane; i < (2 * WS - 1) * (2 * WS - 1); i += 64) s_tbl[w][i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 2 * WS - 1; ++d) atomicAdd(&s_tbl[w][(ry - ky + WS - 1) * (2 * WS - 1) + d], dacc[d]);
+    __syncthreads();
+    if (live)
+      for (int bin = lane; bin < (2 * WS - 1) * (2 * WS - 1); bin += 64)
+        atomicAdd(dtable + (long long)(blockIdx.x % g.nparts) * (2 * WS - 1) * (2 * WS - 1) * g.heads + bin * g.heads + h, s_tbl[w][bin]);
   }
 }
 
@@ -299,7 +318,7 @@ extern "C" int stj_win_attn_fwd(const void* qkv, const float* table, void* out, 
                                 int dtype, hipStream_t stream) {
   if (res % WS != 0 || shift < 0 || shift >= WS) { stj_set_error("win_attn: res %% 8 != 0 or bad shift"); return STJ_EINVAL; }
   if (((uintptr_t)qkv | (uintptr_t)out) & 15) { stj_set_error("win_attn: unaligned pointers"); return STJ_EINVAL; }
-  WinGeom g; g.B = B; g.res = res; g.heads = heads; g.shift = shift;
+  WinGeom g; g.B = B; g.res = res; g.heads = heads; g.shift = shift; g.nparts = 1;
   g.items = (long long)B * (res / WS) * (res / WS) * heads;
   if (g.items <= 0) return STJ_OK;
   if (dtype == STJ_BF16) {
@@ -315,10 +334,11 @@ extern "C" int stj_win_attn_fwd(const void* qkv, const float* table, void* out, 
   return stj_check_launch("stj_win_attn_fwd");
 }
 
-extern "C" int stj_win_attn_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable,
+extern "C" int stj_win_attn_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, int nparts,
                                 int B, int res, int heads, int shift, int dtype, hipStream_t stream) {
   if (res % WS != 0 || shift < 0 || shift >= WS) { stj_set_error("win_attn: res %% 8 != 0 or bad shift"); return STJ_EINVAL; }
-  WinGeom g; g.B = B; g.res = res; g.heads = heads; g.shift = shift;
+  if (nparts < 1) { stj_set_error("win_attn_bwd: nparts must be >= 1"); return STJ_EINVAL; }
+  WinGeom g; g.B = B; g.res = res; g.heads = heads; g.shift = shift; g.nparts = nparts;
   g.items = (long long)B * (res / WS) * (res / WS) * heads;
   if (g.items <= 0) return STJ_OK;
   if (dtype == STJ_BF16) {

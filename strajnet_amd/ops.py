@@ -464,8 +464,16 @@ class _WinAttn(torch.autograd.Function):
         B, res, heads, shift = ctx.geo
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
-        call('stj_win_attn_bwd', _p(qkv), _p(ctx.pt.master), _p(dout), _p(dqkv), _p(ctx.pt.grad), B, res, heads, shift,
-             _dt(qkv), _st())
+        items = B * (res // 8) ** 2 * heads
+        nparts = int(os.environ.get('STJ_WIN_NPARTS', '0')) or (32 if items >= 1024 else (16 if items >= 256 else 1))
+        if nparts == 1:
+            call('stj_win_attn_bwd', _p(qkv), _p(ctx.pt.master), _p(dout), _p(dqkv), _p(ctx.pt.grad), 1, B, res, heads, shift,
+                 _dt(qkv), _st())
+        else:       # the workgroups spread their bias-table atomics over nparts copies (same-address contention), summed here
+            part = torch.zeros((nparts,) + tuple(ctx.pt.grad.shape), dtype=torch.float32, device=qkv.device)
+            call('stj_win_attn_bwd', _p(qkv), _p(ctx.pt.master), _p(dout), _p(dqkv), _p(part), nparts, B, res, heads, shift,
+                 _dt(qkv), _st())
+            ctx.pt.grad.add_(part.sum(0))
         return dqkv, None, None, None, None, None, None
 
 
