@@ -105,8 +105,10 @@ int stj_upconv_fwd(const void* X, const void* Wf, const float* bias, void* Y, in
                    int Cout, int act, int dtype, hipStream_t stream);
 int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout,
                      int dtype, hipStream_t stream);
-int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout,
-                     int dtype, hipStream_t stream);
+int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin,
+                     int Cout, int dtype, hipStream_t stream);
+/* wgrad: dbias (optional) is f32 [db_parts][Cout], "+=": workgroup i adds its share of the bias gradient into copy i % db_parts
+ * and the caller sums the copies (db_parts = 1: plain [Cout]). */
 /* Output heads: Conv2D 3x3 SAME C->2, no activation (modules.py:767-770), written with strides straight into the
  * [B,H,W,32] f32 model output (concat + transpose of modules.py:770,838).  Y element (b,t,y,x,o) at
  * Y + b*y_bstride + t*y_tstride + (y*W+x)*y_pstride + o.  bwd with elu_in != 0: X is an ELU output, dX is multiplied by
@@ -127,7 +129,7 @@ int stj_col2im3(const void* dcols, void* dx, int N, int H, int W, int G, int Cg,
 /* OGMFlow_loss (loss.py:50-170 with train.py:195-196 flags).  All tensors f32: logits [B,H,W,32] (channel 4k+{0,1,2,3},
  * train.py:105-123), gt_obs/gt_occ/origin [B,8,H,W,1], gt_flow [B,8,H,W,2].
  * auc_gate: res_k = [Keras PR-AUC(true_all, warp(origin, id+gt_flow)*true_all) > 0] (loss.py:127-137); hist int[8*202] scratch, zero on entry.
- * fwd: sums f32[40] scratch (zero on entry), loss f32[4] = observed_xe, occluded_xe, flow, flow_warp_xe; coef f32[32] for bwd.
+ * fwd: sums f32[32*40] scratch (32 copies of the 40 accumulators the workgroups spread their atomics over; zero on entry), loss f32[4] = observed_xe, occluded_xe, flow, flow_warp_xe; coef f32[32] for bwd.
  * bwd: dlogits = sum_j upstream[j] * dloss_j/dlogits.
  * flags: bit 0 = flow-warp term on (not no_use_warp), bit 1 = use_focal_loss (tfa SigmoidFocalCrossEntropy added to the three
  * occupancy terms, loss.py:183-190,212-219,244-245), bit 2 = use_pred (loss.py:151-154,253-268); the same value goes to fwd and bwd. */

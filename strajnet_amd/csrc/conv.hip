@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T*
 // ---------------------------------------------------------------------------------------------------
 #define WG_W 32
 template <typename T, int FO, int FI>
-__global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* dP, float* dWeff, float* dbias, int F, int Hi, int Wi,
+__global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi,
                                                            int Cin, int Cout, int chunks_per_block) {
   constexpr int BO = FO * 16, BI = FI * 16;
   constexpr int LDO = BO + ConvPad<T>::P, LDI = BI + ConvPad<T>::P;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const T* X, const T* 
     }
     __syncthreads();
   }
-  if (do_db && co0 + lane < Cout) atomicAdd(dbias + co0 + lane, dbacc);
+  if (do_db && co0 + lane < Cout) atomicAdd(dbias + (long long)(blockIdx.x % db_parts) * Cout + co0 + lane, dbacc);
   const int pt = a * 8 + b * 4 + r * 2 + s;
 #pragma unroll
   for (int m = 0; m < FO; ++m)
@@ -408,7 +408,7 @@ static int upconv_fwd_launch(const void* X, const void* Wf, const float* bias, v
 }
 bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        int dtype, hipStream_t st);   // conv_ws.hip
-bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
+bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
 bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                           long long y_bs, long long y_ts, long long y_ps, int dtype, hipStream_t st);
 bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
@@ -454,34 +454,37 @@ extern "C" int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, const 
 }
 
 template <typename T>
-static int upconv_wgrad_launch(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+static int upconv_wgrad_launch(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   const long long nchunks = (long long)F * Hi * ((Wi + WG_W - 1) / WG_W);
   if (Cout <= 48 && Cin <= 96) {
     const int tiles = 1;
     int strips = (int)min(nchunks, (long long)(1024 / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
-    hipLaunchKernelGGL((upconv_wgrad_kernel<T, 3, 6>), dim3(strips, 4, tiles), dim3(256), 0, st, (const T*)X, (const T*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb);
+    hipLaunchKernelGGL((upconv_wgrad_kernel<T, 3, 6>), dim3(strips, 4, tiles), dim3(256), 0, st, (const T*)X, (const T*)dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, cpb);
   } else {
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     int strips = (int)min(nchunks, (long long)max(1, 1024 / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
-    hipLaunchKernelGGL((upconv_wgrad_kernel<T, 4, 4>), dim3(strips, 4, tiles), dim3(256), 0, st, (const T*)X, (const T*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb);
+    hipLaunchKernelGGL((upconv_wgrad_kernel<T, 4, 4>), dim3(strips, 4, tiles), dim3(256), 0, st, (const T*)X, (const T*)dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, cpb);
   }
   return stj_check_launch("stj_upconv_wgrad");
 }
 // dWeff: f32 [16][Cout][Cin] scratch, must be zero on entry (caller memsets); fold with stj_upconv_fold afterwards.
-// dbias (optional): f32 [Cout], accumulated with sum over all pixels of dP (the conv bias gradient).
-extern "C" int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout,
-                                int dtype, hipStream_t stream) {
+// dbias (optional): f32 [db_parts][Cout], "+=": the sum over all pixels of dP (the conv bias gradient); workgroup i adds into copy
+// i % db_parts and the caller sums the copies (one copy = ~1000 same-address atomics per channel at the end of the kernel).
+extern "C" int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin,
+                                int Cout, int dtype, hipStream_t stream) {
   int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
   if (e) return e;
-  if (dtype == STJ_BF16 && ws_enabled() && upconv_wgrad_tr_try(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream))
+  if (dbias && db_parts < 1) { stj_set_error("upconv_wgrad: db_parts must be >= 1"); return STJ_EINVAL; }
+  if (db_parts < 1) db_parts = 1;
+  if (dtype == STJ_BF16 && ws_enabled() && upconv_wgrad_tr_try(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, stream))
     return stj_check_launch("stj_upconv_wgrad(tr)");
-  if (dtype == STJ_F16) return upconv_wgrad_launch<f16>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream);
-  return dtype == STJ_BF16 ? upconv_wgrad_launch<bf16>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream)
-                           : upconv_wgrad_launch<float>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, stream);
+  if (dtype == STJ_F16) return upconv_wgrad_launch<f16>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, stream);
+  return dtype == STJ_BF16 ? upconv_wgrad_launch<bf16>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, stream)
+                           : upconv_wgrad_launch<float>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -220,8 +220,8 @@ __device__ __forceinline__ s16x8 tr_frag(const bf16* p0, const bf16* p1) {
 
 // chunk = CR rows x CW columns of low-res pixels with CR * CW = 128; CW = 32 (wide layers) or 16 (the 16x16 bottleneck layer)
 template <int FO, int FI, int CW>
-__global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dP,
-                                                              float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin,
+__global__ __launch_bounds__(256, 2) void upconv_wgrad_tr_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dP,
+                                                              float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin,
                                                               int Cout, int chunks_per_block, int nstrips, int ntiles) {
   constexpr int WG2_W = CW, WG2_ROWS = 128 / CW, KROWS = 32 / CW;      // KROWS: chunk rows per 32-pixel k-step
   constexpr int BO = FO * 16, BI = FI * 16;
@@ -258,8 +258,15 @@ __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __rest
   for (int m = 0; m < FO; ++m)
 #pragma unroll
     for (int n = 0; n < FI; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_db = dbias != nullptr && ci0 == 0 && lane < BO;
-  float dbacc = 0.f;
+  // bias gradient db[co] = sum over pixels of dP[.., co]: the A fragments (m = co, k = pixel) are already in registers, so wave 0
+  // of the blocks of the first cin tile multiplies them with an all-ones B fragment -- FO extra MFMAs per k-step on a matrix pipe
+  // that is ~20 % busy -- instead of 32 dependent 2-byte LDS reads per chunk (that loop + the atomics below were 16 % of the
+  // kernel).  Every column n of D then holds the row sums.
+  const bool do_db = dbias != nullptr && ci0 == 0 && w == 0;
+  f32x4 dbf[FO];
+#pragma unroll
+  for (int m = 0; m < FO; ++m) dbf[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const s16x8 ones = (s16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};      // bf16 1.0
 
   uint4 pre[NCH];
   auto prefetch = [&](int c) {
@@ -314,17 +321,26 @@ __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __rest
 #pragma unroll
         for (int n = 0; n < FI; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[m]), __builtin_bit_cast(bf16x8_t, bfr[n]), acc[m][n], 0, 0, 0);
-    }
-    if (do_db) {                       // wave w sums row w of the chunk
-      float sdb = 0.f;
-      for (int q = 0; q < 32; ++q) sdb += bf2f(dYs[(w * 32 + q) * LDO + lane].v);
-      dbacc += sdb;
+      if (do_db) {
+#pragma unroll
+        for (int m = 0; m < FO; ++m)
+          dbf[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[m]), __builtin_bit_cast(bf16x8_t, ones), dbf[m], 0, 0, 0);
+      }
     }
     __syncthreads();
     if (c + 1 < c_end) commit();
     __syncthreads();
   }
-  if (do_db && co0 + lane < Cout) atomicAdd(dbias + co0 + lane, dbacc);
+  if (do_db && p == 0) {               // column n = 0: lane g holds rows m*16 + 4g + 0..3.  The blocks spread over db_parts copies
+    float* dbp = dbias + (long long)(blockIdx.x % db_parts) * Cout;
+#pragma unroll
+    for (int m = 0; m < FO; ++m)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = co0 + m * 16 + g * 4 + rg;
+        if (co < Cout) atomicAdd(dbp + co, dbf[m][rg]);
+      }
+  }
   const int pt = a * 8 + b * 4 + r * 2 + s;
 #pragma unroll
   for (int m = 0; m < FO; ++m)
@@ -342,27 +358,29 @@ __global__ __launch_bounds__(256) void upconv_wgrad_tr_kernel(const bf16* __rest
 
 // returns true when handled (bf16; Wi % 32 == 0 and Hi % 4 == 0, or Wi % 16 == 0 and Hi % 8 == 0; channels % 8 == 0)
 template <int CW>
-static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   constexpr int CR = 128 / CW;
   const long long nchunks = (long long)F * (Hi / CR) * (Wi / CW);
   if (Cout <= 48 && Cin <= 96) {
-    int strips = (int)min(nchunks, (long long)256);
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("STJ_WG_STRIPS"); cap = e ? atoi(e) : 256; }
+    int strips = (int)min(nchunks, (long long)cap);
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
-    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6, CW>), dim3((strips + 7) / 8 * 8 * 4), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb, strips, 1);
+    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6, CW>), dim3((strips + 7) / 8 * 8 * 4), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, cpb, strips, 1);
   } else {
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     int strips = (int)min(nchunks, (long long)max(1, 1024 / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
-    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<4, 4, CW>), dim3((strips + 7) / 8 * 8 * 4 * tiles), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, cpb, strips, tiles);
+    hipLaunchKernelGGL((upconv_wgrad_tr_kernel<4, 4, CW>), dim3((strips + 7) / 8 * 8 * 4 * tiles), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, cpb, strips, tiles);
   }
   return true;
 }
-bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   if (Cin % 8 || Cout % 8) return false;
-  if (Wi % 32 == 0 && Hi % 4 == 0) return wgrad_tr_launch<32>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, st);
-  if (Wi % 16 == 0 && Hi % 8 == 0) return wgrad_tr_launch<16>(X, dP, dWeff, dbias, F, Hi, Wi, Cin, Cout, st);
+  if (Wi % 32 == 0 && Hi % 4 == 0) return wgrad_tr_launch<32>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, st);
+  if (Wi % 16 == 0 && Hi % 8 == 0) return wgrad_tr_launch<16>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, st);
   return false;
 }
 

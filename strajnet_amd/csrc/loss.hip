@@ -17,6 +17,7 @@
 #include "common.h"
 
 #define NWP 8
+#define LOSS_PARTS 32
 // per-waypoint accumulator slots
 enum { S_OBS = 0, S_OCC = 1, S_L1 = 2, S_EX = 3, S_WARP = 4, S_N = 5 };
 
@@ -206,13 +207,23 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* logits, cons
     if (lane == 0) red[w][i] = s;
   }
   __syncthreads();
-  if (threadIdx.x < NWP * S_N) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  // LOSS_PARTS copies of the 40 accumulators: 2048 blocks on one copy queue 2048 same-address atomics per slot (~70 of this
+  // kernel's 92 us); loss_finalize_kernel folds the copies
+  if (threadIdx.x < NWP * S_N)
+    atomicAdd(sums + (blockIdx.x % LOSS_PARTS) * (NWP * S_N) + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 struct LossCfg { float ogm_w, occ_w, fow, replica; int use_warp; };
 
 // loss[4] = observed_xe, occluded_xe, flow, flow_warp_xe ; coef [NWP][4] per-waypoint backward coefficients (before upstream grads)
-__global__ void loss_finalize_kernel(const float* sums, const float* gate, float* loss, float* coef, float npix, LossCfg c) {
+__global__ void loss_finalize_kernel(const float* sums_parts, const float* gate, float* loss, float* coef, float npix, LossCfg c) {
+  __shared__ float sums[NWP * S_N];
+  if (threadIdx.x < NWP * S_N) {
+    float a = 0.f;
+    for (int q = 0; q < LOSS_PARTS; ++q) a += sums_parts[q * (NWP * S_N) + threadIdx.x];
+    sums[threadIdx.x] = a;
+  }
+  __syncthreads();
   if (threadIdx.x != 0) return;
   float so = 0.f, sc = 0.f, sf = 0.f, sw = 0.f, fc = 0.f;
   for (int k = 0; k < NWP; ++k) fc += gate[k];
@@ -306,7 +317,7 @@ extern "C" int stj_loss_auc_gate(const float* gt_obs, const float* gt_occ, const
   hipLaunchKernelGGL(auc_gate_kernel, dim3(NWP), dim3(128), 0, stream, hist, gate, auc_out);
   return stj_check_launch("stj_loss_auc_gate");
 }
-// sums: f32[40] scratch, MUST BE ZERO on entry; loss f32[4]; coef f32[32]
+// sums: f32[32*40] scratch (32 copies of the 40 accumulators), MUST BE ZERO on entry; loss f32[4]; coef f32[32]
 extern "C" int stj_loss_fwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                             const float* gate, float* sums, float* loss, float* coef, int B, int H, int W, float ogm_w, float occ_w,
                             float flow_origin_w, float replica, int flags, hipStream_t stream) {

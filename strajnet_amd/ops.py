@@ -726,6 +726,9 @@ def grouped_conv3(x, pw, pb, G):
 # ----------------------------------------------------------------------------------------------------
 # decoder: nearest-2x upsample folded 3x3 conv + bias + ELU
 # ----------------------------------------------------------------------------------------------------
+_DB_PARTS = 32
+
+
 class _UpConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_master, b_master, pw, pb, grad_is_pre, x_is_elu_out):
@@ -764,10 +767,15 @@ class _UpConv(torch.autograd.Function):
             with _timed(f'upconv_dgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
                 call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), _p(x) if ctx.x_is_elu_out else None, F_, Hi, Wi, Cin, Cout, dt, _st())
         with wgrad_stream(2, x, dpre):
-            dweff = torch.zeros((16, Cout, Cin), dtype=torch.float32, device=x.device)
+            # one zeroed scratch: the 16 folded tap matrices, then DB_PARTS copies of the bias gradient (the ~1000 workgroups
+            # spread their atomics over the copies instead of queueing on Cout addresses)
+            nw = 16 * Cout * Cin
+            scratch = torch.zeros(nw + _DB_PARTS * Cout, dtype=torch.float32, device=x.device)
+            dweff, dbp = scratch[:nw], scratch[nw:]
             with _timed(f'upconv_wgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
-                call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(ctx.pb.grad), F_, Hi, Wi, Cin, Cout, dt, _st())
+                call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), _DB_PARTS, F_, Hi, Wi, Cin, Cout, dt, _st())
             call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
+            ctx.pb.grad.add_(dbp.view(_DB_PARTS, Cout).sum(0))
         return dx, None, None, None, None, None, None
 
 
@@ -835,7 +843,7 @@ class _OgmFlowLoss(torch.autograd.Function):
         logits = logits.contiguous().float()
         B, H, W, _ = logits.shape
         dev = logits.device
-        sums = torch.zeros(40, dtype=torch.float32, device=dev)
+        sums = torch.zeros(32 * 40, dtype=torch.float32, device=dev)       # 32 copies of the 40 accumulators (stj_loss_fwd)
         loss = torch.empty(4, dtype=torch.float32, device=dev)
         coef = torch.empty(32, dtype=torch.float32, device=dev)
         call('stj_loss_fwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(sums), _p(loss), _p(coef),

@@ -29,7 +29,8 @@ for li, (F, Hi, Cin, Cout) in enumerate(LAYERS):
     dp = torch.randn(F, 2 * Hi, 2 * Hi, Cout, device='cuda').to(dtype)
     dx = torch.empty_like(x)
     dweff = torch.zeros(16, Cout, Cin, device='cuda')
-    db = torch.zeros(Cout, device='cuda')
+    NP = int(os.environ.get('NP', '32'))
+    dbp = torch.zeros(NP, Cout, device='cuda')
     flops = 2.0 * 9 * Cin * Cout * 4 * Hi * Hi * F
     def run(name, fn):
         if a.only and a.only != name:
@@ -45,4 +46,4 @@ for li, (F, Hi, Cin, Cout) in enumerate(LAYERS):
     run('fwd', lambda: call('stj_upconv_fwd', _p(x), _p(wf), _p(b), _p(y), F, Hi, Hi, Cin, Cout, 2, dt, _st()))
     run('dgrad', lambda: call('stj_upconv_dgrad', _p(dp), _p(wd), _p(dx), None, F, Hi, Hi, Cin, Cout, dt, _st()))
     run('dgradE', lambda: call('stj_upconv_dgrad', _p(dp), _p(wd), _p(dx), _p(x), F, Hi, Hi, Cin, Cout, dt, _st()))
-    run('wgrad', lambda: call('stj_upconv_wgrad', _p(x), _p(dp), _p(dweff), _p(db), F, Hi, Hi, Cin, Cout, dt, _st()))
+    run('wgrad', lambda: call('stj_upconv_wgrad', _p(x), _p(dp), _p(dweff), _p(None if os.environ.get('NODB') else dbp), NP, F, Hi, Hi, Cin, Cout, dt, _st()))
