@@ -69,8 +69,11 @@ int stj_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
                       long long gstride, int dtype, hipStream_t stream);
 int stj_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       void* dx, float* dgamma, float* dbeta, long long rows, int C, int gather_res, int C0,
-                      long long group_rows, int ngroups, long long gstride, const void* dres, int dtype, hipStream_t stream);
-/* dres (optional, x's layout, no gather): gradient arriving over the residual connection that bypasses the norm; dx += dres. */
+                      long long group_rows, int ngroups, long long gstride, const void* dres, int nparts, long long part_stride,
+                      int dtype, hipStream_t stream);
+/* dres (optional, x's layout, no gather): gradient arriving over the residual connection that bypasses the norm; dx += dres.
+ * nparts / part_stride: dgamma and dbeta are "+=" into nparts copies that lie part_stride floats apart (workgroups rotate over
+ * them: 256 same-address atomics per channel otherwise); the caller sums the copies.  nparts = 1: plain [C] buffers. */
 
 /* Fused (shifted-)window attention, window 8x8, head_dim 32: roll + window_partition + softmax(q k^T*scale +
  * relative_position_bias[+shift mask]) v + window_reverse + roll (modules.py:49-63,103-134,189-216,229-255).

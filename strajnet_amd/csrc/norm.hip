@@ -18,7 +18,8 @@ __device__ __forceinline__ long long ln_src(long long row, int c, int C, int gre
   return ((b * gres + 2 * i + di) * gres + 2 * j + dj) * C0 + cc;
 }
 
-struct LnGroups { long long group_rows; int ngroups; long long gstride; int S; long long L; };   // S sub-runs of L rows per run (bwd)
+struct LnGroups { long long group_rows; int ngroups; long long gstride; int S; long long L;   // S sub-runs of L rows per run (bwd)
+                  int nparts; long long pstride; };    // bwd: dgamma / dbeta copies the blocks spread their atomics over
 
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
@@ -127,8 +128,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dy, con
   for (int j = 0; j < NPL; ++j) { atomicAdd(&red[0][lane + 64 * j], ag[j]); atomicAdd(&red[1][lane + 64 * j], ab[j]); }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 64 * LNB_WAVES) {
-    atomicAdd(dgamma + goff + c, red[0][c]);
-    atomicAdd(dbeta + goff + c, red[1][c]);
+    atomicAdd(dgamma + (blockIdx.x / G.ngroups % G.nparts) * G.pstride + goff + c, red[0][c]);
+    atomicAdd(dbeta + (blockIdx.x / G.ngroups % G.nparts) * G.pstride + goff + c, red[1][c]);
   }
 }
 
@@ -301,8 +302,8 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const T* __restrict__ dy, 
     }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + goff + c, red[0][c]);
-    atomicAdd(dbeta + goff + c, red[1][c]);
+    atomicAdd(dgamma + (blockIdx.x / G.ngroups % G.nparts) * G.pstride + goff + c, red[0][c]);
+    atomicAdd(dbeta + (blockIdx.x / G.ngroups % G.nparts) * G.pstride + goff + c, red[1][c]);
   }
 }
 
@@ -406,17 +407,19 @@ extern "C" int stj_layernorm_fwd(const void* x, const float* gamma, const float*
   if (rows <= 0) return STJ_OK;
   if (gather_res && (C != 4 * C0 || (gather_res & 1))) { stj_set_error("layernorm: bad gather geometry"); return STJ_EINVAL; }
   if (ngroups > 1 && group_rows <= 0) { stj_set_error("layernorm: bad group_rows"); return STJ_EINVAL; }
-  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride; G.S = 1; G.L = G.group_rows;
+  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride; G.S = 1; G.L = G.group_rows; G.nparts = 1; G.pstride = 0;
   if (dtype == STJ_BF16) return ln_launch<bf16>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, G, stream);
   if (dtype == STJ_F16) return ln_launch<f16>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, G, stream);
   return ln_launch<float>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, G, stream);
 }
 extern "C" int stj_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                  void* dx, float* dgamma, float* dbeta, long long rows, int C, int gather_res, int C0,
-                                 long long group_rows, int ngroups, long long gstride, const void* dres, int dtype, hipStream_t stream) {
+                                 long long group_rows, int ngroups, long long gstride, const void* dres, int nparts, long long part_stride,
+                                 int dtype, hipStream_t stream) {
   if (rows <= 0) return STJ_OK;
+  if (nparts < 1 || (nparts > 1 && part_stride < C)) { stj_set_error("layernorm_bwd: bad nparts / part_stride"); return STJ_EINVAL; }
   if (dres && gather_res) { stj_set_error("layernorm_bwd: dres with the PatchMerging gather is not supported"); return STJ_EINVAL; }
-  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride; G.S = 1; G.L = G.group_rows;
+  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride; G.S = 1; G.L = G.group_rows; G.nparts = nparts; G.pstride = part_stride;
   if (dtype == STJ_BF16) return ln_launch<bf16>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream, dres);
   if (dtype == STJ_F16) return ln_launch<f16>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream, dres);
   return ln_launch<float>(false, x, gamma, nullptr, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dy, dx, dgamma, dbeta, rows, C, 0.f, gather_res, C0, G, stream, dres);

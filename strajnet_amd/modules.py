@@ -153,6 +153,7 @@ def _init_tensor(shape, kind, gen):
 
 
 class STrajNet:
+    LN_PARTS = 16
     def __init__(self, cfg, model_name='STrajNet', use_pyramid=True, actor_only=True, sep_actors=False,
                  fg_msa=False, use_last_ref=False, fg=False, large_ogm=True,
                  device='cuda', dtype=torch.float32, seed=0):
@@ -240,6 +241,20 @@ class STrajNet:
             grad = self._gflat[sl].view(s)
             master.grad = grad
             self.params[n] = Param(n, s, master, self._cflat[sl].view(s), grad)
+        # LayerNorm gamma / beta gradients: a 32768-row LayerNorm backward ends with 256 workgroups adding to the same 2C addresses
+        # (~35 ns per same-address atomic, serialised).  They add into LN_PARTS compact copies instead, folded into the flat
+        # gradient buffer once per step (_fold_partials, queued at the end of backward).  The 8-set batched norms of the
+        # time-separated attention keep the direct path (their parameter stride is that of the flat buffer).
+        ln = [n for n in spec if n.rsplit('/', 1)[-1] in ('gamma', 'beta') and not n.startswith('cross_attn_obs')]
+        width = sum(int(np.prod(spec[n][0])) for n in ln)
+        self._lnpart = torch.zeros((self.LN_PARTS, width), dtype=torch.float32, device=self.device)
+        idx, o = [], 0
+        for n in ln:
+            k = int(np.prod(spec[n][0]))
+            self.params[n].part = (self._lnpart[0, o:o + k], self.LN_PARTS, width)
+            idx.append(torch.arange(offs[n], offs[n] + k))
+            o += k
+        self._ln_index = torch.cat(idx).to(self.device)
         self._sync_compute_weights()
 
     # ------------------------------------------------------------------ weights
@@ -289,6 +304,11 @@ class STrajNet:
 
     def zero_grad(self):
         self._gflat.zero_()
+
+    def _fold_partials(self):
+        """Partial-gradient copies -> flat gradient buffer (runs on the caller's stream when backward() has been enqueued)."""
+        self._gflat.index_add_(0, self._ln_index, self._lnpart.sum(0))
+        self._lnpart.zero_()
 
     def grads(self):
         return OrderedDict((n, p.grad) for n, p in self.params.items())
@@ -644,4 +664,4 @@ class STrajNet:
             tmask.record_stream(main)
         x = self._cross_attention_z(query.contiguous(), key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
         out = self._decoder(x, res_list, B, skips)
-        return ops.join_after_backward(out, (self._side, self._side2))
+        return ops.join_after_backward(out, (self._side, self._side2), self._fold_partials)

@@ -160,35 +160,40 @@ class _JoinAfterBackward(torch.autograd.Function):
     written by side-stream kernels straight into the flat buffer (no AccumulateGrad node the engine could track) are then
     ordered before whatever the caller enqueues next (optimizer, all-reduce, end of a graph capture)."""
     @staticmethod
-    def forward(ctx, out, streams):
-        ctx.streams = streams
+    def forward(ctx, out, streams, post):
+        ctx.streams, ctx.post = streams, post
         return out.view_as(out)
 
     @staticmethod
     def backward(ctx, g):
-        streams = ctx.streams
+        streams, post = ctx.streams, ctx.post
         main = torch.cuda.current_stream(g.device)
 
         def join():
             for s in streams:
                 main.wait_stream(s)
+            if post is not None:          # e.g. fold the partial-gradient copies into the flat gradient buffer
+                with torch.cuda.stream(main), torch.no_grad():
+                    post()
         torch.autograd.Variable._execution_engine.queue_callback(join)
-        return g, None
+        return g, None, None
 
 
-def join_after_backward(out, streams):
+def join_after_backward(out, streams, post=None):
     streams = [s for s in streams if s is not None]
-    if not streams or not out.requires_grad:
+    if (not streams and post is None) or not out.requires_grad:
         return out
-    return _JoinAfterBackward.apply(out, streams)
+    return _JoinAfterBackward.apply(out, streams, post)
 
 
 class Param:
     """One trainable tensor: f32 master view, compute-dtype view, f32 gradient view (all slices of flat buffers)."""
-    __slots__ = ('name', 'shape', 'master', 'c', 'grad')
+    __slots__ = ('name', 'shape', 'master', 'c', 'grad', 'part')
 
     def __init__(self, name, shape, master, c, grad):
         self.name, self.shape, self.master, self.c, self.grad = name, tuple(shape), master, c, grad
+        self.part = None        # (view of copy 0, copies, stride): partial-gradient copies that kernels with many workgroups
+                                # per parameter element rotate their atomics over (folded into .grad after backward)
 
 
 def gemm(A, B, C, M, N, K, sA, sB, sC, dt, bias=None, sBias=(0, 0), res=None, sRes=(0, 0, 0), nb=(1, 1),
@@ -427,8 +432,13 @@ class _LayerNorm(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dres = dskip.contiguous() if dskip is not None else None
-        call('stj_layernorm_bwd', _p(dy), _p(x), _p(ctx.pg.master), _p(mean), _p(rstd), _p(dx), _p(ctx.pg.grad),
-             _p(ctx.pb.grad), rows, C, gres, C0, group_rows, ngroups, gstride, _p(dres), _dt(x), _st())
+        pg, pb = ctx.pg, ctx.pb
+        if ngroups <= 1 and pg.part is not None and pb.part is not None:
+            dg, db, nparts, pstride = pg.part[0], pb.part[0], pg.part[1], pg.part[2]
+        else:
+            dg, db, nparts, pstride = pg.grad, pb.grad, 1, 0
+        call('stj_layernorm_bwd', _p(dy), _p(x), _p(pg.master), _p(mean), _p(rstd), _p(dx), _p(dg),
+             _p(db), rows, C, gres, C0, group_rows, ngroups, gstride, _p(dres), nparts, pstride, _dt(x), _st())
         return (dx,) + (None,) * 10
 
 
