@@ -362,9 +362,7 @@ static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* 
   constexpr int CR = 128 / CW;
   const long long nchunks = (long long)F * (Hi / CR) * (Wi / CW);
   if (Cout <= 48 && Cin <= 96) {
-    static int cap = 0;
-    if (!cap) { const char* e = getenv("STJ_WG_STRIPS"); cap = e ? atoi(e) : 256; }
-    int strips = (int)min(nchunks, (long long)cap);
+    int strips = (int)min(nchunks, (long long)256);     // 128 and 512 measured within noise / slower
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
     hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6, CW>), dim3((strips + 7) / 8 * 8 * 4), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, cpb, strips, 1);
