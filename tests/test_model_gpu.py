@@ -427,6 +427,49 @@ def test_cpu_tensor_rejected():
         ops.gelu(torch.zeros(8))
 
 
+def test_edge_cases_no_agents_all_agents_empty_rasters_f32():
+    """Edge cases of the domain: scene 0 has NO valid agent (every obs/occ row is padding -> every tfa mask row is fully masked,
+    the -1e10 additive mask then yields a uniform softmax), an empty occupancy raster and zero flow; scene 1 has
+    every agent valid at every step.  Forward, loss (use_gt=False: the AUC gate of an all-empty waypoint is 0) and gradients
+    against the oracle."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from oracle import np_ref, torch_ref
+    w = np_ref.make_weights(CFG128, 0)
+    x = np_ref.make_inputs(CFG128, 2)
+    x['obs'][0] = 0; x['occ'][0] = 0; x['ogm'][0] = 0; x['flow'][0] = 0
+    rng = np.random.default_rng(11)
+    x['obs'][1] = rng.normal(0, 5, x['obs'][1].shape).astype(np.float32) + 0.5         # no exact zeros in column 0 -> all steps valid
+    x['occ'][1] = rng.normal(0, 5, x['occ'][1].shape).astype(np.float32) + 0.5
+    x['obs'][1][..., 0] = np.abs(x['obs'][1][..., 0]) + 0.1
+    x['occ'][1][..., 0] = np.abs(x['occ'][1][..., 0]) + 0.1
+    for k in ('gt_obs', 'gt_occ', 'gt_flow', 'origin_flow'):
+        x[k][0] = 0                                                                     # nothing to predict in scene 0
+    import strajnet_amd
+    model = strajnet_amd.STrajNet(CFG128, fg_msa=True, fg=True, large_ogm=False, dtype=torch.float32)
+    model.load_weights(w)
+    xt = {k: torch.as_tensor(v).cuda() for k, v in x.items()}
+    model.zero_grad()
+    out = _fwd(model, xt)
+    ref = np_ref.strajnet_forward(w, CFG128, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'])
+    err = np.abs(out.detach().cpu().numpy() - ref).max()
+    assert np.isfinite(ref).all() and err < ABS_TOL_F32, err
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(128, 128, 8), replica=1.0, use_focal_loss=False, use_gt=False)
+    d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+    sum(d.values()).backward()
+    pr = torch_ref.to_torch(w, torch.float64, requires_grad=True)
+    xr = torch_ref.to_torch(x, torch.float64)
+    yr = torch_ref.forward(pr, CFG128, xr['ogm'], xr['map_img'], xr['obs'], xr['occ'], xr['flow'])
+    dr = torch_ref.loss(yr, xr['gt_obs'], xr['gt_occ'], xr['gt_flow'], xr['origin_flow'], replica=1.0, use_gt=False)
+    sum(dr.values()).backward()
+    for k in dr:
+        assert abs(float(d[k].detach()) - float(dr[k].detach())) < 1e-4 * abs(float(dr[k].detach())) + 1e-5, k
+    gmax = max(float(pr[n].grad.abs().max()) for n in model.params)
+    worst = max(float((p.grad.double().cpu() - pr[n].grad).abs().max()) / (float(pr[n].grad.abs().max()) + 1e-6 * gmax)
+                for n, p in model.params.items())
+    _report(f'edge cases (no agents / all agents / empty rasters) 128x128 B=2 f32: fwd max-abs err {err:.3e}, worst relative grad error {worst:.3e}')
+    assert worst < 2e-3
+
+
 def test_bench_config_batch_permutation_bf16():
     """Size-independent property at the bench configuration (cfg-256, B=8, bf16): scenes are independent units, so
     permuting the batch permutes the outputs, leaves the (batch-mean) losses unchanged and leaves every gradient unchanged up to
