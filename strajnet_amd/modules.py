@@ -166,8 +166,6 @@ class STrajNet:
             raise ValueError('dtype must be torch.float32 (parity mode), torch.bfloat16 (throughput mode) or torch.float16 '
                              '(inference mode: no loss scaling is applied to gradients)')
         H, W = cfg['input_size']
-        if H != W or H % 128 != 0 and H != 128:
-            pass
         if H != W:
             raise ValueError('square inputs only (reference modules.py:583-585)')
         if len(cfg['depths']) != 3 or len(cfg['num_heads']) != 3:
@@ -227,9 +225,8 @@ class STrajNet:
         self._seg_onehot = {}
         self.dropctx = ops.DropCtx(self.device, seed)
         self._dctx = None
-        import os as _os
-        self._side = torch.cuda.Stream(self.device) if (self.device.type == 'cuda' and _os.environ.get('STJ_NO_SIDE_STREAM') != '1') else None
-        self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and _os.environ.get('STJ_NO_SIDE_STREAM2') != '1') else None
+        self._side = torch.cuda.Stream(self.device) if (self.device.type == 'cuda' and os.environ.get('STJ_NO_SIDE_STREAM') != '1') else None
+        self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and os.environ.get('STJ_NO_SIDE_STREAM2') != '1') else None
         self._streams = (self._side, self._side2)
         self.serial = False              # True: everything on the current stream (per-kernel timing, debugging)
         self.params = OrderedDict()
