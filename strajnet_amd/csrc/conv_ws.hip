@@ -673,7 +673,11 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
                                                                  int Wi, int Cin, int ntiles) {
   constexpr int Cout = COUT;                       // compile time: the halo loader divides by Cout / 8 forty times per tile (a runtime
                                                    // divisor cost ~1400 VALU instructions per tile, a quarter of the tile's time)
-  constexpr int LDK = KS * 32 + (KS == 3 ? 8 : 16);   // halo pixel stride; +16 = conflict-free b128 reads (KS = 3: only +8 fits in 160 KB); channels >= Cout stay zero
+  // halo pixel stride.  A fragment read takes every OTHER halo pixel (low-res pixel ln <-> high-res 2 ln + v), so consecutive lanes are
+  // 2 * LDK apart: conflict-free b128 reads need 2 * LDK = 2 (mod 4) 16-byte slots, i.e. an ODD number of slots per pixel -> +8 elements
+  // (9 / 13 slots).  (+16 -- the right padding for the stride-1 reads of the forward kernel -- measured 36 % LDS bank-conflict cycles
+  // here for KS = 2; the kernel time did not move with the fix, so conflicts are not what bounds it.)  Channels >= Cout stay zero.
+  constexpr int LDK = KS * 32 + 8;
   constexpr int HH = 2 * WS_TH + 2, HW = 2 * WS_TW + 2, HPIX = HH * HW;
   constexpr int CT = NFI * 16;                     // cin tile of this workgroup
   constexpr int LDR = CT + 4;                      // reduction row stride (floats)
@@ -837,7 +841,7 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
 
 template <int KS, int NFI, bool ELU, int COUT>
 static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
-  constexpr int LDK = KS * 32 + (KS == 3 ? 8 : 16), HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), CT = NFI * 16, LDR = CT + 4;
+  constexpr int LDK = KS * 32 + 8, HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), CT = NFI * 16, LDR = CT + 4;
   const size_t lds = (size_t)(HPIX * LDK + 64) * 2 + (size_t)4 * 2 * 16 * LDR * 4;
   static bool attr_set = false;
   if (!attr_set) {
