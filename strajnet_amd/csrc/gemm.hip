@@ -89,7 +89,7 @@ struct Stage {
 };
 
 template <typename T, int BM, int BN, int WM, int WN, bool TA, bool TB>
-__global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? 5 : 1) void gemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? ((!TA && !TB) ? 4 : 5) : 1) void gemm_kernel(GemmArgs p) {
   constexpr int BK = 128 / sizeof(T);
   constexpr int LD = BK + LdsPad<T>::P;
   constexpr int LDTA = BM + PadT<T>::P, LDTB = BN + PadT<T>::P;
