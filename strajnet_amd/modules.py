@@ -153,7 +153,7 @@ def _init_tensor(shape, kind, gen):
 
 
 class STrajNet:
-    LN_PARTS = 16
+    PARTS = 32
     def __init__(self, cfg, model_name='STrajNet', use_pyramid=True, actor_only=True, sep_actors=False,
                  fg_msa=False, use_last_ref=False, fg=False, large_ogm=True,
                  device='cuda', dtype=torch.float32, seed=0):
@@ -238,20 +238,26 @@ class STrajNet:
             grad = self._gflat[sl].view(s)
             master.grad = grad
             self.params[n] = Param(n, s, master, self._cflat[sl].view(s), grad)
-        # LayerNorm gamma / beta gradients: a 32768-row LayerNorm backward ends with 256 workgroups adding to the same 2C addresses
-        # (~35 ns per same-address atomic, serialised).  They add into LN_PARTS compact copies instead, folded into the flat
-        # gradient buffer once per step (_fold_partials, queued at the end of backward).  The 8-set batched norms of the
-        # time-separated attention keep the direct path (their parameter stride is that of the flat buffer).
-        ln = [n for n in spec if n.rsplit('/', 1)[-1] in ('gamma', 'beta') and not n.startswith('cross_attn_obs')]
-        width = sum(int(np.prod(spec[n][0])) for n in ln)
-        self._lnpart = torch.zeros((self.LN_PARTS, width), dtype=torch.float32, device=self.device)
+        # Partial-gradient copies.  Some backward kernels end with hundreds of workgroups adding into the same few addresses
+        # (LayerNorm gamma / beta, the window-attention bias tables, the up-conv biases); same-address atomics serialise at ~35 ns
+        # each, so these parameters get PARTS copies (contiguous per parameter) that the workgroups rotate over, and ONE
+        # index_add folds all of them into the flat gradient buffer at the end of backward (_fold_partials).  The 8-set batched
+        # norms of the time-separated attention keep the direct path (their parameter stride is that of the flat buffer).
+        def wants_parts(n):
+            leaf = n.rsplit('/', 1)[-1]
+            if n.startswith('cross_attn_obs'):
+                return False
+            return leaf in ('gamma', 'beta', 'relative_position_bias_table') or (leaf == 'bias' and '/upconv' in n)
+        names = [n for n in spec if wants_parts(n)]
+        P = self.PARTS
+        self._parts = torch.zeros(P * sum(int(np.prod(spec[n][0])) for n in names), dtype=torch.float32, device=self.device)
         idx, o = [], 0
-        for n in ln:
+        for n in names:
             k = int(np.prod(spec[n][0]))
-            self.params[n].part = (self._lnpart[0, o:o + k], self.LN_PARTS, width)
-            idx.append(torch.arange(offs[n], offs[n] + k))
-            o += k
-        self._ln_index = torch.cat(idx).to(self.device)
+            self.params[n].part = (self._parts[o:o + k], P, k)
+            idx.append(torch.arange(offs[n], offs[n] + k).repeat(P))
+            o += P * k
+        self._fold_index = torch.cat(idx).to(self.device)
         self._sync_compute_weights()
 
     # ------------------------------------------------------------------ weights
@@ -304,8 +310,8 @@ class STrajNet:
 
     def _fold_partials(self):
         """Partial-gradient copies -> flat gradient buffer (runs on the caller's stream when backward() has been enqueued)."""
-        self._gflat.index_add_(0, self._ln_index, self._lnpart.sum(0))
-        self._lnpart.zero_()
+        self._gflat.index_add_(0, self._fold_index, self._parts)
+        self._parts.zero_()
 
     def grads(self):
         return OrderedDict((n, p.grad) for n, p in self.params.items())

@@ -475,15 +475,19 @@ class _WinAttn(torch.autograd.Function):
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         items = B * (res // 8) ** 2 * heads
+        pt = ctx.pt
         nparts = int(os.environ.get('STJ_WIN_NPARTS', '0')) or (32 if items >= 1024 else (16 if items >= 256 else 1))
-        if nparts == 1:
-            call('stj_win_attn_bwd', _p(qkv), _p(ctx.pt.master), _p(dout), _p(dqkv), _p(ctx.pt.grad), 1, B, res, heads, shift,
+        if pt.part is not None:     # model-owned copies, folded into .grad once per step
+            call('stj_win_attn_bwd', _p(qkv), _p(pt.master), _p(dout), _p(dqkv), _p(pt.part[0]), min(nparts, pt.part[1]), B, res, heads,
+                 shift, _dt(qkv), _st())
+        elif nparts == 1:
+            call('stj_win_attn_bwd', _p(qkv), _p(pt.master), _p(dout), _p(dqkv), _p(pt.grad), 1, B, res, heads, shift,
                  _dt(qkv), _st())
         else:       # the workgroups spread their bias-table atomics over nparts copies (same-address contention), summed here
-            part = torch.zeros((nparts,) + tuple(ctx.pt.grad.shape), dtype=torch.float32, device=qkv.device)
-            call('stj_win_attn_bwd', _p(qkv), _p(ctx.pt.master), _p(dout), _p(dqkv), _p(part), nparts, B, res, heads, shift,
+            part = torch.zeros((nparts,) + tuple(pt.grad.shape), dtype=torch.float32, device=qkv.device)
+            call('stj_win_attn_bwd', _p(qkv), _p(pt.master), _p(dout), _p(dqkv), _p(part), nparts, B, res, heads, shift,
                  _dt(qkv), _st())
-            ctx.pt.grad.add_(part.sum(0))
+            pt.grad.add_(part.sum(0))
         return dqkv, None, None, None, None, None, None
 
 
@@ -777,15 +781,17 @@ class _UpConv(torch.autograd.Function):
             with _timed(f'upconv_dgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
                 call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), _p(x) if ctx.x_is_elu_out else None, F_, Hi, Wi, Cin, Cout, dt, _st())
         with wgrad_stream(2, x, dpre):
-            # one zeroed scratch: the 16 folded tap matrices, then DB_PARTS copies of the bias gradient (the ~1000 workgroups
-            # spread their atomics over the copies instead of queueing on Cout addresses)
-            nw = 16 * Cout * Cin
-            scratch = torch.zeros(nw + _DB_PARTS * Cout, dtype=torch.float32, device=x.device)
-            dweff, dbp = scratch[:nw], scratch[nw:]
+            dweff = torch.zeros(16 * Cout * Cin, dtype=torch.float32, device=x.device)     # the 16 folded tap matrices
+            pb = ctx.pb
+            if pb.part is not None:  # model-owned bias-gradient copies, folded into .grad once per step
+                dbp, nparts, own = pb.part[0], pb.part[1], False
+            else:                    # (~1000 workgroups would queue on Cout addresses otherwise)
+                dbp, nparts, own = torch.zeros(_DB_PARTS * Cout, dtype=torch.float32, device=x.device), _DB_PARTS, True
             with _timed(f'upconv_wgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
-                call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), _DB_PARTS, F_, Hi, Wi, Cin, Cout, dt, _st())
+                call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), nparts, F_, Hi, Wi, Cin, Cout, dt, _st())
             call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
-            ctx.pb.grad.add_(dbp.view(_DB_PARTS, Cout).sum(0))
+            if own:
+                pb.grad.add_(dbp.view(nparts, Cout).sum(0))
         return dx, None, None, None, None, None, None
 
 
