@@ -307,6 +307,7 @@ class STrajNet:
 
     def zero_grad(self):
         self._gflat.zero_()
+        ops._ARENA.arm(self.device)          # the step's zeroed scratch comes out of one arena, re-zeroed here
 
     def _fold_partials(self):
         """Partial-gradient copies -> flat gradient buffer (runs on the caller's stream when backward() has been enqueued)."""
@@ -504,7 +505,7 @@ class STrajNet:
         Ci, Co = pw.shape[3], pw.shape[4]
         sel = self._time_sel
         wz = (sel @ pw.master.detach().view(8, Ci * Co)).view(8, Ci, Co).to(self.dtype)
-        gwz = torch.zeros((8, Ci, Co), dtype=torch.float32, device=self.device)
+        gwz = ops.zeros_f32((8, Ci, Co), self.device)
 
         def fold():
             pw.grad.view(8, Ci * Co).add_(sel.t() @ gwz.view(8, Ci * Co))
@@ -522,7 +523,7 @@ class STrajNet:
         off = self._offs['cross_attn_obs0/' + suffix]
         src = torch.as_strided(self._cflat, (8, H, I, hs), (self._zstride, I * hs, hs, 1), off)
         wz = src.permute(0, 2, 1, 3).reshape(8, I, H * hs).contiguous()
-        gwz = torch.zeros((8, I, H * hs), dtype=torch.float32, device=self.device)
+        gwz = ops.zeros_f32((8, I, H * hs), self.device)
         gdst = torch.as_strided(self._gflat, (8, H, I, hs), (self._zstride, I * hs, hs, 1), off)
 
         def fold():

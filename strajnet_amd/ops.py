@@ -100,6 +100,53 @@ def _workspace(device, size_fn, which=0):
 
 
 # ----------------------------------------------------------------------------------------------------
+# Zeroed scratch.  A step needs ~20 zero-initialised f32 buffers (folded conv tap gradients, batched weight-gradient staging,
+# atomically accumulated sums); as separate torch.zeros calls each is a ~5 us fill launch.  They are carved out of ONE arena that
+# the model re-zeroes (used prefix only) in zero_grad(): one fill per step.  Regions stay valid until the next zero_grad(); callers
+# that never arm the arena (op-level tests) get plain torch.zeros.
+# ----------------------------------------------------------------------------------------------------
+class _ZeroArena:
+    FLOATS = 8 << 20           # 32 MB: ~2x what a cfg-512 step takes
+
+    def __init__(self):
+        self.buf, self.off, self.armed = None, 0, False
+
+    def _here(self, device):
+        d = torch.device(device)
+        return self.buf is not None and self.buf.device.type == d.type and (d.index is None or d.index == self.buf.device.index)
+
+    def arm(self, device):
+        """Start of a step: everything handed out so far is dead; zero it again."""
+        if not self._here(device):
+            self.buf = torch.zeros(self.FLOATS, dtype=torch.float32, device=device)
+        elif self.off:
+            self.buf[:self.off].zero_()
+        self.off, self.armed = 0, True
+
+    def take(self, n, device):
+        n8 = (n + 7) // 8 * 8                     # keep every region 32-byte aligned
+        if not self.armed or not self._here(device) or self.off + n8 > self.buf.numel():
+            return None
+        v = self.buf[self.off:self.off + n]
+        self.off += n8
+        return v
+
+
+_ARENA = _ZeroArena()
+
+
+def zeros_f32(shape, device):
+    """Zero-initialised f32 scratch of `shape`, valid until the model's next zero_grad()."""
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+        n *= int(d)
+    v = _ARENA.take(n, device)
+    if v is None:
+        return torch.zeros(shape, dtype=torch.float32, device=device)
+    return v.view(shape)
+
+
+# ----------------------------------------------------------------------------------------------------
 # Weight gradients on a side stream.  In backward the data-gradient chain (dY -> dX -> ...) is the critical path; the weight
 # gradient of a layer (x^T dY, accumulated into the flat gradient buffer) is a leaf of the dependency graph.  Most kernels of
 # this model are latency-bound and leave CUs idle, so the wgrad launches go to a second stream that forks from the current one
@@ -265,7 +312,7 @@ class _Linear(torch.autograd.Function):
             gemm(dpre, wc, dx, M, K, N, (0, 0, N, 1), (0, 0, 1, N), (0, 0, K), dt)        # dx = dpre W^T
             dx = dx.view(ctx.xshape)
         with wgrad_stream(1, x2, dpre):
-            gw = ctx.gw if ctx.fold is None else torch.zeros((K, N), dtype=torch.float32, device=x2.device)
+            gw = ctx.gw if ctx.fold is None else zeros_f32((K, N), x2.device)
             gemm(x2, dpre, gw, K, N, M, (0, 0, 1, K), (0, 0, N, 1), (0, 0, N), dt, c_f32=1, accumulate=1,
                  splitk=0, colsum=ctx.gb)                                 # dW += x^T dpre ; db += 1^T dpre (fused)
             if ctx.fold is not None:
@@ -338,7 +385,7 @@ class _LinearZ(torch.autograd.Function):
                 dx = torch.empty(xshape, dtype=x.dtype, device=x.device)
                 gemm(dpre, ctx.w0, dx, R, K, N, (0, 0, N, 1), (0, 0, 1, N), (0, 0, K), dt, kseg=(Z, R * N, wstride))
             elif shared_x:     # few rows: Z independent launches-in-one fill the GPU better; all z accumulate with f32 atomics
-                acc = torch.zeros((R, K), dtype=torch.float32, device=x.device)
+                acc = zeros_f32((R, K), x.device)
                 gemm(dpre, ctx.w0, acc, R, K, N, (0, R * N, N, 1), (0, wstride, 1, N), (0, 0, K), dt, nb=(1, Z), c_f32=1, accumulate=1)
                 dx = acc.to(x.dtype).view(xshape)
             else:
@@ -638,7 +685,7 @@ class _FgBias(torch.autograd.Function):
         (off,) = ctx.saved_tensors
         B, G, Hh, Ww = ctx.geo
         dbias = dbias.contiguous().to(off.dtype)
-        doff = torch.zeros(off.shape, dtype=torch.float32, device=off.device)     # accumulated by the kernel's query slices
+        doff = zeros_f32(tuple(off.shape), off.device)     # accumulated by the kernel's query slices
         call('stj_fg_bias_bwd', _p(off), _p(ctx.pt.master), _p(dbias), _p(ctx.pt.grad), _p(doff), B, G, Hh, Ww, _dt(off), _st())
         return doff.to(off.dtype), None, None, None, None
 
@@ -781,7 +828,7 @@ class _UpConv(torch.autograd.Function):
             with _timed(f'upconv_dgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
                 call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), _p(x) if ctx.x_is_elu_out else None, F_, Hi, Wi, Cin, Cout, dt, _st())
         with wgrad_stream(2, x, dpre):
-            dweff = torch.zeros(16 * Cout * Cin, dtype=torch.float32, device=x.device)     # the 16 folded tap matrices
+            dweff = zeros_f32(16 * Cout * Cin, x.device)     # the 16 folded tap matrices
             pb = ctx.pb
             if pb.part is not None:  # model-owned bias-gradient copies, folded into .grad once per step
                 dbp, nparts, own = pb.part[0], pb.part[1], False
@@ -859,7 +906,7 @@ class _OgmFlowLoss(torch.autograd.Function):
         logits = logits.contiguous().float()
         B, H, W, _ = logits.shape
         dev = logits.device
-        sums = torch.zeros(32 * 40, dtype=torch.float32, device=dev)       # 32 copies of the 40 accumulators (stj_loss_fwd)
+        sums = zeros_f32(32 * 40, dev)       # 32 copies of the 40 accumulators (stj_loss_fwd)
         loss = torch.empty(4, dtype=torch.float32, device=dev)
         coef = torch.empty(32, dtype=torch.float32, device=dev)
         call('stj_loss_fwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(sums), _p(loss), _p(coef),
@@ -884,7 +931,7 @@ def auc_gate(gt_obs, gt_occ, gt_flow, origin, return_auc=False):
     _req_cuda(gt_obs)
     B, _, H, W, _ = gt_obs.shape
     dev = gt_obs.device
-    hist = torch.zeros(8 * 202, dtype=torch.int32, device=dev)
+    hist = zeros_f32(8 * 202, dev).view(torch.int32)
     gate = torch.empty(8, dtype=torch.float32, device=dev)
     auc = torch.empty(8, dtype=torch.float32, device=dev)
     call('stj_loss_auc_gate', _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(hist), _p(gate), _p(auc), B, H, W, _st())
