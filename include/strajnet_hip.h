@@ -150,6 +150,12 @@ int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, 
 int stj_decode_raw(const void* src, int kind, float* dst, long long n_outer, int H, int W, int C, int y0, int x0, int Ho,
                    int Wo, float scale, hipStream_t stream);
 
+/* Time-kernel collapse of the decoder's Conv3D(8,1,1) SAME skips (modules.py:693-698,709-716,750-765): the
+ * input is the same frame at all 8 steps, so step t needs W_t = sum_{j=max(0,3-t)}^{min(7,10-t)} W[j].  W f32 [8][n] (n = Cin*Cout),
+ * Wz T [8][n].  fold (backward): dW[j] += sum over the t whose window contains j of dWz[t]. */
+int stj_time_collapse(const float* W, void* Wz, long long n, int dtype, hipStream_t stream);
+int stj_time_fold(const float* dWz, float* dW, long long n, hipStream_t stream);
+
 /* Host-side CRC-32C (Castagnoli) for the two TensorFlow file formats on either side of the hot path: TFRecord framing
  * (train.py:75-78) and the checkpoint bundle written / read by save_weights / load_weights (train.py:358,366,372;
  * inference.py:283).  *crc is the running, unmasked CRC: 0 before the first chunk, the checksum after the last.  Runs on the

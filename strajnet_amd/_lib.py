@@ -19,6 +19,8 @@ SIGNATURES = {
     'stj_colsum': [vp, vp, ci, ci, cl, ci, vp],
     'stj_cast': [vp, ci, vp, ci, cl, vp],
     'stj_crc32c': [vp, cl, vp],
+    'stj_time_collapse': [vp, vp, cl, ci, vp],
+    'stj_time_fold': [vp, vp, cl, vp],
     'stj_decode_raw': [vp, ci, vp, cl, ci, ci, ci, ci, ci, ci, ci, cf, vp],
     'stj_metrics': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_rng_advance': [vp, vp],

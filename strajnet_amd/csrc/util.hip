@@ -208,6 +208,56 @@ extern "C" int stj_decode_raw(const void* src, int kind, float* dst, long long n
   return stj_check_launch("stj_decode_raw");
 }
 
+// ------------------------------------------------------------------------------------------------ Conv3D time-kernel collapse
+// The decoder's Conv3D(8,1,1) SAME skips see the same frame at every time step (modules.py:750-765), so output time t only needs
+// W_t = sum_{j = max(0,3-t)}^{min(7,10-t)} W[j].  fwd: W f32 [8][n] -> Wz T [8][n]; bwd: dW[j] += sum over
+// the t whose window contains j of dWz[t] -- one small launch each instead of an 8x8 matmul, a cast and an add.
+template <typename T>
+__global__ __launch_bounds__(256) void time_collapse_kernel(const float* __restrict__ W, T* __restrict__ Wz, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = W[j * n + i];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j >= 3 - t && j <= 10 - t) a += w[j];
+      stf(Wz + t * n + i, a);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void time_fold_kernel(const float* __restrict__ dWz, float* __restrict__ dW, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+    float g[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) g[t] = dWz[t * n + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (j >= 3 - t && j <= 10 - t) a += g[t];
+      dW[j * n + i] += a;
+    }
+  }
+}
+extern "C" int stj_time_collapse(const float* W, void* Wz, long long n, int dtype, hipStream_t stream) {
+  if (n <= 0) return STJ_OK;
+  const int g = ew_grid(n);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(time_collapse_kernel<bf16>, dim3(g), dim3(256), 0, stream, W, (bf16*)Wz, n);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(time_collapse_kernel<f16>, dim3(g), dim3(256), 0, stream, W, (f16*)Wz, n);
+  else if (dtype == STJ_F32) hipLaunchKernelGGL(time_collapse_kernel<float>, dim3(g), dim3(256), 0, stream, W, (float*)Wz, n);
+  else { stj_set_error("stj_time_collapse: bad dtype %d", dtype); return STJ_EINVAL; }
+  return stj_check_launch("stj_time_collapse");
+}
+extern "C" int stj_time_fold(const float* dWz, float* dW, long long n, hipStream_t stream) {
+  if (n <= 0) return STJ_OK;
+  hipLaunchKernelGGL(time_fold_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, dWz, dW, n);
+  return stj_check_launch("stj_time_fold");
+}
+
 // ------------------------------------------------------------------------------------------------ host CRC-32C
 // TFRecord framing (train.py:75-78 tf.data.TFRecordDataset) and the TF checkpoint bundle (train.py:358,366,372
 // save_weights / load_weights) both checksum with CRC-32C (Castagnoli, reflected 0x82F63B78).  Slice-by-8 on the host: the

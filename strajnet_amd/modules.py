@@ -216,12 +216,7 @@ class STrajNet:
                 self.drop_path_rate[f'layers{i}/blocks{j}'] = float(dpr[sum(cfg['depths'][:i]) + j])
         for j in range(cfg['depths'][0]):
             self.drop_path_rate[f'flow_layers0/blocks{j}'] = float(dpr[j])
-        # constants of the graph, built once: which of the 8 Conv3D time taps see real (non-padded) frames for output time t
-        # (SAME padding 3 before / 4 after), and the obs/occ segment one-hots (trajNet.py:119-120)
-        sel = torch.zeros((8, 8), dtype=torch.float32)
-        for t in range(8):
-            sel[t, max(0, 3 - t):min(7, 10 - t) + 1] = 1
-        self._time_sel = sel.to(self.device)
+        # constants of the graph, built once: the obs/occ segment one-hots (trajNet.py:119-120)
         self._seg_onehot = {}
         self.dropctx = ops.DropCtx(self.device, seed)
         self._dctx = None
@@ -503,12 +498,12 @@ class STrajNet:
         time taps (modules.py:750-765): W_t = sum_{j=max(0,3-t)}^{min(7,10-t)} W[j]."""
         pw, pb = self._p(name + '/kernel'), self._p(name + '/bias')
         Ci, Co = pw.shape[3], pw.shape[4]
-        sel = self._time_sel
-        wz = (sel @ pw.master.detach().view(8, Ci * Co)).view(8, Ci, Co).to(self.dtype)
+        wz = torch.empty((8, Ci, Co), dtype=self.dtype, device=self.device)
+        ops.call('stj_time_collapse', ops._p(pw.master), ops._p(wz), Ci * Co, ops.DTYPE_CODE[self.dtype], ops._st())
         gwz = ops.zeros_f32((8, Ci, Co), self.device)
 
         def fold():
-            pw.grad.view(8, Ci * Co).add_(sel.t() @ gwz.view(8, Ci * Co))
+            ops.call('stj_time_fold', ops._p(gwz), ops._p(pw.grad), Ci * Co, ops._st())
         return ops.linear_z(skip, pw.master, wz[0], Ci * Co, pb.master.detach(), 0, gwz[0], Ci * Co, pb.grad, 8,
                             act=ACT_ELU, shared_x=True, fold=fold)    # [8, B*HW, Co]  (time-major)
 
