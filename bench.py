@@ -182,6 +182,9 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
+        # communicator set-up (seconds the first time) must never land in the timed region, whatever --warmup says
+        dist.all_reduce(torch.zeros(1, device=dev))
+        torch.cuda.synchronize()
 
     if args.dtype is None:
         args.dtype = 'f16' if args.infer else 'bf16'
