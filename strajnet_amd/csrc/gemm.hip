@@ -445,6 +445,10 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   const double flops = 2.0 * p.M * p.N * (double)p.K * nb;
   if (p.N > 64 && p.M > 64 && tiles128 >= 1024 && p.K >= 1024 && flops > 2e11) cfg = 0;
   else cfg = 2;
+  // Few rows (the 16x16 Swin stage, the 64-agent encoder): 64x64 tiles leave most of the 256 CUs idle and a plain GEMM cannot
+  // split K.  32x32 tiles quadruple the workgroups.
+  { static int small = -1; if (small < 0) { const char* e = getenv("STJ_GEMM_SMALL"); small = e ? atoi(e) : 256; }
+    if (!p.accumulate && tiles64 < small && p.M >= 32 && p.N >= 32) cfg = 3; }
   { static int f = -2; if (f == -2) { const char* e = getenv("STJ_GEMM_CFG"); f = e ? atoi(e) : -1; } if (f >= 0 && !p.accumulate) cfg = f; }
   if (p.splitk == 0) {            // auto split-K (accumulating GEMMs only): aim at ~2 blocks per CU
     const long long tiles = cfg == 0 ? tiles128 : (cfg == 1 ? (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * nb : tiles64);
@@ -458,7 +462,8 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
     if (s >= 8 && nb == 1) s = s / 8 * 8;      // multiple of 8: enables the XCD-aware work map
     p.splitk = (int)s;
   }
-  if (cfg == 0) launch_tile<T, 128, 128, 2, 2>(p, ta, tb, st);
+  if (cfg == 3) launch_tile<T, 32, 32, 2, 2>(p, ta, tb, st);
+  else if (cfg == 0) launch_tile<T, 128, 128, 2, 2>(p, ta, tb, st);
   else if (cfg == 1) launch_tile<T, 128, 64, 4, 1>(p, ta, tb, st);
   else launch_tile<T, 64, 64, 2, 2>(p, ta, tb, st);
   return stj_check_launch("stj_gemm");
