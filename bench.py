@@ -7,10 +7,15 @@
 Workload (BASELINE.json configs[1]): batch 8 per GPU, bf16 storage / f32 accumulate, cfg-256
 (input 256x256x11, window 8, embed 96, depths [2,2,2], heads [3,6,12], fg_msa=True, fg=True, large_ogm=False),
 8 waypoints, observed + occluded + flow heads, synthetic inputs of SURVEY.md 8(d), random-init weights.
-A "step" = model forward, OGMFlow_loss (use_gt AUC gate + flow-warp term), backward into the flat f32 gradient
-buffer, and -- for N>1 -- one RCCL SUM all-reduce of that buffer (loss pre-scaled by 1/N via replica=N, exactly as
-loss.py:200 + MirroredStrategy do).  The optimizer is not part of the metric ("next" item 8f-1).
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+A "step" = model forward (training=True draws), OGMFlow_loss (use_gt AUC gate + flow-warp term), backward into the flat f32
+gradient buffer, for N>1 the RCCL SUM all-reduce of that buffer (loss pre-scaled by 1/N via replica=N, exactly as loss.py:200 +
+MirroredStrategy do; the decoder / attention bucket is reduced under the encoder's backward), and the fused Keras-Nadam update
+(train.py:197,224) -- `value` INCLUDES the optimizer (`config.optimizer_in_step`); SURVEY 8d words the metric without it, so
+the optimizer-free rate of the same run is reported next to it (`without_optimizer`; `--no-optimizer` times only that).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; besides the contract fields it carries
+`roofline` (the (kernel, shape) with the largest total time in the step, timed alone with HIP events), `families` (every kernel
+family: ms/step, launches, executed TFLOP/s, algorithmic GB/s), `parity_mode` / `bf16_error` (the f32 mode that holds the 1e-3
+gate: its rate and error vs the CPU oracle; the timed bf16 mode's error vs that f32 mode) and `cpu_baseline`.
 """
 import argparse
 import json
@@ -27,6 +32,7 @@ ALGO_GFLOP_STEP_PER_SCENE = 602.0     # fwd + dgrad + wgrad
 ALGO_GFLOP_STEP_PER_SCENE_512 = 3 * 240.9   # cfg-512 with depths [2,2,6]
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0                # HBM3E (MI355X_MICROARCH.md)
 
 CFG256 = dict(input_size=(256, 256), window_size=8, embed_dim=96, depths=[2, 2, 2], num_heads=[3, 6, 12])
 
@@ -130,6 +136,8 @@ def cpu_baseline(max_seconds=30.0):
     t0 = time.time()
     step()
     warm = time.time() - t0
+    with torch.no_grad():
+        y_ref = torch_ref.forward(p, CFG256, xt['ogm'], xt['map_img'], xt['obs'], xt['occ'], xt['flow']).detach().numpy().copy()
     times = []
     while (sum(times) < 12.0 or len(times) < 2) and len(times) < 64 and (time.time() - t0) < max_seconds:
         t1 = time.time()
@@ -138,9 +146,67 @@ def cpu_baseline(max_seconds=30.0):
     if not times:
         times = [warm]
     sec = float(np.median(times))
-    return {'value': round(1.0 / sec, 4), 'unit': 'scenes/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'B=1 cfg-256 f32 fwd+loss+bwd, oracle/torch_ref.py on CPU (not TensorFlow), 1 warm-up + {len(times)} timed steps '
-                      f'({sum(times):.1f} s of CPU work), median {sec:.2f} s/step'}
+    return ({'value': round(1.0 / sec, 4), 'unit': 'scenes/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+             'sample': f'B=1 cfg-256 f32 fwd+loss+bwd, oracle/torch_ref.py on CPU (not TensorFlow), 1 warm-up + {len(times)} timed steps '
+                       f'({sum(times):.1f} s of CPU work), median {sec:.2f} s/step'}, y_ref, w, x)
+
+
+def parity_extras(model, loss_fn, x, B, dev, with_cpu):
+    """After the timed region, same process: (1) `parity_mode` -- the f32-storage mode (the one that holds north_star's 1e-3
+    abs gate) timed on the same batch, and, inside the cpu_baseline leg (the only place bench.py touches oracle/), its max-abs
+    error against the CPU oracle's forward on the oracle's own B=1 inputs; (2) `bf16_error` -- the timed bf16 mode against that
+    f32 mode on the bench batch (eval forward): max-abs / rms of the logits and the largest PR-AUC difference."""
+    import torch
+    from strajnet_amd import (STrajNet, get_pred_waypoint_logits, warpped_gt, compute_occupancy_flow_metrics,
+                              OccupancyFlowTaskConfig, apply_sigmoid_to_occupancy_logits)
+    m32 = STrajNet(CFG256, fg_msa=True, fg=True, large_ogm=False, dtype=torch.float32, device=dev, seed=0)
+    with torch.no_grad():
+        m32.flat_weights().copy_(model.flat_weights())
+
+    def fwd(m, xx, training=False):
+        return m(xx['ogm'], xx['map_img'], training=training, obs=xx['obs'], occ=xx['occ'], mapt=None, flow=xx['flow'])
+
+    def step32():
+        m32.zero_grad()
+        out = fwd(m32, x, True)
+        d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
+        (d['observed_xe'] + d['occluded_xe'] + d['flow'] + d['flow_warp_xe']).backward()
+    step32()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step32()
+    torch.cuda.synchronize()
+    dt32 = (time.perf_counter() - t0) / 3
+    res = {'parity_mode': {'dtype': 'f32', 'value': round(B / dt32, 2), 'unit': 'scenes/s', 'ms_per_step': round(dt32 * 1e3, 2),
+                           'note': 'same train step, f32 storage + exact-f32 MFMA, eager (no hipGraph), no optimizer',
+                           'max_abs_vs_oracle': None}}
+    with torch.no_grad():
+        y16 = fwd(model, x).float()
+        y32 = fwd(m32, x).float()
+        diff = y16 - y32
+        cfgm = OccupancyFlowTaskConfig(256, 256, 8)
+        gt = warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow'])
+        m16 = compute_occupancy_flow_metrics(cfgm, gt, apply_sigmoid_to_occupancy_logits(get_pred_waypoint_logits(y16))).values.tolist()
+        mm32 = compute_occupancy_flow_metrics(cfgm, gt, apply_sigmoid_to_occupancy_logits(get_pred_waypoint_logits(y32))).values.tolist()
+    res['bf16_error'] = {'vs': 'f32 mode of the same HIP path, same weights and batch, eval forward', 'max_abs': round(float(diff.abs().max()), 5),
+                         'rms': round(float(diff.pow(2).mean().sqrt()), 6), 'logit_scale_max_abs': round(float(y32.abs().max()), 3),
+                         'dAUC_observed': round(abs(m16[0] - mm32[0]), 6), 'dAUC_occluded': round(abs(m16[1] - mm32[1]), 6),
+                         'dAUC_flow_warped': round(abs(m16[5] - mm32[5]), 6)}
+    if with_cpu:
+        try:
+            cb, y_ref, w, xo = cpu_baseline()
+            res['cpu_baseline'] = cb
+            m32.load_weights(w)
+            xt = {k: torch.as_tensor(v).to(dev) for k, v in xo.items()}
+            with torch.no_grad():
+                y = fwd(m32, xt).cpu().numpy()
+            import numpy as np
+            res['parity_mode']['max_abs_vs_oracle'] = float(f'{np.abs(y - y_ref).max():.3e}')
+            res['parity_mode']['oracle'] = 'oracle/torch_ref.py f32 forward on CPU, B=1 cfg-256, oracle inputs/weights (PARITY UNPINNED by the reference: TensorFlow cannot run here)'
+        except Exception as e:
+            res['cpu_baseline'] = {'value': None, 'unit': 'scenes/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e}'}
+    return res
 
 
 def main():
@@ -156,6 +222,7 @@ def main():
     ap.add_argument('--cfg512', action='store_true', help='BASELINE config 5 instead of the metric config: 512x512 rasters, large_ogm, depths [2,2,6] (extra measurement, not the headline)')
     ap.add_argument('--infer', action='store_true', help='BASELINE config 4 instead of the metric config: inference-only forward, batch 32/GPU, fp16 MFMA path, hipGraph replay (extra measurement, not the headline)')
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd + loss + bwd (+ all-reduce) only, without the fused Keras-Nadam update (train.py:197,224) that the default step ends with')
+    ap.add_argument('--no-overlap', action='store_true', help='N>1: one all-reduce of the whole gradient buffer after a monolithic backward instead of two buckets overlapped with the encoder backward')
     ap.add_argument('--serial', action='store_true', help='no side streams: every kernel runs alone (the mode the roofline kernel timings are taken in)')
     ap.add_argument('--gemm-trace', action='store_true', help='print per-shape GEMM launch times (HIP events) to stderr')
     args = ap.parse_args()
@@ -193,7 +260,9 @@ def main():
         sys.exit(2)
     dtype = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f16': torch.float16}[args.dtype]
     cfg = dict(CFG256, input_size=(512, 512), depths=[2, 2, 6]) if args.cfg512 else CFG256
-    model = STrajNet(cfg, fg_msa=True, fg=True, large_ogm=args.cfg512, dtype=dtype, device=dev, seed=0)
+    # weights: the same seed on every rank (replicas start identical); Dropout / DropPath stream: per rank, like MirroredStrategy's
+    # independent per-replica draws
+    model = STrajNet(cfg, fg_msa=True, fg=True, large_ogm=args.cfg512, dtype=dtype, device=dev, seed=0, dropout_seed=rank)
     loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(256, 256, 8), ogm_weight=1000.0, occ_weight=1000.0, flow_weight=1.0,
                            replica=float(world), flow_origin_weight=1000.0, no_use_warp=False, use_pred=False,
                            use_focal_loss=False, use_gt=True)
@@ -208,10 +277,20 @@ def main():
     from strajnet_amd import Nadam
     opt = None if args.no_optimizer else Nadam.for_model(model, lr=1e-4)        # train.py:197
 
+    # Data parallel exchange: SUM all-reduce of the flat f32 gradient buffer, as two buckets.  Backward is cut at the
+    # raster encoder's outputs; the tail bucket (decoder / attention / trajNet gradients, complete first) is reduced on RCCL's
+    # stream UNDER the encoder's backward, the encoder bucket after it.  --no-overlap: one bucket after a monolithic backward.
+    overlap = world > 1 and not args.no_overlap
+    from strajnet_amd import dp
+    sync = dp.OverlappedGradSync(model) if overlap else None
+    model.cut_encoder = overlap
+
     def finish_step():
-        # the exchange step of data parallelism (one SUM all-reduce of the flat f32 gradient bucket), then the optimizer on it
         if world > 1:
-            dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
+            if overlap:
+                sync.head_and_wait()
+            else:
+                dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
         if opt is not None:
             opt.step()
 
@@ -221,6 +300,9 @@ def main():
         d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
         total = d['observed_xe'] + d['occluded_xe'] + d['flow'] + d['flow_warp_xe']
         total.backward()
+        if overlap:
+            sync.tail()
+            model.backward_encoder()
         finish_step()
         return total
 
@@ -228,14 +310,15 @@ def main():
     if not args.no_graph:
         try:
             from strajnet_amd.graph import GraphedTrainStep
-            graphed = GraphedTrainStep(model, loss_fn, x)
+            graphed = GraphedTrainStep(model, loss_fn, x, split=overlap)
         except Exception as e:           # capture is an optimisation, never a requirement
             print(f'bench.py: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
             graphed = None
+            model.cut_encoder = overlap
     eager_step = step
 
     def step_graph():
-        losses = graphed()
+        losses = graphed(between=sync.tail if overlap else None)
         finish_step()
         return losses.sum()
     if graphed is not None:
@@ -286,59 +369,86 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         nbytes = g.numel() * 4
-        allreduce = {'ms': round(ms, 4), 'mbytes': round(nbytes / 1e6, 1), 'collective': 'all_reduce(sum, f32), one bucket after backward',
+        allreduce = {'ms': round(ms, 4), 'mbytes': round(nbytes / 1e6, 1),
+                     'collective': 'all_reduce(sum, f32) of the whole flat gradient buffer, timed alone (the step itself reduces it as '
+                                   + ('two buckets, the tail one under the encoder backward)' if overlap else 'one bucket after backward)'),
+                     'overlapped': bool(overlap), 'bucket_mbytes': [round(model.bucket_split * 4 / 1e6, 1), round((g.numel() - model.bucket_split) * 4 / 1e6, 1)],
                      'busbw_GBps': round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1),
                      'frac_of_step': round(ms / (dt_s / args.steps * 1e3), 4)}
-    # per-kernel HIP-event timing of the conv kernels (roofline of the dominant one): the same launches, issued eagerly
-    # with events recorded on the launch stream -- under graph replay individual launches cannot carry events
-    prof = prof_conc = None
+    dist_info = None
+    if world > 1:
+        dist_info = dp.OverlappedGradSync.info()
+        dist_info['allreduce_overlapped_with_backward'] = bool(overlap)
+        chk = torch.ones(1, device=dev)
+        dist.all_reduce(chk)
+        dist_info['ranks_seen_by_allreduce'] = int(chk.item())       # every rank contributed 1: proof the collective spans N ranks
+    # per-kernel HIP-event timing of EVERY C-ABI launch (strajnet_amd/prof.py): the same launches, issued eagerly with events
+    # recorded on the launch stream -- under graph replay individual launches cannot carry events
+    prof_ser = prof_conc = None
+    nprof = min(args.steps, 3)
     if not args.no_kernel_timing:
+        from strajnet_amd import prof as kprof
         # (a) kernels ALONE: side streams off, so an event pair brackets exactly one kernel -- the roofline figures
         model.serial = True
-        ops.PROF_GEMM = args.gemm_trace
         eager_step()
-        ops.prof_enable()
-        for _ in range(min(args.steps, 3)):
+        kprof.enable()
+        for _ in range(nprof):
             eager_step()
         barrier()
-        prof = ops.prof_disable()
+        prof_ser = kprof.disable()
         # (b) as scheduled in the measured step (branches on concurrent streams share the GPU): reported next to (a)
         model.serial = args.serial
-        ops.PROF_GEMM = False
         eager_step()
-        ops.prof_enable()
-        for _ in range(min(args.steps, 3)):
+        kprof.enable()
+        for _ in range(nprof):
             eager_step()
         barrier()
-        prof_conc = ops.prof_disable()
+        prof_conc = kprof.disable()
     if world > 1:
         t = torch.tensor([dt_s], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t.item())
     loss_val = float(last.detach())
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_kernel_timing and not args.cfg512 and dtype == torch.bfloat16:
+        try:
+            extras = parity_extras(model, loss_fn, x, B, dev, not args.no_cpu_baseline)
+        except Exception as e:          # reported extras, never the product path
+            extras = {'parity_mode': {'error': f'{type(e).__name__}: {e}'}}
 
     if rank == 0:
         scenes = B * world * args.steps
         algo_step = ALGO_GFLOP_STEP_PER_SCENE_512 if args.cfg512 else ALGO_GFLOP_STEP_PER_SCENE
         value = scenes / dt_s
-        peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if dtype != torch.float32 else PEAK_F32_TFLOPS
         roof = None
+        families = None
         kern = {}
-        if prof:
-            for k, evs in prof.items():
-                ms = [a.elapsed_time(b) for a, b, _ in evs]
-                kern[k] = (sum(ms) / len(ms), evs[0][2], sum(ms))
+        if prof_ser:
+            from strajnet_amd import prof as kprof
+            keys, fams = kprof.summarize(prof_ser, nprof)
+            ckeys = kprof.summarize(prof_conc, nprof)[0] if prof_conc else {}
             if args.gemm_trace:
-                tot = sum(v[2] for k, v in kern.items() if k.startswith('gemm')) / min(args.steps, 3)
-                print(f'# GEMM launches by shape: {tot:.3f} ms/step', file=sys.stderr)
-                for k in sorted((k for k in kern if k.startswith('gemm')), key=lambda k: -kern[k][2]):
-                    n = len(prof[k]) / min(args.steps, 3)
-                    print(f'{kern[k][2] / min(args.steps, 3) * 1e3:9.1f} us/step  {n:5.1f} x {kern[k][0] * 1e3:7.1f} us  '
-                          f'{kern[k][1] / kern[k][0] / 1e9:7.1f} TF/s  {k}', file=sys.stderr)
-                kern = {k: v for k, v in kern.items() if not k.startswith('gemm')}
-            dom = max(kern, key=lambda k: kern[k][2])
-            avg_ms, flops, _ = kern[dom]
-            ach = flops / (avg_ms * 1e-3) / 1e12
+                print('# launches by kernel and shape (serial pass)', file=sys.stderr)
+                for k in sorted(keys, key=lambda k: -keys[k]['ms_per_step']):
+                    v = keys[k]
+                    print(f"{v['ms_per_step'] * 1e3:9.1f} us/step  {v['launches']:5.1f} x {v['avg_ms'] * 1e3:7.1f} us  "
+                          f"{v['flops_exec'] / v['avg_ms'] / 1e9:7.1f} TF/s  {v['bytes_alg'] / v['avg_ms'] / 1e6:7.0f} GB/s  {k}", file=sys.stderr)
+            tot_ms = sum(f['ms_per_step'] for f in fams.values())
+            families = {}
+            for n in sorted(fams, key=lambda n: -fams[n]['ms_per_step']):
+                f = fams[n]
+                families[n] = {'ms_per_step': round(f['ms_per_step'], 4), 'launches': round(f['launches'], 1),
+                               'TFLOPs_exec': round(f['flop_exec'] / f['ms_per_step'] / 1e9, 1) if f['flop_exec'] else None,
+                               'GBps': round(f['bytes'] / f['ms_per_step'] / 1e6, 0) if f['bytes'] else None}
+            # the dominant kernel = the (kernel, shape) with the largest total time in the step, whatever its family
+            dom = max(keys, key=lambda k: keys[k]['ms_per_step'])
+            d = keys[dom]
+            t_s = d['avg_ms'] * 1e-3
+            ai_exec = d['flops_exec'] / max(d['bytes_alg'], 1.0)
+            balance = peak * 1e12 / (PEAK_HBM_GBPS * 1e9)
+            bound = 'mfma' if ai_exec >= balance else 'hbm'
+            tf_alg, tf_exec, gbps = d['flops_alg'] / t_s / 1e12, d['flops_exec'] / t_s / 1e12, d['bytes_alg'] / t_s / 1e9
             traffic = None
             tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
             if os.path.exists(tpath):
@@ -346,36 +456,53 @@ def main():
                     traffic = json.load(open(tpath)).get(dom)
                 except Exception:
                     traffic = None
-            conc = prof_conc.get(dom) if prof_conc else None
-            conc_ms = sum(a.elapsed_time(b) for a, b, _ in conc) / len(conc) if conc else None
-            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(ach / peak, 4), 'traffic': traffic, 'avg_launch_ms': round(avg_ms, 4),
-                    'timing': 'kernel alone on the GPU (side streams off, eager pass after the timed region)',
-                    'avg_launch_ms_in_step': round(conc_ms, 4) if conc_ms else None,
-                    'algorithmic_gflop_per_launch': round(flops / 1e9, 2),
-                    'end_to_end_frac': round(value * algo_step / 1e3 / (peak * world), 4)}
+            exec_gf_step = sum(f['flop_exec'] for f in fams.values()) / 1e9
+            roof = {'bound': bound, 'kernel': dom,
+                    'achieved': round(gbps if bound == 'hbm' else tf_alg, 2), 'peak': PEAK_HBM_GBPS if bound == 'hbm' else peak,
+                    'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s',
+                    'frac': round(gbps / PEAK_HBM_GBPS if bound == 'hbm' else tf_alg / peak, 4),
+                    'traffic': traffic,
+                    'mfma_frac_algorithmic': round(tf_alg / peak, 4), 'mfma_frac_executed': round(tf_exec / peak, 4),
+                    'hbm_frac': round(gbps / PEAK_HBM_GBPS, 4),
+                    'hbm_frac_pmc': round(traffic / t_s / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None,
+                    'executed_flop_per_byte': round(ai_exec, 1), 'machine_balance_flop_per_byte': round(balance, 1),
+                    'avg_launch_ms': round(d['avg_ms'], 4), 'launches_per_step': round(d['launches'], 1),
+                    'ms_per_step_of_this_kernel': round(d['ms_per_step'], 4), 'serial_kernel_ms_per_step': round(tot_ms, 3),
+                    'timing': 'kernel alone on the GPU (side streams off, eager pass after the timed region, HIP events on the launch stream)',
+                    'avg_launch_ms_in_step': round(ckeys[dom]['avg_ms'], 4) if dom in ckeys else None,
+                    'algorithmic_gflop_per_launch': round(d['flops_alg'] / 1e9, 2), 'executed_gflop_per_launch': round(d['flops_exec'] / 1e9, 2),
+                    'algorithmic_mbytes_per_launch': round(d['bytes_alg'] / 1e6, 1),
+                    'end_to_end_frac': round(value * algo_step / 1e3 / (peak * world), 4),
+                    'end_to_end_frac_executed': round(value / B * exec_gf_step / 1e3 / (peak * world), 4),
+                    'executed_gflop_per_scene_step': round(exec_gf_step / B, 1)}
+            kern = {k: round(v['avg_ms'], 4) for k, v in sorted(keys.items()) if v['ms_per_step'] >= 0.1}
         out = {
             'metric': 'scenes/sec (fwd+bwd, 256x256 grids)', 'value': round(value, 3), 'unit': 'scenes/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt_s / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'STrajNet {"cfg-512 (large_ogm, depths [2,2,6])" if args.cfg512 else "cfg-256"} train step (fwd+OGMFlow_loss+bwd{"+RCCL grad all-reduce" if world > 1 else ""}{"+Nadam" if opt is not None else ""}), '
                                    f'batch {B}/GPU, 8 waypoints, obs+occ+flow heads, fg_msa+fg, random-init weights',
-                       'global_batch': B * world, 'grid': '256x256x11', 'parallelism': f'dp{world}', 'hipgraph': graphed is not None, 'concurrent_branch_streams': not args.serial,
+                       'global_batch': B * world, 'grid': '512x512x11 rasters, 256x256 output' if args.cfg512 else '256x256x11', 'parallelism': f'dp{world}', 'hipgraph': graphed is not None, 'concurrent_branch_streams': not args.serial,
                        'optimizer_in_step': opt is not None, 'algorithmic_gflop_per_scene_step': algo_step},
             'loss': round(loss_val, 4),
             'without_optimizer': fwd_bwd_only,
             'allreduce': allreduce,
             'roofline': roof,
         }
-        if prof:
-            out['kernel_ms'] = {k: round(v[0], 4) for k, v in sorted(kern.items())}
-        if not args.no_cpu_baseline and world == 1 and not args.cfg512:
-            try:
-                out['cpu_baseline'] = cpu_baseline()
-            except Exception as e:      # the CPU port is a reported extra, never the product path
-                out['cpu_baseline'] = {'value': None, 'unit': 'scenes/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e}'}
-        else:
-            out['cpu_baseline'] = None
+        if world > 1:
+            out['distributed'] = dist_info
+        if families:
+            out['families'] = families
+            out['kernel_ms'] = kern
+        out.update(extras)
+        if 'cpu_baseline' not in out:
+            if not args.no_cpu_baseline and world == 1 and not args.cfg512:
+                try:
+                    out['cpu_baseline'] = cpu_baseline()[0]
+                except Exception as e:      # the CPU port is a reported extra, never the product path
+                    out['cpu_baseline'] = {'value': None, 'unit': 'scenes/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e}'}
+            else:
+                out['cpu_baseline'] = None
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

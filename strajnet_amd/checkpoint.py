@@ -341,18 +341,28 @@ class BundleReader:
         return a.reshape(e['shape'])
 
     def _strings(self, key, e, raw):
-        """[varint64 length]*n, the masked CRC-32C of the lengths (4 bytes), then the bytes back to back."""
+        """[varint64 length]*n, the masked CRC-32C of the lengths (4 bytes), then the bytes back to back.  Checksums follow
+        tensor_bundle ReadStringTensor: lengths enter the running CRC as uint32 (uint64 above 2^32-1)."""
         n = int(np.prod(e['shape'], dtype=np.int64))
         i, lens = 0, []
+        c = 0
         for _ in range(n):
             ln, i = _varint(raw, i)
             lens.append(ln)
+            c = crc32c(_len_word(ln), c)
+        lcs = raw[i:i + 4]
+        if self.verify and (len(lcs) != 4 or struct.unpack('<I', lcs)[0] != _mask(c)):
+            raise ValueError(f'{key}: string length checksum mismatch')
+        c = crc32c(lcs, c)
         i += 4
         out = []
         for ln in lens:
             out.append(raw[i:i + ln]); i += ln
+            c = crc32c(out[-1], c)
         if i != len(raw):
             raise ValueError(f'{key}: string tensor size mismatch')
+        if self.verify and e['crc32c'] is not None and _mask(c) != e['crc32c']:
+            raise ValueError(f'{key}: string tensor checksum mismatch')
         return out[0] if not e['shape'] else np.array(out, dtype=object).reshape(e['shape'])
 
     def object_graph(self):
@@ -375,6 +385,11 @@ class BundleReader:
                         return key
         key = path + VAR_SUFFIX                                 # name-based checkpoints / graphs that miss the path
         return key if key in self.entries else None
+
+
+def _len_word(n):
+    """A string length as it enters the bundle checksum: fixed uint32 when it fits, else uint64 (tensor_bundle.cc)."""
+    return struct.pack('<I', n) if n <= 0xFFFFFFFF else struct.pack('<Q', n)
 
 
 class BundleWriter:
@@ -406,10 +421,11 @@ class BundleWriter:
         self._put(key, DT_OF[np.dtype(dt)], a.shape, raw, _mask(crc32c(raw)))
 
     def add_string(self, key, value):
-        """Scalar DT_STRING: varint64 length, masked CRC-32C of the length as a fixed 64-bit word, then the bytes; the entry
-        checksum runs over the 64-bit length, the 4 checksum bytes and the string bytes."""
+        """Scalar DT_STRING (tensor_bundle WriteStringTensor): varint64 length, masked CRC-32C of the length, then the bytes.  The
+        running checksum is extended with the length as a uint32 when it fits 32 bits (a uint64 only above that), then with the
+        4 bytes of the masked length checksum, then with the string bytes; the entry crc32c is its masked value."""
         value = bytes(value)
-        c = crc32c(struct.pack('<Q', len(value)))
+        c = crc32c(_len_word(len(value)))
         lcs = struct.pack('<I', _mask(c))
         c = crc32c(value, crc32c(lcs, c))
         self._put(key, DT_STRING, (), _enc_varint(len(value)) + lcs + value, _mask(c))

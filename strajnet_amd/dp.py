@@ -5,6 +5,10 @@ on ROCm) / xGMI.  Mirrors the reference's tf.distribute.MirroredStrategy semanti
     gradients are SUM-all-reduced => global-batch mean;
   * ONE exchange step per iteration: the model's flat f32 gradient buffer (13.28 M values, 53 MB) is the bucket --
     a single all-reduce, no per-tensor collectives (xGMI is point-to-point: few large messages).
+  * `OverlappedGradSync`: the same sum as TWO buckets of that buffer.  Backward produces the gradients of everything downstream
+    of the raster encoder first (decoder, cross-attentions, trajNet, FG-MSA: the tail of the flat buffer, ~8 M values); their
+    all-reduce is launched on RCCL's stream as soon as they exist and runs under the encoder's backward; the encoder bucket
+    (~5.4 M values) follows.  Needs the model in cut_encoder mode (modules.STrajNet.backward_encoder).
 Forward-only needs no communication (replicas only).
 """
 import torch
@@ -52,3 +56,43 @@ def reduce_metrics(values):
         dist.all_reduce(values, op=dist.ReduceOp.SUM)
         values /= world()
     return values
+
+
+class OverlappedGradSync:
+    """Two-bucket gradient exchange overlapped with backward (the reference's all-reduce is part of the step: train.py:224).
+
+        model.cut_encoder = True
+        loss.backward()              # ends at the encoder outputs: flat_grads()[split:] is final
+        sync.tail()                  # async SUM all-reduce of that bucket (RCCL stream), returns at once
+        model.backward_encoder()     # runs concurrently with it
+        sync.head_and_wait()         # all-reduce of flat_grads()[:split]; the current stream then waits for both
+
+    With a captured step the two halves are two hipGraphs (graph.GraphedTrainStep(split=True)) and tail() is its `between` hook."""
+
+    def __init__(self, model):
+        g = model.flat_grads()
+        k = int(model.bucket_split)
+        self.head, self.tail_bucket = g[:k], g[k:]
+        self._work = []
+
+    def tail(self):
+        if world() > 1:
+            self._work.append(dist.all_reduce(self.tail_bucket, op=dist.ReduceOp.SUM, async_op=True))
+
+    def head_and_wait(self):
+        if world() > 1:
+            self._work.append(dist.all_reduce(self.head, op=dist.ReduceOp.SUM, async_op=True))
+            for w in self._work:
+                w.wait()             # stream-ordered for RCCL (no host block); blocking for gloo
+        self._work = []
+
+    @staticmethod
+    def info():
+        """What the communicator looks like from this rank (printed by bench.py at N>1 so a scaling run can be audited)."""
+        d = {'backend': dist.get_backend() if world() > 1 else None, 'ranks': world()}
+        try:
+            v = torch.cuda.nccl.version()
+            d['rccl_version'] = '.'.join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        except Exception:
+            d['rccl_version'] = None
+        return d

@@ -13,16 +13,25 @@ from .loss import get_pred_waypoint_logits, warpped_gt
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fn, batch, warmup=2, training=True):
-        self.model, self.loss_fn, self.training = model, loss_fn, training
+    """split=False: ONE graph for the whole step.  split=True (data parallel): TWO graphs cut at the raster encoder's outputs
+    (model.cut_encoder) -- graph A = forward + loss + backward of everything downstream of the encoder, graph B = the encoder's
+    backward; `__call__(between=f)` runs f between the two replays (dp.OverlappedGradSync.tail: the tail bucket's all-reduce then
+    overlaps graph B).  Both graphs share one private memory pool: B reads the activations A saved."""
+
+    def __init__(self, model, loss_fn, batch, warmup=2, training=True, split=False):
+        self.model, self.loss_fn, self.training, self.split = model, loss_fn, training, split
         self.static = {k: v.clone() for k, v in batch.items()}
-        self.graph = None
+        self.graph = self.graph_b = None
         self.losses = None
+        if split:
+            model.cut_encoder = True
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._eager()
+                if split:
+                    model.backward_encoder()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -31,6 +40,11 @@ class GraphedTrainStep:
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
             self.losses = self._eager()
         self.graph = g
+        if split:
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=g.pool(), capture_error_mode='thread_local'):
+                model.backward_encoder()
+            self.graph_b = gb
 
     def _eager(self):
         x, m = self.static, self.model
@@ -48,10 +62,14 @@ class GraphedTrainStep:
             if k in self.static:
                 self.static[k].copy_(v, non_blocking=True)
 
-    def __call__(self, batch=None):
+    def __call__(self, batch=None, between=None):
         if batch is not None:
             self.load(batch)
         self.graph.replay()
+        if self.graph_b is not None:
+            if between is not None:
+                between()
+            self.graph_b.replay()
         return self.losses          # [observed_xe, occluded_xe, flow, flow_warp_xe]; gradients in model.flat_grads()
 
 

@@ -11,8 +11,9 @@ train.py:105-140).  The fast path is the packed form: `get_pred_waypoint_logits(
 were sliced from, so the fused kernel reads [B,H,W,32] / [B,8,H,W,*] directly; hand-built lists are packed with
 torch.cat/stack first (autograd carries the gradient back through that packing).
 
-Only the configuration train.py:195-196 uses is built on the GPU: use_focal_loss=False, use_pred=False
-(constructor defaults of the reference differ: use_focal_loss=True -- requesting it raises NotImplementedError).
+Every flag of the reference constructor is built (template variants of the two loss kernels, csrc/loss.hip): the
+train.py:195-196 configuration (use_focal_loss=False, use_gt=True, use_pred=False) and the constructor defaults
+(use_focal_loss=True: tfa SigmoidFocalCrossEntropy alpha .25 gamma 2 + Keras BCE on probabilities; use_pred; no_use_warp).
 """
 import torch
 

@@ -156,7 +156,7 @@ class STrajNet:
     PARTS = 32
     def __init__(self, cfg, model_name='STrajNet', use_pyramid=True, actor_only=True, sep_actors=False,
                  fg_msa=False, use_last_ref=False, fg=False, large_ogm=True,
-                 device='cuda', dtype=torch.float32, seed=0):
+                 device='cuda', dtype=torch.float32, seed=0, dropout_seed=None):
         if not use_pyramid or not actor_only or sep_actors or use_last_ref:
             raise NotImplementedError('only use_pyramid=True, actor_only=True, sep_actors=False, use_last_ref=False '
                                       '(the configuration train.py:194 / modules.py:851 uses) is built')
@@ -218,7 +218,10 @@ class STrajNet:
             self.drop_path_rate[f'flow_layers0/blocks{j}'] = float(dpr[j])
         # constants of the graph, built once: the obs/occ segment one-hots (trajNet.py:119-120)
         self._seg_onehot = {}
-        self.dropctx = ops.DropCtx(self.device, seed)
+        # weights are seeded by `seed` (identical on every data-parallel replica); the Dropout / DropPath stream by `dropout_seed`
+        # (per replica: seed + rank, like MirroredStrategy's independent per-replica draws)
+        self.dropctx = ops.DropCtx(self.device, seed if dropout_seed is None else dropout_seed)
+        self._arena = ops._ZeroArena()    # this model's zeroed scratch (one fill per step)
         self._dctx = None
         self._side = torch.cuda.Stream(self.device) if (self.device.type == 'cuda' and os.environ.get('STJ_NO_SIDE_STREAM') != '1') else None
         self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and os.environ.get('STJ_NO_SIDE_STREAM2') != '1') else None
@@ -253,6 +256,16 @@ class STrajNet:
             idx.append(torch.arange(offs[n], offs[n] + k).repeat(P))
             o += P * k
         self._fold_index = torch.cat(idx).to(self.device)
+        # Two gradient buckets for data parallelism (dp.BucketedStep): the raster ENCODER's parameters come first in the flat buffer
+        # (patch embeds, Swin stages); everything downstream of the encoder outputs (FG-MSA, trajNet, cross-attentions, decoder)
+        # is the tail.  Backward produces the tail first, so its all-reduce runs under the encoder's backward.
+        enc = ('patch_embed', 'flow_norm', 'all_patch_norm', 'flow_layers', 'layers')
+        first_tail = next(n for n in spec if not n.startswith(enc))
+        assert all(not n.startswith(enc) for n in list(spec)[list(spec).index(first_tail):])
+        self.bucket_split = offs[first_tail]                                  # elements of the flat buffer in the encoder bucket
+        self._parts_split = P * sum(int(np.prod(spec[n][0])) for n in names if n.startswith(enc))
+        self.cut_encoder = False         # True: autograd is cut at the encoder outputs (backward() stops there; backward_encoder() finishes)
+        self._cut_src = self._cut_leaf = None
         self._sync_compute_weights()
 
     # ------------------------------------------------------------------ weights
@@ -302,12 +315,35 @@ class STrajNet:
 
     def zero_grad(self):
         self._gflat.zero_()
-        ops._ARENA.arm(self.device)          # the step's zeroed scratch comes out of one arena, re-zeroed here
+        self._arena.arm(self.device)         # the step's zeroed scratch comes out of this model's arena, re-zeroed here
+        ops.use_arena(self._arena)
 
-    def _fold_partials(self):
-        """Partial-gradient copies -> flat gradient buffer (runs on the caller's stream when backward() has been enqueued)."""
-        self._gflat.index_add_(0, self._fold_index, self._parts)
-        self._parts.zero_()
+    def _fold_partials(self, which=None):
+        """Partial-gradient copies -> flat gradient buffer (runs on the caller's stream when backward() has been enqueued).
+        which: None = all, 'tail' / 'encoder' = the copies of that gradient bucket only (cut_encoder mode)."""
+        k = self._parts_split
+        lo, hi = {None: (0, self._parts.numel()), 'encoder': (0, k), 'tail': (k, self._parts.numel())}[which]
+        if hi > lo:
+            self._gflat.index_add_(0, self._fold_index[lo:hi], self._parts[lo:hi])
+            self._parts[lo:hi].zero_()
+
+    def backward_encoder(self):
+        """cut_encoder mode: the second half of backward -- from the gradients that backward() left on the encoder outputs down to
+        the rasters' patch embeddings.  Ends with the side streams joined and the encoder bucket's partial copies folded, so the
+        caller can all-reduce flat_grads()[:bucket_split] next."""
+        if self._cut_src is None:
+            raise RuntimeError('backward_encoder(): no cut forward pending (set model.cut_encoder = True before the call)')
+        src, leaf = self._cut_src, self._cut_leaf
+        self._cut_src = self._cut_leaf = None
+        pairs = [(s_, l.grad) for s_, l in zip(src, leaf) if l.grad is not None]
+        torch.autograd.backward([a for a, _ in pairs], [g for _, g in pairs])
+        main = torch.cuda.current_stream(self.device)
+        for st in self._streams:
+            if st is not None:
+                main.wait_stream(st)
+        ops.wgrad_join_now(main)
+        with torch.no_grad():
+            self._fold_partials('encoder')
 
     def grads(self):
         return OrderedDict((n, p.grad) for n, p in self.params.items())
@@ -618,6 +654,7 @@ class STrajNet:
                 raise RuntimeError('inputs must be CUDA (ROCm) tensors: the HIP path has no CPU fallback')
         self._side, self._side2 = (None, None) if self.serial else self._streams
         ops.set_serial(self.serial)
+        ops.use_arena(self._arena)
         self._sync_compute_weights()
         self._dctx = None
         if training:                     # Dropout / DropPath draws of this step (reference: training=True, train.py:218)
@@ -636,6 +673,14 @@ class STrajNet:
         else:
             key, tmask = self._traj_net(obs, occ)
         res_list = self._encoder(ogm, map_img, flow)
+        fold = self._fold_partials
+        if self.cut_encoder and torch.is_grad_enabled():
+            # data-parallel overlap: detach here; backward() then ends at these leaves (the tail bucket is complete and can be
+            # all-reduced) and backward_encoder() resumes from their .grad
+            self._cut_src = res_list
+            res_list = [t.detach().requires_grad_(True) for t in res_list]
+            self._cut_leaf = res_list
+            fold = lambda: self._fold_partials('tail')
         # the three time-kernel skips (Conv3D collapsed to per-waypoint 1x1 GEMMs) only need the encoder outputs: side stream,
         # overlapping FG-MSA / the cross-attentions / the first up-convs; joined in the decoder where they are added
         skips = None
@@ -663,4 +708,4 @@ class STrajNet:
             tmask.record_stream(main)
         x = self._cross_attention_z(query.contiguous(), key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
         out = self._decoder(x, res_list, B, skips)
-        return ops.join_after_backward(out, (self._side, self._side2), self._fold_partials)
+        return ops.join_after_backward(out, (self._side, self._side2), fold)

@@ -11,7 +11,15 @@ import os
 
 import torch
 
-from ._lib import call
+from . import prof
+from ._lib import call as _raw_call
+
+
+def call(name, *args):
+    """One C-ABI call (strajnet_amd._lib.call); bracketed by HIP events when bench.py's per-kernel timing pass is on."""
+    if prof.ACTIVE is None:
+        return _raw_call(name, *args)
+    prof.record(name, args, lambda: _raw_call(name, *args))
 
 ACT_NONE, ACT_GELU, ACT_ELU = 0, 1, 2
 U_GELU, U_ELU, U_TANHS = 1, 2, 3
@@ -50,39 +58,6 @@ def _req_cuda(*ts):
         if t is not None and not t.is_cuda:
             raise RuntimeError('strajnet_amd ops run on the GPU only (HIP kernels); got a CPU tensor. '
                                'There is no CPU fallback.')
-
-
-# ---- optional per-kernel timing (bench.py's live roofline measurement): HIP events recorded on the launch stream
-_PROF = None
-PROF_GEMM = False
-
-
-def prof_enable():
-    global _PROF
-    _PROF = {}
-
-
-def prof_disable():
-    global _PROF
-    p, _PROF = _PROF, None
-    return p
-
-
-class _timed:
-    def __init__(self, key, flops):
-        self.key, self.flops = key, flops
-
-    def __enter__(self):
-        if _PROF is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e0.record(torch.cuda.current_stream())
-
-    def __exit__(self, *a):
-        if _PROF is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record(torch.cuda.current_stream())
-            _PROF.setdefault(self.key, []).append((self.e0, e1, self.flops))
-        return False
 
 
 _WS = {}
@@ -132,7 +107,14 @@ class _ZeroArena:
         return v
 
 
-_ARENA = _ZeroArena()
+_ARENA = _ZeroArena()        # the arena of the model whose step is being enqueued (each STrajNet owns one; see use_arena)
+
+
+def use_arena(arena):
+    """Make `arena` the one zeros_f32 carves from.  A model calls this from zero_grad() and call(): regions it took stay valid
+    until ITS next zero_grad(), whatever other models on the device do in between."""
+    global _ARENA
+    _ARENA = arena
 
 
 def zeros_f32(shape, device):
@@ -183,6 +165,15 @@ def _wgrad_join(key):
     st['armed'] = False
 
 
+def wgrad_join_now(main):
+    """Order `main` after everything queued on the weight-gradient side stream of main's device (used where a backward pass is
+    followed by work the autograd engine's callbacks do not cover)."""
+    key = main.device.index if main.device.index is not None else torch.cuda.current_device()
+    st = _WG.get(key)
+    if st is not None:
+        main.wait_stream(st['side'])
+
+
 def wgrad_stream(kind, *operands):
     """Context manager: kernels launched inside run on the weight-gradient side stream of the operands' device."""
     if _SERIAL or not (_WG_MODE & kind):
@@ -219,6 +210,12 @@ class _JoinAfterBackward(torch.autograd.Function):
         def join():
             for s in streams:
                 main.wait_stream(s)
+            # the weight-gradient side stream writes bias-gradient partials that `post` folds: it must be ordered before the fold
+            # (its own join callback is queued later than this one and would run after it)
+            key = g.device.index if g.device.index is not None else torch.cuda.current_device()
+            st = _WG.get(key)
+            if st is not None and st['armed']:
+                main.wait_stream(st['side'])
             if post is not None:          # e.g. fold the partial-gradient copies into the flat gradient buffer
                 with torch.cuda.stream(main), torch.no_grad():
                     post()
@@ -247,11 +244,6 @@ def gemm(A, B, C, M, N, K, sA, sB, sC, dt, bias=None, sBias=(0, 0), res=None, sR
          act=ACT_NONE, alpha=1.0, c_f32=0, accumulate=0, splitk=1, colsum=None, kseg=(1, 0, 0)):
     """sA = (b1, b2, m, k) element strides; sB = (b1, b2, k, n); sC = (b1, b2, ldc); sRes = (b1, b2, ld);
     kseg = (n, sA, sB): the contraction also runs over n K-segments of A / B that lie sA / sB elements apart."""
-    if _PROF is not None and PROF_GEMM:      # per-shape GEMM timing (tools/bench --gemm-trace); off in the normal kernel-timing pass
-        key = f'gemm[{M}x{N}x{K} b{nb[0] * nb[1]} {"T" if sA[3] != 1 else "N"}{"T" if sB[3] != 1 else "N"}{" f32out" if c_f32 else ""}]'
-        with _timed(key, 2.0 * M * N * K * nb[0] * nb[1]):
-            _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum, kseg)
-        return
     _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum, kseg)
 
 
@@ -802,9 +794,7 @@ class _UpConv(torch.autograd.Function):
         wd = torch.empty((16, Cin, Cout), dtype=x.dtype, device=x.device)
         call('stj_upconv_prep', _p(pw.master), _p(wf), _p(wd), Cin, Cout, dt, _st())
         y = torch.empty((F_, 2 * Hi, 2 * Wi, Cout), dtype=x.dtype, device=x.device)
-        flops = 2.0 * 9 * Cin * Cout * 4 * Hi * Wi * F_          # algorithmic (direct 9-tap form on the upsampled map)
-        with _timed(f'upconv_fwd[{Hi}x{Wi},{Cin}->{Cout}]', flops):
-            call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
+        call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
         ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
         ctx.grad_is_pre, ctx.x_is_elu_out = grad_is_pre, x_is_elu_out
         ctx.save_for_backward(x, y, wd)
@@ -821,12 +811,10 @@ class _UpConv(torch.autograd.Function):
         else:
             dpre = torch.empty_like(dy)
             call('stj_unary_bwd', _p(dy), _p(y), _p(dpre), dy.numel(), U_ELU, 0.0, dt, _st())
-        flops = 2.0 * 9 * Cin * Cout * 4 * Hi * Wi * F_
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            with _timed(f'upconv_dgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
-                call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), _p(x) if ctx.x_is_elu_out else None, F_, Hi, Wi, Cin, Cout, dt, _st())
+            call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), _p(x) if ctx.x_is_elu_out else None, F_, Hi, Wi, Cin, Cout, dt, _st())
         with wgrad_stream(2, x, dpre):
             dweff = zeros_f32(16 * Cout * Cin, x.device)     # the 16 folded tap matrices
             pb = ctx.pb
@@ -834,8 +822,7 @@ class _UpConv(torch.autograd.Function):
                 dbp, nparts, own = pb.part[0], pb.part[1], False
             else:                    # (~1000 workgroups would queue on Cout addresses otherwise)
                 dbp, nparts, own = torch.zeros(_DB_PARTS * Cout, dtype=torch.float32, device=x.device), _DB_PARTS, True
-            with _timed(f'upconv_wgrad[{Hi}x{Wi},{Cin}->{Cout}]', flops):
-                call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), nparts, F_, Hi, Wi, Cin, Cout, dt, _st())
+            call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), nparts, F_, Hi, Wi, Cin, Cout, dt, _st())
             call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
             if own:
                 pb.grad.add_(dbp.view(nparts, Cout).sum(0))

@@ -1,0 +1,176 @@
+"""Per-launch timing of EVERY C-ABI call (bench.py's live roofline measurement).
+
+When enabled, each `ops.call(name, ...)` is bracketed by a HIP event pair on the launch stream and filed under a key made of the
+kernel family and its problem shape, together with a cost model of that launch:
+
+    flops_alg   algorithmic FLOPs (2 per MAC of the reference's direct form: SURVEY.md 8d / App. E)
+    flops_exec  FLOPs the kernel actually issues (up-convs fold the nearest 2x upsample into 2x2 taps: 9 -> 4 taps = / 2.25)
+    bytes_alg   algorithmic HBM bytes: every operand read once, every result written once
+
+Only meaningful with the model in serial mode (one stream: an event pair brackets exactly one kernel).  Under hipGraph replay
+individual launches cannot carry events, so bench.py runs this in an eager pass after the timed region.
+"""
+import torch
+
+ACTIVE = None        # dict key -> list of (e0, e1) while enabled
+COST = {}            # key -> (family, flops_alg, flops_exec, bytes_alg)
+
+
+def enable():
+    global ACTIVE
+    ACTIVE = {}
+
+
+def disable():
+    global ACTIVE
+    p, ACTIVE = ACTIVE, None
+    return p
+
+
+def _es(dt):
+    return 4 if dt == 0 else 2
+
+
+def _gemm(a):
+    (M, N, K, nb1, nb2) = a[6:11]
+    sAb1, sAb2, sAm, sAk, sBb1, sBb2, sBk, sBn = a[11:19]
+    act, alpha, dt, c_f32, acc, splitk, nkb = a[27], a[28], a[29], a[30], a[31], a[32], a[33]
+    nb = nb1 * nb2
+    es = _es(dt)
+    na = (nb2 if sAb2 else 1) * (nb1 if sAb1 else 1)
+    nbb = (nb2 if sBb2 else 1) * (nb1 if sBb1 else 1)
+    fl = 2.0 * M * N * K * nb * nkb
+    by = es * (M * K * na + K * N * nbb) * nkb + (4 if c_f32 else es) * M * N * nb
+    if a[4] is not None and getattr(a[4], 'value', None):
+        by += es * M * N * nb
+    form = ('T' if sAm == 1 and sAk != 1 else 'N') + ('T' if sBn == 1 and sBk != 1 else 'N')
+    fam = 'gemm_wgrad' if acc else 'gemm'
+    key = f'{fam}[{M}x{N}x{K}{"x%d" % nkb if nkb > 1 else ""} b{nb} {form}{" f32out" if c_f32 else ""}{" act%d" % act if act else ""}]'
+    return key, fam, fl, fl, by
+
+
+def _upconv(kind):
+    def f(a):
+        if kind == 'fwd':
+            F, Hi, Wi, Cin, Cout, dt = a[4], a[5], a[6], a[7], a[8], a[10]
+        elif kind == 'dgrad':
+            F, Hi, Wi, Cin, Cout, dt = a[4], a[5], a[6], a[7], a[8], a[9]
+        else:
+            F, Hi, Wi, Cin, Cout, dt = a[5], a[6], a[7], a[8], a[9], a[10]
+        es = _es(dt)
+        fl = 2.0 * 9 * Cin * Cout * 4 * Hi * Wi * F
+        by = es * F * Hi * Wi * (Cin + 4 * Cout) + es * 16 * Cin * Cout
+        if kind == 'dgrad' and getattr(a[3], 'value', None):
+            by += es * F * Hi * Wi * Cin              # ELU' operand (the layer input)
+        if kind == 'wgrad':
+            by += 4 * 16 * Cin * Cout
+        return f'upconv_{kind}[{Hi}x{Wi},{Cin}->{Cout},F{F}]', 'upconv_' + kind, fl, fl / 2.25, by
+    return f
+
+
+def _outconv(kind):
+    def f(a):
+        if kind == 'fwd':
+            F, H, W, C, dt = a[4], a[5], a[6], a[7], a[12]
+        else:
+            F, H, W, C, dt = a[6], a[7], a[8], a[9], a[17]
+        es = _es(dt)
+        fl = 2.0 * 9 * C * 2 * H * W * F * (1 if kind == 'fwd' else 2)
+        by = es * F * H * W * C * (1 if kind == 'fwd' else 2) + 4 * F * H * W * 2
+        return f'outconv_{kind}[{H}x{W},{C}->2,F{F}]', 'outconv_' + kind, fl, fl, by
+    return f
+
+
+def _ln(kind):
+    def f(a):
+        if kind == 'fwd':
+            rows, C, dt = a[6], a[7], a[14]
+            by = 2 * _es(dt) * rows * C
+        else:
+            rows, C, dt = a[8], a[9], a[18]
+            by = (4 if getattr(a[15], 'value', None) else 3) * _es(dt) * rows * C
+        return f'layernorm_{kind}[{rows}x{C}]', 'layernorm_' + kind, 8.0 * rows * C, 8.0 * rows * C, by
+    return f
+
+
+def _win(kind):
+    def f(a):
+        if kind == 'fwd':
+            B, res, heads, dt = a[3], a[4], a[5], a[7]
+            nmm, tens = 2, 4
+        else:
+            B, res, heads, dt = a[6], a[7], a[8], a[10]
+            nmm, tens = 5, 8
+        items = B * (res // 8) ** 2 * heads
+        fl = items * nmm * 2.0 * 64 * 64 * 32
+        by = _es(dt) * B * res * res * heads * 32 * tens
+        return f'win_attn_{kind}[B{B} {res}x{res} h{heads}]', 'win_attn_' + kind, fl, fl, by
+    return f
+
+
+def _elem(fam, n_idx, dt_idx, tensors, f32=False):
+    def f(a):
+        n = a[n_idx]
+        es = 4 if f32 else _es(a[dt_idx])
+        return f'{fam}[{n}]', fam, 0.0, 0.0, tensors * es * n
+    return f
+
+
+def _loss(fam, tens):
+    def f(a):
+        B, H, W = (a[9], a[10], a[11]) if fam == 'loss_fwd' else (a[8], a[9], a[10])
+        by = 4.0 * B * H * W * (32 * tens + 8 * 5)
+        return f'{fam}[B{B} {H}x{W}]', fam, 0.0, 0.0, by
+    return f
+
+
+MODELS = {
+    'stj_gemm': _gemm,
+    'stj_upconv_fwd': _upconv('fwd'), 'stj_upconv_dgrad': _upconv('dgrad'), 'stj_upconv_wgrad': _upconv('wgrad'),
+    'stj_outconv_fwd': _outconv('fwd'), 'stj_outconv_bwd': _outconv('bwd'),
+    'stj_layernorm_fwd': _ln('fwd'), 'stj_layernorm_bwd': _ln('bwd'),
+    'stj_win_attn_fwd': _win('fwd'), 'stj_win_attn_bwd': _win('bwd'),
+    'stj_unary_fwd': _elem('unary_fwd', 2, 5, 2), 'stj_unary_bwd': _elem('unary_bwd', 3, 6, 3),
+    'stj_dropout': _elem('dropout', 3, 8, 2),
+    'stj_loss_fwd': _loss('loss_fwd', 1), 'stj_loss_bwd': _loss('loss_bwd', 2),
+    'stj_nadam_step': _elem('nadam', 4, 0, 7, f32=True),
+}
+EXTRA_MODELS = {}        # fused kernels register their models here (ops.py)
+
+
+def record(name, args, launch):
+    """Time one C-ABI call.  `launch` performs it."""
+    m = MODELS.get(name) or EXTRA_MODELS.get(name)
+    if m is not None:
+        try:
+            key, fam, fa, fe, by = m(args)
+        except Exception:
+            key, fam, fa, fe, by = name, name.replace('stj_', ''), 0.0, 0.0, 0.0
+    else:
+        key, fam, fa, fe, by = name, name.replace('stj_', ''), 0.0, 0.0, 0.0
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    launch()
+    e1.record(st)
+    COST[key] = (fam, fa, fe, by)
+    ACTIVE.setdefault(key, []).append((e0, e1))
+
+
+def summarize(events, steps):
+    """-> (per-key table, per-family table); times in ms per step."""
+    keys = {}
+    for k, evs in events.items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        fam, fa, fe, by = COST[k]
+        keys[k] = dict(family=fam, launches=len(ms) / steps, avg_ms=sum(ms) / len(ms), ms_per_step=sum(ms) / steps,
+                       flops_alg=fa, flops_exec=fe, bytes_alg=by)
+    fams = {}
+    for k, v in keys.items():
+        f = fams.setdefault(v['family'], dict(ms_per_step=0.0, launches=0.0, flop_alg=0.0, flop_exec=0.0, bytes=0.0))
+        f['ms_per_step'] += v['ms_per_step']
+        f['launches'] += v['launches']
+        f['flop_alg'] += v['flops_alg'] * v['launches']
+        f['flop_exec'] += v['flops_exec'] * v['launches']
+        f['bytes'] += v['bytes_alg'] * v['launches']
+    return keys, fams

@@ -112,6 +112,31 @@ def test_bundle_roundtrip_dtypes_and_checksum(tmp_path):
     assert ck.BundleReader(p, verify=False).get('a/f32').shape == (3, 4, 5)
 
 
+def test_string_entry_checksum_follows_tensor_bundle(tmp_path):
+    """DT_STRING entries (the object graph): TF's WriteStringTensor extends the running CRC-32C with the element length as a
+    uint32 (uint64 only above 2^32-1), then the 4 bytes of the masked length checksum, then the bytes.  The expected values are
+    assembled here byte by byte, independently of BundleWriter.add_string; the reader verifies both checksums."""
+    import struct
+    p = str(tmp_path / 'c.tf')
+    val = b'object graph bytes'
+    w = ck.BundleWriter(p)
+    w.add_string('s', val)
+    w.finish()
+    raw = open(p + '.data-00000-of-00001', 'rb').read()
+    c_len = ck.crc32c(struct.pack('<I', len(val)))                         # 4-byte length word, NOT 8
+    lcs = struct.pack('<I', ck._mask(c_len))
+    assert raw == bytes([len(val)]) + lcs + val
+    want = ck._mask(ck.crc32c(val, ck.crc32c(lcs, c_len)))
+    r = ck.BundleReader(p)
+    assert r.entry('s')['crc32c'] == want
+    assert r.entry('s')['crc32c'] != ck._mask(ck.crc32c(val, ck.crc32c(lcs, ck.crc32c(struct.pack('<Q', len(val))))))
+    assert r.get('s') == val
+    with open(p + '.data-00000-of-00001', 'r+b') as f:                     # corrupt one string byte: the reader must notice
+        f.seek(7); b = f.read(1); f.seek(7); f.write(bytes([b[0] ^ 1]))
+    with pytest.raises(ValueError, match='checksum'):
+        ck.BundleReader(p).get('s')
+
+
 def test_object_graph_walk_prefers_graph_over_key_names(tmp_path):
     """The graph maps attribute paths to whatever checkpoint key the writer chose (Keras may pick layer_with_weights-N)."""
     def node(children, attr=None):

@@ -354,6 +354,48 @@ def test_side_streams_are_joined_after_backward():
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_two_bucket_backward_matches_one_bucket(dtype):
+    """Data-parallel overlap (dp.OverlappedGradSync): backward cut at the encoder outputs (model.cut_encoder -> backward() then
+    backward_encoder()) must produce the gradients of the monolithic backward, the tail bucket must be FINAL after the first half
+    (it is all-reduced while the second half runs), and the two-graph capture must replay to the same buffer."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from strajnet_amd.graph import GraphedTrainStep
+    model, w, x, xt = _setup(CFG128, 2, dtype)
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(128, 128, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+    k = model.bucket_split
+    assert 0 < k < model.flat_grads().numel()
+    assert k == model._offs['fg_msa/proj_q/kernel']
+
+    def fwd_loss():
+        model.zero_grad()
+        out = _fwd(model, xt)
+        d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+        return sum(d.values())
+    fwd_loss().backward()
+    g_one = model.flat_grads().clone()
+    model.cut_encoder = True
+    fwd_loss().backward()
+    g_half = model.flat_grads().clone()                 # enqueued right after backward(): what the tail all-reduce would read
+    model.backward_encoder()
+    g_two = model.flat_grads().clone()
+    torch.cuda.synchronize()
+    scale = float(g_one.abs().max())
+    tol_ = (1e-5 if dtype == torch.float32 else 2e-3) * scale     # atomics order (f32) / bf16 rounding of re-ordered sums
+    assert float(g_half[:k].abs().max()) == 0.0                          # nothing of the encoder bucket before the second half
+    assert torch.equal(g_half[k:], g_two[k:])                            # the tail bucket is final after the first half
+    assert float((g_two - g_one).abs().max()) < tol_
+    assert float(g_two[:k].abs().max()) > 0
+    step = GraphedTrainStep(model, loss_fn, xt, training=False, split=True)
+    seen = []
+    for _ in range(2):
+        step(between=lambda: seen.append(model.flat_grads()[k:].clone()))
+    torch.cuda.synchronize()
+    assert float((model.flat_grads() - g_one).abs().max()) < tol_
+    assert float((seen[-1] - g_one[k:]).abs().max()) < tol_              # tail complete between the two replays
+    model.cut_encoder = False
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_odd_batch_b3(dtype):
     """B = 3: row counts that are not multiples of the kernels' tile sizes (ragged tails of the GEMM / LayerNorm / conv grids).
     f32: forward within the 1e-3 gate and exact per-scene independence; bf16: same independence, loose error bound."""
@@ -505,17 +547,23 @@ def test_bench_two_ranks_on_one_gpu():
     import subprocess
     import sys
     env = dict(os.environ, STJ_BENCH_SHARE_GPU='1', MASTER_ADDR='127.0.0.1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
-           '--no-kernel-timing', '--no-cpu-baseline']
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, r.stdout[-2000:]                           # rank 0 only
-    d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
-    assert d['value'] > 0 and np.isfinite(d['loss']) and d['allreduce']['ms'] > 0 and d['allreduce']['mbytes'] > 50
-    assert d['config']['optimizer_in_step'] and d['scaling'] == 'weak'
+    res = {}
+    for mode, extra in (('overlap', []), ('one_bucket', ['--no-overlap'])):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+               '--no-kernel-timing', '--no-cpu-baseline'] + extra
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == 1, r.stdout[-2000:]                           # rank 0 only
+        d = res[mode] = json.loads(lines[0])
+        assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
+        assert d['value'] > 0 and np.isfinite(d['loss']) and d['allreduce']['ms'] > 0 and d['allreduce']['mbytes'] > 50
+        assert d['config']['optimizer_in_step'] and d['scaling'] == 'weak'
+        assert d['distributed']['ranks'] == 2 and d['distributed']['ranks_seen_by_allreduce'] == 2
+        assert d['distributed']['allreduce_overlapped_with_backward'] == (mode == 'overlap') == d['allreduce']['overlapped']
+    # same seeds, same draws: three Nadam steps on all-reduced gradients must land on the same loss whichever way they were exchanged
+    assert abs(res['overlap']['loss'] - res['one_bucket']['loss']) < 2e-3 * abs(res['one_bucket']['loss'])
 
 
 def test_golden_train_step_gradients_f32():

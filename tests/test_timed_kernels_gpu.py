@@ -1,0 +1,219 @@
+"""Parity gate for the kernels bench.py actually TIMES (16-bit storage mode), at multi-tile / bench shapes.
+
+The f32 end-to-end suite runs the generic kernels (csrc/conv.hip, gemm_kernel<float>); the bf16 step that the bench measures runs
+the weight-stationary convolutions (csrc/conv_ws.hip: upconv_fwd_ws / upconv_dgrad_ws / upconv_wgrad_tr), the MFMA output heads
+(outconv_fwd_mfma / outconv_bwd_mfma), the row-streaming dense kernel (linear_rs_kernel) and the fused Swin kernels.  Here every
+one of them is run in bf16 at shapes where a persistent block walks many tiles (F >= 8 frames, 128x128 / 64x64 maps, 32768 rows)
+and compared with the f32 HIP path fed THE SAME bf16-rounded operands.
+
+Bound (per element, not relative-to-max): every product term carries at most three bf16 roundings the f32 path does not have
+(folded weight, an intermediate, the stored result: 2^-9 relative each), so
+
+    |y_bf16 - y_f32| <= 2^-7 * sum_k |a_k * b_k|  (+ 2^-7 |bias|)
+
+where the right-hand sum is evaluated by the f32 HIP path itself on |a|, |b|.  Weight gradients have exact bf16 operands and f32
+accumulation: their bound is 2^-12 of the same sum (atomic accumulation order only).
+Reference semantics: /root/reference modules.py:746-770 (decoder), :40-46,103-134 (Swin dense layers).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EPS_ACT = 2.0 ** -7
+EPS_WGRAD = 2.0 ** -12
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _lib(lib_built):
+    assert torch.cuda.is_available()
+    from strajnet_amd import _lib as L
+    L.lib()
+
+
+def mk_param(values, dt):
+    """Param whose f32 master holds `values` (cuda f32); compute copy in `dt`."""
+    from strajnet_amd.ops import Param
+    m = values.detach().clone().float().cuda().requires_grad_(True)
+    grad = torch.zeros_like(m)
+    m.grad = grad
+    c = m.detach() if dt == torch.float32 else m.detach().to(dt)
+    return Param('p', tuple(m.shape), m, c, grad)
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).cuda()
+
+
+def check(name, got, ref, bound, eps, slack=0.0):
+    """per-element: |got - ref| <= eps * bound + slack"""
+    got, ref, bound = got.detach().float(), ref.detach().float(), bound.detach().float().abs()
+    excess = (got - ref).abs() - (eps * bound + slack)
+    worst = float(excess.max())
+    ratio = float(((got - ref).abs() / (bound + 1e-30)).max())
+    assert worst <= 0.0, f'{name}: worst excess {worst:.3e} over the bound (max |err|/sum|terms| = {ratio:.3e}, eps {eps:.3e})'
+    return ratio
+
+
+def _upconv_run(x, w, b, g, dt, grad_is_pre, x_is_elu_out):
+    from strajnet_amd import ops
+    pw, pb = mk_param(w, dt), mk_param(b, dt)
+    xi = x.to(dt).requires_grad_(True)
+    y = ops.upconv(xi, pw, pb, grad_is_pre, x_is_elu_out)
+    y.backward(g.to(dt))
+    torch.cuda.synchronize()
+    return y.detach(), xi.grad.detach(), pw.grad.detach().clone(), pb.grad.detach().clone()
+
+
+@pytest.mark.parametrize('F_,Hi,Cin,Cout', [(8, 128, 96, 48), (8, 64, 128, 96), (8, 32, 192, 128), (16, 16, 384, 192)])
+@pytest.mark.parametrize('x_is_elu_out', [False, True])
+def test_upconv_ws_bench_shapes_bf16(F_, Hi, Cin, Cout, x_is_elu_out):
+    """upconv_fwd_ws / upconv_dgrad_ws (both ELU' variants) / upconv_wgrad_tr at the bench layer shapes, >= 8 frames: every
+    persistent block walks its double-buffered tile loop many times.  grad_is_pre=True (the mode of the model's last two decoder
+    levels): the incoming gradient IS dpre, so both runs hand the dgrad / wgrad kernels identical operands; the separate ELU' pass
+    of grad_is_pre=False is the unary kernel (tests/test_ops_gpu.py::test_unary), not a timed conv kernel."""
+    dt = torch.bfloat16
+    grad_is_pre = True
+    x = rnd((F_, Hi, Hi, Cin), 3).to(dt).float()                  # bf16-representable operands for both paths
+    if x_is_elu_out:
+        x = torch.nn.functional.elu(x).to(dt).float()             # "x is the ELU output of the producer": values > -1
+    w = rnd((3, 3, Cin, Cout), 1, 0.05)
+    b = rnd((Cout,), 2, 0.1)
+    g = rnd((F_, 2 * Hi, 2 * Hi, Cout), 5).to(dt).float()
+    y16, dx16, dw16, db16 = _upconv_run(x, w, b, g, dt, grad_is_pre, x_is_elu_out)
+    y32, dx32, dw32, db32 = _upconv_run(x, w, b, g, torch.float32, grad_is_pre, x_is_elu_out)
+    # sum |terms| from the f32 path on absolute operands (ELU is the identity on the positive results; grad_is_pre=True
+    # hands |g| through unchanged, x_is_elu_out=False applies no ELU' factor)
+    ya, dxa, dwa, dba = _upconv_run(x.abs(), w.abs(), b.abs(), g.abs(), torch.float32, True, False)
+    r = [check('fwd', y16, y32, ya, EPS_ACT)]
+    r.append(check('dgrad', dx16, dx32, dxa, EPS_ACT))
+    r.append(check('wgrad', dw16, dw32, dwa, EPS_WGRAD))
+    r.append(check('bias grad', db16, db32, dba, EPS_WGRAD))
+    print(f'upconv {Cin}->{Cout} @{Hi} F={F_} pre={grad_is_pre} elu_in={x_is_elu_out}: max |err|/sum|terms| ' + ', '.join(f'{v:.2e}' for v in r))
+
+
+def _outconv_run(xo, xf, ws, dout, dt, B, Tn, elu_in):
+    from strajnet_amd import ops
+    ps = [mk_param(w, dt) for w in ws]
+    a, b = xo.to(dt).requires_grad_(True), xf.to(dt).requires_grad_(True)
+    out = ops.outconv_pair(a, b, *ps, B, Tn, t_major=True, x_is_elu_out=elu_in)
+    out.backward(dout)
+    torch.cuda.synchronize()
+    return out.detach(), a.grad.detach(), b.grad.detach(), [p.grad.detach().clone() for p in ps]
+
+
+@pytest.mark.parametrize('elu_in', [False, True])
+def test_outconv_mfma_bench_shape_bf16(elu_in):
+    """outconv_fwd_mfma / outconv_bwd_mfma (+ reduce) on 16 frames of 256x256x48 (bench: 64 frames), t-major like the model."""
+    B, Tn, H, C = 2, 8, 256, 48
+    dt = torch.bfloat16
+    xo = torch.nn.functional.elu(rnd((B * Tn, H, H, C), 5)).to(dt).float()
+    xf = torch.nn.functional.elu(rnd((B * Tn, H, H, C), 6)).to(dt).float()
+    ws = [rnd((3, 3, C, 2), 1, 0.1), rnd((2,), 2, 0.1), rnd((3, 3, C, 2), 3, 0.1), rnd((2,), 4, 0.1)]
+    dout = rnd((B, H, H, 4 * Tn), 7)
+    o16, a16, b16, g16 = _outconv_run(xo, xf, ws, dout, dt, B, Tn, elu_in)
+    o32, a32, b32, g32 = _outconv_run(xo, xf, ws, dout, torch.float32, B, Tn, elu_in)
+    oa, aa, ba, ga = _outconv_run(xo.abs(), xf.abs(), [w.abs() for w in ws], dout.abs(), torch.float32, B, Tn, False)
+    r = [check('fwd', o16, o32, oa, EPS_ACT), check('dxo', a16, a32, aa, EPS_ACT), check('dxf', b16, b32, ba, EPS_ACT)]
+    for i, nm in enumerate(('w1', 'b1', 'w2', 'b2')):
+        r.append(check('d' + nm, g16[i], g32[i], ga[i], EPS_ACT))      # dout is f32 here but dW's MFMA operand is its bf16 rounding
+    print(f'outconv elu_in={elu_in}: max |err|/sum|terms| ' + ', '.join(f'{v:.2e}' for v in r))
+
+
+def _linear_run(x, w, b, res, g, dt, act):
+    from strajnet_amd import ops
+    pw, pb = mk_param(w, dt), mk_param(b, dt)
+    xi = x.to(dt).requires_grad_(True)
+    r = res.to(dt) if res is not None else None
+    y = ops.linear(xi, pw, pb, act, r)
+    y.backward(g.to(dt))
+    torch.cuda.synchronize()
+    return y.detach(), xi.grad.detach(), pw.grad.detach().clone(), pb.grad.detach().clone()
+
+
+@pytest.mark.parametrize('K,N,act,use_res', [(96, 288, 0, False), (96, 384, 0, False), (384, 96, 0, True), (96, 96, 0, True),
+                                             (192, 128, 2, False), (128, 96, 2, False), (288, 96, 0, False)])
+def test_linear_rs_32768_rows_bf16(K, N, act, use_res):
+    """linear_rs_kernel (forward [K,N] form and the dgrad [N,K] form it also serves) at the 32768 token rows of Swin stage 0."""
+    M = 32768
+    dt = torch.bfloat16
+    x = rnd((M, K), 3).to(dt).float()
+    w = rnd((K, N), 1, 0.2).to(dt).float()            # bf16-representable weights: both paths multiply the same numbers
+    b = rnd((N,), 2, 0.2)
+    res = rnd((M, N), 4).to(dt).float() if use_res else None
+    g = rnd((M, N), 5).to(dt).float()
+    y16, dx16, dw16, db16 = _linear_run(x, w, b, res, g, dt, act)
+    y32, dx32, dw32, db32 = _linear_run(x, w, b, res, g, torch.float32, act)
+    ya, dxa, dwa, dba = _linear_run(x.abs(), w.abs(), b.abs(), res.abs() if use_res else None, g.abs(), torch.float32, 0)
+    r = [check('fwd', y16, y32, ya, EPS_ACT)]
+    # ELU: dpre = g * ELU'(y) is rounded to bf16 in the 16-bit run and ELU'(y) = min(1, 1 + y) moves with y's own error
+    # (<= 2^-7 * sum|terms| of the forward), so the backward bound widens by the forward's largest sum
+    eps_b = EPS_ACT if act == 0 else EPS_ACT * (2.0 + float(ya.max()))
+    r.append(check('dgrad', dx16, dx32, dxa, eps_b))
+    r.append(check('wgrad', dw16, dw32, dwa, EPS_WGRAD if act == 0 else eps_b))
+    r.append(check('bias grad', db16, db32, dba, EPS_WGRAD if act == 0 else eps_b))
+    print(f'linear {K}->{N} act={act} res={use_res} M={M}: max |err|/sum|terms| ' + ', '.join(f'{v:.2e}' for v in r))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# whole train step: the bf16 step the bench times vs the f32-mode HIP step (the mode that holds 1e-3 against the oracle),
+# same weights, same inputs, same Dropout / DropPath draws (the Philox stream is keyed by {seed, step, site, element}).
+# ---------------------------------------------------------------------------------------------------------------------
+def _step(cfg, B, dtype, large_ogm, x):
+    from strajnet_amd import STrajNet, OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from oracle import np_ref
+    w = np_ref.make_weights(cfg, 0, large_ogm=large_ogm)
+    model = STrajNet(cfg, fg_msa=True, fg=True, large_ogm=large_ogm, dtype=dtype)
+    model.load_weights(w)
+    xt = {k: torch.as_tensor(v).cuda() for k, v in x.items()}
+    Hg = xt['gt_obs'].shape[2]
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(Hg, Hg, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+    model.zero_grad()
+    out = model(xt['ogm'], xt['map_img'], training=True, obs=xt['obs'], occ=xt['occ'], mapt=xt['mapt'], flow=xt['flow'])
+    d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+    sum(d.values()).backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().double().cpu() for n, p in model.params.items()}
+    masks = {n: model.dropctx.mask(n).cpu() for n in model.dropctx.sites}
+    return {k: float(v) for k, v in d.items()}, grads, out.detach().float().cpu(), masks
+
+
+def _cmp_steps(tag, cfg, B, large_ogm):
+    from oracle import np_ref
+    x = np_ref.make_inputs(cfg, B, large_ogm=large_ogm)
+    l32, g32, o32, m32 = _step(cfg, B, torch.float32, large_ogm, x)
+    l16, g16, o16, m16 = _step(cfg, B, torch.bfloat16, large_ogm, x)
+    assert m32.keys() == m16.keys()
+    for n in m32:
+        assert torch.equal(m32[n], m16[n]), f'dropout site {n}: the two modes drew different masks'
+    tot32, tot16 = sum(l32.values()), sum(l16.values())
+    rel = abs(tot16 - tot32) / abs(tot32)
+    gmax = max(float(g.abs().max()) for g in g32.values())
+    worst, worst_n = 1.0, None
+    for n in g32:
+        a, b = g16[n].reshape(-1), g32[n].reshape(-1)
+        if float(b.abs().max()) < 1e-6 * gmax:          # identically-zero gradients (e.g. key bias under softmax): noise only
+            continue
+        c = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+        if c < worst:
+            worst, worst_n = c, n
+    err = float((o16 - o32).abs().max())
+    print(f'{tag}: loss f32 {tot32:.6f} bf16 {tot16:.6f} (rel {rel:.2e}); worst per-tensor gradient cosine {worst:.5f} ({worst_n}); '
+          f'logits max-abs diff {err:.3e}')
+    assert rel < 1e-3, (tot32, tot16)
+    for k in l32:
+        assert abs(l16[k] - l32[k]) < 2e-3 * abs(l32[k]) + 1e-4, (k, l16[k], l32[k])
+    assert worst >= 0.999, (worst, worst_n)
+
+
+def test_bench_step_bf16_vs_f32_mode_cfg256_b8():
+    """BASELINE config 2 (B=8 cfg-256, training=True): the timed bf16 step against the parity-mode f32 step."""
+    cfg = dict(input_size=(256, 256), window_size=8, embed_dim=96, depths=[2, 2, 2], num_heads=[3, 6, 12])
+    _cmp_steps('cfg-256 B=8 train step bf16 vs f32 mode', cfg, 8, False)
+
+
+def test_bench_step_bf16_vs_f32_mode_cfg512_b2():
+    """BASELINE config 5 (512x512 rasters, large_ogm, depths [2,2,6]) B=2 train step, bf16 vs f32 mode."""
+    cfg = dict(input_size=(512, 512), window_size=8, embed_dim=96, depths=[2, 2, 6], num_heads=[3, 6, 12])
+    _cmp_steps('cfg-512 [2,2,6] B=2 train step bf16 vs f32 mode', cfg, 2, True)
