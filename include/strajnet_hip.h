@@ -85,6 +85,24 @@ int stj_win_attn_bwd(const void* qkv, const float* table, const void* dout, void
 /* bwd: dtable f32 [nparts][225,heads], "+=": workgroup i adds the bias-table gradient of its window into copy i % nparts and the
  * caller sums the copies (one copy = hundreds of same-address atomics per table entry on the 64x64 stage; nparts = 1 is valid). */
 
+/* Fused MLP half of SwinTransformerBlock (modules.py:260 = x + drop_path(mlp(norm2(x))); Mlp.call :40-46; Gelu :18-29; drop_path
+ * :137-151), ONE kernel per direction (csrc/swin_fused.hip).  x, y [M,C] (C in {96,192,384}); gamma/beta f32 [C] (LN eps);
+ * w1 [C,4C], w2 [4C,C] activation dtype (Keras [in,out]); b1 [4C], b2 [C] f32.
+ * DropPath: rng_state = device int64[2] {seed, step} (NULL or p_drop = 0: none), one draw per sample = run of rows_per_sample rows,
+ * drawn exactly as stj_dropout(inner = rows_per_sample * C) draws it.
+ *   fwd: y = x + dp * (gelu(LN(x) w1 + b1) w2 + b2)
+ *   bwd: dx = dy + LN'(...), dgamma/dbeta "+=" (nparts copies part_stride floats apart, as stj_layernorm_bwd), and the operands
+ *        of the two weight gradients written once: h = gelu(pre) [M,4C], dpre [M,4C], ln = LN(x) [M,C], dys = dp*dy [M,C]
+ *        (dys may be NULL when there is no DropPath: use dy).  dW1 = ln^T dpre, db1 = colsum(dpre), dW2 = h^T dys,
+ *        db2 = colsum(dys) are stj_gemm split-K launches. */
+int stj_swin_mlp_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
+                     const float* b2, void* y, long long M, int C, float eps, const long long* rng_state, int site,
+                     float p_drop, long long rows_per_sample, int dtype, hipStream_t stream);
+int stj_swin_mlp_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const void* w1, const float* b1,
+                     const void* w2, void* dx, void* h, void* dpre, void* ln, void* dys, float* dgamma, float* dbeta,
+                     int nparts, long long part_stride, long long M, int C, float eps, const long long* rng_state, int site,
+                     float p_drop, long long rows_per_sample, int dtype, hipStream_t stream);
+
 /* Row softmax of the global attentions: P = softmax(S + bias + (-10e9 where !(qvalid&kvalid))) (tfa MHA mask
  * semantics, f32 add); S f32 [batch,H,Nq,Nk] (Nk <= 256).  bwd: dS = P*(dP - sum(P dP)). */
 int stj_softmax_fwd(const float* S, void* P, const int* qvalid, const int* kvalid, const float* bias,

@@ -227,6 +227,9 @@ class STrajNet:
         self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and os.environ.get('STJ_NO_SIDE_STREAM2') != '1') else None
         self._streams = (self._side, self._side2)
         self.serial = False              # True: everything on the current stream (per-kernel timing, debugging)
+        # fused Swin-block kernels (csrc/swin_fused.hip); STJ_FUSED_MLP=0 selects the layer-by-layer path (A/B runs, debugging)
+        self.fused_mlp = os.environ.get('STJ_FUSED_MLP', '1') != '0'
+        self.fused_mlp_dims = tuple(int(v) for v in os.environ.get('STJ_FUSED_MLP_DIMS', '96,192,384').split(','))
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():
             k = int(np.prod(s))
@@ -370,14 +373,24 @@ class STrajNet:
         h, x = self._ln_skip(x, pre + '/norm1', 1e-5)
         qkv = self._dense(h, pre + '/attn/qkv')
         a = ops.win_attn(qkv, self._p(pre + '/attn/relative_position_bias_table'), B, res, heads, shift)
+        fused_mlp = self.fused_mlp and x.shape[-1] in self.fused_mlp_dims
+
+        def mlp_fused(x):            # LN2 -> fc1 -> GELU -> fc2 -> DropPath -> + shortcut in ONE kernel (csrc/swin_fused.hip)
+            return ops.swin_mlp(x, self._p(pre + '/norm2/gamma'), self._p(pre + '/norm2/beta'), self._p(pre + '/mlp/fc1/kernel'),
+                                self._p(pre + '/mlp/fc1/bias'), self._p(pre + '/mlp/fc2/kernel'), self._p(pre + '/mlp/fc2/bias'), 1e-5,
+                                self._dctx, pre + '/drop_path_mlp', dpr, rows_per_sample=res * res)
         if dpr == 0.0:
             x = self._dense(a, pre + '/attn/proj', res=x)         # shortcut + attn
+            if fused_mlp:
+                return mlp_fused(x)
             h, x = self._ln_skip(x, pre + '/norm2', 1e-5)
             h = ops.gelu(self._dense(h, pre + '/mlp/fc1'))
             return self._dense(h, pre + '/mlp/fc2', res=x)
         # training: shortcut + DropPath(branch), one Bernoulli(keep) draw per sample and branch (modules.py:137-151,258,260)
         a = self._dense(a, pre + '/attn/proj').view(B, -1)
         x = ops.dropout(a, dpr, self._dctx, pre + '/drop_path_attn', res=x.view(B, -1), per_sample=True).view(x.shape)
+        if fused_mlp:
+            return mlp_fused(x)
         h, x = self._ln_skip(x, pre + '/norm2', 1e-5)
         h = ops.gelu(self._dense(h, pre + '/mlp/fc1'))
         h = self._dense(h, pre + '/mlp/fc2').view(B, -1)

@@ -493,6 +493,79 @@ def layernorm_skip(x, pg, pb, eps):
 
 
 # ----------------------------------------------------------------------------------------------------
+# fused MLP half of a Swin block: x + DropPath(fc2(gelu(fc1(LayerNorm(x)))))  -- one kernel per direction (csrc/swin_fused.hip)
+# ----------------------------------------------------------------------------------------------------
+class _SwinMlp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, trig, pg, pb, pw1, pb1, pw2, pb2, eps, drop, rows_per_sample):
+        _req_cuda(x)
+        x = x.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        p_drop, state, site = drop if drop is not None else (0.0, None, 0)
+        call('stj_swin_mlp_fwd', _p(x), _p(pg.master), _p(pb.master), _p(pw1.c), _p(pb1.master), _p(pw2.c), _p(pb2.master), _p(y),
+             M, C, float(eps), _p(state), site, float(p_drop), rows_per_sample, _dt(x), _st())
+        ctx.ps = (pg, pb, pw1, pb1, pw2, pb2)
+        ctx.args = (M, C, float(eps), drop, rows_per_sample)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        pg, pb, pw1, pb1, pw2, pb2 = ctx.ps
+        M, C, eps, drop, rps = ctx.args
+        dt = _dt(x)
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        h = torch.empty((M, 4 * C), dtype=x.dtype, device=x.device)
+        dpre = torch.empty_like(h)
+        ln = torch.empty((M, C), dtype=x.dtype, device=x.device)
+        p_drop, state, site = drop if drop is not None else (0.0, None, 0)
+        dys = torch.empty_like(ln) if drop is not None else None
+        if pg.part is not None and pb.part is not None:
+            dg, db, nparts, pstride = pg.part[0], pb.part[0], pg.part[1], pg.part[2]
+        else:
+            dg, db, nparts, pstride = pg.grad, pb.grad, 1, 0
+        call('stj_swin_mlp_bwd', _p(x), _p(dy), _p(pg.master), _p(pb.master), _p(pw1.c), _p(pb1.master), _p(pw2.c), _p(dx), _p(h),
+             _p(dpre), _p(ln), _p(dys), _p(dg), _p(db), nparts, pstride, M, C, eps, _p(state), site, float(p_drop), rps, dt, _st())
+        g2 = dys if dys is not None else dy.view(M, C)
+        with wgrad_stream(1, ln, dpre, h, g2):
+            gemm(ln, dpre, pw1.grad, C, 4 * C, M, (0, 0, 1, C), (0, 0, 4 * C, 1), (0, 0, 4 * C), dt, c_f32=1, accumulate=1,
+                 splitk=0, colsum=pb1.grad)                               # dW1 += LN(x)^T dpre ; db1 += 1^T dpre
+            gemm(h, g2, pw2.grad, 4 * C, C, M, (0, 0, 1, 4 * C), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1,
+                 splitk=0, colsum=pb2.grad)                               # dW2 += gelu(pre)^T (dp dy) ; db2 += 1^T (dp dy)
+        return (dx,) + (None,) * 10
+
+
+def swin_mlp(x, pg, pb, pw1, pb1, pw2, pb2, eps, dctx=None, name=None, p_drop=0.0, rows_per_sample=None):
+    """x [..., C] -> x + DropPath(Mlp(LayerNorm(x)))  (modules.py:260).  dctx/name/p_drop: the DropPath site of a training step (one
+    draw per run of rows_per_sample rows = per sample)."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    rps = int(rows_per_sample) if rows_per_sample else M
+    drop = None
+    if dctx is not None and p_drop > 0.0:
+        drop = (float(p_drop), dctx.snap, dctx.site(name, (M // rps,), p_drop))
+    return _SwinMlp.apply(x, pg.master, pg, pb, pw1, pb1, pw2, pb2, eps, drop, rps)
+
+
+def _mlp_cost(kind):
+    def f(a):
+        M, C, dt = (a[8], a[9], a[15]) if kind == 'fwd' else (a[16], a[17], a[23])
+        es = 4 if dt == 0 else 2
+        fl = 2.0 * M * C * 4 * C * (2 if kind == 'fwd' else 4)
+        by = es * M * C * 2 if kind == 'fwd' else es * M * (C * 5 + 8 * C)
+        return f'swin_mlp_{kind}[{M}x{C}]', 'swin_mlp_' + kind, fl, fl, by
+    return f
+
+
+prof.EXTRA_MODELS['stj_swin_mlp_fwd'] = _mlp_cost('fwd')
+prof.EXTRA_MODELS['stj_swin_mlp_bwd'] = _mlp_cost('bwd')
+
+
+# ----------------------------------------------------------------------------------------------------
 # fused (shifted) window attention
 # ----------------------------------------------------------------------------------------------------
 class _WinAttn(torch.autograd.Function):

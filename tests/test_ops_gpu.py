@@ -475,6 +475,43 @@ def test_dropout_op(dt):
     assert abs(float(dctx.mask('c').double().mean()) - 0.75) < 0.03
 
 
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('B,N,C,p_drop', [(3, 64, 96, 0.0), (4, 256, 96, 0.3), (2, 128, 192, 0.3), (3, 64, 384, 0.0), (1, 80, 96, 0.0)])
+def test_swin_mlp_fused(dt, B, N, C, p_drop):
+    """csrc/swin_fused.hip: x + DropPath(fc2(gelu(fc1(LN(x))))) in one kernel, and its backward (dx, LN gamma/beta, both weight
+    and bias gradients) vs float64 autograd on the same statement (modules.py:260, :40-46, :18-29, :137-151).  Row counts that
+    are not a multiple of the block's rows exercise the tail guards."""
+    from strajnet_amd import ops
+    pg, pb = mk_param((C,), dt, 0.3, 1), mk_param((C,), dt, 0.3, 2)
+    with torch.no_grad():
+        pg.master.add_(1.0)
+    pw1, pb1 = mk_param((C, 4 * C), dt, 0.1, 3), mk_param((4 * C,), dt, 0.2, 4)
+    pw2, pb2 = mk_param((4 * C, C), dt, 0.1, 5), mk_param((C,), dt, 0.2, 6)
+    x = rnd((B, N, C), dt, 7, 2.0).requires_grad_(True)
+    dctx = None
+    if p_drop > 0:
+        dctx = ops.DropCtx('cuda', seed=11)
+        dctx.begin()
+    y = ops.swin_mlp(x, pg, pb, pw1, pb1, pw2, pb2, 1e-5, dctx, 'dp', p_drop, rows_per_sample=N)
+    keep = torch.ones(B, dtype=torch.float64)
+    if p_drop > 0:
+        keep = dctx.mask('dp').double().cpu() / (1.0 - p_drop)
+        assert keep.shape == (B,)
+    xr, gr, br = ref_of(x), ref_of(pg.master), ref_of(pb.master)
+    w1r, b1r, w2r, b2r = ref_of(pw1.c), ref_of(pb1.master), ref_of(pw2.c), ref_of(pb2.master)
+    hr = F.layer_norm(xr, (C,), gr, br, 1e-5) @ w1r + b1r
+    hr = 0.5 * hr * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (hr + 0.044715 * hr ** 3)))
+    yr = xr + keep.view(B, 1, 1) * (hr @ w2r + b2r)
+    t = tol(dt)
+    assert rel_err(y, yr) < t
+    g = rnd((B, N, C), dt, 9)
+    y.backward(g)
+    yr.backward(g.double().cpu())
+    assert rel_err(x.grad, xr.grad) < t
+    for nm, p_, r_ in (('gamma', pg, gr), ('beta', pb, br), ('w1', pw1, w1r), ('b1', pb1, b1r), ('w2', pw2, w2r), ('b2', pb2, b2r)):
+        assert rel_err(p_.grad, r_.grad) < 2 * t, nm
+
+
 def test_nadam_step_matches_keras_formula():
     """stj_nadam_step vs the Keras Nadam recurrences in float64 over three steps."""
     from strajnet_amd.optim import Nadam

@@ -59,7 +59,7 @@ def check(name, got, ref, bound, eps, slack=0.0):
 def _upconv_run(x, w, b, g, dt, grad_is_pre, x_is_elu_out):
     from strajnet_amd import ops
     pw, pb = mk_param(w, dt), mk_param(b, dt)
-    xi = x.to(dt).requires_grad_(True)
+    xi = x.detach().to(dt).clone().requires_grad_(True)
     y = ops.upconv(xi, pw, pb, grad_is_pre, x_is_elu_out)
     y.backward(g.to(dt))
     torch.cuda.synchronize()
@@ -96,7 +96,7 @@ def test_upconv_ws_bench_shapes_bf16(F_, Hi, Cin, Cout, x_is_elu_out):
 def _outconv_run(xo, xf, ws, dout, dt, B, Tn, elu_in):
     from strajnet_amd import ops
     ps = [mk_param(w, dt) for w in ws]
-    a, b = xo.to(dt).requires_grad_(True), xf.to(dt).requires_grad_(True)
+    a, b = xo.detach().to(dt).clone().requires_grad_(True), xf.detach().to(dt).clone().requires_grad_(True)
     out = ops.outconv_pair(a, b, *ps, B, Tn, t_major=True, x_is_elu_out=elu_in)
     out.backward(dout)
     torch.cuda.synchronize()
@@ -124,7 +124,7 @@ def test_outconv_mfma_bench_shape_bf16(elu_in):
 def _linear_run(x, w, b, res, g, dt, act):
     from strajnet_amd import ops
     pw, pb = mk_param(w, dt), mk_param(b, dt)
-    xi = x.to(dt).requires_grad_(True)
+    xi = x.detach().to(dt).clone().requires_grad_(True)
     r = res.to(dt) if res is not None else None
     y = ops.linear(xi, pw, pb, act, r)
     y.backward(g.to(dt))
