@@ -103,6 +103,18 @@ int stj_swin_mlp_bwd(const void* x, const void* dy, const float* gamma, const fl
                      int nparts, long long part_stride, long long M, int C, float eps, const long long* rng_state, int site,
                      float p_drop, long long rows_per_sample, int dtype, hipStream_t stream);
 
+/* Fused attention half of SwinTransformerBlock, forward (modules.py:225-258: norm1, roll, window_partition, WindowAttention :103-134
+ * with the shift mask :189-216, window_reverse, roll, drop_path + shortcut), one workgroup per 8x8 window (csrc/swin_fused.hip):
+ *   y = x + dp * (proj(window_attention(LN(x) wqkv + bqkv)) + bproj);  x, y [B,res*res,C], C in {96,192}, heads = C/32;
+ *   wqkv [C,3C], wproj [C,C] activation dtype (Keras [in,out]); bqkv [3C], bproj [C], gamma/beta [C], table [225,heads] f32.
+ * Training hand-offs (all or none; NULL for inference): qkv [B,N,3C], a = attention output before proj [B,N,C], ln = LN(x) [B,N,C],
+ * mean / rstd f32 [B*N] -- the operands stj_win_attn_bwd, stj_layernorm_bwd and the dgrad / wgrad stj_gemm launches of backward read.
+ * DropPath: one draw per sample b at (rng_state, site), as stj_dropout(inner = N*C) draws it. */
+int stj_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
+                      const float* table, const void* wproj, const float* bproj, void* y, void* qkv, void* a, void* ln,
+                      float* mean, float* rstd, int B, int res, int C, int shift, float eps, const long long* rng_state,
+                      int site, float p_drop, int dtype, hipStream_t stream);
+
 /* Row softmax of the global attentions: P = softmax(S + bias + (-10e9 where !(qvalid&kvalid))) (tfa MHA mask
  * semantics, f32 add); S f32 [batch,H,Nq,Nk] (Nk <= 256).  bwd: dS = P*(dP - sum(P dP)). */
 int stj_softmax_fwd(const float* S, void* P, const int* qvalid, const int* kvalid, const float* bias,

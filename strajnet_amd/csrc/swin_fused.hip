@@ -521,3 +521,258 @@ extern "C" int stj_swin_mlp_bwd(const void* x, const void* dy, const float* gamm
   a.rng = rng_state; a.site = site; a.p_drop = p_drop; a.rows_per_sample = rows_per_sample;
   return mlp_any(true, C, dtype, a, stream);
 }
+
+// =====================================================================================================================
+// Fused attention half of SwinTransformerBlock, forward:
+//     y = x + dp * ( proj( window_attention( LN(x) Wqkv + bqkv ) ) + bproj )
+// reference modules.py:225-258 (norm1, roll, window_partition, attn, window_reverse, roll, drop_path + shortcut),
+// :103-134 (WindowAttention.call), :189-216 (shift mask), :49-63 (partition / reverse) -- SURVEY.md K2.
+// One workgroup = one 8x8 window (64 tokens), 4 waves, a wave OWNS 16 of the window's tokens (queries) end to end:
+//   phase 1  LayerNorm in registers (rows are B fragments loaded straight from global, gathered through the shift / window
+//            index arithmetic), q|k|v^T = W^T LN(x)^T on the accumulator layout, written token-major into an LDS tile
+//            (the only activation data that goes through LDS: every wave needs all 64 keys / values of the window);
+//   phase 2  per head: S^T = K Q^T (+ relative-position bias, -100 shift mask), softmax over the keys held by the lane and its
+//            3 partner lanes (two xor-shuffles), O^T = V^T P^T with P^T chained in registers (Chain<T>, see the MLP kernels)
+//            and V^T fragments by LDS transpose reads of the token-major tile;
+//   phase 3  out^T += Wproj^T O^T, again chained in registers; epilogue bias + DropPath + shortcut, stores in token order.
+// Heads are processed in groups of HG (LDS budget): a pass stages the q/k/v weight columns of its heads and the matching
+// rows of Wproj.  Training additionally writes what backward needs: qkv [M,3C], a = attention output [M,C], ln = LN(x) [M,C],
+// mean / rstd [M].
+// =====================================================================================================================
+template <typename T, int C> struct AttnCfg {
+  static constexpr int KSTEP = Mma<T>::KSTEP;
+  static constexpr int KS = C / KSTEP, NF = C / 16, HEADS = C / 32;
+  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? 3 : (C == 192 ? 2 : 1)) : 1;     // heads per pass
+  static constexpr int GC = 32 * HG;                                   // q (= k = v) columns per pass
+  static constexpr int LDT = 3 * GC + (sizeof(T) == 2 ? 16 : 8);       // token-major q|k|v tile [64][LDT]
+  static constexpr int LDW = 3 * GC + 4;                               // Wqkv slice image [C][LDW] ([k = c][q seg | k seg | v seg])
+  static constexpr int LDP = C + 4;                                    // Wproj slice image [GC][LDP] ([k = c of the group][oc])
+  static constexpr int TILE = 64 * LDT, WQ = C * LDW, WP = GC * LDP;
+  static constexpr int LDS_BYTES = (TILE + WQ + WP) * (int)sizeof(T) + HG * 225 * 4 + 2 * 64 * 4;
+  static_assert(HEADS % HG == 0, "head groups");
+};
+
+struct AttnArgs {
+  const void* x; const float* gamma; const float* beta; const void* wqkv; const float* bqkv; const float* table;
+  const void* wproj; const float* bproj; void* y;
+  void* qkv; void* a; void* ln; float* mean; float* rstd;         // training hand-offs (all NULL for inference)
+  int B, res, shift; float eps;
+  const long long* rng; int site; float p_drop;
+};
+
+template <typename T, int C>
+__global__ __launch_bounds__(256, 1) void swin_attn_fwd_kernel(AttnArgs p) {
+  typedef AttnCfg<T, C> G;
+  constexpr int KS = G::KS, NF = G::NF, HG = G::HG, GC = G::GC, KSTEP = G::KSTEP, ND = Chain<T>::ND, LK = Mma<T>::LANE_K;
+  constexpr int VN = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) unsigned char at_smem[];
+  T* tile = reinterpret_cast<T*>(at_smem);
+  T* Wqs = tile + G::TILE;
+  T* Wps = Wqs + G::WQ;
+  float* tbl = reinterpret_cast<float*>(Wps + G::WP);               // [HG][225]
+  int* tok = reinterpret_cast<int*>(tbl + HG * 225);                // [64] token index of window slot t (shift + partition)
+  int* lab = tok + 64;                                              // [64] shift-mask region label
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, ln = lane & 15;
+  const int nwx = p.res / 8, nW = nwx * nwx;
+  const int win = blockIdx.x % nW, b = blockIdx.x / nW;
+  const int wy = win / nwx, wx = win % nwx;
+  const long long N = (long long)p.res * p.res;
+  if (tid < 64) {
+    const int t = tid;
+    int ry = wy * 8 + (t >> 3), rx = wx * 8 + (t & 7);
+    int sy = ry + p.shift; if (sy >= p.res) sy -= p.res;
+    int sx = rx + p.shift; if (sx >= p.res) sx -= p.res;
+    tok[t] = sy * p.res + sx;
+    const int ly = ry < p.res - 8 ? 0 : (ry < p.res - p.shift ? 1 : 2);
+    const int lx = rx < p.res - 8 ? 0 : (rx < p.res - p.shift ? 1 : 2);
+    lab[t] = ly * 3 + lx;
+  }
+  __syncthreads();
+  const T* x = reinterpret_cast<const T*>(p.x) + (long long)b * N * C;
+  const long long myrow = (long long)b * N + tok[16 * wv + ln];      // global row (token) this lane's query lives at
+  // ---- rows of this wave as B fragments (gathered), LayerNorm in registers
+  typename Mma<T>::Frag xa[1][KS];
+  {
+    const T* px = x + (long long)tok[16 * wv + ln] * C + LK * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xa[0][ks] = Mma<T>::from_global(px + ks * KSTEP);
+  }
+  float mu[1], rs[1];
+  ln_rows<T, C, 1>(xa, p.gamma, p.beta, p.eps, mu, rs, lane);
+  if (p.ln) {
+    T* lq = reinterpret_cast<T*>(p.ln) + myrow * C + LK * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<typename Mma<T>::Frag*>(lq + ks * KSTEP) = xa[0][ks];
+    if (g == 0) { p.mean[myrow] = mu[0]; p.rstd[myrow] = rs[0]; }
+  }
+
+  f32x4 acco[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) acco[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const T* wq = reinterpret_cast<const T*>(p.wqkv);
+  const T* wp = reinterpret_cast<const T*>(p.wproj);
+  const float scale = 0.17677669529663687f;       // 32^-1/2
+
+  for (int h0 = 0; h0 < G::HEADS; h0 += HG) {
+    // ---- stage the weight slices of this head group: Wqkv[:, seg*C + 32 h0 .. +GC] for seg = q,k,v; Wproj[32 h0 .. +GC, :]
+    {
+      constexpr int CPS = GC / VN;                   // 16-byte chunks per segment row
+      for (int q = tid; q < C * 3 * CPS; q += 256) {
+        const int k = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
+        const uint4 v = *reinterpret_cast<const uint4*>(wq + (long long)k * (3 * C) + seg * C + 32 * h0 + c);
+        T* d = Wqs + k * G::LDW + seg * GC + c;
+        if constexpr (sizeof(T) == 2) { uint2* d2 = reinterpret_cast<uint2*>(d); d2[0] = make_uint2(v.x, v.y); d2[1] = make_uint2(v.z, v.w); }
+        else *reinterpret_cast<uint4*>(d) = v;
+      }
+      constexpr int CPP = C / VN;
+      for (int q = tid; q < GC * CPP; q += 256) {
+        const int k = q / CPP, c = (q % CPP) * VN;
+        const uint4 v = *reinterpret_cast<const uint4*>(wp + (long long)(32 * h0 + k) * C + c);
+        T* d = Wps + k * G::LDP + c;
+        if constexpr (sizeof(T) == 2) { uint2* d2 = reinterpret_cast<uint2*>(d); d2[0] = make_uint2(v.x, v.y); d2[1] = make_uint2(v.z, v.w); }
+        else *reinterpret_cast<uint4*>(d) = v;
+      }
+      for (int q = tid; q < HG * 225; q += 256) tbl[q] = p.table[(q % 225) * G::HEADS + h0 + q / 225];
+    }
+    __syncthreads();
+    // ---- phase 1: q|k|v of this group for the wave's 16 tokens -> tile
+#pragma unroll 1
+    for (int f = 0; f < 3 * GC / 16; ++f) {
+      const int seg = (16 * f) / GC, within = (16 * f) % GC;
+      const float4 bv = *reinterpret_cast<const float4*>(p.bqkv + seg * C + 32 * h0 + within + 4 * g);
+      f32x4 a = (f32x4){bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a = Mma<T>::mma(Mma<T>::load_tr(Wqs, G::LDW, 16 * f, ks * KSTEP, lane), xa[0][ks], a);
+      const float v[4] = {a[0], a[1], a[2], a[3]};
+      st4(tile + (16 * wv + ln) * G::LDT + 16 * f + 4 * g, v);
+    }
+    __syncthreads();
+    if (p.qkv) {                                     // coalesced copy of the tile to qkv[M, 3C] (rows in original token order)
+      constexpr int CPS = GC / VN;
+      T* qo = reinterpret_cast<T*>(p.qkv) + (long long)b * N * 3 * C;
+      for (int q = tid; q < 64 * 3 * CPS; q += 256) {
+        const int t = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
+        *reinterpret_cast<uint4*>(qo + (long long)tok[t] * 3 * C + seg * C + 32 * h0 + c) =
+            *reinterpret_cast<const uint4*>(tile + t * G::LDT + seg * GC + c);
+      }
+    }
+    // ---- phase 2: attention of the wave's 16 queries, head by head
+    f32x4 of[2 * HG];
+    const int qi = 16 * wv + ln;
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh) {
+      f32x4 st[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        st[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += KSTEP)
+          st[j] = Mma<T>::mma(Mma<T>::load(tile + GC + 32 * hh, G::LDT, 16 * j, k0, lane), Mma<T>::load(tile + 32 * hh, G::LDT, 16 * wv, k0, lane), st[j]);
+      }
+      float m = -INFINITY;
+      const int mylab = lab[qi];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * j + 4 * g + r;
+          float v = st[j][r] * scale + tbl[hh * 225 + ((qi >> 3) - (key >> 3) + 7) * 15 + ((qi & 7) - (key & 7) + 7)];
+          if (p.shift > 0 && lab[key] != mylab) v += -100.0f;
+          st[j][r] = v;
+          m = fmaxf(m, v);
+        }
+      m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float e = __expf(st[j][r] - m); st[j][r] = e; sum += e; }
+      sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[j][r] *= inv;
+      of[2 * hh] = (f32x4){0.f, 0.f, 0.f, 0.f}; of[2 * hh + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 64 / KSTEP; ++s) {
+        const typename Chain<T>::Frag pf = Chain<T>::from_acc(&st[s * ND]);
+#pragma unroll
+        for (int jd = 0; jd < 2; ++jd)
+          of[2 * hh + jd] = Mma<T>::mma(Chain<T>::ldA_tr(tile + 2 * GC + 32 * hh, G::LDT, 16 * jd, s * KSTEP, lane), pf, of[2 * hh + jd]);
+      }
+      if (p.a) {
+        T* ao = reinterpret_cast<T*>(p.a) + myrow * C + 32 * (h0 + hh) + 4 * g;
+#pragma unroll
+        for (int jd = 0; jd < 2; ++jd) { const float v[4] = {of[2 * hh + jd][0], of[2 * hh + jd][1], of[2 * hh + jd][2], of[2 * hh + jd][3]}; st4(ao + 16 * jd, v); }
+      }
+    }
+    // ---- phase 3: out^T += Wproj[32 h0 .. +GC, :]^T O^T, O^T chained from the accumulators
+#pragma unroll
+    for (int kk = 0; kk < GC / KSTEP; ++kk) {
+      const typename Chain<T>::Frag ofr = Chain<T>::from_acc(&of[kk * ND]);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acco[f] = Mma<T>::mma(Chain<T>::ldA_tr(Wps, G::LDP, 16 * f, kk * KSTEP, lane), ofr, acco[f]);
+    }
+    __syncthreads();                                  // tile / weight images are overwritten by the next pass
+  }
+
+  // ---- epilogue: y = x + dp * (out + bproj)
+  const float dp = drop_path_scale(p.rng, p.site, b, p.p_drop);
+  T* y = reinterpret_cast<T*>(p.y) + myrow * C;
+  const T* xr = reinterpret_cast<const T*>(p.x) + myrow * C;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int col = 16 * f + 4 * g;
+    const float4 bv = *reinterpret_cast<const float4*>(p.bproj + col);
+    float xv[4];
+    ld4(xr + col, xv);
+    const float v[4] = {xv[0] + dp * (acco[f][0] + bv.x), xv[1] + dp * (acco[f][1] + bv.y), xv[2] + dp * (acco[f][2] + bv.z), xv[3] + dp * (acco[f][3] + bv.w)};
+    st4(y + col, v);
+  }
+}
+
+template <typename T, int C>
+static int attn_launch(const AttnArgs& a, hipStream_t st) {
+  typedef AttnCfg<T, C> G;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)swin_attn_fwd_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
+      stj_set_error("swin_attn: cannot reserve %d bytes of LDS", G::LDS_BYTES); return STJ_ELAUNCH;
+    }
+    attr = true;
+  }
+  const int nW = (a.res / 8) * (a.res / 8);
+  hipLaunchKernelGGL((swin_attn_fwd_kernel<T, C>), dim3((unsigned)(a.B * nW)), dim3(256), G::LDS_BYTES, st, a);
+  return stj_check_launch("stj_swin_attn_fwd");
+}
+template <typename T>
+static int attn_dispatch(int C, const AttnArgs& a, hipStream_t st) {
+  switch (C) {
+    case 96: return attn_launch<T, 96>(a, st);
+    case 192: return attn_launch<T, 192>(a, st);
+    // C = 384 (the 16x16 stage, 32 windows at B = 8): too few workgroups for a window-per-workgroup kernel, and the f32 weight
+    // slice alone would not fit LDS -- that stage keeps the layer-by-layer path
+    default: stj_set_error("swin_attn: C must be 96 or 192 (got %d)", C); return STJ_EUNSUPPORTED;
+  }
+}
+
+extern "C" int stj_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
+                                 const float* table, const void* wproj, const float* bproj, void* y, void* qkv, void* a, void* ln,
+                                 float* mean, float* rstd, int B, int res, int C, int shift, float eps, const long long* rng_state,
+                                 int site, float p_drop, int dtype, hipStream_t stream) {
+  if (B <= 0) return STJ_OK;
+  if (res % 8 != 0 || shift < 0 || shift >= 8) { stj_set_error("swin_attn: res %% 8 != 0 or bad shift"); return STJ_EINVAL; }
+  if (!(p_drop >= 0.f && p_drop < 1.f)) { stj_set_error("swin_attn: need 0 <= p_drop < 1"); return STJ_EINVAL; }
+  if ((qkv || a || ln) && !(qkv && a && ln && mean && rstd)) { stj_set_error("swin_attn: training outputs come all or none"); return STJ_EINVAL; }
+  AttnArgs p = {};
+  p.x = x; p.gamma = gamma; p.beta = beta; p.wqkv = wqkv; p.bqkv = bqkv; p.table = table; p.wproj = wproj; p.bproj = bproj; p.y = y;
+  p.qkv = qkv; p.a = a; p.ln = ln; p.mean = mean; p.rstd = rstd; p.B = B; p.res = res; p.shift = shift; p.eps = eps;
+  p.rng = rng_state; p.site = site; p.p_drop = p_drop;
+  if (dtype == STJ_BF16) return attn_dispatch<bf16>(C, p, stream);
+  if (dtype == STJ_F16) return attn_dispatch<f16>(C, p, stream);
+  if (dtype == STJ_F32) return attn_dispatch<float>(C, p, stream);
+  stj_set_error("swin_attn: bad dtype %d", dtype);
+  return STJ_EINVAL;
+}

@@ -229,7 +229,10 @@ class STrajNet:
         self.serial = False              # True: everything on the current stream (per-kernel timing, debugging)
         # fused Swin-block kernels (csrc/swin_fused.hip); STJ_FUSED_MLP=0 selects the layer-by-layer path (A/B runs, debugging)
         self.fused_mlp = os.environ.get('STJ_FUSED_MLP', '1') != '0'
-        self.fused_mlp_dims = tuple(int(v) for v in os.environ.get('STJ_FUSED_MLP_DIMS', '96,192,384').split(','))
+        self.fused_attn = os.environ.get('STJ_FUSED_ATTN', '1') != '0'
+        self.fused_attn_dims = tuple(int(v) for v in os.environ.get('STJ_FUSED_ATTN_DIMS', '96,192').split(','))
+        # (C = 384, the 16x16 stage: 2048 rows = 32 row blocks / 32 windows at B = 8 -- the fused kernels measured slower there)
+        self.fused_mlp_dims = tuple(int(v) for v in os.environ.get('STJ_FUSED_MLP_DIMS', '96,192').split(','))
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():
             k = int(np.prod(s))
@@ -370,10 +373,26 @@ class STrajNet:
         if res <= 8:
             shift = 0                                             # modules.py:173-175
         dpr = self.drop_path_rate.get(pre, 0.0) if self._dctx is not None else 0.0
+        fused_mlp = self.fused_mlp and x.shape[-1] in self.fused_mlp_dims
+        if self.fused_attn and x.shape[-1] in self.fused_attn_dims:
+            # LN1 -> qkv -> (S)W-MSA -> proj -> DropPath -> + shortcut in ONE kernel, one workgroup per window (csrc/swin_fused.hip)
+            x = ops.swin_attn_half(x, self._p(pre + '/norm1/gamma'), self._p(pre + '/norm1/beta'), self._p(pre + '/attn/qkv/kernel'),
+                                   self._p(pre + '/attn/qkv/bias'), self._p(pre + '/attn/relative_position_bias_table'),
+                                   self._p(pre + '/attn/proj/kernel'), self._p(pre + '/attn/proj/bias'), B, res, shift, 1e-5,
+                                   self._dctx, pre + '/drop_path_attn', dpr)
+            if fused_mlp:
+                return ops.swin_mlp(x, self._p(pre + '/norm2/gamma'), self._p(pre + '/norm2/beta'), self._p(pre + '/mlp/fc1/kernel'),
+                                    self._p(pre + '/mlp/fc1/bias'), self._p(pre + '/mlp/fc2/kernel'), self._p(pre + '/mlp/fc2/bias'), 1e-5,
+                                    self._dctx, pre + '/drop_path_mlp', dpr, rows_per_sample=res * res)
+            h, x = self._ln_skip(x, pre + '/norm2', 1e-5)
+            h = ops.gelu(self._dense(h, pre + '/mlp/fc1'))
+            if dpr == 0.0:
+                return self._dense(h, pre + '/mlp/fc2', res=x)
+            h = self._dense(h, pre + '/mlp/fc2').view(B, -1)
+            return ops.dropout(h, dpr, self._dctx, pre + '/drop_path_mlp', res=x.view(B, -1), per_sample=True).view(x.shape)
         h, x = self._ln_skip(x, pre + '/norm1', 1e-5)
         qkv = self._dense(h, pre + '/attn/qkv')
         a = ops.win_attn(qkv, self._p(pre + '/attn/relative_position_bias_table'), B, res, heads, shift)
-        fused_mlp = self.fused_mlp and x.shape[-1] in self.fused_mlp_dims
 
         def mlp_fused(x):            # LN2 -> fc1 -> GELU -> fc2 -> DropPath -> + shortcut in ONE kernel (csrc/swin_fused.hip)
             return ops.swin_mlp(x, self._p(pre + '/norm2/gamma'), self._p(pre + '/norm2/beta'), self._p(pre + '/mlp/fc1/kernel'),

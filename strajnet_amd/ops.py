@@ -551,6 +551,100 @@ def swin_mlp(x, pg, pb, pw1, pb1, pw2, pb2, eps, dctx=None, name=None, p_drop=0.
     return _SwinMlp.apply(x, pg.master, pg, pb, pw1, pb1, pw2, pb2, eps, drop, rps)
 
 
+class _SwinAttnHalf(torch.autograd.Function):
+    """x -> x + DropPath(proj(W-MSA / SW-MSA(LN(x)))): forward is ONE kernel (stj_swin_attn_fwd); backward runs the proj / qkv
+    input and weight gradients as GEMMs around the window-attention backward kernel, on the operands the forward kernel saved."""
+    @staticmethod
+    def forward(ctx, x, trig, pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, eps, drop):
+        _req_cuda(x)
+        x = x.contiguous()
+        C = x.shape[-1]
+        N = res * res
+        y = torch.empty_like(x)
+        train = torch.is_grad_enabled() and (x.requires_grad or trig.requires_grad)
+        qkv = a = ln = mean = rstd = None
+        if train:
+            qkv = torch.empty((B, N, 3 * C), dtype=x.dtype, device=x.device)
+            a = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
+            ln = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
+            mean = torch.empty(B * N, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(B * N, dtype=torch.float32, device=x.device)
+        p_drop, state, site = drop if drop is not None else (0.0, None, 0)
+        call('stj_swin_attn_fwd', _p(x), _p(pg.master), _p(pb.master), _p(pwq.c), _p(pbq.master), _p(pt.master), _p(pwp.c),
+             _p(pbp.master), _p(y), _p(qkv), _p(a), _p(ln), _p(mean), _p(rstd), B, res, C, shift, float(eps), _p(state), site,
+             float(p_drop), _dt(x), _st())
+        ctx.ps = (pg, pb, pwq, pbq, pt, pwp, pbp)
+        ctx.args = (B, res, C, shift, drop)
+        ctx.save_for_backward(x, qkv, a, ln, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, qkv, a, ln, mean, rstd = ctx.saved_tensors
+        pg, pb, pwq, pbq, pt, pwp, pbp = ctx.ps
+        B, res, C, shift, drop = ctx.args
+        N = res * res
+        M = B * N
+        heads = C // 32
+        dt = _dt(x)
+        dy = dy.contiguous()
+        dys = dy
+        if drop is not None:            # gradient of the branch = DropPath factor * dy (same draw, re-derived)
+            p_drop, state, site = drop
+            dys = torch.empty_like(dy)
+            call('stj_dropout', _p(dy), None, _p(dys), dy.numel(), N * C, float(p_drop), _p(state), site, dt, _st())
+        dys2, a2, ln2 = dys.view(M, C), a.view(M, C), ln.view(M, C)
+        da = torch.empty_like(a)
+        gemm(dys2, pwp.c, da, M, C, C, (0, 0, C, 1), (0, 0, 1, C), (0, 0, C), dt)                        # da = dys Wp^T
+        with wgrad_stream(1, a2, dys2):
+            gemm(a2, dys2, pwp.grad, C, C, M, (0, 0, 1, C), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1, splitk=0,
+                 colsum=pbp.grad)                                                                         # dWp += a^T dys ; dbp
+        dqkv = torch.empty_like(qkv)
+        items = B * (res // 8) ** 2 * heads
+        nparts = 32 if items >= 1024 else (16 if items >= 256 else 1)
+        if pt.part is not None:
+            call('stj_win_attn_bwd', _p(qkv), _p(pt.master), _p(da), _p(dqkv), _p(pt.part[0]), min(nparts, pt.part[1]), B, res, heads,
+                 shift, dt, _st())
+        else:
+            part = zeros_f32((nparts,) + tuple(pt.grad.shape), x.device)
+            call('stj_win_attn_bwd', _p(qkv), _p(pt.master), _p(da), _p(dqkv), _p(part), nparts, B, res, heads, shift, dt, _st())
+            pt.grad.add_(part.sum(0))
+        dq2 = dqkv.view(M, 3 * C)
+        dln = torch.empty_like(ln)
+        gemm(dq2, pwq.c, dln, M, C, 3 * C, (0, 0, 3 * C, 1), (0, 0, 1, 3 * C), (0, 0, C), dt)             # dln = dqkv Wqkv^T
+        with wgrad_stream(1, ln2, dq2):
+            gemm(ln2, dq2, pwq.grad, C, 3 * C, M, (0, 0, 1, C), (0, 0, 3 * C, 1), (0, 0, 3 * C), dt, c_f32=1, accumulate=1,
+                 splitk=0, colsum=pbq.grad)                                                               # dWqkv += ln^T dqkv ; dbqkv
+        dx = torch.empty_like(x)
+        if pg.part is not None and pb.part is not None:
+            dg, db, np_, ps_ = pg.part[0], pb.part[0], pg.part[1], pg.part[2]
+        else:
+            dg, db, np_, ps_ = pg.grad, pb.grad, 1, 0
+        call('stj_layernorm_bwd', _p(dln), _p(x), _p(pg.master), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), M, C, 0, 0, 0, 1, 0,
+             _p(dy), np_, ps_, dt, _st())                                                                 # + the shortcut gradient
+        return (dx,) + (None,) * 13
+
+
+def swin_attn_half(x, pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, eps, dctx=None, name=None, p_drop=0.0):
+    """x [B, res*res, C] -> x + DropPath(proj(window_attention(LN(x))))  (modules.py:225-258)."""
+    drop = None
+    if dctx is not None and p_drop > 0.0:
+        drop = (float(p_drop), dctx.snap, dctx.site(name, (B,), p_drop))
+    return _SwinAttnHalf.apply(x, pg.master, pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, eps, drop)
+
+
+def _attn_cost(a):
+    B, res, C, dt = a[14], a[15], a[16], a[22]
+    es = 4 if dt == 0 else 2
+    M = B * res * res
+    fl = 2.0 * M * C * 4 * C + M * 4.0 * 64 * C
+    tens = 2 + (5 if getattr(a[9], 'value', None) else 0)
+    return f'swin_attn_fwd[B{B} {res}x{res} C{C}]', 'swin_attn_fwd', fl, fl, es * M * C * tens
+
+
+prof.EXTRA_MODELS['stj_swin_attn_fwd'] = _attn_cost
+
+
 def _mlp_cost(kind):
     def f(a):
         M, C, dt = (a[8], a[9], a[15]) if kind == 'fwd' else (a[16], a[17], a[23])

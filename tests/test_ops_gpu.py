@@ -512,6 +512,50 @@ def test_swin_mlp_fused(dt, B, N, C, p_drop):
         assert rel_err(p_.grad, r_.grad) < 2 * t, nm
 
 
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('B,res,C,shift,p_drop', [(2, 16, 96, 0, 0.0), (3, 16, 96, 4, 0.3), (2, 16, 192, 4, 0.3), (1, 32, 192, 0, 0.0), (2, 8, 96, 0, 0.0)])
+def test_swin_attn_half_fused(dt, B, res, C, shift, p_drop):
+    """csrc/swin_fused.hip: x + DropPath(proj(window_attention(LN(x) Wqkv + b))) in one kernel (modules.py:225-258,103-134,189-216)
+    and its backward (GEMMs + window-attention backward on the saved operands) vs float64 autograd on the index formulation."""
+    from strajnet_amd import ops
+    heads = C // 32
+    N = res * res
+    pg, pb = mk_param((C,), dt, 0.3, 1), mk_param((C,), dt, 0.3, 2)
+    with torch.no_grad():
+        pg.master.add_(1.0)
+    pwq, pbq = mk_param((C, 3 * C), dt, 0.15, 3), mk_param((3 * C,), dt, 0.2, 4)
+    pt = mk_param((225, heads), dt, 0.5, 5)
+    pwp, pbp = mk_param((C, C), dt, 0.1, 6), mk_param((C,), dt, 0.2, 7)
+    x = rnd((B, N, C), dt, 8, 2.0).requires_grad_(True)
+    dctx = None
+    if p_drop > 0:
+        dctx = ops.DropCtx('cuda', seed=13)
+        dctx.begin()
+    y = ops.swin_attn_half(x, pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, 1e-5, dctx, 'dp', p_drop)
+    keep = torch.ones(B, dtype=torch.float64)
+    if p_drop > 0:
+        keep = dctx.mask('dp').double().cpu() / (1.0 - p_drop)
+    refs = [ref_of(t) for t in (x, pg.master, pb.master, pwq.c, pbq.master, pt.master, pwp.c, pbp.master)]
+    xr, gr, br, wqr, bqr, tr, wpr, bpr = refs
+    qkvr = F.layer_norm(xr, (C,), gr, br, 1e-5) @ wqr + bqr
+    yr = xr + keep.view(B, 1, 1) * (_win_ref(qkvr, tr, B, res, heads, shift) @ wpr + bpr)
+    t = tol(dt)
+    assert rel_err(y, yr) < t
+    # inference form (no saved operands) gives the same result
+    with torch.no_grad():
+        if dctx is not None:
+            dctx.n = 0              # re-register the same site id for the repeated call
+        y2 = ops.swin_attn_half(x.detach(), pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, 1e-5, dctx, 'dp', p_drop)
+    assert torch.equal(y2, y.detach())
+    g = rnd((B, N, C), dt, 9)
+    y.backward(g)
+    yr.backward(g.double().cpu())
+    assert rel_err(x.grad, xr.grad) < 2 * t
+    for nm, p_, r_ in (('gamma', pg, gr), ('beta', pb, br), ('wqkv', pwq, wqr), ('bqkv', pbq, bqr), ('table', pt, tr), ('wproj', pwp, wpr),
+                       ('bproj', pbp, bpr)):
+        assert rel_err(p_.grad, r_.grad) < 2 * t, nm
+
+
 def test_nadam_step_matches_keras_formula():
     """stj_nadam_step vs the Keras Nadam recurrences in float64 over three steps."""
     from strajnet_amd.optim import Nadam

@@ -31,8 +31,39 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+def attn_half(dt):
+    for B, res, C, shift in ((8, 64, 96, 0), (8, 64, 96, 4), (8, 32, 192, 4), (8, 128, 96, 4)):
+        N = res * res
+        heads = C // 32
+        pg, pb = mk((C,), dt), mk((C,), dt)
+        pwq, pbq, pt, pwp, pbp = mk((C, 3 * C), dt), mk((3 * C,), dt), mk((225, heads), dt), mk((C, C), dt), mk((C,), dt)
+        x = torch.randn(B, N, C, device='cuda').to(dt).requires_grad_(True)
+        g = torch.randn(B, N, C, device='cuda').to(dt)
+
+        def fused(xx):
+            return ops.swin_attn_half(xx, pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, 1e-5)
+
+        def unfused(xx):
+            h, sk = ops.layernorm_skip(xx, pg, pb, 1e-5)
+            a = ops.win_attn(ops.linear(h, pwq, pbq), pt, B, res, heads, shift)
+            return ops.linear(a, pwp, pbp, res=sk)
+
+        def run(fn, grad):
+            def f():
+                if grad:
+                    x.grad = None
+                    fn(x).backward(g)
+                else:
+                    with torch.no_grad():
+                        fn(x)
+            return f
+        print(f'B={B} {res}x{res} C={C} shift={shift}: attention half  fwd fused {timeit(run(fused, False)):7.1f} us  layers {timeit(run(unfused, False)):7.1f} us | '
+              f'fwd+bwd fused {timeit(run(fused, True)):7.1f} us  layers {timeit(run(unfused, True)):7.1f} us', flush=True)
+
+
 def main():
     dt = torch.bfloat16
+    attn_half(dt)
     for B, res, C in ((8, 64, 96), (8, 32, 192), (8, 16, 384), (8, 128, 96), (32, 64, 96)):
         N = res * res
         pg, pb = mk((C,), dt), mk((C,), dt)
