@@ -561,7 +561,7 @@ class _SwinAttnHalf(torch.autograd.Function):
         C = x.shape[-1]
         N = res * res
         y = torch.empty_like(x)
-        train = torch.is_grad_enabled() and (x.requires_grad or trig.requires_grad)
+        train = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])     # False under torch.no_grad(): nothing is saved
         qkv = a = ln = mean = rstd = None
         if train:
             qkv = torch.empty((B, N, 3 * C), dtype=x.dtype, device=x.device)
