@@ -20,6 +20,21 @@
 //     natural Keras [in, out] layouts with coalesced 16-byte loads, shared by the 4 waves of the block.
 #include "common.h"
 #include "rng.h"
+#include <stdlib.h>
+
+// tuning switches (A/B builds: -DSTJ_MLP_MINB=2 ...)
+#ifndef STJ_MLP_MINB
+#define STJ_MLP_MINB 1          // min resident blocks per CU the MLP kernels are compiled for (2 caps them at 256 registers)
+#endif
+#ifndef STJ_MLP_PREFETCH
+#define STJ_MLP_PREFETCH 1      // next weight chunk's global loads issued before the current chunk's MFMAs
+#endif
+#ifndef STJ_ATTN_MINB
+#define STJ_ATTN_MINB 1
+#endif
+#ifndef STJ_ATTN_HG96
+#define STJ_ATTN_HG96 3         // heads per pass of the attention kernel at C = 96 (16-bit types)
+#endif
 
 // ---- chained-operand fragments -------------------------------------------------------------------------------
 template <typename T> struct Chain;
@@ -83,11 +98,11 @@ template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
 }
 
 // ---- geometry ---------------------------------------------------------------------------------------------------
-template <typename T, int C> struct MlpCfg {
+template <typename T, int C, int RF_ = ((C <= 192) ? 2 : 1)> struct MlpCfg {
   static constexpr int KSTEP = Mma<T>::KSTEP;
   static constexpr int KS = C / KSTEP;                // k-steps over the model dimension
   static constexpr int NF = C / 16;                   // 16-column fragments of the model dimension
-  static constexpr int RF = (C <= 192) ? 2 : 1;       // 16-row fragments per wave
+  static constexpr int RF = RF_;                      // 16-row fragments per wave
   static constexpr int ROWS = 4 * RF * 16;            // rows per block
   // hidden columns per staged chunk: as many as keep the two images under ~78 KB (two blocks per CU)
   static constexpr int HC = sizeof(T) == 2 ? (C == 96 ? 192 : (C == 192 ? 96 : 32)) : (C == 96 ? 96 : (C == 192 ? 48 : 16));
@@ -106,25 +121,45 @@ struct MlpArgs {
   const long long* rng; int site; float p_drop; long long rows_per_sample;
 };
 
-// stage W1[:, hc0 : hc0+HC] ([C][4C] global, row stride 4C) and W2[hc0 : hc0+HC, :] ([4C][C] global) into LDS
-template <typename T, int C>
-__device__ __forceinline__ void mlp_stage(T* W1s, T* W2s, const T* w1, const T* w2, int hc0, int tid) {
-  typedef MlpCfg<T, C> G;
-  constexpr int VN = Vec<T>::N;
-  constexpr int CP1 = G::HC / VN;
-  for (int q = tid; q < C * CP1; q += 256) {
-    const int k = q / CP1, c = (q % CP1) * VN;
-    const uint4 v = *reinterpret_cast<const uint4*>(w1 + (long long)k * (4 * C) + hc0 + c);
-    T* d = W1s + k * G::LD1 + c;
-    if constexpr (sizeof(T) == 2) { uint2* d2 = reinterpret_cast<uint2*>(d); d2[0] = make_uint2(v.x, v.y); d2[1] = make_uint2(v.z, v.w); }
-    else *reinterpret_cast<uint4*>(d) = v;
+// Staging of W1[:, hc0 : hc0+HC] ([C][4C] global, row stride 4C) and W2[hc0 : hc0+HC, :] ([4C][C] global) into LDS, split into
+// "global -> registers" (issued one chunk AHEAD: the loads fly while the current chunk's MFMAs run -- with a synchronous copy every
+// chunk exposed a full L2 / HBM round trip per 16 KB in flight, and the weights are cold in the real step: 114 vs 53 us for the
+// 8192 x 192 forward) and "registers -> LDS".
+template <typename T, int C> struct MlpStage {
+  typedef MlpCfg<T, C, 1> G;
+  static constexpr int VN = Vec<T>::N;
+  static constexpr int CP1 = G::HC / VN, CP2 = C / VN;
+  static constexpr int N1 = (C * CP1 + 255) / 256, N2 = (G::HC * CP2 + 255) / 256;
+  uint4 r1[N1], r2[N2];
+  __device__ __forceinline__ void issue(const T* w1, const T* w2, int hc0, int tid) {
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int q = tid + i * 256;
+      if (q < C * CP1) { const int k = q / CP1, c = (q % CP1) * VN; r1[i] = *reinterpret_cast<const uint4*>(w1 + (long long)k * (4 * C) + hc0 + c); }
+    }
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+      const int q = tid + i * 256;
+      if (q < G::HC * CP2) { const int k = q / CP2, c = (q % CP2) * VN; r2[i] = *reinterpret_cast<const uint4*>(w2 + (long long)(hc0 + k) * C + c); }
+    }
   }
-  constexpr int CP2 = C / VN;
-  for (int q = tid; q < G::HC * CP2; q += 256) {
-    const int k = q / CP2, c = (q % CP2) * VN;
-    *reinterpret_cast<uint4*>(W2s + k * G::LD2 + c) = *reinterpret_cast<const uint4*>(w2 + (long long)(hc0 + k) * C + c);
+  __device__ __forceinline__ void commit(T* W1s, T* W2s, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int q = tid + i * 256;
+      if (q < C * CP1) {
+        T* d = W1s + (q / CP1) * G::LD1 + (q % CP1) * VN;
+        if constexpr (sizeof(T) == 2) { uint2* d2 = reinterpret_cast<uint2*>(d); d2[0] = make_uint2(r1[i].x, r1[i].y); d2[1] = make_uint2(r1[i].z, r1[i].w); }
+        else *reinterpret_cast<uint4*>(d) = r1[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+      const int q = tid + i * 256;
+      if (q < G::HC * CP2) *reinterpret_cast<uint4*>(W2s + (q / CP2) * G::LD2 + (q % CP2) * VN) = r2[i];
+    }
   }
-}
+};
 
 // rows of this wave as B fragments + LayerNorm statistics.  xa[i][ks]: row (m0 + 16 i + ln), k = ks*KSTEP + LANE_K*g ..
 template <typename T, int C, int RF>
@@ -207,9 +242,9 @@ __device__ __forceinline__ void ln_rows(typename Mma<T>::Frag (&xa)[RF][C / Mma<
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <typename T, int C>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 && C <= 192) ? 2 : 1) void swin_mlp_fwd_kernel(MlpArgs p) {
-  typedef MlpCfg<T, C> G;
+template <typename T, int C, int RFP>
+__global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs p) {
+  typedef MlpCfg<T, C, RFP> G;
   constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP;
   extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];
   T* W1s = reinterpret_cast<T*>(mlp_smem);
@@ -220,6 +255,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && C <= 192) ? 2 : 1) void swi
   const T* w1 = reinterpret_cast<const T*>(p.w1);
   const T* w2 = reinterpret_cast<const T*>(p.w2);
 
+  MlpStage<T, C> stg;
+  stg.issue(w1, w2, 0, tid);                          // first weight chunk in flight under the row loads + LayerNorm
   typename Mma<T>::Frag xa[RF][KS];
   load_rows<T, C, RF>(xa, x, m0, p.M, lane);
   float mu[RF], rs[RF];
@@ -233,8 +270,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && C <= 192) ? 2 : 1) void swi
 
   for (int hc0 = 0; hc0 < 4 * C; hc0 += G::HC) {
     __syncthreads();                                  // previous chunk's fragment reads are done
-    mlp_stage<T, C>(W1s, W2s, w1, w2, hc0, tid);
+    if (!STJ_MLP_PREFETCH && hc0 > 0) stg.issue(w1, w2, hc0, tid);
+    stg.commit(W1s, W2s, tid);
     __syncthreads();
+    if (STJ_MLP_PREFETCH && hc0 + G::HC < 4 * C) stg.issue(w1, w2, hc0 + G::HC, tid);      // next chunk: global loads overlap this chunk's MFMAs
 #pragma unroll 1
     for (int s = 0; s < G::HC / KSTEP; ++s) {
       f32x4 a1[RF][ND];
@@ -293,9 +332,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && C <= 192) ? 2 : 1) void swi
 // =====================================================================================================================
 // backward
 // =====================================================================================================================
-template <typename T, int C>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 && C <= 96) ? 2 : 1) void swin_mlp_bwd_kernel(MlpArgs p) {
-  typedef MlpCfg<T, C> G;
+template <typename T, int C, int RFP>
+__global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs p) {
+  typedef MlpCfg<T, C, RFP> G;
   constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP, LK = Mma<T>::LANE_K;
   extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];
   __shared__ float red[2][C];
@@ -309,6 +348,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && C <= 96) ? 2 : 1) void swin
   const T* w2 = reinterpret_cast<const T*>(p.w2);
   for (int c = tid; c < 2 * C; c += 256) (&red[0][0])[c] = 0.f;
 
+  MlpStage<T, C> stg;
+  stg.issue(w1, w2, 0, tid);
   typename Mma<T>::Frag xa[RF][KS], da[RF][KS];
   load_rows<T, C, RF>(xa, x, m0, p.M, lane);
   load_rows<T, C, RF>(da, dy, m0, p.M, lane);
@@ -348,8 +389,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && C <= 96) ? 2 : 1) void swin
 
   for (int hc0 = 0; hc0 < 4 * C; hc0 += G::HC) {
     __syncthreads();
-    mlp_stage<T, C>(W1s, W2s, w1, w2, hc0, tid);
+    if (!STJ_MLP_PREFETCH && hc0 > 0) stg.issue(w1, w2, hc0, tid);
+    stg.commit(W1s, W2s, tid);
     __syncthreads();
+    if (STJ_MLP_PREFETCH && hc0 + G::HC < 4 * C) stg.issue(w1, w2, hc0 + G::HC, tid);
 #pragma unroll 1
     for (int s = 0; s < G::HC / KSTEP; ++s) {
       f32x4 a1[RF][ND], a3[RF][ND];                    // pre^T and dh^T, [hidden][row]
@@ -465,10 +508,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && C <= 96) ? 2 : 1) void swin
   for (int c = tid; c < C; c += 256) { atomicAdd(p.dgamma + po + c, red[0][c]); atomicAdd(p.dbeta + po + c, red[1][c]); }
 }
 
-template <typename T, int C>
+template <typename T, int C, int RFP>
 static int mlp_launch(bool bwd, const MlpArgs& a, hipStream_t st) {
-  typedef MlpCfg<T, C> G;
-  const void* fn = bwd ? (const void*)swin_mlp_bwd_kernel<T, C> : (const void*)swin_mlp_fwd_kernel<T, C>;
+  typedef MlpCfg<T, C, RFP> G;
+  const void* fn = bwd ? (const void*)swin_mlp_bwd_kernel<T, C, RFP> : (const void*)swin_mlp_fwd_kernel<T, C, RFP>;
   static bool attr[2] = {false, false};
   if (!attr[bwd]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
@@ -477,16 +520,21 @@ static int mlp_launch(bool bwd, const MlpArgs& a, hipStream_t st) {
     attr[bwd] = true;
   }
   dim3 grid((unsigned)((a.M + G::ROWS - 1) / G::ROWS));
-  if (bwd) hipLaunchKernelGGL((swin_mlp_bwd_kernel<T, C>), grid, dim3(256), G::LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((swin_mlp_fwd_kernel<T, C>), grid, dim3(256), G::LDS_BYTES, st, a);
+  if (bwd) hipLaunchKernelGGL((swin_mlp_bwd_kernel<T, C, RFP>), grid, dim3(256), G::LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((swin_mlp_fwd_kernel<T, C, RFP>), grid, dim3(256), G::LDS_BYTES, st, a);
   return stj_check_launch(bwd ? "stj_swin_mlp_bwd" : "stj_swin_mlp_fwd");
 }
 template <typename T>
 static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
+  // rows per block = 64 * RF: two row fragments per wave halve the weight-fragment LDS reads per MFMA, but the grid must still cover
+  // the 256 CUs (32768 rows: 256 blocks of 128; 8192 rows: 128 blocks of 64)
+  static int rf_force = -1;
+  if (rf_force < 0) { const char* e = getenv("STJ_MLP_RF"); rf_force = e ? atoi(e) : 0; }
+  const bool two = rf_force ? rf_force == 2 : a.M >= 256 * 128;
   switch (C) {
-    case 96: return mlp_launch<T, 96>(bwd, a, st);
-    case 192: return mlp_launch<T, 192>(bwd, a, st);
-    case 384: return mlp_launch<T, 384>(bwd, a, st);
+    case 96: return two ? mlp_launch<T, 96, 2>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
+    case 192: return two ? mlp_launch<T, 192, 2>(bwd, a, st) : mlp_launch<T, 192, 1>(bwd, a, st);
+    case 384: return mlp_launch<T, 384, 1>(bwd, a, st);
     default: stj_set_error("swin_mlp: C must be 96, 192 or 384 (got %d)", C); return STJ_EUNSUPPORTED;
   }
 }
@@ -542,7 +590,7 @@ extern "C" int stj_swin_mlp_bwd(const void* x, const void* dy, const float* gamm
 template <typename T, int C> struct AttnCfg {
   static constexpr int KSTEP = Mma<T>::KSTEP;
   static constexpr int KS = C / KSTEP, NF = C / 16, HEADS = C / 32;
-  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? 3 : (C == 192 ? 2 : 1)) : 1;     // heads per pass
+  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? STJ_ATTN_HG96 : (C == 192 ? 2 : 1)) : 1;     // heads per pass
   static constexpr int GC = 32 * HG;                                   // q (= k = v) columns per pass
   static constexpr int LDT = 3 * GC + (sizeof(T) == 2 ? 16 : 8);       // token-major q|k|v tile [64][LDT]
   static constexpr int LDW = 3 * GC + 4;                               // Wqkv slice image [C][LDW] ([k = c][q seg | k seg | v seg])
@@ -560,8 +608,48 @@ struct AttnArgs {
   const long long* rng; int site; float p_drop;
 };
 
+// weight slices of one head group, global -> registers (issued ahead) -> LDS
+template <typename T, int C> struct AttnStage {
+  typedef AttnCfg<T, C> G;
+  static constexpr int VN = Vec<T>::N, GC = G::GC;
+  static constexpr int CPS = GC / VN, CPP = C / VN;
+  static constexpr int NQ = (C * 3 * CPS + 255) / 256, NP = (GC * CPP + 255) / 256;
+  uint4 rq[NQ], rp[NP];
+  __device__ __forceinline__ void issue(const T* wq, const T* wp, int h0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = tid + i * 256;
+      if (q < C * 3 * CPS) {
+        const int k = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
+        rq[i] = *reinterpret_cast<const uint4*>(wq + (long long)k * (3 * C) + seg * C + 32 * h0 + c);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int q = tid + i * 256;
+      if (q < GC * CPP) rp[i] = *reinterpret_cast<const uint4*>(wp + (long long)(32 * h0 + q / CPP) * C + (q % CPP) * VN);
+    }
+  }
+  __device__ __forceinline__ void commit(T* Wqs, T* Wps, int tid) const {
+    auto put = [](T* d, const uint4& v) {
+      if constexpr (sizeof(T) == 2) { uint2* d2 = reinterpret_cast<uint2*>(d); d2[0] = make_uint2(v.x, v.y); d2[1] = make_uint2(v.z, v.w); }
+      else *reinterpret_cast<uint4*>(d) = v;
+    };
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = tid + i * 256;
+      if (q < C * 3 * CPS) { const int k = q / (3 * CPS), r = q % (3 * CPS); put(Wqs + k * G::LDW + (r / CPS) * GC + (r % CPS) * VN, rq[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int q = tid + i * 256;
+      if (q < GC * CPP) put(Wps + (q / CPP) * G::LDP + (q % CPP) * VN, rp[i]);
+    }
+  }
+};
+
 template <typename T, int C>
-__global__ __launch_bounds__(256, 1) void swin_attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnArgs p) {
   typedef AttnCfg<T, C> G;
   constexpr int KS = G::KS, NF = G::NF, HG = G::HG, GC = G::GC, KSTEP = G::KSTEP, ND = Chain<T>::ND, LK = Mma<T>::LANE_K;
   constexpr int VN = Vec<T>::N;
@@ -574,6 +662,10 @@ __global__ __launch_bounds__(256, 1) void swin_attn_fwd_kernel(AttnArgs p) {
   int* lab = tok + 64;                                              // [64] shift-mask region label
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, ln = lane & 15;
+  const T* wq = reinterpret_cast<const T*>(p.wqkv);
+  const T* wp = reinterpret_cast<const T*>(p.wproj);
+  AttnStage<T, C> stg;
+  stg.issue(wq, wp, 0, tid);                         // first head group's weights in flight under the row gather + LayerNorm
   const int nwx = p.res / 8, nW = nwx * nwx;
   const int win = blockIdx.x % nW, b = blockIdx.x / nW;
   const int wy = win / nwx, wx = win % nwx;
@@ -610,32 +702,14 @@ __global__ __launch_bounds__(256, 1) void swin_attn_fwd_kernel(AttnArgs p) {
   f32x4 acco[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) acco[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const T* wq = reinterpret_cast<const T*>(p.wqkv);
-  const T* wp = reinterpret_cast<const T*>(p.wproj);
   const float scale = 0.17677669529663687f;       // 32^-1/2
 
   for (int h0 = 0; h0 < G::HEADS; h0 += HG) {
-    // ---- stage the weight slices of this head group: Wqkv[:, seg*C + 32 h0 .. +GC] for seg = q,k,v; Wproj[32 h0 .. +GC, :]
-    {
-      constexpr int CPS = GC / VN;                   // 16-byte chunks per segment row
-      for (int q = tid; q < C * 3 * CPS; q += 256) {
-        const int k = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
-        const uint4 v = *reinterpret_cast<const uint4*>(wq + (long long)k * (3 * C) + seg * C + 32 * h0 + c);
-        T* d = Wqs + k * G::LDW + seg * GC + c;
-        if constexpr (sizeof(T) == 2) { uint2* d2 = reinterpret_cast<uint2*>(d); d2[0] = make_uint2(v.x, v.y); d2[1] = make_uint2(v.z, v.w); }
-        else *reinterpret_cast<uint4*>(d) = v;
-      }
-      constexpr int CPP = C / VN;
-      for (int q = tid; q < GC * CPP; q += 256) {
-        const int k = q / CPP, c = (q % CPP) * VN;
-        const uint4 v = *reinterpret_cast<const uint4*>(wp + (long long)(32 * h0 + k) * C + c);
-        T* d = Wps + k * G::LDP + c;
-        if constexpr (sizeof(T) == 2) { uint2* d2 = reinterpret_cast<uint2*>(d); d2[0] = make_uint2(v.x, v.y); d2[1] = make_uint2(v.z, v.w); }
-        else *reinterpret_cast<uint4*>(d) = v;
-      }
-      for (int q = tid; q < HG * 225; q += 256) tbl[q] = p.table[(q % 225) * G::HEADS + h0 + q / 225];
-    }
+    // ---- weight slices of this head group (Wqkv[:, seg*C + 32 h0 .. +GC] for seg = q,k,v; Wproj[32 h0 .. +GC, :]): registers -> LDS
+    stg.commit(Wqs, Wps, tid);
+    for (int q = tid; q < HG * 225; q += 256) tbl[q] = p.table[(q % 225) * G::HEADS + h0 + q / 225];
     __syncthreads();
+    if (h0 + HG < G::HEADS) stg.issue(wq, wp, h0 + HG, tid);       // next group's slices fly while this group computes
     // ---- phase 1: q|k|v of this group for the wave's 16 tokens -> tile
 #pragma unroll 1
     for (int f = 0; f < 3 * GC / 16; ++f) {
