@@ -170,7 +170,7 @@ def parity_extras(model, loss_fn, x, B, dev, with_cpu):
         m32.zero_grad()
         out = fwd(m32, x, True)
         d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
-        (d['observed_xe'] + d['occluded_xe'] + d['flow'] + d['flow_warp_xe']).backward()
+        d.total.backward()
     step32()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -298,7 +298,7 @@ def main():
         model.zero_grad()
         out = model(x['ogm'], x['map_img'], training=True, obs=x['obs'], occ=x['occ'], mapt=x['mapt'], flow=x['flow'])
         d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
-        total = d['observed_xe'] + d['occluded_xe'] + d['flow'] + d['flow_warp_xe']
+        total = d.total                      # observed_xe + occluded_xe + flow + flow_warp_xe (train.py:221)
         total.backward()
         if overlap:
             sync.tail()

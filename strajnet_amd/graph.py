@@ -51,10 +51,9 @@ class GraphedTrainStep:
         m.zero_grad()
         out = m(x['ogm'], x['map_img'], training=self.training, obs=x['obs'], occ=x['occ'], mapt=x.get('mapt'), flow=x['flow'])
         d = self.loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
-        total = d['observed_xe'] + d['occluded_xe'] + d['flow'] + d['flow_warp_xe']
+        total = d.total                      # observed_xe + occluded_xe + flow + flow_warp_xe (train.py:221)
         total.backward()
-        return torch.stack([d['observed_xe'].detach(), d['occluded_xe'].detach(), d['flow'].detach(),
-                            d['flow_warp_xe'].detach() if torch.is_tensor(d['flow_warp_xe']) else torch.zeros((), device=out.device)])
+        return d.packed             # [observed_xe, occluded_xe, flow, flow_warp_xe], detached
 
     def load(self, batch):
         """Copy a new batch into the static input tensors (stream-ordered device copies)."""

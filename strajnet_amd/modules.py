@@ -579,20 +579,6 @@ class STrajNet:
     def _zp(self, suffix):
         return self._p('cross_attn_obs0/' + suffix)
 
-    def _zheads_in(self, suffix):
-        """[8] x tfa kernel [H,in,hs] -> contiguous [8, in, H*hs] compute copy + gradient fold."""
-        p0 = self._zp(suffix)
-        H, I, hs = p0.shape
-        off = self._offs['cross_attn_obs0/' + suffix]
-        src = torch.as_strided(self._cflat, (8, H, I, hs), (self._zstride, I * hs, hs, 1), off)
-        wz = src.permute(0, 2, 1, 3).reshape(8, I, H * hs).contiguous()
-        gwz = ops.zeros_f32((8, I, H * hs), self.device)
-        gdst = torch.as_strided(self._gflat, (8, H, I, hs), (self._zstride, I * hs, hs, 1), off)
-
-        def fold():
-            gdst.add_(gwz.view(8, I, H, hs).permute(0, 2, 1, 3))
-        return p0, wz, gwz, fold
-
     def _cross_attention_z(self, query, key, tmask):
         """8 x Cross_AttentionT (trajNet.py:224-234) + query residual in one batched pass, waypoint-major:
         query [8,B,HW,Cb], key [B,64,Cb] -> [8,B,HW,Cb]."""
@@ -601,10 +587,9 @@ class STrajNet:
         hs = 128 // 3
         A = key.shape[1]
 
-        def proj_in(x, suffix, shared):
-            p0, wz, gwz, fold = self._zheads_in(suffix)
-            return ops.linear_z(x, p0.master, wz[0], wz.shape[1] * wz.shape[2], None, 0, gwz[0], wz.shape[1] * wz.shape[2], None, 8,
-                                shared_x=shared, fold=fold)
+        def proj_in(x, suffix, shared):           # tfa kernels [3, 384, 42] of the 8 sets, addressed in place (set stride zs)
+            p0 = self._zp(suffix)
+            return ops.linear_heads_in_z(x, p0.master, p0.c, p0.grad, zs, 8, shared)
         q = proj_in(query, 'mha/query_kernel', False)                    # [8, B*HW, 126]
         k = proj_in(key, 'mha/key_kernel', True)                         # [8, B*64, 126]
         v = proj_in(key, 'mha/value_kernel', True)

@@ -320,14 +320,59 @@ def linear(x, pw, pb=None, act=ACT_NONE, res=None):
                          pb.grad if pb is not None else None, act, res, None)
 
 
+class _HeadsIn(torch.autograd.Function):
+    """tfa-MHA query / key / value projection for Z weight sets at once: y[z, r, h*hs + o] = sum_i x[(z|shared), r, i] W[z][h, i, o].
+    The kernels [H, in, hs] are read and their gradients written IN PLACE in the flat buffers: every product is a batched GEMM over
+    (z, h) with the head as a batch stride (no permuted weight copy per step, no gradient fold afterwards)."""
+    @staticmethod
+    def forward(ctx, x, trig, w0, gw0, zstride, Z, shared_x):
+        _req_cuda(x)
+        H, I, hs = w0.shape
+        x = x.contiguous()
+        R = x.numel() // I if shared_x else x.numel() // (I * Z)
+        dt = _dt(x)
+        y = torch.empty((Z, R, H * hs), dtype=x.dtype, device=x.device)
+        gemm(x, w0, y, R, hs, I, (0 if shared_x else R * I, 0, I, 1), (zstride, I * hs, hs, 1), (R * H * hs, hs, H * hs), dt, nb=(Z, H))
+        ctx.dims = (Z, R, H, I, hs, zstride, shared_x, x.shape)
+        ctx.w0, ctx.gw0 = w0, gw0
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        Z, R, H, I, hs, zstride, shared_x, xshape = ctx.dims
+        dt = _dt(x)
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dx[z] = sum_h dy[z][:, h-slice] W[z,h]^T : the head sum is the K-segment loop of ONE GEMM per z
+            if shared_x:
+                acc = zeros_f32((R, I), x.device)         # the Z sets accumulate with f32 atomics
+                gemm(dy, ctx.w0, acc, R, I, hs, (R * H * hs, 0, H * hs, 1), (zstride, 0, 1, hs), (0, 0, I), dt, nb=(Z, 1), c_f32=1,
+                     accumulate=1, kseg=(H, hs, I * hs))
+                dx = torch.empty(xshape, dtype=x.dtype, device=x.device)
+                call('stj_cast', _p(acc), 0, _p(dx), dt, R * I, _st())
+            else:
+                dx = torch.empty(xshape, dtype=x.dtype, device=x.device)
+                gemm(dy, ctx.w0, dx, R, I, hs, (R * H * hs, 0, H * hs, 1), (zstride, 0, 1, hs), (R * I, 0, I), dt, nb=(Z, 1),
+                     kseg=(H, hs, I * hs))
+        with wgrad_stream(1, x, dy):      # dW[z,h] += x_z^T dy_z[:, h-slice], straight into the flat gradient buffer
+            gemm(x, dy, ctx.gw0, I, hs, R, (0 if shared_x else R * I, 0, 1, I), (R * H * hs, hs, H * hs, 1), (zstride, I * hs, hs), dt,
+                 nb=(Z, H), c_f32=1, accumulate=1, splitk=0)
+        return (dx,) + (None,) * 6
+
+
 def linear_heads_in(x, pw):
     """tfa-MHA query/key/value kernel [H, in, hs]: y[..., h*hs+o] = sum_i x[..., i] W[h,i,o] (no bias)."""
     H, I, hs = pw.c.shape
-    wc = pw.c.permute(1, 0, 2).reshape(I, H * hs)
+    y = _HeadsIn.apply(x, pw.master, pw.c, pw.grad, 0, 1, False)
+    return y.view(x.shape[:-1] + (H * hs,))
 
-    def fold(g):
-        pw.grad.add_(g.view(I, H, hs).permute(1, 0, 2))
-    return _Linear.apply(x, pw.master, wc, None, None, None, ACT_NONE, None, fold)
+
+def linear_heads_in_z(x, trig, w0, gw0, zstride, Z, shared_x):
+    """the same for Z weight sets lying zstride elements apart in the flat buffers; x [Z,R,in] or shared [R,in] -> [Z,R,H*hs]."""
+    return _HeadsIn.apply(x, trig, w0, gw0, zstride, Z, shared_x)
 
 
 def linear_heads_out(x, pw, pb):
@@ -1054,6 +1099,8 @@ def outconv_pair(xo, xf, p1w, p1b, p2w, p2b, B, Tn, t_major=False, x_is_elu_out=
 # loss
 # ----------------------------------------------------------------------------------------------------
 class _OgmFlowLoss(torch.autograd.Function):
+    """-> (observed_xe, occluded_xe, flow, flow_warp_xe, total): five 0-dim tensors.  `total` (their sum, train.py:221) is an output
+    of its own so that a step which only differentiates the sum runs no select / add / zeros glue around the two loss kernels."""
     @staticmethod
     def forward(ctx, logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, flags):
         _req_cuda(logits)
@@ -1067,13 +1114,21 @@ class _OgmFlowLoss(torch.autograd.Function):
              B, H, W, float(ogm_w), float(occ_w), float(fow), float(replica), int(flags), _st())
         ctx.geo = (B, H, W, int(flags))
         ctx.save_for_backward(logits, gt_obs, gt_occ, gt_flow, origin, coef)
-        return loss
+        ctx.mark_non_differentiable(loss)
+        return tuple(loss.unbind(0)) + (loss.sum(), loss)
 
     @staticmethod
-    def backward(ctx, dloss):
+    def backward(ctx, g0, g1, g2, g3, gt, _gvec):
         logits, gt_obs, gt_occ, gt_flow, origin, coef = ctx.saved_tensors
         B, H, W, flags = ctx.geo
-        up = dloss.contiguous().float()
+        parts = (g0, g1, g2, g3)
+        if all(g is None for g in parts):
+            up = gt.float().expand(4).contiguous()
+        else:
+            z = torch.zeros((), dtype=torch.float32, device=logits.device)
+            up = torch.stack([(g.float() if g is not None else z) for g in parts])
+            if gt is not None:
+                up = up + gt.float()
         dlogits = torch.empty_like(logits)
         call('stj_loss_bwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(coef), _p(up), _p(dlogits), B, H, W,
              flags, _st())
