@@ -181,14 +181,213 @@ static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y,
   return true;
 }
 
+// =====================================================================================================
+// Wave-specialised variant of the forward kernel (round 2).  rocprof PMC on the kernel above: MFMA busy 22 %, HBM 27 %, one wave
+// per SIMD -- the phases of a tile (prefetch issue, MFMA + LDS fragment reads, ELU epilogue, LDS commit of the next halo, barrier,
+// coalesced store loop, barrier) add up serially inside each wave because nothing else is resident on the SIMD to overlap them.
+// Here a workgroup has EIGHT waves with two roles:
+//   * waves 0-3 ("compute"): own one output phase each, tap matrices stationary in VGPRs, do nothing but ds_read fragments ->
+//     MFMA -> bias + ELU -> 8-byte writes into a small output stage;
+//   * waves 4-7 ("movers"): never touch the matrix pipe: they drain the output stage of the PREVIOUS step to global memory
+//     (16-byte coalesced stores), and fetch the next tile's halo (global -> registers at the tile's first step, registers -> LDS at
+//     its last one).
+// A "step" is two low-res rows of a tile (= 4 output rows); the output stage is double buffered at step granularity (2 x 14 KB
+// instead of one 57 KB tile stage), the halo at tile granularity; one workgroup barrier per step.  Both roles run on every SIMD (one
+// compute + one mover wave each), so global traffic, LDS staging and the epilogue's VALU work overlap the MFMAs of the other role.
+// =====================================================================================================
+template <typename T, int KS, int NF>
+__global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
+                                                             const float* __restrict__ bias, T* __restrict__ Y,
+                                                             int F, int Hi, int Wi, int Cout, int ntiles, int dbg) {
+  constexpr int CIN = KS * 32;
+  constexpr int LDK = CIN + 16;
+  constexpr int CT = NF * 16;
+  constexpr int LDO = CT + 8;
+  constexpr int HPIX = WS_HH * WS_HW;
+  constexpr int CPP = CIN / 8;
+  constexpr int NCH = (HPIX * CPP + 255) / 256;          // halo chunks per mover thread
+  constexpr int SR = 4;                                  // low-res rows per step
+  constexpr int OST = 2 * SR * (2 * WS_TW) * LDO;        // one output-stage buffer: 2*SR output rows x 32 pixels
+  constexpr int STEPS = WS_TH / SR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* halo0 = reinterpret_cast<T*>(smem_raw);
+  T* halo1 = halo0 + HPIX * LDK;
+  T* ost0 = halo1 + HPIX * LDK;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool mover = w >= 4;
+  const int mt = tid - 256;                              // mover thread index 0..255
+  const int g = lane >> 4, ln = lane & 15;
+  const int n0 = blockIdx.y * CT;
+  const int tiles_x = (Wi + WS_TW - 1) / WS_TW, tiles_y = (Hi + WS_TH - 1) / WS_TH;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  auto tile_coords = [&](int tile, int& f, int& ty0, int& tx0) {
+    const int tx = tile % tiles_x; const int t2 = tile / tiles_x;
+    ty0 = (t2 % tiles_y) * WS_TH; f = t2 / tiles_y; tx0 = tx * WS_TW;
+  };
+
+  if (!mover) {
+    // ------------------------------------------------------------------ compute role
+    const int a = w >> 1, b = w & 1;
+    s16x8 wf[4][NF][KS];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pt = a * 8 + b * 4 + t;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int co = n0 + n * 16 + ln;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (co < Cout) wf[t][n][ks] = *reinterpret_cast<const s16x8*>(Wf + ((long long)pt * Cout + co) * CIN + ks * 32 + g * 8);
+          else wf[t][n][ks] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
+    }
+    float bv[NF][4];
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = n0 + n * 16 + g * 4 + r;
+        bv[n][r] = co < Cout ? bias[co] : 0.f;
+      }
+    __syncthreads();                                     // halo of the first tile committed by the movers
+    int q = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const T* halo = ((tile - blockIdx.x) / gridDim.x) & 1 ? halo1 : halo0;
+#pragma unroll 1
+      for (int st = 0; st < STEPS; ++st, ++q) {
+        const int mf = SR * st;
+        T* ost = ost0 + (q & 1) * OST;
+        f32x4 acc[SR][NF];
+#pragma unroll
+        for (int m = 0; m < SR; ++m)
+#pragma unroll
+          for (int n = 0; n < NF; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // a halo row feeds tap row r = 0 of output row j and tap row r = 1 of output row j - 1: SR + 1 fragment reads per (s, ks)
+        // serve 2 SR row-taps (the tile-at-a-time kernel reads each twice) -- the B-fragment LDS traffic is what bounds this kernel
+        if (!(dbg & 1))
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j <= SR; ++j) {
+              const s16x8 xb = *reinterpret_cast<const s16x8*>(halo + ((mf + j + a) * WS_HW + ln + b + s2) * LDK + ks * 32 + g * 8);
+              if (j < SR) {
+#pragma unroll
+                for (int n = 0; n < NF; ++n) acc[j][n] = Mma<T>::mma(wf[s2][n][ks], xb, acc[j][n]);
+              }
+              if (j > 0) {
+#pragma unroll
+                for (int n = 0; n < NF; ++n) acc[j - 1][n] = Mma<T>::mma(wf[2 + s2][n][ks], xb, acc[j - 1][n]);
+              }
+            }
+        if (!(dbg & 2))
+#pragma unroll
+        for (int m = 0; m < SR; ++m)
+#pragma unroll
+          for (int n = 0; n < NF; ++n) {
+            const uint32_t p0 = pack2<T>(elu_bf(acc[m][n][0] + bv[n][0]), elu_bf(acc[m][n][1] + bv[n][1]));
+            const uint32_t p1 = pack2<T>(elu_bf(acc[m][n][2] + bv[n][2]), elu_bf(acc[m][n][3] + bv[n][3]));
+            *reinterpret_cast<uint2*>(ost + ((2 * m + a) * (2 * WS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
+          }
+        __syncthreads();                                 // step q's stage is complete; the movers drain it during step q + 1
+      }
+    }
+    __syncthreads();                                     // matches the movers' final drain barrier
+  } else {
+    // ------------------------------------------------------------------ mover role
+    uint4 pre[NCH];
+    auto prefetch = [&](int tile) {
+      int f, ty0, tx0;
+      tile_coords(tile, f, ty0, tx0);
+      const T* Xf = X + (long long)f * Hi * Wi * CIN;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = mt + i * 256;
+        const int px = c / CPP, ch = (c % CPP) * 8;
+        const int gy = ty0 + px / WS_HW - 1, gx = tx0 + px % WS_HW - 1;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < HPIX * CPP && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
+          v = *reinterpret_cast<const uint4*>(Xf + ((long long)gy * Wi + gx) * CIN + ch);
+        pre[i] = v;
+      }
+    };
+    auto commit = [&](T* halo) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = mt + i * 256;
+        if (c < HPIX * CPP) *reinterpret_cast<uint4*>(halo + (c / CPP) * LDK + (c % CPP) * 8) = pre[i];
+      }
+    };
+    constexpr int SEG = CT / 8;
+    auto drain = [&](const T* ost, int f, int ty0, int tx0, int st) {
+      T* Yf = Y + (long long)f * Ho * Wo * Cout;
+      for (int c = mt; c < 2 * SR * 2 * WS_TW * SEG; c += 256) {
+        const int sg = c % SEG, p = c / SEG;
+        const int hr = p / (2 * WS_TW), hc = p % (2 * WS_TW);
+        const int oy = 2 * ty0 + 2 * SR * st + hr, ox = 2 * tx0 + hc, co = n0 + sg * 8;
+        if (oy < Ho && ox < Wo && co < Cout)
+          *reinterpret_cast<uint4*>(Yf + ((long long)oy * Wo + ox) * Cout + co) = *reinterpret_cast<const uint4*>(ost + p * LDO + sg * 8);
+      }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) { prefetch(tile); commit(halo0); }
+    __syncthreads();
+    int q = 0, pf = 0, pty = 0, ptx = 0, pst = 0;       // coordinates of the step whose stage is drained next
+    bool have = false;
+    for (; tile < ntiles; tile += gridDim.x) {
+      const int nbuf = (((tile - blockIdx.x) / gridDim.x) & 1) ^ 1;
+      const int next = tile + gridDim.x;
+      int f, ty0, tx0;
+      tile_coords(tile, f, ty0, tx0);
+#pragma unroll 1
+      for (int st = 0; st < STEPS; ++st, ++q) {
+        if (st == 0 && next < ntiles && !(dbg & 8)) prefetch(next);    // loads fly for the whole tile
+        if (have && !(dbg & 4)) drain(ost0 + ((q - 1) & 1) * OST, pf, pty, ptx, pst);
+        if (st == STEPS - 1 && next < ntiles && !(dbg & 8)) commit(nbuf ? halo1 : halo0);
+        pf = f; pty = ty0; ptx = tx0; pst = st; have = true;
+        __syncthreads();
+      }
+    }
+    if (have) drain(ost0 + ((q - 1) & 1) * OST, pf, pty, ptx, pst);
+    __syncthreads();
+  }
+}
+
+template <typename T, int KS, int NF>
+static bool ws2_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, hipStream_t st) {
+  constexpr int CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 8;
+  const size_t lds = (size_t)(2 * WS_HH * WS_HW * LDK + 2 * 8 * 2 * WS_TW * LDO) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)upconv_fwd_ws2_kernel<T, KS, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    attr_set = true;
+  }
+  const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
+  const int ct = (Cout + CT - 1) / CT;
+  int nblk = 256 / ct;
+  if (nblk > ntiles) nblk = ntiles;
+  if (nblk < 1) nblk = 1;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("STJ_WS2_DBG"); dbg = e ? atoi(e) : 0; }      // ablation switches (profiling only)
+  hipLaunchKernelGGL((upconv_fwd_ws2_kernel<T, KS, NF>), dim3(nblk, ct), dim3(512), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y, F, Hi, Wi, Cout, ntiles, dbg);
+  return true;
+}
+
 // returns true when the weight-stationary kernel handles this shape (bf16 / fp16, Cin in {96,128}, Cout multiple of 8)
 template <typename T>
 static bool upconv_fwd_ws_try_t(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        hipStream_t st) {
   if (Cout % 8 || act != ACT_ELU) return false;
   static int variant = -1;
-  if (variant < 0) { const char* e = getenv("STJ_WS_VARIANT"); variant = e ? atoi(e) : 1; }
+  if (variant < 0) { const char* e = getenv("STJ_WS_VARIANT"); variant = e ? atoi(e) : 3; }
   // Cin=96: the 2-waves-per-SIMD variant spills (144 weight VGPRs + prefetch); one wave per SIMD measured faster (386 vs 432 us)
+  if (variant == 3 || variant == 4) {      // wave-specialised kernel (compute + mover waves)
+    if (Cin == 96) return ws2_launch<T, 3, 3>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
+    if (Cin == 128 && variant == 4) return ws2_launch<T, 4, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
+  }
   if (Cin == 96) return variant == 2 ? ws_launch<T, 3, 3, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st) : ws_launch<T, 3, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
   if (Cin == 128) return variant == 0 ? ws_launch<T, 4, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st) : ws_launch<T, 4, 2, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
   return false;
