@@ -1056,6 +1056,241 @@ static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const voi
                      (const bf16*)Xelu, F, Hi, Wi, Cin, ntiles);
   return true;
 }
+// =====================================================================================================
+// Wave-specialised input gradient for the 96 <- 48 layer (round 2; the largest kernel of the step: 2 x 373 us before).
+// Same decomposition as upconv_dgrad_ws_kernel (a wave per INPUT phase, tap matrices stationary, partial tiles summed through LDS),
+// re-organised like upconv_fwd_ws2_kernel:
+//   * waves 0-3 compute: ds_read fragments -> MFMA -> partial tile (bf16) into a step-granular, double-buffered LDS stage.  K = Cout =
+//     48 is one 16x16x32 + one 16x16x16 MFMA (no zero padding to 64: 144 weight VGPRs instead of 192, which is what lets two waves
+//     share a SIMD);
+//   * waves 4-7 move data: sum the 4 phase partials of the PREVIOUS step, apply ELU'(x) of the layer input, store 16-byte segments;
+//     and keep the dP halo rolling: the 18 x 34 halo tile is ONE buffer whose rows are overwritten with the next tile's rows as soon
+//     as the current tile's steps are done with them (step s reads hi-res rows 4s .. 4s+5), fetched one step ahead in 4-5 registers.
+// One workgroup barrier per step (2 low-res rows).
+// =====================================================================================================
+typedef __attribute__((ext_vector_type(4))) short ws_bf16x4;
+template <bool ELU>
+__global__ __launch_bounds__(512, 1) void upconv_dgrad_ws2_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ Wd,
+                                                                  bf16* __restrict__ dX, const bf16* __restrict__ Xelu, int F, int Hi,
+                                                                  int Wi, int ntiles, int dbg) {
+  constexpr int Cout = 48, Cin = 96, NFI = 6;
+  constexpr int LDK = 48 + 8;                      // halo pixel: 48 channels + 8 pad = 7 16-byte slots (odd: conflict-free stride-2 reads)
+  constexpr int HH = 2 * WS_TH + 2, HW = 2 * WS_TW + 2, HPIX = HH * HW;
+  constexpr int LDR = Cin + 8;                     // partial-tile pixel stride (bf16)
+  constexpr int RED = 4 * 2 * 16 * LDR;            // one stage buffer: [4 phases][2 rows][16 px][LDR]
+  constexpr int CPP = Cout / 8;                    // 16-byte chunks per halo pixel
+  constexpr int STEPS = WS_TH / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16* halo = reinterpret_cast<bf16*>(smem_raw);
+  bf16* red0 = halo + HPIX * LDK;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool mover = w >= 4;
+  const int mt = tid - 256;
+  const int g = lane >> 4, ln = lane & 15;
+  const int tiles_x = (Wi + WS_TW - 1) / WS_TW, tiles_y = (Hi + WS_TH - 1) / WS_TH;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  auto tile_coords = [&](int tile, int& f, int& ty0, int& tx0) {
+    const int tx = tile % tiles_x; const int t2 = tile / tiles_x;
+    ty0 = (t2 % tiles_y) * WS_TH; f = t2 / tiles_y; tx0 = tx * WS_TW;
+  };
+
+  if (!mover) {
+    const int a = w >> 1, b = w & 1;
+    // stationary weights: A[m = cin][k = cout] = Wd[(u+1)*4 + (v+1)][cin][cout], k 0..31 (16x16x32) and 32..47 (16x16x16)
+    s16x8 w32[4][NFI];
+    ws_bf16x4 w16[4][NFI];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = t >> 1, s2 = t & 1;
+      const int uv = (2 - a - 2 * r + 1) * 4 + (2 - b - 2 * s2 + 1);
+#pragma unroll
+      for (int n = 0; n < NFI; ++n) {
+        const bf16* wp = Wd + ((long long)uv * Cin + n * 16 + ln) * Cout;
+        w32[t][n] = *reinterpret_cast<const s16x8*>(wp + g * 8);
+        w16[t][n] = *reinterpret_cast<const ws_bf16x4*>(wp + 32 + g * 4);
+      }
+    }
+    __syncthreads();                                   // first halo committed
+    int q = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll 1
+      for (int st = 0; st < STEPS; ++st, ++q) {
+        const int mf = 2 * st;
+        bf16* red = red0 + (q & 1) * RED;
+        f32x4 acc[2][NFI];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NFI; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!(dbg & 1))
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int u1 = 2 - a - 2 * r + 1, v1 = 2 - b - 2 * s2 + 1;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              const bf16* hp = halo + ((2 * (mf + m) + u1) * HW + 2 * ln + v1) * LDK;
+              const s16x8 x32 = *reinterpret_cast<const s16x8*>(hp + g * 8);
+              const ws_bf16x4 x16 = *reinterpret_cast<const ws_bf16x4*>(hp + 32 + g * 4);
+#pragma unroll
+              for (int n = 0; n < NFI; ++n)      // the six 32-deep MFMAs, then the six 16-deep ones: no back-to-back dependent pair
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w32[r * 2 + s2][n]), __builtin_bit_cast(bf16x8_t, x32), acc[m][n], 0, 0, 0);
+#pragma unroll
+              for (int n = 0; n < NFI; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w16[r * 2 + s2][n], x16, acc[m][n], 0, 0, 0);
+            }
+          }
+        if (!(dbg & 2))
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NFI; ++n)
+            *reinterpret_cast<uint2*>(red + ((w * 2 + m) * 16 + ln) * LDR + n * 16 + g * 4) =
+                make_uint2(pack2bf(acc[m][n][0], acc[m][n][1]), pack2bf(acc[m][n][2], acc[m][n][3]));
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+  } else {
+    // ------------------------------------------------------------------ mover role
+    // halo row groups: j = 0..2 -> rows 4j .. 4j+3 ; j = 3 -> rows 12 .. 17
+    constexpr int NPF = (6 * HW * CPP + 255) / 256;      // chunks per thread of the largest group
+    // Group n of the block's stream (n = 4 * local tile + j; j = 0..2 -> halo rows 4j .. 4j+3, j = 3 -> rows 12 .. 17) is committed at
+    // step n - 3 -- step s of a tile reads rows 4s .. 4s+5, so the rows are dead for the current tile by then -- and FETCHED two steps
+    // before that, into one of two register sets (n & 1): 2 x 20 KB of loads in flight per CU.  (One step of lookahead left the movers
+    // latency-bound: movers alone 205 us against 147 us for the compute waves alone; two steps: 161 us.  Measured and rejected: the two
+    // duties on separate wave pairs (250 vs 228 us), and an LDS-DMA roller -- global_load_lds_dwordx4 straight into the halo rows, counted
+    // vmcnt, raw s_barrier: correct, but a group can only be ISSUED once its rows are dead, which leaves ~1 group in flight: 315 us.)
+    uint4 preA[NPF], preB[NPF];
+    auto grp_rows = [](int j, int& r0, int& nr) { r0 = 4 * j; nr = j == 3 ? 6 : 4; };
+    auto grp_tile = [&](int n) { return blockIdx.x + (n >> 2) * (int)gridDim.x; };
+    auto prefetch = [&](uint4 (&pre)[NPF], int n) {
+      const int tile = grp_tile(n);
+      if (tile >= ntiles) return;
+      int f, ty0, tx0, r0, nr;
+      tile_coords(tile, f, ty0, tx0);
+      grp_rows(n & 3, r0, nr);
+      const bf16* Pf = dP + (long long)f * Ho * Wo * Cout;
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) {
+        const int c = mt + i * 256;
+        const int px = c / CPP, ch = (c % CPP) * 8;
+        const int gy = 2 * ty0 + r0 + px / HW - 1, gx = 2 * tx0 + px % HW - 1;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < nr * HW * CPP && gy >= 0 && gy < Ho && gx >= 0 && gx < Wo) v = *reinterpret_cast<const uint4*>(Pf + ((long long)gy * Wo + gx) * Cout + ch);
+        pre[i] = v;
+      }
+    };
+    auto commit = [&](const uint4 (&pre)[NPF], int n) {
+      if (grp_tile(n) >= ntiles) return;
+      int r0, nr;
+      grp_rows(n & 3, r0, nr);
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) {
+        const int c = mt + i * 256;
+        if (c < nr * HW * CPP) *reinterpret_cast<uint4*>(halo + (r0 * HW + c / CPP) * LDK + (c % CPP) * 8) = pre[i];
+      }
+    };
+    constexpr int NIT = 2 * 16 * (Cin / 8);              // 8-channel items of one step
+    constexpr int NEP = (NIT + 255) / 256;
+    // ELU' operand (the layer input x) of step q's pixels: fetched during step q, used when step q's partials are summed (step q + 1)
+    uint4 xin[ELU ? NEP : 1];
+    auto fetch_x = [&](int f, int ty0, int tx0, int st) {
+      if constexpr (ELU) {
+#pragma unroll
+        for (int i = 0; i < NEP; ++i) {
+          const int c = mt + i * 256;
+          const int c8 = (c % (Cin / 8)) * 8, pp = c / (Cin / 8);
+          const int oy = ty0 + 2 * st + (pp >> 4), ox = tx0 + (pp & 15);
+          xin[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+          if (c < NIT && oy < Hi && ox < Wi) xin[i] = *reinterpret_cast<const uint4*>(Xelu + ((long long)f * Hi * Wi + (long long)oy * Wi + ox) * Cin + c8);
+        }
+      }
+    };
+    auto reduce = [&](const bf16* red, int f, int ty0, int tx0, int st) {
+      bf16* Xf = dX + (long long)f * Hi * Wi * Cin;
+#pragma unroll
+      for (int i = 0; i < NEP; ++i) {
+        const int c = mt + i * 256;
+        if (c >= NIT) break;
+        const int c8 = (c % (Cin / 8)) * 8, pp = c / (Cin / 8);
+        const int m = pp >> 4, px = pp & 15;
+        const int oy = ty0 + 2 * st + m, ox = tx0 + px;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+          float t[8];
+          ld16<bf16>(red + ((ww * 2 + m) * 16 + px) * LDR + c8, t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        if (oy < Hi && ox < Wi) {
+          if constexpr (ELU) {
+            const uint32_t xw[4] = {xin[i].x, xin[i].y, xin[i].z, xin[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
+              v[2 * e] *= x0 > 0.f ? 1.f : x0 + 1.f;
+              v[2 * e + 1] *= x1 > 0.f ? 1.f : x1 + 1.f;
+            }
+          }
+          *reinterpret_cast<uint4*>(Xf + ((long long)oy * Wi + ox) * Cin + c8) =
+              make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        }
+      }
+    };
+    // first tile of the block: whole halo, synchronously; then the first group of the second tile goes in flight
+    int tile = blockIdx.x;
+    if (tile < ntiles)
+      for (int j = 0; j < 4; ++j) { prefetch(preA, j); commit(preA, j); }
+    prefetch(preA, 4);
+    __syncthreads();
+    int q = 0, pf = 0, pty = 0, ptx = 0, pst = 0;
+    bool have = false;
+    // one mover step: roll the halo, sum + store the previous step's partials (its x operand was fetched last step)
+    auto step = [&](uint4 (&pre)[NPF], int f, int ty0, int tx0, int st) {
+      if (q >= 1) commit(pre, q + 3);                    // rows dead for the current tile from this step on
+      if (!(dbg & 8)) prefetch(pre, q + 5);
+      if (have && !(dbg & 4)) reduce(red0 + ((q - 1) & 1) * RED, pf, pty, ptx, pst);
+      fetch_x(f, ty0, tx0, st);
+      pf = f; pty = ty0; ptx = tx0; pst = st; have = true;
+      ++q;
+      __syncthreads();
+    };
+    for (; tile < ntiles; tile += gridDim.x) {
+      int f, ty0, tx0;
+      tile_coords(tile, f, ty0, tx0);
+      // group n lives in register set n & 1; step q handles groups q + 3 (commit) and q + 5 (fetch): set B on even q, set A on odd q
+      step(preB, f, ty0, tx0, 0);
+      step(preA, f, ty0, tx0, 1);
+      step(preB, f, ty0, tx0, 2);
+      step(preA, f, ty0, tx0, 3);
+    }
+    if (have) reduce(red0 + ((q - 1) & 1) * RED, pf, pty, ptx, pst);
+    __syncthreads();
+  }
+}
+
+template <bool ELU>
+static bool dgrad_ws2_launch(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, hipStream_t st) {
+  constexpr int LDK = 56, HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), LDR = 104;
+  const size_t lds = (size_t)(HPIX * LDK + 2 * 4 * 2 * 16 * LDR) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)upconv_dgrad_ws2_kernel<ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    attr_set = true;
+  }
+  const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
+  const int nblk = ntiles < 256 ? ntiles : 256;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("STJ_WS2_DBG"); dbg = e ? atoi(e) : 0; }      // ablation switches (profiling only)
+  hipLaunchKernelGGL((upconv_dgrad_ws2_kernel<ELU>), dim3(nblk), dim3(512), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX, (const bf16*)Xelu, F, Hi, Wi, ntiles, dbg);
+  return true;
+}
+
 template <int KS, int NFI, int COUT>
 static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   return Xelu ? dgrad_ws_launch2<KS, NFI, true, COUT>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st)
@@ -1063,6 +1298,10 @@ static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, const void
 }
 bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   if (Cout % 8 || Cin % 8) return false;
+  static int v2 = -1;
+  if (v2 < 0) { const char* e = getenv("STJ_DGRAD_WS2"); v2 = e ? atoi(e) : 1; }
+  if (Cout == 48 && Cin == 96 && v2)
+    return Xelu ? dgrad_ws2_launch<true>(dP, Wd, dX, Xelu, F, Hi, Wi, st) : dgrad_ws2_launch<false>(dP, Wd, dX, Xelu, F, Hi, Wi, st);
   if (Cout == 48 && Cin == 96) return dgrad_ws_launch<2, 6, 48>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
   if (Cout == 96 && Cin == 128) return dgrad_ws_launch<3, 4, 96>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
   return false;
