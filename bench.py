@@ -329,6 +329,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get('STJ_BENCH_CALIB') == '1':        # PMC passes (tools/pmc_step.sh): a copy of known size calibrates FETCH_SIZE / WRITE_SIZE
+        cal = torch.empty(128 * 1024 * 1024, dtype=torch.bfloat16, device=dev).normal_()
+        torch.empty_like(cal).copy_(cal)
+        del cal
     for _ in range(args.warmup):
         step()
     barrier()

@@ -272,6 +272,7 @@ class STrajNet:
         self._parts_split = P * sum(int(np.prod(spec[n][0])) for n in names if n.startswith(enc))
         self.cut_encoder = False         # True: autograd is cut at the encoder outputs (backward() stops there; backward_encoder() finishes)
         self._cut_src = self._cut_leaf = None
+        self._upconv_prep = {}
         self._sync_compute_weights()
 
     # ------------------------------------------------------------------ weights
@@ -616,7 +617,8 @@ class STrajNet:
         flow_res, r0, r1 = res_list[0], res_list[1], res_list[2]
 
         def up(t, name, grad_is_pre=False, x_is_elu_out=False):
-            return ops.upconv(t, self._p(name + '/kernel'), self._p(name + '/bias'), grad_is_pre, x_is_elu_out)
+            return ops.upconv(t, self._p(name + '/kernel'), self._p(name + '/bias'), grad_is_pre, x_is_elu_out,
+                              prep=self._upconv_prep.get(name))
         x = x.view(8 * B, hb, hb, -1)                                                # frames are TIME-major: f = t*B + b
         x = up(x, 'decoder/upconv_3_0')                                              # [F,2hb,2hb,192]
         if skips is not None:                                                        # computed on the side stream: join
@@ -679,6 +681,12 @@ class STrajNet:
             self._dctx = self.dropctx
         ogm, map_img, flow = ogm.float().contiguous(), map_img.float().contiguous(), flow.float().contiguous()
         hb, Cb = self.hb, self.stage_dim[2]
+        # fold the six decoder kernels into their 2x2-tap phase matrices NOW (they depend on the weights only): as the first launches of
+        # the step they run on an idle GPU; issued where they are consumed, each of these tiny launches sat on the critical path of a
+        # decoder branch behind whatever shared the GPU with it (up to 0.8 ms apiece in the batch-32 inference trace)
+        self._upconv_prep = {n: ops.upconv_prep(self._p(n + '/kernel'), self.dtype)
+                             for n in ('decoder/upconv_3_0', 'decoder/upconv_2_0', 'decoder/upconv_1_0', 'decoder/upconv_0_0',
+                                       'decoder/upconvf_1_0', 'decoder/upconvf_0_0')}
         # The agent branch (trajNet: ~45 small launches that occupy a few CUs each) is independent of the raster encoder up to the
         # cross-attention: it is forked onto a side stream here and joined there, so it overlaps with the Swin stages; autograd
         # replays the fork / join in backward and a hipGraph capture records both branches.

@@ -996,15 +996,16 @@ _DB_PARTS = 32
 
 class _UpConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_master, b_master, pw, pb, grad_is_pre, x_is_elu_out):
+    def forward(ctx, x, w_master, b_master, pw, pb, grad_is_pre, x_is_elu_out, prep):
         _req_cuda(x)
         x = x.contiguous()
         F_, Hi, Wi, Cin = x.shape
         Cout = pw.master.shape[-1]
         dt = _dt(x)
-        wf = torch.empty((16, Cout, Cin), dtype=x.dtype, device=x.device)
-        wd = torch.empty((16, Cin, Cout), dtype=x.dtype, device=x.device)
-        call('stj_upconv_prep', _p(pw.master), _p(wf), _p(wd), Cin, Cout, dt, _st())
+        if prep is not None:         # folded tap matrices made ahead of time (the model folds all decoder weights at the start of a step)
+            wf, wd = prep
+        else:
+            wf, wd = upconv_prep(pw, x.dtype)
         y = torch.empty((F_, 2 * Hi, 2 * Wi, Cout), dtype=x.dtype, device=x.device)
         call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
         ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
@@ -1038,15 +1039,25 @@ class _UpConv(torch.autograd.Function):
             call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
             if own:
                 pb.grad.add_(dbp.view(nparts, Cout).sum(0))
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
-def upconv(x, pw, pb, grad_is_pre=False, x_is_elu_out=False):
+def upconv_prep(pw, dtype):
+    """Fold the 3x3 kernel [3,3,Cin,Cout] (f32 master) into the 16 effective 2x2-tap matrices of the 4 output phases, in the
+    activation dtype: wf [16,Cout,Cin] for the forward / weight-gradient kernels, wd [16,Cin,Cout] for the input gradient."""
+    Cin, Cout = pw.master.shape[2], pw.master.shape[3]
+    wf = torch.empty((16, Cout, Cin), dtype=dtype, device=pw.master.device)
+    wd = torch.empty((16, Cin, Cout), dtype=dtype, device=pw.master.device)
+    call('stj_upconv_prep', _p(pw.master), _p(wf), _p(wd), Cin, Cout, DTYPE_CODE[dtype], _st())
+    return wf, wd
+
+
+def upconv(x, pw, pb, grad_is_pre=False, x_is_elu_out=False, prep=None):
     """x [F,Hi,Wi,Cin] -> ELU(conv3x3(upsample2(x)) + b) [F,2Hi,2Wi,Cout].
     grad_is_pre=True: contract with the (single) consumer of the output -- it returns the gradient already multiplied by
     ELU'(y) (outconv_pair / upconv with x_is_elu_out=True), so the separate ELU' pass over the largest tensors is skipped.
     x_is_elu_out=True: x is the ELU output of a producer called with grad_is_pre=True; dx is returned times ELU'(x)."""
-    return _UpConv.apply(x, pw.master, pb.master, pw, pb, grad_is_pre, x_is_elu_out)
+    return _UpConv.apply(x, pw.master, pb.master, pw, pb, grad_is_pre, x_is_elu_out, prep)
 
 
 def _outconv_workspace(device):
