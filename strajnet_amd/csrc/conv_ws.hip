@@ -590,6 +590,26 @@ bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbi
 // =====================================================================================================
 #define OCM_T 16
 #define OCM_H 18
+// Work index -> (tile column, tile row, frame).  The 8 waypoint frames of one scene write / read the SAME 128-byte lines of the
+// [B,H,W,32] f32 tensor (a frame owns 8 bytes of each line).  Enumerated frame-major, those 8 frames ran on 8 different XCDs at
+// unrelated times: rocprofv3 (profiles/r02_b_pmc_step.txt) counted 1080 MB fetched by the backward kernel for 420 MB of operands and
+// 134 MB written by the forward one for 17 MB of results -- every frame pulled / pushed whole lines through its own L2.  Work items are
+// dealt to the XCDs round-robin (index % 8), so the 8 frames of a spatial tile get indices c + 8 t + 64 u (same XCD c, adjacent in
+// time): the lines are fetched once per tile into ONE L2 and the 8 partial writes merge there.
+__device__ __forceinline__ void oc_decode(int i, int tiles_x, int tiles_y, int F, int inner, long long s_outer, long long s_inner,
+                                          int& tx, int& ty, int& f) {
+  const bool time_outer = s_outer < s_inner;                 // which component of f = outer * inner + in is the waypoint index
+  const int nt = time_outer ? F / inner : inner, nb = F / nt;
+  const int S = nb * tiles_x * tiles_y;
+  int sp, t;
+  if (nt == 8 && (S & 7) == 0) { const int c = i & 7, u = i >> 6; t = (i >> 3) & 7; sp = c + 8 * u; }
+  else { t = i % nt; sp = i / nt; }
+  tx = sp % tiles_x;
+  const int s2 = sp / tiles_x;
+  ty = s2 % tiles_y;
+  const int b = s2 / tiles_y;
+  f = time_outer ? t * inner + b : b * inner + t;
+}
 template <typename T, int C>
 __global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const T* __restrict__ X, const float* __restrict__ W,
                                                                const float* __restrict__ bias, float* __restrict__ Y, int F, int Hh,
@@ -617,7 +637,8 @@ __global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const T* __restri
   const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T, ntiles = F * tiles_x * tiles_y;
   uint4 pre[NCH];
   auto prefetch = [&](int tile) {
-    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, f = t2 / tiles_y;
+    int tx, ty, f;
+    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
     const T* Xf = X + (long long)f * Hh * Ww * C;
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
@@ -644,7 +665,8 @@ __global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const T* __restri
   for (; tile < ntiles; tile += gridDim.x) {
     const int next = tile + gridDim.x;
     if (next < ntiles) prefetch(next);
-    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, f = t2 / tiles_y;
+    int tx, ty, f;
+    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
     const int bb = f / Tn, tt = f % Tn;
     float* Yb = Y + bb * y_bs + tt * y_ts;
 #pragma unroll
@@ -714,7 +736,8 @@ __global__ __launch_bounds__(256, 3) void outconv_bwd_mfma_kernel(const bf16* __
   uint4 pre[NCH];
   float2 pdy[NDY];
   auto prefetch = [&](int tile) {
-    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, f = t2 / tiles_y;
+    int tx, ty, f;
+    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
     const bf16* Xf = X + (long long)f * Hh * Ww * C;
     const float* dYf = dY + (f / Tn) * y_bs + (f % Tn) * y_ts;
 #pragma unroll
@@ -754,7 +777,8 @@ __global__ __launch_bounds__(256, 3) void outconv_bwd_mfma_kernel(const bf16* __
   for (; tile < ntiles; tile += gridDim.x) {
     const int next = tile + gridDim.x;
     if (next < ntiles) prefetch(next);
-    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, f = t2 / tiles_y;
+    int tx, ty, f;
+    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
     bf16* dXf = dX + (long long)f * Hh * Ww * C;
     // ---- dX rows 4w .. 4w+3 ----
 #pragma unroll 1
