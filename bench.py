@@ -280,49 +280,65 @@ def main():
     # Data parallel exchange: SUM all-reduce of the flat f32 gradient buffer, as two buckets.  Backward is cut at the
     # raster encoder's outputs; the tail bucket (decoder / attention / trajNet gradients, complete first) is reduced on RCCL's
     # stream UNDER the encoder's backward, the encoder bucket after it.  --no-overlap: one bucket after a monolithic backward.
-    overlap = world > 1 and not args.no_overlap
     from strajnet_amd import dp
-    sync = dp.OverlappedGradSync(model) if overlap else None
-    model.cut_encoder = overlap
 
-    def finish_step():
-        if world > 1:
+    def build_step(overlap):
+        sync = dp.OverlappedGradSync(model) if overlap else None
+        model.cut_encoder = overlap
+
+        def finish_step():
+            if world > 1:
+                if overlap:
+                    sync.head_and_wait()
+                else:
+                    dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
+            if opt is not None:
+                opt.step()
+
+        def step():
+            model.zero_grad()
+            out = model(x['ogm'], x['map_img'], training=True, obs=x['obs'], occ=x['occ'], mapt=x['mapt'], flow=x['flow'])
+            d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
+            total = d.total                      # observed_xe + occluded_xe + flow + flow_warp_xe (train.py:221)
+            total.backward()
             if overlap:
-                sync.head_and_wait()
-            else:
-                dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
-        if opt is not None:
-            opt.step()
+                sync.tail()
+                model.backward_encoder()
+            finish_step()
+            return total
 
-    def step():
-        model.zero_grad()
-        out = model(x['ogm'], x['map_img'], training=True, obs=x['obs'], occ=x['occ'], mapt=x['mapt'], flow=x['flow'])
-        d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
-        total = d.total                      # observed_xe + occluded_xe + flow + flow_warp_xe (train.py:221)
-        total.backward()
-        if overlap:
-            sync.tail()
-            model.backward_encoder()
-        finish_step()
-        return total
+        graphed = None
+        if not args.no_graph:
+            try:
+                from strajnet_amd.graph import GraphedTrainStep
+                graphed = GraphedTrainStep(model, loss_fn, x, split=overlap)
+            except Exception as e:           # capture is an optimisation, never a requirement
+                print(f'bench.py: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
+                graphed = None
+                model.cut_encoder = overlap
+        eager_step = step
 
-    graphed = None
-    if not args.no_graph:
-        try:
-            from strajnet_amd.graph import GraphedTrainStep
-            graphed = GraphedTrainStep(model, loss_fn, x, split=overlap)
-        except Exception as e:           # capture is an optimisation, never a requirement
-            print(f'bench.py: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
-            graphed = None
-            model.cut_encoder = overlap
-    eager_step = step
+        def step_graph():
+            losses = graphed(between=sync.tail if overlap else None)
+            finish_step()
+            return losses.sum()
+        if graphed is not None:
+            step = step_graph
 
-    def step_graph():
-        losses = graphed(between=sync.tail if overlap else None)
-        finish_step()
-        return losses.sum()
-    if graphed is not None:
-        step = step_graph
+        return step, eager_step, graphed, sync
+
+    overlap = world > 1 and not args.no_overlap
+    step, eager_step, graphed, sync = build_step(overlap)
+    probed = 0
+    if overlap:          # the two-graph / two-bucket path has only ever run over gloo (no multi-GPU node so far): probe it once, and fall
+        try:             # back to the one-bucket exchange rather than lose the run if RCCL disagrees (the probe is the first warm-up step)
+            step()
+            torch.cuda.synchronize()
+            probed = 1
+        except Exception as e:
+            print(f'bench.py: overlapped gradient exchange failed ({type(e).__name__}: {e}); using one bucket after backward', file=sys.stderr)
+            overlap = False
+            step, eager_step, graphed, sync = build_step(False)
 
     def barrier():
         if world > 1:
@@ -333,7 +349,7 @@ def main():
         cal = torch.empty(128 * 1024 * 1024, dtype=torch.bfloat16, device=dev).normal_()
         torch.empty_like(cal).copy_(cal)
         del cal
-    for _ in range(args.warmup):
+    for _ in range(max(0, args.warmup - probed)):
         step()
     barrier()
     t0 = time.perf_counter()
