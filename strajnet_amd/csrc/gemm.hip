@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? ((!
   constexpr int A_ELEMS = TA ? BK * LDTA : BM * LD;
   constexpr int B_ELEMS = ((TB ? BK * LDTB : BN * LD) + 7) / 8 * 8;
   constexpr int A_ELEMS_AL = (A_ELEMS + 7) / 8 * 8;
-  constexpr int EP_ROWS = BM < 64 ? BM : 64;
+  constexpr int EP_ROWS = BM < 64 ? BM : (BM % 64 == 0 ? 64 : FM * 16);      // a wave's rows must lie inside one epilogue pass
   constexpr int LDC = BN + 4;
   constexpr int STAGE_BYTES = (A_ELEMS_AL + B_ELEMS) * (int)sizeof(T);
   constexpr int EPI_BYTES = EP_ROWS * LDC * 4;
@@ -450,8 +450,18 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   { static int small = -1; if (small < 0) { const char* e = getenv("STJ_GEMM_SMALL"); small = e ? atoi(e) : 256; }
     if (!p.accumulate && tiles64 < small && p.M >= 32 && p.N >= 32) cfg = 3; }
   { static int f = -2; if (f == -2) { const char* e = getenv("STJ_GEMM_CFG"); f = e ? atoi(e) : -1; } if (f >= 0 && !p.accumulate) cfg = f; }
+  // Weight gradients (split-K, f32 atomics): measured (tools/bench_gemm.py, STJ_WGRAD_CFG) 96x128 / 128x96 / 96x96 tiles -- exact covers
+  // of the 96 * 2^i Swin widths, 3x the MFMAs per barrier pair -- and 128x128 tiles against the 64x64 default: slower on every
+  // shape but two (e.g. [192x576] over 8192 rows 32.8 vs 18.8 us, [96x384] over 32768 rows 31.8 vs 28.7 us; 128x128: 38-47 us), 828
+  // vs 860 scenes/s end to end: these launches are bound by how many workgroups are in flight, not by what one of them does.
+  if (p.accumulate) {
+    static int wf = -2;
+    if (wf == -2) { const char* e = getenv("STJ_WGRAD_CFG"); wf = e ? atoi(e) : -1; }
+    if (wf >= 0) cfg = wf;
+  }
   if (p.splitk == 0) {            // auto split-K (accumulating GEMMs only): aim at ~2 blocks per CU
-    const long long tiles = cfg == 0 ? tiles128 : (cfg == 1 ? (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * nb : tiles64);
+    auto ntl = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * nb; };
+    const long long tiles = cfg == 0 ? tiles128 : (cfg == 1 ? ntl(128, 64) : (cfg == 4 ? ntl(96, 128) : (cfg == 5 ? ntl(128, 96) : (cfg == 6 ? ntl(96, 96) : tiles64))));
     static int tgt = -1, cap = -1;
     if (tgt < 0) { const char* e = getenv("STJ_SPLITK_TGT"); tgt = e ? atoi(e) : 768; e = getenv("STJ_SPLITK_CAP"); cap = e ? atoi(e) : 96; }
     long long s = (tgt + tiles - 1) / tiles;
@@ -462,7 +472,10 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
     if (s >= 8 && nb == 1) s = s / 8 * 8;      // multiple of 8: enables the XCD-aware work map
     p.splitk = (int)s;
   }
-  if (cfg == 3) launch_tile<T, 32, 32, 2, 2>(p, ta, tb, st);
+  if (cfg == 4) launch_tile<T, 96, 128, 2, 2>(p, ta, tb, st);
+  else if (cfg == 5) launch_tile<T, 128, 96, 2, 2>(p, ta, tb, st);
+  else if (cfg == 6) launch_tile<T, 96, 96, 2, 2>(p, ta, tb, st);
+  else if (cfg == 3) launch_tile<T, 32, 32, 2, 2>(p, ta, tb, st);
   else if (cfg == 0) launch_tile<T, 128, 128, 2, 2>(p, ta, tb, st);
   else if (cfg == 1) launch_tile<T, 128, 64, 4, 1>(p, ta, tb, st);
   else launch_tile<T, 64, 64, 2, 2>(p, ta, tb, st);
