@@ -115,6 +115,17 @@ int stj_swin_attn_fwd(const void* x, const float* gamma, const float* beta, cons
                       float* mean, float* rstd, int B, int res, int C, int shift, float eps, const long long* rng_state,
                       int site, float p_drop, int dtype, hipStream_t stream);
 
+/* Backward of stj_swin_attn_fwd in one launch (one workgroup per window): dys = dp*dy, da = dys wproj^T, window-attention backward,
+ * dLN = dqkv wqkv^T, dx = dy + LayerNorm'(dLN); "+=" outputs: dtable [tparts][225,heads] (workgroup i adds into copy i % tparts),
+ * dgamma / dbeta (nparts copies part_stride floats apart).  Reads x, dy, the saved qkv / mean / rstd; writes dx, dqkv [B,N,3C] and
+ * (when rng_state != NULL and p_drop > 0: else may be NULL) dys [B,N,C] -- the operands of the two weight gradients, which stay
+ * stj_gemm launches: dWproj = a^T dys (+ colsum), dWqkv = ln^T dqkv (+ colsum), a / ln saved by the forward kernel.  C in {96,192}. */
+int stj_swin_attn_bwd(const void* x, const void* dy, const void* qkv, const float* mean, const float* rstd, const float* gamma,
+                      const void* wqkv, const void* wproj, const float* table, void* dx, void* dqkv, void* dys,
+                      float* dtable, int tparts, float* dgamma, float* dbeta, int nparts, long long part_stride,
+                      int B, int res, int C, int shift, const long long* rng_state, int site, float p_drop, int dtype,
+                      hipStream_t stream);
+
 /* Row softmax of the global attentions: P = softmax(S + bias + (-10e9 where !(qvalid&kvalid))) (tfa MHA mask
  * semantics, f32 add); S f32 [batch,H,Nq,Nk] (Nk <= 256).  bwd: dS = P*(dP - sum(P dP)). */
 int stj_softmax_fwd(const float* S, void* P, const int* qvalid, const int* kvalid, const float* bias,

@@ -850,3 +850,362 @@ extern "C" int stj_swin_attn_fwd(const void* x, const float* gamma, const float*
   stj_set_error("swin_attn: bad dtype %d", dtype);
   return STJ_EINVAL;
 }
+
+// =====================================================================================================================
+// Fused attention half of SwinTransformerBlock, backward (tape.gradient of the forward kernel above):
+//     dys = dp * dy ; da = dys Wproj^T ; (dq, dk, dv) = window-attention backward ; dLN = dqkv Wqkv^T ; dx = dy + LN'(dLN)
+// plus the relative-position-bias-table and LN gamma / beta gradients.  One workgroup per window, a wave owns 16 of its tokens
+// (as queries, and -- for dK / dV -- as keys).  What goes through LDS: the saved q|k|v tile of the current head group (the
+// gradients dq|dk|dv overwrite it in place, head by head), per head the P and dS tiles (the sums over QUERIES of dV = P^T dO and
+// dK = dS^T Q cross the waves) and a 64 x 32 dO tile; weights in K-chunks as MFMA A operands.  Everything else chains in registers
+// exactly as in the forward kernel.  The weight gradients stay split-K GEMMs on what this kernel writes once: dqkv [M,3C] and
+// dys [M,C] (next to the forward's saved a = attention output and ln = LN(x)).
+// =====================================================================================================================
+template <typename T, int C> struct AttnBCfg {
+  static constexpr int KSTEP = Mma<T>::KSTEP;
+  static constexpr int KS = C / KSTEP, NF = C / 16, HEADS = C / 32;
+  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? 3 : 2) : 1;    // heads per pass
+  static constexpr int GC = 32 * HG;
+  static constexpr int PADK = sizeof(T) == 2 ? 16 : 8;                 // pad of k-contiguous images read with 16-byte fragments
+  static constexpr int LDT = 3 * GC + PADK;                            // q|k|v (then dq|dk|dv) tile [64][LDT]
+  static constexpr int KW = 3 * GC;                                    // columns of the weight buffer
+  static constexpr int LDW = KW + PADK;                                // weight image [C][LDW] (rows = c, k contiguous)
+  static constexpr int KC1 = C <= KW ? C : 96;                         // K-chunk of the proj product
+  static constexpr int LDP = 64 + (sizeof(T) == 2 ? 8 : 4);            // P / dS tiles [64][LDP]
+  static constexpr int LDO = 32 + (sizeof(T) == 2 ? 8 : 4);            // dO tile of one head [64][LDO]
+  static constexpr int TILE = 64 * LDT, WB = C * LDW, PT = 64 * LDP, DO = 64 * LDO;
+  static constexpr int LDS_BYTES = (TILE + WB + 2 * PT + DO) * (int)sizeof(T) + 225 * 4 + 2 * 64 * 4 + 2 * C * 4;
+  static_assert(HEADS % HG == 0 && C % KC1 == 0, "shape");
+};
+
+struct AttnBArgs {
+  const void* x; const void* dy; const void* qkv; const float* mean; const float* rstd; const float* gamma;
+  const void* wqkv; const void* wproj; const float* table;
+  void* dx; void* dqkv; void* dys; float* dtable; int tparts; float* dgamma; float* dbeta; int nparts; long long pstride;
+  int B, res, shift;
+  const long long* rng; int site; float p_drop;
+};
+
+template <typename T, int C>
+__global__ __launch_bounds__(256, 1) void swin_attn_bwd_kernel(AttnBArgs p) {
+  typedef AttnBCfg<T, C> G;
+  constexpr int KS = G::KS, NF = G::NF, HG = G::HG, GC = G::GC, KSTEP = G::KSTEP, ND = Chain<T>::ND, LK = Mma<T>::LANE_K;
+  constexpr int VN = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ab_smem[];
+  T* tile = reinterpret_cast<T*>(ab_smem);
+  T* Wb = tile + G::TILE;
+  T* Pt = Wb + G::WB;
+  T* dSt = Pt + G::PT;
+  T* dOt = dSt + G::PT;
+  float* tbl = reinterpret_cast<float*>(dOt + G::DO);               // [225] bias table of the current head, then its gradient bins
+  int* tok = reinterpret_cast<int*>(tbl + 225);
+  int* lab = tok + 64;
+  float* red = reinterpret_cast<float*>(lab + 64);                  // [2][C] gamma / beta partial sums of the block
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, ln = lane & 15;
+  const int nwx = p.res / 8, nW = nwx * nwx;
+  const int win = blockIdx.x % nW, b = blockIdx.x / nW;
+  const int wy = win / nwx, wx = win % nwx;
+  const long long N = (long long)p.res * p.res;
+  if (tid < 64) {
+    const int t = tid;
+    int ry = wy * 8 + (t >> 3), rx = wx * 8 + (t & 7);
+    int sy = ry + p.shift; if (sy >= p.res) sy -= p.res;
+    int sx = rx + p.shift; if (sx >= p.res) sx -= p.res;
+    tok[t] = sy * p.res + sx;
+    const int ly = ry < p.res - 8 ? 0 : (ry < p.res - p.shift ? 1 : 2);
+    const int lx = rx < p.res - 8 ? 0 : (rx < p.res - p.shift ? 1 : 2);
+    lab[t] = ly * 3 + lx;
+  }
+  for (int c = tid; c < 2 * C; c += 256) red[c] = 0.f;
+  __syncthreads();
+  const long long myrow = (long long)b * N + tok[16 * wv + ln];
+  const T* wq = reinterpret_cast<const T*>(p.wqkv);
+  const T* wp = reinterpret_cast<const T*>(p.wproj);
+  const float scale = 0.17677669529663687f;
+  auto put = [](T* d, const uint4& v) { *reinterpret_cast<uint4*>(d) = v; };
+
+  // ---- rows of dy (this wave's 16 tokens) as B fragments, scaled by the DropPath factor of the sample; dys for the proj weight gradient
+  typename Mma<T>::Frag dya[KS];
+  {
+    const T* pd = reinterpret_cast<const T*>(p.dy) + myrow * C + LK * g;
+    const float dp = drop_path_scale(p.rng, p.site, b, p.p_drop);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      dya[ks] = Mma<T>::from_global(pd + ks * KSTEP);
+      if (dp != 1.f) {
+        float v[LK];
+        frag_unpack<T>(dya[ks], v);
+#pragma unroll
+        for (int e = 0; e < LK; ++e) v[e] *= dp;
+        dya[ks] = frag_pack<T>(v);
+      }
+      if (p.dys) *reinterpret_cast<typename Mma<T>::Frag*>(reinterpret_cast<T*>(p.dys) + myrow * C + ks * KSTEP + LK * g) = dya[ks];
+    }
+  }
+  // ---- phase 1: da^T[c][tok] = sum_oc Wproj[c][oc] dys^T[oc][tok]  (A = Wproj rows, k = oc contiguous: the natural layout)
+  f32x4 da[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) da[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < C; k0 += G::KC1) {
+    __syncthreads();
+    constexpr int CPR = G::KC1 / VN;
+    for (int q = tid; q < C * CPR; q += 256) {
+      const int r = q / CPR, c = (q % CPR) * VN;
+      put(Wb + r * G::LDW + c, *reinterpret_cast<const uint4*>(wp + (long long)r * C + k0 + c));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < G::KC1 / KSTEP; ++kk)
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+        da[f] = Mma<T>::mma(Mma<T>::load(Wb, G::LDW, 16 * f, kk * KSTEP, lane), dya[k0 / KSTEP + kk], da[f]);
+  }
+
+  f32x4 dln[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) dln[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const T* qkvb = reinterpret_cast<const T*>(p.qkv) + (long long)b * N * 3 * C;
+  T* dqkvb = reinterpret_cast<T*>(p.dqkv) + (long long)b * N * 3 * C;
+  const int qi = 16 * wv + ln;
+  const int mylab = lab[qi];
+
+#pragma unroll
+  for (int h0 = 0; h0 < G::HEADS; h0 += HG) {      // unrolled: the da[] fragments of a head are picked by a compile-time index
+    __syncthreads();                                  // previous pass done with the tile and the weight buffer
+    {   // q|k|v of this head group -> tile (token-major, gathered); Wqkv[:, group columns] -> weight buffer (rows = c)
+      constexpr int CPS = GC / VN;
+      for (int q = tid; q < 64 * 3 * CPS; q += 256) {
+        const int t = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
+        put(tile + t * G::LDT + seg * GC + c, *reinterpret_cast<const uint4*>(qkvb + (long long)tok[t] * 3 * C + seg * C + 32 * h0 + c));
+      }
+      for (int q = tid; q < C * 3 * CPS; q += 256) {
+        const int r0 = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
+        put(Wb + r0 * G::LDW + seg * GC + c, *reinterpret_cast<const uint4*>(wq + (long long)r0 * (3 * C) + seg * C + 32 * h0 + c));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh) {
+      const int h = h0 + hh;
+      if (hh > 0) __syncthreads();                    // previous head's P / dS / dO / table readers are done
+      for (int q = tid; q < 225; q += 256) tbl[q] = p.table[q * G::HEADS + h];
+      {   // dO of this head (this wave's 16 queries) -> LDS, token-major
+#pragma unroll
+        for (int jd = 0; jd < 2; ++jd) {
+          const f32x4 v4 = da[2 * h + jd];
+          const float v[4] = {v4[0], v4[1], v4[2], v4[3]};
+          st4(dOt + qi * G::LDO + 16 * jd + 4 * g, v);
+        }
+      }
+      __syncthreads();                                // table staged
+      // S^T = K Q^T, P^T = softmax over keys (as in the forward kernel)
+      f32x4 st[4], dpt[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        st[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += KSTEP)
+          st[j] = Mma<T>::mma(Mma<T>::load(tile + GC + 32 * hh, G::LDT, 16 * j, k0, lane), Mma<T>::load(tile + 32 * hh, G::LDT, 16 * wv, k0, lane), st[j]);
+      }
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * j + 4 * g + r;
+          float v = st[j][r] * scale + tbl[((qi >> 3) - (key >> 3) + 7) * 15 + ((qi & 7) - (key & 7) + 7)];
+          if (p.shift > 0 && lab[key] != mylab) v += -100.0f;
+          st[j][r] = v;
+          m = fmaxf(m, v);
+        }
+      m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float e = __expf(st[j][r] - m); st[j][r] = e; sum += e; }
+      sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      // dP^T[key][q] = sum_d V[key][d] dO^T[d][q]   (B = dO^T chained from the da accumulators of this head)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dpt[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 32 / KSTEP; ++kk)
+          dpt[j] = Mma<T>::mma(Chain<T>::ldA(tile + 2 * GC + 32 * hh, G::LDT, 16 * j, kk * KSTEP, lane), Chain<T>::from_acc(&da[2 * h + kk * ND]), dpt[j]);
+      }
+      float dsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[j][r] *= inv; dsum += st[j][r] * dpt[j][r]; }
+      dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dpt[j][r] = st[j][r] * (dpt[j][r] - dsum);         // dS^T
+        const float pv[4] = {st[j][0], st[j][1], st[j][2], st[j][3]}, dv_[4] = {dpt[j][0], dpt[j][1], dpt[j][2], dpt[j][3]};
+        st4(Pt + qi * G::LDP + 16 * j + 4 * g, pv);                                    // P[q][key], dS[q][key]: row q, 4 consecutive keys
+        st4(dSt + qi * G::LDP + 16 * j + 4 * g, dv_);
+      }
+      // dQ^T[d][q] = scale sum_key K^T[d][key] dS^T[key][q]   (A = K^T by transposed reads of the token-major tile; B chained)
+      f32x4 dq[2];
+#pragma unroll
+      for (int jd = 0; jd < 2; ++jd) {
+        dq[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 64 / KSTEP; ++s)
+          dq[jd] = Mma<T>::mma(Chain<T>::ldA_tr(tile + GC + 32 * hh, G::LDT, 16 * jd, s * KSTEP, lane), Chain<T>::from_acc(&dpt[s * ND]), dq[jd]);
+      }
+      __syncthreads();                                // P, dS, dO of all 64 queries are in LDS
+      // the sums over queries: this wave's 16 KEYS.  dV^T[d][key] = sum_q dO^T[d][q] P[q][key];  dK^T[d][key] = scale sum_q Q^T[d][q] dS[q][key]
+      f32x4 dv[2], dk[2];
+#pragma unroll
+      for (int jd = 0; jd < 2; ++jd) {
+        dv[jd] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k0 = 0; k0 < 64; k0 += KSTEP) {
+          dv[jd] = Mma<T>::mma(Mma<T>::load_tr(dOt, G::LDO, 16 * jd, k0, lane), Mma<T>::load_tr(Pt, G::LDP, 16 * wv, k0, lane), dv[jd]);
+          dk[jd] = Mma<T>::mma(Mma<T>::load_tr(tile + 32 * hh, G::LDT, 16 * jd, k0, lane), Mma<T>::load_tr(dSt, G::LDP, 16 * wv, k0, lane), dk[jd]);
+        }
+      }
+      // relative-position-bias gradient of this head (one wave): bin (dy, dx) collects dS[(ry,rx)][(ry-dy, rx-dx)]; lane l owns the
+      // 8 x 8 block (query row l / 8, key row l % 8) of the dS tile, whose 15 diagonals are the dx bins of ONE dy
+      float dacc[15];
+      const bool tw = wv == (h & 3);
+      if (tw) {
+        const int ry = lane >> 3, ky = lane & 7;
+#pragma unroll
+        for (int d = 0; d < 15; ++d) dacc[d] = 0.f;
+#pragma unroll
+        for (int rx = 0; rx < 8; ++rx) {
+          const T* src = dSt + (ry * 8 + rx) * G::LDP + ky * 8;
+          float v[8];
+          if constexpr (VN == 8) ld16(src, v);
+          else { ld16(src, v); ld16(src + 4, v + 4); }
+#pragma unroll
+          for (int kx = 0; kx < 8; ++kx) dacc[rx - kx + 7] += v[kx];
+        }
+      }
+      __syncthreads();                                // every wave is done with q_h, k_h, v_h, P, dS, dO and the bias table
+      {   // dq | dk | dv of this head overwrite q | k | v in the tile (rows = this wave's tokens), 4 consecutive d per lane
+#pragma unroll
+        for (int jd = 0; jd < 2; ++jd) {
+          const float a0[4] = {dq[jd][0] * scale, dq[jd][1] * scale, dq[jd][2] * scale, dq[jd][3] * scale};
+          const float a1[4] = {dk[jd][0] * scale, dk[jd][1] * scale, dk[jd][2] * scale, dk[jd][3] * scale};
+          const float a2[4] = {dv[jd][0], dv[jd][1], dv[jd][2], dv[jd][3]};
+          T* row = tile + qi * G::LDT + 32 * hh + 16 * jd + 4 * g;
+          st4(row, a0); st4(row + GC, a1); st4(row + 2 * GC, a2);
+        }
+      }
+      for (int q = tid; q < 225; q += 256) tbl[q] = 0.f;
+      __syncthreads();
+      if (tw) {
+        const int ry = lane >> 3, ky = lane & 7;
+#pragma unroll
+        for (int d = 0; d < 15; ++d) atomicAdd(&tbl[(ry - ky + 7) * 15 + d], dacc[d]);
+      }
+      __syncthreads();
+      for (int bin = tid; bin < 225; bin += 256)
+        atomicAdd(p.dtable + (long long)(blockIdx.x % p.tparts) * 225 * G::HEADS + bin * G::HEADS + h, tbl[bin]);
+    }
+    __syncthreads();                                  // dq | dk | dv of the whole group are in the tile
+    {   // copy-out for the qkv weight gradient (rows in original token order), then dLN^T += Wqkv[:, group] dqkv_group^T
+      constexpr int CPS = GC / VN;
+      for (int q = tid; q < 64 * 3 * CPS; q += 256) {
+        const int t = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
+        *reinterpret_cast<uint4*>(dqkvb + (long long)tok[t] * 3 * C + seg * C + 32 * h0 + c) = *reinterpret_cast<const uint4*>(tile + t * G::LDT + seg * GC + c);
+      }
+    }
+#pragma unroll 1
+    for (int kk = 0; kk < G::KW / KSTEP; ++kk) {
+      const typename Mma<T>::Frag bf = Mma<T>::load(tile, G::LDT, 16 * wv, kk * KSTEP, lane);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) dln[f] = Mma<T>::mma(Mma<T>::load(Wb, G::LDW, 16 * f, kk * KSTEP, lane), bf, dln[f]);
+    }
+  }
+
+  // ---- LayerNorm backward on the accumulator layout + the shortcut gradient; gamma / beta partial sums
+  {
+    const float mu = p.mean[myrow], rs = p.rstd[myrow];
+    const T* xr = reinterpret_cast<const T*>(p.x) + myrow * C;
+    const T* dyr = reinterpret_cast<const T*>(p.dy) + myrow * C;
+    T* dxr = reinterpret_cast<T*>(p.dx) + myrow * C;
+    float xh[NF][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int col = 16 * f + 4 * g;
+      float xv[4];
+      ld4(xr + col, xv);
+      const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
+      const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xh[f][r] = (xv[r] - mu) * rs;
+        const float d = dln[f][r];
+        float a = d * xh[f][r], bsum = d;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); bsum += __shfl_xor(bsum, o, 64); }
+        if (ln == 0) { atomicAdd(&red[col + r], a); atomicAdd(&red[C + col + r], bsum); }
+        const float t = d * gmv[r];
+        dln[f][r] = t;
+        s1 += t; s2 += t * xh[f][r];
+      }
+    }
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    s1 *= (1.f / C); s2 *= (1.f / C);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int col = 16 * f + 4 * g;
+      float dv_[4];
+      ld4(dyr + col, dv_);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = dv_[r] + rs * (dln[f][r] - s1 - xh[f][r] * s2);
+      st4(dxr + col, v);
+    }
+  }
+  __syncthreads();
+  const long long po = (long long)(blockIdx.x % p.nparts) * p.pstride;
+  for (int c = tid; c < C; c += 256) { atomicAdd(p.dgamma + po + c, red[c]); atomicAdd(p.dbeta + po + c, red[C + c]); }
+}
+
+template <typename T, int C>
+static int attnb_launch(const AttnBArgs& a, hipStream_t st) {
+  typedef AttnBCfg<T, C> G;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
+      stj_set_error("swin_attn_bwd: cannot reserve %d bytes of LDS", G::LDS_BYTES); return STJ_ELAUNCH;
+    }
+    attr = true;
+  }
+  const int nW = (a.res / 8) * (a.res / 8);
+  hipLaunchKernelGGL((swin_attn_bwd_kernel<T, C>), dim3((unsigned)(a.B * nW)), dim3(256), G::LDS_BYTES, st, a);
+  return stj_check_launch("stj_swin_attn_bwd");
+}
+
+extern "C" int stj_swin_attn_bwd(const void* x, const void* dy, const void* qkv, const float* mean, const float* rstd, const float* gamma,
+                                 const void* wqkv, const void* wproj, const float* table, void* dx, void* dqkv, void* dys,
+                                 float* dtable, int tparts, float* dgamma, float* dbeta, int nparts, long long part_stride,
+                                 int B, int res, int C, int shift, const long long* rng_state, int site, float p_drop, int dtype,
+                                 hipStream_t stream) {
+  if (B <= 0) return STJ_OK;
+  if (res % 8 != 0 || shift < 0 || shift >= 8) { stj_set_error("swin_attn_bwd: res %% 8 != 0 or bad shift"); return STJ_EINVAL; }
+  if (tparts < 1 || nparts < 1) { stj_set_error("swin_attn_bwd: tparts / nparts must be >= 1"); return STJ_EINVAL; }
+  if (!(p_drop >= 0.f && p_drop < 1.f)) { stj_set_error("swin_attn_bwd: need 0 <= p_drop < 1"); return STJ_EINVAL; }
+  AttnBArgs p = {};
+  p.x = x; p.dy = dy; p.qkv = qkv; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.wqkv = wqkv; p.wproj = wproj; p.table = table;
+  p.dx = dx; p.dqkv = dqkv; p.dys = dys; p.dtable = dtable; p.tparts = tparts; p.dgamma = dgamma; p.dbeta = dbeta; p.nparts = nparts;
+  p.pstride = part_stride; p.B = B; p.res = res; p.shift = shift; p.rng = rng_state; p.site = site; p.p_drop = p_drop;
+#define STJ_AB(TT) (C == 96 ? attnb_launch<TT, 96>(p, stream) : (C == 192 ? attnb_launch<TT, 192>(p, stream) : (stj_set_error("swin_attn_bwd: C must be 96 or 192 (got %d)", C), (int)STJ_EUNSUPPORTED)))
+  if (dtype == STJ_BF16) return STJ_AB(bf16);
+  if (dtype == STJ_F16) return STJ_AB(f16);
+  if (dtype == STJ_F32) return STJ_AB(float);
+#undef STJ_AB
+  stj_set_error("swin_attn_bwd: bad dtype %d", dtype);
+  return STJ_EINVAL;
+}

@@ -633,41 +633,59 @@ class _SwinAttnHalf(torch.autograd.Function):
         heads = C // 32
         dt = _dt(x)
         dy = dy.contiguous()
-        dys = dy
-        if drop is not None:            # gradient of the branch = DropPath factor * dy (same draw, re-derived)
-            p_drop, state, site = drop
-            dys = torch.empty_like(dy)
-            call('stj_dropout', _p(dy), None, _p(dys), dy.numel(), N * C, float(p_drop), _p(state), site, dt, _st())
-        dys2, a2, ln2 = dys.view(M, C), a.view(M, C), ln.view(M, C)
-        da = torch.empty_like(a)
-        gemm(dys2, pwp.c, da, M, C, C, (0, 0, C, 1), (0, 0, 1, C), (0, 0, C), dt)                        # da = dys Wp^T
-        with wgrad_stream(1, a2, dys2):
-            gemm(a2, dys2, pwp.grad, C, C, M, (0, 0, 1, C), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1, splitk=0,
-                 colsum=pbp.grad)                                                                         # dWp += a^T dys ; dbp
-        dqkv = torch.empty_like(qkv)
         items = B * (res // 8) ** 2 * heads
-        nparts = 32 if items >= 1024 else (16 if items >= 256 else 1)
-        if pt.part is not None:
-            call('stj_win_attn_bwd', _p(qkv), _p(pt.master), _p(da), _p(dqkv), _p(pt.part[0]), min(nparts, pt.part[1]), B, res, heads,
-                 shift, dt, _st())
-        else:
-            part = zeros_f32((nparts,) + tuple(pt.grad.shape), x.device)
-            call('stj_win_attn_bwd', _p(qkv), _p(pt.master), _p(da), _p(dqkv), _p(part), nparts, B, res, heads, shift, dt, _st())
-            pt.grad.add_(part.sum(0))
-        dq2 = dqkv.view(M, 3 * C)
-        dln = torch.empty_like(ln)
-        gemm(dq2, pwq.c, dln, M, C, 3 * C, (0, 0, 3 * C, 1), (0, 0, 1, 3 * C), (0, 0, C), dt)             # dln = dqkv Wqkv^T
-        with wgrad_stream(1, ln2, dq2):
-            gemm(ln2, dq2, pwq.grad, C, 3 * C, M, (0, 0, 1, C), (0, 0, 3 * C, 1), (0, 0, 3 * C), dt, c_f32=1, accumulate=1,
-                 splitk=0, colsum=pbq.grad)                                                               # dWqkv += ln^T dqkv ; dbqkv
-        dx = torch.empty_like(x)
+        tparts = 32 if items >= 1024 else (16 if items >= 256 else 1)
         if pg.part is not None and pb.part is not None:
             dg, db, np_, ps_ = pg.part[0], pb.part[0], pg.part[1], pg.part[2]
         else:
             dg, db, np_, ps_ = pg.grad, pb.grad, 1, 0
-        call('stj_layernorm_bwd', _p(dln), _p(x), _p(pg.master), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), M, C, 0, 0, 0, 1, 0,
-             _p(dy), np_, ps_, dt, _st())                                                                 # + the shortcut gradient
+        dx = torch.empty_like(x)
+        dqkv = torch.empty_like(qkv)
+        a2, ln2, dq2 = a.view(M, C), ln.view(M, C), dqkv.view(M, 3 * C)
+        if FUSED_ATTN_BWD:
+            # ONE kernel per window: DropPath factor, proj dgrad, window-attention backward, qkv dgrad, LN backward + shortcut
+            p_drop, state, site = drop if drop is not None else (0.0, None, 0)
+            dys = torch.empty_like(dy) if drop is not None else None
+            if pt.part is not None:
+                dtab, tp, own = pt.part[0], min(tparts, pt.part[1]), None
+            else:
+                own = zeros_f32((tparts,) + tuple(pt.grad.shape), x.device)
+                dtab, tp = own, tparts
+            call('stj_swin_attn_bwd', _p(x), _p(dy), _p(qkv), _p(mean), _p(rstd), _p(pg.master), _p(pwq.c), _p(pwp.c), _p(pt.master),
+                 _p(dx), _p(dqkv), _p(dys), _p(dtab), tp, _p(dg), _p(db), np_, ps_, B, res, C, shift, _p(state), site, float(p_drop),
+                 dt, _st())
+            if own is not None:
+                pt.grad.add_(own.sum(0))
+            dys2 = (dys if dys is not None else dy).view(M, C)
+        else:
+            dys = dy
+            if drop is not None:            # gradient of the branch = DropPath factor * dy (same draw, re-derived)
+                p_drop, state, site = drop
+                dys = torch.empty_like(dy)
+                call('stj_dropout', _p(dy), None, _p(dys), dy.numel(), N * C, float(p_drop), _p(state), site, dt, _st())
+            dys2 = dys.view(M, C)
+            da = torch.empty_like(a)
+            gemm(dys2, pwp.c, da, M, C, C, (0, 0, C, 1), (0, 0, 1, C), (0, 0, C), dt)                    # da = dys Wp^T
+            if pt.part is not None:
+                call('stj_win_attn_bwd', _p(qkv), _p(pt.master), _p(da), _p(dqkv), _p(pt.part[0]), min(tparts, pt.part[1]), B, res, heads,
+                     shift, dt, _st())
+            else:
+                part = zeros_f32((tparts,) + tuple(pt.grad.shape), x.device)
+                call('stj_win_attn_bwd', _p(qkv), _p(pt.master), _p(da), _p(dqkv), _p(part), tparts, B, res, heads, shift, dt, _st())
+                pt.grad.add_(part.sum(0))
+            dln = torch.empty_like(ln)
+            gemm(dq2, pwq.c, dln, M, C, 3 * C, (0, 0, 3 * C, 1), (0, 0, 1, 3 * C), (0, 0, C), dt)         # dln = dqkv Wqkv^T
+            call('stj_layernorm_bwd', _p(dln), _p(x), _p(pg.master), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), M, C, 0, 0, 0, 1, 0,
+                 _p(dy), np_, ps_, dt, _st())                                                             # + the shortcut gradient
+        with wgrad_stream(1, a2, dys2, ln2, dq2):
+            gemm(a2, dys2, pwp.grad, C, C, M, (0, 0, 1, C), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1, splitk=0,
+                 colsum=pbp.grad)                                                                         # dWp += a^T dys ; dbp
+            gemm(ln2, dq2, pwq.grad, C, 3 * C, M, (0, 0, 1, C), (0, 0, 3 * C, 1), (0, 0, 3 * C), dt, c_f32=1, accumulate=1,
+                 splitk=0, colsum=pbq.grad)                                                               # dWqkv += ln^T dqkv ; dbqkv
         return (dx,) + (None,) * 13
+
+
+FUSED_ATTN_BWD = os.environ.get('STJ_FUSED_ATTN_BWD', '1') != '0'
 
 
 def swin_attn_half(x, pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, eps, dctx=None, name=None, p_drop=0.0):
@@ -688,6 +706,17 @@ def _attn_cost(a):
 
 
 prof.EXTRA_MODELS['stj_swin_attn_fwd'] = _attn_cost
+
+
+def _attn_bwd_cost(a):
+    B, res, C, dt = a[18], a[19], a[20], a[25]
+    es = 4 if dt == 0 else 2
+    M = B * res * res
+    fl = 2.0 * M * C * 4 * C + M * 10.0 * 64 * C
+    return f'swin_attn_bwd[B{B} {res}x{res} C{C}]', 'swin_attn_bwd', fl, fl, es * M * C * (3 + 3 + 3 + (1 if getattr(a[11], 'value', None) else 0))
+
+
+prof.EXTRA_MODELS['stj_swin_attn_bwd'] = _attn_bwd_cost
 
 
 def _mlp_cost(kind):
