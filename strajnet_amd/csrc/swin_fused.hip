@@ -135,12 +135,16 @@ template <typename T, int C> struct MlpStage {
 #pragma unroll
     for (int i = 0; i < N1; ++i) {
       const int q = tid + i * 256;
-      if (q < C * CP1) { const int k = q / CP1, c = (q % CP1) * VN; r1[i] = *reinterpret_cast<const uint4*>(w1 + (long long)k * (4 * C) + hc0 + c); }
+      uint4 v = make_uint4(0, 0, 0, 0);          // (always store a selected value: a conditional store keeps the array in scratch memory)
+      if (q < C * CP1) { const int k = q / CP1, c = (q % CP1) * VN; v = *reinterpret_cast<const uint4*>(w1 + (long long)k * (4 * C) + hc0 + c); }
+      r1[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < N2; ++i) {
       const int q = tid + i * 256;
-      if (q < G::HC * CP2) { const int k = q / CP2, c = (q % CP2) * VN; r2[i] = *reinterpret_cast<const uint4*>(w2 + (long long)(hc0 + k) * C + c); }
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < G::HC * CP2) { const int k = q / CP2, c = (q % CP2) * VN; v = *reinterpret_cast<const uint4*>(w2 + (long long)(hc0 + k) * C + c); }
+      r2[i] = v;
     }
   }
   __device__ __forceinline__ void commit(T* W1s, T* W2s, int tid) const {
@@ -619,15 +623,19 @@ template <typename T, int C> struct AttnStage {
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int q = tid + i * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
       if (q < C * 3 * CPS) {
         const int k = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
-        rq[i] = *reinterpret_cast<const uint4*>(wq + (long long)k * (3 * C) + seg * C + 32 * h0 + c);
+        v = *reinterpret_cast<const uint4*>(wq + (long long)k * (3 * C) + seg * C + 32 * h0 + c);
       }
+      rq[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int q = tid + i * 256;
-      if (q < GC * CPP) rp[i] = *reinterpret_cast<const uint4*>(wp + (long long)(32 * h0 + q / CPP) * C + (q % CPP) * VN);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < GC * CPP) v = *reinterpret_cast<const uint4*>(wp + (long long)(32 * h0 + q / CPP) * C + (q % CPP) * VN);
+      rp[i] = v;
     }
   }
   __device__ __forceinline__ void commit(T* Wqs, T* Wps, int tid) const {
@@ -886,6 +894,16 @@ struct AttnBArgs {
   const long long* rng; int site; float p_drop;
 };
 
+// staging geometry of the backward kernel (chunks per thread).  (The first version copied each 16-byte piece load -> store in a loop:
+// 20 dependent round trips per 80 KB chunk, cold; now all loads of a chunk are in flight at once, issued a phase ahead.)
+template <typename T, int C> struct AttnBStage {
+  typedef AttnBCfg<T, C> G;
+  static constexpr int VN = Vec<T>::N, GC = G::GC;
+  static constexpr int CPS = GC / VN, CP1 = G::KC1 / VN;
+  static constexpr int NWQ = (C * 3 * CPS + 255) / 256, NWP = (C * CP1 + 255) / 256;
+  static constexpr int NT = (64 * 3 * CPS + 255) / 256;
+};
+
 template <typename T, int C>
 __global__ __launch_bounds__(256, 1) void swin_attn_bwd_kernel(AttnBArgs p) {
   typedef AttnBCfg<T, C> G;
@@ -923,7 +941,62 @@ __global__ __launch_bounds__(256, 1) void swin_attn_bwd_kernel(AttnBArgs p) {
   const T* wq = reinterpret_cast<const T*>(p.wqkv);
   const T* wp = reinterpret_cast<const T*>(p.wproj);
   const float scale = 0.17677669529663687f;
-  auto put = [](T* d, const uint4& v) { *reinterpret_cast<uint4*>(d) = v; };
+  const T* qkvb = reinterpret_cast<const T*>(p.qkv) + (long long)b * N * 3 * C;
+  T* dqkvb = reinterpret_cast<T*>(p.dqkv) + (long long)b * N * 3 * C;
+  // staging registers: weight chunk / q|k|v tile, global -> registers (all loads of a chunk in flight at once, issued a phase ahead) -> LDS
+  typedef AttnBStage<T, C> SG;
+  uint4 s_wp[SG::NWP], s_wq[SG::NWQ], s_t[SG::NT];
+  auto issue_wp = [&](int k0) __attribute__((always_inline)) {                      // Wproj[:, k0 .. k0+KC1]
+#pragma unroll
+    for (int i = 0; i < SG::NWP; ++i) {
+      const int q = tid + i * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);        // unconditional store of a selected value: a conditional store keeps the array in scratch
+      if (q < C * SG::CP1) v = *reinterpret_cast<const uint4*>(wp + (long long)(q / SG::CP1) * C + k0 + (q % SG::CP1) * VN);
+      s_wp[i] = v;
+    }
+  };
+  auto commit_wp = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < SG::NWP; ++i) {
+      const int q = tid + i * 256;
+      if (q < C * SG::CP1) *reinterpret_cast<uint4*>(Wb + (q / SG::CP1) * G::LDW + (q % SG::CP1) * VN) = s_wp[i];
+    }
+  };
+  auto issue_group = [&](int h0) __attribute__((always_inline)) {                   // Wqkv[:, q|k|v columns of the head group] and the group's q|k|v tile
+#pragma unroll
+    for (int i = 0; i < SG::NWQ; ++i) {
+      const int q = tid + i * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < C * 3 * SG::CPS) {
+        const int r0 = q / (3 * SG::CPS), r = q % (3 * SG::CPS);
+        v = *reinterpret_cast<const uint4*>(wq + (long long)r0 * (3 * C) + (r / SG::CPS) * C + 32 * h0 + (r % SG::CPS) * VN);
+      }
+      s_wq[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < SG::NT; ++i) {
+      const int q = tid + i * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < 64 * 3 * SG::CPS) {
+        const int tt = q / (3 * SG::CPS), r = q % (3 * SG::CPS);
+        v = *reinterpret_cast<const uint4*>(qkvb + (long long)tok[tt] * 3 * C + (r / SG::CPS) * C + 32 * h0 + (r % SG::CPS) * VN);
+      }
+      s_t[i] = v;
+    }
+  };
+  auto commit_group = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < SG::NWQ; ++i) {
+      const int q = tid + i * 256;
+      if (q < C * 3 * SG::CPS) { const int r0 = q / (3 * SG::CPS), r = q % (3 * SG::CPS); *reinterpret_cast<uint4*>(Wb + r0 * G::LDW + (r / SG::CPS) * GC + (r % SG::CPS) * VN) = s_wq[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < SG::NT; ++i) {
+      const int q = tid + i * 256;
+      if (q < 64 * 3 * SG::CPS) { const int tt = q / (3 * SG::CPS), r = q % (3 * SG::CPS); *reinterpret_cast<uint4*>(tile + tt * G::LDT + (r / SG::CPS) * GC + (r % SG::CPS) * VN) = s_t[i]; }
+    }
+  };
+  issue_wp(0);                                       // first Wproj chunk in flight under the dy loads
 
   // ---- rows of dy (this wave's 16 tokens) as B fragments, scaled by the DropPath factor of the sample; dys for the proj weight gradient
   typename Mma<T>::Frag dya[KS];
@@ -947,14 +1020,13 @@ __global__ __launch_bounds__(256, 1) void swin_attn_bwd_kernel(AttnBArgs p) {
   f32x4 da[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) da[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
   for (int k0 = 0; k0 < C; k0 += G::KC1) {
     __syncthreads();
-    constexpr int CPR = G::KC1 / VN;
-    for (int q = tid; q < C * CPR; q += 256) {
-      const int r = q / CPR, c = (q % CPR) * VN;
-      put(Wb + r * G::LDW + c, *reinterpret_cast<const uint4*>(wp + (long long)r * C + k0 + c));
-    }
+    if (k0 > 0) issue_wp(k0);
+    commit_wp();
     __syncthreads();
+    if (k0 + G::KC1 >= C) issue_group(0);             // first head group: in flight under the proj MFMAs
 #pragma unroll
     for (int kk = 0; kk < G::KC1 / KSTEP; ++kk)
 #pragma unroll
@@ -965,26 +1037,17 @@ __global__ __launch_bounds__(256, 1) void swin_attn_bwd_kernel(AttnBArgs p) {
   f32x4 dln[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) dln[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const T* qkvb = reinterpret_cast<const T*>(p.qkv) + (long long)b * N * 3 * C;
-  T* dqkvb = reinterpret_cast<T*>(p.dqkv) + (long long)b * N * 3 * C;
   const int qi = 16 * wv + ln;
   const int mylab = lab[qi];
 
 #pragma unroll
   for (int h0 = 0; h0 < G::HEADS; h0 += HG) {      // unrolled: the da[] fragments of a head are picked by a compile-time index
     __syncthreads();                                  // previous pass done with the tile and the weight buffer
-    {   // q|k|v of this head group -> tile (token-major, gathered); Wqkv[:, group columns] -> weight buffer (rows = c)
-      constexpr int CPS = GC / VN;
-      for (int q = tid; q < 64 * 3 * CPS; q += 256) {
-        const int t = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
-        put(tile + t * G::LDT + seg * GC + c, *reinterpret_cast<const uint4*>(qkvb + (long long)tok[t] * 3 * C + seg * C + 32 * h0 + c));
-      }
-      for (int q = tid; q < C * 3 * CPS; q += 256) {
-        const int r0 = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
-        put(Wb + r0 * G::LDW + seg * GC + c, *reinterpret_cast<const uint4*>(wq + (long long)r0 * (3 * C) + seg * C + 32 * h0 + c));
-      }
-    }
+    // q|k|v of this head group -> tile (token-major, gathered); Wqkv[:, group columns] -> weight buffer (rows = c): fetched during
+    // the previous phase, committed here; the next group's go in flight right away
+    commit_group();
     __syncthreads();
+    if (h0 + HG < G::HEADS) issue_group(h0 + HG);
 #pragma unroll
     for (int hh = 0; hh < HG; ++hh) {
       const int h = h0 + hh;

@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""Dump the kernel timeline of ONE replayed step from a rocprofv3 rocpd database (start offset, duration, stream / queue, kernel name):
+which kernels overlap, where the GPU idles, what the critical chain is.   usage: tools/timeline.py results.db [step_index_from_end]"""
+import sqlite3, sys
+db = sys.argv[1]
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+c = sqlite3.connect(db)
+cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+sid = 'stream_id' if 'stream_id' in cols else ('queue_id' if 'queue_id' in cols else None)
+q = f"select start, end, {sid if sid else 0}, name from kernels order by start"
+rows = list(c.execute(q))
+# steps are separated by the Nadam kernel
+idx = [i for i, r in enumerate(rows) if 'nadam' in r[3]]
+if len(idx) < back + 1:
+    print('not enough steps', len(idx)); sys.exit(1)
+a, b = idx[-back - 1] + 1, idx[-back] + 1
+step = rows[a:b]
+t0 = step[0][0]
+busy_end = t0
+idle = 0.0
+print(f'# {len(step)} kernels, wall {(step[-1][1] - t0) / 1e3:.1f} us, kernel time sum {sum(r[1] - r[0] for r in step) / 1e3:.1f} us; columns: start_us dur_us stream gap_before_us(idle GPU) name')
+for s, e, st, n in step:
+    gap = max(0.0, (s - busy_end) / 1e3)
+    idle += gap
+    busy_end = max(busy_end, e)
+    print(f'{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {st!s:>6} {gap:7.1f}  {n[:110]}')
+print(f'# GPU idle (no kernel running) inside the step: {idle:.1f} us')

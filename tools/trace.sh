@@ -12,3 +12,5 @@ for mode in serial concurrent; do
   python tools/rocpd_summary.py "$db" 9 > gpurun_out/${tag}_kernel_trace_${mode}_b8_bf16.txt 2>> gpurun_out/trace_${tag}_$mode.err
 done
 head -45 gpurun_out/${tag}_kernel_trace_serial_b8_bf16.txt
+db=$(find /tmp/prof_concurrent -name '*.db' | head -1)
+python tools/timeline.py "$db" 2 > gpurun_out/${tag}_timeline_concurrent.txt 2>&1
