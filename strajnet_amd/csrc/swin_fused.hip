@@ -29,6 +29,15 @@
 #ifndef STJ_MLP_PREFETCH
 #define STJ_MLP_PREFETCH 1      // next weight chunk's global loads issued before the current chunk's MFMAs
 #endif
+#ifndef STJ_ATTNB_HG96
+#define STJ_ATTNB_HG96 3       // heads per pass of the attention backward kernel (16-bit types)
+#endif
+#ifndef STJ_ATTNB_HG192
+#define STJ_ATTNB_HG192 2
+#endif
+#ifndef STJ_ATTNB_MINB
+#define STJ_ATTNB_MINB 1
+#endif
 #ifndef STJ_ATTN_MINB
 #define STJ_ATTN_MINB 1
 #endif
@@ -872,7 +881,7 @@ extern "C" int stj_swin_attn_fwd(const void* x, const float* gamma, const float*
 template <typename T, int C> struct AttnBCfg {
   static constexpr int KSTEP = Mma<T>::KSTEP;
   static constexpr int KS = C / KSTEP, NF = C / 16, HEADS = C / 32;
-  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? 3 : 2) : 1;    // heads per pass
+  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? STJ_ATTNB_HG96 : STJ_ATTNB_HG192) : 1;    // heads per pass
   static constexpr int GC = 32 * HG;
   static constexpr int PADK = sizeof(T) == 2 ? 16 : 8;                 // pad of k-contiguous images read with 16-byte fragments
   static constexpr int LDT = 3 * GC + PADK;                            // q|k|v (then dq|dk|dv) tile [64][LDT]
@@ -905,7 +914,7 @@ template <typename T, int C> struct AttnBStage {
 };
 
 template <typename T, int C>
-__global__ __launch_bounds__(256, 1) void swin_attn_bwd_kernel(AttnBArgs p) {
+__global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(AttnBArgs p) {
   typedef AttnBCfg<T, C> G;
   constexpr int KS = G::KS, NF = G::NF, HG = G::HG, GC = G::GC, KSTEP = G::KSTEP, ND = Chain<T>::ND, LK = Mma<T>::LANE_K;
   constexpr int VN = Vec<T>::N;
