@@ -408,6 +408,8 @@ static int upconv_fwd_launch(const void* X, const void* Wf, const float* bias, v
 }
 bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        int dtype, hipStream_t st);   // conv_ws.hip
+bool upconv_fwd_ps_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
+                       int dtype, hipStream_t st);   // conv_ps.hip
 bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
 bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                           long long y_bs, long long y_ts, long long y_ps, int dtype, hipStream_t st);
@@ -426,6 +428,8 @@ extern "C" int stj_upconv_fwd(const void* X, const void* Wf, const float* bias, 
   if (e) return e;
   if (stj_is16(dtype) && ws_enabled() && upconv_fwd_ws_try(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, dtype, stream))
     return stj_check_launch("stj_upconv_fwd(ws)");
+  if (stj_is16(dtype) && ws_enabled() && upconv_fwd_ps_try(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, dtype, stream))
+    return stj_check_launch("stj_upconv_fwd(ps)");
   if (dtype == STJ_F16) return upconv_fwd_launch<f16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream);
   return dtype == STJ_BF16 ? upconv_fwd_launch<bf16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream)
                            : upconv_fwd_launch<float>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream);

@@ -1,0 +1,195 @@
+// Wide-channel layers of the decoder (Cin = 192, 384: upconv_2_0 / upconv_3_0) -- "phase-per-wave, streamed weights".
+// (reference op: UpSampling3D(1,2,2) -> Conv2D 3x3 SAME + bias -> ELU, modules.py:746-748,732-735; tap algebra in conv.hip)
+//
+// The weight-stationary kernels of conv_ws.hip keep all 4 tap matrices of a phase in VGPRs, which stops at Cin = 128.  The generic
+// kernel of conv.hip that served the two wide layers re-staged 8 (phase,tap) weight slots through LDS three times per 32-channel
+// chunk (6 barriers per chunk, 0.64 LDS fragment reads per MFMA, 16-byte row padding with bank conflicts) and ran at 11 % of the
+// MFMA peak.  Here, per 32-channel chunk:
+//   * wave w owns output phase (a,b) = (w>>1, w&1) of an 8x16 low-res tile and ALL 8 tile rows: 8 x FN accumulator fragments;
+//   * its 4 tap matrices of the chunk (4 x FN fragments) come straight from global / L2 into VGPRs, prefetched one chunk ahead --
+//     weights never touch LDS (the 4 waves need disjoint matrices, so an LDS copy would be shared by nobody);
+//   * the input halo chunk (10 x 18 pixels x 32 channels) is double buffered in LDS, prefetched through registers one chunk ahead;
+//     a halo row fragment is read once and feeds the r = 0 tap of tile row j and the r = 1 tap of row j - 1:
+//     18 ds_read_b128 per 32 FN MFMAs (0.14 reads per MFMA at FN = 4), one barrier per chunk;
+//   * bias + ELU epilogue through an LDS stage that aliases the halo buffers, 16-byte coalesced stores.
+#include "common.h"
+#include <stdlib.h>
+
+#define PS_TH 8
+#define PS_TW 16
+#define PS_HW (PS_TW + 2)
+#define PS_HH (PS_TH + 2)
+#define PS_KC 32
+
+template <typename T, int FN, int MINB>
+__global__ __launch_bounds__(256, MINB) void upconv_fwd_ps_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
+                                                                  const float* __restrict__ bias, T* __restrict__ Y,
+                                                                  int F, int Hi, int Wi, int Cin, int Cout) {
+  constexpr int LDK = PS_KC + 16;                  // 96-byte pixel stride: 2 (mod 4) 16-byte slots, conflict-free b128 fragment reads
+  constexpr int CT = FN * 16, LDO = CT + 8;
+  constexpr int HPIX = PS_HH * PS_HW;              // 180
+  constexpr int NCH = (HPIX * 4 + 255) / 256;      // 16-byte chunks per thread per halo chunk (3)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* halo0 = reinterpret_cast<T*>(smem_raw);
+  T* halo1 = halo0 + HPIX * LDK;
+  T* ostage = reinterpret_cast<T*>(smem_raw);      // aliases the halo buffers after the last chunk
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int a = w >> 1, b = w & 1;
+  const int g = lane >> 4, ln = lane & 15;
+  const int tiles_x = (Wi + PS_TW - 1) / PS_TW, tiles_y = (Hi + PS_TH - 1) / PS_TH;
+  int bid = blockIdx.x;
+  const int tx0 = (bid % tiles_x) * PS_TW; bid /= tiles_x;
+  const int ty0 = (bid % tiles_y) * PS_TH; const int f = bid / tiles_y;
+  const int n0 = blockIdx.y * CT;
+  const int nch = Cin / PS_KC;
+  const T* Xf = X + (long long)f * Hi * Wi * Cin;
+
+  f32x4 acc[PS_TH][FN];
+#pragma unroll
+  for (int j = 0; j < PS_TH; ++j)
+#pragma unroll
+    for (int n = 0; n < FN; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-thread halo chunk geometry (does not depend on the channel chunk)
+  long long hoff[NCH]; bool hin[NCH]; int hlds[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int q = tid + i * 256;
+    const int px = q >> 2, ch = (q & 3) * 8;
+    const int gy = ty0 + px / PS_HW - 1, gx = tx0 + px % PS_HW - 1;
+    hin[i] = q < HPIX * 4 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+    hoff[i] = hin[i] ? ((long long)gy * Wi + gx) * Cin + ch : 0;      // out-of-image pixels load pixel 0 and are zeroed on the way to LDS
+    hlds[i] = q < HPIX * 4 ? px * LDK + ch : -1;
+  }
+  long long woff[FN];
+#pragma unroll
+  for (int n = 0; n < FN; ++n) woff[n] = ((long long)(a * 8 + b * 4) * Cout + n0 + n * 16 + ln) * Cin + g * 8;    // Cout % CT == 0 (dispatch)
+  const long long wtap = (long long)Cout * Cin;
+
+  uint4 pre[NCH];
+  auto ld_halo = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      pre[i] = *reinterpret_cast<const uint4*>(Xf + hoff[i] + c0);      // unconditional (no branch, no vmcnt(0) per load)
+    }
+  };
+  auto st_halo = [&](T* h) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (hlds[i] >= 0) *reinterpret_cast<uint4*>(h + hlds[i]) = hin[i] ? pre[i] : make_uint4(0, 0, 0, 0);
+  };
+  auto ld_w = [&](int c0, s16x8 (&wv)[4][FN]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int n = 0; n < FN; ++n) {
+        wv[t][n] = *reinterpret_cast<const s16x8*>(Wf + woff[n] + t * wtap + c0);
+      }
+  };
+  auto compute = [&](const T* h, const s16x8 (&wv)[4][FN]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int hr = 0; hr <= PS_TH; ++hr) {
+        const s16x8 xb = *reinterpret_cast<const s16x8*>(h + ((hr + a) * PS_HW + ln + b + s) * LDK + g * 8);
+        if (hr < PS_TH) {
+#pragma unroll
+          for (int n = 0; n < FN; ++n) acc[hr][n] = Mma<T>::mma(wv[s][n], xb, acc[hr][n]);                 // r = 0: D[cout][pixel]
+        }
+        if (hr >= 1) {
+#pragma unroll
+          for (int n = 0; n < FN; ++n) acc[hr - 1][n] = Mma<T>::mma(wv[2 + s][n], xb, acc[hr - 1][n]);     // r = 1
+        }
+      }
+  };
+
+  s16x8 w0[4][FN], w1[4][FN];
+  ld_w(0, w0);
+  ld_halo(0);
+  st_halo(halo0);
+  __syncthreads();
+  for (int c = 0; c < nch; c += 2) {
+    int cn = min(c + 1, nch - 1) * PS_KC;          // (the last prefetch re-reads the last chunk: unconditional loads keep the
+    ld_w(cn, w1);                                  //  register arrays out of scratch)
+    ld_halo(cn);
+    compute(halo0, w0);
+    st_halo(halo1);
+    __syncthreads();
+    if (c + 1 >= nch) break;
+    cn = min(c + 2, nch - 1) * PS_KC;
+    ld_w(cn, w0);
+    ld_halo(cn);
+    compute(halo1, w1);
+    st_halo(halo0);
+    __syncthreads();
+  }
+  __syncthreads();                                 // (halo stores of the dangling prefetch are done: the stage may overwrite them)
+
+  // ---- bias + ELU into the stage: lane holds couts n*16 + 4g .. +3 of output pixel (2j + a, 2 ln + b) ----
+#pragma unroll
+  for (int n = 0; n < FN; ++n) {
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = n0 + n * 16 + g * 4 + r;
+      bv[r] = co < Cout ? bias[co] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < PS_TH; ++j) {
+      const uint32_t p0 = pack2<T>(elu_bf(acc[j][n][0] + bv[0]), elu_bf(acc[j][n][1] + bv[1]));
+      const uint32_t p1 = pack2<T>(elu_bf(acc[j][n][2] + bv[2]), elu_bf(acc[j][n][3] + bv[3]));
+      *reinterpret_cast<uint2*>(ostage + ((2 * j + a) * (2 * PS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int SEG = CT / 8;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    T* Yf = Y + (long long)f * Ho * Wo * Cout;
+    for (int q = tid; q < 2 * PS_TH * 2 * PS_TW * SEG; q += 256) {
+      const int sg = q % SEG, p = q / SEG;
+      const int oy = 2 * ty0 + p / (2 * PS_TW), ox = 2 * tx0 + p % (2 * PS_TW), co = n0 + sg * 8;
+      if (oy < Ho && ox < Wo && co < Cout)
+        *reinterpret_cast<uint4*>(Yf + ((long long)oy * Wo + ox) * Cout + co) = *reinterpret_cast<const uint4*>(ostage + p * LDO + sg * 8);
+    }
+  }
+}
+
+template <typename T, int FN, int MINB>
+static bool fwd_ps_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  constexpr int LDK = PS_KC + 16, CT = FN * 16, LDO = CT + 8;
+  const size_t lds_h = (size_t)2 * PS_HH * PS_HW * LDK * 2, lds_o = (size_t)2 * PS_TH * 2 * PS_TW * LDO * 2;
+  const size_t lds = lds_h > lds_o ? lds_h : lds_o;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)upconv_fwd_ps_kernel<T, FN, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    attr_set = true;
+  }
+  const int tiles = ((Wi + PS_TW - 1) / PS_TW) * ((Hi + PS_TH - 1) / PS_TH) * F;
+  hipLaunchKernelGGL((upconv_fwd_ps_kernel<T, FN, MINB>), dim3(tiles, (Cout + CT - 1) / CT), dim3(256), lds, st, (const T*)X, (const T*)Wf, bias,
+                     (T*)Y, F, Hi, Wi, Cin, Cout);
+  return true;
+}
+
+template <typename T>
+static bool fwd_ps_try_t(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  static int fn = -1;
+  if (fn < 0) { const char* e = getenv("STJ_PS_FN"); fn = e ? atoi(e) : 0; }
+  // measured (tools/bench_conv.py, us for 384->192 @16^2 / 192->128 @32^2, F = 64; generic kernel 113 / 140): FN = 2, two workgroups
+  // per CU: 64 / 93;  FN = 3: 84 / 137;  FN = 4 (one wave per SIMD): 105 / 128.  At FN = 2 the kernel moves ~6 TB/s from L2 (each
+  // workgroup streams 32 KB of weights + 11.5 KB of halo per 4.2 MFLOP chunk), which is where the 64x64 GEMM tiles saturate too.
+  int use = fn ? fn : 2;
+  if (Cout % (16 * use)) return false;
+  if (use == 4) return fwd_ps_launch<T, 4, 1>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, st);
+  if (use == 3) return fwd_ps_launch<T, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, st);
+  return fwd_ps_launch<T, 2, 2>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, st);
+}
+// true when this kernel took the problem: 16-bit, ELU, Cin a multiple of 32 above the weight-stationary range
+bool upconv_fwd_ps_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
+                       int dtype, hipStream_t st) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("STJ_NO_PS"); on = !(e && atoi(e)); }
+  if (!on || act != ACT_ELU || Cin % PS_KC || Cin <= 128 || Cout % 32) return false;
+  return dtype == STJ_F16 ? fwd_ps_try_t<f16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, st) : fwd_ps_try_t<bf16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, st);
+}

@@ -41,8 +41,14 @@ for e in prof.events():
         else:
             chain.append(q.name)
         q = q.cpu_parent
-    shape = ''
-    key = (e.name, ' <- '.join(chain))
+    q, src = e, ''
+    while q is not None and not src:
+        for fr in (q.stack or []):
+            if 'strajnet_amd/' in fr:
+                src = fr.split('strajnet_amd/')[-1].strip()
+                break
+        q = q.cpu_parent
+    key = (e.name, ' <- '.join(chain[:2]) + '  @ ' + src)
     agg[key][0] += e.self_device_time_total
     agg[key][1] += 1
 tot = sum(v[0] for v in agg.values())
