@@ -47,6 +47,13 @@ int stj_gemm(const void* A, const void* B, void* C, const float* bias, const voi
              long long sBias1, long long sBias2, long long sRes1, long long sRes2, long long ldres,
              int act, float alpha, int dtype, int c_f32, int accumulate, int splitk,
              int nkb, long long sAkb, long long sBkb, hipStream_t stream);
+/* Grouped launch.  Between stj_gemm_group_begin() and stj_gemm_group_end(stream) on one host thread, stj_gemm calls are RECORDED
+ * (arguments validated, their `stream` ignored) and launched by _end as ONE kernel per 4 problems of equal dtype (64x64 or 32x32
+ * tiles): the input and weight gradient of a Dense layer (tape.gradient of modules.py:36-37 etc.), the q / k / v projections of a
+ * tfa MultiHeadAttention (trajNet.py:33,71,195), dP / dV and dQ / dK of an attention.  The problems of a group must not depend on
+ * each other. */
+int stj_gemm_group_begin(void);
+int stj_gemm_group_end(hipStream_t stream);
 /* out[n] += sum_m X[m,n]  (bias gradients of the conv heads). */
 int stj_colsum(const void* X, float* out, int M, int N, long long ld, int dtype, hipStream_t stream);
 /* f32 <-> bf16 / fp16 copy (16-bit compute copy of the flat parameter buffer). */

@@ -16,6 +16,8 @@ SIGNATURES = {
     'stj_gemm': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci,
                  cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl,
                  ci, cf, ci, ci, ci, ci, ci, cl, cl, vp],
+    'stj_gemm_group_begin': [],
+    'stj_gemm_group_end': [vp],
     'stj_colsum': [vp, vp, ci, ci, cl, ci, vp],
     'stj_cast': [vp, ci, vp, ci, cl, vp],
     'stj_crc32c': [vp, cl, vp],

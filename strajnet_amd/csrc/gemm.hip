@@ -88,22 +88,35 @@ struct Stage {
   }
 };
 
+// LDS bytes of one tile configuration (operand stage and epilogue stage share the buffer)
 template <typename T, int BM, int BN, int WM, int WN, bool TA, bool TB>
-__global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? ((!TA && !TB) ? 4 : 5) : 1) void gemm_kernel(GemmArgs p) {
+struct GemmSmem {
+  static constexpr int BK = 128 / sizeof(T);
+  static constexpr int LD = BK + LdsPad<T>::P;
+  static constexpr int LDTA = BM + PadT<T>::P, LDTB = BN + PadT<T>::P;
+  static constexpr int FM = BM / (16 * WM);
+  static constexpr int A_ELEMS = TA ? BK * LDTA : BM * LD;
+  static constexpr int B_ELEMS = ((TB ? BK * LDTB : BN * LD) + 7) / 8 * 8;
+  static constexpr int A_ELEMS_AL = (A_ELEMS + 7) / 8 * 8;
+  static constexpr int EP_ROWS = BM < 64 ? BM : (BM % 64 == 0 ? 64 : FM * 16);
+  static constexpr int LDC = BN + 4;
+  static constexpr int STAGE_BYTES = (A_ELEMS_AL + B_ELEMS) * (int)sizeof(T);
+  static constexpr int EPI_BYTES = EP_ROWS * LDC * 4;
+  static constexpr int BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+};
+
+// One workgroup's share of a GEMM: tile / batch / k-slice (bxi, byi) of a (gdx, gdy) grid.  `smem` has GemmSmem<...>::BYTES bytes,
+// `bias_s` BN floats.  (A function, not the kernel, so that gemm_group_kernel below can run tiles of SEVERAL problems in one launch.)
+template <typename T, int BM, int BN, int WM, int WN, bool TA, bool TB>
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bxi, const int byi, const int gdx, const int gdy,
+                                          unsigned char* smem, float* bias_s) {
   constexpr int BK = 128 / sizeof(T);
   constexpr int LD = BK + LdsPad<T>::P;
   constexpr int LDTA = BM + PadT<T>::P, LDTB = BN + PadT<T>::P;
   constexpr int FM = BM / (16 * WM), FN = BN / (16 * WN);
-  constexpr int A_ELEMS = TA ? BK * LDTA : BM * LD;
-  constexpr int B_ELEMS = ((TB ? BK * LDTB : BN * LD) + 7) / 8 * 8;
-  constexpr int A_ELEMS_AL = (A_ELEMS + 7) / 8 * 8;
+  constexpr int A_ELEMS_AL = GemmSmem<T, BM, BN, WM, WN, TA, TB>::A_ELEMS_AL;
   constexpr int EP_ROWS = BM < 64 ? BM : (BM % 64 == 0 ? 64 : FM * 16);      // a wave's rows must lie inside one epilogue pass
   constexpr int LDC = BN + 4;
-  constexpr int STAGE_BYTES = (A_ELEMS_AL + B_ELEMS) * (int)sizeof(T);
-  constexpr int EPI_BYTES = EP_ROWS * LDC * 4;
-  constexpr int SMEM = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-  __shared__ float bias_s[BN];            // bias of this column tile: ONE coalesced load instead of per-element global loads in the epilogue
   T* As = reinterpret_cast<T*>(smem);
   T* Bs = As + A_ELEMS_AL;
   float* Cs = reinterpret_cast<float*>(smem);
@@ -114,12 +127,12 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? ((!
   // Work map.  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  For split-K GEMMs
   // (weight gradients: 64x64 output tiles, every k-slice of X and dY is needed by ALL tiles) the tiles of one k-slice are
   // therefore given consecutive slots of the SAME XCD, so a slice is fetched into one L2 once instead of by every XCD.
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (p.splitk > 1 && (gridDim.y & 7) == 0) {
-    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+  int bx = bxi, by = byi;
+  if (p.splitk > 1 && (gdy & 7) == 0) {
+    const int lin = bxi + gdx * byi;
     const int xcd = lin & 7, slot = lin >> 3;
-    bx = slot % gridDim.x;
-    by = (slot / gridDim.x) * 8 + xcd;
+    bx = slot % gdx;
+    by = (slot / gdx) * 8 + xcd;
   }
   const int tm = bx / tiles_n, tn = bx % tiles_n;
   const int z = by / p.splitk, ks = by % p.splitk;
@@ -272,6 +285,63 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? ((!
       }
     }
     __syncthreads();
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool TA, bool TB>
+__global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? ((!TA && !TB) ? 4 : 5) : 1) void gemm_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GemmSmem<T, BM, BN, WM, WN, TA, TB>::BYTES];
+  __shared__ float bias_s[BN];            // bias of this column tile: ONE coalesced load instead of per-element global loads in the epilogue
+  gemm_body<T, BM, BN, WM, WN, TA, TB>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem, bias_s);
+}
+
+// ---- grouped launch: up to GG_MAX independent GEMMs (same dtype, 64x64 or 32x32 tiles, any operand orientation) in ONE kernel ----
+// The small layers of the hot path (agent encoder, FG-MSA, the cross-attentions, the 16x16 Swin stage) form dependent chains of
+// 5-15 us launches in which the input gradient and the weight gradient of a Dense layer, the dP / dV and dQ / dK products of an
+// attention, or the q / k / v projections are independent of each other but cost a link of the chain each.  A group puts the tiles
+// of such problems behind one another in one grid: problem i owns workgroups [start[i], start[i+1]) (starts are multiples of 8 so
+// that the XCD-aware work map of split-K problems still sees its own XCD).
+#define GG_MAX 4
+struct GemmGroup {
+  GemmArgs p[GG_MAX];
+  int start[GG_MAX + 1], gx[GG_MAX], gy[GG_MAX], cfg[GG_MAX];      // cfg = (32x32 tiles ? 4 : 0) + 2 TA + TB
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void gemm_group_kernel(GemmGroup g) {
+  constexpr int B0 = GemmSmem<T, 64, 64, 2, 2, false, false>::BYTES, B1 = GemmSmem<T, 64, 64, 2, 2, true, true>::BYTES;
+  constexpr int B2 = GemmSmem<T, 64, 64, 2, 2, true, false>::BYTES, B3 = GemmSmem<T, 64, 64, 2, 2, false, true>::BYTES;
+  constexpr int BA = B0 > B1 ? B0 : B1, BB = B2 > B3 ? B2 : B3;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BA > BB ? BA : BB];
+  __shared__ float bias_s[64];
+  // The descriptor is read straight from the kernarg segment with scalar loads: indexing the by-value parameter `g` with a
+  // run-time i would make the compiler copy all of it to scratch (1.1 KB per lane, every p.field a scratch load).
+  typedef const __attribute__((address_space(4))) GemmGroup* KG;
+  KG kg = (KG)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)g;
+  const int bid = blockIdx.x;
+  const int n = kg->n;
+  int i = 0;
+  while (i + 1 < n && bid >= kg->start[i + 1]) ++i;
+  const int l = bid - kg->start[i];
+  const int gx = kg->gx[i], gy = kg->gy[i];
+  if (l >= gx * gy) return;                      // padding up to the next multiple of 8
+  typedef const __attribute__((address_space(4))) uint32_t* KW;
+  KW src = (KW)(&kg->p[i]);
+  union { GemmArgs a; uint32_t w[sizeof(GemmArgs) / 4]; } u;
+#pragma unroll
+  for (int j = 0; j < (int)(sizeof(GemmArgs) / 4); ++j) u.w[j] = src[j];
+  const GemmArgs& p = u.a;
+  const int bx = l % gx, by = l / gx;
+  switch (kg->cfg[i]) {
+    case 0: gemm_body<T, 64, 64, 2, 2, false, false>(p, bx, by, gx, gy, smem, bias_s); break;
+    case 1: gemm_body<T, 64, 64, 2, 2, false, true>(p, bx, by, gx, gy, smem, bias_s); break;
+    case 2: gemm_body<T, 64, 64, 2, 2, true, false>(p, bx, by, gx, gy, smem, bias_s); break;
+    case 3: gemm_body<T, 64, 64, 2, 2, true, true>(p, bx, by, gx, gy, smem, bias_s); break;
+    case 4: gemm_body<T, 32, 32, 2, 2, false, false>(p, bx, by, gx, gy, smem, bias_s); break;
+    case 5: gemm_body<T, 32, 32, 2, 2, false, true>(p, bx, by, gx, gy, smem, bias_s); break;
+    case 6: gemm_body<T, 32, 32, 2, 2, true, false>(p, bx, by, gx, gy, smem, bias_s); break;
+    default: gemm_body<T, 32, 32, 2, 2, true, true>(p, bx, by, gx, gy, smem, bias_s); break;
   }
 }
 
@@ -428,8 +498,74 @@ static void launch_tile(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, false, false>), grid, blk, 0, st, p);
 }
 
+// ---- group recording (stj_gemm_group_begin / _end): per host thread ----
+static thread_local bool g_rec = false;
+static thread_local int g_rec_dtype = -1;
+static thread_local int g_rec_blocks = 0;
+static thread_local GemmGroup g_grp;
+
+static int group_flush(hipStream_t st) {
+  if (g_grp.n == 0) return STJ_OK;
+  GemmGroup g = g_grp;
+  const int dtype = g_rec_dtype;
+  g_grp.n = 0; g_rec_blocks = 0; g_rec_dtype = -1;
+  if (g.n == 1) {                                   // a group of one is an ordinary launch
+    const int c = g.cfg[0];
+    dim3 grid(g.gx[0], g.gy[0]);
+#define STJ_ONE(T) \
+    switch (c) { \
+      case 0: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, false, false>), grid, dim3(256), 0, st, g.p[0]); break; \
+      case 1: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, false, true>), grid, dim3(256), 0, st, g.p[0]); break; \
+      case 2: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, true, false>), grid, dim3(256), 0, st, g.p[0]); break; \
+      case 3: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, true, true>), grid, dim3(256), 0, st, g.p[0]); break; \
+      case 4: hipLaunchKernelGGL((gemm_kernel<T, 32, 32, 2, 2, false, false>), grid, dim3(256), 0, st, g.p[0]); break; \
+      case 5: hipLaunchKernelGGL((gemm_kernel<T, 32, 32, 2, 2, false, true>), grid, dim3(256), 0, st, g.p[0]); break; \
+      case 6: hipLaunchKernelGGL((gemm_kernel<T, 32, 32, 2, 2, true, false>), grid, dim3(256), 0, st, g.p[0]); break; \
+      default: hipLaunchKernelGGL((gemm_kernel<T, 32, 32, 2, 2, true, true>), grid, dim3(256), 0, st, g.p[0]); break; \
+    }
+    if (dtype == STJ_BF16) { STJ_ONE(bf16) } else if (dtype == STJ_F16) { STJ_ONE(f16) } else { STJ_ONE(float) }
+#undef STJ_ONE
+    return stj_check_launch("stj_gemm(group of 1)");
+  }
+  const int total = g.start[g.n];
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(gemm_group_kernel<bf16>, dim3(total), dim3(256), 0, st, g);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(gemm_group_kernel<f16>, dim3(total), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL(gemm_group_kernel<float>, dim3(total), dim3(256), 0, st, g);
+  return stj_check_launch("stj_gemm(group)");
+}
+
 template <typename T>
-static int launch_gemm(GemmArgs& p, bool ta, bool tb, hipStream_t st) {
+static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, hipStream_t st) {
+  if (g_rec) {
+    // recorded, not launched: 64x64 tiles, or 32x32 when that leaves most CUs idle; split-K as for a plain launch
+    const long long nb = (long long)p.nb1 * p.nb2;
+    const long long tiles64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * nb;
+    const bool small = !p.accumulate && tiles64 < 256 && p.M >= 32 && p.N >= 32;
+    const int bm = small ? 32 : 64;
+    const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bm - 1) / bm);
+    constexpr int BK = 128 / sizeof(T);
+    if (p.splitk == 0) {
+      const int ktiles = ((p.K + BK - 1) / BK) * p.nkb;
+      long long s2 = (768 + tiles * nb - 1) / (tiles * nb);
+      if (s2 > 96) s2 = 96;
+      if (s2 > ktiles / 2) s2 = ktiles / 2;
+      if (s2 < 1) s2 = 1;
+      if (s2 >= 8 && nb == 1) s2 = s2 / 8 * 8;
+      p.splitk = (int)s2;
+    }
+    const long long gy = nb * p.splitk;
+    if (tiles * gy > (1 << 20)) { stj_set_error("stj_gemm: problem too large for a group"); return STJ_EINVAL; }
+    if (g_grp.n == GG_MAX || (g_grp.n > 0 && g_rec_dtype != dtype)) { int e = group_flush(st); if (e) return e; }
+    const int i = g_grp.n++;
+    g_rec_dtype = dtype;
+    g_grp.p[i] = p;
+    g_grp.gx[i] = (int)tiles; g_grp.gy[i] = (int)gy;
+    g_grp.cfg[i] = (small ? 4 : 0) + (ta ? 2 : 0) + (tb ? 1 : 0);
+    g_grp.start[i] = g_rec_blocks;
+    g_rec_blocks += (int)((tiles * gy + 7) / 8 * 8);
+    g_grp.start[i + 1] = g_rec_blocks;
+    return STJ_OK;
+  }
   if constexpr (sizeof(T) == 2) {
     if (linear_rs_try<T>(p, ta, tb, st)) return stj_check_launch("stj_gemm(rs)");
   }
@@ -518,11 +654,25 @@ extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias
   if (nkb > 1) { p.vecA = p.vecA && (sAkb * es) % 16 == 0; p.vecB = p.vecB && (sBkb * es) % 16 == 0; }
   p.vecC = al(C, c_f32 ? 4 : es, ldc, sCb1, sCb2);
   p.vecR = res ? al(res, es, ldres, sRes1, sRes2) : 0;
-  if (dtype == STJ_BF16) return launch_gemm<bf16>(p, ta, tb, stream);
-  if (dtype == STJ_F16) return launch_gemm<f16>(p, ta, tb, stream);
-  if (dtype == STJ_F32) return launch_gemm<float>(p, ta, tb, stream);
+  if (dtype == STJ_BF16) return launch_gemm<bf16>(p, ta, tb, dtype, stream);
+  if (dtype == STJ_F16) return launch_gemm<f16>(p, ta, tb, dtype, stream);
+  if (dtype == STJ_F32) return launch_gemm<float>(p, ta, tb, dtype, stream);
   stj_set_error("stj_gemm: bad dtype %d", dtype);
   return STJ_EINVAL;
+}
+
+// Group launch: between stj_gemm_group_begin() and stj_gemm_group_end(stream) on one host thread, stj_gemm calls are RECORDED
+// (arguments validated, `stream` ignored) and launched by _end as one kernel per GG_MAX problems of equal dtype.  The problems of a
+// group must be independent of each other (no output of one is an operand of another).
+extern "C" int stj_gemm_group_begin(void) {
+  if (g_rec) { stj_set_error("stj_gemm_group_begin: already recording"); return STJ_EINVAL; }
+  g_rec = true; g_grp.n = 0; g_rec_blocks = 0; g_rec_dtype = -1;
+  return STJ_OK;
+}
+extern "C" int stj_gemm_group_end(hipStream_t stream) {
+  if (!g_rec) { stj_set_error("stj_gemm_group_end: not recording"); return STJ_EINVAL; }
+  g_rec = false;
+  return group_flush(stream);
 }
 
 // ---- column sums: out[n] += sum_m X[m, n]  (bias gradients; out is f32, accumulated atomically) ----

@@ -435,7 +435,7 @@ class STrajNet:
         y = self._ln(y, name + '/norm', 1e-5)
         return y.view(B, (H // 4) ** 2, -1)
 
-    def _encoder(self, ogm, map_img, flow):
+    def _encoder(self, ogm, map_img, flow, hook=None):
         """SwinTransformerEncoder.forward_features (modules.py:570-624), sep_encode/flow_sep/use_flow branch."""
         B = ogm.shape[0]
         C, P = self.stage_dim[0], self.P
@@ -478,6 +478,8 @@ class STrajNet:
             x, res = self._basic_layer(x, f'layers{i}', B, r, depths[i], heads[i], i < 2, add=joined_flow_x if i == 0 else None)
             if i == 0:
                 res_list.append(crop(flow_res, r, c) if self.large_ogm else flow_res)
+                if hook is not None:
+                    hook()
             res_list.append(crop(res, r, c) if self.large_ogm else res)
         return res_list
 
@@ -487,15 +489,16 @@ class STrajNet:
         G = 8
         gc = C // G
         HW = Hh * Ww
-        q = self._dense(x, 'fg_msa/proj_q')
+        with ops.gemm_group():           # three independent 1x1 convs of x (k, v use the unsampled x: App. D-3), one launch
+            q = self._dense(x, 'fg_msa/proj_q')
+            k = self._dense(x, 'fg_msa/proj_k')
+            v = self._dense(x, 'fg_msa/proj_v')
         o = ops.grouped_conv3(q, self._p('fg_msa/conv_offset_0/kernel'), self._p('fg_msa/conv_offset_0/bias'), G)
         o = ops.gelu(self._ln(o, 'fg_msa/conv_norm', 1e-3))
         # regroup [B,H,W,G,gc] -> [B,G,HW,gc] then 1x1 conv gc->2 (no bias), tanh * (H/2)
         o = o.view(B, HW, G, gc).permute(0, 2, 1, 3).contiguous()
         off = ops.tanh_scale(self._dense(o, 'fg_msa/conv_offset_proj', bias=False), Hh / 2.0)      # [B,G,HW,2]
         flow_hidden = self._dense(off, 'fg_msa/conv_offset_proj2') if self.fg else None                # [B,G,HW,C]
-        k = self._dense(x, 'fg_msa/proj_k')                                                            # unsampled x (App. D-3)
-        v = self._dense(x, 'fg_msa/proj_v')
         bias = ops.fg_bias(off, self._p('fg_msa/warp_attn_rel_table'), Hh, Ww)
         a = ops.mha_core(q.view(B, HW, C), k.view(B, HW, C), v.view(B, HW, C), G, gc, gc ** -0.5, bias=bias)
         y = self._dense(a.view(B, Hh, Ww, C), 'fg_msa/proj_out')
@@ -505,9 +508,10 @@ class STrajNet:
         """tensorflow_addons MultiHeadAttention with inputs=[query, key] (value=key), eval (trajNet.py:42,80,225)."""
         pq, pk, pv = self._p(pre + '/query_kernel'), self._p(pre + '/key_kernel'), self._p(pre + '/value_kernel')
         hs = pq.shape[-1]
-        q = ops.linear_heads_in(query, pq)
-        k = ops.linear_heads_in(key, pk)
-        v = ops.linear_heads_in(key, pv)
+        with ops.gemm_group():           # three independent projections, one launch
+            q = ops.linear_heads_in(query, pq)
+            k = ops.linear_heads_in(key, pk)
+            v = ops.linear_heads_in(key, pv)
         o = ops.mha_core(q, k, v, H, hs, 1.0 / math.sqrt(hs), qvalid=qvalid, kvalid=kvalid,
                          drop=self._attn_drop(pre + '/dropout', (q.shape[0], H, q.shape[1], k.shape[1])))
         return ops.linear_heads_out(o, self._p(pre + '/projection_kernel'), self._p(pre + '/projection_bias'))
@@ -591,9 +595,10 @@ class STrajNet:
         def proj_in(x, suffix, shared):           # tfa kernels [3, 384, 42] of the 8 sets, addressed in place (set stride zs)
             p0 = self._zp(suffix)
             return ops.linear_heads_in_z(x, p0.master, p0.c, p0.grad, zs, 8, shared)
-        q = proj_in(query, 'mha/query_kernel', False)                    # [8, B*HW, 126]
-        k = proj_in(key, 'mha/key_kernel', True)                         # [8, B*64, 126]
-        v = proj_in(key, 'mha/value_kernel', True)
+        with ops.gemm_group():
+            q = proj_in(query, 'mha/query_kernel', False)                    # [8, B*HW, 126]
+            k = proj_in(key, 'mha/key_kernel', True)                         # [8, B*64, 126]
+            v = proj_in(key, 'mha/value_kernel', True)
         kvalid = tmask[None].expand(Z, B, A).reshape(Z * B, A).contiguous()
         o = ops.mha_core(q.view(Z * B, HW, 3 * hs), k.view(Z * B, A, 3 * hs), v.view(Z * B, A, 3 * hs), 3, hs,
                          1.0 / math.sqrt(hs), kvalid=kvalid, drop=self._attn_drop('cross_attn_obs/mha/dropout', (Z, B, 3, HW, A)))
@@ -690,14 +695,29 @@ class STrajNet:
         # The agent branch (trajNet: ~45 small launches that occupy a few CUs each) is independent of the raster encoder up to the
         # cross-attention: it is forked onto a side stream here and joined there, so it overlaps with the Swin stages; autograd
         # replays the fork / join in backward and a hipGraph capture records both branches.
-        if self._side is not None:
-            main = torch.cuda.current_stream(self.device)
-            self._side.wait_stream(main)
+        # The agent branch (trajNet: a dependent chain of ~45 small launches that occupy a few CUs each, ~0.4 ms end to end) is
+        # independent of the raster encoder up to the cross-attention: it runs on a side stream, forked HERE.  Its launches are ISSUED
+        # after the encoder's first stage though: a replayed hipGraph starts branches roughly in node-creation order, and issued first
+        # the chain ran alone on an idle GPU for 0.5 ms before the first Swin kernel started (profiles/r02_c_timeline_concurrent.txt).
+        mode = int(os.environ.get('STJ_AGENT_LATE', '2')) if self._side is not None else -1
+        agent = []
+
+        def issue_agent():
+            self._side.wait_event(fork)
             with torch.cuda.stream(self._side):
-                key, tmask = self._traj_net(obs, occ)
-        else:
-            key, tmask = self._traj_net(obs, occ)
-        res_list = self._encoder(ogm, map_img, flow)
+                agent.extend(self._traj_net(obs, occ))
+        if mode >= 0:
+            main = torch.cuda.current_stream(self.device)
+            fork = torch.cuda.Event()
+            fork.record(main)
+        if mode == 0:
+            issue_agent()
+        elif mode < 0:
+            agent.extend(self._traj_net(obs, occ))
+        res_list = self._encoder(ogm, map_img, flow, hook=issue_agent if mode == 2 else None)
+        if mode == 1:
+            issue_agent()
+        key, tmask = agent
         fold = self._fold_partials
         if self.cut_encoder and torch.is_grad_enabled():
             # data-parallel overlap: detach here; backward() then ends at these leaves (the tail bucket is complete and can be

@@ -21,6 +21,32 @@ def call(name, *args):
         return _raw_call(name, *args)
     prof.record(name, args, lambda: _raw_call(name, *args))
 
+
+GROUP_GEMMS = os.environ.get('STJ_GEMM_GROUP', '1') != '0'
+_GROUP_MAX_ROWS = int(os.environ.get('STJ_GEMM_GROUP_ROWS', '16384'))      # at and above: the row-streaming kernel's range (gemm.hip)
+_GROUP_DEPTH = [0]
+
+
+class gemm_group:
+    """`with gemm_group():` -- the stj_gemm calls inside (independent of each other, same stream) are recorded and leave as one
+    launch (stj_gemm_group_begin / _end).  A no-op while bench.py's per-kernel timing pass is on, and when nested."""
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.on = self.enabled and GROUP_GEMMS and prof.ACTIVE is None and _GROUP_DEPTH[0] == 0
+        _GROUP_DEPTH[0] += 1
+        if self.on:
+            _raw_call('stj_gemm_group_begin')
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _GROUP_DEPTH[0] -= 1
+        if self.on:
+            _raw_call('stj_gemm_group_end', _st())
+        return False
+
+
 ACT_NONE, ACT_GELU, ACT_ELU = 0, 1, 2
 U_GELU, U_ELU, U_TANHS = 1, 2, 3
 vp = ctypes.c_void_p
@@ -299,15 +325,18 @@ class _Linear(torch.autograd.Function):
         else:
             dpre = dy2
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x2)
-            gemm(dpre, wc, dx, M, K, N, (0, 0, N, 1), (0, 0, 1, N), (0, 0, K), dt)        # dx = dpre W^T
-            dx = dx.view(ctx.xshape)
-        with wgrad_stream(1, x2, dpre):
-            gw = ctx.gw if ctx.fold is None else zeros_f32((K, N), x2.device)
-            gemm(x2, dpre, gw, K, N, M, (0, 0, 1, K), (0, 0, N, 1), (0, 0, N), dt, c_f32=1, accumulate=1,
-                 splitk=0, colsum=ctx.gb)                                 # dW += x^T dpre ; db += 1^T dpre (fused)
-            if ctx.fold is not None:
+        gw = ctx.gw if ctx.fold is None else zeros_f32((K, N), x2.device)
+        # the two products are independent: one grouped launch for the small layers (big ones keep the row-streaming dgrad kernel)
+        with gemm_group(M < _GROUP_MAX_ROWS and not (_WG_MODE & 1)):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x2)
+                gemm(dpre, wc, dx, M, K, N, (0, 0, N, 1), (0, 0, 1, N), (0, 0, K), dt)        # dx = dpre W^T
+                dx = dx.view(ctx.xshape)
+            with wgrad_stream(1, x2, dpre):
+                gemm(x2, dpre, gw, K, N, M, (0, 0, 1, K), (0, 0, N, 1), (0, 0, N), dt, c_f32=1, accumulate=1,
+                     splitk=0, colsum=ctx.gb)                                 # dW += x^T dpre ; db += 1^T dpre (fused)
+        if ctx.fold is not None:
+            with wgrad_stream(1, x2, dpre):
                 ctx.fold(gw)
         dres = dy if ctx.has_res else None
         return dx, None, None, None, None, None, None, dres, None
@@ -344,22 +373,23 @@ class _HeadsIn(torch.autograd.Function):
         Z, R, H, I, hs, zstride, shared_x, xshape = ctx.dims
         dt = _dt(x)
         dy = dy.contiguous()
-        dx = None
-        if ctx.needs_input_grad[0]:
-            # dx[z] = sum_h dy[z][:, h-slice] W[z,h]^T : the head sum is the K-segment loop of ONE GEMM per z
-            if shared_x:
-                acc = zeros_f32((R, I), x.device)         # the Z sets accumulate with f32 atomics
-                gemm(dy, ctx.w0, acc, R, I, hs, (R * H * hs, 0, H * hs, 1), (zstride, 0, 1, hs), (0, 0, I), dt, nb=(Z, 1), c_f32=1,
-                     accumulate=1, kseg=(H, hs, I * hs))
+        dx = acc = None
+        with gemm_group(R < _GROUP_MAX_ROWS and not (_WG_MODE & 1)):          # input and weight gradient: independent products
+            if ctx.needs_input_grad[0]:
+                # dx[z] = sum_h dy[z][:, h-slice] W[z,h]^T : the head sum is the K-segment loop of ONE GEMM per z
                 dx = torch.empty(xshape, dtype=x.dtype, device=x.device)
-                call('stj_cast', _p(acc), 0, _p(dx), dt, R * I, _st())
-            else:
-                dx = torch.empty(xshape, dtype=x.dtype, device=x.device)
-                gemm(dy, ctx.w0, dx, R, I, hs, (R * H * hs, 0, H * hs, 1), (zstride, 0, 1, hs), (R * I, 0, I), dt, nb=(Z, 1),
-                     kseg=(H, hs, I * hs))
-        with wgrad_stream(1, x, dy):      # dW[z,h] += x_z^T dy_z[:, h-slice], straight into the flat gradient buffer
-            gemm(x, dy, ctx.gw0, I, hs, R, (0 if shared_x else R * I, 0, 1, I), (R * H * hs, hs, H * hs, 1), (zstride, I * hs, hs), dt,
-                 nb=(Z, H), c_f32=1, accumulate=1, splitk=0)
+                if shared_x:
+                    acc = zeros_f32((R, I), x.device)         # the Z sets accumulate with f32 atomics
+                    gemm(dy, ctx.w0, acc, R, I, hs, (R * H * hs, 0, H * hs, 1), (zstride, 0, 1, hs), (0, 0, I), dt, nb=(Z, 1), c_f32=1,
+                         accumulate=1, kseg=(H, hs, I * hs))
+                else:
+                    gemm(dy, ctx.w0, dx, R, I, hs, (R * H * hs, 0, H * hs, 1), (zstride, 0, 1, hs), (R * I, 0, I), dt, nb=(Z, 1),
+                         kseg=(H, hs, I * hs))
+            with wgrad_stream(1, x, dy):      # dW[z,h] += x_z^T dy_z[:, h-slice], straight into the flat gradient buffer
+                gemm(x, dy, ctx.gw0, I, hs, R, (0 if shared_x else R * I, 0, 1, I), (R * H * hs, hs, H * hs, 1), (zstride, I * hs, hs),
+                     dt, nb=(Z, H), c_f32=1, accumulate=1, splitk=0)
+        if acc is not None:
+            call('stj_cast', _p(acc), 0, _p(dx), dt, R * I, _st())
         return (dx,) + (None,) * 6
 
 
@@ -415,24 +445,27 @@ class _LinearZ(torch.autograd.Function):
             call('stj_unary_bwd', _p(dy), _p(y), _p(dpre), dy.numel(), U_ELU, 0.0, dt, _st())
         else:
             dpre = dy
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if shared_x and R >= 4096:
-                # dx[r,:] = sum_z dpre[z,r,:] W_z^T : ONE GEMM whose contraction runs over the Z segments (z, n) -- no atomics
-                dx = torch.empty(xshape, dtype=x.dtype, device=x.device)
-                gemm(dpre, ctx.w0, dx, R, K, N, (0, 0, N, 1), (0, 0, 1, N), (0, 0, K), dt, kseg=(Z, R * N, wstride))
-            elif shared_x:     # few rows: Z independent launches-in-one fill the GPU better; all z accumulate with f32 atomics
-                acc = zeros_f32((R, K), x.device)
-                gemm(dpre, ctx.w0, acc, R, K, N, (0, R * N, N, 1), (0, wstride, 1, N), (0, 0, K), dt, nb=(1, Z), c_f32=1, accumulate=1)
-                dx = acc.to(x.dtype).view(xshape)
-            else:
-                dx = torch.empty_like(x)
-                gemm(dpre, ctx.w0, dx, R, K, N, (0, R * N, N, 1), (0, wstride, 1, N), (0, R * K, K), dt, nb=(1, Z))
-        # dW_z += x_z^T dpre_z ; db_z += column sums (fused)
-        with wgrad_stream(1, x, dpre):
-            gemm(x, dpre, ctx.gw0, K, N, R, (0, 0 if shared_x else R * K, 1, K), (0, R * N, N, 1), (0, gwstride, N), dt,
-                 nb=(1, Z), c_f32=1, accumulate=1, splitk=0, colsum=ctx.gb0, sBias=(0, bstride))
-            if ctx.fold is not None:
+        dx = acc = None
+        with gemm_group(R < _GROUP_MAX_ROWS and not (_WG_MODE & 1)):          # input and weight gradient: independent products
+            if ctx.needs_input_grad[0]:
+                if shared_x and R >= 4096:
+                    # dx[r,:] = sum_z dpre[z,r,:] W_z^T : ONE GEMM whose contraction runs over the Z segments (z, n) -- no atomics
+                    dx = torch.empty(xshape, dtype=x.dtype, device=x.device)
+                    gemm(dpre, ctx.w0, dx, R, K, N, (0, 0, N, 1), (0, 0, 1, N), (0, 0, K), dt, kseg=(Z, R * N, wstride))
+                elif shared_x:     # few rows: Z independent launches-in-one fill the GPU better; all z accumulate with f32 atomics
+                    acc = zeros_f32((R, K), x.device)
+                    gemm(dpre, ctx.w0, acc, R, K, N, (0, R * N, N, 1), (0, wstride, 1, N), (0, 0, K), dt, nb=(1, Z), c_f32=1, accumulate=1)
+                else:
+                    dx = torch.empty_like(x)
+                    gemm(dpre, ctx.w0, dx, R, K, N, (0, R * N, N, 1), (0, wstride, 1, N), (0, R * K, K), dt, nb=(1, Z))
+            # dW_z += x_z^T dpre_z ; db_z += column sums (fused)
+            with wgrad_stream(1, x, dpre):
+                gemm(x, dpre, ctx.gw0, K, N, R, (0, 0 if shared_x else R * K, 1, K), (0, R * N, N, 1), (0, gwstride, N), dt,
+                     nb=(1, Z), c_f32=1, accumulate=1, splitk=0, colsum=ctx.gb0, sBias=(0, bstride))
+        if acc is not None:
+            dx = acc.to(x.dtype).view(xshape)
+        if ctx.fold is not None:
+            with wgrad_stream(1, x, dpre):
                 ctx.fold()
         return (dx,) + (None,) * 12
 
@@ -576,7 +609,7 @@ class _SwinMlp(torch.autograd.Function):
         call('stj_swin_mlp_bwd', _p(x), _p(dy), _p(pg.master), _p(pb.master), _p(pw1.c), _p(pb1.master), _p(pw2.c), _p(dx), _p(h),
              _p(dpre), _p(ln), _p(dys), _p(dg), _p(db), nparts, pstride, M, C, eps, _p(state), site, float(p_drop), rps, dt, _st())
         g2 = dys if dys is not None else dy.view(M, C)
-        with wgrad_stream(1, ln, dpre, h, g2):
+        with wgrad_stream(1, ln, dpre, h, g2), gemm_group(M < _GROUP_MAX_ROWS):
             gemm(ln, dpre, pw1.grad, C, 4 * C, M, (0, 0, 1, C), (0, 0, 4 * C, 1), (0, 0, 4 * C), dt, c_f32=1, accumulate=1,
                  splitk=0, colsum=pb1.grad)                               # dW1 += LN(x)^T dpre ; db1 += 1^T dpre
             gemm(h, g2, pw2.grad, 4 * C, C, M, (0, 0, 1, 4 * C), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1,
@@ -677,7 +710,7 @@ class _SwinAttnHalf(torch.autograd.Function):
             gemm(dq2, pwq.c, dln, M, C, 3 * C, (0, 0, 3 * C, 1), (0, 0, 1, 3 * C), (0, 0, C), dt)         # dln = dqkv Wqkv^T
             call('stj_layernorm_bwd', _p(dln), _p(x), _p(pg.master), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), M, C, 0, 0, 0, 1, 0,
                  _p(dy), np_, ps_, dt, _st())                                                             # + the shortcut gradient
-        with wgrad_stream(1, a2, dys2, ln2, dq2):
+        with wgrad_stream(1, a2, dys2, ln2, dq2), gemm_group(M < _GROUP_MAX_ROWS):
             gemm(a2, dys2, pwp.grad, C, C, M, (0, 0, 1, C), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1, splitk=0,
                  colsum=pbp.grad)                                                                         # dWp += a^T dys ; dbp
             gemm(ln2, dq2, pwq.grad, C, 3 * C, M, (0, 0, 1, C), (0, 0, 3 * C, 1), (0, 0, 3 * C), dt, c_f32=1, accumulate=1,
@@ -819,18 +852,19 @@ class _MhaCore(torch.autograd.Function):
         dt = _dt(q)
         do = do.contiguous()
         dP = torch.empty((Bt, H, Nq, Nk), dtype=torch.float32, device=q.device)
-        # dP[b,h] = dO[b,:,h,:] V[b,:,h,:]^T
-        gemm(do, v, dP, Nq, Nk, d, (Nq * HD, d, HD, 1), (Nk * HD, d, 1, HD), (H * Nq * Nk, Nq * Nk, Nk), dt, nb=(Bt, H), c_f32=1)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        with gemm_group():
+            # dP[b,h] = dO[b,:,h,:] V[b,:,h,:]^T ; dV[b,:,h,:] = P[b,h]^T dO
+            gemm(do, v, dP, Nq, Nk, d, (Nq * HD, d, HD, 1), (Nk * HD, d, 1, HD), (H * Nq * Nk, Nq * Nk, Nk), dt, nb=(Bt, H), c_f32=1)
+            gemm(Pd, do, dv, Nk, d, Nq, (H * Nq * Nk, Nq * Nk, 1, Nk), (Nq * HD, d, HD, 1), (Nk * HD, d, HD), dt, nb=(Bt, H))
         if ctx.drop is not None:        # same mask, re-derived from (state, site); dP is f32
             p_drop, state, site = ctx.drop
             call('stj_dropout', _p(dP), None, _p(dP), dP.numel(), 1, float(p_drop), _p(state), site, 0, _st())
         dS = torch.empty_like(P)
         call('stj_softmax_bwd', _p(P), _p(dP), _p(dS), Bt * H * Nq, Nk, dt, _st())
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        # dV[b,:,h,:] = P[b,h]^T dO ; dQ = scale dS K ; dK = scale dS^T Q
-        gemm(Pd, do, dv, Nk, d, Nq, (H * Nq * Nk, Nq * Nk, 1, Nk), (Nq * HD, d, HD, 1), (Nk * HD, d, HD), dt, nb=(Bt, H))
-        gemm(dS, k, dq, Nq, d, Nk, (H * Nq * Nk, Nq * Nk, Nk, 1), (Nk * HD, d, HD, 1), (Nq * HD, d, HD), dt, nb=(Bt, H), alpha=scale)
-        gemm(dS, q, dk, Nk, d, Nq, (H * Nq * Nk, Nq * Nk, 1, Nk), (Nq * HD, d, HD, 1), (Nk * HD, d, HD), dt, nb=(Bt, H), alpha=scale)
+        with gemm_group():        # dQ = scale dS K ; dK = scale dS^T Q
+            gemm(dS, k, dq, Nq, d, Nk, (H * Nq * Nk, Nq * Nk, Nk, 1), (Nk * HD, d, HD, 1), (Nq * HD, d, HD), dt, nb=(Bt, H), alpha=scale)
+            gemm(dS, q, dk, Nk, d, Nq, (H * Nq * Nk, Nq * Nk, 1, Nk), (Nq * HD, d, HD, 1), (Nk * HD, d, HD), dt, nb=(Bt, H), alpha=scale)
         return dq, dk, dv, (dS if has_bias else None), None, None, None, None, None, None
 
 

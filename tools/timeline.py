@@ -25,3 +25,37 @@ for s, e, st, n in step:
     busy_end = max(busy_end, e)
     print(f'{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {st!s:>6} {gap:7.1f}  {n[:110]}')
 print(f'# GPU idle (no kernel running) inside the step: {idle:.1f} us')
+# ---- "thin" stretches: intervals in which every running kernel is a short one (< THIN us): dependent chains of small launches
+# that run alone, i.e. dispatch-latency-bound time.  Listed when longer than 50 us.
+THIN = 16.0
+ev = []
+for s, e, st, n in step:
+    ev.append((s, 1, (e - s) / 1e3 < THIN, n))
+    ev.append((e, -1, (e - s) / 1e3 < THIN, n))
+ev.sort(key=lambda x: (x[0], x[1]))
+big = small = 0
+cur_start, cur_n, total_thin = None, 0, 0.0
+stretches = []
+prev_t = ev[0][0]
+names = []
+for t, d, is_small, n in ev:
+    thin_now = big == 0                      # (idle counts as thin: nothing substantial is running)
+    if thin_now:
+        total_thin += (t - prev_t) / 1e3
+        if cur_start is None:
+            cur_start, names = prev_t, []
+    elif cur_start is not None:
+        stretches.append((cur_start, prev_t, names)); cur_start = None
+    prev_t = t
+    if is_small:
+        small += d
+        if d > 0 and big == 0:
+            names.append(n.split('(')[0][-40:])
+    else:
+        big += d
+        if big > 0 and cur_start is not None:
+            stretches.append((cur_start, t, names)); cur_start = None
+print(f'# time with no kernel >= {THIN:.0f} us running: {total_thin:.1f} us')
+for a_, b_, nm in stretches:
+    if (b_ - a_) / 1e3 > 50:
+        print(f'#   thin {(a_ - t0) / 1e3:8.1f} .. {(b_ - t0) / 1e3:8.1f}  ({(b_ - a_) / 1e3:6.1f} us, {len(nm)} small kernels)')
