@@ -577,3 +577,54 @@ def test_nadam_step_matches_keras_formula():
         m = b1 * m + (1 - b1) * gd; v = b2 * v + (1 - b2) * gd * gd
         wr = wr - 1e-2 * ((1 - mu_t) * gd / (1 - prod_t) + mu_n * m / (1 - prod_n)) / ((v / (1 - b2 ** t)).sqrt() + eps)
     assert rel_err(w, wr) < 1e-5
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_gemm_group_matches_single_launches(dt):
+    """stj_gemm_group_begin/_end: five GEMMs of different shapes, orientations, batch counts and epilogues recorded into grouped
+    launches (4 + 1) give bit-identical results to five single launches (plain outputs) / the same sums up to f32 atomic order
+    (split-K accumulation).  An empty group and a group of one are legal."""
+    from strajnet_amd import ops
+    code = ops.DTYPE_CODE[dt]
+    dev = 'cuda'
+
+    def r(*shape, seed):
+        g = torch.Generator().manual_seed(seed)
+        return (torch.randn(shape, generator=g) * 0.5).to(dev).to(dt)
+    M, K, N = 300, 96, 130
+    x, w, wt = r(M, K, seed=1), r(K, N, seed=2), r(N, K, seed=3)
+    dy = r(M, N, seed=4)
+    bias = torch.randn(N, device=dev)
+    q, k = r(6, 50, 4 * 32, seed=5), r(6, 40, 4 * 32, seed=6)
+
+    def run(grouped):
+        y1 = torch.empty(M, N, device=dev, dtype=dt)          # NN + bias + ELU
+        y2 = torch.empty(M, N, device=dev, dtype=dt)          # NT (weight stored [N,K])
+        dx = torch.empty(M, K, device=dev, dtype=dt)          # dy w^T
+        gw = torch.zeros(K, N, device=dev)                    # x^T dy, split-K, f32 atomics, + column sums
+        gb = torch.zeros(N, device=dev)
+        S = torch.empty(6, 4, 50, 40, device=dev)             # batched q k^T over (batch, head), f32 out
+        import contextlib
+        with (ops.gemm_group() if grouped else contextlib.nullcontext()):
+            ops.gemm(x, w, y1, M, N, K, (0, 0, K, 1), (0, 0, N, 1), (0, 0, N), code, bias=bias, act=ops.ACT_ELU)
+            ops.gemm(x, wt, y2, M, N, K, (0, 0, K, 1), (0, 0, 1, K), (0, 0, N), code)
+            ops.gemm(dy, w, dx, M, K, N, (0, 0, N, 1), (0, 0, 1, N), (0, 0, K), code)
+            ops.gemm(x, dy, gw, K, N, M, (0, 0, 1, K), (0, 0, N, 1), (0, 0, N), code, c_f32=1, accumulate=1, splitk=0, colsum=gb)
+            ops.gemm(q, k, S, 50, 40, 32, (50 * 128, 32, 128, 1), (40 * 128, 32, 1, 128), (4 * 50 * 40, 50 * 40, 40), code, nb=(6, 4),
+                     alpha=0.25, c_f32=1)
+        torch.cuda.synchronize()
+        return y1, y2, dx, gw, gb, S
+    a, b = run(False), run(True)
+    for i in (0, 1, 2, 5):
+        assert torch.equal(a[i], b[i]), i
+    for i in (3, 4):
+        assert rel_err(b[i], a[i]) < 1e-5, i
+    ref = (x.double() @ w.double())
+    assert rel_err(b[0], F.elu(ref + bias.double())) < tol(dt)
+    assert rel_err(b[3], x.double().t() @ dy.double()) < tol(dt)
+    with ops.gemm_group():
+        pass
+    y = torch.empty(M, N, device=dev, dtype=dt)
+    with ops.gemm_group():
+        ops.gemm(x, w, y, M, N, K, (0, 0, K, 1), (0, 0, N, 1), (0, 0, N), code)
+    assert rel_err(y, ref) < tol(dt)
