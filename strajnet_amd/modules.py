@@ -625,6 +625,8 @@ class STrajNet:
             return ops.upconv(t, self._p(name + '/kernel'), self._p(name + '/bias'), grad_is_pre, x_is_elu_out,
                               prep=self._upconv_prep.get(name))
         x = x.view(8 * B, hb, hb, -1)                                                # frames are TIME-major: f = t*B + b
+        if self._prep_event is not None:                                             # folded kernels come from the side stream
+            torch.cuda.current_stream(self.device).wait_event(self._prep_event)
         x = up(x, 'decoder/upconv_3_0')                                              # [F,2hb,2hb,192]
         if skips is not None:                                                        # computed on the side stream: join
             main = torch.cuda.current_stream(self.device)
@@ -686,15 +688,21 @@ class STrajNet:
             self._dctx = self.dropctx
         ogm, map_img, flow = ogm.float().contiguous(), map_img.float().contiguous(), flow.float().contiguous()
         hb, Cb = self.hb, self.stage_dim[2]
-        # fold the six decoder kernels into their 2x2-tap phase matrices NOW (they depend on the weights only): as the first launches of
-        # the step they run on an idle GPU; issued where they are consumed, each of these tiny launches sat on the critical path of a
-        # decoder branch behind whatever shared the GPU with it (up to 0.8 ms apiece in the batch-32 inference trace)
-        self._upconv_prep = {n: ops.upconv_prep(self._p(n + '/kernel'), self.dtype)
-                             for n in ('decoder/upconv_3_0', 'decoder/upconv_2_0', 'decoder/upconv_1_0', 'decoder/upconv_0_0',
-                                       'decoder/upconvf_1_0', 'decoder/upconvf_0_0')}
-        # The agent branch (trajNet: ~45 small launches that occupy a few CUs each) is independent of the raster encoder up to the
-        # cross-attention: it is forked onto a side stream here and joined there, so it overlaps with the Swin stages; autograd
-        # replays the fork / join in backward and a hipGraph capture records both branches.
+        # fold the six decoder kernels into their 2x2-tap phase matrices NOW (they depend on the weights only): issued where they are
+        # consumed, each of these tiny launches sat on the critical path of a decoder branch behind whatever shared the GPU with it (up
+        # to 0.8 ms apiece in the batch-32 inference trace).  They go to the second side stream: as the first launches of the main
+        # stream, the chain of six delayed the first encoder kernel by ~50 us.
+        names = ('decoder/upconv_3_0', 'decoder/upconv_2_0', 'decoder/upconv_1_0', 'decoder/upconv_0_0', 'decoder/upconvf_1_0',
+                 'decoder/upconvf_0_0')
+        self._prep_event = None
+        if self._side2 is not None:
+            self._side2.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side2):
+                self._upconv_prep = {n: ops.upconv_prep(self._p(n + '/kernel'), self.dtype) for n in names}
+                self._prep_event = torch.cuda.Event()
+                self._prep_event.record(self._side2)
+        else:
+            self._upconv_prep = {n: ops.upconv_prep(self._p(n + '/kernel'), self.dtype) for n in names}
         # The agent branch (trajNet: a dependent chain of ~45 small launches that occupy a few CUs each, ~0.4 ms end to end) is
         # independent of the raster encoder up to the cross-attention: it runs on a side stream, forked HERE.  Its launches are ISSUED
         # after the encoder's first stage though: a replayed hipGraph starts branches roughly in node-creation order, and issued first
