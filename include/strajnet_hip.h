@@ -166,6 +166,12 @@ int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, 
  * ELU'(x) (gradient w.r.t. the producing conv's pre-activation; the producer then skips its own ELU' pass). */
 int stj_outconv_fwd(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                     long long y_bstride, long long y_tstride, long long y_pstride, int dtype, hipStream_t stream);
+/* Both heads in ONE launch (the pair of Conv2D 48->2 of modules.py:767-770 + concat + transpose :838): Y [B,H,W,4*Tn] f32, channel
+ * 4 t + 2 head + o; X0 / X1 the two decoder branches [F,H,W,48], frames f = b*Tn + t (t_major = 0) or t*B + b (t_major = 1).  A
+ * workgroup runs all 16 (waypoint, head) frames of a spatial tile and writes whole 128-byte output lines.  16-bit dtypes, C = 48,
+ * Tn = 8 only (STJ_EUNSUPPORTED otherwise: call stj_outconv_fwd per head). */
+int stj_outconv_pair_fwd(const void* X0, const void* X1, const float* W0, const float* W1, const float* bias0, const float* bias1,
+                         float* Y, int B, int Tn, int H, int W, int C, int t_major, int dtype, hipStream_t stream);
 int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww,
                     int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int elu_in, void* ws,
                     long long ws_bytes, int dtype, hipStream_t stream);

@@ -50,6 +50,7 @@ SIGNATURES = {
     'stj_upconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     'stj_upconv_dgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_upconv_wgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
+    'stj_outconv_pair_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
     'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp, cl, ci, vp],
     'stj_outconv_bwd_workspace_bytes': [],

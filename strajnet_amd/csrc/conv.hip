@@ -662,6 +662,20 @@ extern "C" int stj_outconv_fwd(const void* X, const float* W, const float* bias,
   }
   return stj_check_launch("stj_outconv_fwd");
 }
+// Both heads of the model output in one launch: Y [B,H,W,4*Tn] f32, channel 4 t + 2 head + o; X0 / X1 the two 48-channel decoder
+// branches, frames ordered f = b*Tn + t (t_major = 0) or t*B + b (t_major = 1).  16-bit dtypes, C = 48, Tn = 8 (the hot-path shape);
+// STJ_EUNSUPPORTED otherwise: call stj_outconv_fwd once per head instead.
+bool outconv_pair_fwd_try(const void* X0, const void* X1, const float* W0, const float* W1, const float* b0, const float* b1, float* Y,
+                          int B, int Tn, int Hh, int Ww, int C, int t_major, int dtype, hipStream_t st);
+extern "C" int stj_outconv_pair_fwd(const void* X0, const void* X1, const float* W0, const float* W1, const float* bias0,
+                                    const float* bias1, float* Y, int B, int Tn, int Hh, int Ww, int C, int t_major, int dtype,
+                                    hipStream_t stream) {
+  if (B <= 0 || Tn <= 0) { stj_set_error("outconv_pair: empty problem"); return STJ_EINVAL; }
+  if (stj_is16(dtype) && ws_enabled() && outconv_pair_fwd_try(X0, X1, W0, W1, bias0, bias1, Y, B, Tn, Hh, Ww, C, t_major, dtype, stream))
+    return stj_check_launch("stj_outconv_pair_fwd");
+  stj_set_error("outconv_pair: shape / dtype not covered by the paired kernel");
+  return STJ_EUNSUPPORTED;
+}
 // ws: caller-owned scratch of stj_outconv_bwd_workspace_bytes() bytes (need not be zeroed; per-block dW/db partials of the bf16
 // path live there between its two kernels); without it the slower generic kernel runs.
 extern "C" long long stj_outconv_bwd_workspace_bytes() { return outconv_bwd_ws_bytes(); }

@@ -692,6 +692,252 @@ __global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const T* __restri
   }
 }
 
+// v2 of the forward head (round 2).  The kernel above reads one LDS fragment pair per (output row, tap): 72 ds_read_b128 and 72
+// MFMAs per wave and tile, of which 14 of 16 MFMA rows multiply zeros -- 288 KB of LDS reads per 31 KB tile, and LDS, not HBM, set its
+// pace (2.2 us per tile and CU where the fragment reads alone need 1 us; profiles/r02_c_pmc_step.txt: 51 % of HBM peak).  Here the
+// vertical taps move into the M dimension: A row m = 2 dy + o (6 of 16 rows), one A fragment pair per horizontal tap dx; a halo row is
+// read once per dx (3 fragment pairs) and yields its contributions to the THREE output rows it touches (row - dy), which a lane
+// accumulates in registers: 36 reads and 36 MFMAs per wave and tile.  The dy = 2 contributions sit in the lanes of group g = 1 and are
+// added to those of g = 0 with one cross-lane move per output value.  Halo loads are unconditional (clamped address, zeroed on the
+// way to LDS): no branch per 16-byte chunk.
+template <typename T, int C>
+__global__ __launch_bounds__(256, 3) void outconv_fwd_mfma2_kernel(const T* __restrict__ X, const float* __restrict__ W,
+                                                                   const float* __restrict__ bias, float* __restrict__ Y, int F, int Hh,
+                                                                   int Ww, int Tn, long long y_bs, long long y_ts, long long y_ps, int dbg) {
+  static_assert(C == 48, "specialised for 48 input channels (32 + 16)");
+  constexpr int LDH = C + 32;                      // 160-byte pixels: conflict-free b128 fragment reads
+  constexpr int CPP = C / 8, NCH = (OCM_H * OCM_H * CPP + 255) / 256;
+  __shared__ __attribute__((aligned(16))) T halo[OCM_H * OCM_H * LDH + 64];   // pads + tail stay zero (read by the padded 2nd k-step)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
+  // stationary weights: A row m = ln = 2 dy + o (m < 6), one fragment pair per horizontal tap dx
+  s16x8 a32[3], a16[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int t = (ln >> 1) * 3 + dx, o = ln & 1;
+    float v[8], u[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ln < 6 ? W[(t * C + 8 * g + j) * 2 + o] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] = (ln < 6 && g < 2) ? W[(t * C + 32 + 8 * g + j) * 2 + o] : 0.f;   // channels 32..47, rest zero
+    a32[dx] = __builtin_bit_cast(s16x8, make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])));
+    a16[dx] = __builtin_bit_cast(s16x8, make_uint4(pack2<T>(u[0], u[1]), pack2<T>(u[2], u[3]), pack2<T>(u[4], u[5]), pack2<T>(u[6], u[7])));
+  }
+  const float b0 = bias[0], b1 = bias[1];
+  const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T, ntiles = F * tiles_x * tiles_y;
+  // this thread's halo chunks: geometry is the same for every tile (computed once: the divisions by 6 and 18 per chunk and tile
+  // were ~300 VALU instructions per tile, as much issue time as the MFMA loop)
+  int rel[NCH], ryx[NCH], lds[NCH];
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int q = min(tid + u * 256, OCM_H * OCM_H * CPP - 1);
+    const int px = q / CPP, ch = (q % CPP) * 8;
+    const int ry = px / OCM_H - 1, rx = px % OCM_H - 1;
+    rel[u] = (ry * Ww + rx) * C + ch;
+    ryx[u] = (ry & 0xffff) | (rx << 16);
+    lds[u] = tid + u * 256 < OCM_H * OCM_H * CPP ? px * LDH + ch : -1;
+  }
+  uint4 pre[NCH];
+  bool pin[NCH];
+  auto prefetch = [&](int tile) {
+    int tx, ty, f;
+    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
+    const int y0 = ty * OCM_T, x0 = tx * OCM_T;
+    const T* Xt = X + ((long long)f * Hh + y0) * Ww * C + (long long)x0 * C;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int gy = y0 + (short)(ryx[u] & 0xffff), gx = x0 + (ryx[u] >> 16);
+      pin[u] = (unsigned)gy < (unsigned)Hh && (unsigned)gx < (unsigned)Ww;
+      pre[u] = *reinterpret_cast<const uint4*>(Xt + (pin[u] ? rel[u] : 0));      // (the tile's own first pixel is always in the image)
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NCH; ++u)
+      if (lds[u] >= 0) *reinterpret_cast<uint4*>(halo + lds[u]) = pin[u] ? pre[u] : make_uint4(0, 0, 0, 0);
+  };
+  for (int i = tid; i < OCM_H * OCM_H * LDH + 64; i += 256) halo[i].v = 0;
+  __syncthreads();
+  int tile = blockIdx.x;
+  if (tile < ntiles) { prefetch(tile); commit(); }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles && !(dbg & 4)) prefetch(next);
+    int tx, ty, f;
+    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
+    const int bb = f / Tn, tt = f % Tn;
+    float* Yb = Y + bb * y_bs + tt * y_ts;
+    // halo rows 4w .. 4w+5 -> output rows 4w .. 4w+3.  acc rows: [0],[1] = dy 0 (g = 0) / dy 2 (g = 1);  [2],[3] = dy 1 (g = 0)
+    float pa0[6], pa1[6], pb0[6], pb1[6];
+#pragma unroll
+    for (int hr = 0; hr < 6; ++hr) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!(dbg & 1))
+      {const T* hp = halo + ((4 * w + hr) * OCM_H + ln) * LDH;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const s16x8 x32 = *reinterpret_cast<const s16x8*>(hp + dx * LDH + 8 * g);
+        const s16x8 x16 = *reinterpret_cast<const s16x8*>(hp + dx * LDH + 32 + 8 * g);
+        acc = Mma<T>::mma(a32[dx], x32, acc);
+        acc = Mma<T>::mma(a16[dx], x16, acc);
+      }}
+      pa0[hr] = acc[0]; pa1[hr] = acc[1]; pb0[hr] = acc[2]; pb1[hr] = acc[3];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      // g = 0 lanes: dy 0 of halo row jj + dy 1 of halo row jj + 1;  g = 1 lanes: dy 2 of halo row jj + 2
+      float v0 = g == 0 ? pa0[jj] + pb0[jj + 1] : pa0[jj + 2];
+      float v1 = g == 0 ? pa1[jj] + pb1[jj + 1] : pa1[jj + 2];
+      v0 += __shfl_xor(v0, 16);
+      v1 += __shfl_xor(v1, 16);
+      if (g == 0 && !(dbg & 2)) {
+        float* dst = Yb + ((long long)(ty * OCM_T + 4 * w + jj) * Ww + tx * OCM_T + ln) * y_ps;
+        *reinterpret_cast<float2*>(dst) = make_float2(v0 + b0, v1 + b1);
+      }
+    }
+    __syncthreads();
+    if (next < ntiles) commit();
+    __syncthreads();
+  }
+}
+
+// Both heads in one launch (round 2).  Ablation of the kernel above (tools/bench_outconv.py, STJ_OC_DBG): 124 us per head, of which
+// the MFMA loop 8 us and the OUTPUT STORES 35 us -- 17 MB of results: a frame owns 8 bytes of every 128-byte line of the [B,H,W,32]
+// tensor, so each line is written in 16 pieces by 16 different (head, waypoint) work items.  Here a work item is a SPATIAL tile of
+// one scene: the workgroup runs the 16 (waypoint, head) sub-tiles over it back to back (same halo pipeline, 31 KB per sub-tile) and
+// keeps the results in registers -- lane group g collects the 32 bytes of waypoints 2g, 2g+1 -- so every output pixel leaves as ONE
+// full 128-byte line (4 lanes x 2 float4).  Output layout fixed to Tn = 8: channel 4 t + 2 head + o.
+#ifndef OCP_MINB
+#define OCP_MINB 2
+#endif
+template <typename T, int C>
+__global__ __launch_bounds__(256, OCP_MINB) void outconv_pair_fwd_kernel(const T* __restrict__ X0, const T* __restrict__ X1,
+                                                                  const float* __restrict__ W0, const float* __restrict__ W1,
+                                                                  const float* __restrict__ bias0, const float* __restrict__ bias1,
+                                                                  float* __restrict__ Y, int B, int Hh, int Ww, int t_major, int nsp) {
+  static_assert(C == 48, "specialised for 48 input channels (32 + 16)");
+  constexpr int LDH = C + 32;
+  constexpr int CPP = C / 8, NCH = (OCM_H * OCM_H * CPP + 255) / 256;
+  __shared__ __attribute__((aligned(16))) T halo[OCM_H * OCM_H * LDH + 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
+  s16x8 a32[2][3], a16[2][3];      // [head][dx]: A row m = ln = 2 dy + o
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float* W = h ? W1 : W0;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int t = (ln >> 1) * 3 + dx, o = ln & 1;
+      float v[8], u[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ln < 6 ? W[(t * C + 8 * g + j) * 2 + o] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u[j] = (ln < 6 && g < 2) ? W[(t * C + 32 + 8 * g + j) * 2 + o] : 0.f;
+      a32[h][dx] = __builtin_bit_cast(s16x8, make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])));
+      a16[h][dx] = __builtin_bit_cast(s16x8, make_uint4(pack2<T>(u[0], u[1]), pack2<T>(u[2], u[3]), pack2<T>(u[4], u[5]), pack2<T>(u[6], u[7])));
+    }
+  }
+  const float bs[4] = {bias0[0], bias0[1], bias1[0], bias1[1]};       // per (head, o): channel 4 t + 2 head + o
+  const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T;
+  int rel[NCH], ryx[NCH], lds[NCH];
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int q = min(tid + u * 256, OCM_H * OCM_H * CPP - 1);
+    const int px = q / CPP, ch = (q % CPP) * 8;
+    const int ry = px / OCM_H - 1, rx = px % OCM_H - 1;
+    rel[u] = (ry * Ww + rx) * C + ch;
+    ryx[u] = (ry & 0xffff) | (rx << 16);
+    lds[u] = tid + u * 256 < OCM_H * OCM_H * CPP ? px * LDH + ch : -1;
+  }
+  uint4 pre[NCH];
+  bool pin[NCH];
+  // sub-tile it of this workgroup: spatial tile sp = blockIdx.x + (it >> 4) gridDim.x, waypoint t = (it & 15) >> 1, head = it & 1
+  auto prefetch = [&](int it) {
+    const int sp = blockIdx.x + (it >> 4) * gridDim.x, t = (it & 15) >> 1, h = it & 1;
+    const int tx = sp % tiles_x, s2 = sp / tiles_x, ty = s2 % tiles_y, b = s2 / tiles_y;
+    const int f = t_major ? t * B + b : b * 8 + t;
+    const int y0 = ty * OCM_T, x0 = tx * OCM_T;
+    const T* Xt = (h ? X1 : X0) + ((long long)f * Hh + y0) * Ww * C + (long long)x0 * C;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int gy = y0 + (short)(ryx[u] & 0xffff), gx = x0 + (ryx[u] >> 16);
+      pin[u] = (unsigned)gy < (unsigned)Hh && (unsigned)gx < (unsigned)Ww;
+      pre[u] = *reinterpret_cast<const uint4*>(Xt + (pin[u] ? rel[u] : 0));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NCH; ++u)
+      if (lds[u] >= 0) *reinterpret_cast<uint4*>(halo + lds[u]) = pin[u] ? pre[u] : make_uint4(0, 0, 0, 0);
+  };
+  for (int i = tid; i < OCM_H * OCM_H * LDH + 64; i += 256) halo[i].v = 0;
+  __syncthreads();
+  const int nmine = blockIdx.x < nsp ? (nsp - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int nit = nmine * 16;
+  if (nit > 0) { prefetch(0); commit(); }
+  __syncthreads();
+  float keep[4][8] = {};           // this lane group's 32 bytes (waypoints 2g, 2g+1; both heads) of 4 pixels (rows 4w + jj, column ln)
+  for (int it0 = 0; it0 < nit; it0 += 4) {
+    const int d = (it0 & 15) >> 2;                 // lane group that collects these four sub-tiles
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                  // i = 2 (t & 1) + head
+      const int it = it0 + i;
+      if (it + 1 < nit) prefetch(it + 1);
+      float pa0[6], pa1[6], pb0[6], pb1[6];
+#pragma unroll
+      for (int hr = 0; hr < 6; ++hr) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const T* hp = halo + ((4 * w + hr) * OCM_H + ln) * LDH;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const s16x8 x32 = *reinterpret_cast<const s16x8*>(hp + dx * LDH + 8 * g);
+          const s16x8 x16 = *reinterpret_cast<const s16x8*>(hp + dx * LDH + 32 + 8 * g);
+          acc = Mma<T>::mma(a32[i & 1][dx], x32, acc);
+          acc = Mma<T>::mma(a16[i & 1][dx], x16, acc);
+        }
+        pa0[hr] = acc[0]; pa1[hr] = acc[1]; pb0[hr] = acc[2]; pb1[hr] = acc[3];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        float v0 = g == 0 ? pa0[jj] + pb0[jj + 1] : pa0[jj + 2];
+        float v1 = g == 0 ? pa1[jj] + pb1[jj + 1] : pa1[jj + 2];
+        v0 += __shfl_xor(v0, 16);                  // lanes of groups 0 and 1 now hold the pixel's value
+        v1 += __shfl_xor(v1, 16);
+        v0 = __shfl(v0, ln);                       // ... and now every group does
+        v1 = __shfl(v1, ln);
+        keep[jj][2 * i] = g == d ? v0 + bs[2 * (i & 1)] : keep[jj][2 * i];          // (a select, not a conditional store: the array stays in VGPRs)
+        keep[jj][2 * i + 1] = g == d ? v1 + bs[2 * (i & 1) + 1] : keep[jj][2 * i + 1];
+      }
+      __syncthreads();
+      if (it + 1 < nit) commit();
+      __syncthreads();
+    }
+    if (d == 3) {                                  // all 16 sub-tiles of the spatial tile done: 128-byte lines out
+      const int sp = blockIdx.x + (it0 >> 4) * gridDim.x;
+      const int tx = sp % tiles_x, s2 = sp / tiles_x, ty = s2 % tiles_y, b = s2 / tiles_y;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        float* dst = Y + ((((long long)b * Hh + ty * OCM_T + 4 * w + jj) * Ww) + tx * OCM_T + ln) * 32 + 8 * g;
+        *reinterpret_cast<float4*>(dst) = make_float4(keep[jj][0], keep[jj][1], keep[jj][2], keep[jj][3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(keep[jj][4], keep[jj][5], keep[jj][6], keep[jj][7]);
+      }
+    }
+  }
+}
+
+bool outconv_pair_fwd_try(const void* X0, const void* X1, const float* W0, const float* W1, const float* b0, const float* b1, float* Y,
+                          int B, int Tn, int Hh, int Ww, int C, int t_major, int dtype, hipStream_t st) {
+  if (C != 48 || Tn != 8 || Hh % OCM_T || Ww % OCM_T || (((uintptr_t)Y) & 15)) return false;
+  const int nsp = B * (Hh / OCM_T) * (Ww / OCM_T);
+  // OCP_MINB resident workgroups per CU; an equal number of spatial tiles for (nearly) every workgroup
+  const int per = (nsp + 256 * OCP_MINB - 1) / (256 * OCP_MINB);
+  const int nb = (nsp + per - 1) / per;
+  if (dtype == STJ_F16)
+    hipLaunchKernelGGL((outconv_pair_fwd_kernel<f16, 48>), dim3(nb), dim3(256), 0, st, (const f16*)X0, (const f16*)X1, W0, W1, b0, b1, Y, B, Hh, Ww, t_major, nsp);
+  else
+    hipLaunchKernelGGL((outconv_pair_fwd_kernel<bf16, 48>), dim3(nb), dim3(256), 0, st, (const bf16*)X0, (const bf16*)X1, W0, W1, b0, b1, Y, B, Hh, Ww, t_major, nsp);
+  return true;
+}
+
 // Backward.  Occupancy is what matters here (the first MFMA version held all 27 (tap, channel-block) dW accumulators in every
 // wave: 332 VGPRs, one wave per SIMD, and 1.8 M same-address f32 atomics for dW -- 0.5-0.6 ms per head).  Now: wave w owns 7 of
 // the 27 dW accumulators and walks all 16 rows of the tile, so a block needs 168 VGPRs and 39 KB LDS -> 3 blocks per CU (0.28 ms per head); dW/db
@@ -863,6 +1109,18 @@ bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, floa
                           long long y_bs, long long y_ts, long long y_ps, int dtype, hipStream_t st) {
   if (C != 48 || Hh % OCM_T || Ww % OCM_T || (y_ps & 1) || (((uintptr_t)Y) & 7)) return false;
   const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
+  static int ver = -1;
+  if (ver < 0) { const char* e = getenv("STJ_OUTCONV_V"); ver = e ? atoi(e) : 2; }
+  if (ver == 2) {
+    static int dbg = -1, nbm = 768;
+    if (dbg < 0) { const char* e = getenv("STJ_OC_DBG"); dbg = e ? atoi(e) : 0; e = getenv("STJ_OC_NB"); if (e) nbm = atoi(e); }
+    const int nb = min(ntiles, nbm);
+    if (dtype == STJ_F16)
+      hipLaunchKernelGGL((outconv_fwd_mfma2_kernel<f16, 48>), dim3(nb), dim3(256), 0, st, (const f16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps, dbg);
+    else
+      hipLaunchKernelGGL((outconv_fwd_mfma2_kernel<bf16, 48>), dim3(nb), dim3(256), 0, st, (const bf16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps, dbg);
+    return true;
+  }
   if (dtype == STJ_F16)
     hipLaunchKernelGGL((outconv_fwd_mfma_kernel<f16, 48>), dim3(min(ntiles, 1024)), dim3(256), 0, st, (const f16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
   else

@@ -1128,6 +1128,9 @@ def _outconv_workspace(device):
     return _workspace(device, 'stj_outconv_bwd_workspace_bytes')
 
 
+PAIR_OUTCONV = os.environ.get('STJ_PAIR_OUTCONV', '1') != '0'
+
+
 class _OutConvPair(torch.autograd.Function):
     """Two 3x3 C->2 heads written straight into the [B,H,W,32] f32 model output (channel 4t+{0,1} and 4t+{2,3})."""
     @staticmethod
@@ -1141,8 +1144,12 @@ class _OutConvPair(torch.autograd.Function):
         inner = Tn
         if t_major:            # frames ordered f = t*B + b: the kernel's (f / inner, f % inner) split then yields (t, b)
             ybs, yts, inner = 4, H * W * 4 * Tn, B
-        call('stj_outconv_fwd', _p(xo), _p(p1w.master), _p(p1b.master), vp(out.data_ptr()), F_, H, W, C, inner, ybs, yts, yps, dt, _st())
-        call('stj_outconv_fwd', _p(xf), _p(p2w.master), _p(p2b.master), vp(out.data_ptr() + 8), F_, H, W, C, inner, ybs, yts, yps, dt, _st())
+        if PAIR_OUTCONV and dt != 0 and C == 48 and Tn == 8 and H % 16 == 0 and W % 16 == 0:
+            call('stj_outconv_pair_fwd', _p(xo), _p(xf), _p(p1w.master), _p(p2w.master), _p(p1b.master), _p(p2b.master), _p(out),
+                 B, Tn, H, W, C, int(bool(t_major)), dt, _st())
+        else:
+            call('stj_outconv_fwd', _p(xo), _p(p1w.master), _p(p1b.master), vp(out.data_ptr()), F_, H, W, C, inner, ybs, yts, yps, dt, _st())
+            call('stj_outconv_fwd', _p(xf), _p(p2w.master), _p(p2b.master), vp(out.data_ptr() + 8), F_, H, W, C, inner, ybs, yts, yps, dt, _st())
         ctx.ps = (p1w, p1b, p2w, p2b)
         ctx.geo = (F_, H, W, C, inner, ybs, yts, yps)
         ctx.elu_in = int(bool(x_is_elu_out))

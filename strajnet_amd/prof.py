@@ -81,6 +81,14 @@ def _outconv(kind):
     return f
 
 
+def _outconv_pair(a):
+    B, Tn, H, W, C, dt = a[7], a[8], a[9], a[10], a[11], a[13]
+    F = B * Tn
+    fl = 2 * 2.0 * 9 * C * 2 * H * W * F
+    by = 2 * _es(dt) * F * H * W * C + 4 * B * H * W * 4 * Tn
+    return f'outconv_pair_fwd[{H}x{W},{C}->2,F{F}x2]', 'outconv_fwd', fl, fl, by
+
+
 def _ln(kind):
     def f(a):
         if kind == 'fwd':
@@ -127,7 +135,7 @@ def _loss(fam, tens):
 MODELS = {
     'stj_gemm': _gemm,
     'stj_upconv_fwd': _upconv('fwd'), 'stj_upconv_dgrad': _upconv('dgrad'), 'stj_upconv_wgrad': _upconv('wgrad'),
-    'stj_outconv_fwd': _outconv('fwd'), 'stj_outconv_bwd': _outconv('bwd'),
+    'stj_outconv_fwd': _outconv('fwd'), 'stj_outconv_pair_fwd': _outconv_pair, 'stj_outconv_bwd': _outconv('bwd'),
     'stj_layernorm_fwd': _ln('fwd'), 'stj_layernorm_bwd': _ln('bwd'),
     'stj_win_attn_fwd': _win('fwd'), 'stj_win_attn_bwd': _win('bwd'),
     'stj_unary_fwd': _elem('unary_fwd', 2, 5, 2), 'stj_unary_bwd': _elem('unary_bwd', 3, 6, 3),
