@@ -1447,20 +1447,28 @@ __global__ __launch_bounds__(512, 1) void upconv_dgrad_ws2_kernel(const bf16* __
     uint4 preA[NPF], preB[NPF];
     auto grp_rows = [](int j, int& r0, int& nr) { r0 = 4 * j; nr = j == 3 ? 6 : 4; };
     auto grp_tile = [&](int n) { return blockIdx.x + (n >> 2) * (int)gridDim.x; };
+    // chunk geometry of this thread inside a group (the same for every group and tile: the divisions by 6 and 34 per chunk, twice per
+    // step, were a third of the movers' VALU instructions -- and the movers share their SIMDs with the compute waves)
+    int cgeo[NPF];                                       // row | col << 8 | channel-chunk << 16 of chunk i (row < 6, col < 34)
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int c = mt + i * 256, px = c / CPP;
+      cgeo[i] = (px / HW) | ((px % HW) << 8) | ((c % CPP) << 16);
+    }
     auto prefetch = [&](uint4 (&pre)[NPF], int n) {
       const int tile = grp_tile(n);
       if (tile >= ntiles) return;
       int f, ty0, tx0, r0, nr;
       tile_coords(tile, f, ty0, tx0);
       grp_rows(n & 3, r0, nr);
+      const int y0 = 2 * ty0 + r0 - 1, x0 = 2 * tx0 - 1;
       const bf16* Pf = dP + (long long)f * Ho * Wo * Cout;
 #pragma unroll
       for (int i = 0; i < NPF; ++i) {
-        const int c = mt + i * 256;
-        const int px = c / CPP, ch = (c % CPP) * 8;
-        const int gy = 2 * ty0 + r0 + px / HW - 1, gx = 2 * tx0 + px % HW - 1;
+        const int row = cgeo[i] & 0xff, col = (cgeo[i] >> 8) & 0xff, ch = (cgeo[i] >> 16) * 8;
+        const int gy = y0 + row, gx = x0 + col;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < nr * HW * CPP && gy >= 0 && gy < Ho && gx >= 0 && gx < Wo) v = *reinterpret_cast<const uint4*>(Pf + ((long long)gy * Wo + gx) * Cout + ch);
+        if (row < nr && (unsigned)gy < (unsigned)Ho && (unsigned)gx < (unsigned)Wo) v = *reinterpret_cast<const uint4*>(Pf + ((long long)gy * Wo + gx) * Cout + ch);
         pre[i] = v;
       }
     };
@@ -1470,8 +1478,8 @@ __global__ __launch_bounds__(512, 1) void upconv_dgrad_ws2_kernel(const bf16* __
       grp_rows(n & 3, r0, nr);
 #pragma unroll
       for (int i = 0; i < NPF; ++i) {
-        const int c = mt + i * 256;
-        if (c < nr * HW * CPP) *reinterpret_cast<uint4*>(halo + (r0 * HW + c / CPP) * LDK + (c % CPP) * 8) = pre[i];
+        const int row = cgeo[i] & 0xff, col = (cgeo[i] >> 8) & 0xff, ch = (cgeo[i] >> 16) * 8;
+        if (row < nr) *reinterpret_cast<uint4*>(halo + ((r0 + row) * HW + col) * LDK + ch) = pre[i];
       }
     };
     constexpr int NIT = 2 * 16 * (Cin / 8);              // 8-channel items of one step
