@@ -227,6 +227,7 @@ class STrajNet:
         self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and os.environ.get('STJ_NO_SIDE_STREAM2') != '1') else None
         self._streams = (self._side, self._side2)
         self.serial = False              # True: everything on the current stream (per-kernel timing, debugging)
+        self.taps = None                 # a dict: call() stores detached float copies of the stage boundaries in it (tools/bf16_attribution.py)
         # fused Swin-block kernels (csrc/swin_fused.hip); STJ_FUSED_MLP=0 selects the layer-by-layer path (A/B runs, debugging)
         self.fused_mlp = os.environ.get('STJ_FUSED_MLP', '1') != '0'
         self.fused_attn = os.environ.get('STJ_FUSED_ATTN', '1') != '0'
@@ -416,10 +417,15 @@ class STrajNet:
         h = self._dense(h, pre + '/mlp/fc2').view(B, -1)
         return ops.dropout(h, dpr, self._dctx, pre + '/drop_path_mlp', res=x.view(B, -1), per_sample=True).view(x.shape)
 
+    def _tap(self, name, t):
+        if self.taps is not None:
+            self.taps[name] = t.detach().float().clone()
+
     def _basic_layer(self, x, pre, B, res, depth, heads, downsample, add=None):
         """BasicLayer.call (modules.py:351-364) -> (downsampled, pre-merge tokens)."""
         for i in range(depth):
             x = self._swin_block(x, f'{pre}/blocks{i}', B, res, heads, 0 if i % 2 == 0 else 4)
+            self._tap(f'{pre}/block{i}', x)
         if not downsample:
             return x, x
         m = self._ln(x, pre + '/downsample/norm', 1e-5, gather_res=res)      # PatchMerging (modules.py:274-292)
@@ -468,6 +474,7 @@ class STrajNet:
             pad = (P - Pm) // 2
             maps = torch.nn.functional.pad(maps.view(B, Pm, Pm, C), (0, 0, pad, pad, pad, pad)).reshape(B, P * P, C)
         x = self._ln(vec + maps, 'all_patch_norm', 1e-5)
+        self._tap('stem', x)
         res_list = []
 
         def crop(t, r, c):
@@ -638,9 +645,12 @@ class STrajNet:
             s3, s2, sf = (self._resconv(r1, 'decoder/resconv_3'), self._resconv(r0, 'decoder/resconv_2'),
                           self._resconv(flow_res, 'decoder/resconv_f'))
         x = x + s3.view(x.shape)
+        self._tap('decoder/level3', x)
         x = up(x, 'decoder/upconv_2_0')                                              # [F,4hb,4hb,128]
         x = x + s2.view(x.shape)
         fx = x + sf.view(x.shape)
+        self._tap('decoder/level2', x)
+        self._tap('decoder/level2_flow', fx)
         # the last two levels of each branch have a single consumer, whose backward folds ELU' into the gradient it returns
         if self._side2 is not None:      # the observed-occupancy and flow branches of the last two levels are independent
             main = torch.cuda.current_stream(self.device)
@@ -654,6 +664,8 @@ class STrajNet:
         else:
             x = up(up(x, 'decoder/upconv_1_0', grad_is_pre=True), 'decoder/upconv_0_0', grad_is_pre=True, x_is_elu_out=True)
             fx = up(up(fx, 'decoder/upconvf_1_0', grad_is_pre=True), 'decoder/upconvf_0_0', grad_is_pre=True, x_is_elu_out=True)
+        self._tap('decoder/level0', x)
+        self._tap('decoder/level0_flow', fx)
         return ops.outconv_pair(x, fx, self._p('decoder/outconv/kernel'), self._p('decoder/outconv/bias'),
                                 self._p('decoder/outconv_f/kernel'), self._p('decoder/outconv_f/bias'), B, 8, t_major=True, x_is_elu_out=True)
 
@@ -749,6 +761,7 @@ class STrajNet:
         fh = None
         if self.fg_msa:
             y, fh = self._fgmsa(q)
+            self._tap('fg_msa_out', y)
             q = q + y                                                              # modules.py:825
         # waypoint-major [8,B,HW,Cb] (the reference's [B,8,...] transposed): every per-waypoint product downstream is then a
         # plain batched GEMM and the decoder frames are t-major; the output kernel undoes it when writing [B,H,W,32]
@@ -759,6 +772,10 @@ class STrajNet:
             main.wait_stream(self._side)
             key.record_stream(main)
             tmask.record_stream(main)
+        self._tap('agent_key', key)
+        self._tap('query', query)
         x = self._cross_attention_z(query.contiguous(), key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
+        self._tap('cross_attention_out', x)
         out = self._decoder(x, res_list, B, skips)
+        self._tap('output', out)
         return ops.join_after_backward(out, (self._side, self._side2), fold)
