@@ -435,6 +435,21 @@ extern "C" int stj_upconv_fwd(const void* X, const void* Wf, const float* bias, 
                            : upconv_fwd_launch<float>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, act, stream);
 }
 
+// Up-conv with the decoder's skip sums in its epilogue: Y = ELU(conv(up(X)) + bias) + R1 and (optional) Y2 = Y + R2, all [F,2Hi,2Wi,Cout]
+// in the activation dtype, each sum rounded like a separate elementwise add.  Covered: the 16-bit wide layers (Cin = 192, 384: the two
+// levels that take skips, modules.py:750-765); STJ_EUNSUPPORTED otherwise (run stj_upconv_fwd and add).
+bool upconv_fwd_ps_res_try(const void* X, const void* Wf, const float* bias, void* Y, const void* R1, void* Y2, const void* R2, int F, int Hi,
+                           int Wi, int Cin, int Cout, int dtype, hipStream_t st);
+extern "C" int stj_upconv_fwd_res(const void* X, const void* Wf, const float* bias, void* Y, const void* R1, void* Y2, const void* R2, int F,
+                                  int Hi, int Wi, int Cin, int Cout, int dtype, hipStream_t stream) {
+  int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
+  if (e) return e;
+  if (stj_is16(dtype) && ws_enabled() && upconv_fwd_ps_res_try(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, dtype, stream))
+    return stj_check_launch("stj_upconv_fwd_res");
+  stj_set_error("upconv_fwd_res: shape / dtype not covered (Cin=%d Cout=%d dtype=%d)", Cin, Cout, dtype);
+  return STJ_EUNSUPPORTED;
+}
+
 template <typename T>
 static int upconv_dgrad_launch(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   const int tiles = ((Wi + TILE_W - 1) / TILE_W) * ((Hi + TILE_H - 1) / TILE_H) * F;

@@ -24,6 +24,7 @@
 template <typename T, int FN, int MINB>
 __global__ __launch_bounds__(256, MINB) void upconv_fwd_ps_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
                                                                   const float* __restrict__ bias, T* __restrict__ Y,
+                                                                  const T* __restrict__ R1, T* __restrict__ Y2, const T* __restrict__ R2,
                                                                   int F, int Hi, int Wi, int Cin, int Cout) {
   constexpr int LDK = PS_KC + 16;                  // 96-byte pixel stride: 2 (mod 4) 16-byte slots, conflict-free b128 fragment reads
   constexpr int CT = FN * 16, LDO = CT + 8;
@@ -150,14 +151,37 @@ __global__ __launch_bounds__(256, MINB) void upconv_fwd_ps_kernel(const T* __res
     for (int q = tid; q < 2 * PS_TH * 2 * PS_TW * SEG; q += 256) {
       const int sg = q % SEG, p = q / SEG;
       const int oy = 2 * ty0 + p / (2 * PS_TW), ox = 2 * tx0 + p % (2 * PS_TW), co = n0 + sg * 8;
-      if (oy < Ho && ox < Wo && co < Cout)
-        *reinterpret_cast<uint4*>(Yf + ((long long)oy * Wo + ox) * Cout + co) = *reinterpret_cast<const uint4*>(ostage + p * LDO + sg * 8);
+      if (oy < Ho && ox < Wo && co < Cout) {
+        const long long o = ((long long)oy * Wo + ox) * Cout + co;
+        if (R1 == nullptr) {
+          *reinterpret_cast<uint4*>(Yf + o) = *reinterpret_cast<const uint4*>(ostage + p * LDO + sg * 8);
+        } else {
+          // decoder skips (reference modules.py:750-765): Y = ELU(conv) + R1 and, optionally, Y2 = Y + R2 -- each sum rounded to the
+          // storage type exactly as a separate elementwise add of the stored tensors would round it
+          const long long fo = (long long)f * Ho * Wo * Cout + o;
+          float u[8], r[8];
+          ld16<T>(ostage + p * LDO + sg * 8, u);
+          ld16<T>(R1 + fo, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) u[e] += r[e];
+          __attribute__((aligned(16))) T rounded[8];
+          st16<T>(rounded, u);
+          *reinterpret_cast<uint4*>(Yf + o) = *reinterpret_cast<const uint4*>(rounded);
+          if (Y2 != nullptr) {
+            ld16<T>(rounded, u);                   // the rounded sum, as a separate add would read it back
+            ld16<T>(R2 + fo, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] += r[e];
+            st16<T>(Y2 + fo, u);
+          }
+        }
+      }
     }
   }
 }
 
 template <typename T, int FN, int MINB>
-static bool fwd_ps_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+static bool fwd_ps_launch(const void* X, const void* Wf, const float* bias, void* Y, const void* R1, void* Y2, const void* R2, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   constexpr int LDK = PS_KC + 16, CT = FN * 16, LDO = CT + 8;
   const size_t lds_h = (size_t)2 * PS_HH * PS_HW * LDK * 2, lds_o = (size_t)2 * PS_TH * 2 * PS_TW * LDO * 2;
   const size_t lds = lds_h > lds_o ? lds_h : lds_o;
@@ -168,12 +192,12 @@ static bool fwd_ps_launch(const void* X, const void* Wf, const float* bias, void
   }
   const int tiles = ((Wi + PS_TW - 1) / PS_TW) * ((Hi + PS_TH - 1) / PS_TH) * F;
   hipLaunchKernelGGL((upconv_fwd_ps_kernel<T, FN, MINB>), dim3(tiles, (Cout + CT - 1) / CT), dim3(256), lds, st, (const T*)X, (const T*)Wf, bias,
-                     (T*)Y, F, Hi, Wi, Cin, Cout);
+                     (T*)Y, (const T*)R1, (T*)Y2, (const T*)R2, F, Hi, Wi, Cin, Cout);
   return true;
 }
 
 template <typename T>
-static bool fwd_ps_try_t(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+static bool fwd_ps_try_t(const void* X, const void* Wf, const float* bias, void* Y, const void* R1, void* Y2, const void* R2, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   static int fn = -1;
   if (fn < 0) { const char* e = getenv("STJ_PS_FN"); fn = e ? atoi(e) : 0; }
   // measured (tools/bench_conv.py, us for 384->192 @16^2 / 192->128 @32^2, F = 64; generic kernel 113 / 140): FN = 2, two workgroups
@@ -181,9 +205,9 @@ static bool fwd_ps_try_t(const void* X, const void* Wf, const float* bias, void*
   // workgroup streams 32 KB of weights + 11.5 KB of halo per 4.2 MFLOP chunk), which is where the 64x64 GEMM tiles saturate too.
   int use = fn ? fn : 2;
   if (Cout % (16 * use)) return false;
-  if (use == 4) return fwd_ps_launch<T, 4, 1>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, st);
-  if (use == 3) return fwd_ps_launch<T, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, st);
-  return fwd_ps_launch<T, 2, 2>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, st);
+  if (use == 4) return fwd_ps_launch<T, 4, 1>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
+  if (use == 3) return fwd_ps_launch<T, 3, 1>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
+  return fwd_ps_launch<T, 2, 2>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
 }
 // true when this kernel took the problem: 16-bit, ELU, Cin a multiple of 32 above the weight-stationary range
 bool upconv_fwd_ps_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
@@ -191,5 +215,13 @@ bool upconv_fwd_ps_try(const void* X, const void* Wf, const float* bias, void* Y
   static int on = -1;
   if (on < 0) { const char* e = getenv("STJ_NO_PS"); on = !(e && atoi(e)); }
   if (!on || act != ACT_ELU || Cin % PS_KC || Cin <= 128 || Cout % 32) return false;
-  return dtype == STJ_F16 ? fwd_ps_try_t<f16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, st) : fwd_ps_try_t<bf16>(X, Wf, bias, Y, F, Hi, Wi, Cin, Cout, st);
+  return dtype == STJ_F16 ? fwd_ps_try_t<f16>(X, Wf, bias, Y, nullptr, nullptr, nullptr, F, Hi, Wi, Cin, Cout, st)
+                          : fwd_ps_try_t<bf16>(X, Wf, bias, Y, nullptr, nullptr, nullptr, F, Hi, Wi, Cin, Cout, st);
+}
+// the same with the skip sums in the epilogue: Y = ELU(conv) + R1, Y2 = Y + R2 (Y2 / R2 may be null)
+bool upconv_fwd_ps_res_try(const void* X, const void* Wf, const float* bias, void* Y, const void* R1, void* Y2, const void* R2, int F, int Hi,
+                           int Wi, int Cin, int Cout, int dtype, hipStream_t st) {
+  if (Cin % PS_KC || Cin <= 128 || Cout % 32 || R1 == nullptr || ((Y2 == nullptr) != (R2 == nullptr))) return false;
+  return dtype == STJ_F16 ? fwd_ps_try_t<f16>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st)
+                          : fwd_ps_try_t<bf16>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
 }

@@ -131,6 +131,46 @@ extern "C" int stj_unary_bwd(const void* dy, const void* saved, void* dx, long l
   return stj_check_launch("stj_unary_bwd");
 }
 
+// Backward of  y = ELU(pre) + r  [and y2 = y + r2]  (stj_upconv_fwd_res): g = dy (+ dy2), dpre = g * ELU'(pre) with the ELU output
+// recovered as y - r (ELU' = 1 for u > 0, u + 1 otherwise: continuous, so the rounding of y does not matter).  g is written too when
+// dy2 is given (it is the gradient of r; dy2 itself is the gradient of r2).
+template <typename T>
+__global__ __launch_bounds__(256) void elu_res_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ y,
+                                                          const T* __restrict__ r, T* __restrict__ dpre, T* __restrict__ gsum, long long n) {
+  constexpr int VN = Vec<T>::N;
+  const long long nv = n / VN;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += gridDim.x * 256ll) {
+    float g[VN], b[VN], c[VN];
+    ld16(dy + i * VN, g);
+    if (dy2) {
+      ld16(dy2 + i * VN, b);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) g[e] += b[e];
+      __attribute__((aligned(16))) T rounded[VN];
+      st16(rounded, g);
+      *reinterpret_cast<uint4*>(gsum + i * VN) = *reinterpret_cast<const uint4*>(rounded);
+      ld16(rounded, g);                              // the rounded sum, as the consumer of gsum sees it
+    }
+    ld16(y + i * VN, b);
+    ld16(r + i * VN, c);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { const float u = b[e] - c[e]; g[e] *= u > 0.f ? 1.f : u + 1.f; }
+    st16(dpre + i * VN, g);
+  }
+}
+extern "C" int stj_elu_res_bwd(const void* dy, const void* dy2, const void* y, const void* r, void* dpre, void* gsum, long long n, int dtype,
+                               hipStream_t stream) {
+  if (n <= 0) return STJ_OK;
+  if (n % 8) { stj_set_error("stj_elu_res_bwd: n must be a multiple of 8"); return STJ_EINVAL; }
+  if ((dy2 == nullptr) != (gsum == nullptr)) { stj_set_error("stj_elu_res_bwd: dy2 and gsum go together"); return STJ_EINVAL; }
+  if (((uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)y | (uintptr_t)r | (uintptr_t)dpre | (uintptr_t)gsum) & 15) { stj_set_error("stj_elu_res_bwd: pointers must be 16-byte aligned"); return STJ_EINVAL; }
+  const int g = ew_grid(n / 8);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(elu_res_bwd_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)y, (const bf16*)r, (bf16*)dpre, (bf16*)gsum, n);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(elu_res_bwd_kernel<f16>, dim3(g), dim3(256), 0, stream, (const f16*)dy, (const f16*)dy2, (const f16*)y, (const f16*)r, (f16*)dpre, (f16*)gsum, n);
+  else hipLaunchKernelGGL(elu_res_bwd_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)dy, (const float*)dy2, (const float*)y, (const float*)r, (float*)dpre, (float*)gsum, n);
+  return stj_check_launch("stj_elu_res_bwd");
+}
+
 // ---- max over a middle axis: x[outer][T][C] -> y[outer][C], idx (argmax, int8-in-int32) ---------
 // GlobalMaxPooling1D over the 11 time steps (reference trajNet.py:34,44).
 template <typename T>

@@ -634,7 +634,6 @@ class STrajNet:
         x = x.view(8 * B, hb, hb, -1)                                                # frames are TIME-major: f = t*B + b
         if self._prep_event is not None:                                             # folded kernels come from the side stream
             torch.cuda.current_stream(self.device).wait_event(self._prep_event)
-        x = up(x, 'decoder/upconv_3_0')                                              # [F,2hb,2hb,192]
         if skips is not None:                                                        # computed on the side stream: join
             main = torch.cuda.current_stream(self.device)
             main.wait_stream(self._side2)
@@ -644,11 +643,12 @@ class STrajNet:
         else:
             s3, s2, sf = (self._resconv(r1, 'decoder/resconv_3'), self._resconv(r0, 'decoder/resconv_2'),
                           self._resconv(flow_res, 'decoder/resconv_f'))
-        x = x + s3.view(x.shape)
+
+        def up_add(t, name, ra, rb=None):        # up-conv with the skip sum(s) in its epilogue (modules.py:750-765)
+            return ops.upconv_add(t, self._p(name + '/kernel'), self._p(name + '/bias'), ra, rb, prep=self._upconv_prep.get(name))
+        x = up_add(x, 'decoder/upconv_3_0', s3)                                      # [F,2hb,2hb,192]
         self._tap('decoder/level3', x)
-        x = up(x, 'decoder/upconv_2_0')                                              # [F,4hb,4hb,128]
-        x = x + s2.view(x.shape)
-        fx = x + sf.view(x.shape)
+        x, fx = up_add(x, 'decoder/upconv_2_0', s2, sf)                              # [F,4hb,4hb,128] x 2
         self._tap('decoder/level2', x)
         self._tap('decoder/level2_flow', fx)
         # the last two levels of each branch have a single consumer, whose backward folds ELU' into the gradient it returns

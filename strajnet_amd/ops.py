@@ -1057,6 +1057,28 @@ def grouped_conv3(x, pw, pb, G):
 _DB_PARTS = 32
 
 
+def _upconv_backward_tail(ctx, x, dpre, wd, need_dx):
+    """Input gradient (dgrad kernel) and weight / bias gradient (side stream) of an up-conv from the pre-activation gradient."""
+    F_, Hi, Wi, Cin, Cout = ctx.geo
+    dt = _dt(x)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), _p(x) if ctx.x_is_elu_out else None, F_, Hi, Wi, Cin, Cout, dt, _st())
+    with wgrad_stream(2, x, dpre):
+        dweff = zeros_f32(16 * Cout * Cin, x.device)     # the 16 folded tap matrices
+        pb = ctx.pb
+        if pb.part is not None:  # model-owned bias-gradient copies, folded into .grad once per step
+            dbp, nparts, own = pb.part[0], pb.part[1], False
+        else:                    # (~1000 workgroups would queue on Cout addresses otherwise)
+            dbp, nparts, own = torch.zeros(_DB_PARTS * Cout, dtype=torch.float32, device=x.device), _DB_PARTS, True
+        call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), nparts, F_, Hi, Wi, Cin, Cout, dt, _st())
+        call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
+        if own:
+            pb.grad.add_(dbp.view(nparts, Cout).sum(0))
+    return dx
+
+
 class _UpConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_master, b_master, pw, pb, grad_is_pre, x_is_elu_out, prep):
@@ -1087,22 +1109,69 @@ class _UpConv(torch.autograd.Function):
         else:
             dpre = torch.empty_like(dy)
             call('stj_unary_bwd', _p(dy), _p(y), _p(dpre), dy.numel(), U_ELU, 0.0, dt, _st())
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), _p(x) if ctx.x_is_elu_out else None, F_, Hi, Wi, Cin, Cout, dt, _st())
-        with wgrad_stream(2, x, dpre):
-            dweff = zeros_f32(16 * Cout * Cin, x.device)     # the 16 folded tap matrices
-            pb = ctx.pb
-            if pb.part is not None:  # model-owned bias-gradient copies, folded into .grad once per step
-                dbp, nparts, own = pb.part[0], pb.part[1], False
-            else:                    # (~1000 workgroups would queue on Cout addresses otherwise)
-                dbp, nparts, own = torch.zeros(_DB_PARTS * Cout, dtype=torch.float32, device=x.device), _DB_PARTS, True
-            call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), nparts, F_, Hi, Wi, Cin, Cout, dt, _st())
-            call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
-            if own:
-                pb.grad.add_(dbp.view(nparts, Cout).sum(0))
+        dx = _upconv_backward_tail(ctx, x, dpre, wd, ctx.needs_input_grad[0])
         return dx, None, None, None, None, None, None, None
+
+
+class _UpConvAdd(torch.autograd.Function):
+    """y = ELU(upconv(x)) + r1 [, y2 = y + r2] with the sums in the up-conv's epilogue (stj_upconv_fwd_res): the decoder skips of
+    modules.py:750-765.  The ELU output itself is never stored; backward recovers ELU' from y - r1 (stj_elu_res_bwd), which also adds
+    the two incoming gradients when there are two outputs."""
+    @staticmethod
+    def forward(ctx, x, r1, r2, w_master, b_master, pw, pb, prep):
+        _req_cuda(x, r1)
+        x, r1 = x.contiguous(), r1.contiguous()
+        F_, Hi, Wi, Cin = x.shape
+        Cout = pw.master.shape[-1]
+        dt = _dt(x)
+        wf, wd = prep if prep is not None else upconv_prep(pw, x.dtype)
+        y = torch.empty((F_, 2 * Hi, 2 * Wi, Cout), dtype=x.dtype, device=x.device)
+        y2 = None
+        if r2 is not None:
+            r2 = r2.contiguous()
+            y2 = torch.empty_like(y)
+        call('stj_upconv_fwd_res', _p(x), _p(wf), _p(pb.master), _p(y), _p(r1), _p(y2), _p(r2), F_, Hi, Wi, Cin, Cout, dt, _st())
+        ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
+        ctx.x_is_elu_out, ctx.two = False, r2 is not None
+        ctx.save_for_backward(x, y, r1, wd)
+        return (y, y2) if r2 is not None else y
+
+    @staticmethod
+    def backward(ctx, dy, dy2=None):
+        x, y, r1, wd = ctx.saved_tensors
+        dt = _dt(x)
+        if dy is None:
+            dy, dy2 = dy2, None
+        dy = dy.contiguous()
+        dpre = torch.empty_like(dy)
+        gsum = None
+        if dy2 is not None:
+            dy2 = dy2.contiguous()
+            gsum = torch.empty_like(dy)
+        call('stj_elu_res_bwd', _p(dy), _p(dy2), _p(y), _p(r1), _p(dpre), _p(gsum), dy.numel(), dt, _st())
+        dx = _upconv_backward_tail(ctx, x, dpre, wd, ctx.needs_input_grad[0])
+        dr1 = gsum if gsum is not None else dy
+        return dx, dr1, (dy2 if ctx.two else None), None, None, None, None, None
+
+
+# 0: never; 1 (default): in inference only; 2: always.  Measured at B=8 bf16: the training step is 1.2 % SLOWER with the sums in the
+# epilogue (901 vs 912 scenes/s: a workgroup owns 32 of the 128 couts, so the skip operands are read and the sums written in 64-byte
+# pieces, 138 vs 92 us for the 192 -> 128 layer, while the separate adds stream whole lines at 5 TB/s), the B=32 fp16 forward 1.4 % faster.
+FUSED_SKIP = int(os.environ.get('STJ_FUSED_SKIP', '1'))
+
+
+def upconv_add(x, pw, pb, r1, r2=None, prep=None):
+    """ELU(upconv(x)) + r1 -> y, and y + r2 -> y2 when r2 is given (returns y or (y, y2)).  Fused into the up-conv epilogue for the
+    16-bit wide layers (Cin = 192, 384); otherwise the up-conv followed by elementwise adds."""
+    Cin, Cout = pw.master.shape[2], pw.master.shape[3]
+    if (FUSED_SKIP == 2 or (FUSED_SKIP == 1 and not torch.is_grad_enabled())) and x.dtype != torch.float32 and Cin > 128 and Cin % 32 == 0 and Cout % 32 == 0 and os.environ.get('STJ_NO_PS') != '1' \
+            and os.environ.get('STJ_NO_WS') != '1':
+        return _UpConvAdd.apply(x, r1.view(x.shape[0], 2 * x.shape[1], 2 * x.shape[2], Cout),
+                                None if r2 is None else r2.view(x.shape[0], 2 * x.shape[1], 2 * x.shape[2], Cout),
+                                pw.master, pb.master, pw, pb, prep)
+    y = upconv(x, pw, pb, prep=prep)
+    y = y + r1.view(y.shape)
+    return y if r2 is None else (y, y + r2.view(y.shape))
 
 
 def upconv_prep(pw, dtype):

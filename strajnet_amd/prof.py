@@ -68,6 +68,21 @@ def _upconv(kind):
     return f
 
 
+def _upconv_res(a):
+    F, Hi, Wi, Cin, Cout, dt = a[7], a[8], a[9], a[10], a[11], a[12]
+    es = _es(dt)
+    two = getattr(a[5], 'value', None)
+    fl = 2.0 * 9 * Cin * Cout * 4 * Hi * Wi * F
+    by = es * F * Hi * Wi * (Cin + 4 * Cout * (4 if two else 2)) + es * 16 * Cin * Cout
+    return f'upconv_fwd[{Hi}x{Wi},{Cin}->{Cout},F{F}]+skip{2 if two else 1}', 'upconv_fwd', fl, fl / 2.25, by
+
+
+def _elu_res(a):
+    n, dt = a[6], a[7]
+    two = getattr(a[1], 'value', None)
+    return f'elu_res_bwd[{n}]x{2 if two else 1}', 'unary_bwd', 0.0, 0.0, (6 if two else 4) * _es(dt) * n
+
+
 def _outconv(kind):
     def f(a):
         if kind == 'fwd':
@@ -134,7 +149,7 @@ def _loss(fam, tens):
 
 MODELS = {
     'stj_gemm': _gemm,
-    'stj_upconv_fwd': _upconv('fwd'), 'stj_upconv_dgrad': _upconv('dgrad'), 'stj_upconv_wgrad': _upconv('wgrad'),
+    'stj_upconv_fwd': _upconv('fwd'), 'stj_upconv_fwd_res': _upconv_res, 'stj_elu_res_bwd': _elu_res, 'stj_upconv_dgrad': _upconv('dgrad'), 'stj_upconv_wgrad': _upconv('wgrad'),
     'stj_outconv_fwd': _outconv('fwd'), 'stj_outconv_pair_fwd': _outconv_pair, 'stj_outconv_bwd': _outconv('bwd'),
     'stj_layernorm_fwd': _ln('fwd'), 'stj_layernorm_bwd': _ln('bwd'),
     'stj_win_attn_fwd': _win('fwd'), 'stj_win_attn_bwd': _win('bwd'),

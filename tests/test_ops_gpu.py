@@ -628,3 +628,40 @@ def test_gemm_group_matches_single_launches(dt):
     with ops.gemm_group():
         ops.gemm(x, w, y, M, N, K, (0, 0, K, 1), (0, 0, N, 1), (0, 0, N), code)
     assert rel_err(y, ref) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('F_,Hi,Cin,Cout,two', [(3, 16, 192, 128, True), (2, 8, 384, 192, False)])
+def test_upconv_add_fused_skip(dt, F_, Hi, Cin, Cout, two):
+    """Decoder skip sums in the up-conv epilogue (stj_upconv_fwd_res / stj_elu_res_bwd) against the up-conv followed by elementwise adds:
+    forward bit-identical (every sum is rounded like a separate add), gradients equal up to the rounding of ELU'(y - r) vs ELU'(u)."""
+    from strajnet_amd import ops
+    x0 = rnd((F_, Hi, Hi, Cin), dt, 1)
+    r1 = rnd((F_, 2 * Hi, 2 * Hi, Cout), dt, 2)
+    r2 = rnd((F_, 2 * Hi, 2 * Hi, Cout), dt, 3) if two else None
+    g1 = rnd((F_, 2 * Hi, 2 * Hi, Cout), dt, 4)
+    g2 = rnd((F_, 2 * Hi, 2 * Hi, Cout), dt, 5)
+
+    def run(fused):
+        pw, pb = mk_param((3, 3, Cin, Cout), dt, 0.03, seed=7), mk_param((Cout,), dt, 0.1, seed=8)
+        x = x0.clone().requires_grad_(True)
+        a = r1.clone().requires_grad_(True)
+        b = r2.clone().requires_grad_(True) if two else None
+        keep, ops.FUSED_SKIP = ops.FUSED_SKIP, (2 if fused else 0)
+        try:
+            out = ops.upconv_add(x, pw, pb, a, b)
+        finally:
+            ops.FUSED_SKIP = keep
+        y, y2 = out if two else (out, None)
+        loss = (y.float() * g1.float()).sum() + ((y2.float() * g2.float()).sum() if two else 0.0)
+        loss.backward()
+        ops.wgrad_join_now(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        return y, y2, x.grad, a.grad, (b.grad if two else None), pw.grad.clone(), pb.grad.clone()
+    f, u = run(True), run(False)
+    assert torch.equal(f[0], u[0])
+    if two:
+        assert torch.equal(f[1], u[1])
+        assert torch.equal(f[4], u[4])
+    for i in (2, 3, 5, 6):
+        assert rel_err(f[i], u[i]) < (2e-2 if dt == torch.bfloat16 else 3e-3), i
