@@ -71,6 +71,19 @@ struct Stage {
       }
     }
   }
+  // 16-byte-vector operands only (the launcher checks vecA / vecB and K % VN == 0): unconditional loads from a clamped address, zeroed
+  // by a select -- no scalar fallback, no branch per chunk (with 6 chunks per operand the general form above spilled 400 bytes / lane)
+  __device__ static __forceinline__ void load_vec(uint4 (&reg)[NCH], const T* g, long long sR, long long sK, int nr, int nk, int tid) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + i * 256;
+      const int a = idx / CPR, c = (idx % CPR) * VN;
+      const int r = RC ? c : a, k = RC ? a : c;
+      const bool in = RC ? (k < nk && r + VN <= nr) : (r < nr && k + VN <= nk);
+      const uint4 v = *reinterpret_cast<const uint4*>(g + (in ? (long long)r * sR + (long long)k * sK : 0));
+      reg[i] = in ? v : make_uint4(0, 0, 0, 0);
+    }
+  }
   template <int LDX>
   __device__ static __forceinline__ void commit(T* lds, const uint4 (&reg)[NCH], int tid) {
 #pragma unroll
@@ -89,9 +102,9 @@ struct Stage {
 };
 
 // LDS bytes of one tile configuration (operand stage and epilogue stage share the buffer)
-template <typename T, int BM, int BN, int WM, int WN, bool TA, bool TB>
+template <typename T, int BM, int BN, int WM, int WN, bool TA, bool TB, int BKB = 128>
 struct GemmSmem {
-  static constexpr int BK = 128 / sizeof(T);
+  static constexpr int BK = BKB / sizeof(T);        // k-tile: BKB bytes of K per row (128 = the default 64 16-bit / 32 f32 elements)
   static constexpr int LD = BK + LdsPad<T>::P;
   static constexpr int LDTA = BM + PadT<T>::P, LDTB = BN + PadT<T>::P;
   static constexpr int FM = BM / (16 * WM);
@@ -107,14 +120,14 @@ struct GemmSmem {
 
 // One workgroup's share of a GEMM: tile / batch / k-slice (bxi, byi) of a (gdx, gdy) grid.  `smem` has GemmSmem<...>::BYTES bytes,
 // `bias_s` BN floats.  (A function, not the kernel, so that gemm_group_kernel below can run tiles of SEVERAL problems in one launch.)
-template <typename T, int BM, int BN, int WM, int WN, bool TA, bool TB>
+template <typename T, int BM, int BN, int WM, int WN, bool TA, bool TB, int BKB = 128>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bxi, const int byi, const int gdx, const int gdy,
                                           unsigned char* smem, float* bias_s) {
-  constexpr int BK = 128 / sizeof(T);
+  constexpr int BK = BKB / sizeof(T);
   constexpr int LD = BK + LdsPad<T>::P;
   constexpr int LDTA = BM + PadT<T>::P, LDTB = BN + PadT<T>::P;
   constexpr int FM = BM / (16 * WM), FN = BN / (16 * WN);
-  constexpr int A_ELEMS_AL = GemmSmem<T, BM, BN, WM, WN, TA, TB>::A_ELEMS_AL;
+  constexpr int A_ELEMS_AL = GemmSmem<T, BM, BN, WM, WN, TA, TB, BKB>::A_ELEMS_AL;
   constexpr int EP_ROWS = BM < 64 ? BM : (BM % 64 == 0 ? 64 : FM * 16);      // a wave's rows must lie inside one epilogue pass
   constexpr int LDC = BN + 4;
   T* As = reinterpret_cast<T*>(smem);
@@ -163,8 +176,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bxi, cons
   const long long a_sR = TA ? 1 : p.sAm, b_sR = TB ? 1 : p.sBn;
   auto issue = [&](int kt) {
     const int seg = kt / ktiles_seg, k1 = (kt - seg * ktiles_seg) * BK;
-    SA::load(ra, A + seg * p.sAkb + (long long)k1 * p.sAk, a_sR, p.sAk, p.M - m0, p.K - k1, p.vecA, tid);
-    SB::load(rb, B + seg * p.sBkb + (long long)k1 * p.sBk, b_sR, p.sBk, p.N - n0, p.K - k1, p.vecB, tid);
+    if constexpr (BKB != 128) {
+      SA::load_vec(ra, A + seg * p.sAkb + (long long)k1 * p.sAk, a_sR, p.sAk, p.M - m0, p.K - k1, tid);
+      SB::load_vec(rb, B + seg * p.sBkb + (long long)k1 * p.sBk, b_sR, p.sBk, p.N - n0, p.K - k1, tid);
+    } else {
+      SA::load(ra, A + seg * p.sAkb + (long long)k1 * p.sAk, a_sR, p.sAk, p.M - m0, p.K - k1, p.vecA, tid);
+      SB::load(rb, B + seg * p.sBkb + (long long)k1 * p.sBk, b_sR, p.sBk, p.N - n0, p.K - k1, p.vecB, tid);
+    }
   };
   if (kt0 < kt1) issue(kt0);
   for (int kt = kt0; kt < kt1; ++kt) {
@@ -295,6 +313,16 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? ((!
   gemm_body<T, BM, BN, WM, WN, TA, TB>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem, bias_s);
 }
 
+// Deep k-tile variant (16-bit types, plain GEMMs): 192 elements of K per barrier pair instead of 64.  The Dense layers of the small
+// stages (2048 .. 16384 rows, K = 192 .. 1536) are bound by the dependent chain load -> LDS -> barrier -> MFMA -> barrier of each k-tile
+// (~2 us per link whatever its size, tools/bench_gemm_pmc.py); a K = 384 layer is 2 links instead of 6.
+template <typename T, int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256, 3) void gemm_deepk_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GemmSmem<T, BM, BN, 2, 2, TA, TB, 384>::BYTES];
+  __shared__ float bias_s[BN];
+  gemm_body<T, BM, BN, 2, 2, TA, TB, 384>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem, bias_s);
+}
+
 // ---- grouped launch: up to GG_MAX independent GEMMs (same dtype, 64x64 or 32x32 tiles, any operand orientation) in ONE kernel ----
 // The small layers of the hot path (agent encoder, FG-MSA, the cross-attentions, the 16x16 Swin stage) form dependent chains of
 // 5-15 us launches in which the input gradient and the weight gradient of a Dense layer, the dP / dV and dQ / dK products of an
@@ -304,11 +332,11 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? ((!
 #define GG_MAX 4
 struct GemmGroup {
   GemmArgs p[GG_MAX];
-  int start[GG_MAX + 1], gx[GG_MAX], gy[GG_MAX], cfg[GG_MAX];      // cfg = (32x32 tiles ? 4 : 0) + 2 TA + TB
+  int start[GG_MAX + 1], gx[GG_MAX], gy[GG_MAX], cfg[GG_MAX];      // cfg = (32x32 tiles ? 4 : 0) + 2 TA + TB (+ 8: deep k-tile, groups of one only)
   int n;
 };
 template <typename T>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 1) void gemm_group_kernel(GemmGroup g) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 5 : 1) void gemm_group_kernel(GemmGroup g) {
   constexpr int B0 = GemmSmem<T, 64, 64, 2, 2, false, false>::BYTES, B1 = GemmSmem<T, 64, 64, 2, 2, true, true>::BYTES;
   constexpr int B2 = GemmSmem<T, 64, 64, 2, 2, true, false>::BYTES, B3 = GemmSmem<T, 64, 64, 2, 2, false, true>::BYTES;
   constexpr int BA = B0 > B1 ? B0 : B1, BB = B2 > B3 ? B2 : B3;
@@ -510,8 +538,24 @@ static int group_flush(hipStream_t st) {
   const int dtype = g_rec_dtype;
   g_grp.n = 0; g_rec_blocks = 0; g_rec_dtype = -1;
   if (g.n == 1) {                                   // a group of one is an ordinary launch
-    const int c = g.cfg[0];
+    const int c = g.cfg[0] & 7, deep1 = g.cfg[0] & 8;
     dim3 grid(g.gx[0], g.gy[0]);
+    if (deep1) {
+#define STJ_ONE_DEEP(T) \
+      switch (c) { \
+        case 0: hipLaunchKernelGGL((gemm_deepk_kernel<T, 64, 64, false, false>), grid, dim3(256), 0, st, g.p[0]); break; \
+        case 1: hipLaunchKernelGGL((gemm_deepk_kernel<T, 64, 64, false, true>), grid, dim3(256), 0, st, g.p[0]); break; \
+        case 2: hipLaunchKernelGGL((gemm_deepk_kernel<T, 64, 64, true, false>), grid, dim3(256), 0, st, g.p[0]); break; \
+        case 3: hipLaunchKernelGGL((gemm_deepk_kernel<T, 64, 64, true, true>), grid, dim3(256), 0, st, g.p[0]); break; \
+        case 4: hipLaunchKernelGGL((gemm_deepk_kernel<T, 32, 32, false, false>), grid, dim3(256), 0, st, g.p[0]); break; \
+        case 5: hipLaunchKernelGGL((gemm_deepk_kernel<T, 32, 32, false, true>), grid, dim3(256), 0, st, g.p[0]); break; \
+        case 6: hipLaunchKernelGGL((gemm_deepk_kernel<T, 32, 32, true, false>), grid, dim3(256), 0, st, g.p[0]); break; \
+        default: hipLaunchKernelGGL((gemm_deepk_kernel<T, 32, 32, true, true>), grid, dim3(256), 0, st, g.p[0]); break; \
+      }
+      if (dtype == STJ_BF16) { STJ_ONE_DEEP(bf16) } else { STJ_ONE_DEEP(f16) }
+#undef STJ_ONE_DEEP
+      return stj_check_launch("stj_gemm(group of 1, deep k)");
+    }
 #define STJ_ONE(T) \
     switch (c) { \
       case 0: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, false, false>), grid, dim3(256), 0, st, g.p[0]); break; \
@@ -527,6 +571,7 @@ static int group_flush(hipStream_t st) {
 #undef STJ_ONE
     return stj_check_launch("stj_gemm(group of 1)");
   }
+  for (int i = 0; i < g.n; ++i) g.cfg[i] &= 7;      // deep k-tile bodies are not in the group kernel (measured: its occupancy drops 4 -> 3, 916 -> 908 scenes/s)
   const int total = g.start[g.n];
   if (dtype == STJ_BF16) hipLaunchKernelGGL(gemm_group_kernel<bf16>, dim3(total), dim3(256), 0, st, g);
   else if (dtype == STJ_F16) hipLaunchKernelGGL(gemm_group_kernel<f16>, dim3(total), dim3(256), 0, st, g);
@@ -560,7 +605,11 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, hipStream_t st)
     g_rec_dtype = dtype;
     g_grp.p[i] = p;
     g_grp.gx[i] = (int)tiles; g_grp.gy[i] = (int)gy;
-    g_grp.cfg[i] = (small ? 4 : 0) + (ta ? 2 : 0) + (tb ? 1 : 0);
+    static int deepg = -1;
+    if (deepg < 0) { const char* e = getenv("STJ_GEMM_DEEPK"); deepg = e ? atoi(e) : 1; }
+    const bool deep = sizeof(T) == 2 && deepg && !p.accumulate && p.splitk == 1 && p.K > 128 && p.vecA && p.vecB && p.K % 8 == 0 && p.M % 8 == 0 &&
+                      p.N % 8 == 0;
+    g_grp.cfg[i] = (deep ? 8 : 0) + (small ? 4 : 0) + (ta ? 2 : 0) + (tb ? 1 : 0);
     g_grp.start[i] = g_rec_blocks;
     g_rec_blocks += (int)((tiles * gy + 7) / 8 * 8);
     g_grp.start[i + 1] = g_rec_blocks;
@@ -607,6 +656,23 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, hipStream_t st)
     if (s * nb > 65535) s = 65535 / nb;
     if (s >= 8 && nb == 1) s = s / 8 * 8;      // multiple of 8: enables the XCD-aware work map
     p.splitk = (int)s;
+  }
+  if constexpr (sizeof(T) == 2) {
+    static int deep = -1;
+    if (deep < 0) { const char* e = getenv("STJ_GEMM_DEEPK"); deep = e ? atoi(e) : 1; }
+    if (deep && !p.accumulate && p.splitk == 1 && (cfg == 2 || cfg == 3) && p.K > 128 && p.vecA && p.vecB && p.K % 8 == 0 && p.M % 8 == 0 && p.N % 8 == 0) {
+      dim3 grid(cfg == 2 ? (unsigned)(((p.M + 63) / 64) * ((p.N + 63) / 64)) : (unsigned)(((p.M + 31) / 32) * ((p.N + 31) / 32)), p.nb1 * p.nb2), blk(256);
+#define STJ_DEEP(BMN) \
+      do { \
+        if (ta && tb) hipLaunchKernelGGL((gemm_deepk_kernel<T, BMN, BMN, true, true>), grid, blk, 0, st, p); \
+        else if (ta) hipLaunchKernelGGL((gemm_deepk_kernel<T, BMN, BMN, true, false>), grid, blk, 0, st, p); \
+        else if (tb) hipLaunchKernelGGL((gemm_deepk_kernel<T, BMN, BMN, false, true>), grid, blk, 0, st, p); \
+        else hipLaunchKernelGGL((gemm_deepk_kernel<T, BMN, BMN, false, false>), grid, blk, 0, st, p); \
+      } while (0)
+      if (cfg == 2) STJ_DEEP(64); else STJ_DEEP(32);
+#undef STJ_DEEP
+      return stj_check_launch("stj_gemm(deep k)");
+    }
   }
   if (cfg == 4) launch_tile<T, 96, 128, 2, 2>(p, ta, tb, st);
   else if (cfg == 5) launch_tile<T, 128, 96, 2, 2>(p, ta, tb, st);

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from strajnet_amd import ops
-SHAPES = [(32768, 96, 288), (32768, 96, 96), (32768, 96, 384), (32768, 384, 96), (8192, 192, 576), (8192, 768, 192), (2048, 384, 1152),
+SHAPES = [(2048, 384, 384), (2048, 384, 1536), (2048, 1536, 384), (16384, 384, 512), (16384, 512, 384), (512, 384, 384), (8192, 192, 384), (32768, 96, 288), (32768, 96, 96), (32768, 96, 384), (32768, 384, 96), (8192, 192, 576), (8192, 768, 192), (2048, 384, 1152),
           (2048, 1536, 384), (16384, 384, 126), (16384, 128, 512)]
 dt = torch.bfloat16
 def timeit(fn, iters=10):

@@ -59,3 +59,24 @@ print(f'# time with no kernel >= {THIN:.0f} us running: {total_thin:.1f} us')
 for a_, b_, nm in stretches:
     if (b_ - a_) / 1e3 > 50:
         print(f'#   thin {(a_ - t0) / 1e3:8.1f} .. {(b_ - t0) / 1e3:8.1f}  ({(b_ - a_) / 1e3:6.1f} us, {len(nm)} small kernels)')
+# ---- wall-time attribution: every instant of the step is split equally among the kernels running at it; summed per kernel name.
+# (A kernel that always overlaps another costs the step half its duration; the table shows where the WALL time of the concurrent step
+# goes, next to each kernel's summed duration.)
+import re
+pts = sorted(set([s for s, e, st, n in step] + [e for s, e, st, n in step]))
+idx = {t: i for i, t in enumerate(pts)}
+cnt = [0] * len(pts)
+for s, e, st, n in step:
+    for i in range(idx[s], idx[e]):
+        cnt[i] += 1
+share, dur = {}, {}
+for s, e, st, n in step:
+    k = re.sub(r'\(.*', '', n.replace('void ', ''))[:70]
+    w = 0.0
+    for i in range(idx[s], idx[e]):
+        w += (pts[i + 1] - pts[i]) / cnt[i]
+    share[k] = share.get(k, 0.0) + w / 1e3
+    dur[k] = dur.get(k, 0.0) + (e - s) / 1e3
+print(f'# wall-time attribution (us of the {(step[-1][1] - t0) / 1e3:.0f} us step; summed kernel duration in brackets):')
+for k, v in sorted(share.items(), key=lambda kv: -kv[1])[:28]:
+    print(f'#   {v:8.1f}  [{dur[k]:8.1f}]  {k}')
