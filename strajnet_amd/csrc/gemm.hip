@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && sizeof(T) == 2) ? ((!
 // stages (2048 .. 16384 rows, K = 192 .. 1536) are bound by the dependent chain load -> LDS -> barrier -> MFMA -> barrier of each k-tile
 // (~2 us per link whatever its size, tools/bench_gemm_pmc.py); a K = 384 layer is 2 links instead of 6.
 template <typename T, int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256, 3) void gemm_deepk_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, BM == 32 ? 5 : 3) void gemm_deepk_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[GemmSmem<T, BM, BN, 2, 2, TA, TB, 384>::BYTES];
   __shared__ float bias_s[BN];
   gemm_body<T, BM, BN, 2, 2, TA, TB, 384>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem, bias_s);
@@ -606,7 +606,7 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, hipStream_t st)
     g_grp.p[i] = p;
     g_grp.gx[i] = (int)tiles; g_grp.gy[i] = (int)gy;
     static int deepg = -1;
-    if (deepg < 0) { const char* e = getenv("STJ_GEMM_DEEPK"); deepg = e ? atoi(e) : 1; }
+    if (deepg < 0) { const char* e = getenv("STJ_GEMM_DEEPK"); deepg = e ? atoi(e) : 2; }
     const bool deep = sizeof(T) == 2 && deepg && !p.accumulate && p.splitk == 1 && p.K > 128 && p.vecA && p.vecB && p.K % 8 == 0 && p.M % 8 == 0 &&
                       p.N % 8 == 0;
     g_grp.cfg[i] = (deep ? 8 : 0) + (small ? 4 : 0) + (ta ? 2 : 0) + (tb ? 1 : 0);
@@ -659,9 +659,9 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, hipStream_t st)
   }
   if constexpr (sizeof(T) == 2) {
     static int deep = -1;
-    if (deep < 0) { const char* e = getenv("STJ_GEMM_DEEPK"); deep = e ? atoi(e) : 1; }
-    if (deep && !p.accumulate && p.splitk == 1 && (cfg == 2 || cfg == 3) && p.K > 128 && p.vecA && p.vecB && p.K % 8 == 0 && p.M % 8 == 0 && p.N % 8 == 0) {
-      dim3 grid(cfg == 2 ? (unsigned)(((p.M + 63) / 64) * ((p.N + 63) / 64)) : (unsigned)(((p.M + 31) / 32) * ((p.N + 31) / 32)), p.nb1 * p.nb2), blk(256);
+    if (deep < 0) { const char* e = getenv("STJ_GEMM_DEEPK"); deep = e ? atoi(e) : 2; }
+    if (deep && (deep >= 2 || (!p.accumulate && p.splitk == 1)) && (cfg == 2 || cfg == 3) && p.K > 128 && p.vecA && p.vecB && p.K % 8 == 0 && p.M % 8 == 0 && p.N % 8 == 0) {
+      dim3 grid(cfg == 2 ? (unsigned)(((p.M + 63) / 64) * ((p.N + 63) / 64)) : (unsigned)(((p.M + 31) / 32) * ((p.N + 31) / 32)), p.nb1 * p.nb2 * p.splitk), blk(256);
 #define STJ_DEEP(BMN) \
       do { \
         if (ta && tb) hipLaunchKernelGGL((gemm_deepk_kernel<T, BMN, BMN, true, true>), grid, blk, 0, st, p); \
