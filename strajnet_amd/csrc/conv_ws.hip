@@ -555,11 +555,192 @@ __global__ __launch_bounds__(256, 2) void upconv_wgrad_tr_kernel(const bf16* __r
     }
 }
 
+// Weight gradient, v3: BOTH column parities of a row parity in one 512-thread workgroup.  In the kernel above a workgroup is
+// (strip, phase, channel tile): the four phase blocks of a chunk each stage the same X halo (33 of their 45 KB) and their own quarter
+// of dP, 1.47 GB of L1 fills per launch of the 96 -> 48 layer = 5.8 TB/s through L2 at 253 us -- the L2 -> L1 ceiling the 64 x 64 GEMM
+// tiles run into as well.  Here a workgroup is (strip, row parity a, channel tile) and wave w = (column parity b = w >> 2, tap w & 3):
+// X (CR + 1 rows) and the CR hi-res dP rows of parity a are staged once for both b (114 instead of 180 KB per chunk and row-parity
+// pair of the 96 -> 48 layer); every wave reads its own column parity / tap through its transpose-read addresses.  (All four phases in
+// one 1024-thread workgroup would stage 82 KB, but at 128 VGPRs per lane the 72 accumulator registers leave no room for the
+// register-staged prefetch: 140-196 bytes of scratch per lane.)
+template <int FO, int FI, int CW, int NPIX>
+__global__ __launch_bounds__(512, 2) void upconv_wgrad_tr4_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dP,
+                                                                  float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin,
+                                                                  int Cout, int chunks_per_block, int nstrips, int ntiles) {
+  constexpr int CR = NPIX / CW, KROWS = 32 / CW;          // NPIX low-res pixels per barrier pair (NPIX / 32 k-steps)
+  constexpr int BO = FO * 16, BI = FI * 16;
+  constexpr int LDO = BO + 8, LDI = BI + 8;
+  constexpr int YW = 2 * CW, YR = CR, XW = CW + 2, XR = CR + 1;
+  constexpr int DY_CH = YR * YW * (BO / 8), X_CH = XR * XW * (BI / 8);
+  constexpr int NCH = (DY_CH + X_CH + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char w4_smem[];
+  constexpr int BUF = YR * YW * LDO + XR * XW * LDI;       // elements of one stage; TWO stages: the next chunk is written while this one
+  bf16* dYs = reinterpret_cast<bf16*>(w4_smem);            // is read -- one barrier per chunk.  [CR][2 CW][LDO]: hi-res dP rows 2 (i0 + ri) + a
+  bf16* Xs = dYs + YR * YW * LDO;                          // [CR + 1][CW + 2][LDI]: X rows i0 + a - 1 .., columns j0 - 1 ..
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int inner = 2 * ntiles;
+  const int strip = (slot / inner) * 8 + xcd, a = (slot % inner) & 1, ctile = (slot % inner) >> 1;      // same strip: same XCD, adjacent slots
+  if (strip >= nstrips) return;
+  const int b = w >> 2;
+  const int r = (w >> 1) & 1, s = w & 1;
+  const int g = lane >> 4, p = lane & 15;
+  const int cin_tiles = (Cin + BI - 1) / BI;
+  const int co0 = (ctile / cin_tiles) * BO, ci0 = (ctile % cin_tiles) * BI;
+  const int segs = Wi / CW, rgs = Hi / CR;
+  const int nchunks = F * rgs * segs;
+  const int c_begin = strip * chunks_per_block;
+  const int c_end = min(nchunks, c_begin + chunks_per_block);
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+
+  f32x4 acc[FO][FI];
+#pragma unroll
+  for (int m = 0; m < FO; ++m)
+#pragma unroll
+    for (int n = 0; n < FI; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_db = dbias != nullptr && ci0 == 0 && (w & 3) == 0;         // one wave per phase sums its quarter of the pixels
+  f32x4 dbf[FO];
+#pragma unroll
+  for (int m = 0; m < FO; ++m) dbf[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const s16x8 ones = (s16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+  // this thread's staging chunks (geometry independent of the pixel chunk)
+  int soff[NCH], slds[NCH], sryx[NCH];
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int q = tid + u * 512;
+    if (q < DY_CH) {
+      const int px = q / (BO / 8), ch = (q % (BO / 8)) * 8;
+      const int ry = px / YW, rx = px % YW;
+      soff[u] = ((2 * ry + a) * Wo + rx) * Cout + co0 + ch;
+      slds[u] = (co0 + ch < Cout) ? px * LDO + ch : -1;
+      sryx[u] = 0x40000000;                                               // dP chunk: always inside the image
+    } else if (q < DY_CH + X_CH) {
+      const int q2 = q - DY_CH;
+      const int px = q2 / (BI / 8), ch = (q2 % (BI / 8)) * 8;
+      const int ry = px / XW + a - 1, rx = px % XW - 1;
+      soff[u] = (ry * Wi + rx) * Cin + ci0 + ch;
+      slds[u] = (ci0 + ch < Cin) ? YR * YW * LDO + px * LDI + ch : -1;
+      sryx[u] = (ry & 0xff) | ((rx & 0xffff) << 8);
+    } else {
+      soff[u] = 0; slds[u] = -1; sryx[u] = 0x40000000;
+    }
+  }
+  uint4 pre[NCH];
+  bool pin[NCH];
+  auto prefetch = [&](int c) {
+    const int seg = c % segs, t = c / segs;
+    const int i0 = (t % rgs) * CR, f = t / rgs;
+    const int j0 = seg * CW;
+    const bf16* Pt = dP + (((long long)f * Ho + 2 * i0) * Wo + 2 * j0) * Cout;
+    const bf16* Xt = X + (((long long)f * Hi + i0) * Wi + j0) * Cin;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const bool isx = !(sryx[u] & 0x40000000);
+      const int gy = i0 + (signed char)(sryx[u] & 0xff), gx = j0 + (short)((sryx[u] >> 8) & 0xffff);
+      pin[u] = slds[u] >= 0 && (!isx || ((unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi));
+      const bf16* src = isx ? Xt : Pt;
+      pre[u] = *reinterpret_cast<const uint4*>(src + (pin[u] ? soff[u] : 0));      // unconditional (chunk origins are inside the image)
+    }
+  };
+  auto commit = [&](int bo) {
+#pragma unroll
+    for (int u = 0; u < NCH; ++u)
+      if (slds[u] >= 0) *reinterpret_cast<uint4*>(dYs + bo + slds[u]) = pin[u] ? pre[u] : make_uint4(0, 0, 0, 0);
+  };
+  if (c_begin < c_end) { prefetch(c_begin); commit(0); }
+  __syncthreads();
+  const int kpx = 8 * g + (p >> 2), kch = 4 * (p & 3);
+  const int krow = kpx / CW, kcol = kpx % CW;
+  for (int c = c_begin; c < c_end; ++c) {
+    const int bo = ((c - c_begin) & 1) * BUF;
+    if (c + 1 < c_end) prefetch(c + 1);
+#pragma unroll 4
+    for (int rr = 0; rr < NPIX / 32; ++rr) {              // k-step rr = low-res pixels 32 rr .. 32 rr + 31 of the chunk (row-major)
+      s16x8 af[FO], bfr[FI];
+      const bf16* ab = dYs + bo + ((rr * KROWS + krow) * YW + 2 * kcol + b) * LDO + kch;               // this wave's column parity
+#pragma unroll
+      for (int m = 0; m < FO; ++m) af[m] = tr_frag(ab + m * 16, ab + 8 * LDO + m * 16);          // + 4 low-res pixels = + 8 hi-res columns
+      const bf16* bb = Xs + bo + ((rr * KROWS + krow + r) * XW + kcol + b + s) * LDI + kch;
+#pragma unroll
+      for (int n = 0; n < FI; ++n) bfr[n] = tr_frag(bb + n * 16, bb + 4 * LDI + n * 16);
+#pragma unroll
+      for (int m = 0; m < FO; ++m)
+#pragma unroll
+        for (int n = 0; n < FI; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[m]), __builtin_bit_cast(bf16x8_t, bfr[n]), acc[m][n], 0, 0, 0);
+      if (do_db) {
+#pragma unroll
+        for (int m = 0; m < FO; ++m)
+          dbf[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[m]), __builtin_bit_cast(bf16x8_t, ones), dbf[m], 0, 0, 0);
+      }
+    }
+    if (c + 1 < c_end) commit(BUF - bo);                  // the other stage: last read one barrier ago
+    __syncthreads();
+  }
+  if (do_db && p == 0) {
+    float* dbp = dbias + (long long)((blockIdx.x * 2 + b) % db_parts) * Cout;
+#pragma unroll
+    for (int m = 0; m < FO; ++m)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = co0 + m * 16 + g * 4 + rg;
+        if (co < Cout) atomicAdd(dbp + co, dbf[m][rg]);
+      }
+  }
+  const int pt = a * 8 + b * 4 + r * 2 + s;
+#pragma unroll
+  for (int m = 0; m < FO; ++m)
+#pragma unroll
+    for (int n = 0; n < FI; ++n) {
+      const int ci = ci0 + n * 16 + p;
+      if (ci >= Cin) continue;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = co0 + m * 16 + g * 4 + rg;
+        if (co < Cout) atomicAdd(dWeff + ((long long)pt * Cout + co) * Cin + ci, acc[m][n][rg]);
+      }
+    }
+}
+
+template <int FO, int FI, int CW, int NPIX>
+static bool wgrad_tr4_launch(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout,
+                             int tiles, hipStream_t st) {
+  constexpr int CR = NPIX / CW, BO = FO * 16, BI = FI * 16;
+  const size_t lds = (size_t)2 * (CR * 2 * CW * (BO + 8) + (CR + 1) * (CW + 2) * (BI + 8)) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)upconv_wgrad_tr4_kernel<FO, FI, CW, NPIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    attr_set = true;
+  }
+  const long long nchunks = (long long)F * (Hi / CR) * (Wi / CW);
+  static int nb = -1;
+  if (nb < 0) { const char* e = getenv("STJ_WGRAD_V4_BLOCKS"); nb = e ? atoi(e) : 256; }
+  int strips = (int)min(nchunks, (long long)max(1, nb / (2 * tiles)));   // x 2 row parities x tiles workgroups: one per CU
+  const int cpb = (int)((nchunks + strips - 1) / strips);
+  strips = (int)((nchunks + cpb - 1) / cpb);
+  hipLaunchKernelGGL((upconv_wgrad_tr4_kernel<FO, FI, CW, NPIX>), dim3((strips + 7) / 8 * 8 * 2 * tiles), dim3(512), lds, st, (const bf16*)X, (const bf16*)dP,
+                     dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, cpb, strips, tiles);
+  return true;
+}
+
 // returns true when handled (bf16; Wi % 32 == 0 and Hi % 4 == 0, or Wi % 16 == 0 and Hi % 8 == 0; channels % 8 == 0)
 template <int CW>
 static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   constexpr int CR = 128 / CW;
   const long long nchunks = (long long)F * (Hi / CR) * (Wi / CW);
+  static int v4 = -1;
+  if (v4 < 0) { const char* e = getenv("STJ_WGRAD_V4"); v4 = e ? atoi(e) : 1; }
+  // (the two large layers only: at 32 x 32 and below a strip has too few chunks to amortise a 512-thread workgroup: 149 vs 113 us)
+  if (v4 && Hi % (256 / CW) == 0 && nchunks >= 2048) {
+    if (v4 != 3) {       // 128-pixel chunks (256: register-staged prefetch spills)
+      if (Cout <= 48 && Cin <= 96) return wgrad_tr4_launch<3, 6, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, 1, st);
+      return wgrad_tr4_launch<4, 4, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, ((Cout + 63) / 64) * ((Cin + 63) / 64), st);
+    }
+    if (Cout <= 48 && Cin <= 96) return wgrad_tr4_launch<3, 6, CW, 256>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, 1, st);
+    return wgrad_tr4_launch<4, 4, CW, 256>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, ((Cout + 63) / 64) * ((Cin + 63) / 64), st);
+  }
   if (Cout <= 48 && Cin <= 96) {
     int strips = (int)min(nchunks, (long long)256);     // 128 and 512 measured within noise / slower
     const int cpb = (int)((nchunks + strips - 1) / strips);
