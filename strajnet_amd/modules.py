@@ -776,6 +776,7 @@ class STrajNet:
         self._tap('query', query)
         x = self._cross_attention_z(query.contiguous(), key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
         self._tap('cross_attention_out', x)
+        x = ops.wgrad_flush_point(x)             # the decoder's weight gradients are launched when ITS backward is through (ops.py)
         out = self._decoder(x, res_list, B, skips)
         self._tap('output', out)
         return ops.join_after_backward(out, (self._side, self._side2), fold)

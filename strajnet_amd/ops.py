@@ -243,6 +243,8 @@ class _JoinAfterBackward(torch.autograd.Function):
             # (its own join callback is queued later than this one and would run after it)
             key = g.device.index if g.device.index is not None else torch.cuda.current_device()
             st = _WG.get(key)
+            flush_upconv_wgrads()             # (leftovers: a flush point whose backward did not run)
+            st = _WG.get(key)
             if st is not None and st['armed']:
                 main.wait_stream(st['side'])
             if post is not None:          # e.g. fold the partial-gradient copies into the flat gradient buffer
@@ -1068,18 +1070,62 @@ def _upconv_backward_tail(ctx, x, dpre, wd, need_dx):
     if need_dx:
         dx = torch.empty_like(x)
         call('stj_upconv_dgrad', _p(dpre), _p(wd), _p(dx), _p(x) if ctx.x_is_elu_out else None, F_, Hi, Wi, Cin, Cout, dt, _st())
-    with wgrad_stream(2, x, dpre):
+    pw, pb = ctx.pw, ctx.pb
+
+    def wg():
         dweff = zeros_f32(16 * Cout * Cin, x.device)     # the 16 folded tap matrices
-        pb = ctx.pb
         if pb.part is not None:  # model-owned bias-gradient copies, folded into .grad once per step
             dbp, nparts, own = pb.part[0], pb.part[1], False
         else:                    # (~1000 workgroups would queue on Cout addresses otherwise)
             dbp, nparts, own = torch.zeros(_DB_PARTS * Cout, dtype=torch.float32, device=x.device), _DB_PARTS, True
         call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), nparts, F_, Hi, Wi, Cin, Cout, dt, _st())
-        call('stj_upconv_fold', _p(dweff), _p(ctx.pw.grad), Cin, Cout, _st())
+        call('stj_upconv_fold', _p(dweff), _p(pw.grad), Cin, Cout, _st())
         if own:
             pb.grad.add_(dbp.view(nparts, Cout).sum(0))
+    if _UPWG['on'] and not _SERIAL and (_WG_MODE & 2):
+        _UPWG['items'].append((wg, x, dpre))             # launched by flush_upconv_wgrads() (the model's flush point)
+    else:
+        with wgrad_stream(2, x, dpre):
+            wg()
     return dx
+
+
+# Deferred up-conv weight gradients.  Launched where they are produced, the six weight-gradient kernels of the decoder (1.1 ms of work) share
+# HBM with the input-gradient chain they run next to (the 96 <- 48 dgrad takes 0.48 ms in the step, 0.31 ms alone) and are finished long before
+# anybody needs them.  The model puts a flush point behind the decoder (in backward order): the kernels are queued there, on the side stream,
+# under the cross-attention / FG-MSA backward -- a chain of short launches that leaves most of the GPU idle.
+_UPWG = {'on': False, 'items': []}
+
+
+def flush_upconv_wgrads():
+    items, _UPWG['items'] = _UPWG['items'], []
+    if not items:
+        return
+    with wgrad_stream(2, *[t for it in items for t in it[1:]]):
+        for wg, _, _ in items:
+            wg()
+
+
+class _WgradFlushPoint(torch.autograd.Function):
+    """Identity.  Everything downstream of it in the forward pass has finished its backward when this node's backward runs."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        flush_upconv_wgrads()
+        return g
+
+
+def wgrad_flush_point(x):
+    """Mark x as the input of the region whose up-conv weight gradients are deferred (no-op without autograd or with STJ_DEFER_UPWG=0)."""
+    _UPWG['on'] = DEFER_UPWG and x.requires_grad and torch.is_grad_enabled()
+    _UPWG['items'] = []
+    return _WgradFlushPoint.apply(x) if _UPWG['on'] else x
+
+
+DEFER_UPWG = os.environ.get('STJ_DEFER_UPWG', '1') != '0'
 
 
 class _UpConv(torch.autograd.Function):
