@@ -22,9 +22,9 @@
 enum { S_OBS = 0, S_OCC = 1, S_L1 = 2, S_EX = 3, S_WARP = 4, S_N = 5 };
 
 __device__ __forceinline__ float xe_logits(float z, float x) {   // tf.nn.sigmoid_cross_entropy_with_logits
-  return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+  return fmaxf(x, 0.f) - x * z + log1pf(__expf(-fabsf(x)));      // v_exp_f32 (1 ulp on a value in (0, 1]); log1p stays exact for small arguments
 }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return __frcp_rn(1.f + __expf(-x)); }
 // XE + tfa focal term on a logit x with label y; *d = derivative w.r.t. x when d != NULL
 __device__ __forceinline__ float xe_focal_logits(float y, float x, float* d) {
   const float ce = xe_logits(y, x), p = sigmoidf(x);
@@ -161,50 +161,52 @@ __global__ __launch_bounds__(128) void auc_gate_kernel(const int* hist, float* g
 }
 
 // ---- forward sums -------------------------------------------------------------------------------------
+// One thread per (pixel, waypoint) -- thread index = pixel * 8 + k: a lane loads ITS float4 of the pixel's 128-byte logit line (fully
+// coalesced) and carries 5 accumulators; the ground-truth reads of the 8 lanes of a waypoint within a wave cover 8 consecutive pixels
+// (32-byte sectors).  The first version had one thread per pixel with all 8 waypoints (40 accumulators + 32 logits: 154 VGPRs, three
+// waves per SIMD for a kernel that waits on four gathers per waypoint, and every 16-byte logit load touching 64 different cache lines
+// per wave): 85 us for 151 MB.
 template <bool FOCAL, bool PRED>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* logits, const float* gt_obs, const float* gt_occ,
                                                        const float* gt_flow, const float* origin, float* sums,
                                                        int B, int H, int W, int use_warp) {
   __shared__ float red[4][NWP * S_N];
   const float inv_hw = 1.f / ((float)H * (float)W);
-  float acc[NWP * S_N];
+  float acc[S_N];
 #pragma unroll
-  for (int i = 0; i < NWP * S_N; ++i) acc[i] = 0.f;
-  const long long npix = (long long)B * H * W;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += gridDim.x * 256ll) {
+  for (int i = 0; i < S_N; ++i) acc[i] = 0.f;
+  const long long nitem = (long long)B * H * W * NWP;
+  const int k = threadIdx.x & 7;                       // 256 % 8 == 0 and the grid stride is a multiple of 8: k is fixed per thread
+  for (long long it = blockIdx.x * 256ll + threadIdx.x; it < nitem; it += gridDim.x * 256ll) {
+    const long long i = it >> 3;
     const int x = (int)(i % W); long long t = i / W;
     const int y = (int)(t % H); const long long b = t / H;
-    float lg[32];
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      const float4 q = reinterpret_cast<const float4*>(logits + i * 32)[v];
-      lg[4 * v] = q.x; lg[4 * v + 1] = q.y; lg[4 * v + 2] = q.z; lg[4 * v + 3] = q.w;
-    }
-#pragma unroll
-    for (int k = 0; k < NWP; ++k) {
-      const long long g = ((b * NWP + k) * H + y) * W + x;
-      const float to = gt_obs[g], tc = gt_occ[g];
-      const float fx = gt_flow[2 * g], fy = gt_flow[2 * g + 1];
-      acc[k * S_N + S_OBS] += FOCAL ? xe_focal_logits(to, lg[4 * k], nullptr) : xe_logits(to, lg[4 * k]);
-      acc[k * S_N + S_OCC] += FOCAL ? xe_focal_logits(tc, lg[4 * k + 1], nullptr) : xe_logits(tc, lg[4 * k + 1]);
-      const float ex = (fx != 0.f || fy != 0.f) ? 1.f : 0.f;
-      acc[k * S_N + S_L1] += (fabsf(fx - lg[4 * k + 2]) + fabsf(fy - lg[4 * k + 3])) * ex;
-      acc[k * S_N + S_EX] += ex;
-      if (use_warp) {
-        const float* img = origin + (b * NWP + k) * (long long)H * W;
-        const float wp = warp_sample(img, H, W, (float)x + lg[4 * k + 2], (float)y + lg[4 * k + 3], nullptr, nullptr);
-        const float sg = PRED ? fminf(fmaxf(sigmoidf(lg[4 * k]) + sigmoidf(lg[4 * k + 1]), 0.f), 1.f)
-                              : fminf(fmaxf(sigmoidf(to) + sigmoidf(tc), 0.f), 1.f);
-        const float ta = fminf(fmaxf(to + tc, 0.f), 1.f);
-        acc[k * S_N + S_WARP] += warp_term<FOCAL, PRED>(ta, sg * wp, inv_hw, nullptr);
-      }
+    const float4 lg = reinterpret_cast<const float4*>(logits)[it];
+    const long long g = ((b * NWP + k) * H + y) * W + x;
+    const float to = gt_obs[g], tc = gt_occ[g];
+    const float2 fl = reinterpret_cast<const float2*>(gt_flow)[g];
+    const float fx = fl.x, fy = fl.y;
+    acc[S_OBS] += FOCAL ? xe_focal_logits(to, lg.x, nullptr) : xe_logits(to, lg.x);
+    acc[S_OCC] += FOCAL ? xe_focal_logits(tc, lg.y, nullptr) : xe_logits(tc, lg.y);
+    const float ex = (fx != 0.f || fy != 0.f) ? 1.f : 0.f;
+    acc[S_L1] += (fabsf(fx - lg.z) + fabsf(fy - lg.w)) * ex;
+    acc[S_EX] += ex;
+    if (use_warp) {
+      const float* img = origin + (b * NWP + k) * (long long)H * W;
+      const float wp = warp_sample(img, H, W, (float)x + lg.z, (float)y + lg.w, nullptr, nullptr);
+      const float sg = PRED ? fminf(fmaxf(sigmoidf(lg.x) + sigmoidf(lg.y), 0.f), 1.f)
+                            : fminf(fmaxf(sigmoidf(to) + sigmoidf(tc), 0.f), 1.f);
+      const float ta = fminf(fmaxf(to + tc, 0.f), 1.f);
+      acc[S_WARP] += warp_term<FOCAL, PRED>(ta, sg * wp, inv_hw, nullptr);
     }
   }
+  // lanes with equal (lane & 7) hold the same waypoint: reduce over lane bits 3..5, then the 4 waves through LDS
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < NWP * S_N; ++i) {
-    const float s = wave_sum(acc[i]);
-    if (lane == 0) red[w][i] = s;
+  for (int i = 0; i < S_N; ++i) {
+    float v = acc[i];
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if (lane < 8) red[w][lane * S_N + i] = v;
   }
   __syncthreads();
   // LOSS_PARTS copies of the 40 accumulators: 2048 blocks on one copy queue 2048 same-address atomics per slot (~70 of this
@@ -251,59 +253,47 @@ template <bool FOCAL, bool PRED>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* logits, const float* gt_obs, const float* gt_occ,
                                                        const float* gt_flow, const float* origin, const float* coef,
                                                        const float* up, float* dlogits, int B, int H, int W, int use_warp) {
-  __shared__ float cf[NWP * 4];
-  if (threadIdx.x < NWP * 4) cf[threadIdx.x] = coef[threadIdx.x] * up[threadIdx.x & 3];
-  __syncthreads();
-  const long long npix = (long long)B * H * W;
+  // one thread per (pixel, waypoint), as in loss_fwd_kernel: one coalesced float4 in, one out
+  const int k = threadIdx.x & 7;
+  const float c0 = coef[4 * k] * up[0], c1 = coef[4 * k + 1] * up[1], c2 = coef[4 * k + 2] * up[2], c3 = coef[4 * k + 3] * up[3];
+  const long long nitem = (long long)B * H * W * NWP;
   const float inv_hw = 1.f / ((float)H * (float)W);
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += gridDim.x * 256ll) {
+  for (long long it = blockIdx.x * 256ll + threadIdx.x; it < nitem; it += gridDim.x * 256ll) {
+    const long long i = it >> 3;
     const int x = (int)(i % W); long long t = i / W;
     const int y = (int)(t % H); const long long b = t / H;
-    float lg[32], dl[32];
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      const float4 q = reinterpret_cast<const float4*>(logits + i * 32)[v];
-      lg[4 * v] = q.x; lg[4 * v + 1] = q.y; lg[4 * v + 2] = q.z; lg[4 * v + 3] = q.w;
-    }
-#pragma unroll
-    for (int k = 0; k < NWP; ++k) {
-      const long long g = ((b * NWP + k) * H + y) * W + x;
-      const float to = gt_obs[g], tc = gt_occ[g];
-      const float fx = gt_flow[2 * g], fy = gt_flow[2 * g + 1];
-      float g0, g1;
-      if (FOCAL) { xe_focal_logits(to, lg[4 * k], &g0); xe_focal_logits(tc, lg[4 * k + 1], &g1); }
-      else { g0 = sigmoidf(lg[4 * k]) - to; g1 = sigmoidf(lg[4 * k + 1]) - tc; }
-      g0 *= cf[4 * k]; g1 *= cf[4 * k + 1];
-      const float ex = (fx != 0.f || fy != 0.f) ? 1.f : 0.f;
-      const float d0 = fx - lg[4 * k + 2], d1 = fy - lg[4 * k + 3];
-      float g2 = -cf[4 * k + 2] * ex * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
-      float g3 = -cf[4 * k + 2] * ex * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
-      if (use_warp && cf[4 * k + 3] != 0.f) {
-        const float* img = origin + (b * NWP + k) * (long long)H * W;
-        float ddx, ddy;
-        const float wp = warp_sample(img, H, W, (float)x + lg[4 * k + 2], (float)y + lg[4 * k + 3], &ddx, &ddy);
-        const float sa = sigmoidf(PRED ? lg[4 * k] : to), sb = sigmoidf(PRED ? lg[4 * k + 1] : tc);
-        const float ssum = sa + sb;
-        const float sg = fminf(fmaxf(ssum, 0.f), 1.f);
-        const float ta = fminf(fmaxf(to + tc, 0.f), 1.f);
-        float dq;
-        warp_term<FOCAL, PRED>(ta, sg * wp, inv_hw, &dq);
-        dq *= cf[4 * k + 3];
-        g2 += dq * sg * ddx;
-        g3 += dq * sg * ddy;
-        if (PRED && ssum <= 1.f) {          // clip_by_value passes the gradient inside [0, 1] (sum of two sigmoids > 0)
-          g0 += dq * wp * sa * (1.f - sa);
-          g1 += dq * wp * sb * (1.f - sb);
-        }
+    const float4 lg = reinterpret_cast<const float4*>(logits)[it];
+    const long long g = ((b * NWP + k) * H + y) * W + x;
+    const float to = gt_obs[g], tc = gt_occ[g];
+    const float2 fl = reinterpret_cast<const float2*>(gt_flow)[g];
+    const float fx = fl.x, fy = fl.y;
+    float g0, g1;
+    if (FOCAL) { xe_focal_logits(to, lg.x, &g0); xe_focal_logits(tc, lg.y, &g1); }
+    else { g0 = sigmoidf(lg.x) - to; g1 = sigmoidf(lg.y) - tc; }
+    g0 *= c0; g1 *= c1;
+    const float ex = (fx != 0.f || fy != 0.f) ? 1.f : 0.f;
+    const float d0 = fx - lg.z, d1 = fy - lg.w;
+    float g2 = -c2 * ex * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+    float g3 = -c2 * ex * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+    if (use_warp && c3 != 0.f) {
+      const float* img = origin + (b * NWP + k) * (long long)H * W;
+      float ddx, ddy;
+      const float wp = warp_sample(img, H, W, (float)x + lg.z, (float)y + lg.w, &ddx, &ddy);
+      const float sa = sigmoidf(PRED ? lg.x : to), sb = sigmoidf(PRED ? lg.y : tc);
+      const float ssum = sa + sb;
+      const float sg = fminf(fmaxf(ssum, 0.f), 1.f);
+      const float ta = fminf(fmaxf(to + tc, 0.f), 1.f);
+      float dq;
+      warp_term<FOCAL, PRED>(ta, sg * wp, inv_hw, &dq);
+      dq *= c3;
+      g2 += dq * sg * ddx;
+      g3 += dq * sg * ddy;
+      if (PRED && ssum <= 1.f) {          // clip_by_value passes the gradient inside [0, 1] (sum of two sigmoids > 0)
+        g0 += dq * wp * sa * (1.f - sa);
+        g1 += dq * wp * sb * (1.f - sb);
       }
-      dl[4 * k] = g0;
-      dl[4 * k + 1] = g1;
-      dl[4 * k + 2] = g2;
-      dl[4 * k + 3] = g3;
     }
-#pragma unroll
-    for (int v = 0; v < 8; ++v)
-      reinterpret_cast<float4*>(dlogits + i * 32)[v] = make_float4(dl[4 * v], dl[4 * v + 1], dl[4 * v + 2], dl[4 * v + 3]);
+    reinterpret_cast<float4*>(dlogits)[it] = make_float4(g0, g1, g2, g3);
   }
 }
 
@@ -322,9 +312,10 @@ extern "C" int stj_loss_fwd(const float* logits, const float* gt_obs, const floa
                             const float* gate, float* sums, float* loss, float* coef, int B, int H, int W, float ogm_w, float occ_w,
                             float flow_origin_w, float replica, int flags, hipStream_t stream) {
   if (((uintptr_t)logits) & 15) { stj_set_error("loss: logits must be 16-byte aligned"); return STJ_EINVAL; }
+  if (((uintptr_t)gt_flow) & 7) { stj_set_error("loss: gt_flow must be 8-byte aligned"); return STJ_EINVAL; }
   if (flags & ~7) { stj_set_error("loss: unknown flag bits %d", flags); return STJ_EINVAL; }
   const long long npix = (long long)B * H * W;
-  const int gx = (int)min(2048ll, (npix + 255) / 256);
+  const int gx = (int)min(4096ll, (npix * NWP + 255) / 256);
   const int use_warp = flags & 1, focal = (flags >> 1) & 1, pred = (flags >> 2) & 1;
 #define LOSS_FWD(FO, PR) hipLaunchKernelGGL((loss_fwd_kernel<FO, PR>), dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, sums, B, H, W, use_warp)
   if (focal && pred) LOSS_FWD(true, true); else if (focal) LOSS_FWD(true, false); else if (pred) LOSS_FWD(false, true); else LOSS_FWD(false, false);
@@ -336,8 +327,10 @@ extern "C" int stj_loss_fwd(const float* logits, const float* gt_obs, const floa
 extern "C" int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                             const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int flags, hipStream_t stream) {
   if (flags & ~7) { stj_set_error("loss: unknown flag bits %d", flags); return STJ_EINVAL; }
+  if ((((uintptr_t)logits) | ((uintptr_t)dlogits)) & 15) { stj_set_error("loss: logits / dlogits must be 16-byte aligned"); return STJ_EINVAL; }
+  if (((uintptr_t)gt_flow) & 7) { stj_set_error("loss: gt_flow must be 8-byte aligned"); return STJ_EINVAL; }
   const long long npix = (long long)B * H * W;
-  const int gx = (int)min(4096ll, (npix + 255) / 256);
+  const int gx = (int)min(8192ll, (npix * NWP + 255) / 256);
   const int use_warp = flags & 1, focal = (flags >> 1) & 1, pred = (flags >> 2) & 1;
 #define LOSS_BWD(FO, PR) hipLaunchKernelGGL((loss_bwd_kernel<FO, PR>), dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, coef, upstream, dlogits, B, H, W, use_warp)
   if (focal && pred) LOSS_BWD(true, true); else if (focal) LOSS_BWD(true, false); else if (pred) LOSS_BWD(false, true); else LOSS_BWD(false, false);
