@@ -22,6 +22,7 @@ class GraphedTrainStep:
         self.model, self.loss_fn, self.training, self.split = model, loss_fn, training, split
         self.static = {k: v.clone() for k, v in batch.items()}
         self.graph = self.graph_b = None
+        self._side = None
         self.losses = None
         if split:
             model.cut_encoder = True
@@ -49,8 +50,18 @@ class GraphedTrainStep:
     def _eager(self):
         x, m = self.static, self.model
         m.zero_grad()
+        tw = warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow'])
+        main = torch.cuda.current_stream()
+        if hasattr(self.loss_fn, 'prepare'):         # the ground-truth-only part of the loss: side stream, under the forward pass
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self.loss_fn.prepare(tw)
         out = m(x['ogm'], x['map_img'], training=self.training, obs=x['obs'], occ=x['occ'], mapt=x.get('mapt'), flow=x['flow'])
-        d = self.loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
+        if self._side is not None:
+            main.wait_stream(self._side)
+        d = self.loss_fn(get_pred_waypoint_logits(out), tw, None)
         total = d.total                      # observed_xe + occluded_xe + flow + flow_warp_xe (train.py:221)
         total.backward()
         return d.packed             # [observed_xe, occluded_xe, flow, flow_warp_xe], detached
