@@ -1277,6 +1277,186 @@ __global__ __launch_bounds__(256, 3) void outconv_bwd_mfma_kernel(const bf16* __
   if (tid < 2) mypart[9 * C * 2 + tid] = dbs[tid];
 }
 
+// Backward, v2 (round 2).  The weight gradient is re-associated: dW[t][c][o] = sum_p X[p + off(t)][c] dY[p][o] = sum_p' X[p'][c] dY[p' - off(t)][o],
+// p' over the tile's OWN pixels -- so the taps move into the N dimension of the MFMA (B[k = pixel][n = (tap, o)], 18 of 32 columns, built
+// from the 18 x 18 dY halo that the input gradient needs anyway) and the A operand is the UNSHIFTED X tile, read once per k-step for all
+// nine taps: 6 transpose reads + 16 scalar reads + 6 MFMAs per 32-pixel k-step, where v1 (one accumulator per (tap, channel block),
+// the X tile shifted per tap) needs 14 + 8 + 7 in each of its four waves -- and X needs no halo any more (256 instead of 324 pixels per
+// tile).  A wave owns two of the eight k-steps (the four tile rows it also produces dX for); the four partial sums meet in LDS once,
+// at the end of the kernel.
+template <int C>
+__global__ __launch_bounds__(256, 3) void outconv_bwd_mfma2_kernel(const bf16* __restrict__ X, const float* __restrict__ W,
+                                                                   const float* __restrict__ dY, bf16* __restrict__ dX,
+                                                                   float* __restrict__ part, int F, int Hh, int Ww, int Tn,
+                                                                   long long y_bs, long long y_ts, long long y_ps, int elu_in) {
+  static_assert(C == 48, "specialised for 48 channels");
+  constexpr int LDH = C + 8;
+  constexpr int CPP = C / 8, NCH = (OCM_T * OCM_T * CPP + 255) / 256;      // 6
+  constexpr int NDY = (OCM_H * OCM_H + 255) / 256;                         // 2
+  __shared__ __attribute__((aligned(16))) bf16 Xs[OCM_T * OCM_T * LDH];    // the tile's own pixels only
+  __shared__ __attribute__((aligned(16))) float dys[OCM_H * OCM_H * 2];
+  // [mf][nf][row 0..15][col 0..15] cross-wave sum of dW; padded to 10 KB so that the workgroup takes > 40 KB of LDS: with room for a
+  // fourth workgroup per CU the compiler targets 128 VGPRs and keeps the prefetch registers in scratch (112 bytes per lane)
+  __shared__ float wred[3 * 2 * 16 * 16 + 1024];
+  __shared__ float dbs[2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
+  // dX weights: A[m = c][k = (tap, o)], k = 2*tap + o < 18 ; lane row c = mf*16 + ln, k = 8g + j
+  s16x8 ax[3];
+#pragma unroll
+  for (int mf = 0; mf < 3; ++mf) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; v[j] = k < 18 ? W[((k >> 1) * C + mf * 16 + ln) * 2 + (k & 1)] : 0.f; }
+    ax[mf] = __builtin_bit_cast(s16x8, make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])));
+  }
+  f32x4 wacc[3][2];
+#pragma unroll
+  for (int mf = 0; mf < 3; ++mf) { wacc[mf][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; wacc[mf][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int i = tid; i < 3 * 2 * 256; i += 256) wred[i] = 0.f;
+  float db0 = 0.f, db1 = 0.f;
+  if (tid < 2) dbs[tid] = 0.f;
+  const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T, ntiles = F * tiles_x * tiles_y;
+  // staging geometry of this thread (tile independent)
+  int xrel[NCH], xlds[NCH], yrel[NDY], ylds[NDY], yryx[NDY];
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int q = tid + u * 256;
+    const int px = q / CPP, ch = (q % CPP) * 8;
+    xrel[u] = ((px / OCM_T) * Ww + px % OCM_T) * C + ch;
+    xlds[u] = px * LDH + ch;
+  }
+#pragma unroll
+  for (int u = 0; u < NDY; ++u) {
+    const int q = min(tid + u * 256, OCM_H * OCM_H - 1);
+    const int ry = q / OCM_H - 1, rx = q % OCM_H - 1;
+    yrel[u] = ry * Ww + rx;
+    yryx[u] = (ry & 0xffff) | (rx << 16);
+    ylds[u] = tid + u * 256 < OCM_H * OCM_H ? 2 * q : -1;
+  }
+  // staging registers as NAMED scalars (as arrays they stayed in scratch here, 112 bytes per lane, whatever the loop structure)
+  static_assert(NCH == 6 && NDY == 2, "staging code below is written out for 6 + 2 chunks");
+  uint4 p0, p1, p2, p3, p4, p5;
+  float2 q0, q1;
+#define OCB2_PREFETCH(TILE)                                                                                              \
+  do {                                                                                                                   \
+    int tx_, ty_, f_;                                                                                                    \
+    oc_decode(TILE, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx_, ty_, f_);                                                  \
+    const int y0_ = ty_ * OCM_T, x0_ = tx_ * OCM_T;                                                                      \
+    const bf16* Xt_ = X + (((long long)f_ * Hh + y0_) * Ww + x0_) * C;                                                   \
+    const float* dYt_ = dY + (f_ / Tn) * y_bs + (f_ % Tn) * y_ts + ((long long)y0_ * Ww + x0_) * y_ps;                   \
+    p0 = *reinterpret_cast<const uint4*>(Xt_ + xrel[0]); p1 = *reinterpret_cast<const uint4*>(Xt_ + xrel[1]);            \
+    p2 = *reinterpret_cast<const uint4*>(Xt_ + xrel[2]); p3 = *reinterpret_cast<const uint4*>(Xt_ + xrel[3]);            \
+    p4 = *reinterpret_cast<const uint4*>(Xt_ + xrel[4]); p5 = *reinterpret_cast<const uint4*>(Xt_ + xrel[5]);            \
+    {                                                                                                                    \
+      const int gy_ = y0_ + (short)(yryx[0] & 0xffff), gx_ = x0_ + (yryx[0] >> 16);                                      \
+      const bool in_ = (unsigned)gy_ < (unsigned)Hh && (unsigned)gx_ < (unsigned)Ww;                                     \
+      const float2 v_ = *reinterpret_cast<const float2*>(dYt_ + (in_ ? (long long)yrel[0] * y_ps : 0));                  \
+      q0 = in_ ? v_ : make_float2(0.f, 0.f);                                                                             \
+    }                                                                                                                    \
+    {                                                                                                                    \
+      const int gy_ = y0_ + (short)(yryx[1] & 0xffff), gx_ = x0_ + (yryx[1] >> 16);                                      \
+      const bool in_ = (unsigned)gy_ < (unsigned)Hh && (unsigned)gx_ < (unsigned)Ww;                                     \
+      const float2 v_ = *reinterpret_cast<const float2*>(dYt_ + (in_ ? (long long)yrel[1] * y_ps : 0));                  \
+      q1 = in_ ? v_ : make_float2(0.f, 0.f);                                                                             \
+    }                                                                                                                    \
+  } while (0)
+#define OCB2_COMMIT()                                                                                                    \
+  do {                                                                                                                   \
+    *reinterpret_cast<uint4*>(Xs + xlds[0]) = p0; *reinterpret_cast<uint4*>(Xs + xlds[1]) = p1;                          \
+    *reinterpret_cast<uint4*>(Xs + xlds[2]) = p2; *reinterpret_cast<uint4*>(Xs + xlds[3]) = p3;                          \
+    *reinterpret_cast<uint4*>(Xs + xlds[4]) = p4; *reinterpret_cast<uint4*>(Xs + xlds[5]) = p5;                          \
+    if (ylds[0] >= 0) *reinterpret_cast<float2*>(dys + ylds[0]) = q0;                                                    \
+    if (ylds[1] >= 0) *reinterpret_cast<float2*>(dys + ylds[1]) = q1;                                                    \
+  } while (0)
+  int tile = blockIdx.x;                             // (< ntiles: the launcher starts at most ntiles workgroups)
+  OCB2_PREFETCH(tile);
+  OCB2_COMMIT();
+  __syncthreads();
+  const int kpx = 8 * (g & 1) + (ln >> 2), kch = 4 * (ln & 3);
+  // B operand of the weight gradient: column n = ln of fragment nf is (tap, o) = ((ln >> 1) + 8 nf, ln & 1); nf = 1 only has tap 8
+  const int t0 = ln >> 1, o0 = ln & 1;
+  const int sh0 = ((2 - t0 / 3) * OCM_H + 2 - t0 % 3) * 2 + o0;            // dys offset of tap t0 relative to pixel (row, col)
+  const int sh1 = ((2 - 8 / 3) * OCM_H + 2 - 8 % 3) * 2 + o0;              // tap 8
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    OCB2_PREFETCH(min(next, ntiles - 1));            // unconditional; the last one re-reads the last tile
+    int tx, ty, f;
+    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
+    bf16* dXf = dX + (long long)f * Hh * Ww * C;
+    // ---- dX rows 4w .. 4w+3 ----
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = 4 * w + rr;
+      float2 d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = 4 * g + j;
+        d[j] = t < 9 ? *reinterpret_cast<const float2*>(dys + 2 * ((row + 2 - t / 3) * OCM_H + ln + 2 - t % 3)) : make_float2(0.f, 0.f);
+      }
+      const s16x8 bx = __builtin_bit_cast(s16x8, make_uint4(pack2bf(d[0].x, d[0].y), pack2bf(d[1].x, d[1].y), pack2bf(d[2].x, d[2].y), pack2bf(d[3].x, d[3].y)));
+      bf16* orow = dXf + ((long long)(ty * OCM_T + row) * Ww + tx * OCM_T + ln) * C + 4 * g;
+#pragma unroll
+      for (int mf = 0; mf < 3; ++mf) {
+        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax[mf]), __builtin_bit_cast(bf16x8_t, bx), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (elu_in) {        // X is the ELU output of the producing conv: fold ELU'(x) = (x > 0 ? 1 : x + 1) into the input gradient
+          const uint2 xv = *reinterpret_cast<const uint2*>(Xs + (row * OCM_T + ln) * LDH + mf * 16 + 4 * g);
+          const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
+          const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
+          acc[0] *= x0 > 0.f ? 1.f : x0 + 1.f; acc[1] *= x1 > 0.f ? 1.f : x1 + 1.f;
+          acc[2] *= x2 > 0.f ? 1.f : x2 + 1.f; acc[3] *= x3 > 0.f ? 1.f : x3 + 1.f;
+        }
+        *reinterpret_cast<uint2*>(orow + mf * 16) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+      }
+    }
+    // ---- dW: this wave's k-steps 2w, 2w+1 (tile rows 4w .. 4w+3, 32 pixels each) ----
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kk = 2 * w + h;
+      const int prow = 2 * kk + (g >> 1), pcol = 8 * (g & 1);              // this lane group's 8 pixels (k = 8g .. 8g+7 of the k-step)
+      const float* dp = dys + 2 * (prow * OCM_H + pcol);
+      float dv0[8], dv1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { dv0[j] = dp[2 * j + sh0]; dv1[j] = ln < 2 ? dp[2 * j + sh1] : 0.f; }
+      const s16x8 bw0 = __builtin_bit_cast(s16x8, make_uint4(pack2bf(dv0[0], dv0[1]), pack2bf(dv0[2], dv0[3]), pack2bf(dv0[4], dv0[5]), pack2bf(dv0[6], dv0[7])));
+      const s16x8 bw1 = __builtin_bit_cast(s16x8, make_uint4(pack2bf(dv1[0], dv1[1]), pack2bf(dv1[2], dv1[3]), pack2bf(dv1[4], dv1[5]), pack2bf(dv1[6], dv1[7])));
+      const bf16* ap = Xs + (prow * OCM_T + kpx) * LDH + kch;
+#pragma unroll
+      for (int mf = 0; mf < 3; ++mf) {
+        const s16x8 aw = tr_frag(ap + mf * 16, ap + mf * 16 + 4 * LDH);
+        wacc[mf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), __builtin_bit_cast(bf16x8_t, bw0), wacc[mf][0], 0, 0, 0);
+        wacc[mf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), __builtin_bit_cast(bf16x8_t, bw1), wacc[mf][1], 0, 0, 0);
+      }
+    }
+    {
+      const int py = tid / OCM_T, px = tid % OCM_T;
+      const float2 v = *reinterpret_cast<const float2*>(dys + 2 * ((py + 1) * OCM_H + px + 1));
+      db0 += v.x; db1 += v.y;
+    }
+    __syncthreads();
+    OCB2_COMMIT();                                   // (after the last tile: the re-read tile, read by nobody)
+    __syncthreads();
+  }
+  // cross-wave sum of the weight gradient: D[m = c][n = (tap, o)]: lane (g, ln) holds channels mf*16 + 4g + r, column ln
+#pragma unroll
+  for (int mf = 0; mf < 3; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&wred[((mf * 2 + nf) * 16 + 4 * g + r) * 16 + ln], wacc[mf][nf][r]);
+  db0 = wave_sum(db0); db1 = wave_sum(db1);
+  if (lane == 0) { atomicAdd(&dbs[0], db0); atomicAdd(&dbs[1], db1); }
+  __syncthreads();
+  float* mypart = part + (long long)blockIdx.x * OCB_PART;
+  for (int i = tid; i < 9 * C * 2; i += 256) {                             // i = (t * C + c) * 2 + o
+    const int o = i & 1, c = (i >> 1) % C, t = (i >> 1) / C;
+    const int nf = t >> 3, n = (t & 7) * 2 + o;
+    mypart[i] = wred[(((c >> 4) * 2 + nf) * 16 + (c & 15)) * 16 + n];
+  }
+  if (tid < 2) mypart[9 * C * 2 + tid] = dbs[tid];
+}
+#undef OCB2_PREFETCH
+#undef OCB2_COMMIT
+
 // sums the per-block partials: grid (ceil(866 / 64), 16 row groups) x 64 threads
 __global__ __launch_bounds__(64) void outconv_bwd_reduce_kernel(const float* __restrict__ part, int nblk, float* dW, float* db) {
   const int idx = blockIdx.x * 64 + threadIdx.x;
@@ -1315,6 +1495,12 @@ bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* 
   if (!ws || ws_bytes < outconv_bwd_ws_bytes()) return false;
   const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
   const int nblk = min(ntiles, OCB_MAXBLK);          // 3 resident blocks per CU (168 VGPRs, 39 KB LDS): measured best of 512/768/1024
+  static int ver = -1;
+  if (ver < 0) { const char* e = getenv("STJ_OUTCONV_BWD_V"); ver = e ? atoi(e) : 2; }
+  if (ver == 2)
+    hipLaunchKernelGGL(outconv_bwd_mfma2_kernel<48>, dim3(nblk), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, (float*)ws, F, Hh, Ww, Tn,
+                       y_bs, y_ts, y_ps, elu_in);
+  else
   hipLaunchKernelGGL(outconv_bwd_mfma_kernel<48>, dim3(nblk), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, (float*)ws, F, Hh, Ww, Tn,
                      y_bs, y_ts, y_ps, elu_in);
   hipLaunchKernelGGL(outconv_bwd_reduce_kernel, dim3((OCB_PART + 63) / 64, 16), dim3(64), 0, st, (const float*)ws, nblk, dW, db);
