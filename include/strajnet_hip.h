@@ -144,6 +144,19 @@ int stj_softmax_bwd(const void* P, const float* dP, void* dS, long long rows, in
 int stj_fg_bias_fwd(const void* off, const float* table, float* bias, int B, int G, int Hh, int Ww, int dtype, hipStream_t stream);
 int stj_fg_bias_bwd(const void* off, const float* table, const void* dbias, float* dtable, float* doff,
                     int B, int G, int Hh, int Ww, int dtype, hipStream_t stream);
+/* FG-MSA offset head: off[b,g,hw,:] = tanh(o[b,hw,g,:] . W1) * scale (1x1 conv gc -> 2, no bias) and, when fh != NULL,
+ * fh = off . W2 + b2 (1x1 conv 2 -> C2) in one launch (FG_MSA.py:136-146).  o [B,HW,G,gc] (the offset conv's own layout, no
+ * regrouped copy), W1 [gc,2], W2 [2,C2] (T), b2 f32 [C2] or NULL, off [B,G,HW,2]; fh [B,G,HW,C2], or with zmajor [G,B,HW,C2];
+ * qres [B,HW,C2] or NULL is added to every group's fh (zmajor + qres = the decoder query of modules.py:827-831).
+ * o == NULL: off is an input and only fh is produced.  HW % 16 == 0, G <= 8.
+ * bwd: doff / dfh (either may be NULL) -> dO [B,HW,G,gc] (written), dq [B,HW,C2] (sum of dfh over the groups, written; NULL to
+ * skip), dW1 / dW2 / db2 f32 += (db2 may be NULL).  dO == NULL: only the fh half is differentiated and the offset gradient
+ * (doff + dfh . W2^T) is written to doff_out [B,G,HW,2]. */
+int stj_fg_offset_fwd(const void* o, const void* W1, const void* W2, const float* b2, const void* qres, void* off, void* fh,
+                      int B, int HW, int G, int gc, int C2, float scale, int zmajor, int dtype, hipStream_t stream);
+int stj_fg_offset_bwd(const void* o, const void* off, const void* W1, const void* W2, const void* doff, const void* dfh,
+                      void* dO, void* dq, void* doff_out, float* dW1, float* dW2, float* db2, int B, int HW, int G, int gc,
+                      int C2, float scale, int zmajor, int dtype, hipStream_t stream);
 
 /* Decoder: UpSampling3D(1,2,2) nearest + Conv2D 3x3 SAME + bias + ELU (modules.py:746-748,732-735) with the upsample
  * folded into 16 effective 2x2-tap matrices.  prep: W f32 [3,3,Cin,Cout] -> Wf [16,Cout,Cin], Wd [16,Cin,Cout] (T).

@@ -45,6 +45,8 @@ SIGNATURES = {
     'stj_softmax_bwd': [vp, vp, vp, cl, ci, ci, vp],
     'stj_fg_bias_fwd': [vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_fg_bias_bwd': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    'stj_fg_offset_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, ci, ci, vp],
+    'stj_fg_offset_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, ci, ci, vp],
     'stj_upconv_prep': [vp, vp, vp, ci, ci, ci, vp],
     'stj_upconv_fold': [vp, vp, ci, ci, vp],
     'stj_upconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],

@@ -158,6 +158,204 @@ __global__ __launch_bounds__(256) void fg_bias_bwd_kernel(const T* off, const fl
     if (dtb[i] != 0.f) atomicAdd(dtable + i * G + g, dtb[i]);
 }
 
+// ---- FG-MSA offset head ------------------------------------------------------------------------------------------
+// off[b,g,hw,:] = tanh(o[b,hw,g,:] . W1) * scale            (1x1 conv gc -> 2 without bias, FG_MSA.py:136-142)
+// fh [b,g,hw,:] = off[b,g,hw,:] . W2 + b2                   (1x1 conv 2 -> C2, FG_MSA.py:143-146; optional)
+// Both products have one dimension of 2: as GEMM launches they are tile padding (2 of 64 columns live) plus a regrouped copy of o,
+// a tanh kernel and, backwards, two split-K weight gradients over 16384 rows for 864 parameters.  Here one workgroup owns the G
+// groups of 16 pixels of one sample (16 G rows), reads o in the layout the offset conv wrote it ([B,HW,G,gc]) and writes both
+// results.  With `zmajor` the second result is written group-major, [G,B,HW,C2], and `qres` [B,HW,C2] is added to every group:
+// that IS the decoder query of modules.py:827-831 (query = q broadcast over the waypoints + flow_hidden), ready for the batched
+// cross-attention.
+__device__ __forceinline__ long long fgo_fh_row(int zmajor, long long b, int g, int hw, int B, int G, int HW) {
+  return zmajor ? ((long long)g * B + b) * HW + hw : (b * G + g) * HW + hw;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fg_offset_fwd_kernel(const T* __restrict__ o, const T* __restrict__ W1, const T* __restrict__ W2,
+                                                            const float* __restrict__ b2, const T* __restrict__ qres, T* off,
+                                                            T* __restrict__ fh, int B, int HW, int G, int gc, int C2, float scale, int zmajor) {
+  extern __shared__ float fo_lds[];
+  float* w2 = fo_lds;                  // [2][C2]
+  float* bb = w2 + 2 * C2;             // [C2]
+  float* soff = bb + C2;               // [16 G][2]
+  const int t = threadIdx.x, RB = 16 * G;
+  const int nhb = HW / 16;
+  const long long b = blockIdx.x / nhb; const int hw0 = (blockIdx.x % nhb) * 16;
+  if (fh) {
+    for (int i = t; i < 2 * C2; i += 256) w2[i] = ldf(W2 + i);
+    for (int i = t; i < C2; i += 256) bb[i] = b2 ? b2[i] : 0.f;
+  }
+  if (!o) {                                               // second half only: off is an input
+    for (int i = t; i < RB * 2; i += 256) {
+      const int lr = i >> 1, g = lr >> 4, hw = hw0 + (lr & 15);
+      soff[i] = ldf(off + ((b * G + g) * HW + hw) * 2 + (i & 1));
+    }
+  } else
+  for (int lr = t >> 1; lr < RB; lr += 128) {             // two lanes per row
+    const int part = t & 1, g = lr >> 4, hw = hw0 + (lr & 15);
+    const T* op = o + ((b * HW + hw) * G + g) * gc;
+    float a0 = 0.f, a1 = 0.f;
+    for (int i = part; i < gc; i += 2) {
+      const float x = ldf(op + i);
+      a0 += x * ldf(W1 + 2 * i); a1 += x * ldf(W1 + 2 * i + 1);
+    }
+    a0 += __shfl_xor(a0, 1); a1 += __shfl_xor(a1, 1);
+    T* q = off + ((b * G + g) * HW + hw) * 2 + part;
+    stf(q, tanhf(part ? a1 : a0) * scale);
+    soff[lr * 2 + part] = ldf(q);              // fh is the product of the ROUNDED offsets (what the backward and the bias sampler see)
+  }
+  if (!fh) return;
+  __syncthreads();
+  constexpr int VN = Vec<T>::N;
+  const int NV = C2 / VN;
+  for (int i = t; i < RB * NV; i += 256) {
+    const int lr = i / NV, c = (i % NV) * VN, g = lr >> 4, hw = hw0 + (lr & 15);
+    const float o0 = soff[lr * 2], o1 = soff[lr * 2 + 1];
+    float v[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) v[e] = o0 * w2[c + e] + o1 * w2[C2 + c + e] + bb[c + e];
+    if (qres) {
+      float r[VN];
+      ld16(qres + (b * HW + hw) * C2 + c, r);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) v[e] += r[e];
+    }
+    st16(fh + fgo_fh_row(zmajor, b, g, hw, B, G, HW) * C2 + c, v);
+  }
+}
+
+// Either half runs alone: o == null takes off as an input (second half), fh == null stops after off.  The model uses the halves
+// separately -- the query needs the attention output that the offsets feed -- but through the same two kernels.
+// Backward of the pair: doff (gradient of off from the bias sampler, may be null) and dfh (may be null) ->
+// dO [B,HW,G,gc], dq [B,HW,C2] (sum of dfh over the groups, when qres was given), dW1 [gc,2], dW2 [2,C2], db2 [C2] (f32, one
+// atomic per entry and workgroup).  Same row ownership as the forward: (A) lanes over 16-byte column groups of dfh keep the
+// column sums for dW2 / db2 and the per-pixel sum over the groups (dq) in registers and add their slice of dfh . W2^T to the
+// row's offset gradient in LDS; (B) tanh'; (C) lanes over the gc input channels.  dO == null stops after (A) and writes the
+// offset gradient to doff_out [B,G,HW,2] instead (second half alone).
+template <typename T>
+__global__ __launch_bounds__(256) void fg_offset_bwd_kernel(const T* __restrict__ o, const T* __restrict__ off, const T* __restrict__ W1,
+                                                            const T* __restrict__ W2, const T* __restrict__ doff, const T* __restrict__ dfh,
+                                                            T* __restrict__ dO, T* __restrict__ dq, T* __restrict__ doff_out,
+                                                            float* __restrict__ dW1,
+                                                            float* __restrict__ dW2, float* __restrict__ db2, int B, int HW, int G,
+                                                            int gc, int C2, float scale, int zmajor) {
+  constexpr int VN = Vec<T>::N;
+  extern __shared__ float fo_lds[];
+  const int t = threadIdx.x, RB = 16 * G;
+  float* w2 = fo_lds;                  // [2][C2]
+  float* scol = w2 + 2 * C2;           // [3][C2]: dW2 rows, db2
+  float* soff = scol + 3 * C2;         // [RB][2]
+  float* sdo = soff + RB * 2;          // [RB][2]  offset gradient, then pre-activation gradient
+  float* sw1 = sdo + RB * 2;           // [gc][2]
+  float* sdw1 = sw1 + gc * 2;          // [gc][2]
+  const int nhb = HW / 16;
+  const long long b = blockIdx.x / nhb; const int hw0 = (blockIdx.x % nhb) * 16;
+  for (int i = t; i < 2 * C2; i += 256) w2[i] = dfh ? ldf(W2 + i) : 0.f;
+  for (int i = t; i < 3 * C2; i += 256) scol[i] = 0.f;
+  for (int i = t; i < RB * 2; i += 256) {
+    const int lr = i >> 1, g = lr >> 4, hw = hw0 + (lr & 15);
+    const long long at = ((b * G + g) * HW + hw) * 2 + (i & 1);
+    soff[i] = ldf(off + at); sdo[i] = doff ? ldf(doff + at) : 0.f;
+  }
+  for (int i = t; i < gc * 2; i += 256) { sw1[i] = W1 ? ldf(W1 + i) : 0.f; sdw1[i] = 0.f; }
+  __syncthreads();
+  if (dfh) {
+    const int NV = C2 / VN, nrg = 256 / NV;
+    const int cv = t % NV, rg = t / NV, c = cv * VN;
+    if (rg < nrg) {
+      float cs[VN], a0[VN], a1[VN], wa[VN], wb[VN];
+#pragma unroll
+      for (int e = 0; e < VN; ++e) { cs[e] = a0[e] = a1[e] = 0.f; wa[e] = w2[c + e]; wb[e] = w2[C2 + c + e]; }
+      for (int hwl = rg; hwl < 16; hwl += nrg) {
+        float qs[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) qs[e] = 0.f;
+        for (int g = 0; g < G; ++g) {
+          const int lr = g * 16 + hwl;
+          float v[VN];
+          ld16(dfh + fgo_fh_row(zmajor, b, g, hw0 + hwl, B, G, HW) * C2 + c, v);
+          const float o0 = soff[lr * 2], o1 = soff[lr * 2 + 1];
+          float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+          for (int e = 0; e < VN; ++e) {
+            cs[e] += v[e]; a0[e] += o0 * v[e]; a1[e] += o1 * v[e]; qs[e] += v[e];
+            p0 += v[e] * wa[e]; p1 += v[e] * wb[e];
+          }
+          atomicAdd(&sdo[lr * 2], p0); atomicAdd(&sdo[lr * 2 + 1], p1);
+        }
+        if (dq) st16(dq + (b * HW + hw0 + hwl) * C2 + c, qs);
+      }
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        atomicAdd(&scol[c + e], a0[e]); atomicAdd(&scol[C2 + c + e], a1[e]); atomicAdd(&scol[2 * C2 + c + e], cs[e]);
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * C2; i += 256) atomicAdd(dW2 + i, scol[i]);
+    if (db2) for (int i = t; i < C2; i += 256) atomicAdd(db2 + i, scol[2 * C2 + i]);
+  }
+  if (!dO) {                                              // second half only: hand the offset gradient on
+    if (doff_out)
+      for (int i = t; i < RB * 2; i += 256) {
+        const int lr = i >> 1, g = lr >> 4, hw = hw0 + (lr & 15);
+        stf(doff_out + ((b * G + g) * HW + hw) * 2 + (i & 1), sdo[i]);
+      }
+    return;
+  }
+  // (B) d tanh(u)*s = s - off^2 / s
+  if (t < RB * 2) { const float ov = soff[t]; sdo[t] *= scale - ov * ov / scale; }
+  __syncthreads();
+  // (C) lanes over input channels
+  {
+    const int nrg = 256 / gc, i = t % gc, rg = t / gc;
+    if (rg < nrg) {
+      const float wa = sw1[2 * i], wb = sw1[2 * i + 1];
+      float a0 = 0.f, a1 = 0.f;
+      for (int lr = rg; lr < RB; lr += nrg) {
+        const int g = lr >> 4, hw = hw0 + (lr & 15);
+        const long long at = ((b * HW + hw) * G + g) * gc + i;
+        const float d0 = sdo[lr * 2], d1 = sdo[lr * 2 + 1];
+        const float x = ldf(o + at);
+        a0 += x * d0; a1 += x * d1;
+        stf(dO + at, d0 * wa + d1 * wb);
+      }
+      atomicAdd(&sdw1[2 * i], a0); atomicAdd(&sdw1[2 * i + 1], a1);
+    }
+    __syncthreads();
+    for (int j = t; j < gc * 2; j += 256) atomicAdd(dW1 + j, sdw1[j]);
+  }
+}
+
+static int fgo_check(const char* who, int B, int HW, int G, int gc, int C2, int dtype, const void* p16a, const void* p16b) {
+  const int vn = dtype == STJ_F32 ? 4 : 8;
+  if (B < 1 || HW % 16 || G < 1 || G > 8 || gc < 1 || gc > 256 || C2 % vn || C2 / vn > 256) {
+    stj_set_error("%s: unsupported geometry B=%d HW=%d G=%d gc=%d C2=%d", who, B, HW, G, gc, C2); return STJ_EINVAL;
+  }
+  if ((((uintptr_t)p16a) | ((uintptr_t)p16b)) & 15) { stj_set_error("%s: fh / qres pointers must be 16-byte aligned", who); return STJ_EINVAL; }
+  return STJ_OK;
+}
+extern "C" int stj_fg_offset_fwd(const void* o, const void* W1, const void* W2, const float* b2, const void* qres, void* off, void* fh,
+                                 int B, int HW, int G, int gc, int C2, float scale, int zmajor, int dtype, hipStream_t stream) {
+  if (int e = fgo_check("stj_fg_offset_fwd", B, HW, G, gc, C2, dtype, fh, qres)) return e;
+  const size_t lds = (size_t)(3 * C2 + 32 * G) * sizeof(float);
+  const int grid = B * (HW / 16);
+#define FGO_FWD(TT) hipLaunchKernelGGL(fg_offset_fwd_kernel<TT>, dim3(grid), dim3(256), lds, stream, (const TT*)o, (const TT*)W1, (const TT*)W2, b2, (const TT*)qres, (TT*)off, (TT*)fh, B, HW, G, gc, C2, scale, zmajor)
+  if (dtype == STJ_BF16) FGO_FWD(bf16); else if (dtype == STJ_F16) FGO_FWD(f16); else FGO_FWD(float);
+#undef FGO_FWD
+  return stj_check_launch("stj_fg_offset_fwd");
+}
+extern "C" int stj_fg_offset_bwd(const void* o, const void* off, const void* W1, const void* W2, const void* doff, const void* dfh,
+                                 void* dO, void* dq, void* doff_out, float* dW1, float* dW2, float* db2, int B, int HW, int G, int gc,
+                                 int C2, float scale, int zmajor, int dtype, hipStream_t stream) {
+  if (int e = fgo_check("stj_fg_offset_bwd", B, HW, G, gc, C2, dtype, dfh, dq)) return e;
+  const size_t lds = (size_t)(5 * C2 + 64 * G + 4 * gc) * sizeof(float);
+  const int grid = B * (HW / 16);
+#define FGO_BWD(TT) hipLaunchKernelGGL(fg_offset_bwd_kernel<TT>, dim3(grid), dim3(256), lds, stream, (const TT*)o, (const TT*)off, (const TT*)W1, (const TT*)W2, (const TT*)doff, (const TT*)dfh, (TT*)dO, (TT*)dq, (TT*)doff_out, dW1, dW2, db2, B, HW, G, gc, C2, scale, zmajor)
+  if (dtype == STJ_BF16) FGO_BWD(bf16); else if (dtype == STJ_F16) FGO_BWD(f16); else FGO_BWD(float);
+#undef FGO_BWD
+  return stj_check_launch("stj_fg_offset_bwd");
+}
+
 extern "C" int stj_fg_bias_fwd(const void* off, const float* table, float* bias, int B, int G, int Hh, int Ww, int dtype, hipStream_t stream) {
   const long long total = (long long)B * G * Hh * Ww * Hh * Ww;
   if (total <= 0) return STJ_OK;

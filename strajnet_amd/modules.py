@@ -491,7 +491,8 @@ class STrajNet:
         return res_list
 
     def _fgmsa(self, x):
-        """FGMSA.call (FG_MSA.py:106-183), eval semantics.  x [B,hb,hb,384] -> (y, flow_hidden|None)."""
+        """FGMSA.call (FG_MSA.py:106-183), eval semantics, plus what the caller does with its two results (modules.py:825-831):
+        x [B,hb,hb,384] -> (x + y, decoder query [8,B,HW,384] = (x + y) broadcast over the waypoints + flow_hidden)."""
         B, Hh, Ww, C = x.shape
         G = 8
         gc = C // G
@@ -502,14 +503,23 @@ class STrajNet:
             v = self._dense(x, 'fg_msa/proj_v')
         o = ops.grouped_conv3(q, self._p('fg_msa/conv_offset_0/kernel'), self._p('fg_msa/conv_offset_0/bias'), G)
         o = ops.gelu(self._ln(o, 'fg_msa/conv_norm', 1e-3))
-        # regroup [B,H,W,G,gc] -> [B,G,HW,gc] then 1x1 conv gc->2 (no bias), tanh * (H/2)
-        o = o.view(B, HW, G, gc).permute(0, 2, 1, 3).contiguous()
-        off = ops.tanh_scale(self._dense(o, 'fg_msa/conv_offset_proj', bias=False), Hh / 2.0)      # [B,G,HW,2]
-        flow_hidden = self._dense(off, 'fg_msa/conv_offset_proj2') if self.fg else None                # [B,G,HW,C]
-        bias = ops.fg_bias(off, self._p('fg_msa/warp_attn_rel_table'), Hh, Ww)
-        a = ops.mha_core(q.view(B, HW, C), k.view(B, HW, C), v.view(B, HW, C), G, gc, gc ** -0.5, bias=bias)
-        y = self._dense(a.view(B, Hh, Ww, C), 'fg_msa/proj_out')
-        return y, flow_hidden
+        # per group: 1x1 conv gc->2 (no bias), tanh * (H/2); the kernel reads o in place ([B,H,W,G,gc]) and writes [B,G,HW,2]
+        off = ops.fg_offset(o, self._p('fg_msa/conv_offset_proj/kernel'), Hh / 2.0, G)
+        # the sampled relative-position bias is built from `off` inside the attention op
+        a = ops.mha_core(q.view(B, HW, C), k.view(B, HW, C), v.view(B, HW, C), G, gc, gc ** -0.5,
+                         fg_off=off, fg=(self._p('fg_msa/warp_attn_rel_table'), Hh, Ww))
+        if self.taps is not None:
+            y = self._dense(a.view(B, Hh, Ww, C), 'fg_msa/proj_out')
+            self._tap('fg_msa_out', y)
+            xy = x + y
+        else:
+            xy = self._dense(a.view(B, Hh, Ww, C), 'fg_msa/proj_out', res=x)                          # modules.py:825
+        if self.fg:      # flow_hidden = 1x1 conv 2 -> C of the offsets, added per waypoint (= per group) to the broadcast query
+            query = ops.fg_query(off, self._p('fg_msa/conv_offset_proj2/kernel'), self._p('fg_msa/conv_offset_proj2/bias'),
+                                 qres=xy.view(B, HW, C))
+        else:
+            query = xy.reshape(1, B, HW, C).expand(8, B, HW, C).contiguous()
+        return xy, query
 
     def _tfa_mha(self, pre, query, key, H, qvalid, kvalid):
         """tensorflow_addons MultiHeadAttention with inputs=[query, key] (value=key), eval (trajNet.py:42,80,225)."""
@@ -758,23 +768,19 @@ class STrajNet:
                 skips = (self._resconv(res_list[2], 'decoder/resconv_3'), self._resconv(res_list[1], 'decoder/resconv_2'),
                          self._resconv(res_list[0], 'decoder/resconv_f'))
         q = res_list[-1].reshape(B, hb, hb, Cb)
-        fh = None
-        if self.fg_msa:
-            y, fh = self._fgmsa(q)
-            self._tap('fg_msa_out', y)
-            q = q + y                                                              # modules.py:825
         # waypoint-major [8,B,HW,Cb] (the reference's [B,8,...] transposed): every per-waypoint product downstream is then a
         # plain batched GEMM and the decoder frames are t-major; the output kernel undoes it when writing [B,H,W,32]
-        query = q.reshape(1, B, hb * hb, Cb).expand(8, B, hb * hb, Cb)             # modules.py:827
-        if self.fg:
-            query = query + fh.reshape(B, 8, hb * hb, Cb).permute(1, 0, 2, 3)      # modules.py:830-831
+        if self.fg_msa:
+            q, query = self._fgmsa(q)                                              # modules.py:825-831
+        else:
+            query = q.reshape(1, B, hb * hb, Cb).expand(8, B, hb * hb, Cb).contiguous()   # modules.py:827
         if self._side is not None:       # join the agent branch
             main.wait_stream(self._side)
             key.record_stream(main)
             tmask.record_stream(main)
         self._tap('agent_key', key)
         self._tap('query', query)
-        x = self._cross_attention_z(query.contiguous(), key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
+        x = self._cross_attention_z(query, key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
         self._tap('cross_attention_out', x)
         x = ops.wgrad_flush_point(x)             # the decoder's weight gradients are launched when ITS backward is through (ops.py)
         out = self._decoder(x, res_list, B, skips)

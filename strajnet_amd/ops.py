@@ -818,9 +818,12 @@ def win_attn(qkv, pt, B, res, heads, shift):
 # ----------------------------------------------------------------------------------------------------
 class _MhaCore(torch.autograd.Function):
     """q [Bt,Nq,H*d], k,v [Bt,Nk,H*d]; qvalid [Bt,Nq] / kvalid [Bt,Nk] int32 or None; bias f32 [Bt,H,Nq,Nk] or None.
-    Returns o [Bt,Nq,H*d].  Gradient w.r.t. bias is returned in the activation dtype."""
+    Returns o [Bt,Nq,H*d].  Gradient w.r.t. bias is returned in the activation dtype.
+    fg = (table Param, Hh, Ww) with `off` [Bt,H,Nq,2]: the FG-MSA sampled relative-position bias is built here from the offsets
+    (stj_fg_bias_fwd) and its backward consumes dS directly -- as a separate autograd node the [Bt,H,Nq,Nk] gradient crossed the
+    f32 <-> activation dtype boundary twice (two cast kernels over 17 MB at B=8)."""
     @staticmethod
-    def forward(ctx, q, k, v, bias, H, d, scale, qvalid, kvalid, drop):
+    def forward(ctx, q, k, v, bias, H, d, scale, qvalid, kvalid, drop, off=None, t_master=None, fg=None):
         _req_cuda(q, k, v)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         Bt, Nq, HD = q.shape
@@ -831,7 +834,11 @@ class _MhaCore(torch.autograd.Function):
         gemm(q, k, S, Nq, Nk, d, (Nq * HD, d, HD, 1), (Nk * HD, d, 1, HD), (H * Nq * Nk, Nq * Nk, Nk), dt, nb=(Bt, H),
              alpha=scale, c_f32=1)
         P = torch.empty((Bt, H, Nq, Nk), dtype=q.dtype, device=q.device)
-        if bias is not None:
+        if fg is not None:
+            off = off.contiguous()
+            bias = torch.empty((Bt, H, Nq, Nk), dtype=torch.float32, device=q.device)
+            call('stj_fg_bias_fwd', _p(off), _p(fg[0].master), _p(bias), Bt, H, fg[1], fg[2], dt, _st())
+        elif bias is not None:
             bias = bias.contiguous()
         call('stj_softmax_fwd', _p(S), _p(P), _p(qvalid), _p(kvalid), _p(bias), Bt, H, Nq, Nk, dt, _st())
         Pd = P
@@ -842,14 +849,14 @@ class _MhaCore(torch.autograd.Function):
         o = torch.empty_like(q)
         # O[b,:,h,:] = P[b,h] V[b,:,h,:]
         gemm(Pd, v, o, Nq, d, Nk, (H * Nq * Nk, Nq * Nk, Nk, 1), (Nk * HD, d, HD, 1), (Nq * HD, d, HD), dt, nb=(Bt, H))
-        ctx.geo = (Bt, Nq, Nk, H, d, scale, bias is not None)
-        ctx.drop = drop
-        ctx.save_for_backward(q, k, v, P, Pd if drop is not None else None)
+        ctx.geo = (Bt, Nq, Nk, H, d, scale, bias is not None and fg is None)
+        ctx.drop, ctx.fg = drop, fg
+        ctx.save_for_backward(q, k, v, P, Pd if drop is not None else None, off if fg is not None else None)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, P, Pd = ctx.saved_tensors
+        q, k, v, P, Pd, off = ctx.saved_tensors
         if Pd is None:
             Pd = P
         Bt, Nq, Nk, H, d, scale, has_bias = ctx.geo
@@ -870,11 +877,20 @@ class _MhaCore(torch.autograd.Function):
         with gemm_group():        # dQ = scale dS K ; dK = scale dS^T Q
             gemm(dS, k, dq, Nq, d, Nk, (H * Nq * Nk, Nq * Nk, Nk, 1), (Nk * HD, d, HD, 1), (Nq * HD, d, HD), dt, nb=(Bt, H), alpha=scale)
             gemm(dS, q, dk, Nk, d, Nq, (H * Nq * Nk, Nq * Nk, 1, Nk), (Nq * HD, d, HD, 1), (Nk * HD, d, HD), dt, nb=(Bt, H), alpha=scale)
-        return dq, dk, dv, (dS if has_bias else None), None, None, None, None, None, None
+        doff = None
+        if ctx.fg is not None:
+            pt, Hh, Ww = ctx.fg
+            doff32 = zeros_f32(tuple(off.shape), off.device)     # accumulated by the kernel's query slices
+            call('stj_fg_bias_bwd', _p(off), _p(pt.master), _p(dS), _p(pt.grad), _p(doff32), Bt, H, Hh, Ww, dt, _st())
+            doff = doff32.to(off.dtype)
+        return dq, dk, dv, (dS if has_bias else None), None, None, None, None, None, None, doff, None, None
 
 
-def mha_core(q, k, v, H, d, scale, qvalid=None, kvalid=None, bias=None, drop=None):
-    """drop = (p, state, site) applies attention dropout to the softmax output (training)."""
+def mha_core(q, k, v, H, d, scale, qvalid=None, kvalid=None, bias=None, drop=None, fg_off=None, fg=None):
+    """drop = (p, state, site) applies attention dropout to the softmax output (training).
+    fg_off [Bt,H,Nq,2] + fg = (table Param, Hh, Ww): FG-MSA bias sampled from the offsets inside the op."""
+    if fg is not None:
+        return _MhaCore.apply(q, k, v, None, H, d, scale, qvalid, kvalid, drop, fg_off, fg[0].master, fg)
     return _MhaCore.apply(q, k, v, bias, H, d, scale, qvalid, kvalid, drop)
 
 
@@ -964,6 +980,70 @@ class _FgBias(torch.autograd.Function):
 
 def fg_bias(off, pt, Hh, Ww):
     return _FgBias.apply(off, pt.master, pt, Hh, Ww)
+
+
+class _FgOffset(torch.autograd.Function):
+    """First half of the FG-MSA offset head (stj_fg_offset_fwd/_bwd with fh = NULL): off = tanh(o . W1) * scale, o read in the
+    offset conv's own [B,H,W,G*gc] layout, off [B,G,HW,2]."""
+    @staticmethod
+    def forward(ctx, o, t1, p1, scale, G):
+        _req_cuda(o)
+        o = o.contiguous()
+        B, Hh, Ww, C = o.shape
+        HW, gc = Hh * Ww, C // G
+        off = torch.empty((B, G, HW, 2), dtype=o.dtype, device=o.device)
+        call('stj_fg_offset_fwd', _p(o), _p(p1.c), None, None, None, _p(off), None, B, HW, G, gc, 8, float(scale), 0, _dt(o), _st())
+        ctx.p1, ctx.geo = p1, (B, HW, G, gc, float(scale))
+        ctx.save_for_backward(o, off)
+        return off
+
+    @staticmethod
+    def backward(ctx, doff):
+        o, off = ctx.saved_tensors
+        B, HW, G, gc, scale = ctx.geo
+        dO = torch.empty_like(o)
+        call('stj_fg_offset_bwd', _p(o), _p(off), _p(ctx.p1.c), None, _p(doff.contiguous()), None, _p(dO), None, None, _p(ctx.p1.grad),
+             None, None, B, HW, G, gc, 8, scale, 0, _dt(o), _st())
+        return dO, None, None, None, None
+
+
+def fg_offset(o, p1, scale, G):
+    return _FgOffset.apply(o, p1.master, p1, scale, G)
+
+
+class _FgQuery(torch.autograd.Function):
+    """Second half: fh = off . W2 + b2 (1x1 conv 2 -> C2), [B,G,HW,C2]; with qres [B,HW,C2] the output is the group-major decoder
+    query [G,B,HW,C2] = qres (broadcast over the groups) + fh  (modules.py:827-831), written once."""
+    @staticmethod
+    def forward(ctx, off, qres, t2, t3, p2, pb2):
+        _req_cuda(off)
+        off = off.contiguous()
+        B, G, HW, _ = off.shape
+        C2 = p2.c.shape[-1]
+        zmajor = 1 if qres is not None else 0
+        if qres is not None:
+            qres = qres.contiguous()
+        fh = torch.empty((G, B, HW, C2) if zmajor else (B, G, HW, C2), dtype=off.dtype, device=off.device)
+        call('stj_fg_offset_fwd', None, None, _p(p2.c), _p(pb2.master), _p(qres), _p(off), _p(fh), B, HW, G, 1, C2, 1.0, zmajor,
+             _dt(off), _st())
+        ctx.ps, ctx.geo = (p2, pb2), (B, HW, G, C2, zmajor)
+        ctx.save_for_backward(off)
+        return fh
+
+    @staticmethod
+    def backward(ctx, dfh):
+        (off,) = ctx.saved_tensors
+        p2, pb2 = ctx.ps
+        B, HW, G, C2, zmajor = ctx.geo
+        doff = torch.empty_like(off)
+        dq = torch.empty((B, HW, C2), dtype=off.dtype, device=off.device) if (zmajor and ctx.needs_input_grad[1]) else None
+        call('stj_fg_offset_bwd', None, _p(off), None, _p(p2.c), None, _p(dfh.contiguous()), None, _p(dq), _p(doff), None, _p(p2.grad),
+             _p(pb2.grad), B, HW, G, 1, C2, 1.0, zmajor, _dt(off), _st())
+        return doff, dq, None, None, None, None
+
+
+def fg_query(off, p2, pb2, qres=None):
+    return _FgQuery.apply(off, qres, p2.master, pb2.master, p2, pb2)
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -98,14 +98,28 @@ def test_train_step_parity_f32():
     loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(128, 128, 8), replica=1.0, use_focal_loss=False, use_gt=True)
     d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
     total = sum(d.values())
-    total.backward()
+    # two stages, because the flow-warp loss is only piecewise smooth in the predicted flow (bilinear sampling: floor() of the
+    # warped position, occu_metric.py:345-409): where an f32 forward lands on the other side of an integer boundary than the
+    # float64 one, that pixel's output gradient differs by O(1) of its size, and every flow-decoder weight gradient (a sum over
+    # all pixels) inherits ~1e-3 of it.  Stage 1 checks the output gradient element-wise and tolerates a handful of such isolated
+    # flips; stage 2 back-propagates the REFERENCE's output gradient through the HIP model, so every weight gradient is compared
+    # on identical inputs and the tolerance can be tight.
+    (g_out,) = torch.autograd.grad(total, out)
     pr = torch_ref.to_torch(w, torch.float64, requires_grad=True)
     xr = torch_ref.to_torch(x, torch.float64)
     yr = torch_ref.forward(pr, CFG128, xr['ogm'], xr['map_img'], xr['obs'], xr['occ'], xr['flow'])
+    yr.retain_grad()
     dr = torch_ref.loss(yr, xr['gt_obs'], xr['gt_occ'], xr['gt_flow'], xr['origin_flow'], replica=1.0, use_gt=True)
     sum(dr.values()).backward()
     for k in dr:
         assert abs(float(d[k]) - float(dr[k])) < 1e-4 * abs(float(dr[k])) + 1e-5, (k, float(d[k]), float(dr[k]))
+    dg = (g_out.double().cpu() - yr.grad).abs()
+    gscale = float(yr.grad.abs().max())
+    flips = int((dg > 1e-4 * gscale).sum())
+    smooth = float(dg[dg <= 1e-4 * gscale].max()) / gscale
+    assert flips <= 8, f'{flips} output-gradient elements differ from the float64 reference by more than 1e-4 of the largest'
+    assert smooth < 1e-4
+    out.backward(yr.grad.to(torch.float32).to(out.device))
     bad = []
     worst = 0.0
     gmax = max(float(pr[n].grad.abs().max()) for n in model.params)
@@ -116,10 +130,11 @@ def test_train_step_parity_f32():
         # floor the scale at 1e-6 of the largest gradient in the model
         e = float((g - gr).abs().max()) / (scale + 1e-6 * gmax)
         worst = max(worst, e)
-        if e > 2e-3:
+        if e > 1e-3:
             bad.append((n, e, scale))
     _report(f'train step f32 128x128 B=2: losses ' + ', '.join(f'{k}={float(d[k]):.6f}' for k in d) +
-            f'; worst relative grad error {worst:.3e} over {len(model.params)} tensors')
+            f'; output gradient: {flips} sampling-boundary flips, otherwise {smooth:.1e} of max; worst relative grad error '
+            f'{worst:.3e} over {len(model.params)} tensors (reference output gradient back-propagated)')
     assert not bad, bad[:10]
 
 

@@ -248,6 +248,67 @@ def test_fg_bias(dt):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
+def test_mha_core_with_fg_bias_inside(dt):
+    """mha_core(fg_off=, fg=) == mha_core(bias=fg_bias(off)): same kernels, the bias gradient just never leaves the op."""
+    from strajnet_amd import ops
+    B, G, Hh, d = 2, 8, 8, 16
+    HW = Hh * Hh
+    q, k, v = (rnd((B, HW, G * d), dt, 10 + i).requires_grad_(True) for i in range(3))
+    off = rnd((B, G, HW, 2), dt, 2, 3.0).requires_grad_(True)
+    go = rnd((B, HW, G * d), dt, 5)
+    res = []
+    for inside in (False, True):
+        pt = mk_param((2 * Hh - 1, 2 * Hh - 1, G), dt, 0.5, 1)
+        for t in (q, k, v, off):
+            t.grad = None
+        if inside:
+            o = ops.mha_core(q, k, v, G, d, d ** -0.5, fg_off=off, fg=(pt, Hh, Hh))
+        else:
+            o = ops.mha_core(q, k, v, G, d, d ** -0.5, bias=ops.fg_bias(off, pt, Hh, Hh))
+        o.backward(go)
+        res.append([o.detach().clone(), q.grad.clone(), k.grad.clone(), v.grad.clone(), off.grad.clone(), pt.grad.clone()])
+    for i, (a, b) in enumerate(zip(*res)):
+        if i < 4:
+            assert torch.equal(a, b)
+        else:               # offset / table gradients are accumulated with f32 atomics: same terms, run-dependent order
+            assert rel_err(b, a) < 1e-5
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('B,Hh,G,gc,C2', [(2, 16, 8, 48, 384), (1, 8, 4, 24, 64)])
+def test_fg_offset_head(dt, B, Hh, G, gc, C2):
+    """Both halves of the FG-MSA offset head against dense float64 statements (FG_MSA.py:136-146, modules.py:827-831)."""
+    from strajnet_amd import ops
+    HW = Hh * Hh
+    p1, p2, pb2 = mk_param((1, 1, gc, 2), dt, 0.2, 1), mk_param((1, 1, 2, C2), dt, 0.3, 2), mk_param((C2,), dt, 0.1, 3)
+    o = rnd((B, Hh, Hh, G * gc), dt, 4).requires_grad_(True)
+    qres = rnd((B, HW, C2), dt, 5).requires_grad_(True)
+    scale = Hh / 2.0
+    off = ops.fg_offset(o, p1, scale, G)
+    query = ops.fg_query(off, p2, pb2, qres=qres)                 # [G,B,HW,C2]
+    fh = ops.fg_query(off, p2, pb2)                               # [B,G,HW,C2]
+    orf, qr, w1, w2, b2 = ref_of(o), ref_of(qres), ref_of(p1.master), ref_of(p2.master), ref_of(pb2.master)
+    offr = torch.tanh(orf.view(B, HW, G, gc).permute(0, 2, 1, 3) @ w1.view(gc, 2)) * scale
+    assert rel_err(off, offr) < tol(dt)
+    offq = off.detach().double().cpu()                            # the second half sees the rounded offsets
+    fhr = offq @ w2.view(2, C2).detach() + b2.detach()
+    assert rel_err(fh, fhr) < tol(dt)
+    assert rel_err(query, fhr.permute(1, 0, 2, 3) + qr.detach()[None]) < tol(dt)
+    # gradients: both consumers of off at once (autograd adds their offset gradients)
+    g1, g2, g3 = rnd(tuple(query.shape), dt, 6), rnd(tuple(fh.shape), dt, 7), rnd(tuple(off.shape), dt, 8)
+    torch.autograd.backward([query, fh, off], [g1, g2, g3])
+    fr = offr @ w2.view(2, C2) + b2
+    torch.autograd.backward([fr.permute(1, 0, 2, 3) + qr[None], fr, offr],
+                            [g1.double().cpu(), g2.double().cpu(), g3.double().cpu()])
+    t = tol(dt) * (1 if dt == torch.float32 else 2)
+    assert rel_err(qres.grad, qr.grad) < t
+    assert rel_err(o.grad, orf.grad) < t
+    assert rel_err(p1.grad, w1.grad) < t
+    assert rel_err(p2.grad, w2.grad) < t
+    assert rel_err(pb2.grad, b2.grad) < t
+
+
+@pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('F_,Hi,Cin,Cout', [(2, 8, 384, 192), (2, 16, 192, 128), (1, 32, 128, 96), (1, 32, 96, 48), (3, 16, 96, 48)])
 def test_upconv(dt, F_, Hi, Cin, Cout):
     from strajnet_amd import ops
