@@ -74,6 +74,12 @@ int stj_maxpool_bwd(const void* dy, const void* x, const void* y, void* dx, long
 int stj_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       long long rows, int C, float eps, int gather_res, int C0, long long group_rows, int ngroups,
                       long long gstride, int dtype, hipStream_t stream);
+/* y = LayerNorm(x) + res (res [rows,C], type T; no gather): the norm followed by the sum with another branch in one pass
+ * (vec + maps ahead of all_patch_norm, modules.py:589; Cross_AttentionT output + query, trajNet.py:305-317).  Backward:
+ * stj_layernorm_bwd for x; the gradient of res is dy itself. */
+int stj_layernorm_res_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* mean,
+                          float* rstd, long long rows, int C, float eps, long long group_rows, int ngroups,
+                          long long gstride, int dtype, hipStream_t stream);
 int stj_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       void* dx, float* dgamma, float* dbeta, long long rows, int C, int gather_res, int C0,
                       long long group_rows, int ngroups, long long gstride, const void* dres, int nparts, long long part_stride,

@@ -34,6 +34,7 @@ SIGNATURES = {
     'stj_maxpool_fwd': [vp, vp, vp, cl, ci, ci, ci, vp],
     'stj_maxpool_bwd': [vp, vp, vp, vp, cl, ci, ci, ci, vp],
     'stj_layernorm_fwd': [vp, vp, vp, vp, vp, vp, cl, ci, cf, ci, ci, cl, ci, cl, ci, vp],
+    'stj_layernorm_res_fwd': [vp, vp, vp, vp, vp, vp, vp, cl, ci, cf, cl, ci, cl, ci, vp],
     'stj_layernorm_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, cl, ci, cl, vp, ci, cl, ci, vp],
     'stj_win_attn_fwd': [vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_win_attn_bwd': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],

@@ -24,7 +24,7 @@ struct LnGroups { long long group_rows; int ngroups; long long gstride; int S; l
 template <typename T, int NPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
                                                      float* mean, float* rstd, long long rows, int C, float eps,
-                                                     int gres, int C0, LnGroups G) {
+                                                     int gres, int C0, LnGroups G, const T* res) {
   const int lane = threadIdx.x & 63;
   const long long wave = blockIdx.x * 4ll + (threadIdx.x >> 6);
   for (long long row = wave; row < rows; row += gridDim.x * 4ll) {
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
       const int c = lane + 64 * j;
-      if (c < C) stf(y + row * C + c, (v[j] - mu) * rs * gamma[goff + c] + beta[goff + c]);
+      if (c < C) stf(y + row * C + c, (v[j] - mu) * rs * gamma[goff + c] + beta[goff + c] + (res ? ldf(res + row * C + c) : 0.f));
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
   }
@@ -149,7 +149,8 @@ __device__ __forceinline__ float group_sum(float v) {
 template <typename T, int LPR, int NCHK>
 __global__ __launch_bounds__(256) void ln_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                                      long long rows, int C, float eps, int gres, int C0, LnGroups G) {
+                                                      long long rows, int C, float eps, int gres, int C0, LnGroups G,
+                                                      const T* __restrict__ res) {
   constexpr int VN = Vec<T>::N, RPW = 64 / LPR;
   constexpr int U = NCHK == 1 ? 4 : (NCHK == 2 ? 2 : 1);
   const int lane = threadIdx.x & 63, sl = lane % LPR, rsub = lane / LPR;
@@ -199,6 +200,12 @@ __global__ __launch_bounds__(256) void ln_fwd2_kernel(const T* __restrict__ x, c
           const float4 gv = *reinterpret_cast<const float4*>(gamma + goff + c + e), bv = *reinterpret_cast<const float4*>(beta + goff + c + e);
           o[e] = (v[u][k][e] - mu) * rs * gv.x + bv.x; o[e + 1] = (v[u][k][e + 1] - mu) * rs * gv.y + bv.y;
           o[e + 2] = (v[u][k][e + 2] - mu) * rs * gv.z + bv.z; o[e + 3] = (v[u][k][e + 3] - mu) * rs * gv.w + bv.w;
+        }
+        if (res) {                       // y = LN(x) + res: the sum a caller would otherwise make in a pass of its own
+          float r[VN];
+          ld16(res + row * C + c, r);
+#pragma unroll
+          for (int e = 0; e < VN; ++e) o[e] += r[e];
         }
         st16(y + row * C + c, o);
       }
@@ -312,13 +319,13 @@ template <typename T, int LPR, int NCHK>
 static void ln2_launch(bool fwd, int grid, hipStream_t stream, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                        float* rstd, const void* dy, void* dx, float* dgamma, float* dbeta, long long rows, int C, float eps, int gres, int C0,
                        LnGroups G, int nb, const void* dres) {
-  if (fwd) hipLaunchKernelGGL((ln_fwd2_kernel<T, LPR, NCHK>), dim3(grid), dim3(256), 0, stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, gres, C0, G);
+  if (fwd) hipLaunchKernelGGL((ln_fwd2_kernel<T, LPR, NCHK>), dim3(grid), dim3(256), 0, stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, gres, C0, G, (const T*)dres);
   else hipLaunchKernelGGL((ln_bwd2_kernel<T, LPR, NCHK>), dim3(grid), dim3(256), 0, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0, G, nb, (const T*)dres);
 }
 
 #define LN_DISPATCH(NPLV)                                                                                         \
   if (fwd) hipLaunchKernelGGL((ln_fwd_kernel<T, NPLV>), dim3(grid), dim3(256), 0, stream, (const T*)x, gamma, beta, \
-                              (T*)y, mean, rstd, rows, C, eps, gres, C0, G);                                       \
+                              (T*)y, mean, rstd, rows, C, eps, gres, C0, G, (const T*)dres);                       \
   else hipLaunchKernelGGL((ln_bwd_kernel<T, NPLV>), dim3(grid), dim3(64 * LNB_WAVES), 0, stream, (const T*)dy, (const T*)x,    \
                           gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C, gres, C0, G, nb, (const T*)dres);
 
@@ -334,7 +341,7 @@ static int ln_launch(bool fwd, const void* x, const float* gamma, const float* b
     static int v2 = -1;
     if (v2 < 0) { const char* e = getenv("STJ_LN_V1"); v2 = !(e && atoi(e)); }
     const int chunks = C / VN;
-    const bool al = ((uintptr_t)x % 16 == 0) && (!fwd || (uintptr_t)y % 16 == 0) && (fwd || ((uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)dres % 16 == 0)) &&
+    const bool al = ((uintptr_t)x % 16 == 0) && (!fwd || ((uintptr_t)y % 16 == 0 && (uintptr_t)dres % 16 == 0)) && (fwd || ((uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)dres % 16 == 0)) &&
                     ((uintptr_t)gamma % 16 == 0) && (fwd ? (uintptr_t)beta % 16 == 0 : true) && (G.gstride % 4 == 0);
     if (v2 && C % VN == 0 && (gres == 0 || C0 % VN == 0) && chunks <= 192 && al) {
       LnGroups G2 = G;
@@ -411,6 +418,18 @@ extern "C" int stj_layernorm_fwd(const void* x, const float* gamma, const float*
   if (dtype == STJ_BF16) return ln_launch<bf16>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, G, stream);
   if (dtype == STJ_F16) return ln_launch<f16>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, G, stream);
   return ln_launch<float>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, gather_res, C0, G, stream);
+}
+// y = LayerNorm(x) * gamma + beta + res (res [rows, C], same type): LayerNorm followed by a sum with another branch
+// (the stem's vec + maps before all_patch_norm's input, modules.py:589; Cross_AttentionT's output + query, trajNet.py:305-317).
+extern "C" int stj_layernorm_res_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* mean,
+                                     float* rstd, long long rows, int C, float eps, long long group_rows, int ngroups,
+                                     long long gstride, int dtype, hipStream_t stream) {
+  if (rows <= 0) return STJ_OK;
+  if (ngroups > 1 && group_rows <= 0) { stj_set_error("layernorm: bad group_rows"); return STJ_EINVAL; }
+  LnGroups G; G.group_rows = group_rows > 0 ? group_rows : rows; G.ngroups = ngroups > 1 ? ngroups : 1; G.gstride = gstride; G.S = 1; G.L = G.group_rows; G.nparts = 1; G.pstride = 0;
+  if (dtype == STJ_BF16) return ln_launch<bf16>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, 0, 0, G, stream, res);
+  if (dtype == STJ_F16) return ln_launch<f16>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, 0, 0, G, stream, res);
+  return ln_launch<float>(true, x, gamma, beta, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, rows, C, eps, 0, 0, G, stream, res);
 }
 extern "C" int stj_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                  void* dx, float* dgamma, float* dbeta, long long rows, int C, int gather_res, int C0,

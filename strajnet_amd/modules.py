@@ -360,8 +360,8 @@ class STrajNet:
     def _p(self, name):
         return self.params[name]
 
-    def _ln(self, x, name, eps, gather_res=0):
-        return ops.layernorm(x, self._p(name + '/gamma'), self._p(name + '/beta'), eps, gather_res)
+    def _ln(self, x, name, eps, gather_res=0, res=None):
+        return ops.layernorm(x, self._p(name + '/gamma'), self._p(name + '/beta'), eps, gather_res, res=res)
 
     def _ln_skip(self, x, name, eps):
         """(LayerNorm(x), x) -- x for the residual that bypasses the norm (gradient accumulation fused into the LN backward)."""
@@ -433,12 +433,13 @@ class STrajNet:
             add = add()                                                      # join point of a branch computed on a side stream
         return self._dense(m, pre + '/downsample/reduction', bias=False, res=add), x
 
-    def _patch_embed(self, src, name, Cin, ch_stride, pix_stride):
-        """PatchEmbed.call (modules.py:437-446): conv4x4/s4 as im2col + dense, then LN(1e-5)."""
+    def _patch_embed(self, src, name, Cin, ch_stride, pix_stride, add=None):
+        """PatchEmbed.call (modules.py:437-446): conv4x4/s4 as im2col + dense, then LN(1e-5) (+ `add`, the other embedding the
+        caller sums it with, in the norm's epilogue)."""
         B, H = src.shape[0], src.shape[1]
         cols = ops.patch_im2col(src, Cin, ch_stride, pix_stride, self.dtype)
         y = self._dense(cols, name + '/proj')
-        y = self._ln(y, name + '/norm', 1e-5)
+        y = self._ln(y, name + '/norm', 1e-5, res=add.view(y.shape) if add is not None else None)
         return y.view(B, (H // 4) ** 2, -1)
 
     def _encoder(self, ogm, map_img, flow, hook=None):
@@ -468,12 +469,15 @@ class STrajNet:
             flow_x, flow_res = flow_branch()
             joined_flow_x = flow_x
         vec = self._patch_embed(ogm, 'patch_embed_vecicle', 11, 2, 22)          # ogm[...,0]: stride-2 channel pick (:572)
-        maps = self._patch_embed(map_img, 'patch_embed_map', 3, 1, 3)
         if self.large_ogm:                                                      # modules.py:582-587
+            maps = self._patch_embed(map_img, 'patch_embed_map', 3, 1, 3)
             Pm = self.map_size // 4
             pad = (P - Pm) // 2
             maps = torch.nn.functional.pad(maps.view(B, Pm, Pm, C), (0, 0, pad, pad, pad, pad)).reshape(B, P * P, C)
-        x = self._ln(vec + maps, 'all_patch_norm', 1e-5)
+            x = vec + maps
+        else:
+            x = self._patch_embed(map_img, 'patch_embed_map', 3, 1, 3, add=vec)   # vec + maps (modules.py:589)
+        x = self._ln(x, 'all_patch_norm', 1e-5)
         self._tap('stem', x)
         res_list = []
 
@@ -630,8 +634,9 @@ class STrajNet:
         pw, pb = self._zp('FFN2/kernel'), self._zp('FFN2/bias')
         v1 = self._drop(ops.linear_z(v1, pw.master, pw.c, zs, pb.master.detach(), zs, pw.grad, zs, pb.grad, 8),
                         'cross_attn_obs/dropout2')
-        v1 = ops.layernorm(v1, self._zp('norm2/gamma'), self._zp('norm2/beta'), 1e-3, group_rows=B * HW, ngroups=8, gstride=zs)
-        return v1.view(Z, B, HW, Cb) + query
+        v1 = ops.layernorm(v1, self._zp('norm2/gamma'), self._zp('norm2/beta'), 1e-3, group_rows=B * HW, ngroups=8, gstride=zs,
+                           res=query.reshape(v1.shape))                             # + query (trajNet.py:317)
+        return v1.view(Z, B, HW, Cb)
 
     def _decoder(self, x, res_list, B, skips=None):
         """Pyramid3DDecoder.call (modules.py:739-772): shallow_decode=1, flow_sep_decode, use_pyramid, rep_res."""

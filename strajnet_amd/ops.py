@@ -519,7 +519,7 @@ def tanh_scale(x, s):
 # ----------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g_master, b_master, pg, pb, eps, gather_res, group_rows, ngroups, gstride, with_skip):
+    def forward(ctx, x, g_master, b_master, pg, pb, eps, gather_res, group_rows, ngroups, gstride, with_skip, res=None):
         _req_cuda(x)
         x = x.contiguous()
         dt = _dt(x)
@@ -537,8 +537,16 @@ class _LayerNorm(torch.autograd.Function):
         y = torch.empty(oshape, dtype=x.dtype, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        call('stj_layernorm_fwd', _p(x), _p(pg.master), _p(pb.master), _p(y), _p(mean), _p(rstd), rows, C, float(eps),
-             gather_res, C0, group_rows, ngroups, gstride, dt, _st())
+        if res is not None:     # y = LN(x) + res in the same pass
+            if gather_res or res.numel() != rows * C:
+                raise RuntimeError('layernorm: res needs the plain (no gather) form and the output shape')
+            call('stj_layernorm_res_fwd', _p(x), _p(pg.master), _p(pb.master), _p(res.contiguous()), _p(y), _p(mean), _p(rstd), rows, C,
+                 float(eps), group_rows, ngroups, gstride, dt, _st())
+        else:
+            call('stj_layernorm_fwd', _p(x), _p(pg.master), _p(pb.master), _p(y), _p(mean), _p(rstd), rows, C, float(eps),
+                 gather_res, C0, group_rows, ngroups, gstride, dt, _st())
+        ctx.has_res = res is not None
+        ctx.res_shape = res.shape if res is not None else None
         ctx.pg, ctx.pb, ctx.geo = pg, pb, (rows, C, gather_res, C0, group_rows, ngroups, gstride)
         ctx.save_for_backward(x, mean, rstd)
         if with_skip:           # second output: x itself, for the residual connection that bypasses the norm
@@ -550,7 +558,7 @@ class _LayerNorm(torch.autograd.Function):
         x, mean, rstd = ctx.saved_tensors
         rows, C, gres, C0, group_rows, ngroups, gstride = ctx.geo
         if dy is None:          # only the skip output was used
-            return (dskip,) + (None,) * 10
+            return (dskip,) + (None,) * 11
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dres = dskip.contiguous() if dskip is not None else None
@@ -561,12 +569,13 @@ class _LayerNorm(torch.autograd.Function):
             dg, db, nparts, pstride = pg.grad, pb.grad, 1, 0
         call('stj_layernorm_bwd', _p(dy), _p(x), _p(pg.master), _p(mean), _p(rstd), _p(dx), _p(dg),
              _p(db), rows, C, gres, C0, group_rows, ngroups, gstride, _p(dres), nparts, pstride, _dt(x), _st())
-        return (dx,) + (None,) * 10
+        return (dx,) + (None,) * 10 + ((dy.view(ctx.res_shape) if ctx.has_res else None),)
 
 
-def layernorm(x, pg, pb, eps, gather_res=0, group_rows=0, ngroups=1, gstride=0):
-    """pg/pb: Param of gamma/beta (of group 0 when ngroups > 1; group g's live gstride*g elements further)."""
-    return _LayerNorm.apply(x, pg.master, pb.master, pg, pb, eps, gather_res, group_rows, ngroups, gstride, False)
+def layernorm(x, pg, pb, eps, gather_res=0, group_rows=0, ngroups=1, gstride=0, res=None):
+    """pg/pb: Param of gamma/beta (of group 0 when ngroups > 1; group g's live gstride*g elements further).
+    res (same shape as the output): returns LayerNorm(x) + res from the one pass."""
+    return _LayerNorm.apply(x, pg.master, pb.master, pg, pb, eps, gather_res, group_rows, ngroups, gstride, False, res)
 
 
 def layernorm_skip(x, pg, pb, eps):

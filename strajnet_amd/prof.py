@@ -109,6 +109,10 @@ def _ln(kind):
         if kind == 'fwd':
             rows, C, dt = a[6], a[7], a[14]
             by = 2 * _es(dt) * rows * C
+        elif kind == 'res_fwd':
+            rows, C, dt = a[7], a[8], a[13]
+            by = 3 * _es(dt) * rows * C
+            return f'layernorm_res_fwd[{rows}x{C}]', 'layernorm_fwd', 9.0 * rows * C, 9.0 * rows * C, by
         else:
             rows, C, dt = a[8], a[9], a[18]
             by = (4 if getattr(a[15], 'value', None) else 3) * _es(dt) * rows * C
@@ -151,7 +155,7 @@ MODELS = {
     'stj_gemm': _gemm,
     'stj_upconv_fwd': _upconv('fwd'), 'stj_upconv_fwd_res': _upconv_res, 'stj_elu_res_bwd': _elu_res, 'stj_upconv_dgrad': _upconv('dgrad'), 'stj_upconv_wgrad': _upconv('wgrad'),
     'stj_outconv_fwd': _outconv('fwd'), 'stj_outconv_pair_fwd': _outconv_pair, 'stj_outconv_bwd': _outconv('bwd'),
-    'stj_layernorm_fwd': _ln('fwd'), 'stj_layernorm_bwd': _ln('bwd'),
+    'stj_layernorm_fwd': _ln('fwd'), 'stj_layernorm_bwd': _ln('bwd'), 'stj_layernorm_res_fwd': _ln('res_fwd'),
     'stj_win_attn_fwd': _win('fwd'), 'stj_win_attn_bwd': _win('bwd'),
     'stj_unary_fwd': _elem('unary_fwd', 2, 5, 2), 'stj_unary_bwd': _elem('unary_bwd', 3, 6, 3),
     'stj_dropout': _elem('dropout', 3, 8, 2),

@@ -106,6 +106,26 @@ def test_layernorm(dt, rows, C, eps):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('rows,C', [(300, 96), (257, 384), (64, 100)])
+def test_layernorm_res(dt, rows, C):
+    """LayerNorm(x) + res from one pass (v2 vector path and, for C = 100, the v1 path); d res = dy."""
+    from strajnet_amd import ops
+    pg, pb = mk_param((C,), dt, 0.3, 1), mk_param((C,), dt, 0.3, 2)
+    x = rnd((rows, C), dt, 3, 2.0).requires_grad_(True)
+    r = rnd((rows, C), dt, 4, 2.0).requires_grad_(True)
+    y = ops.layernorm(x, pg, pb, 1e-3, res=r)
+    xr, rr, gr, br = ref_of(x), ref_of(r), ref_of(pg.master), ref_of(pb.master)
+    yr = F.layer_norm(xr, (C,), gr, br, 1e-3) + rr
+    assert rel_err(y, yr) < tol(dt)
+    g = rnd((rows, C), dt, 5)
+    y.backward(g)
+    yr.backward(g.double().cpu())
+    assert rel_err(x.grad, xr.grad) < tol(dt)
+    assert torch.equal(r.grad, g)
+    assert rel_err(pg.grad, gr.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
 def test_layernorm_merge_gather(dt):
     from strajnet_amd import ops
     B, res, C0 = 2, 16, 96
