@@ -13,6 +13,7 @@
 //   * results (bias + ELU applied) are staged in LDS and leave as full rows of 8-byte segments, coalesced.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define WS_TH 8
 #define WS_TW 16
@@ -1718,7 +1719,7 @@ static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const voi
 // One workgroup barrier per step (2 low-res rows).
 // =====================================================================================================
 typedef __attribute__((ext_vector_type(4))) short ws_bf16x4;
-template <bool ELU>
+template <bool ELU, bool V3>
 __global__ __launch_bounds__(512, 1) void upconv_dgrad_ws2_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ Wd,
                                                                   bf16* __restrict__ dX, const bf16* __restrict__ Xelu, int F, int Hi,
                                                                   int Wi, int ntiles, int dbg) {
@@ -1799,6 +1800,153 @@ __global__ __launch_bounds__(512, 1) void upconv_dgrad_ws2_kernel(const bf16* __
                 make_uint2(pack2bf(acc[m][n][0], acc[m][n][1]), pack2bf(acc[m][n][2], acc[m][n][3]));
         __syncthreads();
       }
+    }
+    __syncthreads();
+  } else if constexpr (V3) {
+    // ------------------------------------------------------------------ mover role, straight-line version (whole tiles only)
+    // The first mover (below) guards every load and store (image border, ragged tile, group size, end of the tile stream).  Each
+    // guard is a branch, and with memory operations under divergent branches the compiler gives up counting: every use of a
+    // prefetched register waits on vmcnt(0) -- i.e. on the loads issued a few instructions earlier, which were meant to stay in
+    // flight for two steps (ablation: 318 us, of which the movers alone 277; without the sum 208).  Here every load, LDS write and
+    // store of a step is unconditional: out-of-image addresses are clamped and the value zeroed when it is committed, a thread's
+    // surplus chunk of a short group repeats its previous chunk (same address, same data), a tile index past the end is clamped to
+    // the last tile (its groups are fetched and committed again: dead rows, never read), the 384 16-byte items of a step are one
+    // item + one half item per thread.  The waits then carry exact counts and the two-step lookahead is real.
+    constexpr int NP4 = (4 * HW * CPP + 255) / 256, NP6 = (6 * HW * CPP + 255) / 256;     // 4, 5 chunks per thread
+    int cgeo[NP6];                                       // row | col << 8 | channel-chunk << 16 of chunk i (row < 6, col < 34)
+#pragma unroll
+    for (int i = 0; i < NP6; ++i) {
+      const int c = mt + i * 256, px = c / CPP;
+      cgeo[i] = (px / HW) | ((px % HW) << 8) | ((c % CPP) << 16);
+    }
+    uint4 preA[NP6], preB[NP6];
+    int mskA = 0, mskB = 0;                              // bit i: chunk i of the set lies inside the image
+    const int last_tile = ntiles - 1;
+    // group n = 4 * (local tile) + j; J = n & 3 is a compile-time constant at every call site
+    auto prefetch = [&](uint4 (&pre)[NP6], int& msk, int n, auto JC) {
+      constexpr int J = decltype(JC)::value, NR = J == 3 ? 6 : 4, NP = J == 3 ? NP6 : NP4;
+      int tile = blockIdx.x + (n >> 2) * (int)gridDim.x;
+      tile = tile < last_tile ? tile : last_tile;
+      int f, ty0, tx0;
+      tile_coords(tile, f, ty0, tx0);
+      const int y0 = 2 * ty0 + 4 * J - 1, x0 = 2 * tx0 - 1;
+      const bf16* Pf = dP + (long long)f * Ho * Wo * Cout;
+      int m = 0;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int ge = (i > 0 && (cgeo[i] & 0xff) >= NR) ? cgeo[i - 1] : cgeo[i];
+        const int gy = y0 + (ge & 0xff), gx = x0 + ((ge >> 8) & 0xff), ch = (ge >> 16) * 8;
+        const int cy = min(max(gy, 0), Ho - 1), cx = min(max(gx, 0), Wo - 1);
+        m |= (cy == gy && cx == gx) ? (1 << i) : 0;
+        pre[i] = *reinterpret_cast<const uint4*>(Pf + (cy * Wo + cx) * Cout + ch);
+      }
+      msk = m;
+    };
+    auto commit = [&](const uint4 (&pre)[NP6], int msk, auto JC) {
+      constexpr int J = decltype(JC)::value, NR = J == 3 ? 6 : 4, NP = J == 3 ? NP6 : NP4;
+      // the zeroing of out-of-image chunks must not be scheduled above the barrier that precedes this commit (it would wait for the
+      // loads a step early): the mask goes through a volatile asm, which keeps its uses below it
+      int m = msk;
+      asm volatile("" : "+v"(m));
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int ge = (i > 0 && (cgeo[i] & 0xff) >= NR) ? cgeo[i - 1] : cgeo[i];
+        const bool in = (m >> i) & 1;
+        const uint4 v = make_uint4(in ? pre[i].x : 0u, in ? pre[i].y : 0u, in ? pre[i].z : 0u, in ? pre[i].w : 0u);
+        *reinterpret_cast<uint4*>(halo + ((4 * J + (ge & 0xff)) * HW + ((ge >> 8) & 0xff)) * LDK + (ge >> 16) * 8) = v;
+      }
+    };
+    // items of a step: A = 16 bytes (8 channels) of pixel mt / 12; B = 8 bytes (4 channels) of the remaining 128 items, two threads each
+    const int ppA = mt / 12, cA = (mt % 12) * 8;
+    const int itB = 256 + (mt >> 1), ppB = itB / 12, cB = (itB % 12) * 8 + (mt & 1) * 4;
+    uint4 xA = make_uint4(0, 0, 0, 0);
+    uint2 xB = make_uint2(0, 0);
+    auto item_off = [&](int f, int ty0, int tx0, int st, int pp, int c) {
+      return ((long long)f * Hi * Wi + (long long)(ty0 + 2 * st + (pp >> 4)) * Wi + tx0 + (pp & 15)) * Cin + c;
+    };
+    auto fetch_x = [&](int f, int ty0, int tx0, int st) {
+      if constexpr (ELU) {
+        xA = *reinterpret_cast<const uint4*>(Xelu + item_off(f, ty0, tx0, st, ppA, cA));
+        xB = *reinterpret_cast<const uint2*>(Xelu + item_off(f, ty0, tx0, st, ppB, cB));
+      }
+    };
+    auto elu2 = [](float& v0, float& v1, uint32_t xw) {      // v *= ELU'(x) = min(x, 0) + 1
+      const float x0 = __uint_as_float(xw << 16), x1 = __uint_as_float(xw & 0xffff0000u);
+      v0 = fmaf(v0, fminf(x0, 0.f), v0);
+      v1 = fmaf(v1, fminf(x1, 0.f), v1);
+    };
+    auto reduce = [&](const bf16* red, int f, int ty0, int tx0, int st) {
+      // x was fetched a step ago; without this pin its unpacking (pure register arithmetic) is scheduled ABOVE the preceding barrier,
+      // into the step that issued the loads, and waits for them there
+      uint4 xa = xA; uint2 xb = xB;
+      if constexpr (ELU) asm volatile("" : "+v"(xa.x), "+v"(xa.y), "+v"(xa.z), "+v"(xa.w), "+v"(xb.x), "+v"(xb.y));
+      {
+        const bf16* rp = red + ((ppA >> 4) * 16 + (ppA & 15)) * LDR + cA;
+        float v[8], t[8];
+        ld16<bf16>(rp, v);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+          ld16<bf16>(rp + ww * 2 * 16 * LDR, t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        if constexpr (ELU) { elu2(v[0], v[1], xa.x); elu2(v[2], v[3], xa.y); elu2(v[4], v[5], xa.z); elu2(v[6], v[7], xa.w); }
+        *reinterpret_cast<uint4*>(dX + item_off(f, ty0, tx0, st, ppA, cA)) =
+            make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+      }
+      {
+        const bf16* rp = red + ((ppB >> 4) * 16 + (ppB & 15)) * LDR + cB;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+          const uint2 u = *reinterpret_cast<const uint2*>(rp + ww * 2 * 16 * LDR);
+          v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+          v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+        }
+        if constexpr (ELU) { elu2(v[0], v[1], xb.x); elu2(v[2], v[3], xb.y); }
+        *reinterpret_cast<uint2*>(dX + item_off(f, ty0, tx0, st, ppB, cB)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+    };
+    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+    // first tile of the block: whole halo, synchronously; groups 3 (again: step 0 commits it) and 4 go in flight
+    prefetch(preA, mskA, 0, J0{}); commit(preA, mskA, J0{});
+    prefetch(preA, mskA, 1, J1{}); commit(preA, mskA, J1{});
+    prefetch(preA, mskA, 2, J2{}); commit(preA, mskA, J2{});
+    prefetch(preB, mskB, 3, J3{}); commit(preB, mskB, J3{});
+    prefetch(preA, mskA, 4, J0{});
+    __syncthreads();
+    int q = 0, pf = 0, pty = 0, ptx = 0;
+    // one mover step: roll the halo (commit group q + 3, fetch group q + 5), sum + store the previous step's partials (their x
+    // operand was fetched last step), fetch this step's x.  FIRST: there is no previous step.
+    auto step = [&](uint4 (&pre)[NP6], int& msk, int f, int ty0, int tx0, auto STC, auto FIRSTC) {
+      constexpr int ST = decltype(STC)::value;
+      constexpr bool FIRST = decltype(FIRSTC)::value;
+      commit(pre, msk, std::integral_constant<int, (ST + 3) & 3>{});
+      prefetch(pre, msk, q + 5, std::integral_constant<int, (ST + 1) & 3>{});
+      if constexpr (!FIRST) reduce(red0 + ((q - 1) & 1) * RED, pf, pty, ptx, (ST + 3) & 3);
+      fetch_x(f, ty0, tx0, ST);
+      pf = f; pty = ty0; ptx = tx0;
+      ++q;
+      __syncthreads();
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+      int f, ty0, tx0;
+      tile_coords(tile, f, ty0, tx0);
+      step(preB, mskB, f, ty0, tx0, J0{}, T_{});
+      step(preA, mskA, f, ty0, tx0, J1{}, F_{});
+      step(preB, mskB, f, ty0, tx0, J2{}, F_{});
+      step(preA, mskA, f, ty0, tx0, J3{}, F_{});
+      for (tile += gridDim.x; tile < ntiles; tile += gridDim.x) {
+        tile_coords(tile, f, ty0, tx0);
+        step(preB, mskB, f, ty0, tx0, J0{}, F_{});
+        step(preA, mskA, f, ty0, tx0, J1{}, F_{});
+        step(preB, mskB, f, ty0, tx0, J2{}, F_{});
+        step(preA, mskA, f, ty0, tx0, J3{}, F_{});
+      }
+      reduce(red0 + ((q - 1) & 1) * RED, pf, pty, ptx, 3);
     }
     __syncthreads();
   } else {
@@ -1931,20 +2079,20 @@ __global__ __launch_bounds__(512, 1) void upconv_dgrad_ws2_kernel(const bf16* __
   }
 }
 
-template <bool ELU>
+template <bool ELU, bool V3>
 static bool dgrad_ws2_launch(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, hipStream_t st) {
   constexpr int LDK = 56, HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), LDR = 104;
   const size_t lds = (size_t)(HPIX * LDK + 2 * 4 * 2 * 16 * LDR) * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)upconv_dgrad_ws2_kernel<ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)upconv_dgrad_ws2_kernel<ELU, V3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
   }
   const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
   const int nblk = ntiles < 256 ? ntiles : 256;
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("STJ_WS2_DBG"); dbg = e ? atoi(e) : 0; }      // ablation switches (profiling only)
-  hipLaunchKernelGGL((upconv_dgrad_ws2_kernel<ELU>), dim3(nblk), dim3(512), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX, (const bf16*)Xelu, F, Hi, Wi, ntiles, dbg);
+  hipLaunchKernelGGL((upconv_dgrad_ws2_kernel<ELU, V3>), dim3(nblk), dim3(512), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX, (const bf16*)Xelu, F, Hi, Wi, ntiles, dbg);
   return true;
 }
 
@@ -1957,8 +2105,11 @@ bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, const void* X
   if (Cout % 8 || Cin % 8) return false;
   static int v2 = -1;
   if (v2 < 0) { const char* e = getenv("STJ_DGRAD_WS2"); v2 = e ? atoi(e) : 1; }
-  if (Cout == 48 && Cin == 96 && v2)
-    return Xelu ? dgrad_ws2_launch<true>(dP, Wd, dX, Xelu, F, Hi, Wi, st) : dgrad_ws2_launch<false>(dP, Wd, dX, Xelu, F, Hi, Wi, st);
+  if (Cout == 48 && Cin == 96 && v2) {
+    if (v2 != 2 && Hi % WS_TH == 0 && Wi % WS_TW == 0)      // whole tiles: straight-line movers (STJ_DGRAD_WS2=2: the guarded ones)
+      return Xelu ? dgrad_ws2_launch<true, true>(dP, Wd, dX, Xelu, F, Hi, Wi, st) : dgrad_ws2_launch<false, true>(dP, Wd, dX, Xelu, F, Hi, Wi, st);
+    return Xelu ? dgrad_ws2_launch<true, false>(dP, Wd, dX, Xelu, F, Hi, Wi, st) : dgrad_ws2_launch<false, false>(dP, Wd, dX, Xelu, F, Hi, Wi, st);
+  }
   if (Cout == 48 && Cin == 96) return dgrad_ws_launch<2, 6, 48>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
   if (Cout == 96 && Cin == 128) return dgrad_ws_launch<3, 4, 96>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
   return false;
