@@ -196,7 +196,7 @@ static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y,
 // instead of one 57 KB tile stage), the halo at tile granularity; one workgroup barrier per step.  Both roles run on every SIMD (one
 // compute + one mover wave each), so global traffic, LDS staging and the epilogue's VALU work overlap the MFMAs of the other role.
 // =====================================================================================================
-template <typename T, int KS, int NF>
+template <typename T, int KS, int NF, bool EXACT>
 __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
                                                              const float* __restrict__ bias, T* __restrict__ Y,
                                                              int F, int Hi, int Wi, int Cout, int ntiles, int dbg) {
@@ -297,6 +297,85 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
       }
     }
     __syncthreads();                                     // matches the movers' final drain barrier
+  } else if constexpr (EXACT) {
+    // ------------------------------------------------------------------ mover role, straight-line version (whole tiles, Cout % CT == 0)
+    // Same duties as below with every load, LDS write and store unconditional (clamped halo addresses, zeroing at commit through a
+    // pinned mask, a thread's surplus chunk repeats its previous one, the tile after the last is the last again): with guarded
+    // memory operations the compiler waits on vmcnt(0) before the commit -- i.e. for the drain's STORES, which count in vmcnt on
+    // gfx9 -- once per tile, and before every drain on the prefetch issued just above it.
+    static_assert(STEPS == 2, "the step sequence below is written out for two steps per tile");
+    constexpr int NCHK = HPIX * CPP;
+    uint4 pre[NCH];
+    int msk = 0;
+    int cgeo[NCH];                                        // halo pixel | channel chunk << 16
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int c = mt + i * 256;
+      if (c >= NCHK) c -= 256;                            // surplus chunk of the last round: the thread's previous chunk again
+      cgeo[i] = (c / CPP) | ((c % CPP) << 16);
+    }
+    const int last_tile = ntiles - 1;
+    auto prefetch = [&](int tile) {
+      tile = tile < last_tile ? tile : last_tile;
+      int f, ty0, tx0;
+      tile_coords(tile, f, ty0, tx0);
+      const T* Xf = X + (long long)f * Hi * Wi * CIN;
+      int m = 0;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int px = cgeo[i] & 0xffff, ch = (cgeo[i] >> 16) * 8;
+        const int gy = ty0 + px / WS_HW - 1, gx = tx0 + px % WS_HW - 1;
+        const int cy = min(max(gy, 0), Hi - 1), cx = min(max(gx, 0), Wi - 1);
+        m |= (cy == gy && cx == gx) ? (1 << i) : 0;
+        pre[i] = *reinterpret_cast<const uint4*>(Xf + (cy * Wi + cx) * CIN + ch);
+      }
+      msk = m;
+    };
+    auto commit = [&](T* halo) {
+      int m = msk;
+      asm volatile("" : "+v"(m));                         // keeps the zeroing below the barrier that precedes the commit
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const bool in = (m >> i) & 1;
+        const uint4 v = make_uint4(in ? pre[i].x : 0u, in ? pre[i].y : 0u, in ? pre[i].z : 0u, in ? pre[i].w : 0u);
+        *reinterpret_cast<uint4*>(halo + (cgeo[i] & 0xffff) * LDK + (cgeo[i] >> 16) * 8) = v;
+      }
+    };
+    constexpr int SEG = CT / 8, NIT = 2 * SR * 2 * WS_TW * SEG;
+    static_assert(NIT % 256 == 0, "whole rounds of 16-byte items per step");
+    auto drain = [&](const T* ost, int f, int ty0, int tx0, int st) {
+      T* Yf = Y + (long long)f * Ho * Wo * Cout + ((long long)(2 * ty0 + 2 * SR * st) * Wo + 2 * tx0) * Cout + n0;
+#pragma unroll
+      for (int i = 0; i < NIT / 256; ++i) {
+        const int c = mt + i * 256;
+        const int sg = c % SEG, p = c / SEG;
+        *reinterpret_cast<uint4*>(Yf + ((p / (2 * WS_TW)) * Wo + p % (2 * WS_TW)) * Cout + sg * 8) = *reinterpret_cast<const uint4*>(ost + p * LDO + sg * 8);
+      }
+    };
+    int tile = blockIdx.x;
+    prefetch(tile); commit(halo0);
+    __syncthreads();
+    int lt = 0, f, ty0, tx0, pf, pty, ptx;
+    // first tile: no previous stage at its first step
+    tile_coords(tile, f, ty0, tx0);
+    prefetch(tile + gridDim.x);                           // loads fly for the whole tile
+    __syncthreads();
+    drain(ost0, f, ty0, tx0, 0);
+    commit(halo1);
+    pf = f; pty = ty0; ptx = tx0; lt = 1;
+    __syncthreads();
+    for (tile += gridDim.x; tile < ntiles; tile += gridDim.x, ++lt) {
+      tile_coords(tile, f, ty0, tx0);
+      prefetch(tile + gridDim.x);
+      drain(ost0 + OST, pf, pty, ptx, 1);                 // stage of the previous tile's second step (odd q)
+      __syncthreads();
+      drain(ost0, f, ty0, tx0, 0);
+      commit((lt & 1) ? halo0 : halo1);                   // the NEXT tile's buffer
+      pf = f; pty = ty0; ptx = tx0;
+      __syncthreads();
+    }
+    drain(ost0 + OST, pf, pty, ptx, 1);
+    __syncthreads();
   } else {
     // ------------------------------------------------------------------ mover role
     uint4 pre[NCH];
@@ -357,13 +436,13 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
   }
 }
 
-template <typename T, int KS, int NF>
-static bool ws2_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, hipStream_t st) {
+template <typename T, int KS, int NF, bool EXACT>
+static bool ws2_launch_t(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, hipStream_t st) {
   constexpr int CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 8;
   const size_t lds = (size_t)(2 * WS_HH * WS_HW * LDK + 2 * 8 * 2 * WS_TW * LDO) * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)upconv_fwd_ws2_kernel<T, KS, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)upconv_fwd_ws2_kernel<T, KS, NF, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
   }
   const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
@@ -373,8 +452,16 @@ static bool ws2_launch(const void* X, const void* Wf, const float* bias, void* Y
   if (nblk < 1) nblk = 1;
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("STJ_WS2_DBG"); dbg = e ? atoi(e) : 0; }      // ablation switches (profiling only)
-  hipLaunchKernelGGL((upconv_fwd_ws2_kernel<T, KS, NF>), dim3(nblk, ct), dim3(512), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y, F, Hi, Wi, Cout, ntiles, dbg);
+  hipLaunchKernelGGL((upconv_fwd_ws2_kernel<T, KS, NF, EXACT>), dim3(nblk, ct), dim3(512), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y, F, Hi, Wi, Cout, ntiles, dbg);
   return true;
+}
+template <typename T, int KS, int NF>
+static bool ws2_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, hipStream_t st) {
+  static int guarded = -1;
+  if (guarded < 0) { const char* e = getenv("STJ_WS2_GUARDED"); guarded = e && atoi(e); }
+  if (!guarded && Hi % WS_TH == 0 && Wi % WS_TW == 0 && Cout % (NF * 16) == 0)      // whole tiles: straight-line movers
+    return ws2_launch_t<T, KS, NF, true>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
+  return ws2_launch_t<T, KS, NF, false>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
 }
 
 // returns true when the weight-stationary kernel handles this shape (bf16 / fp16, Cin in {96,128}, Cout multiple of 8)
@@ -1648,6 +1735,10 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
         for (int n = 0; n < NFI; ++n)
           *reinterpret_cast<float4*>(red + ((w * 2 + m) * 16 + ln) * LDR + n * 16 + g * 4) = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
       __syncthreads();
+      // the halo is dead once the last pass's fragments are read: the next tile goes in HERE, before this pass's stores are issued --
+      // after them, the commit's wait for the prefetched registers (vmcnt(0): the loads sit under guards, so the compiler cannot
+      // count) would also wait for those stores, once per tile
+      if (mf == WS_TH - 2 && next < ntiles) commit();
       // sum the 4 phases, 8 channels per thread-iteration, coalesced 16-byte stores
 #pragma unroll
       for (int i = 0; i < NEP; ++i) {
@@ -1683,8 +1774,6 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
       }
       __syncthreads();
     }
-    if (next < ntiles) commit();
-    __syncthreads();
   }
 }
 

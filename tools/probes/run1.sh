@@ -1,2 +1,3 @@
-timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_timed_kernels_gpu.py -x -q -k "upconv" 2>&1 | tail -2
-for v in 1 2 1 2; do echo -n "STJ_DGRAD_WS2=$v "; STJ_DGRAD_WS2=$v python tools/bench_conv.py --layer 3 --only dgradE --iters 20 2>/dev/null | tail -1; done
+run() { python bench.py --no-cpu-baseline --no-kernel-timing $* 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
+for i in 1 2 3; do echo -n "new "; run; echo -n "old-movers "; STJ_DGRAD_WS2=2 STJ_WS2_GUARDED=1 run; done
+echo -n "infer new "; run --infer; echo -n "infer old "; STJ_WS2_GUARDED=1 run --infer
