@@ -73,15 +73,39 @@ struct Stage {
   }
   // 16-byte-vector operands only (the launcher checks vecA / vecB and K % VN == 0): unconditional loads from a clamped address, zeroed
   // by a select -- no scalar fallback, no branch per chunk (with 6 chunks per operand the general form above spilled 400 bytes / lane)
-  __device__ static __forceinline__ void load_vec(uint4 (&reg)[NCH], const T* g, long long sR, long long sK, int nr, int nk, int tid) {
+  // The zeroing of out-of-range chunks happens in commit_m, from the mask returned here (bit i = chunk i in range).  Written as
+  // `reg = in ? load : 0` the compiler sinks every load under its own exec-masked branch and rebuilds the value from phis: a
+  // `s_waitcnt vmcnt(0)` directly behind the 5th of 12 loads of each k-tile (gemm_deepk TT 64x64), i.e. one exposed memory latency
+  // per k-tile before the MFMAs start.
+  __device__ static __forceinline__ int load_vec(uint4 (&reg)[NCH], const T* g, long long sR, long long sK, int nr, int nk, int tid) {
+    int msk = 0;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int idx = tid + i * 256;
       const int a = idx / CPR, c = (idx % CPR) * VN;
       const int r = RC ? c : a, k = RC ? a : c;
       const bool in = RC ? (k < nk && r + VN <= nr) : (r < nr && k + VN <= nk);
-      const uint4 v = *reinterpret_cast<const uint4*>(g + (in ? (long long)r * sR + (long long)k * sK : 0));
-      reg[i] = in ? v : make_uint4(0, 0, 0, 0);
+      reg[i] = *reinterpret_cast<const uint4*>(g + (in ? (long long)r * sR + (long long)k * sK : 0));
+      msk |= in ? (1 << i) : 0;
+    }
+    return msk;
+  }
+  template <int LDX>
+  __device__ static __forceinline__ void commit_m(T* lds, const uint4 (&reg)[NCH], int msk, int tid) {
+    asm volatile("" : "+v"(msk));        // keeps the selects below (and with them the wait for the loads) at the commit
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + i * 256;
+      const int a = idx / CPR, c = (idx % CPR) * VN;
+      T* dst = lds + a * LDX + c;
+      const bool in = (msk >> i) & 1;
+      const uint4 v = make_uint4(in ? reg[i].x : 0u, in ? reg[i].y : 0u, in ? reg[i].z : 0u, in ? reg[i].w : 0u);
+      if constexpr (RC && sizeof(T) == 2) {                  // rows only 8-byte aligned (LDT = ROWS + 4)
+        uint2* d = reinterpret_cast<uint2*>(dst);
+        d[0] = make_uint2(v.x, v.y); d[1] = make_uint2(v.z, v.w);
+      } else {
+        *reinterpret_cast<uint4*>(dst) = v;
+      }
     }
   }
   template <int LDX>
@@ -174,11 +198,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bxi, cons
   typedef Stage<T, BN, BK, TB> SB;
   uint4 ra[SA::NCH], rb[SB::NCH];
   const long long a_sR = TA ? 1 : p.sAm, b_sR = TB ? 1 : p.sBn;
+  int ma = 0, mb = 0;
   auto issue = [&](int kt) {
     const int seg = kt / ktiles_seg, k1 = (kt - seg * ktiles_seg) * BK;
     if constexpr (BKB != 128) {
-      SA::load_vec(ra, A + seg * p.sAkb + (long long)k1 * p.sAk, a_sR, p.sAk, p.M - m0, p.K - k1, tid);
-      SB::load_vec(rb, B + seg * p.sBkb + (long long)k1 * p.sBk, b_sR, p.sBk, p.N - n0, p.K - k1, tid);
+      ma = SA::load_vec(ra, A + seg * p.sAkb + (long long)k1 * p.sAk, a_sR, p.sAk, p.M - m0, p.K - k1, tid);
+      mb = SB::load_vec(rb, B + seg * p.sBkb + (long long)k1 * p.sBk, b_sR, p.sBk, p.N - n0, p.K - k1, tid);
     } else {
       SA::load(ra, A + seg * p.sAkb + (long long)k1 * p.sAk, a_sR, p.sAk, p.M - m0, p.K - k1, p.vecA, tid);
       SB::load(rb, B + seg * p.sBkb + (long long)k1 * p.sBk, b_sR, p.sBk, p.N - n0, p.K - k1, p.vecB, tid);
@@ -186,10 +211,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bxi, cons
   };
   if (kt0 < kt1) issue(kt0);
   for (int kt = kt0; kt < kt1; ++kt) {
-    SA::template commit<TA ? LDTA : LD>(As, ra, tid);
-    SB::template commit<TB ? LDTB : LD>(Bs, rb, tid);
+    if constexpr (BKB != 128) {
+      SA::template commit_m<TA ? LDTA : LD>(As, ra, ma, tid);
+      SB::template commit_m<TB ? LDTB : LD>(Bs, rb, mb, tid);
+    } else {
+      SA::template commit<TA ? LDTA : LD>(As, ra, tid);
+      SB::template commit<TB ? LDTB : LD>(Bs, rb, tid);
+    }
     __syncthreads();
-    if (kt + 1 < kt1) issue(kt + 1);    // next tile's global loads overlap this tile's MFMAs
+    // next tile's global loads overlap this tile's MFMAs (deep k-tiles: unconditionally -- the last tile is fetched once more and
+    // dropped -- so that the loads are straight-line code)
+    if constexpr (BKB != 128) issue(kt + 1 < kt1 ? kt + 1 : kt);
+    else if (kt + 1 < kt1) issue(kt + 1);
     if (do_cs && tid < BN) {           // fused bias gradient: column sums of the B (= dY) tile over this block's k range
       float s = 0.f;
       if constexpr (TB) { for (int k = 0; k < BK; ++k) s += ldf(Bs + k * LDTB + tid); }
