@@ -7,10 +7,16 @@ copy kernel) is printed first so the correction can be checked in the same pass.
 import collections, csv, json, re, sys
 
 # kernels that serve exactly one (layer, shape) of the bench step -> the key bench.py files that launch under (roofline.traffic)
-BENCH_KEY = {'upconv_dgrad_ws2_kernel<true>': 'upconv_dgrad[128x128,96->48,F64]',
+BENCH_KEY = {'upconv_dgrad_ws2_kernel<true, true>': 'upconv_dgrad[128x128,96->48,F64]',
+             'upconv_dgrad_ws2_kernel<true>': 'upconv_dgrad[128x128,96->48,F64]',
+             'upconv_fwd_ws2_kernel<bf16, 3, 3, true>': 'upconv_fwd[128x128,96->48,F64]',
              'upconv_fwd_ws2_kernel<bf16, 3, 3>': 'upconv_fwd[128x128,96->48,F64]',
+             'upconv_wgrad_tr4_kernel<3, 6, 32, 128>': 'upconv_wgrad[128x128,96->48,F64]',
              'upconv_wgrad_tr_kernel<3, 6, 32>': 'upconv_wgrad[128x128,96->48,F64]',
+             'upconv_wgrad_tr4_kernel<4, 4, 32, 128>': 'upconv_wgrad[64x64,128->96,F64]',
+             'outconv_bwd_mfma2_kernel<48>': 'outconv_bwd[256x256,48->2,F64]',
              'outconv_bwd_mfma_kernel<48>': 'outconv_bwd[256x256,48->2,F64]',
+             'outconv_pair_fwd_kernel<bf16, 48>': 'outconv_pair_fwd[256x256,48->2,F64x2]',
              'outconv_fwd_mfma_kernel<bf16, 48>': 'outconv_fwd[256x256,48->2,F64]',
              'upconv_fwd_ws_kernel<bf16, 4, 2, 2>': 'upconv_fwd[64x64,128->96,F64]',
              'upconv_dgrad_ws_kernel<3, 4, false, 96>': 'upconv_dgrad[64x64,128->96,F64]'}
