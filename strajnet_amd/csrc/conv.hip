@@ -282,6 +282,146 @@ __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T*
 }
 
 // ---------------------------------------------------------------------------------------------------
+// dgrad of the wide layers (192 <- 128, 384 <- 192; 16-bit, whole tiles), pipelined.  The kernel above stages one quarter of the tap
+// matrices at a time, synchronously: 16 dependent global -> LDS -> barrier -> 32 MFMA rounds per tile, each exposing a full memory
+// latency (PMC: 153 us per launch, MFMA busy 12 %, 72 % of the wave cycles waiting).  Here a K-chunk (32 couts) of the dP halo AND of
+// all 16 tap matrices (16 x 64 x 32) is resident at once (131 KB LDS, one persistent workgroup per CU): one barrier pair per 128 MFMAs
+// per wave, and the next chunk -- of this tile or of the workgroup's next tile -- is in flight in 26 registers per lane meanwhile.
+// All loads, LDS writes and stores are unconditional (clamped halo addresses, zeroed at the commit through a pinned mask: conv_ws.hip
+// has the story), so the commit's wait counts only what it needs.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int FN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void upconv_dgrad_pf_kernel(const T* __restrict__ dP, const T* __restrict__ Wd, T* __restrict__ dX,
+                                                                 const T* __restrict__ Xelu, int F, int Hi, int Wi, int Cin, int Cout, int ntiles) {
+  static_assert(sizeof(T) == 2, "16-bit operands");
+  constexpr int BN = FN * 16, LDK = KC + 8, CPR = KC / 8;
+  constexpr int HH = 2 * TILE_H + 2, HW = 2 * TILE_W + 2, HPIX = HH * HW;
+  constexpr int NH = (HPIX * CPR + 255) / 256, NB = 16 * BN * CPR / 256;
+  static_assert(16 * BN * CPR % 256 == 0, "tap matrices split evenly over the threads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char pf_smem[];
+  T* halo = reinterpret_cast<T*>(pf_smem);             // [HPIX][LDK]
+  T* Bs = halo + HPIX * LDK;                           // [16 taps][BN][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n0 = blockIdx.y * BN, mf0 = 2 * w;
+  const int tiles_x = Wi / TILE_W, tiles_y = Hi / TILE_H;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  // chunk geometry: with CPR = 4 a thread's chunks are pixel (tid >> 2) + 64 i, channels 8 (tid & 3) .. of the halo, and cin row
+  // (tid >> 2) of tap j of the tap matrices: everything but the halo pixel's (row, column) is a compile-time stride from one base
+  static_assert(CPR == 4 && BN == 64, "chunk geometry below");
+  const int p0 = tid >> 2, ch0 = (tid & 3) * 8;
+  const bool dup_last = tid >= HPIX * CPR - (NH - 1) * 256;       // surplus chunk of the last round: the previous chunk again
+  const int bg0 = (n0 + p0) * Cout + ch0, bl0 = p0 * LDK + ch0, hl0 = p0 * LDK + ch0;
+  uint4 hb[NH], bb[NB];
+  int hmsk = 0;
+  auto fetch = [&](int tile, int c0) {
+    const int tx = tile % tiles_x, t2 = tile / tiles_x;
+    const int ty0 = (t2 % tiles_y) * TILE_H, f = t2 / tiles_y, tx0 = tx * TILE_W;
+    const T* Pf = dP + (long long)f * Ho * Wo * Cout + c0 + ch0;
+    int m = 0;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int px = p0 + 64 * ((i == NH - 1 && dup_last) ? i - 1 : i);
+      const int gy = 2 * ty0 + px / HW - 1, gx = 2 * tx0 + px % HW - 1;
+      const int cy = min(max(gy, 0), Ho - 1), cx = min(max(gx, 0), Wo - 1);
+      m |= (cy == gy && cx == gx) ? (1 << i) : 0;
+      hb[i] = *reinterpret_cast<const uint4*>(Pf + (cy * Wo + cx) * Cout);
+    }
+    hmsk = m;
+    const T* Wc = Wd + bg0 + c0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const uint4 t = *reinterpret_cast<const uint4*>(Wc + (long long)j * Cin * Cout);
+      bb[j] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+  };
+  auto commit = [&]() {
+    int m = hmsk;
+    asm volatile("" : "+v"(m));                        // the zeroing (and the wait for the loads) stays below the barrier
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const bool in = (m >> i) & 1;
+      const int o = hl0 + 64 * LDK * ((i == NH - 1 && dup_last) ? i - 1 : i);
+      *reinterpret_cast<uint4*>(halo + o) = make_uint4(in ? hb[i].x : 0u, in ? hb[i].y : 0u, in ? hb[i].z : 0u, in ? hb[i].w : 0u);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(Bs + bl0 + j * BN * LDK) = make_uint4(bb[j].x, bb[j].y, bb[j].z, bb[j].w);
+  };
+  const int last_tile = ntiles - 1;
+  int tile = blockIdx.x;
+  fetch(tile, 0);
+  for (; tile < ntiles; tile += gridDim.x) {
+    f32x4 acc[2][FN];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < FN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < Cout; c0 += KC) {
+      __syncthreads();                                 // the previous chunk's fragment reads are finished
+      commit();
+      __syncthreads();
+      const bool more = c0 + KC < Cout;
+      const int nt = more ? tile : min(tile + (int)gridDim.x, last_tile);
+      fetch(nt, more ? c0 + KC : 0);                   // in flight during the 128 MFMAs below (after the last tile: fetched, never used)
+#pragma unroll
+      for (int ui = 0; ui < 4; ++ui)
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi) {
+          typename Mma<T>::Frag af[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) af[m] = Mma<T>::load(halo + ((2 * (mf0 + m) + ui) * HW + vi) * LDK, 2 * LDK, 0, 0, lane);
+#pragma unroll
+          for (int n = 0; n < FN; ++n) {
+            const typename Mma<T>::Frag bf = Mma<T>::load(Bs + ((ui * 4 + vi) * BN + n * 16) * LDK, LDK, 0, 0, lane);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m][n] = Mma<T>::mma(bf, af[m], acc[m][n]);   // D[m = cin][n = pixel]
+          }
+        }
+    }
+    // lane = 4 consecutive cins (n0 + 16 n + 4 (lane >> 4) ..) of pixel (row mf0 + m, column lane & 15)
+    const int tx = tile % tiles_x, t2 = tile / tiles_x;
+    const int ty0 = (t2 % tiles_y) * TILE_H, f = t2 / tiles_y, tx0 = tx * TILE_W;
+    const long long fo = (long long)f * Hi * Wi * Cin;
+    const int g4 = (lane >> 4) * 4, px = tx0 + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int py = ty0 + mf0 + m;
+#pragma unroll
+      for (int n = 0; n < FN; ++n) {
+        const long long o = fo + ((long long)py * Wi + px) * Cin + n0 + n * 16 + g4;
+        float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+        if (Xelu) {                                    // uniform
+          float xv[4];
+          ld4(Xelu + o, xv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= xv[e] > 0.f ? 1.f : xv[e] + 1.f;
+        }
+        st4(dX + o, v);
+      }
+    }
+  }
+}
+template <typename T>
+static bool upconv_dgrad_pf_try(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("STJ_NO_DGRAD_PF"); on = !(e && atoi(e)); }
+  if (!on || Hi % TILE_H || Wi % TILE_W || Cin % 64 || Cout % KC || Cin <= 128) return false;
+  constexpr int FN = 4, BN = FN * 16, LDK = KC + 8;
+  const size_t lds = (size_t)((2 * TILE_H + 2) * (2 * TILE_W + 2) * LDK + 16 * BN * LDK) * sizeof(T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)upconv_dgrad_pf_kernel<T, FN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    attr_set = true;
+  }
+  const int ntiles = (Wi / TILE_W) * (Hi / TILE_H) * F, ct = Cin / BN;
+  int nblk = 256 / ct;
+  if (nblk > ntiles) nblk = ntiles;
+  if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL((upconv_dgrad_pf_kernel<T, FN>), dim3(nblk, ct), dim3(256), lds, st, (const T*)dP, (const T*)Wd, (T*)dX, (const T*)Xelu, F, Hi, Wi,
+                     Cin, Cout, ntiles);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // wgrad: block = (pixel strip, phase, cout-tile x cin-tile); wave = tap (r,s); K = pixels in chunks of one
 // low-res row segment of 32 columns.
 // ---------------------------------------------------------------------------------------------------
@@ -467,6 +607,8 @@ extern "C" int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, const 
   if (e) return e;
   if (dtype == STJ_BF16 && ws_enabled() && upconv_dgrad_ws_try(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream))
     return stj_check_launch("stj_upconv_dgrad(ws)");
+  if (dtype == STJ_BF16 && upconv_dgrad_pf_try<bf16>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream)) return stj_check_launch("stj_upconv_dgrad(pf)");
+  if (dtype == STJ_F16 && upconv_dgrad_pf_try<f16>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream)) return stj_check_launch("stj_upconv_dgrad(pf)");
   if (dtype == STJ_F16) return upconv_dgrad_launch<f16>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream);
   return dtype == STJ_BF16 ? upconv_dgrad_launch<bf16>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream)
                            : upconv_dgrad_launch<float>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, stream);

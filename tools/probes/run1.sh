@@ -1,5 +1,3 @@
-for i in 1 2; do
-for v in base xpad16 xpad24; do
-  if [ $v = base ]; then L=$PWD/strajnet_amd/libstrajnet_hip.so; else L=$PWD/strajnet_amd/variants/lib_$v.so; fi
-  for l in 2 3; do echo -n "$v layer$l "; STJ_LIB_PATH=$L python tools/bench_conv.py --layer $l --only wgrad --iters 20 2>/dev/null | tail -1; done
-done; done
+run() { python bench.py --no-cpu-baseline --no-kernel-timing $* 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
+for i in 1 2 3; do echo -n "new "; run; echo -n "no-pf "; STJ_NO_DGRAD_PF=1 run; done
+timeout 1200 python -m pytest tests/test_model_gpu.py tests/test_timed_kernels_gpu.py -x -q 2>&1 | tail -2
