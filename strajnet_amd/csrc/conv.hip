@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T*
 // matrices at a time, synchronously: 16 dependent global -> LDS -> barrier -> 32 MFMA rounds per tile, each exposing a full memory
 // latency (PMC: 153 us per launch, MFMA busy 12 %, 72 % of the wave cycles waiting).  Here a K-chunk (32 couts) of the dP halo AND of
 // all 16 tap matrices (16 x 64 x 32) is resident at once (131 KB LDS, one persistent workgroup per CU): one barrier pair per 128 MFMAs
-// per wave, and the next chunk -- of this tile or of the workgroup's next tile -- is in flight in 26 registers per lane meanwhile.
+// per wave, and the next halo chunk (of the next tile of a group of four that share the weight chunk) and the next weight chunk are in
+// flight in 26 registers per lane meanwhile.
 // All loads, LDS writes and stores are unconditional (clamped halo addresses, zeroed at the commit through a pinned mask: conv_ws.hip
 // has the story), so the commit's wait counts only what it needs.
 // ---------------------------------------------------------------------------------------------------
@@ -327,11 +328,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       hb[i] = *reinterpret_cast<const uint4*>(Pf + (cy * Wo + cx) * Cout);
     }
     hmsk = m;
+  };
+  auto fetch_w = [&](int c0) {
     const T* Wc = Wd + bg0 + c0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const uint4 t = *reinterpret_cast<const uint4*>(Wc + (long long)j * Cin * Cout);
-      bb[j] = make_uint4(t.x, t.y, t.z, t.w);
+      bb[j] = make_uint4(t.x, t.y, t.z, t.w);        // (component-wise: a whole-struct copy of the array element leaves bb[] in scratch)
     }
   };
   auto commit = [&]() {
@@ -343,59 +346,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int o = hl0 + 64 * LDK * ((i == NH - 1 && dup_last) ? i - 1 : i);
       *reinterpret_cast<uint4*>(halo + o) = make_uint4(in ? hb[i].x : 0u, in ? hb[i].y : 0u, in ? hb[i].z : 0u, in ? hb[i].w : 0u);
     }
+  };
+  auto commit_w = [&]() {
 #pragma unroll
     for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(Bs + bl0 + j * BN * LDK) = make_uint4(bb[j].x, bb[j].y, bb[j].z, bb[j].w);
   };
+  // TG tiles of this workgroup share every weight chunk: with one tile per chunk the 65 KB of tap matrices were re-read from L2 for
+  // each of 4 x 512 x 3 (chunk, tile, cin tile) steps -- 0.64 GB per launch of the 192 <- 128 layer at the L2 -> L1 ceiling (~6.5 TB/s)
+  // that the 64 x 64 GEMM tiles hit as well.  The TG accumulator sets live in AGPRs (one wave per SIMD: 512 registers).
+  constexpr int TG = 4;                                // measured 76 / 107 us; TG = 2: 82 / 112; TG = 1: 91 / 109
   const int last_tile = ntiles - 1;
-  int tile = blockIdx.x;
-  fetch(tile, 0);
-  for (; tile < ntiles; tile += gridDim.x) {
-    f32x4 acc[2][FN];
+  const int nchunk = Cout / KC;
+  auto tile_of = [&](int k) { return min((int)blockIdx.x + k * (int)gridDim.x, last_tile); };
+  const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  fetch(tile_of(0), 0);
+  fetch_w(0);
+  for (int k0 = 0; k0 < my_tiles; k0 += TG) {
+    f32x4 acc[TG][2][FN];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int t = 0; t < TG; ++t)
 #pragma unroll
-      for (int n = 0; n < FN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < Cout; c0 += KC) {
-      __syncthreads();                                 // the previous chunk's fragment reads are finished
-      commit();
-      __syncthreads();
-      const bool more = c0 + KC < Cout;
-      const int nt = more ? tile : min(tile + (int)gridDim.x, last_tile);
-      fetch(nt, more ? c0 + KC : 0);                   // in flight during the 128 MFMAs below (after the last tile: fetched, never used)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int ui = 0; ui < 4; ++ui)
+        for (int n = 0; n < FN; ++n) acc[t][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ci = 0; ci < nchunk; ++ci) {
+      const int c0 = ci * KC;
 #pragma unroll
-        for (int vi = 0; vi < 4; ++vi) {
-          typename Mma<T>::Frag af[2];
+      for (int t = 0; t < TG; ++t) {
+        __syncthreads();                               // the previous step's fragment reads are finished
+        commit();
+        if (t == 0) commit_w();
+        __syncthreads();
+        // next step: the next tile of the group at this chunk, or the group's first tile at the next chunk, or the next group
+        const bool last_t = t == TG - 1;
+        const bool more = ci + 1 < nchunk;
+        const int nk = !last_t ? k0 + t + 1 : (more ? k0 : k0 + TG);
+        const int nc = !last_t ? c0 : (more ? c0 + KC : 0);
+        fetch(tile_of(nk), nc);                        // in flight during the 128 MFMAs below (past the end: fetched, never used)
+        if (t == 0) fetch_w(more ? c0 + KC : 0);       // the NEXT chunk's tap matrices: four steps to arrive
+        // one wave per SIMD: nothing else hides the LDS latency, so the fragments of tap q + 1 are read before the MFMAs of tap q
+        // are issued (left to the compiler the reads came two MFMAs ahead, with an lgkmcnt wait in front of every second MFMA)
+        typedef typename Mma<T>::Frag Frag;
+        Frag af[2][2], bf[2][FN];
+        auto load_tap = [&](int q, Frag (&a)[2], Frag (&b)[FN]) {
+          const int ui = q >> 2, vi = q & 3;
 #pragma unroll
-          for (int m = 0; m < 2; ++m) af[m] = Mma<T>::load(halo + ((2 * (mf0 + m) + ui) * HW + vi) * LDK, 2 * LDK, 0, 0, lane);
+          for (int m = 0; m < 2; ++m) a[m] = Mma<T>::load(halo + ((2 * (mf0 + m) + ui) * HW + vi) * LDK, 2 * LDK, 0, 0, lane);
 #pragma unroll
-          for (int n = 0; n < FN; ++n) {
-            const typename Mma<T>::Frag bf = Mma<T>::load(Bs + ((ui * 4 + vi) * BN + n * 16) * LDK, LDK, 0, 0, lane);
+          for (int n = 0; n < FN; ++n) b[n] = Mma<T>::load(Bs + (q * BN + n * 16) * LDK, LDK, 0, 0, lane);
+        };
+        load_tap(0, af[0], bf[0]);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) acc[m][n] = Mma<T>::mma(bf, af[m], acc[m][n]);   // D[m = cin][n = pixel]
-          }
+        for (int q = 0; q < 16; ++q) {
+          if (q + 1 < 16) load_tap(q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);           // (the machine scheduler sinks the reads back to their uses otherwise)
+#pragma unroll
+          for (int n = 0; n < FN; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[t][m][n] = Mma<T>::mma(bf[q & 1][n], af[q & 1][m], acc[t][m][n]);   // D[m = cin][n = pixel]
         }
+      }
     }
     // lane = 4 consecutive cins (n0 + 16 n + 4 (lane >> 4) ..) of pixel (row mf0 + m, column lane & 15)
-    const int tx = tile % tiles_x, t2 = tile / tiles_x;
-    const int ty0 = (t2 % tiles_y) * TILE_H, f = t2 / tiles_y, tx0 = tx * TILE_W;
-    const long long fo = (long long)f * Hi * Wi * Cin;
-    const int g4 = (lane >> 4) * 4, px = tx0 + (lane & 15);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int py = ty0 + mf0 + m;
+    for (int t = 0; t < TG; ++t) {
+      if (k0 + t >= my_tiles) break;                   // uniform: the group's tail
+      const int tile = blockIdx.x + (k0 + t) * gridDim.x;
+      const int tx = tile % tiles_x, t2 = tile / tiles_x;
+      const int ty0 = (t2 % tiles_y) * TILE_H, f = t2 / tiles_y, tx0 = tx * TILE_W;
+      const long long fo = (long long)f * Hi * Wi * Cin;
+      const int g4 = (lane >> 4) * 4, px = tx0 + (lane & 15);
 #pragma unroll
-      for (int n = 0; n < FN; ++n) {
-        const long long o = fo + ((long long)py * Wi + px) * Cin + n0 + n * 16 + g4;
-        float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-        if (Xelu) {                                    // uniform
-          float xv[4];
-          ld4(Xelu + o, xv);
+      for (int m = 0; m < 2; ++m) {
+        const int py = ty0 + mf0 + m;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= xv[e] > 0.f ? 1.f : xv[e] + 1.f;
+        for (int n = 0; n < FN; ++n) {
+          const long long o = fo + ((long long)py * Wi + px) * Cin + n0 + n * 16 + g4;
+          float v[4] = {acc[t][m][n][0], acc[t][m][n][1], acc[t][m][n][2], acc[t][m][n][3]};
+          if (Xelu) {                                  // uniform
+            float xv[4];
+            ld4(Xelu + o, xv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= xv[e] > 0.f ? 1.f : xv[e] + 1.f;
+          }
+          st4(dX + o, v);
         }
-        st4(dX + o, v);
       }
     }
   }
