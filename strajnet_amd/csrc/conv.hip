@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const T* dP, const T*
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int FN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void upconv_dgrad_pf_kernel(const T* __restrict__ dP, const T* __restrict__ Wd, T* __restrict__ dX,
-                                                                 const T* __restrict__ Xelu, int F, int Hi, int Wi, int Cin, int Cout, int ntiles) {
+                                                                 const T* __restrict__ Xelu, int F, int Hi, int Wi, int Cin, int Cout, int ntiles, int nseq) {
   static_assert(sizeof(T) == 2, "16-bit operands");
   constexpr int BN = FN * 16, LDK = KC + 8, CPR = KC / 8;
   constexpr int HH = 2 * TILE_H + 2, HW = 2 * TILE_W + 2, HPIX = HH * HW;
@@ -303,7 +303,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   T* halo = reinterpret_cast<T*>(pf_smem);             // [HPIX][LDK]
   T* Bs = halo + HPIX * LDK;                           // [16 taps][BN][LDK]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int n0 = blockIdx.y * BN, mf0 = 2 * w;
+  // Work map: workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2.  The ct cin tiles of one tile
+  // sequence read the same dP halo, so they get adjacent slots of the SAME XCD (bxs = this workgroup's tile sequence, nseq of them)
+  const int ct = Cin / BN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bxs = (slot / ct) * 8 + xcd, byc = slot % ct;
+  if (bxs >= nseq) return;
+  const int n0 = byc * BN, mf0 = 2 * w;
   const int tiles_x = Wi / TILE_W, tiles_y = Hi / TILE_H;
   const int Ho = 2 * Hi, Wo = 2 * Wi;
   // chunk geometry: with CPR = 4 a thread's chunks are pixel (tid >> 2) + 64 i, channels 8 (tid & 3) .. of the halo, and cin row
@@ -357,8 +363,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int TG = 4;                                // measured 76 / 107 us; TG = 2: 82 / 112; TG = 1: 91 / 109
   const int last_tile = ntiles - 1;
   const int nchunk = Cout / KC;
-  auto tile_of = [&](int k) { return min((int)blockIdx.x + k * (int)gridDim.x, last_tile); };
-  const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  auto tile_of = [&](int k) { return min(bxs + k * nseq, last_tile); };
+  const int my_tiles = (bxs < ntiles) ? (ntiles - 1 - bxs) / nseq + 1 : 0;
   fetch(tile_of(0), 0);
   fetch_w(0);
   for (int k0 = 0; k0 < my_tiles; k0 += TG) {
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
       if (k0 + t >= my_tiles) break;                   // uniform: the group's tail
-      const int tile = blockIdx.x + (k0 + t) * gridDim.x;
+      const int tile = bxs + (k0 + t) * nseq;
       const int tx = tile % tiles_x, t2 = tile / tiles_x;
       const int ty0 = (t2 % tiles_y) * TILE_H, f = t2 / tiles_y, tx0 = tx * TILE_W;
       const long long fo = (long long)f * Hi * Wi * Cin;
@@ -448,11 +454,18 @@ static bool upconv_dgrad_pf_try(const void* dP, const void* Wd, void* dX, const 
     attr_set = true;
   }
   const int ntiles = (Wi / TILE_W) * (Hi / TILE_H) * F, ct = Cin / BN;
-  int nblk = 256 / ct;
+  // tile sequences: a multiple of 8 (whole XCD rounds of the work map) with all their workgroups resident at once (one per CU, 32 CUs
+  // per XCD -- with 85 sequences x 3 cin tiles five XCDs got 33 workgroups and the kernel took two rounds)
+  int nblk = 256 / ct / 8 * 8;
+  if (nblk < 8) nblk = 8;
   if (nblk > ntiles) nblk = ntiles;
-  if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL((upconv_dgrad_pf_kernel<T, FN>), dim3(nblk, ct), dim3(256), lds, st, (const T*)dP, (const T*)Wd, (T*)dX, (const T*)Xelu, F, Hi, Wi,
-                     Cin, Cout, ntiles);
+  // ... and no more of them than the step count needs: a sequence runs ceil(tiles / 4) groups of four tile slots, so 64 sequences of
+  // 8 tiles take as long as 80 of 6-7 and leave a quarter of the L2 / LDS traffic's contenders out (96 -> 93 us, 70 -> 68 us)
+  auto slots = [&](int n) { return ((ntiles + n - 1) / n + 3) / 4 * 4; };
+  while (nblk > 8 && slots(nblk - 8) == slots(nblk)) nblk -= 8;
+  const int nseq8 = (nblk + 7) / 8 * 8;                // (ntiles < 8: padded, the surplus workgroups exit at once)
+  hipLaunchKernelGGL((upconv_dgrad_pf_kernel<T, FN>), dim3(nseq8 * ct), dim3(256), lds, st, (const T*)dP, (const T*)Wd, (T*)dX, (const T*)Xelu, F, Hi, Wi,
+                     Cin, Cout, ntiles, nblk);
   return true;
 }
 
