@@ -231,6 +231,20 @@ int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, 
 int stj_decode_raw(const void* src, int kind, float* dst, long long n_outer, int H, int W, int C, int y0, int x0, int Ho,
                    int Wo, float scale, hipStream_t stream);
 
+/* trajNet input plumbing (trajNet.py:125-140), one launch: obs [B,n_obs,Tn,8] and occ [B,n_occ,Tn,8] (f32, 16-byte aligned) ->
+ * x5 [B*A*Tn,5] node features, v3 [B*A,3] vector features of step 0, vt [B*A,Tn] int32 step-valid (feature 0 != 0), cmi [B*A] int32 /
+ * cmf [B*A] (type T) agent-valid (any step valid); A = n_obs + n_occ, obs rows first. */
+int stj_agent_prep(const float* obs, const float* occ, int n_obs, int n_occ, int B, int Tn, void* x5, void* v3, int* vt, int* cmi,
+                   void* cmf, int dtype, hipStream_t stream);
+/* trajNet branch sums (trajNet.py:166-171), enc / value / concat / qin / out [B,A,C], embed [A,C], cm [B,A], all type T:
+ * mix: concat = enc * cm, qin = concat + embed;  bwd: denc = (dconcat + dqin) * cm, dembed = sum_b dqin (either gradient may be NULL).
+ * sum: out = enc + value + embed;                bwd: dembed = sum_b dout (the gradients of enc and value are dout itself). */
+int stj_agent_mix_fwd(const void* enc, const void* embed, const void* cm, void* concat, void* qin, int B, int A, int C, int dtype,
+                      hipStream_t stream);
+int stj_agent_mix_bwd(const void* dconcat, const void* dqin, const void* cm, void* denc, void* dembed, int B, int A, int C, int dtype,
+                      hipStream_t stream);
+int stj_agent_sum_fwd(const void* enc, const void* value, const void* embed, void* out, int B, int A, int C, int dtype, hipStream_t stream);
+int stj_agent_sum_bwd(const void* dout, void* dembed, int B, int A, int C, int dtype, hipStream_t stream);
 /* Time-kernel collapse of the decoder's Conv3D(8,1,1) SAME skips (modules.py:693-698,709-716,750-765): the
  * input is the same frame at all 8 steps, so step t needs W_t = sum_{j=max(0,3-t)}^{min(7,10-t)} W[j].  W f32 [8][n] (n = Cin*Cout),
  * Wz T [8][n].  fold (backward): dW[j] += sum over the t whose window contains j of dWz[t]. */

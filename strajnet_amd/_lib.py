@@ -22,6 +22,11 @@ SIGNATURES = {
     'stj_cast': [vp, ci, vp, ci, cl, vp],
     'stj_crc32c': [vp, cl, vp],
     'stj_time_collapse': [vp, vp, cl, ci, vp],
+    'stj_agent_prep': [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp],
+    'stj_agent_mix_fwd': [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    'stj_agent_mix_bwd': [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    'stj_agent_sum_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    'stj_agent_sum_bwd': [vp, vp, ci, ci, ci, ci, vp],
     'stj_time_fold': [vp, vp, cl, vp],
     'stj_decode_raw': [vp, ci, vp, cl, ci, ci, ci, ci, ci, ci, ci, cf, vp],
     'stj_metrics': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],

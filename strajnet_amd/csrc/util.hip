@@ -283,6 +283,131 @@ __global__ __launch_bounds__(256) void time_fold_kernel(const float* __restrict_
     }
   }
 }
+// ---- trajNet input plumbing and branch sums (trajNet.py:125-187) -------------------------------------------------------------
+// One launch instead of cat / != 0 / any / three casts / two strided copies: tr = [obs | occ] [B,A,Tn,8] f32 ->
+//   x5 [B*A*Tn,5] (node features), v3 [B*A,3] (vector features of step 0), vt [B*A,Tn] (step valid: tr[...,0] != 0), cmi / cmf [B*A]
+//   (agent valid: any step valid) as int32 and in the activation dtype.
+template <typename T>
+__global__ __launch_bounds__(256) void agent_prep_kernel(const float* __restrict__ obs, const float* __restrict__ occ, int n_obs, int n_occ, int B,
+                                                         int Tn, T* __restrict__ x5, T* __restrict__ v3, int* __restrict__ vt,
+                                                         int* __restrict__ cmi, T* __restrict__ cmf) {
+  const int A = n_obs + n_occ;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * A; i += gridDim.x * 256) {
+    const int b = i / A, a = i % A;
+    const float* src = a < n_obs ? obs + ((long long)b * n_obs + a) * Tn * 8 : occ + ((long long)b * n_occ + (a - n_obs)) * Tn * 8;
+    int any = 0;
+    for (int t = 0; t < Tn; ++t) {
+      const float4 lo = *reinterpret_cast<const float4*>(src + t * 8), hi = *reinterpret_cast<const float4*>(src + t * 8 + 4);
+      T* o = x5 + ((long long)i * Tn + t) * 5;
+      stf(o, lo.x); stf(o + 1, lo.y); stf(o + 2, lo.z); stf(o + 3, lo.w); stf(o + 4, hi.x);
+      const int v = lo.x != 0.f;
+      vt[(long long)i * Tn + t] = v;
+      any |= v;
+      if (t == 0) { stf(v3 + i * 3, hi.y); stf(v3 + i * 3 + 1, hi.z); stf(v3 + i * 3 + 2, hi.w); }
+    }
+    cmi[i] = any;
+    stf(cmf + i, any ? 1.f : 0.f);
+  }
+}
+// concat = enc * cm ; qin = concat + embed   (trajNet.py:166-170; enc [B,A,C], embed [A,C] broadcast over B, cm [B,A])
+template <typename T>
+__global__ __launch_bounds__(256) void agent_mix_fwd_kernel(const T* __restrict__ enc, const T* __restrict__ embed, const T* __restrict__ cm,
+                                                            T* __restrict__ concat, T* __restrict__ qin, int B, int A, int C) {
+  const long long n = (long long)B * A * C;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+    const int c = (int)(i % C); const long long ba = i / C; const int a = (int)(ba % A);
+    T t;
+    stf(&t, ldf(enc + i) * ldf(cm + ba));
+    concat[i] = t;
+    stf(qin + i, ldf(&t) + ldf(embed + (long long)a * C + c));       // the sum of the ROUNDED product, like the two separate ops
+  }
+}
+// d_enc = (dconcat + dqin) * cm ; d_embed[a,c] = sum_b dqin[b,a,c]   (thread = (a,c), loop over b: no atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void agent_mix_bwd_kernel(const T* __restrict__ dconcat, const T* __restrict__ dqin, const T* __restrict__ cm,
+                                                            T* __restrict__ denc, T* __restrict__ dembed, int B, int A, int C) {
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < A * C; j += gridDim.x * 256) {
+    const int a = j / C;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const long long i = (long long)b * A * C + j;
+      const float dq = dqin ? ldf(dqin + i) : 0.f;
+      s += dq;
+      stf(denc + i, ((dconcat ? ldf(dconcat + i) : 0.f) + dq) * ldf(cm + (long long)b * A + a));
+    }
+    if (dembed) stf(dembed + j, s);
+  }
+}
+// out = enc + value + embed (trajNet.py:171); bwd: d_embed[a,c] = sum_b dout[b,a,c] (d_enc = d_value = dout)
+template <typename T>
+__global__ __launch_bounds__(256) void agent_sum_fwd_kernel(const T* __restrict__ enc, const T* __restrict__ value, const T* __restrict__ embed,
+                                                            T* __restrict__ out, int B, int A, int C) {
+  const long long n = (long long)B * A * C;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+    T t;
+    stf(&t, ldf(enc + i) + ldf(value + i));                            // (enc + value) rounded, then + embed: the order of the two adds
+    stf(out + i, ldf(&t) + ldf(embed + i % ((long long)A * C)));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void agent_sum_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dembed, int B, int A, int C) {
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < A * C; j += gridDim.x * 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += ldf(dout + (long long)b * A * C + j);
+    stf(dembed + j, s);
+  }
+}
+extern "C" int stj_agent_prep(const float* obs, const float* occ, int n_obs, int n_occ, int B, int Tn, void* x5, void* v3, int* vt, int* cmi,
+                              void* cmf, int dtype, hipStream_t stream) {
+  const int rows = B * (n_obs + n_occ);
+  if (rows <= 0) return STJ_OK;
+  if (((uintptr_t)obs | (uintptr_t)occ) & 15) { stj_set_error("stj_agent_prep: obs / occ must be 16-byte aligned"); return STJ_EINVAL; }
+  const int g = (rows + 255) / 256;
+#define TT_ARGS(TT) obs, occ, n_obs, n_occ, B, Tn, (TT*)x5, (TT*)v3, vt, cmi, (TT*)cmf
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(agent_prep_kernel<bf16>, dim3(g), dim3(256), 0, stream, TT_ARGS(bf16));
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(agent_prep_kernel<f16>, dim3(g), dim3(256), 0, stream, TT_ARGS(f16));
+  else if (dtype == STJ_F32) hipLaunchKernelGGL(agent_prep_kernel<float>, dim3(g), dim3(256), 0, stream, TT_ARGS(float));
+  else { stj_set_error("stj_agent_prep: bad dtype %d", dtype); return STJ_EINVAL; }
+#undef TT_ARGS
+  return stj_check_launch("stj_agent_prep");
+}
+#define AGENT_EW(NAME, KERN, G, ARGS_BF, ARGS_H, ARGS_F)                                                             \
+  if (dtype == STJ_BF16) hipLaunchKernelGGL(KERN<bf16>, dim3(G), dim3(256), 0, stream, ARGS_BF);                     \
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(KERN<f16>, dim3(G), dim3(256), 0, stream, ARGS_H);                   \
+  else if (dtype == STJ_F32) hipLaunchKernelGGL(KERN<float>, dim3(G), dim3(256), 0, stream, ARGS_F);                 \
+  else { stj_set_error(NAME ": bad dtype %d", dtype); return STJ_EINVAL; }                                           \
+  return stj_check_launch(NAME)
+extern "C" int stj_agent_mix_fwd(const void* enc, const void* embed, const void* cm, void* concat, void* qin, int B, int A, int C, int dtype,
+                                 hipStream_t stream) {
+  if ((long long)B * A * C <= 0) return STJ_OK;
+  const int g = ew_grid((long long)B * A * C);
+#define A_(TT) (const TT*)enc, (const TT*)embed, (const TT*)cm, (TT*)concat, (TT*)qin, B, A, C
+  AGENT_EW("stj_agent_mix_fwd", agent_mix_fwd_kernel, g, A_(bf16), A_(f16), A_(float));
+#undef A_
+}
+extern "C" int stj_agent_mix_bwd(const void* dconcat, const void* dqin, const void* cm, void* denc, void* dembed, int B, int A, int C, int dtype,
+                                 hipStream_t stream) {
+  if ((long long)B * A * C <= 0) return STJ_OK;
+  const int g = (A * C + 255) / 256;
+#define A_(TT) (const TT*)dconcat, (const TT*)dqin, (const TT*)cm, (TT*)denc, (TT*)dembed, B, A, C
+  AGENT_EW("stj_agent_mix_bwd", agent_mix_bwd_kernel, g, A_(bf16), A_(f16), A_(float));
+#undef A_
+}
+extern "C" int stj_agent_sum_fwd(const void* enc, const void* value, const void* embed, void* out, int B, int A, int C, int dtype, hipStream_t stream) {
+  if ((long long)B * A * C <= 0) return STJ_OK;
+  const int g = ew_grid((long long)B * A * C);
+#define A_(TT) (const TT*)enc, (const TT*)value, (const TT*)embed, (TT*)out, B, A, C
+  AGENT_EW("stj_agent_sum_fwd", agent_sum_fwd_kernel, g, A_(bf16), A_(f16), A_(float));
+#undef A_
+}
+extern "C" int stj_agent_sum_bwd(const void* dout, void* dembed, int B, int A, int C, int dtype, hipStream_t stream) {
+  if ((long long)B * A * C <= 0) return STJ_OK;
+  const int g = (A * C + 255) / 256;
+#define A_(TT) (const TT*)dout, (TT*)dembed, B, A, C
+  AGENT_EW("stj_agent_sum_bwd", agent_sum_bwd_kernel, g, A_(bf16), A_(f16), A_(float));
+#undef A_
+}
+
 extern "C" int stj_time_collapse(const float* W, void* Wz, long long n, int dtype, hipStream_t stream) {
   if (n <= 0) return STJ_OK;
   const int g = ew_grid(n);

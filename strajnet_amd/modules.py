@@ -558,20 +558,16 @@ class STrajNet:
     def _traj_net(self, obs, occ):
         """TrajNet.call (trajNet.py:125-187) with the 64-way TrajEncoder loop batched.  -> key [B,64,384], mask [B,64]."""
         pre = 'traj_net/traj_encoder'
-        tr = torch.cat([obs, occ], 1).to(torch.float32)                    # [B,64,11,8]
-        B, A, T, _ = tr.shape
-        n_obs = obs.shape[1]
-        valid_t = (tr[..., 0] != 0)                                        # [B,64,11]   (trajNet.py:127,131)
-        vt = valid_t.to(torch.int32).contiguous().view(B * A, T)
-        cm = valid_t.any(-1)                                               # [B,64]      (trajNet.py:138)
-        cmi = cm.to(torch.int32).contiguous()
-        trc = tr.to(self.dtype)
-        nodes = ops.linear(trc[..., :5].contiguous(), self._p(pre + '/node_feature/kernel'),
-                           self._p(pre + '/node_feature/bias'), act=ACT_ELU)               # Conv1D(64,1)+ELU
+        B, n_obs, T = obs.shape[0], obs.shape[1], obs.shape[2]
+        A = n_obs + occ.shape[1]
+        # tr = cat(obs, occ) [B,64,11,8]; step valid = tr[...,0] != 0 (trajNet.py:127,131); agent valid = any step (trajNet.py:138):
+        # one launch writes the two feature slices in the activation dtype and the masks
+        x5, v3, vt, cmi, cmf = ops.agent_prep(obs, occ, self.dtype)
+        nodes = ops.linear(x5, self._p(pre + '/node_feature/kernel'), self._p(pre + '/node_feature/bias'), act=ACT_ELU)   # Conv1D(64,1)+ELU
         nodes = nodes.view(B * A, T, 64)
         nodes = self._tfa_mha(pre + '/node_attention', nodes, nodes, 4, vt, vt)           # [B*A,T,320]
         nodes = ops.maxpool_time(nodes).view(B, A, 320)
-        vec = ops.linear(trc[:, :, 0, 5:].contiguous(), self._p(pre + '/vector_feature/kernel'))
+        vec = ops.linear(v3.view(B, A, 3), self._p(pre + '/vector_feature/kernel'))
         enc = ops.linear(torch.cat([nodes, vec], -1), self._p(pre + '/sublayer/kernel'), self._p(pre + '/sublayer/bias'), act=ACT_ELU)
         onehot = self._seg_onehot.get((A, n_obs))
         if onehot is None:
@@ -579,10 +575,10 @@ class STrajNet:
             onehot[:n_obs, 0] = 1
             onehot[n_obs:, 1] = 1
             self._seg_onehot[(A, n_obs)] = onehot
-        embed = ops.linear(onehot, self._p('traj_net/seg_embed/kernel'))[None]            # [1,64,384]
-        concat = enc * cm[..., None].to(enc.dtype)
-        value = self._cross_attention('traj_net/cross_attention', concat + embed, concat, 6, cmi, cmi)
-        out = enc + value + embed
+        embed = ops.linear(onehot, self._p('traj_net/seg_embed/kernel'))                  # [64,384]
+        concat, q_in = ops.agent_mix(enc, embed, cmf)                                     # enc * mask ; + embed
+        value = self._cross_attention('traj_net/cross_attention', q_in, concat, 6, cmi, cmi)
+        out = ops.agent_sum(enc, value, embed)
         o1 = self._ln(out[:, :n_obs].contiguous(), 'traj_net/obs_norm', 1e-3)
         o2 = self._ln(out[:, n_obs:].contiguous(), 'traj_net/occ_norm', 1e-3)
         return torch.cat([o1, o2], 1), cmi

@@ -1056,6 +1056,82 @@ def fg_query(off, p2, pb2, qres=None):
 
 
 # ----------------------------------------------------------------------------------------------------
+# trajNet input plumbing and branch sums (one launch each instead of 3-8 torch dispatches on a chain of 5 us kernels)
+# ----------------------------------------------------------------------------------------------------
+def agent_prep(obs, occ, dtype):
+    """obs [B,n_obs,T,8], occ [B,n_occ,T,8] -> x5 [B*A*T,5], v3 [B*A,3], vt [B*A,T] int32, cmi [B,A] int32, cmf [B,A] (no gradients)."""
+    _req_cuda(obs, occ)
+    obs, occ = obs.float().contiguous(), occ.float().contiguous()
+    B, n_obs, Tn, _ = obs.shape
+    n_occ = occ.shape[1]
+    A = n_obs + n_occ
+    dev = obs.device
+    x5 = torch.empty((B * A * Tn, 5), dtype=dtype, device=dev)
+    v3 = torch.empty((B * A, 3), dtype=dtype, device=dev)
+    vt = torch.empty((B * A, Tn), dtype=torch.int32, device=dev)
+    cmi = torch.empty((B, A), dtype=torch.int32, device=dev)
+    cmf = torch.empty((B, A), dtype=dtype, device=dev)
+    call('stj_agent_prep', _p(obs), _p(occ), n_obs, n_occ, B, Tn, _p(x5), _p(v3), _p(vt), _p(cmi), _p(cmf), DTYPE_CODE[dtype], _st())
+    return x5, v3, vt, cmi, cmf
+
+
+class _AgentMix(torch.autograd.Function):
+    """concat = enc * cm ; qin = concat + embed  (trajNet.py:166-170)."""
+    @staticmethod
+    def forward(ctx, enc, embed, cm):
+        _req_cuda(enc)
+        enc, embed = enc.contiguous(), embed.contiguous()
+        B, A, C = enc.shape
+        concat, qin = torch.empty_like(enc), torch.empty_like(enc)
+        call('stj_agent_mix_fwd', _p(enc), _p(embed), _p(cm), _p(concat), _p(qin), B, A, C, _dt(enc), _st())
+        ctx.geo = (B, A, C, embed.shape)
+        ctx.save_for_backward(cm)
+        return concat, qin
+
+    @staticmethod
+    def backward(ctx, dconcat, dqin):
+        (cm,) = ctx.saved_tensors
+        B, A, C, eshape = ctx.geo
+        dconcat = dconcat.contiguous() if dconcat is not None else None
+        dqin = dqin.contiguous() if dqin is not None else None
+        denc = torch.empty((B, A, C), dtype=cm.dtype, device=cm.device)
+        dembed = torch.empty(eshape, dtype=cm.dtype, device=cm.device) if ctx.needs_input_grad[1] else None
+        call('stj_agent_mix_bwd', _p(dconcat), _p(dqin), _p(cm), _p(denc), _p(dembed), B, A, C, _dt(cm), _st())
+        return denc, dembed, None
+
+
+def agent_mix(enc, embed, cm):
+    return _AgentMix.apply(enc, embed, cm)
+
+
+class _AgentSum(torch.autograd.Function):
+    """out = enc + value + embed (trajNet.py:171)."""
+    @staticmethod
+    def forward(ctx, enc, value, embed):
+        _req_cuda(enc)
+        enc, value, embed = enc.contiguous(), value.contiguous(), embed.contiguous()
+        B, A, C = enc.shape
+        out = torch.empty_like(enc)
+        call('stj_agent_sum_fwd', _p(enc), _p(value), _p(embed), _p(out), B, A, C, _dt(enc), _st())
+        ctx.geo = (B, A, C, embed.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, A, C, eshape = ctx.geo
+        dout = dout.contiguous()
+        dembed = None
+        if ctx.needs_input_grad[2]:
+            dembed = torch.empty(eshape, dtype=dout.dtype, device=dout.device)
+            call('stj_agent_sum_bwd', _p(dout), _p(dembed), B, A, C, _dt(dout), _st())
+        return dout, dout, dembed
+
+
+def agent_sum(enc, value, embed):
+    return _AgentSum.apply(enc, value, embed)
+
+
+# ----------------------------------------------------------------------------------------------------
 # max over time (GlobalMaxPooling1D)
 # ----------------------------------------------------------------------------------------------------
 class _MaxPool(torch.autograd.Function):

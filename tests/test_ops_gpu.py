@@ -268,6 +268,40 @@ def test_fg_bias(dt):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
+def test_agent_branch_ops(dt):
+    """trajNet plumbing (stj_agent_prep) and branch sums (stj_agent_mix / _sum) against the torch expressions they replace."""
+    from strajnet_amd import ops
+    B, n_obs, n_occ, T, C = 3, 5, 3, 11, 64
+    A = n_obs + n_occ
+    g = torch.Generator().manual_seed(0)
+    obs, occ = torch.randn(B, n_obs, T, 8, generator=g), torch.randn(B, n_occ, T, 8, generator=g)
+    obs[0, 1] = 0.0                                   # an absent agent
+    occ[1, 2, 3:, 0] = 0.0                            # invalid steps
+    obs[2, :, :, 0] = 0.0                             # a scene without observed agents
+    x5, v3, vt, cmi, cmf = ops.agent_prep(obs.cuda(), occ.cuda(), dt)
+    tr = torch.cat([obs, occ], 1)
+    valid = tr[..., 0] != 0
+    assert torch.equal(vt.cpu(), valid.reshape(B * A, T).int())
+    assert torch.equal(cmi.cpu(), valid.any(-1).int())
+    assert torch.equal(cmf.float().cpu(), valid.any(-1).float())
+    assert torch.equal(x5.cpu(), tr[..., :5].to(dt).reshape(-1, 5))
+    assert torch.equal(v3.cpu(), tr[:, :, 0, 5:].to(dt).reshape(-1, 3))
+    enc, value = rnd((B, A, C), dt, 1).requires_grad_(True), rnd((B, A, C), dt, 2).requires_grad_(True)
+    embed = rnd((A, C), dt, 3).requires_grad_(True)
+    concat, qin = ops.agent_mix(enc, embed, cmf)
+    out = ops.agent_sum(enc, value, embed)
+    er, vr, mr, cr = ref_of(enc), ref_of(value), ref_of(embed), cmf.double().cpu()
+    cref = er * cr[..., None]
+    assert rel_err(concat, cref) < tol(dt) and rel_err(qin, cref + mr[None]) < tol(dt) and rel_err(out, er + vr + mr[None]) < tol(dt)
+    g1, g2, g3 = rnd((B, A, C), dt, 4), rnd((B, A, C), dt, 5), rnd((B, A, C), dt, 6)
+    torch.autograd.backward([concat, qin, out], [g1, g2, g3])
+    torch.autograd.backward([cref, cref + mr[None], er + vr + mr[None]], [g1.double().cpu(), g2.double().cpu(), g3.double().cpu()])
+    assert rel_err(enc.grad, er.grad) < tol(dt)
+    assert rel_err(value.grad, vr.grad) < tol(dt)
+    assert rel_err(embed.grad, mr.grad) < 2 * tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
 def test_mha_core_with_fg_bias_inside(dt):
     """mha_core(fg_off=, fg=) == mha_core(bias=fg_bias(off)): same kernels, the bias gradient just never leaves the op."""
     from strajnet_amd import ops
