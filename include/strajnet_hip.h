@@ -213,8 +213,8 @@ int stj_col2im3(const void* dcols, void* dx, int N, int H, int W, int G, int Cg,
 /* OGMFlow_loss (loss.py:50-170 with train.py:195-196 flags).  All tensors f32: logits [B,H,W,32] (channel 4k+{0,1,2,3},
  * train.py:105-123), gt_obs/gt_occ/origin [B,8,H,W,1], gt_flow [B,8,H,W,2].
  * auc_gate: res_k = [Keras PR-AUC(true_all, warp(origin, id+gt_flow)*true_all) > 0] (loss.py:127-137); hist int[8*202] scratch, zero on entry.
- * fwd: sums f32[32*40] scratch (32 copies of the 40 accumulators the workgroups spread their atomics over; zero on entry), loss f32[4] = observed_xe, occluded_xe, flow, flow_warp_xe; coef f32[32] for bwd.
- * bwd: dlogits = sum_j upstream[j] * dloss_j/dlogits.
+ * fwd: sums f32[32*40] scratch (32 copies of the 40 accumulators the workgroups spread their atomics over; zero on entry), loss f32[5] = observed_xe, occluded_xe, flow, flow_warp_xe, their sum (train.py:221); coef f32[32] for bwd.
+ * bwd: dlogits = sum_j upstream[j] * dloss_j/dlogits; with flag bit 3 (bwd only) upstream is ONE value for all four terms.
  * flags: bit 0 = flow-warp term on (not no_use_warp), bit 1 = use_focal_loss (tfa SigmoidFocalCrossEntropy added to the three
  * occupancy terms, loss.py:183-190,212-219,244-245), bit 2 = use_pred (loss.py:151-154,253-268); the same value goes to fwd and bwd. */
 int stj_loss_auc_gate(const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,

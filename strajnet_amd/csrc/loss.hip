@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* logits, cons
 
 struct LossCfg { float ogm_w, occ_w, fow, replica; int use_warp; };
 
-// loss[4] = observed_xe, occluded_xe, flow, flow_warp_xe ; coef [NWP][4] per-waypoint backward coefficients (before upstream grads)
+// loss[5] = observed_xe, occluded_xe, flow, flow_warp_xe, their sum ; coef [NWP][4] per-waypoint backward coefficients (before upstream grads)
 __global__ void loss_finalize_kernel(const float* sums_parts, const float* gate, float* loss, float* coef, float npix, LossCfg c) {
   __shared__ float sums[NWP * S_N];
   if (threadIdx.x < NWP * S_N) {
@@ -246,16 +246,18 @@ __global__ void loss_finalize_kernel(const float* sums_parts, const float* gate,
   loss[1] = sc / NWP;
   loss[2] = sf / fc;
   loss[3] = c.use_warp ? sw / fc : 0.f;
+  loss[4] = loss[0] + loss[1] + loss[2] + loss[3];      // the training objective (train.py:221), in the order a host-side sum adds them
 }
 
 // dlogits[B,H,W,32] = sum_j up[j] * d loss_j / d logits
 template <bool FOCAL, bool PRED>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* logits, const float* gt_obs, const float* gt_occ,
                                                        const float* gt_flow, const float* origin, const float* coef,
-                                                       const float* up, float* dlogits, int B, int H, int W, int use_warp) {
+                                                       const float* up, float* dlogits, int B, int H, int W, int use_warp, int up1) {
   // one thread per (pixel, waypoint), as in loss_fwd_kernel: one coalesced float4 in, one out
   const int k = threadIdx.x & 7;
-  const float c0 = coef[4 * k] * up[0], c1 = coef[4 * k + 1] * up[1], c2 = coef[4 * k + 2] * up[2], c3 = coef[4 * k + 3] * up[3];
+  // up1: ONE upstream gradient for all four terms (the step differentiates their sum)
+  const float c0 = coef[4 * k] * up[0], c1 = coef[4 * k + 1] * up[up1 ? 0 : 1], c2 = coef[4 * k + 2] * up[up1 ? 0 : 2], c3 = coef[4 * k + 3] * up[up1 ? 0 : 3];
   const long long nitem = (long long)B * H * W * NWP;
   const float inv_hw = 1.f / ((float)H * (float)W);
   for (long long it = blockIdx.x * 256ll + threadIdx.x; it < nitem; it += gridDim.x * 256ll) {
@@ -326,13 +328,13 @@ extern "C" int stj_loss_fwd(const float* logits, const float* gt_obs, const floa
 }
 extern "C" int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                             const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int flags, hipStream_t stream) {
-  if (flags & ~7) { stj_set_error("loss: unknown flag bits %d", flags); return STJ_EINVAL; }
+  if (flags & ~15) { stj_set_error("loss: unknown flag bits %d", flags); return STJ_EINVAL; }
   if ((((uintptr_t)logits) | ((uintptr_t)dlogits)) & 15) { stj_set_error("loss: logits / dlogits must be 16-byte aligned"); return STJ_EINVAL; }
   if (((uintptr_t)gt_flow) & 7) { stj_set_error("loss: gt_flow must be 8-byte aligned"); return STJ_EINVAL; }
   const long long npix = (long long)B * H * W;
   const int gx = (int)min(8192ll, (npix * NWP + 255) / 256);
   const int use_warp = flags & 1, focal = (flags >> 1) & 1, pred = (flags >> 2) & 1;
-#define LOSS_BWD(FO, PR) hipLaunchKernelGGL((loss_bwd_kernel<FO, PR>), dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, coef, upstream, dlogits, B, H, W, use_warp)
+#define LOSS_BWD(FO, PR) hipLaunchKernelGGL((loss_bwd_kernel<FO, PR>), dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, coef, upstream, dlogits, B, H, W, use_warp, (flags >> 3) & 1)
   if (focal && pred) LOSS_BWD(true, true); else if (focal) LOSS_BWD(true, false); else if (pred) LOSS_BWD(false, true); else LOSS_BWD(false, false);
 #undef LOSS_BWD
   return stj_check_launch("stj_loss_bwd");

@@ -1472,14 +1472,15 @@ class _OgmFlowLoss(torch.autograd.Function):
         B, H, W, _ = logits.shape
         dev = logits.device
         sums = zeros_f32(32 * 40, dev)       # 32 copies of the 40 accumulators (stj_loss_fwd)
-        loss = torch.empty(4, dtype=torch.float32, device=dev)
+        loss = torch.empty(5, dtype=torch.float32, device=dev)      # the four terms + their sum
         coef = torch.empty(32, dtype=torch.float32, device=dev)
         call('stj_loss_fwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(sums), _p(loss), _p(coef),
              B, H, W, float(ogm_w), float(occ_w), float(fow), float(replica), int(flags), _st())
         ctx.geo = (B, H, W, int(flags))
         ctx.save_for_backward(logits, gt_obs, gt_occ, gt_flow, origin, coef)
-        ctx.mark_non_differentiable(loss)
-        return tuple(loss.unbind(0)) + (loss.sum(), loss)
+        terms = loss[:4]
+        ctx.mark_non_differentiable(terms)
+        return tuple(terms.unbind(0)) + (loss[4], terms)
 
     @staticmethod
     def backward(ctx, g0, g1, g2, g3, gt, _gvec):
@@ -1487,7 +1488,8 @@ class _OgmFlowLoss(torch.autograd.Function):
         B, H, W, flags = ctx.geo
         parts = (g0, g1, g2, g3)
         if all(g is None for g in parts):
-            up = gt.float().expand(4).contiguous()
+            up = gt.float().contiguous()             # one value for the four terms (flag bit 3): no expand / copy launch
+            flags |= 8
         else:
             z = torch.zeros((), dtype=torch.float32, device=logits.device)
             up = torch.stack([(g.float() if g is not None else z) for g in parts])
