@@ -291,22 +291,24 @@ template <typename T>
 __global__ __launch_bounds__(256) void agent_prep_kernel(const float* __restrict__ obs, const float* __restrict__ occ, int n_obs, int n_occ, int B,
                                                          int Tn, T* __restrict__ x5, T* __restrict__ v3, int* __restrict__ vt,
                                                          int* __restrict__ cmi, T* __restrict__ cmf) {
+  // one thread per (agent, step) -- a thread per agent walking its steps was a chain of 11 dependent round trips, 30 us on the
+  // branch's critical path; the step-0 thread also scans the agent's 11 validity flags (independent loads)
   const int A = n_obs + n_occ;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * A; i += gridDim.x * 256) {
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < B * A * Tn; it += gridDim.x * 256) {
+    const int i = it / Tn, t = it % Tn;
     const int b = i / A, a = i % A;
     const float* src = a < n_obs ? obs + ((long long)b * n_obs + a) * Tn * 8 : occ + ((long long)b * n_occ + (a - n_obs)) * Tn * 8;
-    int any = 0;
-    for (int t = 0; t < Tn; ++t) {
-      const float4 lo = *reinterpret_cast<const float4*>(src + t * 8), hi = *reinterpret_cast<const float4*>(src + t * 8 + 4);
-      T* o = x5 + ((long long)i * Tn + t) * 5;
-      stf(o, lo.x); stf(o + 1, lo.y); stf(o + 2, lo.z); stf(o + 3, lo.w); stf(o + 4, hi.x);
-      const int v = lo.x != 0.f;
-      vt[(long long)i * Tn + t] = v;
-      any |= v;
-      if (t == 0) { stf(v3 + i * 3, hi.y); stf(v3 + i * 3 + 1, hi.z); stf(v3 + i * 3 + 2, hi.w); }
+    const float4 lo = *reinterpret_cast<const float4*>(src + t * 8), hi = *reinterpret_cast<const float4*>(src + t * 8 + 4);
+    T* o = x5 + (long long)it * 5;
+    stf(o, lo.x); stf(o + 1, lo.y); stf(o + 2, lo.z); stf(o + 3, lo.w); stf(o + 4, hi.x);
+    vt[it] = lo.x != 0.f;
+    if (t == 0) {
+      stf(v3 + i * 3, hi.y); stf(v3 + i * 3 + 1, hi.z); stf(v3 + i * 3 + 2, hi.w);
+      int any = 0;
+      for (int u = 0; u < Tn; ++u) any |= src[u * 8] != 0.f;
+      cmi[i] = any;
+      stf(cmf + i, any ? 1.f : 0.f);
     }
-    cmi[i] = any;
-    stf(cmf + i, any ? 1.f : 0.f);
   }
 }
 // concat = enc * cm ; qin = concat + embed   (trajNet.py:166-170; enc [B,A,C], embed [A,C] broadcast over B, cm [B,A])
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void agent_sum_bwd_kernel(const T* __restrict_
 }
 extern "C" int stj_agent_prep(const float* obs, const float* occ, int n_obs, int n_occ, int B, int Tn, void* x5, void* v3, int* vt, int* cmi,
                               void* cmf, int dtype, hipStream_t stream) {
-  const int rows = B * (n_obs + n_occ);
+  const int rows = B * (n_obs + n_occ) * Tn;
   if (rows <= 0) return STJ_OK;
   if (((uintptr_t)obs | (uintptr_t)occ) & 15) { stj_set_error("stj_agent_prep: obs / occ must be 16-byte aligned"); return STJ_EINVAL; }
   const int g = (rows + 255) / 256;

@@ -1,4 +1,2 @@
-run() { python bench.py --no-cpu-baseline --no-kernel-timing $* 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
-timeout 1500 python -m pytest tests -x -q -m gpu -k "loss or train or graph or step or parity" 2>&1 | tail -3
-for i in 1 2 3; do echo -n "new "; run; done
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -k "agent" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_model_gpu.py -x -q -k "edge or forward_parity" 2>&1 | tail -2
