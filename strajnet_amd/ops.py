@@ -1332,7 +1332,7 @@ class _UpConvAdd(torch.autograd.Function):
     modules.py:750-765.  The ELU output itself is never stored; backward recovers ELU' from y - r1 (stj_elu_res_bwd), which also adds
     the two incoming gradients when there are two outputs."""
     @staticmethod
-    def forward(ctx, x, r1, r2, w_master, b_master, pw, pb, prep):
+    def forward(ctx, x, r1, r2, w_master, b_master, pw, pb, prep, in_epilogue=True):
         _req_cuda(x, r1)
         x, r1 = x.contiguous(), r1.contiguous()
         F_, Hi, Wi, Cin = x.shape
@@ -1344,10 +1344,16 @@ class _UpConvAdd(torch.autograd.Function):
         if r2 is not None:
             r2 = r2.contiguous()
             y2 = torch.empty_like(y)
-        call('stj_upconv_fwd_res', _p(x), _p(wf), _p(pb.master), _p(y), _p(r1), _p(y2), _p(r2), F_, Hi, Wi, Cin, Cout, dt, _st())
+        if in_epilogue:
+            call('stj_upconv_fwd_res', _p(x), _p(wf), _p(pb.master), _p(y), _p(r1), _p(y2), _p(r2), F_, Hi, Wi, Cin, Cout, dt, _st())
+            ctx.save_for_backward(x, y, r1, wd)
+        else:       # the up-conv stores its ELU output (kept for ELU'), the sums are one pass of their own
+            ye = torch.empty_like(y)
+            call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(ye), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
+            call('stj_skip_add', _p(ye), _p(r1), _p(r2), _p(y), _p(y2), y.numel(), dt, _st())
+            ctx.save_for_backward(x, ye, None, wd)
         ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
         ctx.x_is_elu_out, ctx.two = False, r2 is not None
-        ctx.save_for_backward(x, y, r1, wd)
         return (y, y2) if r2 is not None else y
 
     @staticmethod
@@ -1365,10 +1371,10 @@ class _UpConvAdd(torch.autograd.Function):
         call('stj_elu_res_bwd', _p(dy), _p(dy2), _p(y), _p(r1), _p(dpre), _p(gsum), dy.numel(), dt, _st())
         dx = _upconv_backward_tail(ctx, x, dpre, wd, ctx.needs_input_grad[0])
         dr1 = gsum if gsum is not None else dy
-        return dx, dr1, (dy2 if ctx.two else None), None, None, None, None, None
+        return dx, dr1, (dy2 if ctx.two else None), None, None, None, None, None, None
 
 
-# 0: never; 1 (default): in inference only; 2: always.  Measured at B=8 bf16: the training step is 1.2 % SLOWER with the sums in the
+# 0: never; 1 (default): in inference only; 2: always; 3: like 1, and in training the sums as one separate pass (see upconv_add).  Measured at B=8 bf16: the training step is 1.2 % SLOWER with the sums in the
 # epilogue (901 vs 912 scenes/s: a workgroup owns 32 of the 128 couts, so the skip operands are read and the sums written in 64-byte
 # pieces, 138 vs 92 us for the 192 -> 128 layer, while the separate adds stream whole lines at 5 TB/s), the B=32 fp16 forward 1.4 % faster.
 FUSED_SKIP = int(os.environ.get('STJ_FUSED_SKIP', '1'))
@@ -1378,11 +1384,15 @@ def upconv_add(x, pw, pb, r1, r2=None, prep=None):
     """ELU(upconv(x)) + r1 -> y, and y + r2 -> y2 when r2 is given (returns y or (y, y2)).  Fused into the up-conv epilogue for the
     16-bit wide layers (Cin = 192, 384); otherwise the up-conv followed by elementwise adds."""
     Cin, Cout = pw.master.shape[2], pw.master.shape[3]
+    oshape = (x.shape[0], 2 * x.shape[1], 2 * x.shape[2], Cout)
     if (FUSED_SKIP == 2 or (FUSED_SKIP == 1 and not torch.is_grad_enabled())) and x.dtype != torch.float32 and Cin > 128 and Cin % 32 == 0 and Cout % 32 == 0 and os.environ.get('STJ_NO_PS') != '1' \
             and os.environ.get('STJ_NO_WS') != '1':
-        return _UpConvAdd.apply(x, r1.view(x.shape[0], 2 * x.shape[1], 2 * x.shape[2], Cout),
-                                None if r2 is None else r2.view(x.shape[0], 2 * x.shape[1], 2 * x.shape[2], Cout),
-                                pw.master, pb.master, pw, pb, prep)
+        return _UpConvAdd.apply(x, r1.view(oshape), None if r2 is None else r2.view(oshape), pw.master, pb.master, pw, pb, prep)
+    if FUSED_SKIP == 3 and torch.is_grad_enabled() and (oshape[1] * oshape[2] * Cout) % 8 == 0:
+        # the sums as ONE pass over the stored ELU output (stj_skip_add), and in the backward the sum of the two incoming gradients
+        # together with ELU' (stj_elu_res_bwd) -- instead of two adds, an autograd accumulation pass and the ELU' pass: 4 launches and
+        # 0.2 GB of traffic less per step, but measured 0.5 % SLOWER end to end (1036 vs 1043 scenes/s), so not the default
+        return _UpConvAdd.apply(x, r1.view(oshape), None if r2 is None else r2.view(oshape), pw.master, pb.master, pw, pb, prep, False)
     y = upconv(x, pw, pb, prep=prep)
     y = y + r1.view(y.shape)
     return y if r2 is None else (y, y + r2.view(y.shape))
