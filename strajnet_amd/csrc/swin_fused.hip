@@ -30,7 +30,7 @@
 #define STJ_MLP_PREFETCH 1      // next weight chunk's global loads issued before the current chunk's MFMAs
 #endif
 #ifndef STJ_ATTNB_HG96
-#define STJ_ATTNB_HG96 3       // heads per pass of the attention backward kernel (16-bit types)
+#define STJ_ATTNB_HG96 1       // heads per pass of the attention backward kernel (16-bit types); 1: 1068 vs 1059 scenes/s for 3 (59 instead of 121 KB LDS per window)
 #endif
 #ifndef STJ_ATTNB_HG192
 #define STJ_ATTNB_HG192 2
@@ -42,7 +42,7 @@
 #define STJ_ATTN_MINB 1
 #endif
 #ifndef STJ_ATTN_HG96
-#define STJ_ATTN_HG96 3         // heads per pass of the attention kernel at C = 96 (16-bit types)
+#define STJ_ATTN_HG96 1         // heads per pass of the attention kernel at C = 96 (16-bit types); 1: 1059 vs 1052 scenes/s for 3 (less LDS per window)
 #endif
 
 // ---- chained-operand fragments -------------------------------------------------------------------------------
