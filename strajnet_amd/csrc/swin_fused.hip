@@ -29,6 +29,15 @@
 #ifndef STJ_MLP_PREFETCH
 #define STJ_MLP_PREFETCH 1      // next weight chunk's global loads issued before the current chunk's MFMAs
 #endif
+#ifndef STJ_ATTN_HG192
+#define STJ_ATTN_HG192 2
+#endif
+#ifndef STJ_MLP_HC96
+#define STJ_MLP_HC96 96         // (96: 1076 vs 1070 scenes/s for 192) hidden columns per staged weight chunk of the MLP kernels (16-bit types), C = 96 / C = 192
+#endif
+#ifndef STJ_MLP_HC192
+#define STJ_MLP_HC192 96
+#endif
 #ifndef STJ_ATTNB_HG96
 #define STJ_ATTNB_HG96 1       // heads per pass of the attention backward kernel (16-bit types); 1: 1068 vs 1059 scenes/s for 3 (59 instead of 121 KB LDS per window)
 #endif
@@ -114,7 +123,7 @@ template <typename T, int C, int RF_ = ((C <= 192) ? 2 : 1)> struct MlpCfg {
   static constexpr int RF = RF_;                      // 16-row fragments per wave
   static constexpr int ROWS = 4 * RF * 16;            // rows per block
   // hidden columns per staged chunk: as many as keep the two images under ~78 KB (two blocks per CU)
-  static constexpr int HC = sizeof(T) == 2 ? (C == 96 ? 192 : (C == 192 ? 96 : 32)) : (C == 96 ? 96 : (C == 192 ? 48 : 16));
+  static constexpr int HC = sizeof(T) == 2 ? (C == 96 ? STJ_MLP_HC96 : (C == 192 ? STJ_MLP_HC192 : 32)) : (C == 96 ? 96 : (C == 192 ? 48 : 16));
   static constexpr int P1 = 4;                        // W1 image [C][HC + P1]: rows 8-byte aligned (tr reads, 8-byte chain reads)
   static constexpr int P2 = sizeof(T) == 2 ? 8 : 4;   // W2 image [HC][C + P2]: rows 16-byte aligned (16-byte fragment reads in backward)
   static constexpr int LD1 = HC + P1, LD2 = C + P2;
@@ -603,7 +612,7 @@ extern "C" int stj_swin_mlp_bwd(const void* x, const void* dy, const float* gamm
 template <typename T, int C> struct AttnCfg {
   static constexpr int KSTEP = Mma<T>::KSTEP;
   static constexpr int KS = C / KSTEP, NF = C / 16, HEADS = C / 32;
-  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? STJ_ATTN_HG96 : (C == 192 ? 2 : 1)) : 1;     // heads per pass
+  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? STJ_ATTN_HG96 : (C == 192 ? STJ_ATTN_HG192 : 1)) : 1;     // heads per pass
   static constexpr int GC = 32 * HG;                                   // q (= k = v) columns per pass
   static constexpr int LDT = 3 * GC + (sizeof(T) == 2 ? 16 : 8);       // token-major q|k|v tile [64][LDT]
   static constexpr int LDW = 3 * GC + 4;                               // Wqkv slice image [C][LDW] ([k = c][q seg | k seg | v seg])
