@@ -26,7 +26,7 @@ GROUP_GEMMS = os.environ.get('STJ_GEMM_GROUP', '1') != '0'
 # Layers with at least this many rows launch their input and weight gradient separately: each then runs with 192-element k-tiles
 # (gemm_deepk_kernel: a third of the barrier-bound links), which the grouped kernel does not have.  Measured, scenes/s: no grouping
 # 943, limit 1024 rows 939, limit 16384 rows (every small layer grouped) 927.
-_GROUP_MAX_ROWS = int(os.environ.get('STJ_GEMM_GROUP_ROWS', '1024'))
+_GROUP_MAX_ROWS = int(os.environ.get('STJ_GEMM_GROUP_ROWS', '8192'))      # re-measured at the end of round 2: 1024 -> 1071, 4096 -> 1082, 8192 -> 1088, 16384 -> 1078, 65536 -> 1064 scenes/s
 _GROUP_DEPTH = [0]
 
 
