@@ -804,8 +804,12 @@ static bool wgrad_tr4_launch(const void* X, const void* dP, float* dWeff, float*
   }
   const long long nchunks = (long long)F * (Hi / CR) * (Wi / CW);
   static int nb = -1;
-  if (nb < 0) { const char* e = getenv("STJ_WGRAD_V4_BLOCKS"); nb = e ? atoi(e) : 256; }
-  int strips = (int)min(nchunks, (long long)max(1, nb / (2 * tiles)));   // x 2 row parities x tiles workgroups: one per CU
+  // Workgroups: HALF the CUs.  Alone the kernel is faster with one workgroup per CU (246 vs 344 us for the 96 -> 48 layer), but the
+  // decoder's weight gradients are deferred (ops.py) and run next to the backward of the cross-attentions / FG-MSA / the encoder, chains
+  // of short launches that then find the other half of the CUs free: 1085 -> 1130 scenes/s (256 -> 128 workgroups; 192: 1116, 96: 1121,
+  // 64: 1131, 32: 842)
+  if (nb < 0) { const char* e = getenv("STJ_WGRAD_V4_BLOCKS"); nb = e ? atoi(e) : 128; }
+  int strips = (int)min(nchunks, (long long)max(1, nb / (2 * tiles)));   // x 2 row parities x tiles workgroups
   const int cpb = (int)((nchunks + strips - 1) / strips);
   strips = (int)((nchunks + cpb - 1) / cpb);
   hipLaunchKernelGGL((upconv_wgrad_tr4_kernel<FO, FI, CW, NPIX>), dim3((strips + 7) / 8 * 8 * 2 * tiles), dim3(512), lds, st, (const bf16*)X, (const bf16*)dP,
@@ -836,7 +840,9 @@ static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* 
     hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6, CW>), dim3((strips + 7) / 8 * 8 * 4), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, cpb, strips, 1);
   } else {
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    int strips = (int)min(nchunks, (long long)max(1, 1024 / (4 * tiles)));
+    static int tgt = -1;
+    if (tgt < 0) { const char* e = getenv("STJ_WGRAD_TR_BLOCKS"); tgt = e ? atoi(e) : 1024; }
+    int strips = (int)min(nchunks, (long long)max(1, tgt / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
     hipLaunchKernelGGL((upconv_wgrad_tr_kernel<4, 4, CW>), dim3((strips + 7) / 8 * 8 * 4 * tiles), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, cpb, strips, tiles);
