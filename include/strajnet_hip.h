@@ -187,6 +187,11 @@ int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, const void* Xelu,
                      int dtype, hipStream_t stream);
 int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin,
                      int Cout, int dtype, hipStream_t stream);
+/* Workgroup budget of the large (>= 2048 pixel chunks) weight-gradient launches.  0 = default = 128: half the CUs, because in a step
+ * whose branches run on concurrent streams these launches are deferred next to chains of short kernels, which then find the other half
+ * free (alone the kernel is 1.5x faster on 256).  A host that runs every kernel alone (serial / per-kernel timing mode) sets 256.
+ * Process-wide, not thread-safe. */
+int stj_upconv_wgrad_share(int workgroups);
 /* wgrad: dbias (optional) is f32 [db_parts][Cout], "+=": workgroup i adds its share of the bias gradient into copy i % db_parts
  * and the caller sums the copies (db_parts = 1: plain [Cout]). */
 /* Output heads: Conv2D 3x3 SAME C->2, no activation (modules.py:767-770), written with strides straight into the

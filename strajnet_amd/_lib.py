@@ -61,6 +61,7 @@ SIGNATURES = {
     'stj_skip_add': [vp, vp, vp, vp, vp, cl, ci, vp],
     'stj_upconv_dgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_upconv_wgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
+    'stj_upconv_wgrad_share': [ci],
     'stj_outconv_pair_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
     'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp, cl, ci, vp],

@@ -792,6 +792,14 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_tr4_kernel(const bf16* __
     }
 }
 
+// Workgroup budget of the two large weight-gradient launches: 128 (half the CUs) for a step whose branches run concurrently, 256 when
+// every kernel runs alone (serial mode: the host says so through stj_upconv_wgrad_share).
+static int g_wgrad_share = 0;
+extern "C" int stj_upconv_wgrad_share(int workgroups) {
+  if (workgroups < 0 || workgroups > 4096) { stj_set_error("stj_upconv_wgrad_share: %d out of range", workgroups); return STJ_EINVAL; }
+  g_wgrad_share = workgroups;
+  return STJ_OK;
+}
 template <int FO, int FI, int CW, int NPIX>
 static bool wgrad_tr4_launch(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout,
                              int tiles, hipStream_t st) {
@@ -808,8 +816,9 @@ static bool wgrad_tr4_launch(const void* X, const void* dP, float* dWeff, float*
   // decoder's weight gradients are deferred (ops.py) and run next to the backward of the cross-attentions / FG-MSA / the encoder, chains
   // of short launches that then find the other half of the CUs free: 1085 -> 1130 scenes/s (256 -> 128 workgroups; 192: 1116, 96: 1121,
   // 64: 1131, 32: 842)
-  if (nb < 0) { const char* e = getenv("STJ_WGRAD_V4_BLOCKS"); nb = e ? atoi(e) : 128; }
-  int strips = (int)min(nchunks, (long long)max(1, nb / (2 * tiles)));   // x 2 row parities x tiles workgroups
+  if (nb < 0) { const char* e = getenv("STJ_WGRAD_V4_BLOCKS"); nb = e ? atoi(e) : 0; }
+  const int budget = nb > 0 ? nb : (g_wgrad_share > 0 ? g_wgrad_share : 128);
+  int strips = (int)min(nchunks, (long long)max(1, budget / (2 * tiles)));   // x 2 row parities x tiles workgroups
   const int cpb = (int)((nchunks + strips - 1) / strips);
   strips = (int)((nchunks + cpb - 1) / cpb);
   hipLaunchKernelGGL((upconv_wgrad_tr4_kernel<FO, FI, CW, NPIX>), dim3((strips + 7) / 8 * 8 * 2 * tiles), dim3(512), lds, st, (const bf16*)X, (const bf16*)dP,

@@ -176,6 +176,9 @@ _SERIAL = False
 def set_serial(flag):
     """True: weight-gradient launches stay on the current stream (per-kernel timing with HIP events needs kernels to run alone)."""
     global _SERIAL
+    if bool(flag) != _SERIAL:
+        # alone on the GPU the large weight-gradient launches take all CUs; in the concurrent step half of them (see the header)
+        call('stj_upconv_wgrad_share', 256 if flag else 0)
     _SERIAL = bool(flag)
 
 
