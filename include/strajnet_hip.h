@@ -139,6 +139,38 @@ int stj_swin_attn_bwd(const void* x, const void* dy, const void* qkv, const floa
                       int B, int res, int C, int shift, const long long* rng_state, int site, float p_drop, int dtype,
                       hipStream_t stream);
 
+/* Fused Cross_AttentionT block: the 8 time-separated cross-attentions of TrajNetCrossAttention (trajNet.py:189-234 Cross_AttentionT --
+ * tfa MultiHeadAttention(head 42 x 3, out 128, dropout .1), LayerNorm(1e-3), Dense(512, elu), Dropout, Dense(384), Dropout,
+ * LayerNorm(1e-3) -- and :305-317, the loop over the waypoints with `+ query`) as ONE kernel per direction (csrc/xattn_fused.hip):
+ * one workgroup per 64 tokens of a (set z, scene b), every intermediate chained in registers, weights streamed through LDS.
+ *   stj_xattn_pack: the set's weights (f32 masters wq [3,384,42], wo [3,42,128], w1 [128,512], w2 [512,384] of set 0; set z lies
+ *     zstride elements further) -> `pack`, Z streams of stj_xattn_pack_workspace_bytes(dtype) bytes in the activation dtype, laid out
+ *     as the LDS images the kernels stage (once per step: the weights change).
+ *   stj_xattn_fwd: y [Z,B,HW,384] = LN2(dropout(dropout(elu(LN1(MHA(query,k,v)) W1 + b1)) W2 + b2)) + query.  query [Z,B,HW,384];
+ *     k, v [Z,B,64,126] = key Wk[z], key Wv[z] (stj_gemm); kvalid int32 [B,64] or NULL; bo/g1/be1 [128], b1 [512], b2/g2/be2 [384]
+ *     f32 vectors of set 0.  rng_state != NULL: training, the three dropout sites draw with the layouts [Z,B,3,HW,64],
+ *     [Z,B*HW,512], [Z,B*HW,384] (as stj_dropout would).  sq, so [Z,B,HW,144], sv1 [.,128], su2 [.,384]: saves for backward
+ *     (all or none; NULL for inference).  HW % 64 == 0.
+ *   stj_xattn_bwd: reads dy, query, k, v, sq, sv1, su2 and the pack; writes dquery, dk, dv (via the f32 per-tile partials dkp / dvp,
+ *     stj_xattn_bwd_workspace_bytes(Z,B,HW) bytes each, reduced by a second launch) and the operands of the weight-gradient
+ *     stj_gemm launches the caller makes: hd, dpre [Z,B,HW,512], du2 [.,384], n1, dv1 [.,128], dq [.,144]
+ *     (dW2 = hd^T du2 + colsum, dW1 = n1^T dpre + colsum, dWo[h] = so_h^T dv1, dWq[h] = query^T dq_h);
+ *     "+=": dg1, dbe1, dbo [128], dg2, dbe2 [384] of set z at + z * zstride. */
+long long stj_xattn_pack_workspace_bytes(int dtype);
+int stj_xattn_pack(const float* wq, const float* wo, const float* w1, const float* w2, long long zstride, int Z, void* pack, int dtype,
+                   hipStream_t stream);
+int stj_xattn_fwd(const void* query, const void* k, const void* v, const int* kvalid, const void* pack, const float* bo,
+                  const float* g1, const float* be1, const float* b1, const float* b2, const float* g2, const float* be2,
+                  long long zstride, void* y, void* sq, void* so, void* sv1, void* su2, int Z, int B, int HW,
+                  const long long* rng_state, int site_a, int site_1, int site_2, float p_drop, int dtype, hipStream_t stream);
+long long stj_xattn_bwd_workspace_bytes(int Z, int B, int HW);
+int stj_xattn_bwd(const void* dy, const void* query, const void* k, const void* v, const int* kvalid, const void* pack,
+                  const float* g1, const float* be1, const float* b1, const float* g2, long long zstride, const void* sq,
+                  const void* sv1, const void* su2, void* dquery, void* dk, void* dv, float* dkp, float* dvp, void* hd,
+                  void* dpre, void* du2, void* n1, void* dv1, void* dq, float* dg1, float* dbe1, float* dbo, float* dg2,
+                  float* dbe2, int Z, int B, int HW, const long long* rng_state, int site_a, int site_1, int site_2,
+                  float p_drop, int dtype, hipStream_t stream);
+
 /* Row softmax of the global attentions: P = softmax(S + bias + (-10e9 where !(qvalid&kvalid))) (tfa MHA mask
  * semantics, f32 add); S f32 [batch,H,Nq,Nk] (Nk <= 256).  bwd: dS = P*(dP - sum(P dP)). */
 int stj_softmax_fwd(const float* S, void* P, const int* qvalid, const int* kvalid, const float* bias,

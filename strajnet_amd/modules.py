@@ -234,6 +234,10 @@ class STrajNet:
         self.fused_attn_dims = tuple(int(v) for v in os.environ.get('STJ_FUSED_ATTN_DIMS', '96,192').split(','))
         # (C = 384, the 16x16 stage: 2048 rows = 32 row blocks / 32 windows at B = 8 -- the fused kernels measured slower there)
         self.fused_mlp_dims = tuple(int(v) for v in os.environ.get('STJ_FUSED_MLP_DIMS', '96,192').split(','))
+        # the 8 time-separated cross-attentions as one kernel per direction (csrc/xattn_fused.hip); False = the layer-by-layer chain
+        # (the parity tests run both and compare)
+        self.fused_xattn = True
+        self._xattn_pack = None
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():
             k = int(np.prod(s))
@@ -274,6 +278,8 @@ class STrajNet:
         self.cut_encoder = False         # True: autograd is cut at the encoder outputs (backward() stops there; backward_encoder() finishes)
         self._cut_src = self._cut_leaf = None
         self._upconv_prep = {}
+        self._xattn_pack_stale = True
+        self._prep_event = None
         self._sync_compute_weights()
 
     # ------------------------------------------------------------------ weights
@@ -601,6 +607,17 @@ class STrajNet:
     def _zp(self, suffix):
         return self._p('cross_attn_obs0/' + suffix)
 
+    def _xattn_params(self):
+        z = self._zp
+        return {'wq': z('mha/query_kernel'), 'wo': z('mha/projection_kernel'), 'bo': z('mha/projection_bias'), 'g1': z('norm1/gamma'),
+                'be1': z('norm1/beta'), 'w1': z('FFN1/kernel'), 'b1': z('FFN1/bias'), 'w2': z('FFN2/kernel'), 'b2': z('FFN2/bias'),
+                'g2': z('norm2/gamma'), 'be2': z('norm2/beta')}
+
+    def _pack_xattn(self):
+        """The 8 sets' weights as the LDS-image stream the fused kernels stage (depends on the weights only: once per step)."""
+        self._xattn_pack = ops.xattn_pack(self._xattn_params(), self._zstride, 8, self.dtype, out=self._xattn_pack)
+        self._xattn_pack_stale = False
+
     def _cross_attention_z(self, query, key, tmask):
         """8 x Cross_AttentionT (trajNet.py:224-234) + query residual in one batched pass, waypoint-major:
         query [8,B,HW,Cb], key [B,64,Cb] -> [8,B,HW,Cb]."""
@@ -612,6 +629,17 @@ class STrajNet:
         def proj_in(x, suffix, shared):           # tfa kernels [3, 384, 42] of the 8 sets, addressed in place (set stride zs)
             p0 = self._zp(suffix)
             return ops.linear_heads_in_z(x, p0.master, p0.c, p0.grad, zs, 8, shared)
+        if self.fused_xattn and A == 64 and HW % 64 == 0 and Cb == 384:
+            # ONE kernel: q projection, masked softmax attention, out projection, LN, FFN, LN, + query (csrc/xattn_fused.hip);
+            # only the projections of the 64 agent keys / values stay GEMMs (one grouped launch)
+            with ops.gemm_group():
+                k = proj_in(key, 'mha/key_kernel', True)                         # [8, B*64, 126]
+                v = proj_in(key, 'mha/value_kernel', True)
+            ps = self._xattn_params()
+            if self._xattn_pack_stale:
+                self._pack_xattn()
+            return ops.xattn(query, k, v, tmask, self._xattn_pack, ps, zs, self._dctx,
+                             ('cross_attn_obs/mha/dropout', 'cross_attn_obs/dropout1', 'cross_attn_obs/dropout2'))
         with ops.gemm_group():
             q = proj_in(query, 'mha/query_kernel', False)                    # [8, B*HW, 126]
             k = proj_in(key, 'mha/key_kernel', True)                         # [8, B*64, 126]
@@ -718,13 +746,18 @@ class STrajNet:
         names = ('decoder/upconv_3_0', 'decoder/upconv_2_0', 'decoder/upconv_1_0', 'decoder/upconv_0_0', 'decoder/upconvf_1_0',
                  'decoder/upconvf_0_0')
         self._prep_event = None
+        self._xattn_pack_stale = True
         if self._side2 is not None:
             self._side2.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side2):
+                if self.fused_xattn:
+                    self._pack_xattn()
                 self._upconv_prep = {n: ops.upconv_prep(self._p(n + '/kernel'), self.dtype) for n in names}
                 self._prep_event = torch.cuda.Event()
                 self._prep_event.record(self._side2)
         else:
+            if self.fused_xattn:
+                self._pack_xattn()
             self._upconv_prep = {n: ops.upconv_prep(self._p(n + '/kernel'), self.dtype) for n in names}
         # The agent branch (trajNet: a dependent chain of ~45 small launches that occupy a few CUs each, ~0.4 ms end to end) is
         # independent of the raster encoder up to the cross-attention: it runs on a side stream, forked HERE.  Its launches are ISSUED
@@ -781,6 +814,8 @@ class STrajNet:
             tmask.record_stream(main)
         self._tap('agent_key', key)
         self._tap('query', query)
+        if self._prep_event is not None:                 # the packed cross-attention weights come from the side stream
+            torch.cuda.current_stream(self.device).wait_event(self._prep_event)
         x = self._cross_attention_z(query, key, tmask)               # [8,B,hb*hb,Cb]  (trajNet.py:305-317)
         self._tap('cross_attention_out', x)
         x = ops.wgrad_flush_point(x)             # the decoder's weight gradients are launched when ITS backward is through (ops.py)

@@ -907,6 +907,122 @@ def mha_core(q, k, v, H, d, scale, qvalid=None, kvalid=None, bias=None, drop=Non
 
 
 # ----------------------------------------------------------------------------------------------------
+# fused Cross_AttentionT block x Z weight sets (csrc/xattn_fused.hip): one kernel per direction
+# ----------------------------------------------------------------------------------------------------
+def xattn_pack(ps, zstride, Z, dtype, out=None):
+    """The Z weight sets' packed LDS-image stream (stj_xattn_pack) in `dtype`; ps = set-0 Params (see xattn).  Once per step."""
+    from ._lib import lib
+    dev = ps['wq'].master.device
+    nbytes = int(lib().stj_xattn_pack_workspace_bytes(DTYPE_CODE[dtype]))
+    if out is None:
+        out = torch.empty(Z * nbytes, dtype=torch.uint8, device=dev)
+    call('stj_xattn_pack', _p(ps['wq'].master), _p(ps['wo'].master), _p(ps['w1'].master), _p(ps['w2'].master), zstride, Z, _p(out),
+         DTYPE_CODE[dtype], _st())
+    return out
+
+
+class _XAttn(torch.autograd.Function):
+    """y = LN2(FFN(LN1(MHA(query, k, v)))) + query for Z weight sets (trajNet.py:224-234,305-317).  query [Z,B,HW,384]; k, v [Z,B*64,126]
+    (projected keys / values: their projections stay autograd nodes of their own); ps: Params of set 0 (set z lies zstride elements
+    further in the flat buffers).  Backward = ONE kernel + the dk / dv tile reduction + one grouped launch of the four weight-gradient
+    GEMMs, on operands the backward kernel writes once."""
+    @staticmethod
+    def forward(ctx, query, k, v, trig, kvalid, pack, ps, zstride, drop):
+        _req_cuda(query, k, v)
+        query, k, v = query.contiguous(), k.contiguous(), v.contiguous()
+        Z, B, HW, Cb = query.shape
+        dt = _dt(query)
+        y = torch.empty_like(query)
+        train = any(ctx.needs_input_grad[:4])
+        sq = so = sv1 = su2 = None
+        if train:
+            sq = torch.empty((Z, B, HW, 144), dtype=query.dtype, device=query.device)
+            so = torch.empty_like(sq)
+            sv1 = torch.empty((Z, B, HW, 128), dtype=query.dtype, device=query.device)
+            su2 = torch.empty_like(query)
+        p_drop, state, sites = drop if drop is not None else (0.0, None, (0, 0, 0))
+        call('stj_xattn_fwd', _p(query), _p(k), _p(v), _p(kvalid), _p(pack), _p(ps['bo'].master), _p(ps['g1'].master), _p(ps['be1'].master),
+             _p(ps['b1'].master), _p(ps['b2'].master), _p(ps['g2'].master), _p(ps['be2'].master), zstride, _p(y), _p(sq), _p(so), _p(sv1),
+             _p(su2), Z, B, HW, _p(state), sites[0], sites[1], sites[2], float(p_drop), dt, _st())
+        ctx.ps, ctx.zstride, ctx.drop, ctx.pack = ps, zstride, drop, pack
+        ctx.save_for_backward(query, k, v, kvalid, sq, so, sv1, su2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ._lib import lib
+        query, k, v, kvalid, sq, so, sv1, su2 = ctx.saved_tensors
+        ps, zs, drop = ctx.ps, ctx.zstride, ctx.drop
+        Z, B, HW, Cb = query.shape
+        R = B * HW
+        dt = _dt(query)
+        dev, ty = query.device, query.dtype
+        dy = dy.contiguous()
+        dquery = torch.empty_like(query)
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        wsn = int(lib().stj_xattn_bwd_workspace_bytes(Z, B, HW)) // 4
+        dkp = torch.empty(wsn, dtype=torch.float32, device=dev)
+        dvp = torch.empty(wsn, dtype=torch.float32, device=dev)
+        hd = torch.empty((Z, R, 512), dtype=ty, device=dev)
+        dpre = torch.empty_like(hd)
+        du2 = torch.empty((Z, R, 384), dtype=ty, device=dev)
+        n1 = torch.empty((Z, R, 128), dtype=ty, device=dev)
+        dv1 = torch.empty_like(n1)
+        dq = torch.empty((Z, R, 144), dtype=ty, device=dev)
+        p_drop, state, sites = drop if drop is not None else (0.0, None, (0, 0, 0))
+        call('stj_xattn_bwd', _p(dy), _p(query), _p(k), _p(v), _p(kvalid), _p(ctx.pack), _p(ps['g1'].master), _p(ps['be1'].master),
+             _p(ps['b1'].master), _p(ps['g2'].master), zs, _p(sq), _p(sv1), _p(su2), _p(dquery), _p(dk), _p(dv), _p(dkp), _p(dvp), _p(hd),
+             _p(dpre), _p(du2), _p(n1), _p(dv1), _p(dq), _p(ps['g1'].grad), _p(ps['be1'].grad), _p(ps['bo'].grad), _p(ps['g2'].grad),
+             _p(ps['be2'].grad), Z, B, HW, _p(state), sites[0], sites[1], sites[2], float(p_drop), dt, _st())
+        # the four weight gradients of the Z sets, straight into the flat gradient buffer: one grouped launch
+        with wgrad_stream(1, hd, dpre, du2, n1, dv1, dq, so, query), gemm_group():
+            gemm(hd, du2, ps['w2'].grad, 512, 384, R, (0, R * 512, 1, 512), (0, R * 384, 384, 1), (0, zs, 384), dt, nb=(1, Z), c_f32=1,
+                 accumulate=1, splitk=0, colsum=ps['b2'].grad, sBias=(0, zs))                      # dW2 += hd^T du2 ; db2
+            gemm(n1, dpre, ps['w1'].grad, 128, 512, R, (0, R * 128, 1, 128), (0, R * 512, 512, 1), (0, zs, 512), dt, nb=(1, Z), c_f32=1,
+                 accumulate=1, splitk=0, colsum=ps['b1'].grad, sBias=(0, zs))                      # dW1 += n1^T dpre ; db1
+            gemm(so, dv1, ps['wo'].grad, 42, 128, R, (R * 144, 48, 1, 144), (R * 128, 0, 128, 1), (zs, 42 * 128, 128), dt, nb=(Z, 3),
+                 c_f32=1, accumulate=1, splitk=0)                                                  # dWo[z,h] += O_h^T dv1
+            gemm(query, dq, ps['wq'].grad, 384, 42, R, (R * 384, 0, 1, 384), (R * 144, 48, 144, 1), (zs, 384 * 42, 42), dt, nb=(Z, 3),
+                 c_f32=1, accumulate=1, splitk=0)                                                  # dWq[z,h] += query^T dq_h
+        return dquery, dk, dv, None, None, None, None, None, None
+
+
+def xattn(query, k, v, kvalid, pack, ps, zstride, dctx=None, names=None, p_drop=0.1):
+    """Fused Cross_AttentionT x Z.  ps: dict of set-0 Params {wq, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2}; dctx / names: the three
+    dropout sites of a training step (attention coefficients, after FFN1, after FFN2), registered with the unfused draw shapes."""
+    Z, B, HW, _ = query.shape
+    drop = None
+    if dctx is not None:
+        sites = (dctx.site(names[0], (Z, B, 3, HW, 64), p_drop), dctx.site(names[1], (Z, B * HW, 512), p_drop),
+                 dctx.site(names[2], (Z, B * HW, 384), p_drop))
+        drop = (float(p_drop), dctx.snap, sites)
+    return _XAttn.apply(query, k, v, ps['wq'].master, kvalid, pack, ps, zstride, drop)
+
+
+def _xattn_cost(kind):
+    def f(a):
+        if kind == 'fwd':
+            Z, B, HW, dt, train = a[18], a[19], a[20], a[26], bool(getattr(a[14], 'value', None))
+        else:
+            Z, B, HW, dt, train = a[30], a[31], a[32], a[38], True
+        es = 4 if dt == 0 else 2
+        rows = Z * B * HW
+        macs = 384 * 126 + 2 * 64 * 126 + 126 * 128 + 128 * 512 + 512 * 384            # per token: q proj, q k^T + P v, out proj, FFN1, FFN2
+        fl = 2.0 * rows * macs * (1 if kind == 'fwd' else 2)                          # (weight gradients are the caller's GEMMs)
+        if kind == 'fwd':
+            by = es * rows * (2 * 384 + ((144 + 144 + 128 + 384) if train else 0))
+        else:
+            by = es * rows * (3 * 384 + 144 + 128 + 384 + 2 * 512 + 384 + 2 * 128 + 144)
+        by += Z * 707840 * es // 2 * max(1, B * HW // 64 // 32)                           # the set's weight stream (re-read from L2 by the tiles)
+        return f'xattn_{kind}[Z{Z} B{B} HW{HW}]', 'xattn_' + kind, fl, fl, by
+    return f
+
+
+prof.EXTRA_MODELS['stj_xattn_fwd'] = _xattn_cost('fwd')
+prof.EXTRA_MODELS['stj_xattn_bwd'] = _xattn_cost('bwd')
+
+
+# ----------------------------------------------------------------------------------------------------
 # Dropout / DropPath (+ fused residual)
 # ----------------------------------------------------------------------------------------------------
 class DropCtx:
