@@ -69,6 +69,68 @@ def synth_batch(B, seed, device, grid=256):
     return {k: v.to(device) for k, v in d.items()}
 
 
+def build_roofline(prof_ser, prof_conc, nprof, value, B, world, algo_gflop_per_scene, peak, gemm_trace=False):
+    """-> (roofline dict of the (kernel, shape) with the largest total time per step, families table, kernel_ms table) from the
+    per-launch HIP-event records of strajnet_amd/prof.py (serial pass = every kernel alone; concurrent pass = as scheduled)."""
+    if not prof_ser:
+        return None, None, {}
+    from strajnet_amd import prof as kprof
+    keys, fams = kprof.summarize(prof_ser, nprof)
+    ckeys = kprof.summarize(prof_conc, nprof)[0] if prof_conc else {}
+    if gemm_trace:
+        print('# launches by kernel and shape (serial pass)', file=sys.stderr)
+        for k in sorted(keys, key=lambda k: -keys[k]['ms_per_step']):
+            v = keys[k]
+            print(f"{v['ms_per_step'] * 1e3:9.1f} us/step  {v['launches']:5.1f} x {v['avg_ms'] * 1e3:7.1f} us  "
+                  f"{v['flops_exec'] / v['avg_ms'] / 1e9:7.1f} TF/s  {v['bytes_alg'] / v['avg_ms'] / 1e6:7.0f} GB/s  {k}", file=sys.stderr)
+    tot_ms = sum(f['ms_per_step'] for f in fams.values())
+    families = {}
+    for n in sorted(fams, key=lambda n: -fams[n]['ms_per_step']):
+        f = fams[n]
+        families[n] = {'ms_per_step': round(f['ms_per_step'], 4), 'launches': round(f['launches'], 1),
+                       'TFLOPs_exec': round(f['flop_exec'] / f['ms_per_step'] / 1e9, 1) if f['flop_exec'] else None,
+                       'GBps': round(f['bytes'] / f['ms_per_step'] / 1e6, 0) if f['bytes'] else None}
+    # the dominant kernel = the (kernel, shape) with the largest total time in the step, whatever its family
+    dom = max(keys, key=lambda k: keys[k]['ms_per_step'])
+    d = keys[dom]
+    t_s = d['avg_ms'] * 1e-3
+    ai_exec = d['flops_exec'] / max(d['bytes_alg'], 1.0)
+    balance = peak * 1e12 / (PEAK_HBM_GBPS * 1e9)
+    bound = 'mfma' if ai_exec >= balance else 'hbm'
+    tf_alg, tf_exec, gbps = d['flops_alg'] / t_s / 1e12, d['flops_exec'] / t_s / 1e12, d['bytes_alg'] / t_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+    exec_gf_step = sum(f['flop_exec'] for f in fams.values()) / 1e9
+    roof = {'bound': bound, 'kernel': dom,
+            'achieved': round(gbps if bound == 'hbm' else tf_alg, 2), 'peak': PEAK_HBM_GBPS if bound == 'hbm' else peak,
+            'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s',
+            'frac': round(gbps / PEAK_HBM_GBPS if bound == 'hbm' else tf_alg / peak, 4),
+            'traffic': traffic,
+            'mfma_frac_algorithmic': round(tf_alg / peak, 4), 'mfma_frac_executed': round(tf_exec / peak, 4),
+            'hbm_frac': round(gbps / PEAK_HBM_GBPS, 4),
+            'hbm_frac_pmc': round(traffic / t_s / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None,
+            'executed_flop_per_byte': round(ai_exec, 1), 'machine_balance_flop_per_byte': round(balance, 1),
+            'avg_launch_ms': round(d['avg_ms'], 4), 'launches_per_step': round(d['launches'], 1),
+            'ms_per_step_of_this_kernel': round(d['ms_per_step'], 4), 'serial_kernel_ms_per_step': round(tot_ms, 3),
+            'timing': 'kernel alone on the GPU (side streams off, eager pass after the timed region, HIP events on the launch stream)',
+            'workgroup_budget': ('the two large up-conv weight-gradient launches take 256 workgroups when alone (this timing) and 128 -- half '
+                                 'the CUs -- in the timed step, where they are deferred next to chains of short kernels: avg_launch_ms_in_step '
+                                 'is the duration there (stj_upconv_wgrad_share)') if dom.startswith('upconv_wgrad[') else None,
+            'avg_launch_ms_in_step': round(ckeys[dom]['avg_ms'], 4) if dom in ckeys else None,
+            'algorithmic_gflop_per_launch': round(d['flops_alg'] / 1e9, 2), 'executed_gflop_per_launch': round(d['flops_exec'] / 1e9, 2),
+            'algorithmic_mbytes_per_launch': round(d['bytes_alg'] / 1e6, 1),
+            'end_to_end_frac': round(value * algo_gflop_per_scene / 1e3 / (peak * world), 4),
+            'end_to_end_frac_executed': round(value / B * exec_gf_step / 1e3 / (peak * world), 4),
+            'executed_gflop_per_scene_step': round(exec_gf_step / B, 1)}
+    kern = {k: round(v['avg_ms'], 4) for k, v in sorted(keys.items()) if v['ms_per_step'] >= 0.1}
+    return roof, families, kern
+
+
 def bench_infer(args, model, x, world, rank, dist):
     """BASELINE config 4: replicas only (no collective), one hipGraph replay of the eval forward per step."""
     import torch
@@ -97,6 +159,25 @@ def bench_infer(args, model, x, world, rank, dist):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_s = float(t)
+    roof = families = None
+    if not args.no_kernel_timing:        # every C-ABI launch of the forward timed alone (serial eager pass), as in the train leg
+        from strajnet_amd import prof as kprof
+        model.serial = True
+
+        def eager():
+            with torch.no_grad():
+                return model(x['ogm'], x['map_img'], training=False, obs=x['obs'], occ=x['occ'], mapt=None, flow=x['flow'])
+        eager()
+        kprof.enable()
+        for _ in range(3):
+            eager()
+        barrier()
+        prof_ser = kprof.disable()
+        model.serial = args.serial
+        value = args.batch * world * args.steps / dt_s
+        peak = PEAK_BF16_TFLOPS if args.dtype != 'f32' else PEAK_F32_TFLOPS
+        algo = (240.9 if args.cfg512 else ALGO_GFLOP_FWD_PER_SCENE)
+        roof, families, _ = build_roofline(prof_ser, None, 3, value, args.batch, world, algo, peak)
     if rank == 0:
         B = args.batch
         print(json.dumps({
@@ -105,7 +186,8 @@ def bench_infer(args, model, x, world, rank, dist):
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'STrajNet {"cfg-512" if args.cfg512 else "cfg-256"} inference forward (BASELINE config 4: extra measurement, not the headline metric), '
                                    f'batch {B}/GPU, fg_msa+fg, random-init weights', 'global_batch': B * world, 'parallelism': f'replicas x{world}',
-                       'hipgraph': gf is not None, 'finite': bool(torch.isfinite(out).all())}}))
+                       'hipgraph': gf is not None, 'finite': bool(torch.isfinite(out).all())},
+            'roofline': roof, 'families': families}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -209,6 +291,97 @@ def parity_extras(model, loss_fn, x, B, dev, with_cpu):
     return res
 
 
+def run_extra_configs(steps=10, warmup=3):
+    """BASELINE configs 4 and 5 measured in the SAME default run (the driver only runs `bench.py --gpus 1`): each is this file again,
+    in a child process on the same GPU, with its own hipGraph capture, timed region and per-kernel roofline pass.  -> dict for the
+    `extra_configs` field of the headline line (never the headline itself)."""
+    import subprocess
+    res = {}
+    for name, flags in (('infer', ['--infer']), ('cfg512', ['--cfg512'])):
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline',
+               '--no-extra-configs'] + flags
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.strip().splitlines() if l.startswith('{')][-1]
+            d = json.loads(line)
+            roof = d.get('roofline') or {}
+            res[name] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'warmup': d['warmup'],
+                         'dtype': d['dtype'], 'workload': d['config']['workload'], 'global_batch': d['config']['global_batch'],
+                         'roofline': {k: roof.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms',
+                                                               'launches_per_step', 'mfma_frac_executed', 'hbm_frac', 'serial_kernel_ms_per_step',
+                                                               'end_to_end_frac')} if roof else None,
+                         'wall_s': round(time.time() - t0, 1)}
+        except Exception as e:           # a reported extra, never the headline
+            res[name] = {'value': None, 'error': f'{type(e).__name__}: {e}'[:300]}
+    return res
+
+
+def input_feed(graphed, x, steps, finish_step, dev):
+    """The step WITH its input feed (reference train.py:85-103,319: every step consumes a new batch): the batch comes from pinned
+    host memory on a copy stream while the previous step runs, then lands in the captured step's static inputs.  Two host formats:
+    'f32' = the decoded float32 tensors; 'raw' = the TFRecord's own bytes (bool occupancy grids, int8 map, f32 flows) expanded on
+    the device by stj_decode_raw (strajnet_amd/data.py).  -> {'f32': {...}, 'raw': {...}} scenes/s including the feed."""
+    import torch
+    from strajnet_amd import ops
+    B = x['ogm'].shape[0]
+    raw_kind = {'ogm': 'bool', 'gt_obs': 'bool', 'gt_occ': 'bool', 'map_img': 'int8'}
+    KIND = {'bool': 0, 'int8': 1}
+    copy = torch.cuda.Stream(dev)
+    res = {}
+    for mode in ('f32', 'raw'):
+        host, stage = {}, {}
+        for k, v in x.items():
+            if k not in graphed.static:
+                continue
+            if mode == 'raw' and k in raw_kind:
+                h = (v != 0).to(torch.uint8) if raw_kind[k] == 'bool' else torch.round(v * 256.0).to(torch.int8).view(torch.uint8)
+                host[k] = h.cpu().contiguous().pin_memory()
+            else:
+                host[k] = v.detach().float().cpu().contiguous().pin_memory()
+            stage[k] = torch.empty(host[k].shape, dtype=host[k].dtype, device=dev)
+        nbytes = sum(h.numel() * h.element_size() for h in host.values())
+        up, landed = torch.cuda.Event(), torch.cuda.Event()
+
+        def upload():
+            with torch.cuda.stream(copy):
+                copy.wait_event(landed)              # the staging buffers are free once the previous batch left them
+                for k in host:
+                    stage[k].copy_(host[k], non_blocking=True)
+                up.record(copy)
+
+        def land():
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(up)
+            for k, st in stage.items():
+                dst = graphed.static[k]
+                if mode == 'raw' and k in raw_kind:
+                    n = dst.numel()
+                    ops.call('stj_decode_raw', ops._p(st), KIND[raw_kind[k]], ops._p(dst), 1, 1, n, 1, 0, 0, 1, n,
+                             (1.0 / 256.0) if raw_kind[k] == 'int8' else 1.0, ops._st())
+                else:
+                    dst.copy_(st, non_blocking=True)
+            landed.record(main)
+        landed.record(torch.cuda.current_stream(dev))
+        upload()
+        for _ in range(2):
+            land(); upload(); graphed(); finish_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            land()
+            upload()                                  # the NEXT batch crosses PCIe under this step
+            graphed()
+            finish_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[mode] = {'value': round(B * steps / dt, 3), 'unit': 'scenes/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+                     'host_mbytes_per_step': round(nbytes / 1e6, 1)}
+    res['note'] = ('same captured step, every step preceded by a fresh batch from pinned host memory (upload on a copy stream under the '
+                   'previous step, then device copies / stj_decode_raw into the static inputs); `value` of the headline has the inputs resident')
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -224,6 +397,7 @@ def main():
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd + loss + bwd (+ all-reduce) only, without the fused Keras-Nadam update (train.py:197,224) that the default step ends with')
     ap.add_argument('--no-overlap', action='store_true', help='N>1: one all-reduce of the whole gradient buffer after a monolithic backward instead of two buckets overlapped with the encoder backward')
     ap.add_argument('--serial', action='store_true', help='no side streams: every kernel runs alone (the mode the roofline kernel timings are taken in)')
+    ap.add_argument('--no-extra-configs', action='store_true', help='default N=1 run only: skip the child runs of BASELINE configs 4 (--infer) and 5 (--cfg512) that fill `extra_configs`, and the input-feed measurement')
     ap.add_argument('--gemm-trace', action='store_true', help='print per-shape GEMM launch times (HIP events) to stderr')
     args = ap.parse_args()
 
@@ -282,6 +456,8 @@ def main():
     # stream UNDER the encoder's backward, the encoder bucket after it.  --no-overlap: one bucket after a monolithic backward.
     from strajnet_amd import dp
 
+    finish_step_ref = [None]
+
     def build_step(overlap):
         sync = dp.OverlappedGradSync(model) if overlap else None
         model.cut_encoder = overlap
@@ -294,6 +470,7 @@ def main():
                     dist.all_reduce(model.flat_grads(), op=dist.ReduceOp.SUM)
             if opt is not None:
                 opt.step()
+        finish_step_ref[0] = finish_step
 
         def step():
             model.zero_grad()
@@ -330,14 +507,33 @@ def main():
     overlap = world > 1 and not args.no_overlap
     step, eager_step, graphed, sync = build_step(overlap)
     probed = 0
+    overlap_fallback_reason = None
     if overlap:          # the two-graph / two-bucket path has only ever run over gloo (no multi-GPU node so far): probe it once, and fall
-        try:             # back to the one-bucket exchange rather than lose the run if RCCL disagrees (the probe is the first warm-up step)
+        err = None       # back to the one-bucket exchange rather than lose the run if RCCL disagrees (the probe is the first warm-up step)
+        try:
             step()
             torch.cuda.synchronize()
             probed = 1
         except Exception as e:
-            print(f'bench.py: overlapped gradient exchange failed ({type(e).__name__}: {e}); using one bucket after backward', file=sys.stderr)
-            overlap = False
+            err = f'{type(e).__name__}: {e}'[:300]
+        # every rank must take the same path (mismatched collectives hang): agree on the outcome with a MIN all-reduce
+        ok = torch.tensor([0.0 if err else 1.0], device=dev)
+        try:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            all_ok = bool(ok.item() >= 1.0)
+        except Exception as e:
+            all_ok, err = False, (err or f'agreement all-reduce failed: {type(e).__name__}: {e}'[:300])
+        if not all_ok:
+            overlap_fallback_reason = err or 'another rank failed the overlapped probe step'
+            print(f'bench.py: overlapped gradient exchange failed ({overlap_fallback_reason}); using one bucket after backward', file=sys.stderr)
+            if sync is not None:
+                for w in sync._work:         # drain what the failed probe left in flight before the step is rebuilt
+                    try:
+                        w.wait()
+                    except Exception:
+                        pass
+                sync._work = []
+            overlap, probed = False, 0
             step, eager_step, graphed, sync = build_step(False)
 
     def barrier():
@@ -399,6 +595,7 @@ def main():
     if world > 1:
         dist_info = dp.OverlappedGradSync.info()
         dist_info['allreduce_overlapped_with_backward'] = bool(overlap)
+        dist_info['overlap_fallback_reason'] = overlap_fallback_reason
         chk = torch.ones(1, device=dev)
         dist.all_reduce(chk)
         dist_info['ranks_seen_by_allreduce'] = int(chk.item())       # every rank contributed 1: proof the collective spans N ranks
@@ -429,6 +626,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t.item())
     loss_val = float(last.detach())
+    feed = None
+    if rank == 0 and world == 1 and graphed is not None and not args.no_extra_configs and not args.no_kernel_timing:
+        try:
+            feed = input_feed(graphed, x, args.steps, finish_step_ref[0], dev)
+        except Exception as e:
+            feed = {'error': f'{type(e).__name__}: {e}'[:300]}
     extras = {}
     if rank == 0 and world == 1 and not args.no_kernel_timing and not args.cfg512 and dtype == torch.bfloat16:
         try:
@@ -441,64 +644,7 @@ def main():
         algo_step = ALGO_GFLOP_STEP_PER_SCENE_512 if args.cfg512 else ALGO_GFLOP_STEP_PER_SCENE
         value = scenes / dt_s
         peak = PEAK_BF16_TFLOPS if dtype != torch.float32 else PEAK_F32_TFLOPS
-        roof = None
-        families = None
-        kern = {}
-        if prof_ser:
-            from strajnet_amd import prof as kprof
-            keys, fams = kprof.summarize(prof_ser, nprof)
-            ckeys = kprof.summarize(prof_conc, nprof)[0] if prof_conc else {}
-            if args.gemm_trace:
-                print('# launches by kernel and shape (serial pass)', file=sys.stderr)
-                for k in sorted(keys, key=lambda k: -keys[k]['ms_per_step']):
-                    v = keys[k]
-                    print(f"{v['ms_per_step'] * 1e3:9.1f} us/step  {v['launches']:5.1f} x {v['avg_ms'] * 1e3:7.1f} us  "
-                          f"{v['flops_exec'] / v['avg_ms'] / 1e9:7.1f} TF/s  {v['bytes_alg'] / v['avg_ms'] / 1e6:7.0f} GB/s  {k}", file=sys.stderr)
-            tot_ms = sum(f['ms_per_step'] for f in fams.values())
-            families = {}
-            for n in sorted(fams, key=lambda n: -fams[n]['ms_per_step']):
-                f = fams[n]
-                families[n] = {'ms_per_step': round(f['ms_per_step'], 4), 'launches': round(f['launches'], 1),
-                               'TFLOPs_exec': round(f['flop_exec'] / f['ms_per_step'] / 1e9, 1) if f['flop_exec'] else None,
-                               'GBps': round(f['bytes'] / f['ms_per_step'] / 1e6, 0) if f['bytes'] else None}
-            # the dominant kernel = the (kernel, shape) with the largest total time in the step, whatever its family
-            dom = max(keys, key=lambda k: keys[k]['ms_per_step'])
-            d = keys[dom]
-            t_s = d['avg_ms'] * 1e-3
-            ai_exec = d['flops_exec'] / max(d['bytes_alg'], 1.0)
-            balance = peak * 1e12 / (PEAK_HBM_GBPS * 1e9)
-            bound = 'mfma' if ai_exec >= balance else 'hbm'
-            tf_alg, tf_exec, gbps = d['flops_alg'] / t_s / 1e12, d['flops_exec'] / t_s / 1e12, d['bytes_alg'] / t_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(dom)
-                except Exception:
-                    traffic = None
-            exec_gf_step = sum(f['flop_exec'] for f in fams.values()) / 1e9
-            roof = {'bound': bound, 'kernel': dom,
-                    'achieved': round(gbps if bound == 'hbm' else tf_alg, 2), 'peak': PEAK_HBM_GBPS if bound == 'hbm' else peak,
-                    'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s',
-                    'frac': round(gbps / PEAK_HBM_GBPS if bound == 'hbm' else tf_alg / peak, 4),
-                    'traffic': traffic,
-                    'mfma_frac_algorithmic': round(tf_alg / peak, 4), 'mfma_frac_executed': round(tf_exec / peak, 4),
-                    'hbm_frac': round(gbps / PEAK_HBM_GBPS, 4),
-                    'hbm_frac_pmc': round(traffic / t_s / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None,
-                    'executed_flop_per_byte': round(ai_exec, 1), 'machine_balance_flop_per_byte': round(balance, 1),
-                    'avg_launch_ms': round(d['avg_ms'], 4), 'launches_per_step': round(d['launches'], 1),
-                    'ms_per_step_of_this_kernel': round(d['ms_per_step'], 4), 'serial_kernel_ms_per_step': round(tot_ms, 3),
-                    'timing': 'kernel alone on the GPU (side streams off, eager pass after the timed region, HIP events on the launch stream)',
-                    'workgroup_budget': ('the two large up-conv weight-gradient launches take 256 workgroups when alone (this timing) and 128 -- half '
-                                         'the CUs -- in the timed step, where they are deferred next to chains of short kernels: avg_launch_ms_in_step '
-                                         'is the duration there (stj_upconv_wgrad_share)') if dom.startswith('upconv_wgrad[') else None,
-                    'avg_launch_ms_in_step': round(ckeys[dom]['avg_ms'], 4) if dom in ckeys else None,
-                    'algorithmic_gflop_per_launch': round(d['flops_alg'] / 1e9, 2), 'executed_gflop_per_launch': round(d['flops_exec'] / 1e9, 2),
-                    'algorithmic_mbytes_per_launch': round(d['bytes_alg'] / 1e6, 1),
-                    'end_to_end_frac': round(value * algo_step / 1e3 / (peak * world), 4),
-                    'end_to_end_frac_executed': round(value / B * exec_gf_step / 1e3 / (peak * world), 4),
-                    'executed_gflop_per_scene_step': round(exec_gf_step / B, 1)}
-            kern = {k: round(v['avg_ms'], 4) for k, v in sorted(keys.items()) if v['ms_per_step'] >= 0.1}
+        roof, families, kern = build_roofline(prof_ser, prof_conc, nprof, value, B, world, algo_step, peak, args.gemm_trace)
         out = {
             'metric': 'scenes/sec (fwd+bwd, 256x256 grids)', 'value': round(value, 3), 'unit': 'scenes/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt_s / args.steps * 1e3, 3),
@@ -518,6 +664,12 @@ def main():
             out['families'] = families
             out['kernel_ms'] = kern
         out.update(extras)
+        if feed is not None:
+            out['with_input_feed'] = feed
+        if world == 1 and not args.cfg512 and not args.no_extra_configs and not args.no_kernel_timing and dtype == torch.bfloat16:
+            del graphed
+            torch.cuda.empty_cache()
+            out['extra_configs'] = run_extra_configs()
         if 'cpu_baseline' not in out:
             if not args.no_cpu_baseline and world == 1 and not args.cfg512:
                 try:

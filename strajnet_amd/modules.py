@@ -820,5 +820,6 @@ class STrajNet:
         self._tap('cross_attention_out', x)
         x = ops.wgrad_flush_point(x)             # the decoder's weight gradients are launched when ITS backward is through (ops.py)
         out = self._decoder(x, res_list, B, skips)
+        ops.wgrad_defer_end()
         self._tap('output', out)
         return ops.join_after_backward(out, (self._side, self._side2), fold)

@@ -1366,7 +1366,7 @@ def _upconv_backward_tail(ctx, x, dpre, wd, need_dx):
         call('stj_upconv_fold', _p(dweff), _p(pw.grad), Cin, Cout, _st())
         if own:
             pb.grad.add_(dbp.view(nparts, Cout).sum(0))
-    if _UPWG['on'] and not _SERIAL and (_WG_MODE & 2):
+    if ctx.defer and not _SERIAL and (_WG_MODE & 2):
         _UPWG['items'].append((wg, x, dpre))             # launched by flush_upconv_wgrads() (the model's flush point)
     else:
         with wgrad_stream(2, x, dpre):
@@ -1378,6 +1378,8 @@ def _upconv_backward_tail(ctx, x, dpre, wd, need_dx):
 # HBM with the input-gradient chain they run next to (the 96 <- 48 dgrad takes 0.48 ms in the step, 0.31 ms alone) and are finished long before
 # anybody needs them.  The model puts a flush point behind the decoder (in backward order): the kernels are queued there, on the side stream,
 # under the cross-attention / FG-MSA backward -- a chain of short launches that leaves most of the GPU idle.
+# Whether an up-conv defers is decided when its FORWARD runs (ctx.defer) and only between wgrad_flush_point() and wgrad_defer_end():
+# an up-conv applied outside that region (op-level use, another graph) launches its weight gradient at once, whatever ran before.
 _UPWG = {'on': False, 'items': []}
 
 
@@ -1403,10 +1405,16 @@ class _WgradFlushPoint(torch.autograd.Function):
 
 
 def wgrad_flush_point(x):
-    """Mark x as the input of the region whose up-conv weight gradients are deferred (no-op without autograd or with STJ_DEFER_UPWG=0)."""
+    """Mark x as the input of the region whose up-conv weight gradients are deferred (no-op without autograd or with STJ_DEFER_UPWG=0).
+    The region ends at wgrad_defer_end()."""
     _UPWG['on'] = DEFER_UPWG and x.requires_grad and torch.is_grad_enabled()
     _UPWG['items'] = []
     return _WgradFlushPoint.apply(x) if _UPWG['on'] else x
+
+
+def wgrad_defer_end():
+    """End of the forward region opened by wgrad_flush_point(): up-convs applied from here on do not defer."""
+    _UPWG['on'] = False
 
 
 DEFER_UPWG = os.environ.get('STJ_DEFER_UPWG', '1') != '0'
@@ -1428,6 +1436,7 @@ class _UpConv(torch.autograd.Function):
         call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
         ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
         ctx.grad_is_pre, ctx.x_is_elu_out = grad_is_pre, x_is_elu_out
+        ctx.defer = _UPWG['on']
         ctx.save_for_backward(x, y, wd)
         return y
 
@@ -1473,15 +1482,14 @@ class _UpConvAdd(torch.autograd.Function):
             ctx.save_for_backward(x, ye, None, wd)
         ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
         ctx.x_is_elu_out, ctx.two = False, r2 is not None
+        ctx.defer = _UPWG['on']
         return (y, y2) if r2 is not None else y
 
     @staticmethod
     def backward(ctx, dy, dy2=None):
         x, y, r1, wd = ctx.saved_tensors
         dt = _dt(x)
-        if dy is None:
-            dy, dy2 = dy2, None
-        dy = dy.contiguous()
+        dy = dy.contiguous()          # (undefined output gradients arrive materialised as zeros: dy is never None)
         dpre = torch.empty_like(dy)
         gsum = None
         if dy2 is not None:
@@ -1493,6 +1501,8 @@ class _UpConvAdd(torch.autograd.Function):
         return dx, dr1, (dy2 if ctx.two else None), None, None, None, None, None, None
 
 
+# (FUSED_SKIP = 2 in training recovers ELU' from y - r1 in 16-bit storage: for |ELU output| below the rounding step of y the
+# branch can flip -- one more reason it is not the training default.)
 # 0: never; 1 (default): in inference only; 2: always; 3: like 1, and in training the sums as one separate pass (see upconv_add).  Measured at B=8 bf16: the training step is 1.2 % SLOWER with the sums in the
 # epilogue (901 vs 912 scenes/s: a workgroup owns 32 of the 128 couts, so the skip operands are read and the sums written in 64-byte
 # pieces, 138 vs 92 us for the 192 -> 128 layer, while the separate adds stream whole lines at 5 TB/s), the B=32 fp16 forward 1.4 % faster.
@@ -1606,6 +1616,7 @@ class _OgmFlowLoss(torch.autograd.Function):
         call('stj_loss_fwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(sums), _p(loss), _p(coef),
              B, H, W, float(ogm_w), float(occ_w), float(fow), float(replica), int(flags), _st())
         ctx.geo = (B, H, W, int(flags))
+        ctx.set_materialize_grads(False)     # a step that differentiates only `total` gets None for the four terms: one-scalar path below
         ctx.save_for_backward(logits, gt_obs, gt_occ, gt_flow, origin, coef)
         terms = loss[:4]
         ctx.mark_non_differentiable(terms)
@@ -1616,6 +1627,8 @@ class _OgmFlowLoss(torch.autograd.Function):
         logits, gt_obs, gt_occ, gt_flow, origin, coef = ctx.saved_tensors
         B, H, W, flags = ctx.geo
         parts = (g0, g1, g2, g3)
+        if all(g is None for g in parts) and gt is None:
+            return (None,) * 11
         if all(g is None for g in parts):
             up = gt.float().contiguous()             # one value for the four terms (flag bit 3): no expand / copy launch
             flags |= 8

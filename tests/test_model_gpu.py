@@ -343,6 +343,38 @@ def test_save_and_load_weights_tf_checkpoint(tmp_path):
         strajnet_amd.STrajNet(dict(CFG128, depths=[2, 2, 6]), fg_msa=True, fg=True, large_ogm=False).load_weights(path)
 
 
+def test_upconv_wgrad_not_deferred_outside_the_model_graph():
+    """The decoder's up-conv weight gradients are deferred to the model's flush point.  That decision is taken per op while the
+    model's forward runs: an up-conv applied on its own afterwards -- even after a training forward whose backward never ran -- must
+    launch its weight gradient itself (the deferral switch used to be a process global that stayed on)."""
+    from strajnet_amd import ops
+    model, w, x, xt = _setup(CFG128, 1, torch.float32)
+    model.zero_grad()
+    out = model(xt['ogm'], xt['map_img'], training=True, obs=xt['obs'], occ=xt['occ'], mapt=xt['mapt'], flow=xt['flow'])
+    del out                                                     # forward only: no backward, no flush point ever runs
+    pw, pb = model.params['decoder/upconv_0_0/kernel'], model.params['decoder/upconv_0_0/bias']
+    model.zero_grad()
+    xx = torch.randn(2, 8, 8, 96, device='cuda', requires_grad=True)
+    y = ops.upconv(xx, pw, pb)
+    y.sum().backward()
+    torch.cuda.synchronize()
+    assert float(pw.grad.abs().sum()) > 0 and float(xx.grad.abs().sum()) > 0
+    g1 = pw.grad.clone()
+    if pb.part is not None:
+        model._fold_partials()
+    assert float(pb.grad.abs().sum()) > 0
+    # and again after a complete training step (flush point + join ran): same gradient increment
+    model.zero_grad()
+    out = model(xt['ogm'], xt['map_img'], training=True, obs=xt['obs'], occ=xt['occ'], mapt=xt['mapt'], flow=xt['flow'])
+    out.sum().backward()
+    torch.cuda.synchronize()
+    model.zero_grad()
+    y = ops.upconv(xx, pw, pb)
+    y.sum().backward()
+    torch.cuda.synchronize()
+    assert float((pw.grad - g1).abs().max()) <= 1e-5 * float(g1.abs().max()), (float((pw.grad - g1).abs().max()), float(g1.abs().max()))
+
+
 def test_side_streams_are_joined_after_backward():
     """Branches run on side streams and write their weight gradients straight into the flat buffer; work enqueued on the caller's
     stream right after backward() (here: a clone of the gradients) must already see all of it, and serial mode must agree."""

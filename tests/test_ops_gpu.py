@@ -529,6 +529,23 @@ def test_loss_and_gate():
             assert rel_err(lt.grad, lr.grad) < 1e-4, flags
     d0 = OGMFlow_loss(OccupancyFlowTaskConfig(Hg, Hg, 8))                  # the reference's own defaults construct and run
     assert d0.use_focal_loss and not d0.use_gt and not d0.use_pred
+    # differentiating `.total` alone takes the one-upstream-scalar path of stj_loss_bwd (flag bit 3): same d/dlogits as the sum of the
+    # four entries; mixed use (one entry + total) goes through the general path
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(Hg, Hg, 8), replica=2.0, use_gt=True, use_focal_loss=False)
+    tw = warpped_gt(gt['gt_obs'], gt['gt_occ'], gt['gt_flow'], gt['origin_flow'])
+    lt.grad = None
+    sum(loss_fn(get_pred_waypoint_logits(lt), tw, None).values()).backward()
+    g_sum = lt.grad.clone()
+    lt.grad = None
+    (3.0 * loss_fn(get_pred_waypoint_logits(lt), tw, None).total).backward()
+    assert rel_err(lt.grad, 3.0 * g_sum) < 1e-6
+    lt.grad = None
+    d = loss_fn(get_pred_waypoint_logits(lt), tw, None)
+    (d.total + d['flow']).backward()
+    lt.grad2, lt.grad = lt.grad.clone(), None
+    d = loss_fn(get_pred_waypoint_logits(lt), tw, None)
+    (sum(d.values()) + d['flow']).backward()
+    assert rel_err(lt.grad2, lt.grad) < 1e-6
 
 
 @pytest.mark.parametrize('dt', DTYPES)
