@@ -120,7 +120,7 @@ def build_roofline(prof_ser, prof_conc, nprof, value, B, world, algo_gflop_per_s
             'timing': 'kernel alone on the GPU (side streams off, eager pass after the timed region, HIP events on the launch stream)',
             'workgroup_budget': ('the two large up-conv weight-gradient launches take 256 workgroups when alone (this timing) and 128 -- half '
                                  'the CUs -- in the timed step, where they are deferred next to chains of short kernels: avg_launch_ms_in_step '
-                                 'is the duration there (stj_upconv_wgrad_share)') if dom.startswith('upconv_wgrad[') else None,
+                                 'is the duration there (the wg_budget argument of stj_upconv_wgrad)') if dom.startswith('upconv_wgrad[') else None,
             'avg_launch_ms_in_step': round(ckeys[dom]['avg_ms'], 4) if dom in ckeys else None,
             'algorithmic_gflop_per_launch': round(d['flops_alg'] / 1e9, 2), 'executed_gflop_per_launch': round(d['flops_exec'] / 1e9, 2),
             'algorithmic_mbytes_per_launch': round(d['bytes_alg'] / 1e6, 1),

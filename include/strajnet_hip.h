@@ -46,14 +46,16 @@ int stj_gemm(const void* A, const void* B, void* C, const float* bias, const voi
              long long sCb1, long long sCb2, long long ldc,
              long long sBias1, long long sBias2, long long sRes1, long long sRes2, long long ldres,
              int act, float alpha, int dtype, int c_f32, int accumulate, int splitk,
-             int nkb, long long sAkb, long long sBkb, hipStream_t stream);
-/* Grouped launch.  Between stj_gemm_group_begin() and stj_gemm_group_end(stream) on one host thread, stj_gemm calls are RECORDED
- * (arguments validated, their `stream` ignored) and launched by _end as ONE kernel per 4 problems of equal dtype (64x64 or 32x32
+             int nkb, long long sAkb, long long sBkb, void* group, hipStream_t stream);
+/* Grouped launch.  `group` (last pointer argument of stj_gemm; NULL = launch at once) is CALLER-OWNED HOST memory of
+ * stj_gemm_group_workspace_bytes() bytes, initialised by stj_gemm_group_begin: stj_gemm calls handed the group are RECORDED in it
+ * (arguments validated) and launched by stj_gemm_group_end(group, stream) as ONE kernel per 4 problems of equal dtype (64x64 or 32x32
  * tiles): the input and weight gradient of a Dense layer (tape.gradient of modules.py:36-37 etc.), the q / k / v projections of a
  * tfa MultiHeadAttention (trajNet.py:33,71,195), dP / dV and dQ / dK of an attention.  The problems of a group must not depend on
- * each other. */
-int stj_gemm_group_begin(void);
-int stj_gemm_group_end(hipStream_t stream);
+ * each other.  The library keeps no state between calls: two host threads use two groups. */
+long long stj_gemm_group_workspace_bytes(void);
+int stj_gemm_group_begin(void* group);
+int stj_gemm_group_end(void* group, hipStream_t stream);
 /* out[n] += sum_m X[m,n]  (bias gradients of the conv heads). */
 int stj_colsum(const void* X, float* out, int M, int N, long long ld, int dtype, hipStream_t stream);
 /* f32 <-> bf16 / fp16 copy (16-bit compute copy of the flat parameter buffer). */
@@ -217,13 +219,12 @@ int stj_elu_res_bwd(const void* dy, const void* dy2, const void* y, const void* 
 int stj_skip_add(const void* y, const void* r1, const void* r2, void* y1, void* y2, long long n, int dtype, hipStream_t stream);
 int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout,
                      int dtype, hipStream_t stream);
+/* wg_budget: workgroups the two large weight-gradient launches (>= 64x64 inputs) may occupy.  0 = 128: half the CUs, because in a
+ * step whose branches run on concurrent streams these launches are deferred next to chains of short kernels, which then find the
+ * other half free (alone the kernel is 1.5x faster on 256).  A host that runs every kernel alone (serial / per-kernel timing) passes
+ * 256.  An argument, not library state: the ABI is stateless and re-entrant. */
 int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin,
-                     int Cout, int dtype, hipStream_t stream);
-/* Workgroup budget of the large (>= 2048 pixel chunks) weight-gradient launches.  0 = default = 128: half the CUs, because in a step
- * whose branches run on concurrent streams these launches are deferred next to chains of short kernels, which then find the other half
- * free (alone the kernel is 1.5x faster on 256).  A host that runs every kernel alone (serial / per-kernel timing mode) sets 256.
- * Process-wide, not thread-safe. */
-int stj_upconv_wgrad_share(int workgroups);
+                     int Cout, int wg_budget, int dtype, hipStream_t stream);
 /* wgrad: dbias (optional) is f32 [db_parts][Cout], "+=": workgroup i adds its share of the bias gradient into copy i % db_parts
  * and the caller sums the copies (db_parts = 1: plain [Cout]). */
 /* Output heads: Conv2D 3x3 SAME C->2, no activation (modules.py:767-770), written with strides straight into the

@@ -15,9 +15,10 @@ SIGNATURES = {
     'stj_abi_version': [],
     'stj_gemm': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci,
                  cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl, cl,
-                 ci, cf, ci, ci, ci, ci, ci, cl, cl, vp],
-    'stj_gemm_group_begin': [],
-    'stj_gemm_group_end': [vp],
+                 ci, cf, ci, ci, ci, ci, ci, cl, cl, vp, vp],
+    'stj_gemm_group_workspace_bytes': [],
+    'stj_gemm_group_begin': [vp],
+    'stj_gemm_group_end': [vp, vp],
     'stj_colsum': [vp, vp, ci, ci, cl, ci, vp],
     'stj_cast': [vp, ci, vp, ci, cl, vp],
     'stj_crc32c': [vp, cl, vp],
@@ -66,8 +67,7 @@ SIGNATURES = {
     'stj_elu_res_bwd': [vp, vp, vp, vp, vp, vp, cl, ci, vp],
     'stj_skip_add': [vp, vp, vp, vp, vp, cl, ci, vp],
     'stj_upconv_dgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
-    'stj_upconv_wgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
-    'stj_upconv_wgrad_share': [ci],
+    'stj_upconv_wgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_pair_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
     'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp, cl, ci, vp],

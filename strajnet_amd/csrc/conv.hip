@@ -598,7 +598,7 @@ bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y
                        int dtype, hipStream_t st);   // conv_ws.hip
 bool upconv_fwd_ps_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        int dtype, hipStream_t st);   // conv_ps.hip
-bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st);
+bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, int wg_budget, hipStream_t st);
 bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, float* Y, int F, int Hh, int Ww, int C, int Tn,
                           long long y_bs, long long y_ts, long long y_ps, int dtype, hipStream_t st);
 bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww, int C,
@@ -683,13 +683,16 @@ static int upconv_wgrad_launch(const void* X, const void* dP, float* dWeff, floa
 // dWeff: f32 [16][Cout][Cin] scratch, must be zero on entry (caller memsets); fold with stj_upconv_fold afterwards.
 // dbias (optional): f32 [db_parts][Cout], "+=": the sum over all pixels of dP (the conv bias gradient); workgroup i adds into copy
 // i % db_parts and the caller sums the copies (one copy = ~1000 same-address atomics per channel at the end of the kernel).
+// wg_budget: workgroups the two large layers (>= 64x64 inputs) may occupy; 0 = 128, half the CUs (a step whose branches run
+// concurrently leaves the other half to them), 256 = one per CU (the kernel alone on the GPU).
 extern "C" int stj_upconv_wgrad(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin,
-                                int Cout, int dtype, hipStream_t stream) {
+                                int Cout, int wg_budget, int dtype, hipStream_t stream) {
   int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
   if (e) return e;
   if (dbias && db_parts < 1) { stj_set_error("upconv_wgrad: db_parts must be >= 1"); return STJ_EINVAL; }
+  if (wg_budget < 0 || wg_budget > 4096) { stj_set_error("upconv_wgrad: wg_budget %d out of range", wg_budget); return STJ_EINVAL; }
   if (db_parts < 1) db_parts = 1;
-  if (dtype == STJ_BF16 && ws_enabled() && upconv_wgrad_tr_try(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, stream))
+  if (dtype == STJ_BF16 && ws_enabled() && upconv_wgrad_tr_try(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, wg_budget, stream))
     return stj_check_launch("stj_upconv_wgrad(tr)");
   if (dtype == STJ_F16) return upconv_wgrad_launch<f16>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, stream);
   return dtype == STJ_BF16 ? upconv_wgrad_launch<bf16>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, stream)

@@ -792,17 +792,11 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_tr4_kernel(const bf16* __
     }
 }
 
-// Workgroup budget of the two large weight-gradient launches: 128 (half the CUs) for a step whose branches run concurrently, 256 when
-// every kernel runs alone (serial mode: the host says so through stj_upconv_wgrad_share).
-static int g_wgrad_share = 0;
-extern "C" int stj_upconv_wgrad_share(int workgroups) {
-  if (workgroups < 0 || workgroups > 4096) { stj_set_error("stj_upconv_wgrad_share: %d out of range", workgroups); return STJ_EINVAL; }
-  g_wgrad_share = workgroups;
-  return STJ_OK;
-}
+// Workgroup budget of the two large weight-gradient launches (an argument of stj_upconv_wgrad): 128 (half the CUs) for a step whose
+// branches run concurrently, 256 when every kernel runs alone (serial mode).
 template <int FO, int FI, int CW, int NPIX>
 static bool wgrad_tr4_launch(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout,
-                             int tiles, hipStream_t st) {
+                             int tiles, int wg_budget, hipStream_t st) {
   constexpr int CR = NPIX / CW, BO = FO * 16, BI = FI * 16;
   const size_t lds = (size_t)2 * (CR * 2 * CW * (BO + 8) + (CR + 1) * (CW + 2) * (BI + 8)) * 2;
   static bool attr_set = false;
@@ -811,13 +805,11 @@ static bool wgrad_tr4_launch(const void* X, const void* dP, float* dWeff, float*
     attr_set = true;
   }
   const long long nchunks = (long long)F * (Hi / CR) * (Wi / CW);
-  static int nb = -1;
   // Workgroups: HALF the CUs.  Alone the kernel is faster with one workgroup per CU (246 vs 344 us for the 96 -> 48 layer), but the
   // decoder's weight gradients are deferred (ops.py) and run next to the backward of the cross-attentions / FG-MSA / the encoder, chains
   // of short launches that then find the other half of the CUs free: 1085 -> 1130 scenes/s (256 -> 128 workgroups; 192: 1116, 96: 1121,
   // 64: 1131, 32: 842)
-  if (nb < 0) { const char* e = getenv("STJ_WGRAD_V4_BLOCKS"); nb = e ? atoi(e) : 0; }
-  const int budget = nb > 0 ? nb : (g_wgrad_share > 0 ? g_wgrad_share : 128);
+  const int budget = wg_budget > 0 ? wg_budget : 128;
   int strips = (int)min(nchunks, (long long)max(1, budget / (2 * tiles)));   // x 2 row parities x tiles workgroups
   const int cpb = (int)((nchunks + strips - 1) / strips);
   strips = (int)((nchunks + cpb - 1) / cpb);
@@ -828,7 +820,7 @@ static bool wgrad_tr4_launch(const void* X, const void* dP, float* dWeff, float*
 
 // returns true when handled (bf16; Wi % 32 == 0 and Hi % 4 == 0, or Wi % 16 == 0 and Hi % 8 == 0; channels % 8 == 0)
 template <int CW>
-static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, int wg_budget, hipStream_t st) {
   constexpr int CR = 128 / CW;
   const long long nchunks = (long long)F * (Hi / CR) * (Wi / CW);
   static int v4 = -1;
@@ -836,11 +828,11 @@ static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* 
   // (the two large layers only: at 32 x 32 and below a strip has too few chunks to amortise a 512-thread workgroup: 149 vs 113 us)
   if (v4 && Hi % (256 / CW) == 0 && nchunks >= 2048) {
     if (v4 != 3) {       // 128-pixel chunks (256: register-staged prefetch spills)
-      if (Cout <= 48 && Cin <= 96) return wgrad_tr4_launch<3, 6, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, 1, st);
-      return wgrad_tr4_launch<4, 4, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, ((Cout + 63) / 64) * ((Cin + 63) / 64), st);
+      if (Cout <= 48 && Cin <= 96) return wgrad_tr4_launch<3, 6, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, 1, wg_budget, st);
+      return wgrad_tr4_launch<4, 4, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, ((Cout + 63) / 64) * ((Cin + 63) / 64), wg_budget, st);
     }
-    if (Cout <= 48 && Cin <= 96) return wgrad_tr4_launch<3, 6, CW, 256>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, 1, st);
-    return wgrad_tr4_launch<4, 4, CW, 256>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, ((Cout + 63) / 64) * ((Cin + 63) / 64), st);
+    if (Cout <= 48 && Cin <= 96) return wgrad_tr4_launch<3, 6, CW, 256>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, 1, wg_budget, st);
+    return wgrad_tr4_launch<4, 4, CW, 256>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, ((Cout + 63) / 64) * ((Cin + 63) / 64), wg_budget, st);
   }
   if (Cout <= 48 && Cin <= 96) {
     int strips = (int)min(nchunks, (long long)256);     // 128 and 512 measured within noise / slower
@@ -858,10 +850,10 @@ static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* 
   }
   return true;
 }
-bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
+bool upconv_wgrad_tr_try(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, int wg_budget, hipStream_t st) {
   if (Cin % 8 || Cout % 8) return false;
-  if (Wi % 32 == 0 && Hi % 4 == 0) return wgrad_tr_launch<32>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, st);
-  if (Wi % 16 == 0 && Hi % 8 == 0) return wgrad_tr_launch<16>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, st);
+  if (Wi % 32 == 0 && Hi % 4 == 0) return wgrad_tr_launch<32>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, wg_budget, st);
+  if (Wi % 16 == 0 && Hi % 8 == 0) return wgrad_tr_launch<16>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, wg_budget, st);
   return false;
 }
 

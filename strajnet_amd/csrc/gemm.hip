@@ -559,17 +559,16 @@ static void launch_tile(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, false, false>), grid, blk, 0, st, p);
 }
 
-// ---- group recording (stj_gemm_group_begin / _end): per host thread ----
-static thread_local bool g_rec = false;
-static thread_local int g_rec_dtype = -1;
-static thread_local int g_rec_blocks = 0;
-static thread_local GemmGroup g_grp;
+// ---- group recording (stj_gemm_group_begin / _end): the state lives in a CALLER-OWNED host buffer (the library keeps none) ----
+struct GroupState { unsigned magic; int rec_dtype, rec_blocks; GemmGroup grp; };
+static constexpr unsigned GROUP_MAGIC = 0x53544a47u;     // "STJG"
 
-static int group_flush(hipStream_t st) {
+static int group_flush(GroupState* gs, hipStream_t st) {
+  GemmGroup& g_grp = gs->grp;
   if (g_grp.n == 0) return STJ_OK;
   GemmGroup g = g_grp;
-  const int dtype = g_rec_dtype;
-  g_grp.n = 0; g_rec_blocks = 0; g_rec_dtype = -1;
+  const int dtype = gs->rec_dtype;
+  g_grp.n = 0; gs->rec_blocks = 0; gs->rec_dtype = -1;
   if (g.n == 1) {                                   // a group of one is an ordinary launch
     const int c = g.cfg[0] & 7, deep1 = g.cfg[0] & 8;
     dim3 grid(g.gx[0], g.gy[0]);
@@ -613,8 +612,11 @@ static int group_flush(hipStream_t st) {
 }
 
 template <typename T>
-static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, hipStream_t st) {
-  if (g_rec) {
+static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, GroupState* gs, hipStream_t st) {
+  if (gs) {
+    GemmGroup& g_grp = gs->grp;
+    int& g_rec_dtype = gs->rec_dtype;
+    int& g_rec_blocks = gs->rec_blocks;
     // recorded, not launched: 64x64 tiles, or 32x32 when that leaves most CUs idle; split-K as for a plain launch
     const long long nb = (long long)p.nb1 * p.nb2;
     const long long tiles64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * nb;
@@ -633,7 +635,7 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, hipStream_t st)
     }
     const long long gy = nb * p.splitk;
     if (tiles * gy > (1 << 20)) { stj_set_error("stj_gemm: problem too large for a group"); return STJ_EINVAL; }
-    if (g_grp.n == GG_MAX || (g_grp.n > 0 && g_rec_dtype != dtype)) { int e = group_flush(st); if (e) return e; }
+    if (g_grp.n == GG_MAX || (g_grp.n > 0 && g_rec_dtype != dtype)) { int e = group_flush(gs, st); if (e) return e; }
     const int i = g_grp.n++;
     g_rec_dtype = dtype;
     g_grp.p[i] = p;
@@ -726,8 +728,10 @@ extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias
                         long long sCb1, long long sCb2, long long ldc,
                         long long sBias1, long long sBias2, long long sRes1, long long sRes2, long long ldres,
                         int act, float alpha, int dtype, int c_f32, int accumulate, int splitk,
-                        int nkb, long long sAkb, long long sBkb, hipStream_t stream) {
+                        int nkb, long long sAkb, long long sBkb, void* group, hipStream_t stream) {
   if (M <= 0 || N <= 0 || nb1 <= 0 || nb2 <= 0) return STJ_OK;
+  GroupState* gs = reinterpret_cast<GroupState*>(group);
+  if (gs && gs->magic != GROUP_MAGIC) { stj_set_error("stj_gemm: group was not initialised by stj_gemm_group_begin"); return STJ_EINVAL; }
   if (K < 0 || splitk < 0 || nkb < 1) { stj_set_error("stj_gemm: bad K/splitk/nkb"); return STJ_EINVAL; }
   if (accumulate && !c_f32) { stj_set_error("stj_gemm: accumulate requires f32 output"); return STJ_EINVAL; }
   if (splitk != 1 && !accumulate) { stj_set_error("stj_gemm: splitk != 1 requires accumulate"); return STJ_EINVAL; }
@@ -753,25 +757,28 @@ extern "C" int stj_gemm(const void* A, const void* B, void* C, const float* bias
   if (nkb > 1) { p.vecA = p.vecA && (sAkb * es) % 16 == 0; p.vecB = p.vecB && (sBkb * es) % 16 == 0; }
   p.vecC = al(C, c_f32 ? 4 : es, ldc, sCb1, sCb2);
   p.vecR = res ? al(res, es, ldres, sRes1, sRes2) : 0;
-  if (dtype == STJ_BF16) return launch_gemm<bf16>(p, ta, tb, dtype, stream);
-  if (dtype == STJ_F16) return launch_gemm<f16>(p, ta, tb, dtype, stream);
-  if (dtype == STJ_F32) return launch_gemm<float>(p, ta, tb, dtype, stream);
+  if (dtype == STJ_BF16) return launch_gemm<bf16>(p, ta, tb, dtype, gs, stream);
+  if (dtype == STJ_F16) return launch_gemm<f16>(p, ta, tb, dtype, gs, stream);
+  if (dtype == STJ_F32) return launch_gemm<float>(p, ta, tb, dtype, gs, stream);
   stj_set_error("stj_gemm: bad dtype %d", dtype);
   return STJ_EINVAL;
 }
 
-// Group launch: between stj_gemm_group_begin() and stj_gemm_group_end(stream) on one host thread, stj_gemm calls are RECORDED
-// (arguments validated, `stream` ignored) and launched by _end as one kernel per GG_MAX problems of equal dtype.  The problems of a
-// group must be independent of each other (no output of one is an operand of another).
-extern "C" int stj_gemm_group_begin(void) {
-  if (g_rec) { stj_set_error("stj_gemm_group_begin: already recording"); return STJ_EINVAL; }
-  g_rec = true; g_grp.n = 0; g_rec_blocks = 0; g_rec_dtype = -1;
+// Group launch: stj_gemm calls that are handed a group (their last pointer argument) are RECORDED into it (arguments validated, their
+// `stream` only used if the group fills up and has to be flushed early) and launched by stj_gemm_group_end as one kernel per GG_MAX
+// problems of equal dtype.  The problems of a group must be independent of each other (no output of one is an operand of another).
+// `group` is caller-owned HOST memory of stj_gemm_group_workspace_bytes() bytes: the library itself holds no state.
+extern "C" long long stj_gemm_group_workspace_bytes(void) { return (long long)sizeof(GroupState); }
+extern "C" int stj_gemm_group_begin(void* group) {
+  if (!group) { stj_set_error("stj_gemm_group_begin: NULL group"); return STJ_EINVAL; }
+  GroupState* gs = reinterpret_cast<GroupState*>(group);
+  gs->magic = GROUP_MAGIC; gs->grp.n = 0; gs->rec_blocks = 0; gs->rec_dtype = -1;
   return STJ_OK;
 }
-extern "C" int stj_gemm_group_end(hipStream_t stream) {
-  if (!g_rec) { stj_set_error("stj_gemm_group_end: not recording"); return STJ_EINVAL; }
-  g_rec = false;
-  return group_flush(stream);
+extern "C" int stj_gemm_group_end(void* group, hipStream_t stream) {
+  GroupState* gs = reinterpret_cast<GroupState*>(group);
+  if (!gs || gs->magic != GROUP_MAGIC) { stj_set_error("stj_gemm_group_end: not a group"); return STJ_EINVAL; }
+  return group_flush(gs, stream);
 }
 
 // ---- column sums: out[n] += sum_m X[m, n]  (bias gradients; out is f32, accumulated atomically) ----

@@ -23,6 +23,7 @@ def call(name, *args):
 
 
 GROUP_GEMMS = os.environ.get('STJ_GEMM_GROUP', '1') != '0'
+_GROUP = [None, None]       # [the open group's handle (None: stj_gemm launches at once), its host buffer]
 # Layers with at least this many rows launch their input and weight gradient separately: each then runs with 192-element k-tiles
 # (gemm_deepk_kernel: a third of the barrier-bound links), which the grouped kernel does not have.  Measured, scenes/s: no grouping
 # 943, limit 1024 rows 939, limit 16384 rows (every small layer grouped) 927.
@@ -40,13 +41,19 @@ class gemm_group:
         self.on = self.enabled and GROUP_GEMMS and prof.ACTIVE is None and _GROUP_DEPTH[0] == 0
         _GROUP_DEPTH[0] += 1
         if self.on:
-            _raw_call('stj_gemm_group_begin')
+            if _GROUP[1] is None:       # caller-owned host memory the C ABI records the group in (the library keeps no state)
+                from ._lib import lib
+                _GROUP[1] = ctypes.create_string_buffer(int(lib().stj_gemm_group_workspace_bytes()))
+            h = ctypes.cast(_GROUP[1], vp)
+            _raw_call('stj_gemm_group_begin', h)
+            _GROUP[0] = h
         return self
 
     def __exit__(self, et, ev, tb):
         _GROUP_DEPTH[0] -= 1
         if self.on:
-            _raw_call('stj_gemm_group_end', _st())
+            h, _GROUP[0] = _GROUP[0], None
+            _raw_call('stj_gemm_group_end', h, _st())
         return False
 
 
@@ -176,9 +183,6 @@ _SERIAL = False
 def set_serial(flag):
     """True: weight-gradient launches stay on the current stream (per-kernel timing with HIP events needs kernels to run alone)."""
     global _SERIAL
-    if bool(flag) != _SERIAL:
-        # alone on the GPU the large weight-gradient launches take all CUs; in the concurrent step half of them (see the header)
-        call('stj_upconv_wgrad_share', 256 if flag else 0)
     _SERIAL = bool(flag)
 
 
@@ -285,7 +289,7 @@ def _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act
     call('stj_gemm', _p(A), _p(B), _p(C), _p(bias), _p(res), _p(colsum), M, N, K, nb[0], nb[1],
          sA[0], sA[1], sA[2], sA[3], sB[0], sB[1], sB[2], sB[3], sC[0], sC[1], sC[2],
          sBias[0], sBias[1], sRes[0], sRes[1], sRes[2], act, float(alpha), dt, c_f32, accumulate, splitk,
-         kseg[0], kseg[1], kseg[2], _st())
+         kseg[0], kseg[1], kseg[2], _GROUP[0], _st())
 
 
 def _splitk(M_out, N_out, Kdim):
@@ -1362,7 +1366,8 @@ def _upconv_backward_tail(ctx, x, dpre, wd, need_dx):
             dbp, nparts, own = pb.part[0], pb.part[1], False
         else:                    # (~1000 workgroups would queue on Cout addresses otherwise)
             dbp, nparts, own = torch.zeros(_DB_PARTS * Cout, dtype=torch.float32, device=x.device), _DB_PARTS, True
-        call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), nparts, F_, Hi, Wi, Cin, Cout, dt, _st())
+        # alone on the GPU (serial mode) the large weight-gradient launches take all CUs; in the concurrent step half of them
+        call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), nparts, F_, Hi, Wi, Cin, Cout, 256 if _SERIAL else 128, dt, _st())
         call('stj_upconv_fold', _p(dweff), _p(pw.grad), Cin, Cout, _st())
         if own:
             pb.grad.add_(dbp.view(nparts, Cout).sum(0))

@@ -56,7 +56,7 @@ def _upconv(kind):
         elif kind == 'dgrad':
             F, Hi, Wi, Cin, Cout, dt = a[4], a[5], a[6], a[7], a[8], a[9]
         else:
-            F, Hi, Wi, Cin, Cout, dt = a[5], a[6], a[7], a[8], a[9], a[10]
+            F, Hi, Wi, Cin, Cout, dt = a[5], a[6], a[7], a[8], a[9], a[11]
         es = _es(dt)
         fl = 2.0 * 9 * Cin * Cout * 4 * Hi * Wi * F
         by = es * F * Hi * Wi * (Cin + 4 * Cout) + es * 16 * Cin * Cout

@@ -46,4 +46,4 @@ for li, (F, Hi, Cin, Cout) in enumerate(LAYERS):
     run('fwd', lambda: call('stj_upconv_fwd', _p(x), _p(wf), _p(b), _p(y), F, Hi, Hi, Cin, Cout, 2, dt, _st()))
     run('dgrad', lambda: call('stj_upconv_dgrad', _p(dp), _p(wd), _p(dx), None, F, Hi, Hi, Cin, Cout, dt, _st()))
     run('dgradE', lambda: call('stj_upconv_dgrad', _p(dp), _p(wd), _p(dx), _p(x), F, Hi, Hi, Cin, Cout, dt, _st()))
-    run('wgrad', lambda: call('stj_upconv_wgrad', _p(x), _p(dp), _p(dweff), _p(None if os.environ.get('NODB') else dbp), NP, F, Hi, Hi, Cin, Cout, dt, _st()))
+    run('wgrad', lambda: call('stj_upconv_wgrad', _p(x), _p(dp), _p(dweff), _p(None if os.environ.get('NODB') else dbp), NP, F, Hi, Hi, Cin, Cout, 256, dt, _st()))

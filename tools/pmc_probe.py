@@ -26,6 +26,6 @@ for _ in range(2):
     dst.copy_(cal)                                                     # calibration: 268,435,456 B read, same written
     call('stj_upconv_fwd', _p(x), _p(wf), _p(b), _p(y), F, Hi, Hi, Cin, Cout, 2, 1, _st())
     call('stj_upconv_dgrad', _p(dp), _p(wd), _p(dx), _p(x), F, Hi, Hi, Cin, Cout, 1, _st())
-    call('stj_upconv_wgrad', _p(x), _p(dp), _p(dweff), _p(db), 1, F, Hi, Hi, Cin, Cout, 1, _st())
+    call('stj_upconv_wgrad', _p(x), _p(dp), _p(dweff), _p(db), 1, F, Hi, Hi, Cin, Cout, 256, 1, _st())
 torch.cuda.synchronize()
 print('algorithmic bytes: fwd', x.numel() * 2 + y.numel() * 2, 'dgrad(+Xelu)', dp.numel() * 2 + 2 * x.numel() * 2, 'wgrad', x.numel() * 2 + dp.numel() * 2)
