@@ -159,6 +159,7 @@ int stj_swin_attn_bwd(const void* x, const void* dy, const void* qkv, const floa
  *     (dW2 = hd^T du2 + colsum, dW1 = n1^T dpre + colsum, dWo[h] = so_h^T dv1, dWq[h] = query^T dq_h);
  *     "+=": dg1, dbe1, dbo [128], dg2, dbe2 [384] of set z at + z * zstride. */
 long long stj_xattn_pack_workspace_bytes(int dtype);
+long long stj_xattn_pack_tail_workspace_bytes(int dtype);    /* once behind the Z streams: the kernels copy fixed-size pieces */
 int stj_xattn_pack(const float* wq, const float* wo, const float* w1, const float* w2, long long zstride, int Z, void* pack, int dtype,
                    hipStream_t stream);
 int stj_xattn_fwd(const void* query, const void* k, const void* v, const int* kvalid, const void* pack, const float* bo,

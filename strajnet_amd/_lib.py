@@ -49,6 +49,7 @@ SIGNATURES = {
     'stj_swin_attn_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, ci, cf, ci, vp],
     'stj_swin_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, cl, ci, ci, ci, ci, vp, ci, cf, ci, vp],
     'stj_xattn_pack_workspace_bytes': [ci],
+    'stj_xattn_pack_tail_workspace_bytes': [ci],
     'stj_xattn_pack': [vp, vp, vp, vp, cl, ci, vp, ci, vp],
     'stj_xattn_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cl, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, ci, cf, ci, vp],
     'stj_xattn_bwd_workspace_bytes': [ci, ci, ci],

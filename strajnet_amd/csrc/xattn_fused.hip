@@ -28,16 +28,26 @@ template <typename T> struct Geo {
   static constexpr int KQ = ES == 2 ? 192 : 96;            // `in` rows per Wq chunk
   static constexpr int NQC = CB / KQ;                      // chunks per head
   static constexpr int QCH = KQ * LDQ;                     // elements per Wq chunk
-  static constexpr int LDO = O1 + (ES == 2 ? 8 : 4);       // Wo head image [48][LDO] (k = head column rows, m = out contiguous)
+  // row strides of the images read with ds_read_b64_tr_b16 (4 k-rows x 32 bytes per 16-lane group): stride = 8 dwords (mod 64) keeps the
+  // four rows on distinct banks; C + 8 elements (stride 4 mod 64 for C = 128, 384) measured 2.2 us per FFN chunk, i.e. LDS-conflict bound
+  static constexpr int LDO = O1 + (ES == 2 ? 16 : 4);      // Wo head image [48][LDO] (k = head column rows, m = out contiguous)
   static constexpr int OCH = HP * LDO;
   static constexpr int HC = KSTEP;                         // hidden columns per FFN chunk (one MFMA k-step)
   static constexpr int NFC = F1 / HC;
   static constexpr int LD1 = HC + 4;                       // W1 slice image [128][LD1]
-  static constexpr int LD2 = CB + (ES == 2 ? 8 : 4);       // W2 slice image [HC][LD2]
+  static constexpr int LD2 = CB + (ES == 2 ? 16 : 4);      // W2 slice image [HC][LD2]
   static constexpr int FCH = O1 * LD1 + HC * LD2;
   static constexpr int OFF_Q = 0, OFF_O = NH * NQC * QCH, OFF_F = OFF_O + NH * OCH;
   static constexpr int STREAM = OFF_F + NFC * FCH;         // elements per weight set
   static constexpr int BUF = cmax(QCH, cmax(OCH, FCH));
+  // the forward kernel stages every chunk as a FIXED-size copy of BUFE elements (whole 4 KB pieces: 256 threads x 16 bytes), reading
+  // past the end of the shorter chunks into what follows them in the stream (stj_xattn_pack pads the tail): no size cases, no guards
+  static constexpr int BUFE = (BUF * ES + 4095) / 4096 * 4096 / ES;
+  static constexpr int NCH = NH * NQC + NH + NFC;          // chunks per set: Wq (head, k-part), Wo (head), FFN slices
+  static constexpr int FI = NH * NQC + NH;                 // index of the first FFN chunk
+  __host__ __device__ static constexpr long long chunk_off(int i) {
+    return i < NH * NQC ? (long long)i * QCH : (i < FI ? (long long)OFF_O + (long long)(i - NH * NQC) * OCH : (long long)OFF_F + (long long)(i - FI) * FCH);
+  }
   static constexpr int LDK = HP + 4;                       // per-head K / V tiles [64][LDK]
   static constexpr int KS1 = O1 / KSTEP;                   // k-steps over the 128 projection outputs
   static constexpr int QS = NH * HP;                       // row stride of the saved q / O / dq tensors (3 x 48, pads zero)
@@ -145,6 +155,22 @@ template <typename T> struct Stage {
         if ((i + 1) * 256 <= NV || q < NV) d[q] = r[i];
       }
     }
+  }
+};
+
+// fixed-size variant (forward kernel): BUFE elements per chunk, every load unconditional, TWO chunks in flight (two of these)
+template <typename T> struct StageF {
+  static constexpr int NR = Geo<T>::BUFE * (int)sizeof(T) / 16 / 256;
+  uint4 r[NR];
+  __device__ __forceinline__ void issue(const T* src, int tid) {
+    const uint4* s = reinterpret_cast<const uint4*>(src) + tid;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { const uint4 t = s[i * 256]; r[i] = make_uint4(t.x, t.y, t.z, t.w); }   // (component-wise: whole-struct copies keep r[] in scratch)
+  }
+  __device__ __forceinline__ void commit(T* dst, int tid) const {
+    uint4* d = reinterpret_cast<uint4*>(dst) + tid;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) d[i * 256] = make_uint4(r[i].x, r[i].y, r[i].z, r[i].w);
   }
 };
 
@@ -294,7 +320,8 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(Args p) {
   T* Kt = reinterpret_cast<T*>(xa_smem);
   T* Vt = Kt + NKEY * G::LDK;
   T* buf0 = Vt + NKEY * G::LDK;
-  int* kval = reinterpret_cast<int*>(buf0 + 2 * G::BUF);
+  int* kval = reinterpret_cast<int*>(buf0 + 2 * G::BUFE);
+  float* b1s = reinterpret_cast<float*>(kval + NKEY);         // FFN1 bias in LDS: a global load inside the chunk loop would wait for the weight prefetch issued just before it
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, ln = lane & 15;
   const int z = blockIdx.x % p.Z, rest = blockIdx.x / p.Z, tiles = p.HW / TOK, tile = rest % tiles, b = rest / tiles;
   const int tok = tile * TOK + wv * 16 + ln;
@@ -306,8 +333,14 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(Args p) {
   const bool train = p.rng != nullptr && p.p_drop > 0.f;
   const float dsc = train ? 1.0f / (1.0f - p.p_drop) : 1.f;
 
-  Stage<T> stg;
-  stg.template issue<G::QCH>(wz + G::OFF_Q, tid);
+  // weight chunks: two in flight in registers (st[i & 1] holds chunk i), committed to LDS buffer i & 1 when chunk i - 2 has been consumed
+  // (two named objects and lambdas that take one by reference: an array indexed by the chunk parity stayed in scratch memory)
+  StageF<T> sA, sB;
+  T* const bufA = buf0;
+  T* const bufB = buf0 + G::BUFE;
+  static_assert(G::NQC % 2 == 0 && (NH * G::NQC) % 2 == 0 && G::NFC % 2 == 0, "chunk parities are fixed per phase");
+  sA.issue(wz + G::chunk_off(0), tid);
+  sB.issue(wz + G::chunk_off(1), tid);
   KvStage<T> kvs;
   kvs.issue(reinterpret_cast<const T*>(p.k), reinterpret_cast<const T*>(p.v), kvrow0, 0, tid);
   typename Mma<T>::Frag xa[KS];
@@ -321,33 +354,31 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(Args p) {
     stf((t ? Vt : Kt) + (rem / (G::LDK - HS)) * G::LDK + HS + rem % (G::LDK - HS), 0.f);
   }
   if (tid < NKEY) kval[tid] = p.kvalid ? p.kvalid[(long long)b * NKEY + tid] : 1;
+  for (int i = tid; i < F1; i += 256) b1s[i] = p.b1[zo + i];
 
   const float scale = 0.15430334996209191f;        // 42^-1/2 (tfa: query /= sqrt(head_size))
   f32x4 of[NH][3];
-  int cur = 0;
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     f32x4 qf[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) qf[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < G::NQC; ++c) {
-      T* W = buf0 + cur * G::BUF;
-      stg.template commit<G::QCH>(W, tid);
+    auto q_step = [&](int c, StageF<T>& sg, T* W) __attribute__((always_inline)) {
+      const int gi = h * G::NQC + c;
+      sg.commit(W, tid);
       // every wave is past the previous head's attention once it has passed the barrier of chunk 0: the tiles may be rewritten now
       if (c == 1) kvs.commit(Kt, Vt, tid);
       __syncthreads();
-      if (c + 1 < G::NQC) stg.template issue<G::QCH>(wz + G::OFF_Q + (h * G::NQC + c + 1) * G::QCH, tid);
-      else if (h + 1 < NH) stg.template issue<G::QCH>(wz + G::OFF_Q + (h + 1) * G::NQC * G::QCH, tid);
-      else stg.template issue<G::OCH>(wz + G::OFF_O, tid);
+      sg.issue(wz + G::chunk_off(gi + 2), tid);
       if (c == 1 && h + 1 < NH) kvs.issue(reinterpret_cast<const T*>(p.k), reinterpret_cast<const T*>(p.v), kvrow0, h + 1, tid);
 #pragma unroll
       for (int kk = 0; kk < G::KQ / KSTEP; ++kk)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           qf[j] = Mma<T>::mma(Mma<T>::load_tr(W, G::LDQ, 16 * j, kk * KSTEP, lane), xa[c * (G::KQ / KSTEP) + kk], qf[j]);
-      cur ^= 1;
-    }
+    };
+#pragma unroll
+    for (int c = 0; c < G::NQC; c += 2) { q_step(c, sA, bufA); q_step(c + 1, sB, bufB); }
     if (p.sq) {
       T* sq = reinterpret_cast<T*>(p.sq) + zrow * G::QS + HP * h + 4 * g;
 #pragma unroll
@@ -389,21 +420,18 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(Args p) {
     const float4 bv = *reinterpret_cast<const float4*>(p.bo + zo + 16 * f + 4 * g);
     o1[f] = (f32x4){bv.x, bv.y, bv.z, bv.w};
   }
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    T* W = buf0 + cur * G::BUF;
-    stg.template commit<G::OCH>(W, tid);
+  auto o_step = [&](int h, StageF<T>& sg, T* W) __attribute__((always_inline)) {
+    const int gi = NH * G::NQC + h;
+    sg.commit(W, tid);
     __syncthreads();
-    if (h + 1 < NH) stg.template issue<G::OCH>(wz + G::OFF_O + (h + 1) * G::OCH, tid);
-    else stg.template issue<G::FCH>(wz + G::OFF_F, tid);
-    {
-      HeadOp<T> oop;
-      oop.from_acc(of[h]);
+    sg.issue(wz + G::chunk_off(gi + 2), tid);
+    HeadOp<T> oop;
+    oop.from_acc(of[h]);
 #pragma unroll
-      for (int f = 0; f < O1 / 16; ++f) o1[f] = k48_tr<T>(W, G::LDO, 16 * f, oop, lane, o1[f]);
-    }
-    cur ^= 1;
-  }
+    for (int f = 0; f < O1 / 16; ++f) o1[f] = k48_tr<T>(W, G::LDO, 16 * f, oop, lane, o1[f]);
+  };
+  static_assert(NH == 3, "three Wo chunks: A, B, A");
+  o_step(0, sA, bufA); o_step(1, sB, bufB); o_step(2, sA, bufA);
   if (p.sv1) {
     T* s1 = reinterpret_cast<T*>(p.sv1) + zrow * O1 + 4 * g;
 #pragma unroll
@@ -441,17 +469,16 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(Args p) {
   f32x4 o2[CB / 16];
 #pragma unroll
   for (int f = 0; f < CB / 16; ++f) o2[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int c = 0; c < G::NFC; ++c) {
-    T* W1s = buf0 + cur * G::BUF;
+  auto ffn_step = [&](int c, StageF<T>& sg, T* W1s) __attribute__((always_inline)) {
     T* W2s = W1s + O1 * G::LD1;
-    stg.template commit<G::FCH>(W1s, tid);
+    sg.commit(W1s, tid);
     __syncthreads();
-    if (c + 1 < G::NFC) stg.template issue<G::FCH>(wz + G::OFF_F + (long long)(c + 1) * G::FCH, tid);
+    // (unconditional: a staging array written under a condition stays in scratch memory; past the end the last chunk is simply fetched again)
+    sg.issue(wz + G::OFF_F + (long long)(c + 2 < G::NFC ? c + 2 : G::NFC - 1) * G::FCH, tid);
     f32x4 a1[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
-      const float4 bv = *reinterpret_cast<const float4*>(p.b1 + zo + c * G::HC + 16 * d + 4 * g);
+      const float4 bv = *reinterpret_cast<const float4*>(b1s + c * G::HC + 16 * d + 4 * g);
       a1[d] = (f32x4){bv.x, bv.y, bv.z, bv.w};
     }
 #pragma unroll
@@ -468,7 +495,12 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(Args p) {
     const typename Ch<T>::Frag hf = Ch<T>::from_acc(a1);
 #pragma unroll
     for (int f = 0; f < CB / 16; ++f) o2[f] = Mma<T>::mma(Ch<T>::ldA_tr(W2s, G::LD2, 16 * f, 0, lane), hf, o2[f]);
-    cur ^= 1;
+  };
+  static_assert(G::FI % 2 == 1, "first FFN chunk on the B stage");
+#pragma unroll 1
+  for (int c = 0; c < G::NFC; c += 2) {
+    ffn_step(c, sB, bufB);              // (the first FFN chunk has odd index FI)
+    ffn_step(c + 1, sA, bufA);
   }
 
   // ---- epilogue: u2 = dropout(acc + b2) ; y = LN(u2) + query
@@ -562,7 +594,7 @@ template <typename T> struct BGeo {
   static constexpr int NBUF = sizeof(T) == 2 ? 2 : 1;               // f32: one weight buffer (LDS budget), two barriers per chunk
   static constexpr int LDP = NKEY + (sizeof(T) == 2 ? 8 : 4);       // Pd / dS tiles [64 tokens][LDP] (k = token rows, m = key contiguous)
   static constexpr int LDT = HP + 4;                                // dO / q tiles [64 tokens][LDT]
-  static constexpr int NRED = 3 * O1 + 2 * CB;
+  static constexpr int NRED = 3 * O1 + 2 * CB + F1;             // LayerNorm / bias gradient sums + the FFN1 bias copy
   static constexpr int LDS_BYTES = (2 * NKEY * G::LDK + NBUF * G::BUF + 2 * TOK * LDP + 2 * TOK * LDT) * (int)sizeof(T) + NKEY * 4 + NRED * 4;
 };
 template <typename T> __device__ __forceinline__ void unpackB(const typename Mma<T>::Frag& f, float* v) {
@@ -609,6 +641,7 @@ __global__ __launch_bounds__(256, 1) void xattn_bwd_kernel(Args p) {
   T* QT = OT + TOK * BG::LDT;
   int* kval = reinterpret_cast<int*>(QT + TOK * BG::LDT);
   float* red = reinterpret_cast<float*>(kval + NKEY);          // [dg1 128 | dbe1 128 | dbo 128 | dg2 384 | dbe2 384]
+  float* b1s = red + 3 * O1 + 2 * CB;                          // FFN1 bias (LDS copy: no global load inside the chunk loop)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, ln = lane & 15;
   const int z = blockIdx.x % p.Z, rest = blockIdx.x / p.Z, tiles = p.HW / TOK, tile = rest % tiles, b = rest / tiles;
   const int tok = tile * TOK + wv * 16 + ln;
@@ -625,7 +658,8 @@ __global__ __launch_bounds__(256, 1) void xattn_bwd_kernel(Args p) {
   stg.template issue<G::FCH>(wz + G::OFF_F, tid);
   KvStage<T> kvs;
   kvs.issue(reinterpret_cast<const T*>(p.k), reinterpret_cast<const T*>(p.v), kvrow0, 0, tid);
-  for (int i = tid; i < BG::NRED; i += 256) red[i] = 0.f;
+  for (int i = tid; i < BG::NRED - F1; i += 256) red[i] = 0.f;
+  for (int i = tid; i < F1; i += 256) b1s[i] = p.b1[zo + i];
   for (int i = tid; i < 2 * NKEY * (G::LDK - HS); i += 256) {
     const int t = i / (NKEY * (G::LDK - HS)), rem = i % (NKEY * (G::LDK - HS));
     stf((t ? Vt : Kt) + (rem / (G::LDK - HS)) * G::LDK + HS + rem % (G::LDK - HS), 0.f);
@@ -757,7 +791,7 @@ __global__ __launch_bounds__(256, 1) void xattn_bwd_kernel(Args p) {
     f32x4 a1[ND], a3[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
-      const float4 bv = *reinterpret_cast<const float4*>(p.b1 + zo + c * G::HC + 16 * d + 4 * g);
+      const float4 bv = *reinterpret_cast<const float4*>(b1s + c * G::HC + 16 * d + 4 * g);
       a1[d] = (f32x4){bv.x, bv.y, bv.z, bv.w};
       a3[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -1003,7 +1037,7 @@ template <typename T> static int launch_bwd(const Args& a, hipStream_t st) {
   return stj_check_launch("stj_xattn_bwd");
 }
 
-template <typename T> static int lds_bytes_fwd() { return (2 * NKEY * Geo<T>::LDK + 2 * Geo<T>::BUF) * (int)sizeof(T) + NKEY * 4; }
+template <typename T> static int lds_bytes_fwd() { return (2 * NKEY * Geo<T>::LDK + 2 * Geo<T>::BUFE) * (int)sizeof(T) + NKEY * 4 + F1 * 4; }
 
 template <typename T> static int launch_fwd(const Args& a, hipStream_t st) {
   static bool attr = false;
@@ -1022,6 +1056,10 @@ template <typename T> static int launch_fwd(const Args& a, hipStream_t st) {
 // bytes of one set's packed weight stream (stj_xattn_pack writes Z of them back to back)
 extern "C" long long stj_xattn_pack_workspace_bytes(int dtype) {
   return stj_is16(dtype) ? (long long)xat::Geo<bf16>::STREAM * 2 : (long long)xat::Geo<float>::STREAM * 4;
+}
+// bytes the caller adds ONCE behind the Z streams: the kernels copy fixed-size pieces and read this far past the last chunk
+extern "C" long long stj_xattn_pack_tail_workspace_bytes(int dtype) {
+  return stj_is16(dtype) ? (long long)xat::Geo<bf16>::BUFE * 2 : (long long)xat::Geo<float>::BUFE * 4;
 }
 // wq [3,384,42], wo [3,42,128], w1 [128,512], w2 [512,384] of set 0 (f32 masters; set z lies zstride elements further) -> pack
 extern "C" int stj_xattn_pack(const float* wq, const float* wo, const float* w1, const float* w2, long long zstride, int Z, void* pack, int dtype,

@@ -918,8 +918,8 @@ def xattn_pack(ps, zstride, Z, dtype, out=None):
     from ._lib import lib
     dev = ps['wq'].master.device
     nbytes = int(lib().stj_xattn_pack_workspace_bytes(DTYPE_CODE[dtype]))
-    if out is None:
-        out = torch.empty(Z * nbytes, dtype=torch.uint8, device=dev)
+    if out is None:         # (+ the tail the kernels' fixed-size chunk copies may read past the last set)
+        out = torch.zeros(Z * nbytes + int(lib().stj_xattn_pack_tail_workspace_bytes(DTYPE_CODE[dtype])), dtype=torch.uint8, device=dev)
     call('stj_xattn_pack', _p(ps['wq'].master), _p(ps['wo'].master), _p(ps['w1'].master), _p(ps['w2'].master), zstride, Z, _p(out),
          DTYPE_CODE[dtype], _st())
     return out
