@@ -253,16 +253,25 @@ def parity_extras(model, loss_fn, x, B, dev, with_cpu):
         out = fwd(m32, x, True)
         d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
         d.total.backward()
-    step32()
+    graphed32 = None
+    try:                                     # the same capture as the headline step (one hipGraph per step)
+        from strajnet_amd.graph import GraphedTrainStep
+        graphed32 = GraphedTrainStep(m32, loss_fn, x)
+        step = graphed32
+    except Exception:
+        step = step32
+    step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(3):
-        step32()
+    for _ in range(5):
+        step()
     torch.cuda.synchronize()
-    dt32 = (time.perf_counter() - t0) / 3
+    dt32 = (time.perf_counter() - t0) / 5
     res = {'parity_mode': {'dtype': 'f32', 'value': round(B / dt32, 2), 'unit': 'scenes/s', 'ms_per_step': round(dt32 * 1e3, 2),
-                           'note': 'same train step, f32 storage + exact-f32 MFMA, eager (no hipGraph), no optimizer',
+                           'note': 'same train step, f32 storage + exact-f32 MFMA (v_mfma_f32_16x16x4_f32), ' +
+                                   ('replayed hipGraph' if graphed32 is not None else 'eager (capture failed)') + ', no optimizer',
                            'max_abs_vs_oracle': None}}
+    del graphed32
     with torch.no_grad():
         y16 = fwd(model, x).float()
         y32 = fwd(m32, x).float()

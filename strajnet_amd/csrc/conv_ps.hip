@@ -198,15 +198,10 @@ static bool fwd_ps_launch(const void* X, const void* Wf, const float* bias, void
 
 template <typename T>
 static bool fwd_ps_try_t(const void* X, const void* Wf, const float* bias, void* Y, const void* R1, void* Y2, const void* R2, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
-  static int fn = -1;
-  if (fn < 0) { const char* e = getenv("STJ_PS_FN"); fn = e ? atoi(e) : 0; }
   // measured (tools/bench_conv.py, us for 384->192 @16^2 / 192->128 @32^2, F = 64; generic kernel 113 / 140): FN = 2, two workgroups
   // per CU: 64 / 93;  FN = 3: 84 / 137;  FN = 4 (one wave per SIMD): 105 / 128.  At FN = 2 the kernel moves ~6 TB/s from L2 (each
   // workgroup streams 32 KB of weights + 11.5 KB of halo per 4.2 MFLOP chunk), which is where the 64x64 GEMM tiles saturate too.
-  int use = fn ? fn : 2;
-  if (Cout % (16 * use)) return false;
-  if (use == 4) return fwd_ps_launch<T, 4, 1>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
-  if (use == 3) return fwd_ps_launch<T, 3, 1>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
+  if (Cout % 32) return false;
   return fwd_ps_launch<T, 2, 2>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
 }
 // true when this kernel took the problem: 16-bit, ELU, Cin a multiple of 32 above the weight-stationary range

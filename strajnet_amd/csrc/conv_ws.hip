@@ -450,8 +450,7 @@ static bool ws2_launch_t(const void* X, const void* Wf, const float* bias, void*
   int nblk = 256 / ct;
   if (nblk > ntiles) nblk = ntiles;
   if (nblk < 1) nblk = 1;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("STJ_WS2_DBG"); dbg = e ? atoi(e) : 0; }      // ablation switches (profiling only)
+  const int dbg = 0;      // (role-ablation mask of the kernel; profiling builds only)
   hipLaunchKernelGGL((upconv_fwd_ws2_kernel<T, KS, NF, EXACT>), dim3(nblk, ct), dim3(512), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y, F, Hi, Wi, Cout, ntiles, dbg);
   return true;
 }
@@ -469,15 +468,10 @@ template <typename T>
 static bool upconv_fwd_ws_try_t(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        hipStream_t st) {
   if (Cout % 8 || act != ACT_ELU) return false;
-  static int variant = -1;
-  if (variant < 0) { const char* e = getenv("STJ_WS_VARIANT"); variant = e ? atoi(e) : 3; }
-  // Cin=96: the 2-waves-per-SIMD variant spills (144 weight VGPRs + prefetch); one wave per SIMD measured faster (386 vs 432 us)
-  if (variant == 3 || variant == 4) {      // wave-specialised kernel (compute + mover waves)
-    if (Cin == 96) return ws2_launch<T, 3, 3>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
-    if (Cin == 128 && variant == 4) return ws2_launch<T, 4, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
-  }
-  if (Cin == 96) return variant == 2 ? ws_launch<T, 3, 3, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st) : ws_launch<T, 3, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
-  if (Cin == 128) return variant == 0 ? ws_launch<T, 4, 3, 1>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st) : ws_launch<T, 4, 2, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
+  // Cin = 96: the wave-specialised kernel (compute + mover waves).  Cin = 128: one role, two workgroups per CU (the wave-specialised
+  // form measured 139 vs 142 us there; the single-workgroup variants 386 vs 432 us: superseded, removed)
+  if (Cin == 96) return ws2_launch<T, 3, 3>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
+  if (Cin == 128) return ws_launch<T, 4, 2, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
   return false;
 }
 bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
@@ -841,8 +835,7 @@ static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* 
     hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6, CW>), dim3((strips + 7) / 8 * 8 * 4), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, cpb, strips, 1);
   } else {
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    static int tgt = -1;
-    if (tgt < 0) { const char* e = getenv("STJ_WGRAD_TR_BLOCKS"); tgt = e ? atoi(e) : 1024; }
+    const int tgt = 1024;      // workgroups (swept: more or fewer are equal or worse)
     int strips = (int)min(nchunks, (long long)max(1, tgt / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
@@ -1568,8 +1561,7 @@ bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, floa
   static int ver = -1;
   if (ver < 0) { const char* e = getenv("STJ_OUTCONV_V"); ver = e ? atoi(e) : 2; }
   if (ver == 2) {
-    static int dbg = -1, nbm = 768;
-    if (dbg < 0) { const char* e = getenv("STJ_OC_DBG"); dbg = e ? atoi(e) : 0; e = getenv("STJ_OC_NB"); if (e) nbm = atoi(e); }
+    const int dbg = 0, nbm = 768;
     const int nb = min(ntiles, nbm);
     if (dtype == STJ_F16)
       hipLaunchKernelGGL((outconv_fwd_mfma2_kernel<f16, 48>), dim3(nb), dim3(256), 0, st, (const f16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps, dbg);
@@ -2186,8 +2178,7 @@ static bool dgrad_ws2_launch(const void* dP, const void* Wd, void* dX, const voi
   }
   const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
   const int nblk = ntiles < 256 ? ntiles : 256;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("STJ_WS2_DBG"); dbg = e ? atoi(e) : 0; }      // ablation switches (profiling only)
+  const int dbg = 0;      // (role-ablation mask of the kernel; profiling builds only)
   hipLaunchKernelGGL((upconv_dgrad_ws2_kernel<ELU, V3>), dim3(nblk), dim3(512), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX, (const bf16*)Xelu, F, Hi, Wi, ntiles, dbg);
   return true;
 }

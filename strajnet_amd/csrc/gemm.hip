@@ -531,8 +531,8 @@ static bool rs_launch(const GemmArgs& p, bool tb, hipStream_t st) {
 template <typename T>
 static bool linear_rs_try(const GemmArgs& p, bool ta, bool tb, hipStream_t st) {
   static int enabled = -1;
-  static int rs_min_m = 16384;     // measured: wins at 32768 tokens (1.3-1.7x), loses at <= 8192 (too few 128-row blocks for 256 CUs)
-  if (enabled < 0) { const char* e = getenv("STJ_NO_RS"); enabled = !(e && atoi(e)); e = getenv("STJ_RS_MIN_M"); if (e) rs_min_m = atoi(e); }
+  const int rs_min_m = 16384;      // measured: wins at 32768 tokens (1.3-1.7x), loses at <= 8192 (too few 128-row blocks for 256 CUs)
+  if (enabled < 0) { const char* e = getenv("STJ_NO_RS"); enabled = !(e && atoi(e)); }
   if (!enabled || ta || p.c_f32 || p.accumulate || p.splitk != 1 || p.colsum || p.nkb != 1) return false;
   if (p.M < rs_min_m || p.K % 32 || p.N % 8 || p.sAk != 1 || !p.vecA || !p.vecB || !p.vecC) return false;
   if (p.act != ACT_NONE && p.act != ACT_ELU) return false;
@@ -667,23 +667,15 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, GroupState* gs,
   else cfg = 2;
   // Few rows (the 16x16 Swin stage, the 64-agent encoder): 64x64 tiles leave most of the 256 CUs idle and a plain GEMM cannot
   // split K.  32x32 tiles quadruple the workgroups.
-  { static int small = -1; if (small < 0) { const char* e = getenv("STJ_GEMM_SMALL"); small = e ? atoi(e) : 256; }
-    if (!p.accumulate && tiles64 < small && p.M >= 32 && p.N >= 32) cfg = 3; }
-  { static int f = -2; if (f == -2) { const char* e = getenv("STJ_GEMM_CFG"); f = e ? atoi(e) : -1; } if (f >= 0 && !p.accumulate) cfg = f; }
+  if (!p.accumulate && tiles64 < 256 && p.M >= 32 && p.N >= 32) cfg = 3;
   // Weight gradients (split-K, f32 atomics): measured (tools/bench_gemm.py, STJ_WGRAD_CFG) 96x128 / 128x96 / 96x96 tiles -- exact covers
   // of the 96 * 2^i Swin widths, 3x the MFMAs per barrier pair -- and 128x128 tiles against the 64x64 default: slower on every
   // shape but two (e.g. [192x576] over 8192 rows 32.8 vs 18.8 us, [96x384] over 32768 rows 31.8 vs 28.7 us; 128x128: 38-47 us), 828
   // vs 860 scenes/s end to end: these launches are bound by how many workgroups are in flight, not by what one of them does.
-  if (p.accumulate) {
-    static int wf = -2;
-    if (wf == -2) { const char* e = getenv("STJ_WGRAD_CFG"); wf = e ? atoi(e) : -1; }
-    if (wf >= 0) cfg = wf;
-  }
   if (p.splitk == 0) {            // auto split-K (accumulating GEMMs only): aim at ~2 blocks per CU
     auto ntl = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * nb; };
     const long long tiles = cfg == 0 ? tiles128 : (cfg == 1 ? ntl(128, 64) : (cfg == 4 ? ntl(96, 128) : (cfg == 5 ? ntl(128, 96) : (cfg == 6 ? ntl(96, 96) : tiles64))));
-    static int tgt = -1, cap = -1;
-    if (tgt < 0) { const char* e = getenv("STJ_SPLITK_TGT"); tgt = e ? atoi(e) : 768; e = getenv("STJ_SPLITK_CAP"); cap = e ? atoi(e) : 96; }
+    const int tgt = 768, cap = 96;      // (swept repeatedly: within noise around these)
     long long s = (tgt + tiles - 1) / tiles;
     if (s > cap) s = cap;                 // bound same-address atomic contention
     if (s > ktiles / 2) s = ktiles / 2;

@@ -550,9 +550,7 @@ template <typename T>
 static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
   // rows per block = 64 * RF: two row fragments per wave halve the weight-fragment LDS reads per MFMA, but the grid must still cover
   // the 256 CUs (32768 rows: 256 blocks of 128; 8192 rows: 128 blocks of 64)
-  static int rf_force = -1;
-  if (rf_force < 0) { const char* e = getenv("STJ_MLP_RF"); rf_force = e ? atoi(e) : 0; }
-  const bool two = rf_force ? rf_force == 2 : a.M >= 256 * 128;
+  const bool two = a.M >= 256 * 128;
   switch (C) {
     case 96: return two ? mlp_launch<T, 96, 2>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
     case 192: return two ? mlp_launch<T, 192, 2>(bwd, a, st) : mlp_launch<T, 192, 1>(bwd, a, st);

@@ -231,9 +231,9 @@ class STrajNet:
         # fused Swin-block kernels (csrc/swin_fused.hip); STJ_FUSED_MLP=0 selects the layer-by-layer path (A/B runs, debugging)
         self.fused_mlp = os.environ.get('STJ_FUSED_MLP', '1') != '0'
         self.fused_attn = os.environ.get('STJ_FUSED_ATTN', '1') != '0'
-        self.fused_attn_dims = tuple(int(v) for v in os.environ.get('STJ_FUSED_ATTN_DIMS', '96,192').split(','))
+        self.fused_attn_dims = (96, 192)
         # (C = 384, the 16x16 stage: 2048 rows = 32 row blocks / 32 windows at B = 8 -- the fused kernels measured slower there)
-        self.fused_mlp_dims = tuple(int(v) for v in os.environ.get('STJ_FUSED_MLP_DIMS', '96,192').split(','))
+        self.fused_mlp_dims = (96, 192)
         # the 8 time-separated cross-attentions as one kernel per direction (csrc/xattn_fused.hip); False = the layer-by-layer chain
         # (the parity tests run both and compare)
         self.fused_xattn = True
@@ -763,7 +763,7 @@ class STrajNet:
         # independent of the raster encoder up to the cross-attention: it runs on a side stream, forked HERE.  Its launches are ISSUED
         # after the encoder's first stage though: a replayed hipGraph starts branches roughly in node-creation order, and issued first
         # the chain ran alone on an idle GPU for 0.5 ms before the first Swin kernel started (profiles/r02_c_timeline_concurrent.txt).
-        mode = int(os.environ.get('STJ_AGENT_LATE', '2')) if self._side is not None else -1
+        mode = 2 if self._side is not None else -1       # (0: issued at the head of the step, 1: after the encoder -- both measured equal or worse)
         agent = []
 
         def issue_agent():

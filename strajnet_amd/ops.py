@@ -27,7 +27,7 @@ _GROUP = [None, None]       # [the open group's handle (None: stj_gemm launches 
 # Layers with at least this many rows launch their input and weight gradient separately: each then runs with 192-element k-tiles
 # (gemm_deepk_kernel: a third of the barrier-bound links), which the grouped kernel does not have.  Measured, scenes/s: no grouping
 # 943, limit 1024 rows 939, limit 16384 rows (every small layer grouped) 927.
-_GROUP_MAX_ROWS = int(os.environ.get('STJ_GEMM_GROUP_ROWS', '8192'))      # re-measured at the end of round 2: 1024 -> 1071, 4096 -> 1082, 8192 -> 1088, 16384 -> 1078, 65536 -> 1064 scenes/s
+_GROUP_MAX_ROWS = 8192      # re-measured at the end of round 2: 1024 -> 1071, 4096 -> 1082, 8192 -> 1088, 16384 -> 1078, 65536 -> 1064 scenes/s
 _GROUP_DEPTH = [0]
 
 
@@ -810,7 +810,7 @@ class _WinAttn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         items = B * (res // 8) ** 2 * heads
         pt = ctx.pt
-        nparts = int(os.environ.get('STJ_WIN_NPARTS', '0')) or (32 if items >= 1024 else (16 if items >= 256 else 1))
+        nparts = 32 if items >= 1024 else (16 if items >= 256 else 1)
         if pt.part is not None:     # model-owned copies, folded into .grad once per step
             call('stj_win_attn_bwd', _p(qkv), _p(pt.master), _p(dout), _p(dqkv), _p(pt.part[0]), min(nparts, pt.part[1]), B, res, heads,
                  shift, _dt(qkv), _st())
@@ -1555,7 +1555,7 @@ def _outconv_workspace(device):
     return _workspace(device, 'stj_outconv_bwd_workspace_bytes')
 
 
-PAIR_OUTCONV = os.environ.get('STJ_PAIR_OUTCONV', '1') != '0'
+PAIR_OUTCONV = os.environ.get('STJ_PAIR_OUTCONV', '1') != '0' and os.environ.get('STJ_NO_WS') != '1'     # (the paired kernel belongs to the MFMA / weight-stationary family)
 
 
 class _OutConvPair(torch.autograd.Function):
