@@ -185,6 +185,19 @@ int stj_softmax_bwd(const void* P, const float* dP, void* dS, long long rows, in
 int stj_fg_bias_fwd(const void* off, const float* table, float* bias, int B, int G, int Hh, int Ww, int dtype, hipStream_t stream);
 int stj_fg_bias_bwd(const void* off, const float* table, const void* dbias, float* dtable, float* doff,
                     int B, int G, int Hh, int Ww, int dtype, hipStream_t stream);
+/* Fused FG-MSA attention core (FG_MSA.py:138-178; csrc/fgattn.hip): a [B,HW,G*48] = softmax(scale q k^T + sampled bias) v per sample and
+ * group, the bias sampled from `table` at the key's offsets as stj_fg_bias_fwd does -- the [B,G,HW,HW] logits / bias / probabilities
+ * never reach HBM.  q, k, v [B,HW,G*48], off [B,G,HW,2] (activation dtype), table f32 [2Hh-1,2Ww-1,G]; lse f32 [B,G,HW] (log-sum-exp of
+ * each row, the backward's input) or NULL.  Hh = Ww in {8, 16}; dtype STJ_BF16 / STJ_F16 (STJ_F32: STJ_EUNSUPPORTED -- the f32 parity
+ * mode runs the layer-by-layer kernels).
+ * Backward: dq, dk, dv written (dk / dv through the f32 per-tile partials dkp / dvp, stj_fg_attn_bwd_workspace_bytes() bytes each, and a
+ * second launch); dtable f32 "+="; doff f32 [B,G,HW,2] written when Hh = 8 and "+=" (zeroed by the caller) when Hh = 16. */
+int stj_fg_attn_fwd(const void* q, const void* k, const void* v, const void* off, const float* table, void* a, float* lse, int B, int G,
+                    int Hh, int Ww, float scale, int dtype, hipStream_t stream);
+long long stj_fg_attn_bwd_workspace_bytes(int B, int G, int Hh, int Ww);
+int stj_fg_attn_bwd(const void* q, const void* k, const void* v, const void* off, const float* table, const void* a, const float* lse,
+                    const void* da, void* dq, void* dk, void* dv, float* dkp, float* dvp, float* dtable, float* doff, int B, int G,
+                    int Hh, int Ww, float scale, int dtype, hipStream_t stream);
 /* FG-MSA offset head: off[b,g,hw,:] = tanh(o[b,hw,g,:] . W1) * scale (1x1 conv gc -> 2, no bias) and, when fh != NULL,
  * fh = off . W2 + b2 (1x1 conv 2 -> C2) in one launch (FG_MSA.py:136-146).  o [B,HW,G,gc] (the offset conv's own layout, no
  * regrouped copy), W1 [gc,2], W2 [2,C2] (T), b2 f32 [C2] or NULL, off [B,G,HW,2]; fh [B,G,HW,C2], or with zmajor [G,B,HW,C2];

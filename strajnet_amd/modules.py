@@ -237,6 +237,7 @@ class STrajNet:
         # the 8 time-separated cross-attentions as one kernel per direction (csrc/xattn_fused.hip); False = the layer-by-layer chain
         # (the parity tests run both and compare)
         self.fused_xattn = True
+        self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (16-bit modes, 8 x 8 / 16 x 16 maps)
         self._xattn_pack = None
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():
@@ -516,8 +517,11 @@ class STrajNet:
         # per group: 1x1 conv gc->2 (no bias), tanh * (H/2); the kernel reads o in place ([B,H,W,G,gc]) and writes [B,G,HW,2]
         off = ops.fg_offset(o, self._p('fg_msa/conv_offset_proj/kernel'), Hh / 2.0, G)
         # the sampled relative-position bias is built from `off` inside the attention op
-        a = ops.mha_core(q.view(B, HW, C), k.view(B, HW, C), v.view(B, HW, C), G, gc, gc ** -0.5,
-                         fg_off=off, fg=(self._p('fg_msa/warp_attn_rel_table'), Hh, Ww))
+        if self.fused_fgattn and ops.fg_attn_ok(self.dtype, Hh, Ww, gc):      # one kernel per direction (csrc/fgattn.hip)
+            a = ops.fg_attn(q.view(B, HW, C), k.view(B, HW, C), v.view(B, HW, C), off, self._p('fg_msa/warp_attn_rel_table'), Hh, Ww, gc ** -0.5)
+        else:
+            a = ops.mha_core(q.view(B, HW, C), k.view(B, HW, C), v.view(B, HW, C), G, gc, gc ** -0.5,
+                             fg_off=off, fg=(self._p('fg_msa/warp_attn_rel_table'), Hh, Ww))
         if self.taps is not None:
             y = self._dense(a.view(B, Hh, Ww, C), 'fg_msa/proj_out')
             self._tap('fg_msa_out', y)

@@ -911,6 +911,74 @@ def mha_core(q, k, v, H, d, scale, qvalid=None, kvalid=None, bias=None, drop=Non
 
 
 # ----------------------------------------------------------------------------------------------------
+# fused FG-MSA attention core (csrc/fgattn.hip): one kernel per direction, 16-bit storage types
+# ----------------------------------------------------------------------------------------------------
+class _FgAttn(torch.autograd.Function):
+    """a = softmax(scale q k^T + bias(off, table)) v (FG_MSA.py:150-176) for q, k, v [B,HW,G*48], off [B,G,HW,2], table Param
+    [2Hh-1,2Ww-1,G]; the logits / bias / probabilities stay on chip.  Same arguments and results as mha_core(..., fg_off=, fg=)."""
+    @staticmethod
+    def forward(ctx, q, k, v, off, t_master, pt, Hh, Ww, scale):
+        _req_cuda(q, k, v, off)
+        q, k, v, off = q.contiguous(), k.contiguous(), v.contiguous(), off.contiguous()
+        B, HW, C = q.shape
+        G = off.shape[1]
+        a = torch.empty_like(q)
+        train = any(ctx.needs_input_grad[:5])
+        lse = torch.empty((B, G, HW), dtype=torch.float32, device=q.device) if train else None
+        call('stj_fg_attn_fwd', _p(q), _p(k), _p(v), _p(off), _p(pt.master), _p(a), _p(lse), B, G, Hh, Ww, float(scale), _dt(q), _st())
+        ctx.geo = (B, G, Hh, Ww, float(scale))
+        ctx.pt = pt
+        ctx.save_for_backward(q, k, v, off, a, lse)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        from ._lib import lib
+        q, k, v, off, a, lse = ctx.saved_tensors
+        B, G, Hh, Ww, scale = ctx.geo
+        pt = ctx.pt
+        da = da.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        n = int(lib().stj_fg_attn_bwd_workspace_bytes(B, G, Hh, Ww)) // 4
+        part = torch.empty((2, n), dtype=torch.float32, device=q.device)
+        doff32 = zeros_f32(tuple(off.shape), off.device)          # accumulated by the kernel's query tiles
+        call('stj_fg_attn_bwd', _p(q), _p(k), _p(v), _p(off), _p(pt.master), _p(a), _p(lse), _p(da), _p(dq), _p(dk), _p(dv), _p(part[0]),
+             _p(part[1]), _p(pt.grad), _p(doff32), B, G, Hh, Ww, scale, _dt(q), _st())
+        return dq, dk, dv, doff32.to(off.dtype), None, None, None, None, None
+
+
+def fg_attn_ok(dtype, Hh, Ww, gc):
+    """The geometries the fused FG-MSA kernel covers: 16-bit activations, 48-wide groups, an 8 x 8 or 16 x 16 map."""
+    return dtype != torch.float32 and gc == 48 and Hh == Ww and Hh in (8, 16)
+
+
+def fg_attn(q, k, v, off, pt, Hh, Ww, scale):
+    return _FgAttn.apply(q, k, v, off, pt.master, pt, Hh, Ww, scale)
+
+
+def _fgattn_cost(kind):
+    def f(a):
+        if kind == 'fwd':
+            B, G, Hh, Ww, train = a[7], a[8], a[9], a[10], bool(getattr(a[6], 'value', None))
+        else:
+            B, G, Hh, Ww, train = a[15], a[16], a[17], a[18], True
+        HW = Hh * Ww
+        fl = 2.0 * B * G * HW * HW * 48 * (2 if kind == 'fwd' else 5)
+        act = 2 * B * HW * G * 48
+        if kind == 'fwd':
+            by = 4 * act + (4 * B * G * HW if train else 0)
+        else:
+            by = 8 * act + 2 * (HW // 64) * 2 * act * 2           # + the f32 per-tile partials, written and read back
+        by += B * G * HW * 2 * 2
+        return f'fgattn_{kind}[B{B} G{G} {Hh}x{Ww}]', 'fgattn_' + kind, fl, fl, by
+    return f
+
+
+prof.EXTRA_MODELS['stj_fg_attn_fwd'] = _fgattn_cost('fwd')
+prof.EXTRA_MODELS['stj_fg_attn_bwd'] = _fgattn_cost('bwd')
+
+
+# ----------------------------------------------------------------------------------------------------
 # fused Cross_AttentionT block x Z weight sets (csrc/xattn_fused.hip): one kernel per direction
 # ----------------------------------------------------------------------------------------------------
 def xattn_pack(ps, zstride, Z, dtype, out=None):
