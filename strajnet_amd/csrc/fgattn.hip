@@ -5,14 +5,17 @@
 // S and the bias in f32 and P in the activation type: 3 x 17 MB per direction at B = 8, in 4 + 5 launches).  16-bit storage types;
 // the f32 parity mode keeps the layer-by-layer kernels (its K / V / P tiles would not fit LDS in the backward kernel).
 //
-// Work layout (the scheme of xattn_fused.hip): one workgroup = 64 queries of one (b, g); a wave owns 16 queries; K and V of the group
-// ([HW][48], HW = 64 or 256) sit in LDS next to the group's 31 x 31 table and the keys' offsets; S^T = K q^T on the accumulator layout
-// (a lane holds 4 consecutive keys of its query, the 3 partner lanes the rest), the bilinear bias is sampled per (query, key) pair
-// from the LDS table (zero pad + clamp rules of occu_metric.sample, common.h bil_setup), softmax by two xor-shuffles, O^T = V^T P^T
-// with P^T chained in registers.  Backward recomputes S / P, chains dP^T = V dO^T and dq^T = K^T dS^T, sends the bias gradient to an
-// LDS copy of the table gradient and (reduced over the wave's 16 queries by shuffles) to the keys' offset gradients, and -- the sums
-// over QUERIES cross the waves -- computes dV = P^T dO, dK = dS^T q for the keys each wave owns from [query][.] tiles in LDS; per-tile
-// partial sums are reduced by a second small kernel.
+// Work layout (the chained-operand scheme of xattn_fused.hip): a workgroup = 32 (forward) or 64 (backward) queries of one (b, g); a wave
+// = 16 queries against a quarter of the keys (Split<>; 4 waves per SIMD at B = 8).  K and V of the group ([HW][48], HW = 64 or 256) sit
+// in LDS next to the group's 31 x 31 table and the keys' offsets.  S^T = K q^T lands on the accumulator layout (a lane holds 4
+// consecutive keys of its query, the 3 partner lanes the rest); the bilinear bias is sampled per (query, key) pair from the LDS table
+// (zero pad + clamp rules of occu_metric.sample: common.h bil_setup); the keys are visited 32 at a time with a running maximum / sum
+// (the logits of a query never exist all at once); O^T = V^T P^T with P^T chained in registers; the key slices merge through LDS.
+// Backward: P = exp(logit - lse) from the forward's log-sum-exp, sum_k P dP = dO . O from the forward output; dP^T = V dO^T and
+// dq^T = K^T dS^T are chained; the bias gradient goes to an LDS copy of the table gradient (neighbouring lanes share cells: see there)
+// and, summed over the wave's 16 queries by DPP, to the keys' offset gradients; the sums over QUERIES cross the waves: dV = P^T dO,
+// dK = dS^T q for the keys each wave owns come from [query][.] tiles in LDS, as per-tile f32 partials that a second small kernel sums.
+// Measured alone at B = 8, 16 x 16, bf16: forward 19 us, backward 47 + 10 us (layer by layer: ~55 + ~100 us in 4 + 5 launches).
 #include "common.h"
 #include "chain48.h"
 
@@ -41,24 +44,34 @@ __device__ __forceinline__ float bias_at(const float* tbl, int TH, int TW, int q
 }
 
 // K / V rows of group g: global [B, HW, C] (48 contiguous channels at column 48 g) -> LDS tiles [HW][LDK]
-template <typename T>
+template <typename T, int NT>
 __device__ __forceinline__ void load_kv(const T* k, const T* v, T* Kt, T* Vt, long long row0, int HW, int C, int g, int tid) {
   constexpr int VN = 8, CPR = D / VN;            // 16-byte pieces per row
-  for (int i = tid; i < 2 * HW * CPR; i += 256) {
+  for (int i = tid; i < 2 * HW * CPR; i += NT) {
     const int t = i / (HW * CPR), rem = i % (HW * CPR), r = rem / CPR, c = (rem % CPR) * VN;
     const uint4 w = *reinterpret_cast<const uint4*>((t ? v : k) + (row0 + r) * C + D * g + c);
     uint2* d = reinterpret_cast<uint2*>((t ? Vt : Kt) + r * LDK + c);          // rows are 8-byte aligned (104 bytes)
     d[0] = make_uint2(w.x, w.y); d[1] = make_uint2(w.z, w.w);
   }
-  for (int i = tid; i < 2 * HW * (LDK - D); i += 256) {
+  for (int i = tid; i < 2 * HW * (LDK - D); i += NT) {
     const int t = i / (HW * (LDK - D)), rem = i % (HW * (LDK - D));
     stf((t ? Vt : Kt) + (rem / (LDK - D)) * LDK + D + rem % (LDK - D), 0.f);
   }
 }
 
+// sum over the 16 lanes of a DPP row (the lanes of equal lane >> 4); every lane gets the total.  quad_perm xor 1, xor 2, then
+// row_half_mirror / row_mirror (the quads / halves already hold equal values)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
 // the 8 logits (scaled product + sampled bias) a lane holds of key fragments 2s, 2s+1: v[e], keys 32 s + 16 (e / 4) + 4 g4 + e % 4
-template <typename T, int NKF, bool GRAD>
-__device__ __forceinline__ void logits8(float (&v)[8], BiasPt (&bp)[GRAD ? 8 : 1], const T* Kt, const HeadOp<T>& qop, const float* tbl, const float* offs,
+template <typename T, int NKF>
+__device__ __forceinline__ void logits8(float (&v)[8], const T* Kt, const HeadOp<T>& qop, const float* tbl, const float* offs,
                                         int TH, int TW, int s, int qi, int qj, float scale, int lane) {
   constexpr int Ww = NKF == 4 ? 8 : 16;          // square maps only (check()): 8 x 8 or 16 x 16
   const int g4 = lane >> 4;
@@ -68,23 +81,35 @@ __device__ __forceinline__ void logits8(float (&v)[8], BiasPt (&bp)[GRAD ? 8 : 1
   for (int e = 0; e < 8; ++e) {
     const int key = 32 * s + 16 * (e >> 2) + 4 * g4 + (e & 3);
     const float2 o = *reinterpret_cast<const float2*>(offs + 2 * key);
-    v[e] = (e < 4 ? sa[e & 3] : sb[e & 3]) * scale + bias_at(tbl, TH, TW, qi, qj, key / Ww, key % Ww, o.x, o.y, bp[GRAD ? e : 0]);
+    BiasPt bp;
+    v[e] = (e < 4 ? sa[e & 3] : sb[e & 3]) * scale + bias_at(tbl, TH, TW, qi, qj, key / Ww, key % Ww, o.x, o.y, bp);
   }
 }
 
+// The waves of a workgroup: QG groups of 16 queries x KS slices of the keys (a wave = 16 queries against HW / KS keys).  One wave per
+// 16 queries against all 256 keys left the chip at one wave per SIMD (8 x 8 x 16 waves at B = 8) with every LDS / transcendental
+// latency exposed: 35 us forward, 111 us backward; the key slices of one query group merge through LDS.
+template <int NKF, bool BWD> struct Split {
+  static constexpr int KS = NKF == 16 ? 4 : 1;
+  static constexpr int QG = (NKF == 16 && !BWD) ? 2 : 4;
+  static constexpr int NT = 64 * QG * KS;
+  static constexpr int TQ = 16 * QG;               // queries per workgroup
+  static constexpr int IT = NKF / 2 / KS;          // 32-key steps per wave
+};
 template <typename T, int NKF> struct Lds {
   static constexpr int HW = 16 * NKF;
   static constexpr int LDP = HW + 8;
+  static constexpr int TQB = Split<NKF, true>::TQ;
   static int fwd_bytes(int tt) { return 2 * HW * LDK * (int)sizeof(T) + (tt + 2 * HW) * 4; }
-  static int bwd_bytes(int tt) { return (2 * HW * LDK + 2 * TOK * LDP + 2 * TOK * LDT) * (int)sizeof(T) + (2 * tt + 4 * HW) * 4; }
+  static int bwd_bytes(int tt) { return (2 * HW * LDK + 2 * TQB * LDP + 2 * TQB * LDT) * (int)sizeof(T) + (2 * tt + 4 * HW) * 4; }
 };
 
 // =====================================================================================================================
-// Forward: the keys are visited 32 at a time with a running maximum / sum (the logits of a query never exist all at once: 16 x 4 live
-// accumulator registers per lane instead of 256 x 4 / 4).
+// Forward: the keys are visited 32 at a time with a running maximum / sum (the logits of a query never exist all at once).
 template <typename T, int NKF>
-__global__ __launch_bounds__(256, 2) void fgattn_fwd_kernel(Args p) {
-  constexpr int HW = 16 * NKF, Ww = NKF == 4 ? 8 : 16;
+__global__ __launch_bounds__((Split<NKF, false>::NT)) void fgattn_fwd_kernel(Args p) {
+  typedef Split<NKF, false> W;
+  constexpr int HW = 16 * NKF, Ww = NKF == 4 ? 8 : 16, NT = W::NT, QG = W::QG, KS = W::KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char fg_smem[];
   const int TH = 2 * p.Hh - 1, TW = 2 * p.Ww - 1, TT = TH * TW, C = p.G * D;
   T* Kt = reinterpret_cast<T*>(fg_smem);
@@ -92,17 +117,18 @@ __global__ __launch_bounds__(256, 2) void fgattn_fwd_kernel(Args p) {
   float* tbl = reinterpret_cast<float*>(Vt + HW * LDK);
   float* offs = tbl + TT;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g4 = lane >> 4, ln = lane & 15;
-  constexpr int tiles = HW / TOK;
+  const int qg = wv % QG, kq = wv / QG;
+  constexpr int tiles = HW / W::TQ;
   const int tile = blockIdx.x % tiles, g = (blockIdx.x / tiles) % p.G, b = blockIdx.x / (tiles * p.G);
   const long long row0 = (long long)b * HW;
   const T* q = reinterpret_cast<const T*>(p.q);
-  load_kv<T>(reinterpret_cast<const T*>(p.k), reinterpret_cast<const T*>(p.v), Kt, Vt, row0, HW, C, g, tid);
-  for (int i = tid; i < TT; i += 256) tbl[i] = p.table[i * p.G + g];
+  load_kv<T, NT>(reinterpret_cast<const T*>(p.k), reinterpret_cast<const T*>(p.v), Kt, Vt, row0, HW, C, g, tid);
+  for (int i = tid; i < TT; i += NT) tbl[i] = p.table[i * p.G + g];
   {
     const T* o = reinterpret_cast<const T*>(p.off) + ((long long)b * p.G + g) * HW * 2;
-    for (int i = tid; i < 2 * HW; i += 256) offs[i] = ldf(o + i);
+    for (int i = tid; i < 2 * HW; i += NT) offs[i] = ldf(o + i);
   }
-  const int tok = tile * TOK + wv * 16 + ln;
+  const int tok = tile * W::TQ + qg * 16 + ln;
   HeadOp<T> qop;
   qop.from_row(q + (row0 + tok) * C + D * g, lane);
   __syncthreads();
@@ -111,10 +137,9 @@ __global__ __launch_bounds__(256, 2) void fgattn_fwd_kernel(Args p) {
   for (int jd = 0; jd < 3; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
 #pragma unroll 1
-  for (int s = 0; s < NKF / 2; ++s) {
+  for (int s = kq * W::IT; s < (kq + 1) * W::IT; ++s) {
     float v[8];
-    BiasPt bp[1];
-    logits8<T, NKF, false>(v, bp, Kt, qop, tbl, offs, TH, TW, s, tok / Ww, tok % Ww, p.scale, lane);
+    logits8<T, NKF>(v, Kt, qop, tbl, offs, TH, TW, s, tok / Ww, tok % Ww, p.scale, lane);
     float mx = v[0];
 #pragma unroll
     for (int e = 1; e < 8; ++e) mx = fmaxf(mx, v[e]);
@@ -133,6 +158,35 @@ __global__ __launch_bounds__(256, 2) void fgattn_fwd_kernel(Args p) {
     }
   }
   l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+  if constexpr (KS > 1) {          // merge the key slices of a query group through LDS (over the K / V tiles, which are done with)
+    __syncthreads();
+    float* mb = reinterpret_cast<float*>(fg_smem);                       // [KS][QG][14][64]
+    float* my = mb + ((kq * QG + qg) * 14) * 64 + lane;
+    my[0] = m; my[64] = l;
+#pragma unroll
+    for (int jd = 0; jd < 3; ++jd)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) my[(2 + 4 * jd + r) * 64] = o[jd][r];
+    __syncthreads();
+    if (kq != 0) return;
+    float M = m;
+#pragma unroll
+    for (int i = 1; i < KS; ++i) M = fmaxf(M, mb[((i * QG + qg) * 14) * 64 + lane]);
+    l = 0.f;
+#pragma unroll
+    for (int jd = 0; jd < 3; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const float* src = mb + ((i * QG + qg) * 14) * 64 + lane;
+      const float w = __expf(src[0] - M);
+      l += src[64] * w;
+#pragma unroll
+      for (int jd = 0; jd < 3; ++jd)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[jd][r] += src[(2 + 4 * jd + r) * 64] * w;
+    }
+    m = M;
+  }
   const float inv = 1.f / l;
   T* a = reinterpret_cast<T*>(p.a) + (row0 + tok) * C + D * g + 4 * g4;
 #pragma unroll
@@ -143,31 +197,35 @@ __global__ __launch_bounds__(256, 2) void fgattn_fwd_kernel(Args p) {
 // =====================================================================================================================
 // Backward: P = exp(logit - lse) from the forward's log-sum-exp, the softmax's row term sum_k P dP = dO . O from the forward output.
 template <typename T, int NKF>
-__global__ __launch_bounds__(256, 1) void fgattn_bwd_kernel(Args p) {
-  constexpr int HW = 16 * NKF, LDP = HW + 8, MW = NKF / 4, Ww = NKF == 4 ? 8 : 16;       // MW: 16-key fragments each wave owns for dK / dV
+__global__ __launch_bounds__((Split<NKF, true>::NT)) void fgattn_bwd_kernel(Args p) {
+  typedef Split<NKF, true> W;
+  constexpr int HW = 16 * NKF, LDP = HW + 8, Ww = NKF == 4 ? 8 : 16, NT = W::NT, QG = W::QG, KS = W::KS, TQ = W::TQ;
+  constexpr int MW = NKF / (QG * KS);          // 16-key fragments each wave owns for dK / dV
+  static_assert(MW >= 1 && TQ == 64, "the dK / dV contraction runs over 64 queries");
   extern __shared__ __attribute__((aligned(16))) unsigned char fg_smem[];
   const int TH = 2 * p.Hh - 1, TW = 2 * p.Ww - 1, TT = TH * TW, C = p.G * D;
   T* Kt = reinterpret_cast<T*>(fg_smem);
   T* Vt = Kt + HW * LDK;
   T* PT = Vt + HW * LDK;                   // P   [64 queries][LDP]
-  T* ST = PT + TOK * LDP;                  // dS  [64 queries][LDP]   (times 48^-1/2)
-  T* OT = ST + TOK * LDP;                  // dO  [64 queries][LDT]
-  T* QT = OT + TOK * LDT;                  // q   [64 queries][LDT]
-  float* tbl = reinterpret_cast<float*>(QT + TOK * LDT);
+  T* ST = PT + TQ * LDP;                   // dS  [64 queries][LDP]   (times 48^-1/2)
+  T* OT = ST + TQ * LDP;                   // dO  [64 queries][LDT]
+  T* QT = OT + TQ * LDT;                   // q   [64 queries][LDT]
+  float* tbl = reinterpret_cast<float*>(QT + TQ * LDT);
   float* dtb = tbl + TT;
   float* offs = dtb + TT;                  // [HW][2]
   float* doffs = offs + 2 * HW;            // [HW][2]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g4 = lane >> 4, ln = lane & 15;
-  constexpr int tiles = HW / TOK;
+  const int qg = wv % QG, kq = wv / QG;
+  constexpr int tiles = HW / TQ;
   const int tile = blockIdx.x % tiles, g = (blockIdx.x / tiles) % p.G, b = blockIdx.x / (tiles * p.G);
   const long long row0 = (long long)b * HW;
-  load_kv<T>(reinterpret_cast<const T*>(p.k), reinterpret_cast<const T*>(p.v), Kt, Vt, row0, HW, C, g, tid);
-  for (int i = tid; i < TT; i += 256) { tbl[i] = p.table[i * p.G + g]; dtb[i] = 0.f; }
+  load_kv<T, NT>(reinterpret_cast<const T*>(p.k), reinterpret_cast<const T*>(p.v), Kt, Vt, row0, HW, C, g, tid);
+  for (int i = tid; i < TT; i += NT) { tbl[i] = p.table[i * p.G + g]; dtb[i] = 0.f; }
   {
     const T* o = reinterpret_cast<const T*>(p.off) + ((long long)b * p.G + g) * HW * 2;
-    for (int i = tid; i < 2 * HW; i += 256) { offs[i] = ldf(o + i); doffs[i] = 0.f; }
+    for (int i = tid; i < 2 * HW; i += NT) { offs[i] = ldf(o + i); doffs[i] = 0.f; }
   }
-  const int tok = tile * TOK + wv * 16 + ln;
+  const int tok = tile * TQ + qg * 16 + ln;
   const int qi = tok / Ww, qj = tok % Ww;
   const T* qrow = reinterpret_cast<const T*>(p.q) + (row0 + tok) * C + D * g;
   const T* drow = reinterpret_cast<const T*>(p.da) + (row0 + tok) * C + D * g;
@@ -176,15 +234,15 @@ __global__ __launch_bounds__(256, 1) void fgattn_bwd_kernel(Args p) {
   qop.from_row(qrow, lane);
   dop.from_row(drow, lane);
   float dsum = 0.f;
-  {   // dO and q of the wave's queries -> tiles [query][head column]; dO . O
-    T* orow = OT + (16 * wv + ln) * LDT + 4 * g4;
-    T* qtr = QT + (16 * wv + ln) * LDT + 4 * g4;
+  {   // dO . O; dO and q of the group's queries -> tiles [query][head column] (by the group's first key slice)
+    T* orow = OT + (16 * qg + ln) * LDT + 4 * g4;
+    T* qtr = QT + (16 * qg + ln) * LDT + 4 * g4;
 #pragma unroll
     for (int jd = 0; jd < 3; ++jd) {
       float a4[4], b4[4], c4[4];
-      ld4(drow + 16 * jd + 4 * g4, a4); st4(orow + 16 * jd, a4);
-      ld4(qrow + 16 * jd + 4 * g4, b4); st4(qtr + 16 * jd, b4);
+      ld4(drow + 16 * jd + 4 * g4, a4);
       ld4(arow + 16 * jd + 4 * g4, c4);
+      if (kq == 0) { ld4(qrow + 16 * jd + 4 * g4, b4); st4(orow + 16 * jd, a4); st4(qtr + 16 * jd, b4); }
 #pragma unroll
       for (int r = 0; r < 4; ++r) dsum += a4[r] * c4[r];
     }
@@ -195,39 +253,56 @@ __global__ __launch_bounds__(256, 1) void fgattn_bwd_kernel(Args p) {
   f32x4 dq[3];
 #pragma unroll
   for (int jd = 0; jd < 3; ++jd) dq[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  T* prow = PT + (16 * wv + ln) * LDP + 4 * g4;
-  T* srow = ST + (16 * wv + ln) * LDP + 4 * g4;
+  T* prow = PT + (16 * qg + ln) * LDP + 4 * g4;
+  T* srow = ST + (16 * qg + ln) * LDP + 4 * g4;
 #pragma unroll 1
-  for (int s = 0; s < NKF / 2; ++s) {
-    float v[8];
-    BiasPt bp[8];
-    logits8<T, NKF, true>(v, bp, Kt, qop, tbl, offs, TH, TW, s, qi, qj, p.scale, lane);
+  for (int s = kq * W::IT; s < (kq + 1) * W::IT; ++s) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 sa = k48_rows<T>(Kt, LDK, 32 * s, qop, lane, z), sb = k48_rows<T>(Kt, LDK, 32 * s + 16, qop, lane, z);
     const f32x4 dPa = k48_rows<T>(Vt, LDK, 32 * s, dop, lane, z), dPb = k48_rows<T>(Vt, LDK, 32 * s + 16, dop, lane, z);
     f32x4 ds2[2];
     float pv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int key = 32 * s + 16 * (e >> 2) + 4 * g4 + (e & 3);
-      const float pr = __expf(v[e] - lse);
+      const float2 ok = *reinterpret_cast<const float2*>(offs + 2 * key);
+      BiasPt c;
+      const float v = (e < 4 ? sa[e & 3] : sb[e & 3]) * p.scale + bias_at(tbl, TH, TW, qi, qj, key / Ww, key % Ww, ok.x, ok.y, c);
+      const float pr = __expf(v - lse);
       pv[e] = pr;
       const float go = pr * ((e < 4 ? dPa[e & 3] : dPb[e & 3]) - dsum);        // d(logit) = d(bias): the bias enters the logit with weight 1
       ds2[e >> 2][e & 3] = go * p.scale;
       // bias backward (the gradient rules of stj_fg_bias_bwd: TF's clip gradients, zero outside the padded table)
-      const BiasPt& c = bp[e];
       const float top = c.c.ax * (c.tr - c.tl) + c.tl, bot = c.c.ax * (c.br - c.bl) + c.bl;
       float d0 = c.c.gy ? -go * (bot - top) : 0.f;
       float d1 = c.c.gx ? -go * (c.c.ay * (c.br - c.bl) + (1.f - c.c.ay) * (c.tr - c.tl)) : 0.f;
-      if (go != 0.f) {
-        const float w[4] = {(1.f - c.c.ay) * (1.f - c.c.ax), (1.f - c.c.ay) * c.c.ax, c.c.ay * (1.f - c.c.ax), c.c.ay * c.c.ax};
-        const int yy[4] = {c.c.y0, c.c.y0, c.c.y0 + 1, c.c.y0 + 1}, xx[4] = {c.c.x0, c.c.x0 + 1, c.c.x0, c.c.x0 + 1};
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (yy[t] >= 1 && yy[t] <= TH && xx[t] >= 1 && xx[t] <= TW && w[t] != 0.f) atomicAdd(&dtb[(yy[t] - 1) * TW + (xx[t] - 1)], go * w[t]);
+      {
+        // table gradient: go (1 - ay) goes to table row y0, go ay to row y0 + 1, each split (1 - ax, ax) over columns x0, x0 + 1.  The 16
+        // queries of a wave run along one map row, so for one key lane ln's row y0 + 1 IS lane ln + 1's row y0 (same x0): the upper half
+        // is handed to the next lane inside the DPP row and one LDS atomic covers both -- LDS float atomics retire about one lane per
+        // clock, and with four of them per (query, key) pair they were 34 of this kernel's 64 us.  (Lanes whose sample point was
+        // clamped carry weight 0 for every cell inside the table and drop out.)
+        const float hi = go * c.c.ay;
+        const int y0p = __builtin_amdgcn_update_dpp(-9, c.c.y0, 0x111, 0xF, 0xF, false), x0p = __builtin_amdgcn_update_dpp(-9, c.c.x0, 0x111, 0xF, 0xF, false);
+        const int y0n = __builtin_amdgcn_update_dpp(-9, c.c.y0, 0x101, 0xF, 0xF, false), x0n = __builtin_amdgcn_update_dpp(-9, c.c.x0, 0x101, 0xF, 0xF, false);
+        const float hip = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x111, 0xF, 0xF, false));
+        const bool absorb = ln > 0 && y0p + 1 == c.c.y0 && x0p == c.c.x0;          // this lane adds the previous lane's upper half
+        const bool given = ln < 15 && c.c.y0 + 1 == y0n && c.c.x0 == x0n;          // the next lane adds this lane's upper half
+        const float lo = go * (1.f - c.c.ay) + (absorb ? hip : 0.f);
+        const bool xa = c.c.x0 >= 1 && c.c.x0 <= TW, xb = c.c.x0 + 1 >= 1 && c.c.x0 + 1 <= TW;
+        if (c.c.y0 >= 1 && c.c.y0 <= TH && lo != 0.f) {
+          float* row = dtb + (c.c.y0 - 1) * TW + (c.c.x0 - 1);
+          if (xa && c.c.ax != 1.f) atomicAdd(row, lo * (1.f - c.c.ax));
+          if (xb && c.c.ax != 0.f) atomicAdd(row + 1, lo * c.c.ax);
+        }
+        if (!given && c.c.y0 + 1 >= 1 && c.c.y0 + 1 <= TH && hi != 0.f) {
+          float* row = dtb + c.c.y0 * TW + (c.c.x0 - 1);
+          if (xa && c.c.ax != 1.f) atomicAdd(row, hi * (1.f - c.c.ax));
+          if (xb && c.c.ax != 0.f) atomicAdd(row + 1, hi * c.c.ax);
+        }
       }
-      // the key's offset gradient: sum over the wave's 16 queries (lanes of equal g4), one LDS add per wave
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o, 64); d1 += __shfl_xor(d1, o, 64); }
+      // the key's offset gradient: sum over the wave's 16 queries (the lanes of equal g4 = a DPP row), one LDS add per wave
+      d0 = row16_sum(d0); d1 = row16_sum(d1);
       if (ln == 0) { atomicAdd(&doffs[2 * key], d0); atomicAdd(&doffs[2 * key + 1], d1); }
     }
     st4(prow + 32 * s, pv); st4(prow + 32 * s + 16, pv + 4);
@@ -237,12 +312,15 @@ __global__ __launch_bounds__(256, 1) void fgattn_bwd_kernel(Args p) {
 #pragma unroll
     for (int jd = 0; jd < 3; ++jd) dq[jd] = Mma<T>::mma(Ch<T>::ldA_tr(Kt, LDK, 16 * jd, 32 * s, lane), sf, dq[jd]);
   }
-  {
-    T* dqo = reinterpret_cast<T*>(p.dq) + (row0 + tok) * C + D * g + 4 * g4;
-#pragma unroll
-    for (int jd = 0; jd < 3; ++jd) { const float w[4] = {dq[jd][0], dq[jd][1], dq[jd][2], dq[jd][3]}; st4(dqo + 16 * jd, w); }
-  }
   __syncthreads();
+  float* mb = reinterpret_cast<float*>(fg_smem);                       // dq of the key slices [KS][QG][12][64], over the K / V tiles
+  if constexpr (KS > 1) {
+    float* my = mb + ((kq * QG + qg) * 12) * 64 + lane;
+#pragma unroll
+    for (int jd = 0; jd < 3; ++jd)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) my[(4 * jd + r) * 64] = dq[jd][r];
+  }
   {   // dV = P^T dO, dK = dS^T q for the MW x 16 keys this wave owns: m = key, n = head column, k = the tile's 64 queries
     f32x4 dv[MW][3], dk[MW][3];
 #pragma unroll
@@ -250,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void fgattn_bwd_kernel(Args p) {
 #pragma unroll
       for (int jd = 0; jd < 3; ++jd) { dv[m][jd] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[m][jd] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int s = 0; s < TOK / 32; ++s) {
+    for (int s = 0; s < TQ / 32; ++s) {
       typename Mma<T>::Frag bo[3], bq[3];
 #pragma unroll
       for (int jd = 0; jd < 3; ++jd) { bo[jd] = Mma<T>::load_tr(OT, LDT, 16 * jd, 32 * s, lane); bq[jd] = Mma<T>::load_tr(QT, LDT, 16 * jd, 32 * s, lane); }
@@ -274,11 +352,29 @@ __global__ __launch_bounds__(256, 1) void fgattn_bwd_kernel(Args p) {
           p.dkp[o] = dk[m][jd][r];
         }
   }
+  if constexpr (KS > 1) {
+    __syncthreads();
+    if (kq == 0) {
+#pragma unroll
+      for (int i = 1; i < KS; ++i) {
+        const float* src = mb + ((i * QG + qg) * 12) * 64 + lane;
+#pragma unroll
+        for (int jd = 0; jd < 3; ++jd)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dq[jd][r] += src[(4 * jd + r) * 64];
+      }
+    }
+  }
+  if (kq == 0) {
+    T* dqo = reinterpret_cast<T*>(p.dq) + (row0 + tok) * C + D * g + 4 * g4;
+#pragma unroll
+    for (int jd = 0; jd < 3; ++jd) { const float w[4] = {dq[jd][0], dq[jd][1], dq[jd][2], dq[jd][3]}; st4(dqo + 16 * jd, w); }
+  }
   // table / offset gradients of this tile
-  for (int i = tid; i < TT; i += 256)
+  for (int i = tid; i < TT; i += NT)
     if (dtb[i] != 0.f) atomicAdd(p.dtable + i * p.G + g, dtb[i]);
   float* dof = p.doff + ((long long)b * p.G + g) * HW * 2;
-  for (int i = tid; i < 2 * HW; i += 256) {
+  for (int i = tid; i < 2 * HW; i += NT) {
     if (tiles == 1) dof[i] = doffs[i];
     else atomicAdd(dof + i, doffs[i]);
   }
@@ -307,9 +403,8 @@ template <typename T, int NKF> static int launch(bool bwd, const Args& a, hipStr
   if (lds > 160 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
     stj_set_error("fg_attn: cannot reserve %d bytes of LDS", lds); return STJ_ELAUNCH;
   }
-  const dim3 grid((unsigned)(a.B * a.G * (16 * NKF / TOK)));
-  if (bwd) hipLaunchKernelGGL((fgattn_bwd_kernel<T, NKF>), grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((fgattn_fwd_kernel<T, NKF>), grid, dim3(256), lds, st, a);
+  if (bwd) hipLaunchKernelGGL((fgattn_bwd_kernel<T, NKF>), dim3((unsigned)(a.B * a.G * (16 * NKF / Split<NKF, true>::TQ))), dim3(Split<NKF, true>::NT), lds, st, a);
+  else hipLaunchKernelGGL((fgattn_fwd_kernel<T, NKF>), dim3((unsigned)(a.B * a.G * (16 * NKF / Split<NKF, false>::TQ))), dim3(Split<NKF, false>::NT), lds, st, a);
   return stj_check_launch(bwd ? "stj_fg_attn_bwd" : "stj_fg_attn_fwd");
 }
 template <typename T> static int dispatch(bool bwd, const Args& a, hipStream_t st) {

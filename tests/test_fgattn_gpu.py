@@ -38,8 +38,10 @@ def test_fg_attn_vs_f64_and_layerwise(dt, B, Hh):
     HW, C = Hh * Hh, G * gc
     q, k, v = (rnd((B, HW, C), dt, 10 + i).requires_grad_(True) for i in range(3))
     # offsets off the integer lattice (there TF's clip gradient and the float64 reference's one-sided one differ); some far outside the table
-    off = (rnd((B, G, HW, 2), torch.float32, 2, 3.0) + 0.37).to(dt)
-    off[0, 0, :4] = 40.0
+    # (exactly representable in bf16: integer part below 16, fraction a multiple of 1/8)
+    gen = torch.Generator().manual_seed(2)
+    off = (torch.randint(-9, 10, (B, G, HW, 2), generator=gen) + torch.randint(2, 7, (B, G, HW, 2), generator=gen) / 8.0).to(dt).cuda()
+    off[0, 0, :4] = 40.5
     off = off.requires_grad_(True)
     go = rnd((B, HW, C), dt, 5)
     res = []
