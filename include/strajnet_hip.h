@@ -109,18 +109,24 @@ int stj_win_attn_bwd(const void* qkv, const float* table, const void* dout, void
  *   bwd: dx = dy + LN'(...), dgamma/dbeta "+=" (nparts copies part_stride floats apart, as stj_layernorm_bwd), and the operands
  *        of the two weight gradients written once: h = gelu(pre) [M,4C], dpre [M,4C], ln = LN(x) [M,C], dys = dp*dy [M,C]
  *        (dys may be NULL when there is no DropPath: use dy).  dW1 = ln^T dpre, db1 = colsum(dpre), dW2 = h^T dys,
- *        db2 = colsum(dys) are stj_gemm split-K launches. */
+ *        db2 = colsum(dys) are stj_gemm split-K launches.
+ * ws (C = 384 only; ignored for the other widths): f32 workspace of stj_swin_split_workspace_bytes(M, C) bytes.  With it the 2048-row
+ *   stage runs as (row block, 1/8 of the hidden dimension) workgroups -- 256 at B = 8 instead of 32, each streaming 1/8 of the weights
+ *   -- whose partial sums [8][M][C] a second launch adds up and finishes (bias + DropPath + shortcut; LayerNorm backward + dgamma /
+ *   dbeta).  NULL: one workgroup per row block.  The four stj_swin_* entry points share the workspace layout; stj_swin_attn_* at
+ *   C = 384 REQUIRE it (and a 16-bit dtype): (window, 2 of the 12 heads) workgroups. */
+long long stj_swin_split_workspace_bytes(long long M, int C);
 int stj_swin_mlp_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
                      const float* b2, void* y, long long M, int C, float eps, const long long* rng_state, int site,
-                     float p_drop, long long rows_per_sample, int dtype, hipStream_t stream);
+                     float p_drop, long long rows_per_sample, int dtype, void* ws, hipStream_t stream);
 int stj_swin_mlp_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const void* w1, const float* b1,
                      const void* w2, void* dx, void* h, void* dpre, void* ln, void* dys, float* dgamma, float* dbeta,
                      int nparts, long long part_stride, long long M, int C, float eps, const long long* rng_state, int site,
-                     float p_drop, long long rows_per_sample, int dtype, hipStream_t stream);
+                     float p_drop, long long rows_per_sample, int dtype, void* ws, hipStream_t stream);
 
 /* Fused attention half of SwinTransformerBlock, forward (modules.py:225-258: norm1, roll, window_partition, WindowAttention :103-134
  * with the shift mask :189-216, window_reverse, roll, drop_path + shortcut), one workgroup per 8x8 window (csrc/swin_fused.hip):
- *   y = x + dp * (proj(window_attention(LN(x) wqkv + bqkv)) + bproj);  x, y [B,res*res,C], C in {96,192}, heads = C/32;
+ *   y = x + dp * (proj(window_attention(LN(x) wqkv + bqkv)) + bproj);  x, y [B,res*res,C], C in {96,192,384}, heads = C/32;
  *   wqkv [C,3C], wproj [C,C] activation dtype (Keras [in,out]); bqkv [3C], bproj [C], gamma/beta [C], table [225,heads] f32.
  * Training hand-offs (all or none; NULL for inference): qkv [B,N,3C], a = attention output before proj [B,N,C], ln = LN(x) [B,N,C],
  * mean / rstd f32 [B*N] -- the operands stj_win_attn_bwd, stj_layernorm_bwd and the dgrad / wgrad stj_gemm launches of backward read.
@@ -128,17 +134,17 @@ int stj_swin_mlp_bwd(const void* x, const void* dy, const float* gamma, const fl
 int stj_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
                       const float* table, const void* wproj, const float* bproj, void* y, void* qkv, void* a, void* ln,
                       float* mean, float* rstd, int B, int res, int C, int shift, float eps, const long long* rng_state,
-                      int site, float p_drop, int dtype, hipStream_t stream);
+                      int site, float p_drop, int dtype, void* ws, hipStream_t stream);
 
 /* Backward of stj_swin_attn_fwd in one launch (one workgroup per window): dys = dp*dy, da = dys wproj^T, window-attention backward,
  * dLN = dqkv wqkv^T, dx = dy + LayerNorm'(dLN); "+=" outputs: dtable [tparts][225,heads] (workgroup i adds into copy i % tparts),
  * dgamma / dbeta (nparts copies part_stride floats apart).  Reads x, dy, the saved qkv / mean / rstd; writes dx, dqkv [B,N,3C] and
  * (when rng_state != NULL and p_drop > 0: else may be NULL) dys [B,N,C] -- the operands of the two weight gradients, which stay
- * stj_gemm launches: dWproj = a^T dys (+ colsum), dWqkv = ln^T dqkv (+ colsum), a / ln saved by the forward kernel.  C in {96,192}. */
+ * stj_gemm launches: dWproj = a^T dys (+ colsum), dWqkv = ln^T dqkv (+ colsum), a / ln saved by the forward kernel.  C in {96,192,384}. */
 int stj_swin_attn_bwd(const void* x, const void* dy, const void* qkv, const float* mean, const float* rstd, const float* gamma,
                       const void* wqkv, const void* wproj, const float* table, void* dx, void* dqkv, void* dys,
                       float* dtable, int tparts, float* dgamma, float* dbeta, int nparts, long long part_stride,
-                      int B, int res, int C, int shift, const long long* rng_state, int site, float p_drop, int dtype,
+                      int B, int res, int C, int shift, const long long* rng_state, int site, float p_drop, int dtype, void* ws,
                       hipStream_t stream);
 
 /* Fused Cross_AttentionT block: the 8 time-separated cross-attentions of TrajNetCrossAttention (trajNet.py:189-234 Cross_AttentionT --

@@ -44,10 +44,11 @@ SIGNATURES = {
     'stj_layernorm_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, cl, ci, cl, vp, ci, cl, ci, vp],
     'stj_win_attn_fwd': [vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_win_attn_bwd': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
-    'stj_swin_mlp_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, cf, vp, ci, cf, cl, ci, vp],
-    'stj_swin_mlp_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cl, cl, ci, cf, vp, ci, cf, cl, ci, vp],
-    'stj_swin_attn_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, ci, cf, ci, vp],
-    'stj_swin_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, cl, ci, ci, ci, ci, vp, ci, cf, ci, vp],
+    'stj_swin_split_workspace_bytes': [cl, ci],
+    'stj_swin_mlp_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, cf, vp, ci, cf, cl, ci, vp, vp],
+    'stj_swin_mlp_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cl, cl, ci, cf, vp, ci, cf, cl, ci, vp, vp],
+    'stj_swin_attn_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, ci, cf, ci, vp, vp],
+    'stj_swin_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, cl, ci, ci, ci, ci, vp, ci, cf, ci, vp, vp],
     'stj_xattn_pack_workspace_bytes': [ci],
     'stj_xattn_pack_tail_workspace_bytes': [ci],
     'stj_xattn_pack': [vp, vp, vp, vp, cl, ci, vp, ci, vp],

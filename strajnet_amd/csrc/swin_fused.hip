@@ -38,6 +38,9 @@
 #ifndef STJ_MLP_HC192
 #define STJ_MLP_HC192 96
 #endif
+#ifndef STJ_MLP_HC384
+#define STJ_MLP_HC384 32        // C = 384 (the split kernels: 192 hidden columns per workgroup)
+#endif
 #ifndef STJ_ATTNB_HG96
 #define STJ_ATTNB_HG96 1       // heads per pass of the attention backward kernel (16-bit types); 1: 1068 vs 1059 scenes/s for 3 (59 instead of 121 KB LDS per window)
 #endif
@@ -123,7 +126,7 @@ template <typename T, int C, int RF_ = ((C <= 192) ? 2 : 1)> struct MlpCfg {
   static constexpr int RF = RF_;                      // 16-row fragments per wave
   static constexpr int ROWS = 4 * RF * 16;            // rows per block
   // hidden columns per staged chunk: as many as keep the two images under ~78 KB (two blocks per CU)
-  static constexpr int HC = sizeof(T) == 2 ? (C == 96 ? STJ_MLP_HC96 : (C == 192 ? STJ_MLP_HC192 : 32)) : (C == 96 ? 96 : (C == 192 ? 48 : 16));
+  static constexpr int HC = sizeof(T) == 2 ? (C == 96 ? STJ_MLP_HC96 : (C == 192 ? STJ_MLP_HC192 : STJ_MLP_HC384)) : (C == 96 ? 96 : (C == 192 ? 48 : 16));
   static constexpr int P1 = 4;                        // W1 image [C][HC + P1]: rows 8-byte aligned (tr reads, 8-byte chain reads)
   static constexpr int P2 = sizeof(T) == 2 ? 8 : 4;   // W2 image [HC][C + P2]: rows 16-byte aligned (16-byte fragment reads in backward)
   static constexpr int LD1 = HC + P1, LD2 = C + P2;
@@ -137,6 +140,7 @@ struct MlpArgs {
   const void* dy; void* dx; void* h; void* dpre; void* ln; void* dys; float* dgamma; float* dbeta; int nparts; long long pstride;
   long long M; float eps;
   const long long* rng; int site; float p_drop; long long rows_per_sample;
+  int split; float* part;        // SPLIT kernels: workgroup = (row block, slice of the hidden dimension); partial sums [split][M][C] f32
 };
 
 // Staging of W1[:, hc0 : hc0+HC] ([C][4C] global, row stride 4C) and W2[hc0 : hc0+HC, :] ([4C][C] global) into LDS, split into
@@ -264,7 +268,7 @@ __device__ __forceinline__ void ln_rows(typename Mma<T>::Frag (&xa)[RF][C / Mma<
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <typename T, int C, int RFP>
+template <typename T, int C, int RFP, bool SPLIT = false>
 __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs p) {
   typedef MlpCfg<T, C, RFP> G;
   constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP;
@@ -272,13 +276,24 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
   T* W1s = reinterpret_cast<T*>(mlp_smem);
   T* W2s = W1s + C * G::LD1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ln = lane & 15;
-  const long long m0 = (long long)blockIdx.x * G::ROWS + wave * (RF * 16);
+  // SPLIT (the 2048-row C = 384 stage: 32 row blocks cannot fill 256 CUs, and each would stream all 2.4 MB of weights): workgroup =
+  // (row block, slice sp of the hidden dimension); consecutive workgroups take consecutive slices, so slice sp of the weights is
+  // read by the workgroups of ONE XCD (blockIdx % 8 with 8 slices) and stays in that L2.  Where its 29 us go at 2048 rows (parts
+  // switched off one at a time): 6 weight chunks 13 us (LDS-read bound: with one 16-row fragment per wave every MFMA needs its own A
+  // fragment from LDS), the 25 MB of f32 partial sums 8 us, LayerNorm 2, launch + row loads + first chunk 6; layer by layer: 48 us
+  const int unit = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x, sp = SPLIT ? (int)blockIdx.x % p.split : 0;
+  const int hs0 = SPLIT ? sp * (4 * C / p.split) : 0, hs1 = SPLIT ? hs0 + 4 * C / p.split : 4 * C;
+  const long long m0 = (long long)unit * G::ROWS + wave * (RF * 16);
   const T* x = reinterpret_cast<const T*>(p.x);
   const T* w1 = reinterpret_cast<const T*>(p.w1);
   const T* w2 = reinterpret_cast<const T*>(p.w2);
 
+  // FFN1 bias in LDS: a global load inside the chunk loop sits BEHIND the prefetched weight chunk in the in-order vmcnt queue, so waiting
+  // for it waited for the whole prefetch -- every chunk paid a full memory round trip (found on the C = 384 split kernels: 6 chunks, 32 us)
+  __shared__ float b1s[4 * C];
+  for (int c = hs0 + tid; c < hs1; c += 256) b1s[c] = p.b1[c];
   MlpStage<T, C> stg;
-  stg.issue(w1, w2, 0, tid);                          // first weight chunk in flight under the row loads + LayerNorm
+  stg.issue(w1, w2, hs0, tid);                        // first weight chunk in flight under the row loads + LayerNorm
   typename Mma<T>::Frag xa[RF][KS];
   load_rows<T, C, RF>(xa, x, m0, p.M, lane);
   float mu[RF], rs[RF];
@@ -290,18 +305,18 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc2[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int hc0 = 0; hc0 < 4 * C; hc0 += G::HC) {
+  for (int hc0 = hs0; hc0 < hs1; hc0 += G::HC) {
     __syncthreads();                                  // previous chunk's fragment reads are done
-    if (!STJ_MLP_PREFETCH && hc0 > 0) stg.issue(w1, w2, hc0, tid);
+    if (!STJ_MLP_PREFETCH && hc0 > hs0) stg.issue(w1, w2, hc0, tid);
     stg.commit(W1s, W2s, tid);
     __syncthreads();
-    if (STJ_MLP_PREFETCH && hc0 + G::HC < 4 * C) stg.issue(w1, w2, hc0 + G::HC, tid);      // next chunk: global loads overlap this chunk's MFMAs
+    if (STJ_MLP_PREFETCH && hc0 + G::HC < hs1) stg.issue(w1, w2, hc0 + G::HC, tid);      // next chunk: global loads overlap this chunk's MFMAs
 #pragma unroll 1
     for (int s = 0; s < G::HC / KSTEP; ++s) {
       f32x4 a1[RF][ND];
 #pragma unroll
       for (int d = 0; d < ND; ++d) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.b1 + hc0 + s * KSTEP + 16 * d + 4 * g);
+        const float4 bv = *reinterpret_cast<const float4*>(b1s + hc0 + s * KSTEP + 16 * d + 4 * g);
 #pragma unroll
         for (int i = 0; i < RF; ++i) a1[i][d] = (f32x4){bv.x, bv.y, bv.z, bv.w};
       }
@@ -332,6 +347,17 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
   }
 
   // epilogue: y = x + dp * (acc + b2); the lane holds columns 16 f + 4 g .. +3 of row (m0 + 16 i + ln)
+  if constexpr (SPLIT) {          // this slice's share of the sum over the hidden dimension; swin_split_fwd_epi_kernel finishes the rows
+#pragma unroll
+    for (int i = 0; i < RF; ++i) {
+      const long long row = m0 + 16 * i + ln;
+      if (row >= p.M) continue;
+      float* pr = p.part + ((long long)sp * p.M + row) * C + 4 * g;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(pr + 16 * f) = acc2[i][f];
+    }
+    return;
+  }
   T* y = reinterpret_cast<T*>(p.y);
 #pragma unroll
   for (int i = 0; i < RF; ++i) {
@@ -354,7 +380,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
 // =====================================================================================================================
 // backward
 // =====================================================================================================================
-template <typename T, int C, int RFP>
+template <typename T, int C, int RFP, bool SPLIT = false>
 __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs p) {
   typedef MlpCfg<T, C, RFP> G;
   constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP, LK = Mma<T>::LANE_K;
@@ -363,15 +389,19 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
   T* W1s = reinterpret_cast<T*>(mlp_smem);
   T* W2s = W1s + C * G::LD1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ln = lane & 15;
-  const long long m0 = (long long)blockIdx.x * G::ROWS + wave * (RF * 16);
+  const int unit = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x, sp = SPLIT ? (int)blockIdx.x % p.split : 0;     // see the forward kernel
+  const int hs0 = SPLIT ? sp * (4 * C / p.split) : 0, hs1 = SPLIT ? hs0 + 4 * C / p.split : 4 * C;
+  const long long m0 = (long long)unit * G::ROWS + wave * (RF * 16);
   const T* x = reinterpret_cast<const T*>(p.x);
   const T* dy = reinterpret_cast<const T*>(p.dy);
   const T* w1 = reinterpret_cast<const T*>(p.w1);
   const T* w2 = reinterpret_cast<const T*>(p.w2);
   for (int c = tid; c < 2 * C; c += 256) (&red[0][0])[c] = 0.f;
+  __shared__ float b1s[4 * C];                         // (see the forward kernel)
+  for (int c = hs0 + tid; c < hs1; c += 256) b1s[c] = p.b1[c];
 
   MlpStage<T, C> stg;
-  stg.issue(w1, w2, 0, tid);
+  stg.issue(w1, w2, hs0, tid);
   typename Mma<T>::Frag xa[RF][KS], da[RF][KS];
   load_rows<T, C, RF>(xa, x, m0, p.M, lane);
   load_rows<T, C, RF>(da, dy, m0, p.M, lane);
@@ -393,7 +423,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
         for (int e = 0; e < LK; ++e) v[e] *= dp[i];
         da[i][ks] = frag_pack<T>(v);
       }
-      if (row < p.M) {
+      if (row < p.M && sp == 0) {
         const long long o = row * C + ks * KSTEP + LK * g;
         *reinterpret_cast<typename Mma<T>::Frag*>(lnq + o) = xa[i][ks];
         if (dysq) *reinterpret_cast<typename Mma<T>::Frag*>(dysq + o) = da[i][ks];
@@ -409,18 +439,18 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
   T* hq = reinterpret_cast<T*>(p.h);
   T* dpq = reinterpret_cast<T*>(p.dpre);
 
-  for (int hc0 = 0; hc0 < 4 * C; hc0 += G::HC) {
+  for (int hc0 = hs0; hc0 < hs1; hc0 += G::HC) {
     __syncthreads();
-    if (!STJ_MLP_PREFETCH && hc0 > 0) stg.issue(w1, w2, hc0, tid);
+    if (!STJ_MLP_PREFETCH && hc0 > hs0) stg.issue(w1, w2, hc0, tid);
     stg.commit(W1s, W2s, tid);
     __syncthreads();
-    if (STJ_MLP_PREFETCH && hc0 + G::HC < 4 * C) stg.issue(w1, w2, hc0 + G::HC, tid);
+    if (STJ_MLP_PREFETCH && hc0 + G::HC < hs1) stg.issue(w1, w2, hc0 + G::HC, tid);
 #pragma unroll 1
     for (int s = 0; s < G::HC / KSTEP; ++s) {
       f32x4 a1[RF][ND], a3[RF][ND];                    // pre^T and dh^T, [hidden][row]
 #pragma unroll
       for (int d = 0; d < ND; ++d) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.b1 + hc0 + s * KSTEP + 16 * d + 4 * g);
+        const float4 bv = *reinterpret_cast<const float4*>(b1s + hc0 + s * KSTEP + 16 * d + 4 * g);
 #pragma unroll
         for (int i = 0; i < RF; ++i) { a1[i][d] = (f32x4){bv.x, bv.y, bv.z, bv.w}; a3[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
       }
@@ -467,6 +497,17 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
     }
   }
 
+  if constexpr (SPLIT) {          // this slice's share of d LN(x); swin_split_bwd_epi_kernel sums the slices and runs the LayerNorm backward
+#pragma unroll
+    for (int i = 0; i < RF; ++i) {
+      const long long row = m0 + 16 * i + ln;
+      if (row >= p.M) continue;
+      float* pr = p.part + ((long long)sp * p.M + row) * C + 4 * g;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(pr + 16 * f) = acc[i][f];
+    }
+    return;
+  }
   // LayerNorm backward on the accumulator layout (lane: columns 16 f + 4 g .. +3 of row m0 + 16 i + ln) + the skip gradient
   T* dx = reinterpret_cast<T*>(p.dx);
   float dgs[NF][4], dbs[NF][4];
@@ -530,10 +571,168 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
   for (int c = tid; c < C; c += 256) { atomicAdd(p.dgamma + po + c, red[0][c]); atomicAdd(p.dbeta + po + c, red[1][c]); }
 }
 
-template <typename T, int C, int RFP>
+// ---- the second launch of the SPLIT kernels: sum the slices' partial sums and finish the rows -----------------------------------
+// forward: y = x + dp * (sum_s part[s] + bias)   (both halves of the block: rows_per_sample rows share one DropPath factor)
+template <typename T>
+__global__ __launch_bounds__(256) void swin_split_fwd_epi_kernel(const T* x, const float* part, int S, const float* bias, T* y, long long M, int C,
+                                                                 const long long* rng, int site, float p_drop, long long rows_per_sample) {
+  const long long n4 = M * C / 4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += gridDim.x * 256ll) {
+    const long long row = i / (C / 4);
+    const int col = (int)(i % (C / 4)) * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+    float a[4] = {bv.x, bv.y, bv.z, bv.w};
+    for (int s = 0; s < S; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((long long)s * M + row) * C + col);
+      a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+    }
+    const float dp = drop_path_scale(rng, site, row / rows_per_sample, p_drop);
+    float xv[4];
+    ld4(x + row * C + col, xv);
+    const float v[4] = {xv[0] + dp * a[0], xv[1] + dp * a[1], xv[2] + dp * a[2], xv[3] + dp * a[3]};
+    st4(y + row * C + col, v);
+  }
+}
+template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b) {
+  if constexpr (sizeof(T) == 4) { const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y; }
+  else unpack2<T>(*reinterpret_cast<const uint32_t*>(p), a, b);
+}
+template <typename T> __device__ __forceinline__ void st2(T* p, float a, float b) {
+  if constexpr (sizeof(T) == 4) *reinterpret_cast<float2*>(p) = make_float2(a, b);
+  else *reinterpret_cast<uint32_t*>(p) = pack2<T>(a, b);
+}
+// backward: d = sum_s part[s] = d LN(x); dx = dy + LN'(d) with the row statistics recomputed from x (or read from mean / rstd when given);
+// gamma / beta gradients into copy (block % nparts).  A wave owns RPW rows at a time (all their loads in flight together: one row at a
+// time ran 19 us for 2048 rows, a chain of load -> three wave reductions per row), a lane 2 adjacent columns of every 128.
+template <typename T, int C, int RPW>
+__global__ __launch_bounds__(256) void swin_split_bwd_epi_kernel(const T* x, const T* dy, const float* part, int S, const float* gamma, float eps,
+                                                                 const float* mean, const float* rstd, T* dx, float* dgamma, float* dbeta,
+                                                                 int nparts, long long pstride, long long M) {
+  constexpr int NJ = C / 128;
+  __shared__ float red[2][C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < 2 * C; c += 256) (&red[0][0])[c] = 0.f;
+  __syncthreads();
+  float dg[NJ][2], db[NJ][2], gm[NJ][2];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const float2 g2 = *reinterpret_cast<const float2*>(gamma + 128 * j + 2 * lane);
+    gm[j][0] = g2.x; gm[j][1] = g2.y;
+    dg[j][0] = dg[j][1] = db[j][0] = db[j][1] = 0.f;
+  }
+  for (long long r0 = (blockIdx.x * 4ll + wave) * RPW; r0 < M; r0 += gridDim.x * 4ll * RPW) {
+    float xv[RPW][NJ][2], d[RPW][NJ][2], dv[RPW][NJ][2], s[RPW], q[RPW], mu[RPW], rs[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const long long row = r0 + i < M ? r0 + i : M - 1;            // (tail rows repeat the last row; their results are dropped)
+      s[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const long long o = row * C + 128 * j + 2 * lane;
+        ld2<T>(x + o, xv[i][j][0], xv[i][j][1]);
+        ld2<T>(dy + o, dv[i][j][0], dv[i][j][1]);
+        d[i][j][0] = d[i][j][1] = 0.f;
+        s[i] += xv[i][j][0] + xv[i][j][1];
+      }
+    }
+    for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const long long row = r0 + i < M ? r0 + i : M - 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float2 v = *reinterpret_cast<const float2*>(part + ((long long)sl * M + row) * C + 128 * j + 2 * lane);
+          d[i][j][0] += v.x; d[i][j][1] += v.y;
+        }
+      }
+    if (mean != nullptr) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) { const long long row = r0 + i < M ? r0 + i : M - 1; mu[i] = mean[row]; rs[i] = rstd[row]; }
+    } else {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) s[i] += __shfl_xor(s[i], o, 64);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        mu[i] = s[i] * (1.f / C);
+        q[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const float a = xv[i][j][0] - mu[i], b = xv[i][j][1] - mu[i]; q[i] += a * a + b * b; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) q[i] += __shfl_xor(q[i], o, 64);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) rs[i] = rsqrtf(q[i] * (1.f / C) + eps);
+    }
+    float s1[RPW], s2[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const bool live = r0 + i < M;
+      s1[i] = s2[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float xh = (xv[i][j][e] - mu[i]) * rs[i];
+          xv[i][j][e] = xh;
+          const float dd = live ? d[i][j][e] : 0.f;
+          dg[j][e] += dd * xh;
+          db[j][e] += dd;
+          const float t = dd * gm[j][e];
+          d[i][j][e] = t;
+          s1[i] += t; s2[i] += t * xh;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) { s1[i] += __shfl_xor(s1[i], o, 64); s2[i] += __shfl_xor(s2[i], o, 64); }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      if (r0 + i >= M) continue;
+      const float a1 = s1[i] * (1.f / C), a2 = s2[i] * (1.f / C);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const long long o = (r0 + i) * C + 128 * j + 2 * lane;
+        st2<T>(dx + o, dv[i][j][0] + rs[i] * (d[i][j][0] - a1 - xv[i][j][0] * a2), dv[i][j][1] + rs[i] * (d[i][j][1] - a1 - xv[i][j][1] * a2));
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { atomicAdd(&red[0][128 * j + 2 * lane + e], dg[j][e]); atomicAdd(&red[1][128 * j + 2 * lane + e], db[j][e]); }
+  __syncthreads();
+  const long long po = (long long)(blockIdx.x % nparts) * pstride;
+  for (int c = tid; c < C; c += 256) { atomicAdd(dgamma + po + c, red[0][c]); atomicAdd(dbeta + po + c, red[1][c]); }
+}
+template <typename T>
+static int split_fwd_epi(const void* x, const float* part, int S, const float* bias, void* y, long long M, int C, const long long* rng, int site,
+                         float p_drop, long long rows_per_sample, hipStream_t st) {
+  const long long n4 = M * C / 4;
+  const int grid = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+  hipLaunchKernelGGL(swin_split_fwd_epi_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)x, part, S, bias, (T*)y, M, C, rng, site, p_drop, rows_per_sample);
+  return stj_check_launch("swin_split_fwd_epi");
+}
+template <typename T>
+static int split_bwd_epi(const void* x, const void* dy, const float* part, int S, const float* gamma, float eps, const float* mean, const float* rstd,
+                         void* dx, float* dgamma, float* dbeta, int nparts, long long pstride, long long M, hipStream_t st) {
+  // 2 rows per wave in flight, 256 workgroups at 2048 rows: 16 us; (4 rows, 128 workgroups) 27 us, (1, 512) 23 us, (1 at a time, 128) 19 us
+  const int grid = (int)((M + 7) / 8);
+  hipLaunchKernelGGL((swin_split_bwd_epi_kernel<T, 384, 2>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dy, part, S, gamma, eps, mean, rstd,
+                     (T*)dx, dgamma, dbeta, nparts, pstride, M);
+  return stj_check_launch("swin_split_bwd_epi");
+}
+constexpr int SPLIT_MAX = 8;         // slices of a split launch (the workspace holds SPLIT_MAX x M x C floats)
+constexpr int MLP_SPLIT = 8;         // hidden-dimension slices of the C = 384 MLP half: 32 row blocks x 8 = 256 workgroups at B = 8
+
+template <typename T, int C, int RFP, bool SPLIT = false>
 static int mlp_launch(bool bwd, const MlpArgs& a, hipStream_t st) {
   typedef MlpCfg<T, C, RFP> G;
-  const void* fn = bwd ? (const void*)swin_mlp_bwd_kernel<T, C, RFP> : (const void*)swin_mlp_fwd_kernel<T, C, RFP>;
+  const void* fn = bwd ? (const void*)swin_mlp_bwd_kernel<T, C, RFP, SPLIT> : (const void*)swin_mlp_fwd_kernel<T, C, RFP, SPLIT>;
   static bool attr[2] = {false, false};
   if (!attr[bwd]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
@@ -541,9 +740,9 @@ static int mlp_launch(bool bwd, const MlpArgs& a, hipStream_t st) {
     }
     attr[bwd] = true;
   }
-  dim3 grid((unsigned)((a.M + G::ROWS - 1) / G::ROWS));
-  if (bwd) hipLaunchKernelGGL((swin_mlp_bwd_kernel<T, C, RFP>), grid, dim3(256), G::LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((swin_mlp_fwd_kernel<T, C, RFP>), grid, dim3(256), G::LDS_BYTES, st, a);
+  dim3 grid((unsigned)((a.M + G::ROWS - 1) / G::ROWS) * (SPLIT ? a.split : 1));
+  if (bwd) hipLaunchKernelGGL((swin_mlp_bwd_kernel<T, C, RFP, SPLIT>), grid, dim3(256), G::LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((swin_mlp_fwd_kernel<T, C, RFP, SPLIT>), grid, dim3(256), G::LDS_BYTES, st, a);
   return stj_check_launch(bwd ? "stj_swin_mlp_bwd" : "stj_swin_mlp_fwd");
 }
 template <typename T>
@@ -554,7 +753,15 @@ static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
   switch (C) {
     case 96: return two ? mlp_launch<T, 96, 2>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
     case 192: return two ? mlp_launch<T, 192, 2>(bwd, a, st) : mlp_launch<T, 192, 1>(bwd, a, st);
-    case 384: return mlp_launch<T, 384, 1>(bwd, a, st);
+    case 384: {
+      if (a.part == nullptr) return mlp_launch<T, 384, 1>(bwd, a, st);
+      MlpArgs s = a;                 // with a workspace: (row block, hidden slice) workgroups + the finishing launch
+      s.split = MLP_SPLIT;
+      const int rc = mlp_launch<T, 384, 1, true>(bwd, s, st);
+      if (rc != STJ_OK) return rc;
+      if (bwd) return split_bwd_epi<T>(a.x, a.dy, a.part, MLP_SPLIT, a.gamma, a.eps, nullptr, nullptr, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.M, st);
+      return split_fwd_epi<T>(a.x, a.part, MLP_SPLIT, a.b2, a.y, a.M, C, a.rng, a.site, a.p_drop, a.rows_per_sample, st);
+    }
     default: stj_set_error("swin_mlp: C must be 96, 192 or 384 (got %d)", C); return STJ_EUNSUPPORTED;
   }
 }
@@ -569,10 +776,15 @@ static int mlp_any(bool bwd, int C, int dtype, const MlpArgs& a, hipStream_t st)
   return STJ_EINVAL;
 }
 
+// bytes of the f32 workspace `ws` of the four stj_swin_* entry points at C = 384 (NULL: the one-workgroup-per-row-block kernels; other
+// C: ignored): the slices' partial sums [SPLIT_MAX][M][C]
+extern "C" long long stj_swin_split_workspace_bytes(long long M, int C) { return (long long)SPLIT_MAX * M * C * 4; }
+
 extern "C" int stj_swin_mlp_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
                                 const float* b2, void* y, long long M, int C, float eps, const long long* rng_state, int site,
-                                float p_drop, long long rows_per_sample, int dtype, hipStream_t stream) {
+                                float p_drop, long long rows_per_sample, int dtype, void* ws, hipStream_t stream) {
   MlpArgs a = {};
+  a.part = reinterpret_cast<float*>(ws);
   a.x = x; a.gamma = gamma; a.beta = beta; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.M = M; a.eps = eps;
   a.rng = rng_state; a.site = site; a.p_drop = p_drop; a.rows_per_sample = rows_per_sample;
   return mlp_any(false, C, dtype, a, stream);
@@ -581,9 +793,10 @@ extern "C" int stj_swin_mlp_fwd(const void* x, const float* gamma, const float* 
 extern "C" int stj_swin_mlp_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const void* w1, const float* b1,
                                 const void* w2, void* dx, void* h, void* dpre, void* ln, void* dys, float* dgamma, float* dbeta,
                                 int nparts, long long part_stride, long long M, int C, float eps, const long long* rng_state, int site,
-                                float p_drop, long long rows_per_sample, int dtype, hipStream_t stream) {
+                                float p_drop, long long rows_per_sample, int dtype, void* ws, hipStream_t stream) {
   if (nparts < 1) { stj_set_error("swin_mlp_bwd: nparts must be >= 1"); return STJ_EINVAL; }
   MlpArgs a = {};
+  a.part = reinterpret_cast<float*>(ws);
   a.x = x; a.dy = dy; a.gamma = gamma; a.beta = beta; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.dx = dx; a.h = h; a.dpre = dpre; a.ln = ln;
   a.dys = dys; a.dgamma = dgamma; a.dbeta = dbeta; a.nparts = nparts; a.pstride = part_stride; a.M = M; a.eps = eps;
   a.rng = rng_state; a.site = site; a.p_drop = p_drop; a.rows_per_sample = rows_per_sample;
@@ -626,6 +839,7 @@ struct AttnArgs {
   void* qkv; void* a; void* ln; float* mean; float* rstd;         // training hand-offs (all NULL for inference)
   int B, res, shift; float eps;
   const long long* rng; int site; float p_drop;
+  int split; float* part;        // SPLIT kernel: workgroup = (window, slice of the heads); partial sums [split][M][C] f32 in token order
 };
 
 // weight slices of one head group, global -> registers (issued ahead) -> LDS
@@ -672,7 +886,7 @@ template <typename T, int C> struct AttnStage {
   }
 };
 
-template <typename T, int C>
+template <typename T, int C, bool SPLIT = false>
 __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnArgs p) {
   typedef AttnCfg<T, C> G;
   constexpr int KS = G::KS, NF = G::NF, HG = G::HG, GC = G::GC, KSTEP = G::KSTEP, ND = Chain<T>::ND, LK = Mma<T>::LANE_K;
@@ -688,10 +902,15 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, ln = lane & 15;
   const T* wq = reinterpret_cast<const T*>(p.wqkv);
   const T* wp = reinterpret_cast<const T*>(p.wproj);
+  // SPLIT (C = 384: 32 windows at B = 8 cannot fill the chip): workgroup = (window, slice sp of the heads)
+  const int unit = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x, sp = SPLIT ? (int)blockIdx.x % p.split : 0;
+  const int hb0 = SPLIT ? sp * (G::HEADS / p.split) : 0, hb1 = SPLIT ? hb0 + G::HEADS / p.split : G::HEADS;
+  __shared__ float bqs[3 * C];                       // qkv bias in LDS (a global load inside the head loop would wait for the prefetched weights)
+  for (int c = tid; c < 3 * C; c += 256) bqs[c] = p.bqkv[c];
   AttnStage<T, C> stg;
-  stg.issue(wq, wp, 0, tid);                         // first head group's weights in flight under the row gather + LayerNorm
+  stg.issue(wq, wp, hb0, tid);                       // first head group's weights in flight under the row gather + LayerNorm
   const int nwx = p.res / 8, nW = nwx * nwx;
-  const int win = blockIdx.x % nW, b = blockIdx.x / nW;
+  const int win = unit % nW, b = unit / nW;
   const int wy = win / nwx, wx = win % nwx;
   const long long N = (long long)p.res * p.res;
   if (tid < 64) {
@@ -716,7 +935,7 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   }
   float mu[1], rs[1];
   ln_rows<T, C, 1>(xa, p.gamma, p.beta, p.eps, mu, rs, lane);
-  if (p.ln) {
+  if (p.ln && sp == 0) {
     T* lq = reinterpret_cast<T*>(p.ln) + myrow * C + LK * g;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<typename Mma<T>::Frag*>(lq + ks * KSTEP) = xa[0][ks];
@@ -728,17 +947,17 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   for (int f = 0; f < NF; ++f) acco[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float scale = 0.17677669529663687f;       // 32^-1/2
 
-  for (int h0 = 0; h0 < G::HEADS; h0 += HG) {
+  for (int h0 = hb0; h0 < hb1; h0 += HG) {
     // ---- weight slices of this head group (Wqkv[:, seg*C + 32 h0 .. +GC] for seg = q,k,v; Wproj[32 h0 .. +GC, :]): registers -> LDS
     stg.commit(Wqs, Wps, tid);
     for (int q = tid; q < HG * 225; q += 256) tbl[q] = p.table[(q % 225) * G::HEADS + h0 + q / 225];
     __syncthreads();
-    if (h0 + HG < G::HEADS) stg.issue(wq, wp, h0 + HG, tid);       // next group's slices fly while this group computes
+    if (h0 + HG < hb1) stg.issue(wq, wp, h0 + HG, tid);            // next group's slices fly while this group computes
     // ---- phase 1: q|k|v of this group for the wave's 16 tokens -> tile
 #pragma unroll 1
     for (int f = 0; f < 3 * GC / 16; ++f) {
       const int seg = (16 * f) / GC, within = (16 * f) % GC;
-      const float4 bv = *reinterpret_cast<const float4*>(p.bqkv + seg * C + 32 * h0 + within + 4 * g);
+      const float4 bv = *reinterpret_cast<const float4*>(bqs + seg * C + 32 * h0 + within + 4 * g);
       f32x4 a = (f32x4){bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) a = Mma<T>::mma(Mma<T>::load_tr(Wqs, G::LDW, 16 * f, ks * KSTEP, lane), xa[0][ks], a);
@@ -817,6 +1036,12 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   }
 
   // ---- epilogue: y = x + dp * (out + bproj)
+  if constexpr (SPLIT) {          // this head slice's share of the projection; swin_split_fwd_epi_kernel finishes the rows
+    float* pr = p.part + ((long long)sp * p.B * N + myrow) * C + 4 * g;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(pr + 16 * f) = acco[f];
+    return;
+  }
   const float dp = drop_path_scale(p.rng, p.site, b, p.p_drop);
   T* y = reinterpret_cast<T*>(p.y) + myrow * C;
   const T* xr = reinterpret_cast<const T*>(p.x) + myrow * C;
@@ -831,35 +1056,51 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   }
 }
 
-template <typename T, int C>
+constexpr int ATTN_SPLIT = 6;        // head slices of the C = 384 attention half (2 of the 12 heads each): 32 windows x 6 = 192 workgroups at B = 8
+template <typename T, int C, bool SPLIT = false>
 static int attn_launch(const AttnArgs& a, hipStream_t st) {
   typedef AttnCfg<T, C> G;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)swin_attn_fwd_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)swin_attn_fwd_kernel<T, C, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
       stj_set_error("swin_attn: cannot reserve %d bytes of LDS", G::LDS_BYTES); return STJ_ELAUNCH;
     }
     attr = true;
   }
   const int nW = (a.res / 8) * (a.res / 8);
-  hipLaunchKernelGGL((swin_attn_fwd_kernel<T, C>), dim3((unsigned)(a.B * nW)), dim3(256), G::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((swin_attn_fwd_kernel<T, C, SPLIT>), dim3((unsigned)(a.B * nW * (SPLIT ? a.split : 1))), dim3(256), G::LDS_BYTES, st, a);
   return stj_check_launch("stj_swin_attn_fwd");
+}
+// C = 384 (the 16 x 16 stage: 32 windows at B = 8): (window, head slice) workgroups + the finishing launch; 16-bit types with a workspace
+// (the f32 weight slice of a head does not fit LDS next to the tile: that mode keeps the layer-by-layer path)
+template <typename T>
+static int attn_split384(const AttnArgs& a, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (a.part == nullptr) { stj_set_error("swin_attn: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
+    AttnArgs s = a;
+    s.split = ATTN_SPLIT;
+    const int rc = attn_launch<T, 384, true>(s, st);
+    if (rc != STJ_OK) return rc;
+    const long long N = (long long)a.res * a.res;
+    return split_fwd_epi<T>(a.x, a.part, ATTN_SPLIT, a.bproj, a.y, a.B * N, 384, a.rng, a.site, a.p_drop, N, st);
+  } else {
+    stj_set_error("swin_attn: C = 384 is built for the 16-bit storage types"); return STJ_EUNSUPPORTED;
+  }
 }
 template <typename T>
 static int attn_dispatch(int C, const AttnArgs& a, hipStream_t st) {
   switch (C) {
     case 96: return attn_launch<T, 96>(a, st);
     case 192: return attn_launch<T, 192>(a, st);
-    // C = 384 (the 16x16 stage, 32 windows at B = 8): too few workgroups for a window-per-workgroup kernel, and the f32 weight
-    // slice alone would not fit LDS -- that stage keeps the layer-by-layer path
-    default: stj_set_error("swin_attn: C must be 96 or 192 (got %d)", C); return STJ_EUNSUPPORTED;
+    case 384: return attn_split384<T>(a, st);
+    default: stj_set_error("swin_attn: C must be 96, 192 or 384 (got %d)", C); return STJ_EUNSUPPORTED;
   }
 }
 
 extern "C" int stj_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wqkv, const float* bqkv,
                                  const float* table, const void* wproj, const float* bproj, void* y, void* qkv, void* a, void* ln,
                                  float* mean, float* rstd, int B, int res, int C, int shift, float eps, const long long* rng_state,
-                                 int site, float p_drop, int dtype, hipStream_t stream) {
+                                 int site, float p_drop, int dtype, void* ws, hipStream_t stream) {
   if (B <= 0) return STJ_OK;
   if (res % 8 != 0 || shift < 0 || shift >= 8) { stj_set_error("swin_attn: res %% 8 != 0 or bad shift"); return STJ_EINVAL; }
   if (!(p_drop >= 0.f && p_drop < 1.f)) { stj_set_error("swin_attn: need 0 <= p_drop < 1"); return STJ_EINVAL; }
@@ -867,7 +1108,7 @@ extern "C" int stj_swin_attn_fwd(const void* x, const float* gamma, const float*
   AttnArgs p = {};
   p.x = x; p.gamma = gamma; p.beta = beta; p.wqkv = wqkv; p.bqkv = bqkv; p.table = table; p.wproj = wproj; p.bproj = bproj; p.y = y;
   p.qkv = qkv; p.a = a; p.ln = ln; p.mean = mean; p.rstd = rstd; p.B = B; p.res = res; p.shift = shift; p.eps = eps;
-  p.rng = rng_state; p.site = site; p.p_drop = p_drop;
+  p.rng = rng_state; p.site = site; p.p_drop = p_drop; p.part = reinterpret_cast<float*>(ws);
   if (dtype == STJ_BF16) return attn_dispatch<bf16>(C, p, stream);
   if (dtype == STJ_F16) return attn_dispatch<f16>(C, p, stream);
   if (dtype == STJ_F32) return attn_dispatch<float>(C, p, stream);
@@ -888,7 +1129,7 @@ extern "C" int stj_swin_attn_fwd(const void* x, const float* gamma, const float*
 template <typename T, int C> struct AttnBCfg {
   static constexpr int KSTEP = Mma<T>::KSTEP;
   static constexpr int KS = C / KSTEP, NF = C / 16, HEADS = C / 32;
-  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? STJ_ATTNB_HG96 : STJ_ATTNB_HG192) : 1;    // heads per pass
+  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? STJ_ATTNB_HG96 : (C == 192 ? STJ_ATTNB_HG192 : 1)) : 1;    // heads per pass
   static constexpr int GC = 32 * HG;
   static constexpr int PADK = sizeof(T) == 2 ? 16 : 8;                 // pad of k-contiguous images read with 16-byte fragments
   static constexpr int LDT = 3 * GC + PADK;                            // q|k|v (then dq|dk|dv) tile [64][LDT]
@@ -908,6 +1149,7 @@ struct AttnBArgs {
   void* dx; void* dqkv; void* dys; float* dtable; int tparts; float* dgamma; float* dbeta; int nparts; long long pstride;
   int B, res, shift;
   const long long* rng; int site; float p_drop;
+  int split; float* part;        // SPLIT kernel: workgroup = (window, slice of the heads); partial d LN(x) [split][M][C] f32 in token order
 };
 
 // staging geometry of the backward kernel (chunks per thread).  (The first version copied each 16-byte piece load -> store in a loop:
@@ -920,11 +1162,20 @@ template <typename T, int C> struct AttnBStage {
   static constexpr int NT = (64 * 3 * CPS + 255) / 256;
 };
 
-template <typename T, int C>
+template <typename T, int C, int NSPLIT = 1>
 __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(AttnBArgs p) {
   typedef AttnBCfg<T, C> G;
   constexpr int KS = G::KS, NF = G::NF, HG = G::HG, GC = G::GC, KSTEP = G::KSTEP, ND = Chain<T>::ND, LK = Mma<T>::LANE_K;
   constexpr int VN = Vec<T>::N;
+  // NSPLIT > 1 (C = 384: 32 windows at B = 8 cannot fill the chip): workgroup = (window, slice sp of the heads); it needs da only for
+  // its NH heads (their 32 NH rows of Wproj), and leaves its share of d LN(x) to swin_split_bwd_epi_kernel
+  constexpr bool SPLIT = NSPLIT > 1;
+  constexpr int NH = G::HEADS / NSPLIT;               // heads of this workgroup
+  constexpr int DAF = SPLIT ? 2 * NH : NF;            // 16-column fragments of da it computes
+  constexpr int PR = SPLIT ? 32 * NH : C;             // rows of Wproj it stages
+  static_assert(G::HEADS % NSPLIT == 0 && NH % HG == 0, "head slices");
+  const int unit = SPLIT ? (int)blockIdx.x / NSPLIT : (int)blockIdx.x, sp = SPLIT ? (int)blockIdx.x % NSPLIT : 0;
+  const int hb0 = SPLIT ? sp * NH : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char ab_smem[];
   T* tile = reinterpret_cast<T*>(ab_smem);
   T* Wb = tile + G::TILE;
@@ -938,7 +1189,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, ln = lane & 15;
   const int nwx = p.res / 8, nW = nwx * nwx;
-  const int win = blockIdx.x % nW, b = blockIdx.x / nW;
+  const int win = unit % nW, b = unit / nW;
   const int wy = win / nwx, wx = win % nwx;
   const long long N = (long long)p.res * p.res;
   if (tid < 64) {
@@ -952,6 +1203,10 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
     lab[t] = ly * 3 + lx;
   }
   for (int c = tid; c < 2 * C; c += 256) red[c] = 0.f;
+  // bias tables of the workgroup's heads in LDS up front: a global load inside the head loop sits behind the prefetched weight group in the
+  // in-order vmcnt queue and made every head wait for the whole prefetch
+  __shared__ float tbv[NH * 225];
+  for (int q = tid; q < NH * 225; q += 256) tbv[q] = p.table[(q % 225) * G::HEADS + hb0 + q / 225];
   __syncthreads();
   const long long myrow = (long long)b * N + tok[16 * wv + ln];
   const T* wq = reinterpret_cast<const T*>(p.wqkv);
@@ -961,21 +1216,22 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
   T* dqkvb = reinterpret_cast<T*>(p.dqkv) + (long long)b * N * 3 * C;
   // staging registers: weight chunk / q|k|v tile, global -> registers (all loads of a chunk in flight at once, issued a phase ahead) -> LDS
   typedef AttnBStage<T, C> SG;
-  uint4 s_wp[SG::NWP], s_wq[SG::NWQ], s_t[SG::NT];
-  auto issue_wp = [&](int k0) __attribute__((always_inline)) {                      // Wproj[:, k0 .. k0+KC1]
+  constexpr int NWP = (PR * SG::CP1 + 255) / 256;
+  uint4 s_wp[NWP], s_wq[SG::NWQ], s_t[SG::NT];
+  auto issue_wp = [&](int k0) __attribute__((always_inline)) {                      // Wproj[rows of the workgroup's heads, k0 .. k0+KC1]
 #pragma unroll
-    for (int i = 0; i < SG::NWP; ++i) {
+    for (int i = 0; i < NWP; ++i) {
       const int q = tid + i * 256;
       uint4 v = make_uint4(0, 0, 0, 0);        // unconditional store of a selected value: a conditional store keeps the array in scratch
-      if (q < C * SG::CP1) v = *reinterpret_cast<const uint4*>(wp + (long long)(q / SG::CP1) * C + k0 + (q % SG::CP1) * VN);
+      if (q < PR * SG::CP1) v = *reinterpret_cast<const uint4*>(wp + (long long)(32 * hb0 + q / SG::CP1) * C + k0 + (q % SG::CP1) * VN);
       s_wp[i] = v;
     }
   };
   auto commit_wp = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < SG::NWP; ++i) {
+    for (int i = 0; i < NWP; ++i) {
       const int q = tid + i * 256;
-      if (q < C * SG::CP1) *reinterpret_cast<uint4*>(Wb + (q / SG::CP1) * G::LDW + (q % SG::CP1) * VN) = s_wp[i];
+      if (q < PR * SG::CP1) *reinterpret_cast<uint4*>(Wb + (q / SG::CP1) * G::LDW + (q % SG::CP1) * VN) = s_wp[i];
     }
   };
   auto issue_group = [&](int h0) __attribute__((always_inline)) {                   // Wqkv[:, q|k|v columns of the head group] and the group's q|k|v tile
@@ -1029,24 +1285,24 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
         for (int e = 0; e < LK; ++e) v[e] *= dp;
         dya[ks] = frag_pack<T>(v);
       }
-      if (p.dys) *reinterpret_cast<typename Mma<T>::Frag*>(reinterpret_cast<T*>(p.dys) + myrow * C + ks * KSTEP + LK * g) = dya[ks];
+      if (p.dys && sp == 0) *reinterpret_cast<typename Mma<T>::Frag*>(reinterpret_cast<T*>(p.dys) + myrow * C + ks * KSTEP + LK * g) = dya[ks];
     }
   }
   // ---- phase 1: da^T[c][tok] = sum_oc Wproj[c][oc] dys^T[oc][tok]  (A = Wproj rows, k = oc contiguous: the natural layout)
-  f32x4 da[NF];
+  f32x4 da[DAF];
 #pragma unroll
-  for (int f = 0; f < NF; ++f) da[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < DAF; ++f) da[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k0 = 0; k0 < C; k0 += G::KC1) {
     __syncthreads();
     if (k0 > 0) issue_wp(k0);
     commit_wp();
     __syncthreads();
-    if (k0 + G::KC1 >= C) issue_group(0);             // first head group: in flight under the proj MFMAs
+    if (k0 + G::KC1 >= C) issue_group(hb0);           // first head group: in flight under the proj MFMAs
 #pragma unroll
     for (int kk = 0; kk < G::KC1 / KSTEP; ++kk)
 #pragma unroll
-      for (int f = 0; f < NF; ++f)
+      for (int f = 0; f < DAF; ++f)
         da[f] = Mma<T>::mma(Mma<T>::load(Wb, G::LDW, 16 * f, kk * KSTEP, lane), dya[k0 / KSTEP + kk], da[f]);
   }
 
@@ -1057,22 +1313,23 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
   const int mylab = lab[qi];
 
 #pragma unroll
-  for (int h0 = 0; h0 < G::HEADS; h0 += HG) {      // unrolled: the da[] fragments of a head are picked by a compile-time index
+  for (int hl = 0; hl < NH; hl += HG) {            // unrolled: the da[] fragments of a head are picked by a compile-time index
+    const int h0 = hb0 + hl;
     __syncthreads();                                  // previous pass done with the tile and the weight buffer
     // q|k|v of this head group -> tile (token-major, gathered); Wqkv[:, group columns] -> weight buffer (rows = c): fetched during
     // the previous phase, committed here; the next group's go in flight right away
     commit_group();
     __syncthreads();
-    if (h0 + HG < G::HEADS) issue_group(h0 + HG);
+    if (hl + HG < NH) issue_group(h0 + HG);
 #pragma unroll
     for (int hh = 0; hh < HG; ++hh) {
-      const int h = h0 + hh;
+      const int h = h0 + hh, hd = hl + hh;             // head; its index among the da[] fragments
       if (hh > 0) __syncthreads();                    // previous head's P / dS / dO / table readers are done
-      for (int q = tid; q < 225; q += 256) tbl[q] = p.table[q * G::HEADS + h];
+      for (int q = tid; q < 225; q += 256) tbl[q] = tbv[hd * 225 + q];
       {   // dO of this head (this wave's 16 queries) -> LDS, token-major
 #pragma unroll
         for (int jd = 0; jd < 2; ++jd) {
-          const f32x4 v4 = da[2 * h + jd];
+          const f32x4 v4 = da[2 * hd + jd];
           const float v[4] = {v4[0], v4[1], v4[2], v4[3]};
           st4(dOt + qi * G::LDO + 16 * jd + 4 * g, v);
         }
@@ -1112,7 +1369,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
         dpt[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 32 / KSTEP; ++kk)
-          dpt[j] = Mma<T>::mma(Chain<T>::ldA(tile + 2 * GC + 32 * hh, G::LDT, 16 * j, kk * KSTEP, lane), Chain<T>::from_acc(&da[2 * h + kk * ND]), dpt[j]);
+          dpt[j] = Mma<T>::mma(Chain<T>::ldA(tile + 2 * GC + 32 * hh, G::LDT, 16 * j, kk * KSTEP, lane), Chain<T>::from_acc(&da[2 * hd + kk * ND]), dpt[j]);
       }
       float dsum = 0.f;
 #pragma unroll
@@ -1187,7 +1444,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
       }
       __syncthreads();
       for (int bin = tid; bin < 225; bin += 256)
-        atomicAdd(p.dtable + (long long)(blockIdx.x % p.tparts) * 225 * G::HEADS + bin * G::HEADS + h, tbl[bin]);
+        atomicAdd(p.dtable + (long long)(unit % p.tparts) * 225 * G::HEADS + bin * G::HEADS + h, tbl[bin]);
     }
     __syncthreads();                                  // dq | dk | dv of the whole group are in the tile
     {   // copy-out for the qkv weight gradient (rows in original token order), then dLN^T += Wqkv[:, group] dqkv_group^T
@@ -1205,6 +1462,12 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
     }
   }
 
+  if constexpr (SPLIT) {          // this head slice's share of d LN(x)
+    float* pr = p.part + ((long long)sp * p.B * N + myrow) * C + 4 * g;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(pr + 16 * f) = dln[f];
+    return;
+  }
   // ---- LayerNorm backward on the accumulator layout + the shortcut gradient; gamma / beta partial sums
   {
     const float mu = p.mean[myrow], rs = p.rstd[myrow];
@@ -1252,26 +1515,38 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
   for (int c = tid; c < C; c += 256) { atomicAdd(p.dgamma + po + c, red[c]); atomicAdd(p.dbeta + po + c, red[C + c]); }
 }
 
-template <typename T, int C>
+template <typename T, int C, int NSPLIT = 1>
 static int attnb_launch(const AttnBArgs& a, hipStream_t st) {
   typedef AttnBCfg<T, C> G;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel<T, C, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
       stj_set_error("swin_attn_bwd: cannot reserve %d bytes of LDS", G::LDS_BYTES); return STJ_ELAUNCH;
     }
     attr = true;
   }
   const int nW = (a.res / 8) * (a.res / 8);
-  hipLaunchKernelGGL((swin_attn_bwd_kernel<T, C>), dim3((unsigned)(a.B * nW)), dim3(256), G::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((swin_attn_bwd_kernel<T, C, NSPLIT>), dim3((unsigned)(a.B * nW * NSPLIT)), dim3(256), G::LDS_BYTES, st, a);
   return stj_check_launch("stj_swin_attn_bwd");
+}
+template <typename T>
+static int attnb_split384(const AttnBArgs& a, hipStream_t st) {          // see attn_split384
+  if constexpr (sizeof(T) == 2) {
+    if (a.part == nullptr) { stj_set_error("swin_attn_bwd: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
+    const int rc = attnb_launch<T, 384, ATTN_SPLIT>(a, st);
+    if (rc != STJ_OK) return rc;
+    const long long N = (long long)a.res * a.res;
+    return split_bwd_epi<T>(a.x, a.dy, a.part, ATTN_SPLIT, a.gamma, 0.f, a.mean, a.rstd, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.B * N, st);
+  } else {
+    stj_set_error("swin_attn_bwd: C = 384 is built for the 16-bit storage types"); return STJ_EUNSUPPORTED;
+  }
 }
 
 extern "C" int stj_swin_attn_bwd(const void* x, const void* dy, const void* qkv, const float* mean, const float* rstd, const float* gamma,
                                  const void* wqkv, const void* wproj, const float* table, void* dx, void* dqkv, void* dys,
                                  float* dtable, int tparts, float* dgamma, float* dbeta, int nparts, long long part_stride,
                                  int B, int res, int C, int shift, const long long* rng_state, int site, float p_drop, int dtype,
-                                 hipStream_t stream) {
+                                 void* ws, hipStream_t stream) {
   if (B <= 0) return STJ_OK;
   if (res % 8 != 0 || shift < 0 || shift >= 8) { stj_set_error("swin_attn_bwd: res %% 8 != 0 or bad shift"); return STJ_EINVAL; }
   if (tparts < 1 || nparts < 1) { stj_set_error("swin_attn_bwd: tparts / nparts must be >= 1"); return STJ_EINVAL; }
@@ -1280,7 +1555,8 @@ extern "C" int stj_swin_attn_bwd(const void* x, const void* dy, const void* qkv,
   p.x = x; p.dy = dy; p.qkv = qkv; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.wqkv = wqkv; p.wproj = wproj; p.table = table;
   p.dx = dx; p.dqkv = dqkv; p.dys = dys; p.dtable = dtable; p.tparts = tparts; p.dgamma = dgamma; p.dbeta = dbeta; p.nparts = nparts;
   p.pstride = part_stride; p.B = B; p.res = res; p.shift = shift; p.rng = rng_state; p.site = site; p.p_drop = p_drop;
-#define STJ_AB(TT) (C == 96 ? attnb_launch<TT, 96>(p, stream) : (C == 192 ? attnb_launch<TT, 192>(p, stream) : (stj_set_error("swin_attn_bwd: C must be 96 or 192 (got %d)", C), (int)STJ_EUNSUPPORTED)))
+  p.part = reinterpret_cast<float*>(ws);
+#define STJ_AB(TT) (C == 96 ? attnb_launch<TT, 96>(p, stream) : (C == 192 ? attnb_launch<TT, 192>(p, stream) : (C == 384 ? attnb_split384<TT>(p, stream) : (stj_set_error("swin_attn_bwd: C must be 96, 192 or 384 (got %d)", C), (int)STJ_EUNSUPPORTED))))
   if (dtype == STJ_BF16) return STJ_AB(bf16);
   if (dtype == STJ_F16) return STJ_AB(f16);
   if (dtype == STJ_F32) return STJ_AB(float);

@@ -231,9 +231,12 @@ class STrajNet:
         # fused Swin-block kernels (csrc/swin_fused.hip); STJ_FUSED_MLP=0 selects the layer-by-layer path (A/B runs, debugging)
         self.fused_mlp = os.environ.get('STJ_FUSED_MLP', '1') != '0'
         self.fused_attn = os.environ.get('STJ_FUSED_ATTN', '1') != '0'
-        self.fused_attn_dims = (96, 192)
-        # (C = 384, the 16x16 stage: 2048 rows = 32 row blocks / 32 windows at B = 8 -- the fused kernels measured slower there)
-        self.fused_mlp_dims = (96, 192)
+        # C = 384 (the 16x16 stage: 2048 rows = 32 row blocks / 32 windows at B = 8) runs the SPLIT variants of the fused kernels --
+        # (row block | window) x (slice of the hidden dimension | of the heads) workgroups + a finishing launch -- in the 16-bit modes;
+        # the f32 parity mode keeps that stage layer by layer
+        wide = (384,) if self.dtype != torch.float32 else ()
+        self.fused_attn_dims = (96, 192) + wide
+        self.fused_mlp_dims = (96, 192) + wide
         # the 8 time-separated cross-attentions as one kernel per direction (csrc/xattn_fused.hip); False = the layer-by-layer chain
         # (the parity tests run both and compare)
         self.fused_xattn = True

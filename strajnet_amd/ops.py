@@ -591,6 +591,15 @@ def layernorm_skip(x, pg, pb, eps):
     return _LayerNorm.apply(x, pg.master, pb.master, pg, pb, eps, 0, 0, 1, 0, True)
 
 
+def _swin_ws(x, M, C):
+    """f32 workspace of the fused Swin kernels at C = 384 (partial sums of the hidden / head slices: stj_swin_split_workspace_bytes);
+    the other widths take none."""
+    if C != 384:
+        return None
+    from ._lib import lib
+    return torch.empty(int(lib().stj_swin_split_workspace_bytes(M, C)) // 4, dtype=torch.float32, device=x.device)
+
+
 # ----------------------------------------------------------------------------------------------------
 # fused MLP half of a Swin block: x + DropPath(fc2(gelu(fc1(LayerNorm(x)))))  -- one kernel per direction (csrc/swin_fused.hip)
 # ----------------------------------------------------------------------------------------------------
@@ -604,7 +613,7 @@ class _SwinMlp(torch.autograd.Function):
         y = torch.empty_like(x)
         p_drop, state, site = drop if drop is not None else (0.0, None, 0)
         call('stj_swin_mlp_fwd', _p(x), _p(pg.master), _p(pb.master), _p(pw1.c), _p(pb1.master), _p(pw2.c), _p(pb2.master), _p(y),
-             M, C, float(eps), _p(state), site, float(p_drop), rows_per_sample, _dt(x), _st())
+             M, C, float(eps), _p(state), site, float(p_drop), rows_per_sample, _dt(x), _p(_swin_ws(x, M, C)), _st())
         ctx.ps = (pg, pb, pw1, pb1, pw2, pb2)
         ctx.args = (M, C, float(eps), drop, rows_per_sample)
         ctx.save_for_backward(x)
@@ -628,7 +637,7 @@ class _SwinMlp(torch.autograd.Function):
         else:
             dg, db, nparts, pstride = pg.grad, pb.grad, 1, 0
         call('stj_swin_mlp_bwd', _p(x), _p(dy), _p(pg.master), _p(pb.master), _p(pw1.c), _p(pb1.master), _p(pw2.c), _p(dx), _p(h),
-             _p(dpre), _p(ln), _p(dys), _p(dg), _p(db), nparts, pstride, M, C, eps, _p(state), site, float(p_drop), rps, dt, _st())
+             _p(dpre), _p(ln), _p(dys), _p(dg), _p(db), nparts, pstride, M, C, eps, _p(state), site, float(p_drop), rps, dt, _p(_swin_ws(x, M, C)), _st())
         g2 = dys if dys is not None else dy.view(M, C)
         with wgrad_stream(1, ln, dpre, h, g2), gemm_group(M < _GROUP_MAX_ROWS):
             gemm(ln, dpre, pw1.grad, C, 4 * C, M, (0, 0, 1, C), (0, 0, 4 * C, 1), (0, 0, 4 * C), dt, c_f32=1, accumulate=1,
@@ -671,7 +680,7 @@ class _SwinAttnHalf(torch.autograd.Function):
         p_drop, state, site = drop if drop is not None else (0.0, None, 0)
         call('stj_swin_attn_fwd', _p(x), _p(pg.master), _p(pb.master), _p(pwq.c), _p(pbq.master), _p(pt.master), _p(pwp.c),
              _p(pbp.master), _p(y), _p(qkv), _p(a), _p(ln), _p(mean), _p(rstd), B, res, C, shift, float(eps), _p(state), site,
-             float(p_drop), _dt(x), _st())
+             float(p_drop), _dt(x), _p(_swin_ws(x, B * N, C)), _st())
         ctx.ps = (pg, pb, pwq, pbq, pt, pwp, pbp)
         ctx.args = (B, res, C, shift, drop)
         ctx.save_for_backward(x, qkv, a, ln, mean, rstd)
@@ -707,7 +716,7 @@ class _SwinAttnHalf(torch.autograd.Function):
                 dtab, tp = own, tparts
             call('stj_swin_attn_bwd', _p(x), _p(dy), _p(qkv), _p(mean), _p(rstd), _p(pg.master), _p(pwq.c), _p(pwp.c), _p(pt.master),
                  _p(dx), _p(dqkv), _p(dys), _p(dtab), tp, _p(dg), _p(db), np_, ps_, B, res, C, shift, _p(state), site, float(p_drop),
-                 dt, _st())
+                 dt, _p(_swin_ws(x, M, C)), _st())
             if own is not None:
                 pt.grad.add_(own.sum(0))
             dys2 = (dys if dys is not None else dy).view(M, C)
