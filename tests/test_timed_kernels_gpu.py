@@ -210,9 +210,9 @@ def _cmp_steps(tag, cfg, B, large_ogm, loss_gate=1e-3):
     # (tests/test_switches_gpu.py re-runs this under every retained STJ_* switch with a 3x wider loss gate: the superseded generic kernels
     # round a little differently -- STJ_NO_WS=1 measured 1.4e-3 -- and what that run checks is that they are still CORRECT)
     wide = float(os.environ.get('STJ_TEST_LOSS_GATE_SCALE', '1'))
-    assert rel < 1e-3 * wide, (tot32, tot16)
+    assert rel < loss_gate * wide, (tot32, tot16)
     for k in l32:
-        assert abs(l16[k] - l32[k]) < 2e-3 * wide * abs(l32[k]) + 1e-4, (k, l16[k], l32[k])
+        assert abs(l16[k] - l32[k]) < 2 * loss_gate * wide * abs(l32[k]) + 1e-4, (k, l16[k], l32[k])
     # Gate: the whole gradient and all but a handful of tensors at cosine >= 0.999.  The exceptions measured on MI355X are the
     # query / key kernels of the 11-token agent self-attention (tfa-MHA over time steps, trajNet.py:33,42): their gradient is the
     # small difference of softmax-weighted terms, which bf16 storage of P / dS resolves to ~2.5 digits; they stay above 0.99.
