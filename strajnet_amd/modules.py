@@ -240,6 +240,7 @@ class STrajNet:
         # the 8 time-separated cross-attentions as one kernel per direction (csrc/xattn_fused.hip); False = the layer-by-layer chain
         # (the parity tests run both and compare)
         self.fused_xattn = True
+        self.agent_after_prepare = True    # captured step: the agent branch continues the loss preparation's chain (graph.py)
         self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (16-bit modes, 8 x 8 / 16 x 16 maps)
         self._xattn_pack = None
         self.params = OrderedDict()
