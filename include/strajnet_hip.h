@@ -305,6 +305,14 @@ int stj_agent_mix_bwd(const void* dconcat, const void* dqin, const void* cm, voi
                       hipStream_t stream);
 int stj_agent_sum_fwd(const void* enc, const void* value, const void* embed, void* out, int B, int A, int C, int dtype, hipStream_t stream);
 int stj_agent_sum_bwd(const void* dout, void* dembed, int B, int A, int C, int dtype, hipStream_t stream);
+/* The tail of TrajNet.call in one launch per direction (trajNet.py:171-187): out = enc + value + embed (rounded like stj_agent_sum_fwd), then
+ * LayerNorm(eps) with parameters (g0, b0) on the first n0 agents of every scene (obs_norm) and (g1, b1) on the others (occ_norm): y [B,A,C].
+ * Saves out [B,A,C], mean / rstd f32 [B*A].  Backward: dout [B,A,C] (= d_enc = d_value), dembed [A,C] = sum over scenes of dout (written);
+ * dg0 / db0 / dg1 / db1 f32 "+=".  C = 384. */
+int stj_agent_out_fwd(const void* enc, const void* value, const void* embed, const float* g0, const float* b0, const float* g1, const float* b1,
+                      void* out, void* y, float* mean, float* rstd, int B, int A, int n0, int C, float eps, int dtype, hipStream_t stream);
+int stj_agent_out_bwd(const void* dy, const void* out, const float* mean, const float* rstd, const float* g0, const float* g1, void* dout,
+                      void* dembed, float* dg0, float* db0, float* dg1, float* db1, int B, int A, int n0, int C, int dtype, hipStream_t stream);
 /* Time-kernel collapse of the decoder's Conv3D(8,1,1) SAME skips (modules.py:693-698,709-716,750-765): the
  * input is the same frame at all 8 steps, so step t needs W_t = sum_{j=max(0,3-t)}^{min(7,10-t)} W[j].  W f32 [8][n] (n = Cin*Cout),
  * Wz T [8][n].  fold (backward): dW[j] += sum over the t whose window contains j of dWz[t]. */

@@ -450,6 +450,143 @@ extern "C" int stj_agent_sum_bwd(const void* dout, void* dembed, int B, int A, i
 #undef A_
 }
 
+// ---- tail of TrajNet.call (trajNet.py:171-187): out = enc + value + embed, then obs_norm on the first n0 agents of a scene and occ_norm on
+// the rest, as ONE launch per direction.  (Layer by layer: the sum, two slice copies, two LayerNorm launches and a concat -- six dependent
+// ~5 us launches at the very end of the agent chain, on which the cross-attention waits; backward ten.)  A wave owns a row (forward) or
+// all B rows of one agent (backward: d_embed[a] and the parameter gradients accumulate in registers); a lane 2 adjacent columns of every 128.
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void agent_out_fwd_kernel(const T* __restrict__ enc, const T* __restrict__ value, const T* __restrict__ embed,
+                                                            const float* __restrict__ g0, const float* __restrict__ b0, const float* __restrict__ g1,
+                                                            const float* __restrict__ b1, T* __restrict__ out, T* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int B, int A, int n0, float eps) {
+  constexpr int C = 128 * NJ;
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (row >= (long long)B * A) return;
+  const int a = (int)(row % A);
+  const float* gm = a < n0 ? g0 : g1;
+  const float* bt = a < n0 ? b0 : b1;
+  float v[NJ][2];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = 128 * j + 2 * lane + e;
+      T t;
+      stf(&t, ldf(enc + row * C + c) + ldf(value + row * C + c));          // (enc + value) rounded, then + embed: the order of the two adds
+      stf(&t, ldf(&t) + ldf(embed + (long long)a * C + c));
+      stf(out + row * C + c, ldf(&t));
+      v[j][e] = ldf(&t);
+      s += v[j][e];
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mu = s * (1.f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { const float d = v[j][e] - mu; q += d * d; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rs = rsqrtf(q * (1.f / C) + eps);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = 128 * j + 2 * lane + e;
+      stf(y + row * C + c, (v[j][e] - mu) * rs * gm[c] + bt[c]);
+    }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void agent_out_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ out, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ g0, const float* __restrict__ g1,
+                                                            T* __restrict__ dout, T* __restrict__ dembed, float* __restrict__ dg0, float* __restrict__ db0,
+                                                            float* __restrict__ dg1, float* __restrict__ db1, int B, int A, int n0) {
+  constexpr int C = 128 * NJ;
+  const int lane = threadIdx.x & 63;
+  const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (a >= A) return;
+  const float* gm = a < n0 ? g0 : g1;
+  float de[NJ][2], dg[NJ][2], db[NJ][2], gv[NJ][2];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { de[j][e] = dg[j][e] = db[j][e] = 0.f; gv[j][e] = gm[128 * j + 2 * lane + e]; }
+  for (int b = 0; b < B; ++b) {
+    const long long row = (long long)b * A + a;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NJ][2], t[NJ][2];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = 128 * j + 2 * lane + e;
+        const float d = ldf(dy + row * C + c);
+        xh[j][e] = (ldf(out + row * C + c) - mu) * rs;
+        dg[j][e] += d * xh[j][e];
+        db[j][e] += d;
+        t[j][e] = d * gv[j][e];
+        s1 += t[j][e]; s2 += t[j][e] * xh[j][e];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 *= (1.f / C); s2 *= (1.f / C);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = 128 * j + 2 * lane + e;
+        T r;
+        stf(&r, rs * (t[j][e] - s1 - xh[j][e] * s2));
+        dout[row * C + c] = r;
+        de[j][e] += ldf(&r);                                               // d_embed sums the ROUNDED row gradients, like the stand-alone sum kernel
+      }
+  }
+  float* dgp = a < n0 ? dg0 : dg1;
+  float* dbp = a < n0 ? db0 : db1;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = 128 * j + 2 * lane + e;
+      stf(dembed + (long long)a * C + c, de[j][e]);
+      atomicAdd(dgp + c, dg[j][e]);
+      atomicAdd(dbp + c, db[j][e]);
+    }
+}
+extern "C" int stj_agent_out_fwd(const void* enc, const void* value, const void* embed, const float* g0, const float* b0, const float* g1,
+                                 const float* b1, void* out, void* y, float* mean, float* rstd, int B, int A, int n0, int C, float eps, int dtype,
+                                 hipStream_t stream) {
+  if ((long long)B * A <= 0) return STJ_OK;
+  if (C != 384 || n0 < 0 || n0 > A) { stj_set_error("stj_agent_out_fwd: C must be 384 and 0 <= n0 <= A (got C = %d, n0 = %d)", C, n0); return STJ_EUNSUPPORTED; }
+  const int g = (B * A + 3) / 4;
+#define A_(TT) (const TT*)enc, (const TT*)value, (const TT*)embed, g0, b0, g1, b1, (TT*)out, (TT*)y, mean, rstd, B, A, n0, eps
+  if (dtype == STJ_BF16) hipLaunchKernelGGL((agent_out_fwd_kernel<bf16, 3>), dim3(g), dim3(256), 0, stream, A_(bf16));
+  else if (dtype == STJ_F16) hipLaunchKernelGGL((agent_out_fwd_kernel<f16, 3>), dim3(g), dim3(256), 0, stream, A_(f16));
+  else if (dtype == STJ_F32) hipLaunchKernelGGL((agent_out_fwd_kernel<float, 3>), dim3(g), dim3(256), 0, stream, A_(float));
+  else { stj_set_error("stj_agent_out_fwd: bad dtype %d", dtype); return STJ_EINVAL; }
+#undef A_
+  return stj_check_launch("stj_agent_out_fwd");
+}
+extern "C" int stj_agent_out_bwd(const void* dy, const void* out, const float* mean, const float* rstd, const float* g0, const float* g1, void* dout,
+                                 void* dembed, float* dg0, float* db0, float* dg1, float* db1, int B, int A, int n0, int C, int dtype,
+                                 hipStream_t stream) {
+  if ((long long)B * A <= 0) return STJ_OK;
+  if (C != 384 || n0 < 0 || n0 > A) { stj_set_error("stj_agent_out_bwd: C must be 384 and 0 <= n0 <= A (got C = %d, n0 = %d)", C, n0); return STJ_EUNSUPPORTED; }
+  const int g = (A + 3) / 4;
+#define A_(TT) (const TT*)dy, (const TT*)out, mean, rstd, g0, g1, (TT*)dout, (TT*)dembed, dg0, db0, dg1, db1, B, A, n0
+  if (dtype == STJ_BF16) hipLaunchKernelGGL((agent_out_bwd_kernel<bf16, 3>), dim3(g), dim3(256), 0, stream, A_(bf16));
+  else if (dtype == STJ_F16) hipLaunchKernelGGL((agent_out_bwd_kernel<f16, 3>), dim3(g), dim3(256), 0, stream, A_(f16));
+  else if (dtype == STJ_F32) hipLaunchKernelGGL((agent_out_bwd_kernel<float, 3>), dim3(g), dim3(256), 0, stream, A_(float));
+  else { stj_set_error("stj_agent_out_bwd: bad dtype %d", dtype); return STJ_EINVAL; }
+#undef A_
+  return stj_check_launch("stj_agent_out_bwd");
+}
+
 extern "C" int stj_time_collapse(const float* W, void* Wz, long long n, int dtype, hipStream_t stream) {
   if (n <= 0) return STJ_OK;
   const int g = ew_grid(n);

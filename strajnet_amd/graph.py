@@ -24,7 +24,6 @@ class GraphedTrainStep:
         self.graph = self.graph_b = None
         self._side = None
         self.losses = None
-        self.agent_after_prepare = getattr(model, 'agent_after_prepare', True)
         if split:
             model.cut_encoder = True
         side = torch.cuda.Stream()
@@ -59,19 +58,7 @@ class GraphedTrainStep:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 self.loss_fn.prepare(tw)
-        # The agent branch (trajNet: ~40 launches of ~5 us) continues the chain of the loss preparation: a replayed hipGraph maps every
-        # chain onto one of 4 hardware queues and chains that share a queue run one after the other -- on a stream of its own the agent
-        # chain landed behind the second raster encoder's and started ~0.9 ms into the step, where the cross-attention then waited for
-        # its tail on an idle GPU; the loss-preparation chain's queue is free after ~70 us
-        streams = getattr(m, '_streams', None)
-        chain_agent = self.agent_after_prepare and self._side is not None and streams is not None and streams[0] is not None
-        if chain_agent:
-            m._streams = (self._side, streams[1])
-        try:
-            out = m(x['ogm'], x['map_img'], training=self.training, obs=x['obs'], occ=x['occ'], mapt=x.get('mapt'), flow=x['flow'])
-        finally:
-            if chain_agent:
-                m._streams = streams
+        out = m(x['ogm'], x['map_img'], training=self.training, obs=x['obs'], occ=x['occ'], mapt=x.get('mapt'), flow=x['flow'])
         if self._side is not None:
             main.wait_stream(self._side)
         d = self.loss_fn(get_pred_waypoint_logits(out), tw, None)

@@ -240,7 +240,6 @@ class STrajNet:
         # the 8 time-separated cross-attentions as one kernel per direction (csrc/xattn_fused.hip); False = the layer-by-layer chain
         # (the parity tests run both and compare)
         self.fused_xattn = True
-        self.agent_after_prepare = True    # captured step: the agent branch continues the loss preparation's chain (graph.py)
         self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (16-bit modes, 8 x 8 / 16 x 16 maps)
         self._xattn_pack = None
         self.params = OrderedDict()
@@ -592,6 +591,10 @@ class STrajNet:
         embed = ops.linear(onehot, self._p('traj_net/seg_embed/kernel'))                  # [64,384]
         concat, q_in = ops.agent_mix(enc, embed, cmf)                                     # enc * mask ; + embed
         value = self._cross_attention('traj_net/cross_attention', q_in, concat, 6, cmi, cmi)
+        if enc.shape[-1] == 384:          # sum + obs_norm | occ_norm in one launch (the cross-attention waits on the end of this chain)
+            key = ops.agent_out(enc, value, embed, self._p('traj_net/obs_norm/gamma'), self._p('traj_net/obs_norm/beta'),
+                                self._p('traj_net/occ_norm/gamma'), self._p('traj_net/occ_norm/beta'), n_obs, 1e-3)
+            return key, cmi
         out = ops.agent_sum(enc, value, embed)
         o1 = self._ln(out[:, :n_obs].contiguous(), 'traj_net/obs_norm', 1e-3)
         o2 = self._ln(out[:, n_obs:].contiguous(), 'traj_net/occ_norm', 1e-3)

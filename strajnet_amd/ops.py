@@ -1331,6 +1331,40 @@ def agent_sum(enc, value, embed):
     return _AgentSum.apply(enc, value, embed)
 
 
+class _AgentOut(torch.autograd.Function):
+    """LayerNorm_{obs | occ}(enc + value + embed): the tail of TrajNet.call (trajNet.py:171-187) as one launch per direction -- the first n_obs
+    agents of a scene go through obs_norm, the others through occ_norm."""
+    @staticmethod
+    def forward(ctx, enc, value, embed, g0m, b0m, g1m, b1m, pg0, pb0, pg1, pb1, n_obs, eps):
+        _req_cuda(enc)
+        enc, value, embed = enc.contiguous(), value.contiguous(), embed.contiguous()
+        B, A, C = enc.shape
+        out, y = torch.empty_like(enc), torch.empty_like(enc)
+        mean = torch.empty(B * A, dtype=torch.float32, device=enc.device)
+        rstd = torch.empty_like(mean)
+        call('stj_agent_out_fwd', _p(enc), _p(value), _p(embed), _p(pg0.master), _p(pb0.master), _p(pg1.master), _p(pb1.master), _p(out), _p(y),
+             _p(mean), _p(rstd), B, A, n_obs, C, float(eps), _dt(enc), _st())
+        ctx.ps, ctx.geo = (pg0, pb0, pg1, pb1), (B, A, C, n_obs, embed.shape)
+        ctx.save_for_backward(out, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        out, mean, rstd = ctx.saved_tensors
+        pg0, pb0, pg1, pb1 = ctx.ps
+        B, A, C, n_obs, eshape = ctx.geo
+        dy = dy.contiguous()
+        dout = torch.empty_like(out)
+        dembed = torch.empty(eshape, dtype=out.dtype, device=out.device)
+        call('stj_agent_out_bwd', _p(dy), _p(out), _p(mean), _p(rstd), _p(pg0.master), _p(pg1.master), _p(dout), _p(dembed), _p(pg0.grad),
+             _p(pb0.grad), _p(pg1.grad), _p(pb1.grad), B, A, n_obs, C, _dt(out), _st())
+        return (dout, dout, dembed) + (None,) * 10
+
+
+def agent_out(enc, value, embed, pg0, pb0, pg1, pb1, n_obs, eps):
+    return _AgentOut.apply(enc, value, embed, pg0.master, pb0.master, pg1.master, pb1.master, pg0, pb0, pg1, pb1, n_obs, eps)
+
+
 # ----------------------------------------------------------------------------------------------------
 # max over time (GlobalMaxPooling1D)
 # ----------------------------------------------------------------------------------------------------

@@ -302,6 +302,42 @@ def test_agent_branch_ops(dt):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
+def test_agent_out_fused_tail(dt):
+    """stj_agent_out_fwd / _bwd (enc + value + embed, obs_norm | occ_norm by agent index: trajNet.py:171-187) against float64 and against the
+    layer-by-layer composition it replaces (agent_sum, two slice LayerNorms, concat): same values, same gradients."""
+    from strajnet_amd import ops
+    B, n_obs, A, C = 3, 48, 64, 384
+    enc, value = rnd((B, A, C), dt, 1).requires_grad_(True), rnd((B, A, C), dt, 2).requires_grad_(True)
+    embed = rnd((A, C), dt, 3).requires_grad_(True)
+    g = rnd((B, A, C), dt, 4)
+    res = []
+    for fused in (True, False):
+        ps = [mk_param((C,), dt, 0.3, 10 + i) for i in range(4)]
+        with torch.no_grad():
+            ps[0].master.add_(1.0); ps[2].master.add_(1.0)
+        for t in (enc, value, embed):
+            t.grad = None
+        if fused:
+            y = ops.agent_out(enc, value, embed, ps[0], ps[1], ps[2], ps[3], n_obs, 1e-3)
+        else:
+            out = ops.agent_sum(enc, value, embed)
+            y = torch.cat([ops.layernorm(out[:, :n_obs].contiguous(), ps[0], ps[1], 1e-3), ops.layernorm(out[:, n_obs:].contiguous(), ps[2], ps[3], 1e-3)], 1)
+        y.backward(g)
+        res.append([y.detach().clone(), enc.grad.clone(), value.grad.clone(), embed.grad.clone()] + [p_.grad.clone() for p_ in ps])
+    for a, b in zip(*res):
+        assert rel_err(a, b) < (1e-5 if dt == torch.float32 else 1e-2)
+    er, vr, mr = ref_of(enc), ref_of(value), ref_of(embed)
+    pr = [ref_of(p_.master) for p_ in ps]
+    o = ((er + vr).to(dt).double() + mr).to(dt).double()   # the kernels round the first sum to the storage type, then the second
+    yr = torch.cat([F.layer_norm(o[:, :n_obs], (C,), pr[0], pr[1], 1e-3), F.layer_norm(o[:, n_obs:], (C,), pr[2], pr[3], 1e-3)], 1)
+    yr.backward(g.double().cpu())
+    assert rel_err(res[0][0], yr) < tol(dt)
+    assert rel_err(res[0][1], er.grad) < tol(dt) and rel_err(res[0][3], mr.grad) < 2 * tol(dt)
+    for i in range(4):
+        assert rel_err(res[0][4 + i], pr[i].grad) < 2 * tol(dt), i
+
+
+@pytest.mark.parametrize('dt', DTYPES)
 def test_mha_core_with_fg_bias_inside(dt):
     """mha_core(fg_off=, fg=) == mha_core(bias=fg_bias(off)): same kernels, the bias gradient just never leaves the op."""
     from strajnet_amd import ops
