@@ -185,6 +185,17 @@ int stj_xattn_bwd(const void* dy, const void* query, const void* k, const void* 
 int stj_softmax_fwd(const float* S, void* P, const int* qvalid, const int* kvalid, const float* bias,
                     long long batch, int H, int Nq, int Nk, int dtype, hipStream_t stream);
 int stj_softmax_bwd(const void* P, const float* dP, void* dS, long long rows, int Nk, int dtype, hipStream_t stream);
+/* Tiny attention (at most 16 queries / keys per batch element and head: the TrajEncoder's self-attention over 11 time steps, trajNet.py:33,42)
+ * in one launch per direction: o [Bt,N,H*d] = dropout(softmax(scale q k^T, masked logits += -10e9)) v; q, k, v [Bt,N,H*d]; qvalid / kvalid
+ * int32 [Bt,N] or NULL; dropout on the coefficients [Bt,H,N,N] at (rng_state, site), drawn as stj_dropout draws that tensor (NULL / p = 0:
+ * none).  Backward recomputes the probabilities: dq, dk, dv written.  stj_small_attn_supported(N, H, d, dtype) = 1 for the geometries it
+ * takes (otherwise: stj_gemm + stj_softmax_* + stj_dropout). */
+int stj_small_attn_supported(int N, int H, int d, int dtype);
+int stj_small_attn_fwd(const void* q, const void* k, const void* v, const int* qvalid, const int* kvalid, void* o, long long Bt, int N, int H,
+                       int d, float scale, const long long* rng_state, int site, float p_drop, int dtype, hipStream_t stream);
+int stj_small_attn_bwd(const void* q, const void* k, const void* v, const int* qvalid, const int* kvalid, const void* dO, void* dq, void* dk,
+                       void* dv, long long Bt, int N, int H, int d, float scale, const long long* rng_state, int site, float p_drop, int dtype,
+                       hipStream_t stream);
 /* FG-MSA relative-position bias: bilinear `sample` of rpe_table at (query - key - offset) displacements
  * (FG_MSA.py:150-172 via occu_metric.py:345-409 + tfa_image.py:87-173).  off [B,G,H*W,2], table f32 [2H-1,2W-1,G],
  * bias f32 [B,G,HW,HW]; bwd: dtable +=, doff f32 [B,G,HW,2] += (zeroed by the caller: query slices accumulate). */

@@ -60,6 +60,9 @@ SIGNATURES = {
     'stj_softmax_bwd': [vp, vp, vp, cl, ci, ci, vp],
     'stj_fg_bias_fwd': [vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_fg_bias_bwd': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    'stj_small_attn_supported': [ci, ci, ci, ci],
+    'stj_small_attn_fwd': [vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, cf, vp, ci, cf, ci, vp],
+    'stj_small_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, cf, vp, ci, cf, ci, vp],
     'stj_agent_out_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp],
     'stj_agent_out_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_fg_attn_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp],

@@ -83,6 +83,152 @@ extern "C" int stj_softmax_bwd(const void* P, const float* dP, void* dS, long lo
   return stj_check_launch("stj_softmax_bwd");
 }
 
+// ---- tiny attention: at most 16 queries / keys per (batch element, head) -----------------------------------------------------------
+// The TrajEncoder's self-attention over the 11 time steps of an agent (trajNet.py:33,42: 512 agents x 4 heads x 11 x 11 at B = 8) as ONE
+// launch per direction: layer by layer it was Q K^T, softmax, dropout, P V -- four dependent launches (76 us, the 11 x 11 products as
+// batched GEMM tiles of 64 x 64) in the chain the cross-attention waits on, and five + the dropout in backward.  One workgroup per batch
+// element: q, k, v (and dO) rows in LDS, every product as plain FMAs, the probabilities rounded to the storage type where the layer-by-layer
+// path stores them, the dropout draws of the [Bt,H,N,N] tensor re-derived (rng.h).  Backward recomputes P.
+struct SmallAttnArgs {
+  const void* q; const void* k; const void* v; const int* qvalid; const int* kvalid; void* o;
+  const void* dO; void* dq; void* dk; void* dv;
+  int N, H, d; float scale; const long long* rng; int site; float p_drop;
+};
+#include "rng.h"
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
+  const int N = a.N, H = a.H, d = a.d, HD = H * d, NN = N * N, tid = threadIdx.x;
+  const int LD = HD + 2;                                 // row stride of the LDS tiles: rows of different keys on different banks
+  float* P = reinterpret_cast<float*>(sa_smem);         // [H][N][N] probabilities (values of the storage type)
+  float* Pd = P + H * NN;                                // after dropout
+  float* dS = Pd + H * NN;                               // backward: dP, then dS
+  float* ksc = dS + H * NN;                              // keep / (1 - p) of every coefficient
+  T* qs = reinterpret_cast<T*>(ksc + H * NN);
+  T* ks = qs + N * LD;
+  T* vs = ks + N * LD;
+  T* gs = vs + N * LD;                                   // backward: dO
+  const long long bt = blockIdx.x, base = bt * N * HD;
+  const T* q = reinterpret_cast<const T*>(a.q) + base;
+  const T* k = reinterpret_cast<const T*>(a.k) + base;
+  const T* v = reinterpret_cast<const T*>(a.v) + base;
+  for (int i = tid; i < N * HD; i += 256) {
+    const int o = (i / HD) * LD + i % HD;
+    qs[o] = q[i]; ks[o] = k[i]; vs[o] = v[i];
+    if (BWD) gs[o] = reinterpret_cast<const T*>(a.dO)[base + i];
+  }
+  __syncthreads();
+  const bool drop = a.rng != nullptr && a.p_drop > 0.f;
+  const float dsc = drop ? 1.f / (1.f - a.p_drop) : 1.f;
+  for (int e = tid; e < H * NN; e += 256) {
+    const int h = e / NN, i = (e / N) % N, j = e % N;
+    const T* qr = qs + i * LD + h * d;
+    const T* kr = ks + j * LD + h * d;
+    float acc = 0.f;
+    for (int c = 0; c < d; ++c) acc += ldf(qr + c) * ldf(kr + c);
+    float x = acc * a.scale;
+    const bool ok = (a.qvalid ? a.qvalid[bt * N + i] != 0 : true) && (a.kvalid ? a.kvalid[bt * N + j] != 0 : true);
+    if (!ok) x = x + (-10e9f);                           // f32 add, exactly as the reference (absorbs the logit)
+    P[e] = x;
+    float f = 1.f;
+    if (drop) {
+      const long long idx = (bt * H + h) * NN + i * N + j;
+      bool k4[4];
+      keep4(a.rng, a.site, idx >> 2, a.p_drop, k4);
+      f = k4[idx & 3] ? dsc : 0.f;
+    }
+    ksc[e] = f;
+    if (BWD) {                                           // dPd = dO V^T
+      const T* gr = gs + i * LD + h * d;
+      const T* vr = vs + j * LD + h * d;
+      float g = 0.f;
+      for (int c = 0; c < d; ++c) g += ldf(gr + c) * ldf(vr + c);
+      dS[e] = g * f;                                     // dropout backward on the f32 product
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < H * N; r += 256) {               // softmax of row r over its N keys; dS = P (dP - sum P dP)
+    float* row = P + r * N;
+    float m = -INFINITY;
+    for (int j = 0; j < N; ++j) m = fmaxf(m, row[j]);
+    float sum = 0.f;
+    for (int j = 0; j < N; ++j) { const float x = expf(row[j] - m); row[j] = x; sum += x; }
+    const float inv = 1.f / sum;
+    float t = 0.f;
+    for (int j = 0; j < N; ++j) {
+      T pr;
+      stf(&pr, row[j] * inv);
+      row[j] = ldf(&pr);
+      T pd;
+      stf(&pd, row[j] * ksc[r * N + j]);
+      Pd[r * N + j] = ldf(&pd);
+      if (BWD) t += row[j] * dS[r * N + j];
+    }
+    if (BWD)
+      for (int j = 0; j < N; ++j) { T s_; stf(&s_, row[j] * (dS[r * N + j] - t)); dS[r * N + j] = ldf(&s_); }
+  }
+  __syncthreads();
+  if (!BWD) {
+    T* o = reinterpret_cast<T*>(a.o) + base;
+    for (int e = tid; e < N * HD; e += 256) {
+      const int i = e / HD, hc = e % HD, h = hc / d;
+      const float* pr = Pd + (h * N + i) * N;
+      float acc = 0.f;
+      for (int j = 0; j < N; ++j) acc += pr[j] * ldf(vs + j * LD + hc);
+      stf(o + e, acc);
+    }
+  } else {
+    T* dq = reinterpret_cast<T*>(a.dq) + base;
+    T* dk = reinterpret_cast<T*>(a.dk) + base;
+    T* dv = reinterpret_cast<T*>(a.dv) + base;
+    for (int e = tid; e < N * HD; e += 256) {
+      const int i = e / HD, hc = e % HD, h = hc / d;
+      float aq = 0.f, ak = 0.f, av = 0.f;
+      for (int j = 0; j < N; ++j) {
+        aq += dS[(h * N + i) * N + j] * ldf(ks + j * LD + hc);          // dq[i] = scale sum_j dS[i][j] k[j]
+        ak += dS[(h * N + j) * N + i] * ldf(qs + j * LD + hc);          // dk[i] = scale sum_j dS[j][i] q[j]
+        av += Pd[(h * N + j) * N + i] * ldf(gs + j * LD + hc);          // dv[i] = sum_j Pd[j][i] dO[j]
+      }
+      stf(dq + e, aq * a.scale); stf(dk + e, ak * a.scale); stf(dv + e, av);
+    }
+  }
+}
+static size_t small_attn_lds(int N, int H, int d, int dtype, bool bwd) {
+  return (size_t)4 * H * N * N * 4 + (size_t)(bwd ? 4 : 3) * N * (H * d + 2) * (dtype == STJ_F32 ? 4 : 2);
+}
+// 1 when stj_small_attn_* take this geometry (else use stj_gemm + stj_softmax_* + stj_dropout)
+extern "C" int stj_small_attn_supported(int N, int H, int d, int dtype) {
+  return N >= 1 && N <= 16 && H >= 1 && H <= 16 && d >= 1 && small_attn_lds(N, H, d, dtype, true) <= 64 * 1024;
+}
+template <bool BWD> static int small_attn_launch(const SmallAttnArgs& a, long long Bt, int dtype, hipStream_t stream) {
+  if (Bt <= 0) return STJ_OK;
+  if (!stj_small_attn_supported(a.N, a.H, a.d, dtype)) { stj_set_error("small_attn: N = %d, H = %d, d = %d not supported", a.N, a.H, a.d); return STJ_EUNSUPPORTED; }
+  if (!(a.p_drop >= 0.f && a.p_drop < 1.f)) { stj_set_error("small_attn: need 0 <= p_drop < 1"); return STJ_EINVAL; }
+  const size_t lds = small_attn_lds(a.N, a.H, a.d, dtype, BWD);
+  if (dtype == STJ_BF16) hipLaunchKernelGGL((small_attn_kernel<bf16, BWD>), dim3((unsigned)Bt), dim3(256), lds, stream, a);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL((small_attn_kernel<f16, BWD>), dim3((unsigned)Bt), dim3(256), lds, stream, a);
+  else if (dtype == STJ_F32) hipLaunchKernelGGL((small_attn_kernel<float, BWD>), dim3((unsigned)Bt), dim3(256), lds, stream, a);
+  else { stj_set_error("small_attn: bad dtype %d", dtype); return STJ_EINVAL; }
+  return stj_check_launch(BWD ? "stj_small_attn_bwd" : "stj_small_attn_fwd");
+}
+// o [Bt,N,H*d] = dropout(softmax(scale q k^T + mask)) v per batch element and head; q, k, v [Bt,N,H*d]; qvalid / kvalid int32 [Bt,N] or NULL
+// (tfa MultiHeadAttention: masked logits += -10e9); dropout on the coefficients [Bt,H,N,N] at (rng_state, site) drawn as stj_dropout draws it.
+extern "C" int stj_small_attn_fwd(const void* q, const void* k, const void* v, const int* qvalid, const int* kvalid, void* o, long long Bt, int N,
+                                  int H, int d, float scale, const long long* rng_state, int site, float p_drop, int dtype, hipStream_t stream) {
+  SmallAttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.qvalid = qvalid; a.kvalid = kvalid; a.o = o; a.N = N; a.H = H; a.d = d; a.scale = scale;
+  a.rng = rng_state; a.site = site; a.p_drop = p_drop;
+  return small_attn_launch<false>(a, Bt, dtype, stream);
+}
+extern "C" int stj_small_attn_bwd(const void* q, const void* k, const void* v, const int* qvalid, const int* kvalid, const void* dO, void* dq,
+                                  void* dk, void* dv, long long Bt, int N, int H, int d, float scale, const long long* rng_state, int site,
+                                  float p_drop, int dtype, hipStream_t stream) {
+  SmallAttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.qvalid = qvalid; a.kvalid = kvalid; a.dO = dO; a.dq = dq; a.dk = dk; a.dv = dv; a.N = N; a.H = H; a.d = d;
+  a.scale = scale; a.rng = rng_state; a.site = site; a.p_drop = p_drop;
+  return small_attn_launch<true>(a, Bt, dtype, stream);
+}
+
 // ---- FG-MSA sampled relative-position bias -------------------------------------------------------------------
 // bias[b,g,q,k] = sample(table_g)(x = drow - off1[k], y = dcol - off0[k]),  q=(iq,jq), k=(ik,jk), drow=iq-ik,
 // dcol=jq-jk (reference FG_MSA.py:155-166 with the 'xy' meshgrid of :96-100): x indexes the

@@ -103,6 +103,7 @@ extern "C" int stj_dropout(const void* x, const void* res, void* y, long long n,
     const int g = rng_grid(n / vn);
     if (dtype == STJ_BF16 && inner == 1) hipLaunchKernelGGL((dropout_vec_kernel<bf16, false>), dim3(g), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, (bf16*)y, n, inner, p, scale, state, site);
     else if (dtype == STJ_BF16) hipLaunchKernelGGL((dropout_vec_kernel<bf16, true>), dim3(g), dim3(256), 0, stream, (const bf16*)x, (const bf16*)res, (bf16*)y, n, inner, p, scale, state, site);
+    else if (dtype == STJ_F16 && inner == 1) hipLaunchKernelGGL((dropout_vec_kernel<f16, false>), dim3(g), dim3(256), 0, stream, (const f16*)x, (const f16*)res, (f16*)y, n, inner, p, scale, state, site);
     else if (dtype == STJ_F16) hipLaunchKernelGGL((dropout_vec_kernel<f16, true>), dim3(g), dim3(256), 0, stream, (const f16*)x, (const f16*)res, (f16*)y, n, inner, p, scale, state, site);
     else if (inner == 1) hipLaunchKernelGGL((dropout_vec_kernel<float, false>), dim3(g), dim3(256), 0, stream, (const float*)x, (const float*)res, (float*)y, n, inner, p, scale, state, site);
     else hipLaunchKernelGGL((dropout_vec_kernel<float, true>), dim3(g), dim3(256), 0, stream, (const float*)x, (const float*)res, (float*)y, n, inner, p, scale, state, site);

@@ -240,6 +240,7 @@ class STrajNet:
         # the 8 time-separated cross-attentions as one kernel per direction (csrc/xattn_fused.hip); False = the layer-by-layer chain
         # (the parity tests run both and compare)
         self.fused_xattn = True
+        self.agent_issue_mode = 2
         self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (16-bit modes, 8 x 8 / 16 x 16 maps)
         self._xattn_pack = None
         self.params = OrderedDict()
@@ -774,7 +775,7 @@ class STrajNet:
         # independent of the raster encoder up to the cross-attention: it runs on a side stream, forked HERE.  Its launches are ISSUED
         # after the encoder's first stage though: a replayed hipGraph starts branches roughly in node-creation order, and issued first
         # the chain ran alone on an idle GPU for 0.5 ms before the first Swin kernel started (profiles/r02_c_timeline_concurrent.txt).
-        mode = 2 if self._side is not None else -1       # (0: issued at the head of the step, 1: after the encoder -- both measured equal or worse)
+        mode = self.agent_issue_mode if self._side is not None else -1       # (0: issued at the head of the step, 1: after the encoder -- both measured equal or worse)
         agent = []
 
         def issue_agent():

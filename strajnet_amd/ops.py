@@ -911,9 +911,43 @@ class _MhaCore(torch.autograd.Function):
         return dq, dk, dv, (dS if has_bias else None), None, None, None, None, None, None, doff, None, None
 
 
+class _SmallAttn(torch.autograd.Function):
+    """mha_core for at most 16 queries / keys per (batch element, head): one launch per direction (stj_small_attn_*)."""
+    @staticmethod
+    def forward(ctx, q, k, v, H, d, scale, qvalid, kvalid, drop):
+        _req_cuda(q, k, v)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        Bt, N, HD = q.shape
+        o = torch.empty_like(q)
+        p_drop, state, site = drop if drop is not None else (0.0, None, 0)
+        call('stj_small_attn_fwd', _p(q), _p(k), _p(v), _p(qvalid), _p(kvalid), _p(o), Bt, N, H, d, float(scale), _p(state), site, float(p_drop),
+             _dt(q), _st())
+        ctx.geo, ctx.drop = (Bt, N, H, d, float(scale)), drop
+        ctx.save_for_backward(q, k, v, qvalid, kvalid)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, qvalid, kvalid = ctx.saved_tensors
+        Bt, N, H, d, scale = ctx.geo
+        p_drop, state, site = ctx.drop if ctx.drop is not None else (0.0, None, 0)
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        call('stj_small_attn_bwd', _p(q), _p(k), _p(v), _p(qvalid), _p(kvalid), _p(do), _p(dq), _p(dk), _p(dv), Bt, N, H, d, scale, _p(state),
+             site, float(p_drop), _dt(q), _st())
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+SMALL_ATTN = True       # False: the layer-by-layer path for every geometry (tests compare the two)
+
+
 def mha_core(q, k, v, H, d, scale, qvalid=None, kvalid=None, bias=None, drop=None, fg_off=None, fg=None):
     """drop = (p, state, site) applies attention dropout to the softmax output (training).
     fg_off [Bt,H,Nq,2] + fg = (table Param, Hh, Ww): FG-MSA bias sampled from the offsets inside the op."""
+    if SMALL_ATTN and fg is None and bias is None and q.shape[1] == k.shape[1]:
+        from ._lib import lib
+        if lib().stj_small_attn_supported(q.shape[1], H, d, _dt(q)):
+            return _SmallAttn.apply(q, k, v, H, d, scale, qvalid, kvalid, drop)
     if fg is not None:
         return _MhaCore.apply(q, k, v, None, H, d, scale, qvalid, kvalid, drop, fg_off, fg[0].master, fg)
     return _MhaCore.apply(q, k, v, bias, H, d, scale, qvalid, kvalid, drop)

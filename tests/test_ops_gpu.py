@@ -202,7 +202,8 @@ def test_win_attn(dt, res, heads, shift):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
-@pytest.mark.parametrize('Bt,Nq,Nk,H,d,masks,use_bias', [(6, 11, 11, 4, 64, 'qk', False), (2, 64, 64, 6, 64, 'qk', False),
+@pytest.mark.parametrize('Bt,Nq,Nk,H,d,masks,use_bias', [(6, 11, 11, 4, 64, 'qk', False), (5, 11, 11, 4, 80, 'qk', False), (3, 16, 16, 2, 24, '', False),
+                                                        (2, 64, 64, 6, 64, 'qk', False),
                                                         (3, 256, 64, 3, 42, 'k', False), (2, 64, 64, 8, 48, '', True)])
 def test_mha_core(dt, Bt, Nq, Nk, H, d, masks, use_bias):
     from strajnet_amd import ops
@@ -239,6 +240,36 @@ def test_mha_core(dt, Bt, Nq, Nk, H, d, masks, use_bias):
     assert rel_err(v.grad, vr.grad) < tol(dt)
     if use_bias:
         assert rel_err(bias.grad, br.grad) < tol(dt)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_small_attn_matches_layerwise_with_dropout(dt):
+    """stj_small_attn_* (one launch per direction for <= 16 queries / keys) against the layer-by-layer path it replaces (GEMM, softmax, dropout,
+    GEMM) with attention dropout on: the SAME Philox draws of the [Bt,H,N,N] coefficients, so values and gradients agree to rounding."""
+    from strajnet_amd import ops
+    Bt, N, H, d = 40, 11, 4, 80
+    q, k, v = (rnd((Bt, N, H * d), dt, 30 + i).requires_grad_(True) for i in range(3))
+    g = torch.Generator().manual_seed(4)
+    qv = (torch.rand((Bt, N), generator=g) > 0.3).int().cuda()
+    qv[1] = 0
+    go = rnd((Bt, N, H * d), dt, 5)
+    res = []
+    for small in (True, False):
+        ops.SMALL_ATTN = small
+        try:
+            dctx = ops.DropCtx('cuda', seed=21)
+            dctx.begin()
+            drop = (0.1, dctx.snap, dctx.site('a', (Bt, H, N, N), 0.1))
+            for t in (q, k, v):
+                t.grad = None
+            o = ops.mha_core(q, k, v, H, d, d ** -0.5, qvalid=qv, kvalid=qv, drop=drop)
+            o.backward(go)
+            res.append([o.detach().clone(), q.grad.clone(), k.grad.clone(), v.grad.clone(), dctx.mask('a').clone()])
+        finally:
+            ops.SMALL_ATTN = True
+    assert torch.equal(res[0][4], res[1][4]) and 0.05 < 1.0 - float(res[0][4].float().mean()) < 0.15
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert rel_err(a, b) < (2e-5 if dt == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize('dt', DTYPES)
@@ -633,6 +664,12 @@ def test_dropout_op(dt):
     (y2.float() * g.float()).sum().backward()
     assert rel_err(x.grad, g.double().cpu() * m2.view(6, 1, 1) / 0.7) < (1e-6 if dt == torch.float32 else 5e-3)
     assert rel_err(r.grad, g.double().cpu()) < 1e-6
+    # a size the vectorised kernels take (n % 8 == 0, 16-byte aligned): per-ELEMENT decisions there too (the f16 instantiation once shared one
+    # decision among the 8 elements of a vector)
+    x8 = rnd((4, 16, 64), dt, 7)
+    y8 = ops.dropout(x8, 0.4, dctx, 'v')
+    m8 = dctx.mask('v').double().cpu()
+    assert rel_err(y8, x8.double().cpu() * m8 / 0.6) < (1e-6 if dt == torch.float32 else 5e-3)
     # streams: another site or another step gives another mask, the same (step, site) the same one
     ma = dctx.mask('a').clone()
     dctx.begin()
