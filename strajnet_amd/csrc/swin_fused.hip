@@ -727,7 +727,10 @@ static int split_bwd_epi(const void* x, const void* dy, const float* part, int S
   return stj_check_launch("swin_split_bwd_epi");
 }
 constexpr int SPLIT_MAX = 8;         // slices of a split launch (the workspace holds SPLIT_MAX x M x C floats)
-constexpr int MLP_SPLIT = 8;         // hidden-dimension slices of the C = 384 MLP half: 32 row blocks x 8 = 256 workgroups at B = 8
+// slices per unit: enough for ~256 workgroups, no more -- every slice costs a [M][C] f32 partial-sum pass (cfg-512's 8192-row stage with
+// 8 / 6 slices: 100 / 75 MB per kernel, the step 3 % slower than layer by layer; with 2: the 25 MB of the 2048-row stage)
+static int mlp_split_for(long long M) { const long long blocks = (M + 63) / 64; return blocks <= 32 ? 8 : (blocks <= 64 ? 4 : 2); }
+static int attn_split_for(long long windows) { return windows <= 48 ? 6 : 2; }
 
 template <typename T, int C, int RFP, bool SPLIT = false>
 static int mlp_launch(bool bwd, const MlpArgs& a, hipStream_t st) {
@@ -756,11 +759,11 @@ static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
     case 384: {
       if (a.part == nullptr) return mlp_launch<T, 384, 1>(bwd, a, st);
       MlpArgs s = a;                 // with a workspace: (row block, hidden slice) workgroups + the finishing launch
-      s.split = MLP_SPLIT;
+      s.split = mlp_split_for(a.M);
       const int rc = mlp_launch<T, 384, 1, true>(bwd, s, st);
       if (rc != STJ_OK) return rc;
-      if (bwd) return split_bwd_epi<T>(a.x, a.dy, a.part, MLP_SPLIT, a.gamma, a.eps, nullptr, nullptr, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.M, st);
-      return split_fwd_epi<T>(a.x, a.part, MLP_SPLIT, a.b2, a.y, a.M, C, a.rng, a.site, a.p_drop, a.rows_per_sample, st);
+      if (bwd) return split_bwd_epi<T>(a.x, a.dy, a.part, s.split, a.gamma, a.eps, nullptr, nullptr, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.M, st);
+      return split_fwd_epi<T>(a.x, a.part, s.split, a.b2, a.y, a.M, C, a.rng, a.site, a.p_drop, a.rows_per_sample, st);
     }
     default: stj_set_error("swin_mlp: C must be 96, 192 or 384 (got %d)", C); return STJ_EUNSUPPORTED;
   }
@@ -1056,7 +1059,6 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   }
 }
 
-constexpr int ATTN_SPLIT = 6;        // head slices of the C = 384 attention half (2 of the 12 heads each): 32 windows x 6 = 192 workgroups at B = 8
 template <typename T, int C, bool SPLIT = false>
 static int attn_launch(const AttnArgs& a, hipStream_t st) {
   typedef AttnCfg<T, C> G;
@@ -1078,11 +1080,11 @@ static int attn_split384(const AttnArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if (a.part == nullptr) { stj_set_error("swin_attn: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
     AttnArgs s = a;
-    s.split = ATTN_SPLIT;
+    const long long N = (long long)a.res * a.res;
+    s.split = attn_split_for(a.B * (N / 64));          // 6 slices of 2 heads (32 windows at B = 8: 192 workgroups) or 2 of 6
     const int rc = attn_launch<T, 384, true>(s, st);
     if (rc != STJ_OK) return rc;
-    const long long N = (long long)a.res * a.res;
-    return split_fwd_epi<T>(a.x, a.part, ATTN_SPLIT, a.bproj, a.y, a.B * N, 384, a.rng, a.site, a.p_drop, N, st);
+    return split_fwd_epi<T>(a.x, a.part, s.split, a.bproj, a.y, a.B * N, 384, a.rng, a.site, a.p_drop, N, st);
   } else {
     stj_set_error("swin_attn: C = 384 is built for the 16-bit storage types"); return STJ_EUNSUPPORTED;
   }
@@ -1533,10 +1535,11 @@ template <typename T>
 static int attnb_split384(const AttnBArgs& a, hipStream_t st) {          // see attn_split384
   if constexpr (sizeof(T) == 2) {
     if (a.part == nullptr) { stj_set_error("swin_attn_bwd: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
-    const int rc = attnb_launch<T, 384, ATTN_SPLIT>(a, st);
-    if (rc != STJ_OK) return rc;
     const long long N = (long long)a.res * a.res;
-    return split_bwd_epi<T>(a.x, a.dy, a.part, ATTN_SPLIT, a.gamma, 0.f, a.mean, a.rstd, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.B * N, st);
+    const int split = attn_split_for(a.B * (N / 64));
+    const int rc = split == 6 ? attnb_launch<T, 384, 6>(a, st) : attnb_launch<T, 384, 2>(a, st);
+    if (rc != STJ_OK) return rc;
+    return split_bwd_epi<T>(a.x, a.dy, a.part, split, a.gamma, 0.f, a.mean, a.rstd, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.B * N, st);
   } else {
     stj_set_error("swin_attn_bwd: C = 384 is built for the 16-bit storage types"); return STJ_EUNSUPPORTED;
   }

@@ -683,7 +683,7 @@ def test_dropout_op(dt):
 
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('B,N,C,p_drop', [(3, 64, 96, 0.0), (4, 256, 96, 0.3), (2, 128, 192, 0.3), (3, 64, 384, 0.0), (1, 80, 96, 0.0),
-                                          (8, 256, 384, 0.3), (1, 80, 384, 0.3)])
+                                          (8, 256, 384, 0.3), (1, 80, 384, 0.3), (8, 1024, 384, 0.3)])
 def test_swin_mlp_fused(dt, B, N, C, p_drop):
     """csrc/swin_fused.hip: x + DropPath(fc2(gelu(fc1(LN(x))))) in one kernel, and its backward (dx, LN gamma/beta, both weight
     and bias gradients) vs float64 autograd on the same statement (modules.py:260, :40-46, :18-29, :137-151).  Row counts that
@@ -768,7 +768,7 @@ def test_swin_attn_half_fused(dt, B, res, C, shift, p_drop):
 
 
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('B,res,shift', [(8, 16, 4), (2, 32, 0)])
+@pytest.mark.parametrize('B,res,shift', [(8, 16, 4), (2, 32, 0), (4, 32, 4)])          # 6 / 6 / 2 head slices, 8 / 8 / 4 hidden slices
 def test_swin384_block_split_vs_layerwise_vs_f64(dt, B, res, shift):
     """One whole C = 384 Swin block (the 16 x 16 stage of cfg-256, the 32 x 32 stage of cfg-512): the split fused kernels
     ((window, head slice) / (row block, hidden slice) workgroups + finishing launches) against float64, and never noticeably
