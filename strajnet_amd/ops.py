@@ -911,6 +911,9 @@ class _MhaCore(torch.autograd.Function):
         return dq, dk, dv, (dS if has_bias else None), None, None, None, None, None, None, doff, None, None
 
 
+UPWG_BUDGET = 128       # workgroups of the two large up-conv weight-gradient launches inside the concurrent step (half the CUs; 256 when alone)
+
+
 class _SmallAttn(torch.autograd.Function):
     """mha_core for at most 16 queries / keys per (batch element, head): one launch per direction (stj_small_attn_*)."""
     @staticmethod
@@ -1512,7 +1515,7 @@ def _upconv_backward_tail(ctx, x, dpre, wd, need_dx):
         else:                    # (~1000 workgroups would queue on Cout addresses otherwise)
             dbp, nparts, own = torch.zeros(_DB_PARTS * Cout, dtype=torch.float32, device=x.device), _DB_PARTS, True
         # alone on the GPU (serial mode) the large weight-gradient launches take all CUs; in the concurrent step half of them
-        call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), nparts, F_, Hi, Wi, Cin, Cout, 256 if _SERIAL else 128, dt, _st())
+        call('stj_upconv_wgrad', _p(x), _p(dpre), _p(dweff), _p(dbp), nparts, F_, Hi, Wi, Cin, Cout, 256 if _SERIAL else UPWG_BUDGET, dt, _st())
         call('stj_upconv_fold', _p(dweff), _p(pw.grad), Cin, Cout, _st())
         if own:
             pb.grad.add_(dbp.view(nparts, Cout).sum(0))
