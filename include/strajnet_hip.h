@@ -56,6 +56,23 @@ int stj_gemm(const void* A, const void* B, void* C, const float* bias, const voi
 long long stj_gemm_group_workspace_bytes(void);
 int stj_gemm_group_begin(void* group);
 int stj_gemm_group_end(void* group, hipStream_t stream);
+/* Grouped stream-K weight gradients (csrc/wgrad_sk.hip): for every job  dw[z] += x[z]^T dy[z]  and, if db != NULL,
+ * db[z] += column sums of dy[z]  (z = z1*nb2 + z2 < nb1*nb2) -- tape.gradient (train.py:223) w.r.t. the kernel / bias of the Keras
+ * Dense layers, 1x1 convs and tfa-MHA projections (modules.py:36-37,76-83,270-272; trajNet.py:71-77,195-211; FG_MSA.py:54-64) --
+ * ALL jobs of the list in ONE launch (per 28 jobs) on `wg_budget` workgroups (<= 0: one per CU).  x [rows, cin] with row stride ldx,
+ * dy [rows, cout] with row stride lddy (activation dtype, 16-byte aligned), dw f32 [cin, cout] with row stride lddw, db f32 [cout];
+ * s*1 / s*2 are the element strides of the two batch levels.  A workgroup owns a full-width 96 x 384 tile of a job, streams the rows
+ * once through an LDS-DMA ring, and the launch's workgroups share the 32-row slabs of all jobs evenly (stream-K): f32 atomics only
+ * where a workgroup leaves a tile.  Jobs must satisfy stj_wgrad_job_supported (16-bit dtype, rows % 32 == 0, cin, cout and all
+ * strides of x / dy multiples of 8); anything else is stj_gemm's (accumulate = 1). */
+typedef struct stj_wgrad_job {
+  const void* x; const void* dy; float* dw; float* db;
+  int rows, cin, cout, nb1, nb2;
+  long long ldx, lddy, lddw;
+  long long sx1, sx2, sdy1, sdy2, sdw1, sdw2, sdb1, sdb2;
+} stj_wgrad_job;
+int stj_wgrad_job_supported(const stj_wgrad_job* job, int dtype);
+int stj_wgrad_group(const stj_wgrad_job* jobs, int njobs, int dtype, int wg_budget, hipStream_t stream);
 /* out[n] += sum_m X[m,n]  (bias gradients of the conv heads). */
 int stj_colsum(const void* X, float* out, int M, int N, long long ld, int dtype, hipStream_t stream);
 /* f32 <-> bf16 / fp16 copy (16-bit compute copy of the flat parameter buffer). */

@@ -19,6 +19,8 @@ SIGNATURES = {
     'stj_gemm_group_workspace_bytes': [],
     'stj_gemm_group_begin': [vp],
     'stj_gemm_group_end': [vp, vp],
+    'stj_wgrad_job_supported': [vp, ci],
+    'stj_wgrad_group': [vp, ci, ci, ci, vp],
     'stj_colsum': [vp, vp, ci, ci, cl, ci, vp],
     'stj_cast': [vp, ci, vp, ci, cl, vp],
     'stj_crc32c': [vp, cl, vp],
@@ -89,6 +91,14 @@ SIGNATURES = {
     'stj_loss_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp],
     'stj_loss_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
 }
+
+class WgradJob(ctypes.Structure):
+    """struct stj_wgrad_job (include/strajnet_hip.h)"""
+    _fields_ = [('x', vp), ('dy', vp), ('dw', vp), ('db', vp),
+                ('rows', ci), ('cin', ci), ('cout', ci), ('nb1', ci), ('nb2', ci),
+                ('ldx', cl), ('lddy', cl), ('lddw', cl),
+                ('sx1', cl), ('sx2', cl), ('sdy1', cl), ('sdy2', cl), ('sdw1', cl), ('sdw2', cl), ('sdb1', cl), ('sdb2', cl)]
+
 
 _lib = None
 

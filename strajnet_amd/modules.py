@@ -355,11 +355,16 @@ class STrajNet:
         src, leaf = self._cut_src, self._cut_leaf
         self._cut_src = self._cut_leaf = None
         pairs = [(s_, l.grad) for s_, l in zip(src, leaf) if l.grad is not None]
-        torch.autograd.backward([a for a, _ in pairs], [g for _, g in pairs])
-        main = torch.cuda.current_stream(self.device)
-        for st in self._streams:
-            if st is not None:
-                main.wait_stream(st)
+        ops.wgrad_queue_begin()               # the encoder's dense weight gradients: queued, flushed at the stage boundaries and here
+        try:
+            torch.autograd.backward([a for a, _ in pairs], [g for _, g in pairs])
+            main = torch.cuda.current_stream(self.device)
+            for st in self._streams:
+                if st is not None:
+                    main.wait_stream(st)
+        finally:
+            with torch.no_grad():
+                ops.wgrad_queue_end()
         ops.wgrad_join_now(main)
         with torch.no_grad():
             self._fold_partials('encoder')
@@ -498,6 +503,8 @@ class STrajNet:
         for i in range(3):
             r, c = self.stage_res[i], self.stage_dim[i]
             x, res = self._basic_layer(x, f'layers{i}', B, r, depths[i], heads[i], i < 2, add=joined_flow_x if i == 0 else None)
+            if i < 2:       # in backward: stage i + 1 is through -> its weight gradients (and whatever else is queued) leave as one launch
+                x = ops.wgrad_queue_flush_point(x)
             if i == 0:
                 res_list.append(crop(flow_res, r, c) if self.large_ogm else flow_res)
                 if hook is not None:
@@ -743,6 +750,7 @@ class STrajNet:
                 raise RuntimeError('inputs must be CUDA (ROCm) tensors: the HIP path has no CPU fallback')
         self._side, self._side2 = (None, None) if self.serial else self._streams
         ops.set_serial(self.serial)
+        ops.wgrad_queue_reset()
         ops.use_arena(self._arena)
         self._sync_compute_weights()
         self._dctx = None
@@ -813,7 +821,7 @@ class STrajNet:
             with torch.cuda.stream(self._side2):
                 skips = (self._resconv(res_list[2], 'decoder/resconv_3'), self._resconv(res_list[1], 'decoder/resconv_2'),
                          self._resconv(res_list[0], 'decoder/resconv_f'))
-        q = res_list[-1].reshape(B, hb, hb, Cb)
+        q = ops.wgrad_queue_flush_point(res_list[-1]).reshape(B, hb, hb, Cb)     # backward: FG-MSA / cross-attention / agent branch are through
         # waypoint-major [8,B,HW,Cb] (the reference's [B,8,...] transposed): every per-waypoint product downstream is then a
         # plain batched GEMM and the decoder frames are t-major; the output kernel undoes it when writing [B,H,W,32]
         if self.fg_msa:

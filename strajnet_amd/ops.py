@@ -242,10 +242,13 @@ class _JoinAfterBackward(torch.autograd.Function):
     def backward(ctx, g):
         streams, post = ctx.streams, ctx.post
         main = torch.cuda.current_stream(g.device)
+        wgrad_queue_begin()
 
         def join():
             for s in streams:
                 main.wait_stream(s)
+            with torch.cuda.stream(main), torch.no_grad():
+                wgrad_queue_end()             # the dense weight gradients still queued (one grouped stream-K launch)
             # the weight-gradient side stream writes bias-gradient partials that `post` folds: it must be ordered before the fold
             # (its own join callback is queued later than this one and would run after it)
             key = g.device.index if g.device.index is not None else torch.cuda.current_device()
@@ -279,10 +282,21 @@ class Param:
 
 
 def gemm(A, B, C, M, N, K, sA, sB, sC, dt, bias=None, sBias=(0, 0), res=None, sRes=(0, 0, 0), nb=(1, 1),
-         act=ACT_NONE, alpha=1.0, c_f32=0, accumulate=0, splitk=1, colsum=None, kseg=(1, 0, 0)):
+         act=ACT_NONE, alpha=1.0, c_f32=0, accumulate=0, splitk=1, colsum=None, kseg=(1, 0, 0), post=None):
     """sA = (b1, b2, m, k) element strides; sB = (b1, b2, k, n); sC = (b1, b2, ldc); sRes = (b1, b2, ld);
-    kseg = (n, sA, sB): the contraction also runs over n K-segments of A / B that lie sA / sB elements apart."""
+    kseg = (n, sA, sB): the contraction also runs over n K-segments of A / B that lie sA / sB elements apart.
+    post: callable that consumes C; it travels with a DEFERRED weight gradient and runs behind the flush that carries it.
+    Returns True when the product was queued (post will run), False when it was launched (or recorded in the open group): the
+    caller then runs its post-processing itself, after closing the group."""
+    if (accumulate and _WQ['on'] and splitk == 0 and c_f32 and kseg[0] == 1 and sA[2] == 1 and sB[3] == 1 and bias is None
+            and res is None and alpha == 1.0 and isinstance(A, torch.Tensor) and isinstance(B, torch.Tensor)):
+        # a weight gradient dW += x^T dY inside a model's backward pass: queued for the grouped stream-K launch of the next flush
+        j = WJob(A, B, C, colsum, K, M, N, sA[3], sB[2], sC[2], dt, nb=nb, sx=sA[:2], sdy=sB[:2], sdw=sC[:2], sdb=sBias)
+        if j.supported():
+            wgrad_queue_push(j, post)
+            return True
     _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum, kseg)
+    return False
 
 
 def _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum, kseg):
@@ -290,6 +304,145 @@ def _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act
          sA[0], sA[1], sA[2], sA[3], sB[0], sB[1], sB[2], sB[3], sC[0], sC[1], sC[2],
          sBias[0], sBias[1], sRes[0], sRes[1], sRes[2], act, float(alpha), dt, c_f32, accumulate, splitk,
          kseg[0], kseg[1], kseg[2], _GROUP[0], _st())
+
+
+# ----------------------------------------------------------------------------------------------------
+# Grouped stream-K weight gradients (csrc/wgrad_sk.hip): dW += x^T dY (+ db += 1^T dY) of MANY Dense layers in one launch
+# ----------------------------------------------------------------------------------------------------
+class WJob:
+    """One weight-gradient problem: dw[z] += x[z]^T dy[z], db[z] += colsum(dy[z]) over nb = (nb1, nb2) batch levels.
+    x / dy / dw / db are tensors or raw device pointers (ctypes.c_void_p) -- the batch strides may reach outside a tensor's own view
+    (flat-buffer addressing); sx / sdy / sdw / sdb = (stride of level 1, of level 2) in elements."""
+    __slots__ = ('x', 'dy', 'dw', 'db', 'rows', 'cin', 'cout', 'ldx', 'lddy', 'lddw', 'nb', 'sx', 'sdy', 'sdw', 'sdb', 'dt', 'keep')
+
+    def __init__(self, x, dy, dw, db, rows, cin, cout, ldx, lddy, lddw, dt, nb=(1, 1), sx=(0, 0), sdy=(0, 0), sdw=(0, 0), sdb=(0, 0), keep=()):
+        self.x, self.dy, self.dw, self.db = x, dy, dw, db
+        self.rows, self.cin, self.cout, self.ldx, self.lddy, self.lddw = rows, cin, cout, ldx, lddy, lddw
+        self.nb, self.sx, self.sdy, self.sdw, self.sdb, self.dt, self.keep = nb, sx, sdy, sdw, sdb, dt, keep
+
+    def c(self):
+        from ._lib import WgradJob
+        return WgradJob(_p(self.x), _p(self.dy), _p(self.dw), _p(self.db), self.rows, self.cin, self.cout, self.nb[0], self.nb[1],
+                        self.ldx, self.lddy, self.lddw, self.sx[0], self.sx[1], self.sdy[0], self.sdy[1], self.sdw[0], self.sdw[1],
+                        self.sdb[0], self.sdb[1])
+
+    def supported(self):
+        from ._lib import lib
+        return bool(lib().stj_wgrad_job_supported(ctypes.byref(self.c()), self.dt))
+
+    def gemm(self):
+        """the same problem through stj_gemm (split-K tile kernel): shapes the stream-K kernel does not take"""
+        call('stj_gemm', _p(self.x), _p(self.dy), _p(self.dw), vp(0), vp(0), _p(self.db), self.cin, self.cout, self.rows, self.nb[0], self.nb[1],
+             self.sx[0], self.sx[1], 1, self.ldx, self.sdy[0], self.sdy[1], self.lddy, 1, self.sdw[0], self.sdw[1], self.lddw,
+             self.sdb[0], self.sdb[1], 0, 0, 0, ACT_NONE, 1.0, self.dt, 1, 1, 0, 1, 0, 0, _GROUP[0], _st())
+
+
+WG_BUDGET = int(os.environ.get('STJ_WGRAD_SK_WGS', '0'))       # workgroups of a grouped weight-gradient launch (0: one per CU)
+_WJ_LAST = [None]
+
+
+def _wgrad_group_model(a):
+    jobs = _WJ_LAST[0]
+    fl = sum(2.0 * j.rows * j.cin * j.cout * j.nb[0] * j.nb[1] for j in jobs)
+    by = 0.0
+    for j in jobs:
+        nb, es = j.nb[0] * j.nb[1], 2
+        nx = (j.nb[0] if j.sx[0] else 1) * (j.nb[1] if j.sx[1] else 1)
+        by += es * j.rows * (j.cin * nx + j.cout * nb) + 4 * j.cin * j.cout * nb
+    return f'wgrad_group[{len(jobs)} jobs, {sum(j.rows * j.nb[0] * j.nb[1] for j in jobs)} rows]', 'gemm_wgrad', fl, fl, by
+
+
+prof.EXTRA_MODELS['stj_wgrad_group'] = _wgrad_group_model
+
+
+def wgrad_group(jobs, budget=None):
+    """Launch the weight gradients `jobs` (list of WJob, one dtype): those the stream-K kernel takes leave as ONE launch, the rest as
+    stj_gemm split-K launches."""
+    from ._lib import WgradJob
+    fast = [j for j in jobs if j.supported()]
+    for j in jobs:
+        if j not in fast:
+            j.gemm()
+    if fast:
+        arr = (WgradJob * len(fast))(*[j.c() for j in fast])
+        _WJ_LAST[0] = fast
+        call('stj_wgrad_group', ctypes.cast(arr, vp), len(fast), fast[0].dt, WG_BUDGET if budget is None else budget, _st())
+
+
+# Deferred weight gradients.  Inside a model's backward pass (between _JoinAfterBackward.backward, the first node the engine runs, and its
+# end-of-pass callback) every dW += x^T dY that gemm() is asked for is QUEUED instead of launched; a flush (the model's flush points and
+# the end of the pass) sends everything queued so far as one stj_wgrad_group launch per 28 problems.  The queue holds the operands, so
+# the caching allocator cannot recycle them before the flush is enqueued; operands produced on another stream are ordered in front of
+# the flush with an event and recorded on the flush stream.
+WGRAD_SK = os.environ.get('STJ_WGRAD_SK', '1') != '0'
+_WQ = {'on': False, 'jobs': []}
+
+
+def wgrad_queue_begin():
+    _WQ['on'] = WGRAD_SK
+    _WQ['jobs'] = []
+
+
+def wgrad_queue_reset():
+    """Start of a forward pass: whatever an aborted backward pass left behind is dropped."""
+    _WQ['on'] = False
+    _WQ['jobs'] = []
+
+
+def wgrad_queue_push(job, post=None):
+    st = torch.cuda.current_stream()
+    ev = None
+    if not _SERIAL:
+        ev = torch.cuda.Event()
+        ev.record(st)
+    _WQ['jobs'].append((job, post, st, ev))
+
+
+def wgrad_queue_flush():
+    """Launch everything queued, on the current stream."""
+    items, _WQ['jobs'] = _WQ['jobs'], []
+    if not items:
+        return
+    cur = torch.cuda.current_stream()
+    last = {}
+    for job, post, st, ev in items:
+        if ev is not None and st != cur:
+            last[st] = ev                       # events of one stream are ordered: the last one covers the earlier ones
+            for t in (job.x, job.dy):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
+    for ev in last.values():
+        cur.wait_event(ev)
+    wgrad_group([it[0] for it in items])
+    for _, post, _, _ in items:
+        if post is not None:
+            post()
+
+
+def wgrad_queue_end():
+    wgrad_queue_flush()
+    _WQ['on'] = False
+
+
+class _WgradQueueFlush(torch.autograd.Function):
+    """Identity whose backward flushes the weight-gradient queue: everything downstream of it in the forward pass has been through."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        wgrad_queue_flush()
+        return g
+
+
+def wgrad_queue_flush_point(x):
+    if WGRAD_SK and WGRAD_SK_POINTS and x.requires_grad and torch.is_grad_enabled():
+        return _WgradQueueFlush.apply(x)
+    return x
+
+
+WGRAD_SK_POINTS = os.environ.get('STJ_WGRAD_SK_POINTS', '1') != '0'
 
 
 def _splitk(M_out, N_out, Kdim):
@@ -344,12 +497,13 @@ class _Linear(torch.autograd.Function):
                 dx = torch.empty_like(x2)
                 gemm(dpre, wc, dx, M, K, N, (0, 0, N, 1), (0, 0, 1, N), (0, 0, K), dt)        # dx = dpre W^T
                 dx = dx.view(ctx.xshape)
+            fold = ctx.fold
             with wgrad_stream(1, x2, dpre):
-                gemm(x2, dpre, gw, K, N, M, (0, 0, 1, K), (0, 0, N, 1), (0, 0, N), dt, c_f32=1, accumulate=1,
-                     splitk=0, colsum=ctx.gb)                                 # dW += x^T dpre ; db += 1^T dpre (fused)
-        if ctx.fold is not None:
+                queued = gemm(x2, dpre, gw, K, N, M, (0, 0, 1, K), (0, 0, N, 1), (0, 0, N), dt, c_f32=1, accumulate=1,
+                              splitk=0, colsum=ctx.gb, post=(lambda: fold(gw)) if fold is not None else None)   # dW += x^T dpre ; db += 1^T dpre (fused)
+        if fold is not None and not queued:
             with wgrad_stream(1, x2, dpre):
-                ctx.fold(gw)
+                fold(gw)
         dres = dy if ctx.has_res else None
         return dx, None, None, None, None, None, None, dres, None
 
@@ -472,11 +626,11 @@ class _LinearZ(torch.autograd.Function):
                     gemm(dpre, ctx.w0, dx, R, K, N, (0, R * N, N, 1), (0, wstride, 1, N), (0, R * K, K), dt, nb=(1, Z))
             # dW_z += x_z^T dpre_z ; db_z += column sums (fused)
             with wgrad_stream(1, x, dpre):
-                gemm(x, dpre, ctx.gw0, K, N, R, (0, 0 if shared_x else R * K, 1, K), (0, R * N, N, 1), (0, gwstride, N), dt,
-                     nb=(1, Z), c_f32=1, accumulate=1, splitk=0, colsum=ctx.gb0, sBias=(0, bstride))
+                queued = gemm(x, dpre, ctx.gw0, K, N, R, (0, 0 if shared_x else R * K, 1, K), (0, R * N, N, 1), (0, gwstride, N), dt,
+                              nb=(1, Z), c_f32=1, accumulate=1, splitk=0, colsum=ctx.gb0, sBias=(0, bstride), post=ctx.fold)
         if acc is not None:
             dx = acc.to(x.dtype).view(xshape)
-        if ctx.fold is not None:
+        if ctx.fold is not None and not queued:
             with wgrad_stream(1, x, dpre):
                 ctx.fold()
         return (dx,) + (None,) * 12
@@ -1554,6 +1708,8 @@ class _WgradFlushPoint(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         flush_upconv_wgrads()
+        if WGRAD_SK_POINTS:
+            wgrad_queue_flush()             # the decoder's dense weight gradients (the three time-kernel skips)
         return g
 
 
