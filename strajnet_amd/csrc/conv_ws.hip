@@ -506,7 +506,12 @@ __global__ __launch_bounds__(256, 2) void upconv_wgrad_tr_kernel(const bf16* __r
                                                               int Cout, int chunks_per_block, int nstrips, int ntiles) {
   constexpr int WG2_W = CW, WG2_ROWS = 128 / CW, KROWS = 32 / CW;      // KROWS: chunk rows per 32-pixel k-step
   constexpr int BO = FO * 16, BI = FI * 16;
-  constexpr int LDO = BO + 8, LDI = BI + 8;
+  // Row strides of the two [pixel][channel] images: 16 * odd elements = 8 * odd dwords.  A 32-lane pass of ds_read_b64_tr_b16 reads 8
+  // pixels x 32 bytes; with the k-permutation below those are 8 CONSECUTIVE pixels, and a stride of 8 * odd dwords spreads them over
+  // the 8 disjoint 8-bank groups: conflict-free (the strides BO + 8 / BI + 8 with pixels {0..3, 8..11} per pass measured 41-47 % conflict
+  // cycles, profiles/r03_h_pmc_step.txt).
+  constexpr int LDO = (BO / 16) % 2 ? BO : BO + 16, LDI = (BI / 16) % 2 ? BI : BI + 16;
+  static_assert((LDO / 16) % 2 == 1 && (LDI / 16) % 2 == 1 && LDO % 16 == 0 && LDI % 16 == 0, "row strides must be 16 * odd elements");
   constexpr int XW = WG2_W + 2, XR = WG2_ROWS + 1;
   constexpr int NPX = WG2_ROWS * WG2_W;
   constexpr int DY_CH = NPX * (BO / 8), X_CH = XR * XW * (BI / 8);
@@ -584,8 +589,11 @@ __global__ __launch_bounds__(256, 2) void upconv_wgrad_tr_kernel(const bf16* __r
 
   if (c_begin < c_end) { prefetch(c_begin); commit(); }
   __syncthreads();
-  // per-lane tr-read bases: lane p of group g addresses pixel (8g + p/4 [+4]) and channels 4*(p%4).. of a 16-channel block
-  const int kpx = 8 * g + (p >> 2), kch = 4 * (p & 3);
+  // per-lane tr-read bases: lane p of group g addresses pixel (4g + p/4 [+16]) of the 32-pixel k-step and channels 4*(p%4).. of a
+  // 16-channel block.  (Which 8 of the 32 pixels a lane group contributes is free as long as both operands agree: the MFMA sums
+  // over k.  Pixels 4g .. 4g+3 and 16+4g .. make every 32-lane pass read 8 consecutive pixels.)
+  const int kpx = 4 * g + (p >> 2), kch = 4 * (p & 3);
+  constexpr int XHI = CW == 32 ? 16 * LDI : XW * LDI;          // + 16 pixels: same row (CW = 32) or the next chunk row (CW = 16)
   for (int c = c_begin; c < c_end; ++c) {
     if (c + 1 < c_end) prefetch(c + 1);
 #pragma unroll
@@ -593,10 +601,10 @@ __global__ __launch_bounds__(256, 2) void upconv_wgrad_tr_kernel(const bf16* __r
       s16x8 af[FO], bfr[FI];
       const bf16* ab = dYs + (rr * 32 + kpx) * LDO + kch;
 #pragma unroll
-      for (int m = 0; m < FO; ++m) af[m] = tr_frag(ab + m * 16, ab + 4 * LDO + m * 16);
-      const bf16* bb = Xs + ((rr * KROWS + kpx / CW + r) * XW + kpx % CW + s) * LDI + kch;
+      for (int m = 0; m < FO; ++m) af[m] = tr_frag(ab + m * 16, ab + 16 * LDO + m * 16);
+      const bf16* bb = Xs + ((rr * KROWS + r) * XW + kpx + s) * LDI + kch;
 #pragma unroll
-      for (int n = 0; n < FI; ++n) bfr[n] = tr_frag(bb + n * 16, bb + 4 * LDI + n * 16);
+      for (int n = 0; n < FI; ++n) bfr[n] = tr_frag(bb + n * 16, bb + XHI + n * 16);
 #pragma unroll
       for (int m = 0; m < FO; ++m)
 #pragma unroll
@@ -651,7 +659,10 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_tr4_kernel(const bf16* __
                                                                   int Cout, int chunks_per_block, int nstrips, int ntiles) {
   constexpr int CR = NPIX / CW, KROWS = 32 / CW;          // NPIX low-res pixels per barrier pair (NPIX / 32 k-steps)
   constexpr int BO = FO * 16, BI = FI * 16;
-  constexpr int LDO = BO + 8, LDI = BI + 8;
+  // row strides: consecutive low-res pixels lie 2 hi-res columns = LDO dwords apart in the dP image and LDI / 2 dwords apart in the X
+  // image; both 8 * odd dwords, so the 8 consecutive pixels of a 32-lane transpose-read pass (k-permutation below) hit disjoint banks
+  constexpr int LDO = BO + 8, LDI = (BI / 16) % 2 ? BI : BI + 16;
+  static_assert((LDO / 8) % 2 == 1 && (LDI / 16) % 2 == 1 && LDI % 16 == 0, "conflict-free transpose-read strides");
   constexpr int YW = 2 * CW, YR = CR, XW = CW + 2, XR = CR + 1;
   constexpr int DY_CH = YR * YW * (BO / 8), X_CH = XR * XW * (BI / 8);
   constexpr int NCH = (DY_CH + X_CH + 511) / 512;
@@ -733,8 +744,9 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_tr4_kernel(const bf16* __
   };
   if (c_begin < c_end) { prefetch(c_begin); commit(0); }
   __syncthreads();
-  const int kpx = 8 * g + (p >> 2), kch = 4 * (p & 3);
-  const int krow = kpx / CW, kcol = kpx % CW;
+  const int kpx = 4 * g + (p >> 2), kch = 4 * (p & 3);        // pixels 4g + p/4 and 16 + 4g + p/4 of a 32-pixel k-step (see upconv_wgrad_tr_kernel)
+  const int krow = 0, kcol = kpx;
+  constexpr int XHI = CW == 32 ? 16 * LDI : XW * LDI;          // + 16 pixels: same row (CW = 32) or the next chunk row (CW = 16)
   for (int c = c_begin; c < c_end; ++c) {
     const int bo = ((c - c_begin) & 1) * BUF;
     if (c + 1 < c_end) prefetch(c + 1);
@@ -743,10 +755,10 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_tr4_kernel(const bf16* __
       s16x8 af[FO], bfr[FI];
       const bf16* ab = dYs + bo + ((rr * KROWS + krow) * YW + 2 * kcol + b) * LDO + kch;               // this wave's column parity
 #pragma unroll
-      for (int m = 0; m < FO; ++m) af[m] = tr_frag(ab + m * 16, ab + 8 * LDO + m * 16);          // + 4 low-res pixels = + 8 hi-res columns
+      for (int m = 0; m < FO; ++m) af[m] = tr_frag(ab + m * 16, ab + 32 * LDO + m * 16);         // + 16 low-res pixels = + 32 hi-res columns (CW = 16: = the next row, YW = 32)
       const bf16* bb = Xs + bo + ((rr * KROWS + krow + r) * XW + kcol + b + s) * LDI + kch;
 #pragma unroll
-      for (int n = 0; n < FI; ++n) bfr[n] = tr_frag(bb + n * 16, bb + 4 * LDI + n * 16);
+      for (int n = 0; n < FI; ++n) bfr[n] = tr_frag(bb + n * 16, bb + XHI + n * 16);
 #pragma unroll
       for (int m = 0; m < FO; ++m)
 #pragma unroll
@@ -792,7 +804,7 @@ template <int FO, int FI, int CW, int NPIX>
 static bool wgrad_tr4_launch(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout,
                              int tiles, int wg_budget, hipStream_t st) {
   constexpr int CR = NPIX / CW, BO = FO * 16, BI = FI * 16;
-  const size_t lds = (size_t)2 * (CR * 2 * CW * (BO + 8) + (CR + 1) * (CW + 2) * (BI + 8)) * 2;
+  const size_t lds = (size_t)2 * (CR * 2 * CW * (BO + 8) + (CR + 1) * (CW + 2) * ((BI / 16) % 2 ? BI : BI + 16)) * 2;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)upconv_wgrad_tr4_kernel<FO, FI, CW, NPIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
