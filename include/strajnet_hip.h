@@ -258,13 +258,11 @@ int stj_upconv_fwd(const void* X, const void* Wf, const float* bias, void* Y, in
 /* Up-conv with the decoder skip sums in the epilogue (modules.py:750-765: x = upconv(x) + skip): Y = ELU(conv + bias) + R1 and, when
  * Y2 / R2 are not NULL, Y2 = Y + R2; every sum rounded to the activation dtype like a separate add.  16-bit dtypes, Cin in {192, 384, ...}
  * (multiple of 32 above 128), Cout multiple of 32; STJ_EUNSUPPORTED otherwise.  Backward of the sums + ELU: stj_elu_res_bwd:
- * g = dy (+ dy2, then g is also written to gsum: the gradient of R1), dpre = g * ELU'(Y - R1) (r == NULL: y is the ELU output itself).
- * stj_skip_add: the same sums as a pass of their own over an up-conv's stored ELU output: y1 = y + r1, y2 = y1 + r2 (r2 / y2 NULL: one sum). */
+ * g = dy (+ dy2, then g is also written to gsum: the gradient of R1), dpre = g * ELU'(Y - R1) (r == NULL: y is the ELU output itself). */
 int stj_upconv_fwd_res(const void* X, const void* Wf, const float* bias, void* Y, const void* R1, void* Y2, const void* R2, int F, int Hi,
                        int Wi, int Cin, int Cout, int dtype, hipStream_t stream);
 int stj_elu_res_bwd(const void* dy, const void* dy2, const void* y, const void* r, void* dpre, void* gsum, long long n, int dtype,
                     hipStream_t stream);
-int stj_skip_add(const void* y, const void* r1, const void* r2, void* y1, void* y2, long long n, int dtype, hipStream_t stream);
 int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout,
                      int dtype, hipStream_t stream);
 /* wg_budget: workgroups the two large weight-gradient launches (>= 64x64 inputs) may occupy.  0 = 128: half the CUs, because in a

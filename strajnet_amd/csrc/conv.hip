@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <typename T>
 static bool upconv_dgrad_pf_try(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("STJ_NO_DGRAD_PF"); on = !(e && atoi(e)); }
+  if (on < 0) { const char* e = getenv("STJ_NO_WS"); on = !(e && atoi(e)); }      // STJ_NO_WS=1: generic conv kernels everywhere
   if (!on || Hi % TILE_H || Wi % TILE_W || Cin % 64 || Cout % KC || Cin <= 128) return false;
   constexpr int FN = 4, BN = FN * 16, LDK = KC + 8;
   const size_t lds = (size_t)((2 * TILE_H + 2) * (2 * TILE_W + 2) * LDK + 16 * BN * LDK) * sizeof(T);

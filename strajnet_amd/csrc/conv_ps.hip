@@ -208,7 +208,7 @@ static bool fwd_ps_try_t(const void* X, const void* Wf, const float* bias, void*
 bool upconv_fwd_ps_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        int dtype, hipStream_t st) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("STJ_NO_PS"); on = !(e && atoi(e)); }
+  if (on < 0) { const char* e = getenv("STJ_NO_WS"); on = !(e && atoi(e)); }      // STJ_NO_WS=1: generic conv kernels everywhere
   if (!on || act != ACT_ELU || Cin % PS_KC || Cin <= 128 || Cout % 32) return false;
   return dtype == STJ_F16 ? fwd_ps_try_t<f16>(X, Wf, bias, Y, nullptr, nullptr, nullptr, F, Hi, Wi, Cin, Cout, st)
                           : fwd_ps_try_t<bf16>(X, Wf, bias, Y, nullptr, nullptr, nullptr, F, Hi, Wi, Cin, Cout, st);

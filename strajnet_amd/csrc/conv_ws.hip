@@ -456,9 +456,7 @@ static bool ws2_launch_t(const void* X, const void* Wf, const float* bias, void*
 }
 template <typename T, int KS, int NF>
 static bool ws2_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, hipStream_t st) {
-  static int guarded = -1;
-  if (guarded < 0) { const char* e = getenv("STJ_WS2_GUARDED"); guarded = e && atoi(e); }
-  if (!guarded && Hi % WS_TH == 0 && Wi % WS_TW == 0 && Cout % (NF * 16) == 0)      // whole tiles: straight-line movers
+  if (Hi % WS_TH == 0 && Wi % WS_TW == 0 && Cout % (NF * 16) == 0)      // whole tiles: straight-line movers (ragged ones: the guarded form)
     return ws2_launch_t<T, KS, NF, true>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
   return ws2_launch_t<T, KS, NF, false>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
 }
@@ -829,16 +827,11 @@ template <int CW>
 static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* dbias, int db_parts, int F, int Hi, int Wi, int Cin, int Cout, int wg_budget, hipStream_t st) {
   constexpr int CR = 128 / CW;
   const long long nchunks = (long long)F * (Hi / CR) * (Wi / CW);
-  static int v4 = -1;
-  if (v4 < 0) { const char* e = getenv("STJ_WGRAD_V4"); v4 = e ? atoi(e) : 1; }
-  // (the two large layers only: at 32 x 32 and below a strip has too few chunks to amortise a 512-thread workgroup: 149 vs 113 us)
-  if (v4 && Hi % (256 / CW) == 0 && nchunks >= 2048) {
-    if (v4 != 3) {       // 128-pixel chunks (256: register-staged prefetch spills)
-      if (Cout <= 48 && Cin <= 96) return wgrad_tr4_launch<3, 6, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, 1, wg_budget, st);
-      return wgrad_tr4_launch<4, 4, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, ((Cout + 63) / 64) * ((Cin + 63) / 64), wg_budget, st);
-    }
-    if (Cout <= 48 && Cin <= 96) return wgrad_tr4_launch<3, 6, CW, 256>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, 1, wg_budget, st);
-    return wgrad_tr4_launch<4, 4, CW, 256>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, ((Cout + 63) / 64) * ((Cin + 63) / 64), wg_budget, st);
+  // (the two large layers only: at 32 x 32 and below a strip has too few chunks to amortise a 512-thread workgroup: 149 vs 113 us;
+  //  128-pixel chunks: with 256 the register-staged prefetch spills)
+  if (Hi % (256 / CW) == 0 && nchunks >= 2048) {
+    if (Cout <= 48 && Cin <= 96) return wgrad_tr4_launch<3, 6, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, 1, wg_budget, st);
+    return wgrad_tr4_launch<4, 4, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, ((Cout + 63) / 64) * ((Cin + 63) / 64), wg_budget, st);
   }
   if (Cout <= 48 && Cin <= 96) {
     int strips = (int)min(nchunks, (long long)256);     // 128 and 512 measured within noise / slower
@@ -891,88 +884,6 @@ __device__ __forceinline__ void oc_decode(int i, int tiles_x, int tiles_y, int F
   const int b = s2 / tiles_y;
   f = time_outer ? t * inner + b : b * inner + t;
 }
-template <typename T, int C>
-__global__ __launch_bounds__(256) void outconv_fwd_mfma_kernel(const T* __restrict__ X, const float* __restrict__ W,
-                                                               const float* __restrict__ bias, float* __restrict__ Y, int F, int Hh,
-                                                               int Ww, int Tn, long long y_bs, long long y_ts, long long y_ps) {
-  static_assert(C == 48, "specialised for 48 input channels (32 + 16)");
-  constexpr int LDH = C + 32;                      // 160-byte pixels: conflict-free b128 fragment reads
-  constexpr int CPP = C / 8, NCH = (OCM_H * OCM_H * CPP + 255) / 256;
-  __shared__ __attribute__((aligned(16))) T halo[OCM_H * OCM_H * LDH + 64];   // pads + tail stay zero (read by the padded 2nd k-step)
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
-  // stationary weights: row m = ln is output channel o (only o < 2 non-zero)
-  s16x8 a32[9];
-  s16x8 a16[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    float v[8], u[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = ln < 2 ? W[(t * C + 8 * g + j) * 2 + ln] : 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) u[j] = (ln < 2 && g < 2) ? W[(t * C + 32 + 8 * g + j) * 2 + ln] : 0.f;   // channels 32..47, rest zero
-    const uint32_t p0 = pack2<T>(v[0], v[1]), p1 = pack2<T>(v[2], v[3]), p2 = pack2<T>(v[4], v[5]), p3 = pack2<T>(v[6], v[7]);
-    a32[t] = __builtin_bit_cast(s16x8, make_uint4(p0, p1, p2, p3));
-    a16[t] = __builtin_bit_cast(s16x8, make_uint4(pack2<T>(u[0], u[1]), pack2<T>(u[2], u[3]), pack2<T>(u[4], u[5]), pack2<T>(u[6], u[7])));
-  }
-  const float b0 = bias[0], b1 = bias[1];
-  const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T, ntiles = F * tiles_x * tiles_y;
-  uint4 pre[NCH];
-  auto prefetch = [&](int tile) {
-    int tx, ty, f;
-    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
-    const T* Xf = X + (long long)f * Hh * Ww * C;
-#pragma unroll
-    for (int u = 0; u < NCH; ++u) {
-      const int q = tid + u * 256;
-      const int px = q / CPP, ch = (q % CPP) * 8;
-      const int gy = ty * OCM_T + px / OCM_H - 1, gx = tx * OCM_T + px % OCM_H - 1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (q < OCM_H * OCM_H * CPP && gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) v = *reinterpret_cast<const uint4*>(Xf + ((long long)gy * Ww + gx) * C + ch);
-      pre[u] = v;
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int u = 0; u < NCH; ++u) {
-      const int q = tid + u * 256;
-      if (q < OCM_H * OCM_H * CPP) *reinterpret_cast<uint4*>(halo + (q / CPP) * LDH + (q % CPP) * 8) = pre[u];
-    }
-  };
-  for (int i = tid; i < OCM_H * OCM_H * LDH + 64; i += 256) halo[i].v = 0;
-  __syncthreads();
-  int tile = blockIdx.x;
-  if (tile < ntiles) { prefetch(tile); commit(); }
-  __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int next = tile + gridDim.x;
-    if (next < ntiles) prefetch(next);
-    int tx, ty, f;
-    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
-    const int bb = f / Tn, tt = f % Tn;
-    float* Yb = Y + bb * y_bs + tt * y_ts;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = 4 * w + rr;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const T* hp = halo + ((row + t / 3) * OCM_H + ln + t % 3) * LDH;
-        const s16x8 x32 = *reinterpret_cast<const s16x8*>(hp + 8 * g);
-        const s16x8 x16 = *reinterpret_cast<const s16x8*>(hp + 32 + 8 * g);
-        acc = Mma<T>::mma(a32[t], x32, acc);
-        acc = Mma<T>::mma(a16[t], x16, acc);
-      }
-      if (g == 0) {
-        float* dst = Yb + ((long long)(ty * OCM_T + row) * Ww + tx * OCM_T + ln) * y_ps;
-        *reinterpret_cast<float2*>(dst) = make_float2(acc[0] + b0, acc[1] + b1);
-      }
-    }
-    __syncthreads();
-    if (next < ntiles) commit();
-    __syncthreads();
-  }
-}
-
 // v2 of the forward head (round 2).  The kernel above reads one LDS fragment pair per (output row, tap): 72 ds_read_b128 and 72
 // MFMAs per wave and tile, of which 14 of 16 MFMA rows multiply zeros -- 288 KB of LDS reads per 31 KB tile, and LDS, not HBM, set its
 // pace (2.2 us per tile and CU where the fragment reads alone need 1 us; profiles/r02_c_pmc_step.txt: 51 % of HBM peak).  Here the
@@ -1225,158 +1136,6 @@ bool outconv_pair_fwd_try(const void* X0, const void* X1, const float* W0, const
 // partials leave as plain stores into a caller-provided workspace [blocks][866] and a small second kernel sums them.
 #define OCB_PART (9 * 48 * 2 + 2)
 #define OCB_MAXBLK 768
-template <int C>
-__global__ __launch_bounds__(256, 3) void outconv_bwd_mfma_kernel(const bf16* __restrict__ X, const float* __restrict__ W,
-                                                                  const float* __restrict__ dY, bf16* __restrict__ dX,
-                                                                  float* __restrict__ part, int F, int Hh, int Ww, int Tn,
-                                                                  long long y_bs, long long y_ts, long long y_ps, int elu_in) {
-  static_assert(C == 48, "specialised for 48 channels");
-  constexpr int LDH = C + 8;
-  constexpr int CPP = C / 8, NCH = (OCM_H * OCM_H * CPP + 255) / 256;
-  constexpr int NDY = (OCM_H * OCM_H + 255) / 256;
-  constexpr int NACC = 7;                          // ceil(27 / 4) accumulators per wave
-  __shared__ __attribute__((aligned(16))) bf16 halo[OCM_H * OCM_H * LDH];
-  __shared__ __attribute__((aligned(16))) float dys[OCM_H * OCM_H * 2];
-  __shared__ float dbs[2];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ln = lane & 15;
-  // dX weights: A[m = c][k = (tap, o)], k = 2*tap + o < 18 ; lane row c = mf*16 + ln, k = 8g + j
-  s16x8 ax[3];
-#pragma unroll
-  for (int mf = 0; mf < 3; ++mf) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; v[j] = k < 18 ? W[((k >> 1) * C + mf * 16 + ln) * 2 + (k & 1)] : 0.f; }
-    ax[mf] = __builtin_bit_cast(s16x8, make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])));
-  }
-  // dW accumulators of this wave: combo c = 7w + i  ->  tap t = c / 3, channel block mf = c % 3
-  f32x4 wacc[NACC];
-  int aoff[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) {
-    wacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int c = min(NACC * w + i, 26), t = c / 3, mf = c % 3;
-    aoff[i] = ((t / 3) * OCM_H + t % 3) * LDH + mf * 16;
-  }
-  float db0 = 0.f, db1 = 0.f;
-  if (tid < 2) dbs[tid] = 0.f;
-  const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T, ntiles = F * tiles_x * tiles_y;
-  uint4 pre[NCH];
-  float2 pdy[NDY];
-  auto prefetch = [&](int tile) {
-    int tx, ty, f;
-    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
-    const bf16* Xf = X + (long long)f * Hh * Ww * C;
-    const float* dYf = dY + (f / Tn) * y_bs + (f % Tn) * y_ts;
-#pragma unroll
-    for (int u = 0; u < NCH; ++u) {
-      const int q = tid + u * 256;
-      const int px = q / CPP, ch = (q % CPP) * 8;
-      const int gy = ty * OCM_T + px / OCM_H - 1, gx = tx * OCM_T + px % OCM_H - 1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (q < OCM_H * OCM_H * CPP && gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) v = *reinterpret_cast<const uint4*>(Xf + ((long long)gy * Ww + gx) * C + ch);
-      pre[u] = v;
-    }
-#pragma unroll
-    for (int u = 0; u < NDY; ++u) {
-      const int q = tid + u * 256;
-      const int gy = ty * OCM_T + q / OCM_H - 1, gx = tx * OCM_T + q % OCM_H - 1;
-      float2 v = make_float2(0.f, 0.f);
-      if (q < OCM_H * OCM_H && gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) v = *reinterpret_cast<const float2*>(dYf + ((long long)gy * Ww + gx) * y_ps);
-      pdy[u] = v;
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int u = 0; u < NCH; ++u) {
-      const int q = tid + u * 256;
-      if (q < OCM_H * OCM_H * CPP) *reinterpret_cast<uint4*>(halo + (q / CPP) * LDH + (q % CPP) * 8) = pre[u];
-    }
-#pragma unroll
-    for (int u = 0; u < NDY; ++u) {
-      const int q = tid + u * 256;
-      if (q < OCM_H * OCM_H) *reinterpret_cast<float2*>(dys + 2 * q) = pdy[u];
-    }
-  };
-  int tile = blockIdx.x;
-  if (tile < ntiles) { prefetch(tile); commit(); }
-  __syncthreads();
-  const int kpx = 8 * (g & 1) + (ln >> 2), kch = 4 * (ln & 3);
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int next = tile + gridDim.x;
-    if (next < ntiles) prefetch(next);
-    int tx, ty, f;
-    oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
-    bf16* dXf = dX + (long long)f * Hh * Ww * C;
-    // ---- dX rows 4w .. 4w+3 ----
-#pragma unroll 1
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = 4 * w + rr;
-      // B[k = 2*tap + o][n = pixel ln] = dY[(row,ln) - off(tap)][o]; this lane supplies taps 4g .. 4g+3
-      float2 d[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int t = 4 * g + j;
-        d[j] = t < 9 ? *reinterpret_cast<const float2*>(dys + 2 * ((row + 2 - t / 3) * OCM_H + ln + 2 - t % 3)) : make_float2(0.f, 0.f);
-      }
-      const s16x8 bx = __builtin_bit_cast(s16x8, make_uint4(pack2bf(d[0].x, d[0].y), pack2bf(d[1].x, d[1].y), pack2bf(d[2].x, d[2].y), pack2bf(d[3].x, d[3].y)));
-      bf16* orow = dXf + ((long long)(ty * OCM_T + row) * Ww + tx * OCM_T + ln) * C + 4 * g;
-#pragma unroll
-      for (int mf = 0; mf < 3; ++mf) {
-        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax[mf]), __builtin_bit_cast(bf16x8_t, bx), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        if (elu_in) {        // X is the ELU output of the producing conv: fold ELU'(x) = (x > 0 ? 1 : x + 1) into the input gradient
-          const uint2 xv = *reinterpret_cast<const uint2*>(halo + ((row + 1) * OCM_H + ln + 1) * LDH + mf * 16 + 4 * g);
-          const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
-          const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
-          acc[0] *= x0 > 0.f ? 1.f : x0 + 1.f; acc[1] *= x1 > 0.f ? 1.f : x1 + 1.f;
-          acc[2] *= x2 > 0.f ? 1.f : x2 + 1.f; acc[3] *= x3 > 0.f ? 1.f : x3 + 1.f;
-        }
-        // the three stores of a row fill whole 96-byte pixels back to back; L2 merges them into full lines
-        *reinterpret_cast<uint2*>(orow + mf * 16) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
-      }
-    }
-    // ---- dW: k-step kk = tile rows 2kk, 2kk+1 (32 pixels); every wave walks all 8 k-steps for its own accumulators ----
-#pragma unroll 1
-    for (int kk = 0; kk < OCM_T / 2; ++kk) {
-      // B[k = pixel][n = o]: lane (g, ln) supplies pixels 8g .. 8g+7 of the k-step for output channel ln (0 beyond the 2 real ones)
-      const float* dp = dys + 2 * ((2 * kk + (g >> 1) + 1) * OCM_H + 8 * (g & 1) + 1) + (ln & 1);
-      float dv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dv[j] = ln < 2 ? dp[2 * j] : 0.f;
-      const s16x8 bw = __builtin_bit_cast(s16x8, make_uint4(pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3]), pack2bf(dv[4], dv[5]), pack2bf(dv[6], dv[7])));
-      const bf16* ap = halo + ((2 * kk + (g >> 1)) * OCM_H + kpx) * LDH + kch;
-#pragma unroll
-      for (int i = 0; i < NACC; ++i) {
-        const s16x8 aw = tr_frag(ap + aoff[i], ap + aoff[i] + 4 * LDH);
-        wacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw), __builtin_bit_cast(bf16x8_t, bw), wacc[i], 0, 0, 0);
-      }
-    }
-    {
-      const int py = tid / OCM_T, px = tid % OCM_T;
-      const float2 v = *reinterpret_cast<const float2*>(dys + 2 * ((py + 1) * OCM_H + px + 1));
-      db0 += v.x; db1 += v.y;
-    }
-    __syncthreads();
-    if (next < ntiles) commit();
-    __syncthreads();
-  }
-  // partials: D[m = c][n = o] -> lanes with ln < 2 hold dW[t][mf*16 + 4g + r][ln]
-  float* mypart = part + (long long)blockIdx.x * OCB_PART;
-  if (ln < 2) {
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-      const int c = NACC * w + i, t = c / 3, mf = c % 3;
-      if (c < 27) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mypart[(t * C + mf * 16 + 4 * g + r) * 2 + ln] = wacc[i][r];
-      }
-    }
-  }
-  db0 = wave_sum(db0); db1 = wave_sum(db1);
-  if (lane == 0) { atomicAdd(&dbs[0], db0); atomicAdd(&dbs[1], db1); }
-  __syncthreads();
-  if (tid < 2) mypart[9 * C * 2 + tid] = dbs[tid];
-}
-
 // Backward, v2 (round 2).  The weight gradient is re-associated: dW[t][c][o] = sum_p X[p + off(t)][c] dY[p][o] = sum_p' X[p'][c] dY[p' - off(t)][o],
 // p' over the tile's OWN pixels -- so the taps move into the N dimension of the MFMA (B[k = pixel][n = (tap, o)], 18 of 32 columns, built
 // from the 18 x 18 dY halo that the input gradient needs anyway) and the A operand is the UNSHIFTED X tile, read once per k-step for all
@@ -1570,21 +1329,12 @@ bool outconv_fwd_mfma_try(const void* X, const float* W, const float* bias, floa
                           long long y_bs, long long y_ts, long long y_ps, int dtype, hipStream_t st) {
   if (C != 48 || Hh % OCM_T || Ww % OCM_T || (y_ps & 1) || (((uintptr_t)Y) & 7)) return false;
   const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
-  static int ver = -1;
-  if (ver < 0) { const char* e = getenv("STJ_OUTCONV_V"); ver = e ? atoi(e) : 2; }
-  if (ver == 2) {
-    const int dbg = 0, nbm = 768;
-    const int nb = min(ntiles, nbm);
-    if (dtype == STJ_F16)
-      hipLaunchKernelGGL((outconv_fwd_mfma2_kernel<f16, 48>), dim3(nb), dim3(256), 0, st, (const f16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps, dbg);
-    else
-      hipLaunchKernelGGL((outconv_fwd_mfma2_kernel<bf16, 48>), dim3(nb), dim3(256), 0, st, (const bf16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps, dbg);
-    return true;
-  }
+  const int dbg = 0, nbm = 768;
+  const int nb = min(ntiles, nbm);
   if (dtype == STJ_F16)
-    hipLaunchKernelGGL((outconv_fwd_mfma_kernel<f16, 48>), dim3(min(ntiles, 1024)), dim3(256), 0, st, (const f16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
+    hipLaunchKernelGGL((outconv_fwd_mfma2_kernel<f16, 48>), dim3(nb), dim3(256), 0, st, (const f16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps, dbg);
   else
-    hipLaunchKernelGGL((outconv_fwd_mfma_kernel<bf16, 48>), dim3(min(ntiles, 1024)), dim3(256), 0, st, (const bf16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps);
+    hipLaunchKernelGGL((outconv_fwd_mfma2_kernel<bf16, 48>), dim3(nb), dim3(256), 0, st, (const bf16*)X, W, bias, Y, F, Hh, Ww, Tn, y_bs, y_ts, y_ps, dbg);
   return true;
 }
 long long outconv_bwd_ws_bytes() { return (long long)OCB_MAXBLK * OCB_PART * sizeof(float); }
@@ -1594,13 +1344,7 @@ bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* 
   if (!ws || ws_bytes < outconv_bwd_ws_bytes()) return false;
   const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
   const int nblk = min(ntiles, OCB_MAXBLK);          // 3 resident blocks per CU (168 VGPRs, 39 KB LDS): measured best of 512/768/1024
-  static int ver = -1;
-  if (ver < 0) { const char* e = getenv("STJ_OUTCONV_BWD_V"); ver = e ? atoi(e) : 2; }
-  if (ver == 2)
-    hipLaunchKernelGGL(outconv_bwd_mfma2_kernel<48>, dim3(nblk), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, (float*)ws, F, Hh, Ww, Tn,
-                       y_bs, y_ts, y_ps, elu_in);
-  else
-  hipLaunchKernelGGL(outconv_bwd_mfma_kernel<48>, dim3(nblk), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, (float*)ws, F, Hh, Ww, Tn,
+  hipLaunchKernelGGL(outconv_bwd_mfma2_kernel<48>, dim3(nblk), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, (float*)ws, F, Hh, Ww, Tn,
                      y_bs, y_ts, y_ps, elu_in);
   hipLaunchKernelGGL(outconv_bwd_reduce_kernel, dim3((OCB_PART + 63) / 64, 16), dim3(64), 0, st, (const float*)ws, nblk, dW, db);
   return true;
@@ -2202,14 +1946,11 @@ static bool dgrad_ws_launch(const void* dP, const void* Wd, void* dX, const void
 }
 bool upconv_dgrad_ws_try(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   if (Cout % 8 || Cin % 8) return false;
-  static int v2 = -1;
-  if (v2 < 0) { const char* e = getenv("STJ_DGRAD_WS2"); v2 = e ? atoi(e) : 1; }
-  if (Cout == 48 && Cin == 96 && v2) {
-    if (v2 != 2 && Hi % WS_TH == 0 && Wi % WS_TW == 0)      // whole tiles: straight-line movers (STJ_DGRAD_WS2=2: the guarded ones)
+  if (Cout == 48 && Cin == 96) {
+    if (Hi % WS_TH == 0 && Wi % WS_TW == 0)      // whole tiles: straight-line movers (ragged ones: the guarded form)
       return Xelu ? dgrad_ws2_launch<true, true>(dP, Wd, dX, Xelu, F, Hi, Wi, st) : dgrad_ws2_launch<false, true>(dP, Wd, dX, Xelu, F, Hi, Wi, st);
     return Xelu ? dgrad_ws2_launch<true, false>(dP, Wd, dX, Xelu, F, Hi, Wi, st) : dgrad_ws2_launch<false, false>(dP, Wd, dX, Xelu, F, Hi, Wi, st);
   }
-  if (Cout == 48 && Cin == 96) return dgrad_ws_launch<2, 6, 48>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
   if (Cout == 96 && Cin == 128) return dgrad_ws_launch<3, 4, 96>(dP, Wd, dX, Xelu, F, Hi, Wi, Cin, Cout, st);
   return false;
 }

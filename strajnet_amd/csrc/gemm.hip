@@ -640,9 +640,7 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, GroupState* gs,
     g_rec_dtype = dtype;
     g_grp.p[i] = p;
     g_grp.gx[i] = (int)tiles; g_grp.gy[i] = (int)gy;
-    static int deepg = -1;
-    if (deepg < 0) { const char* e = getenv("STJ_GEMM_DEEPK"); deepg = e ? atoi(e) : 2; }
-    const bool deep = sizeof(T) == 2 && deepg && !p.accumulate && p.splitk == 1 && p.K > 128 && p.vecA && p.vecB && p.K % 8 == 0 && p.M % 8 == 0 &&
+    const bool deep = sizeof(T) == 2 && !p.accumulate && p.splitk == 1 && p.K > 128 && p.vecA && p.vecB && p.K % 8 == 0 && p.M % 8 == 0 &&
                       p.N % 8 == 0;
     g_grp.cfg[i] = (deep ? 8 : 0) + (small ? 4 : 0) + (ta ? 2 : 0) + (tb ? 1 : 0);
     g_grp.start[i] = g_rec_blocks;
@@ -661,7 +659,7 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, GroupState* gs,
   // Tile choice.  The hot-path GEMMs are skinny (K <= 1536, mostly 96..384) and latency / memory-parallelism bound, not
   // MFMA bound: measured on every Dense shape of the model, 64x64 tiles (4x the workgroups in flight) beat 128x128 by
   // 1.3-1.8x (profiles/r01_c_gemm_tiles.txt), so 64x64 is the default; 128x128 only pays for genuinely large problems.
-  int cfg;   // 0: 128x128, 1: 128x64 (narrow N), 2: 64x64
+  int cfg;   // 0: 128x128, 2: 64x64, 3: 32x32
   const double flops = 2.0 * p.M * p.N * (double)p.K * nb;
   if (p.N > 64 && p.M > 64 && tiles128 >= 1024 && p.K >= 1024 && flops > 2e11) cfg = 0;
   else cfg = 2;
@@ -673,8 +671,7 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, GroupState* gs,
   // shape but two (e.g. [192x576] over 8192 rows 32.8 vs 18.8 us, [96x384] over 32768 rows 31.8 vs 28.7 us; 128x128: 38-47 us), 828
   // vs 860 scenes/s end to end: these launches are bound by how many workgroups are in flight, not by what one of them does.
   if (p.splitk == 0) {            // auto split-K (accumulating GEMMs only): aim at ~2 blocks per CU
-    auto ntl = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * nb; };
-    const long long tiles = cfg == 0 ? tiles128 : (cfg == 1 ? ntl(128, 64) : (cfg == 4 ? ntl(96, 128) : (cfg == 5 ? ntl(128, 96) : (cfg == 6 ? ntl(96, 96) : tiles64))));
+    const long long tiles = cfg == 0 ? tiles128 : tiles64;
     const int tgt = 768, cap = 96;      // (swept repeatedly: within noise around these)
     long long s = (tgt + tiles - 1) / tiles;
     if (s > cap) s = cap;                 // bound same-address atomic contention
@@ -685,9 +682,7 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, GroupState* gs,
     p.splitk = (int)s;
   }
   if constexpr (sizeof(T) == 2) {
-    static int deep = -1;
-    if (deep < 0) { const char* e = getenv("STJ_GEMM_DEEPK"); deep = e ? atoi(e) : 2; }
-    if (deep && (deep >= 2 || (!p.accumulate && p.splitk == 1)) && (cfg == 2 || cfg == 3) && p.K > 128 && p.vecA && p.vecB && p.K % 8 == 0 && p.M % 8 == 0 && p.N % 8 == 0) {
+    if ((cfg == 2 || cfg == 3) && p.K > 128 && p.vecA && p.vecB && p.K % 8 == 0 && p.M % 8 == 0 && p.N % 8 == 0) {
       dim3 grid(cfg == 2 ? (unsigned)(((p.M + 63) / 64) * ((p.N + 63) / 64)) : (unsigned)(((p.M + 31) / 32) * ((p.N + 31) / 32)), p.nb1 * p.nb2 * p.splitk), blk(256);
 #define STJ_DEEP(BMN) \
       do { \
@@ -701,12 +696,8 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, GroupState* gs,
       return stj_check_launch("stj_gemm(deep k)");
     }
   }
-  if (cfg == 4) launch_tile<T, 96, 128, 2, 2>(p, ta, tb, st);
-  else if (cfg == 5) launch_tile<T, 128, 96, 2, 2>(p, ta, tb, st);
-  else if (cfg == 6) launch_tile<T, 96, 96, 2, 2>(p, ta, tb, st);
-  else if (cfg == 3) launch_tile<T, 32, 32, 2, 2>(p, ta, tb, st);
+  if (cfg == 3) launch_tile<T, 32, 32, 2, 2>(p, ta, tb, st);
   else if (cfg == 0) launch_tile<T, 128, 128, 2, 2>(p, ta, tb, st);
-  else if (cfg == 1) launch_tile<T, 128, 64, 4, 1>(p, ta, tb, st);
   else launch_tile<T, 64, 64, 2, 2>(p, ta, tb, st);
   return stj_check_launch("stj_gemm");
 }

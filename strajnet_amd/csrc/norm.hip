@@ -338,8 +338,7 @@ static int ln_launch(bool fwd, const void* x, const float* gamma, const float* b
   {
     // v2 path: whole 16-byte chunks, aligned rows, gather quadrants a multiple of the chunk, parameter sets 16-byte aligned
     constexpr int VN = Vec<T>::N;
-    static int v2 = -1;
-    if (v2 < 0) { const char* e = getenv("STJ_LN_V1"); v2 = !(e && atoi(e)); }
+    const bool v2 = true;          // (the scalar-row kernels below serve the widths / alignments this form does not take)
     const int chunks = C / VN;
     const bool al = ((uintptr_t)x % 16 == 0) && (!fwd || ((uintptr_t)y % 16 == 0 && (uintptr_t)dres % 16 == 0)) && (fwd || ((uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)dres % 16 == 0)) &&
                     ((uintptr_t)gamma % 16 == 0) && (fwd ? (uintptr_t)beta % 16 == 0 : true) && (G.gstride % 4 == 0);

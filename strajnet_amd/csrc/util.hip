@@ -162,42 +162,6 @@ __global__ __launch_bounds__(256) void elu_res_bwd_kernel(const T* __restrict__ 
     st16(dpre + i * VN, g);
   }
 }
-// y1 = y + r1 ; y2 = y1 + r2 (optional): the decoder's skip sums (modules.py:750-765) in ONE pass when they are not in the up-conv's epilogue
-template <typename T>
-__global__ __launch_bounds__(256) void skip_add_kernel(const T* __restrict__ y, const T* __restrict__ r1, const T* __restrict__ r2,
-                                                       T* __restrict__ y1, T* __restrict__ y2, long long n) {
-  constexpr int VN = Vec<T>::N;
-  const long long nv = n / VN;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += gridDim.x * 256ll) {
-    float a[VN], b[VN];
-    ld16(y + i * VN, a);
-    ld16(r1 + i * VN, b);
-#pragma unroll
-    for (int e = 0; e < VN; ++e) a[e] += b[e];
-    __attribute__((aligned(16))) T rounded[VN];
-    st16(rounded, a);
-    *reinterpret_cast<uint4*>(y1 + i * VN) = *reinterpret_cast<const uint4*>(rounded);
-    if (y2) {
-      ld16(rounded, a);                              // the rounded first sum, as a separate add would read it
-      ld16(r2 + i * VN, b);
-#pragma unroll
-      for (int e = 0; e < VN; ++e) a[e] += b[e];
-      st16(y2 + i * VN, a);
-    }
-  }
-}
-extern "C" int stj_skip_add(const void* y, const void* r1, const void* r2, void* y1, void* y2, long long n, int dtype, hipStream_t stream) {
-  if (n <= 0) return STJ_OK;
-  const int vn = dtype == STJ_F32 ? 4 : 8;
-  if (n % vn) { stj_set_error("stj_skip_add: n must be a multiple of %d", vn); return STJ_EINVAL; }
-  if ((r2 == nullptr) != (y2 == nullptr)) { stj_set_error("stj_skip_add: r2 and y2 go together"); return STJ_EINVAL; }
-  if (((uintptr_t)y | (uintptr_t)r1 | (uintptr_t)r2 | (uintptr_t)y1 | (uintptr_t)y2) & 15) { stj_set_error("stj_skip_add: pointers must be 16-byte aligned"); return STJ_EINVAL; }
-  const int g = ew_grid(n / vn);
-  if (dtype == STJ_BF16) hipLaunchKernelGGL(skip_add_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)y, (const bf16*)r1, (const bf16*)r2, (bf16*)y1, (bf16*)y2, n);
-  else if (dtype == STJ_F16) hipLaunchKernelGGL(skip_add_kernel<f16>, dim3(g), dim3(256), 0, stream, (const f16*)y, (const f16*)r1, (const f16*)r2, (f16*)y1, (f16*)y2, n);
-  else hipLaunchKernelGGL(skip_add_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)y, (const float*)r1, (const float*)r2, (float*)y1, (float*)y2, n);
-  return stj_check_launch("stj_skip_add");
-}
 extern "C" int stj_elu_res_bwd(const void* dy, const void* dy2, const void* y, const void* r, void* dpre, void* gsum, long long n, int dtype,
                                hipStream_t stream) {
   if (n <= 0) return STJ_OK;

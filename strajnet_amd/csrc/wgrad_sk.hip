@@ -51,7 +51,6 @@ struct Desc {
   Job job[MAXJ];               // [0, n0): X is the narrow operand; [n0, n): dY is (the "swapped" orientation)
   int n0, n, total0, total1;   // units of the two lists
   int g0;                      // workgroups [0, g0) serve list 0, the rest list 1
-  int dbg;                     // measurement only (STJ_WGRAD_SK_DBG): 1 = no LDS reads / MFMAs, 2 = no flush
 };
 static_assert(sizeof(Desc) <= 4096, "kernarg segment");
 
@@ -229,7 +228,6 @@ __device__ __forceinline__ void body(const KL kl, const int u0, const int u1, un
     if (lu < u1) issue();               // refill the slot of unit cu - 1 with unit cu + NS - 1
 
     const uint32_t st = (uint32_t)((cu - u0) % NS) * STAGE;
-    if (!(kl.kd->dbg & 1)) {
     s16x8 an[3], bw[12];
 #pragma unroll
     for (int i = 0; i < 3; ++i) an[i] = read_tr(aN + st + i * 32, aN + st + i * 32 + 16 * LDN * 2);
@@ -243,7 +241,6 @@ __device__ __forceinline__ void body(const KL kl, const int u0, const int u1, un
 #pragma unroll
       for (int j = 0; j < NCS; ++j) csum[j] = frag_sum<T>(csum[j], SWAP ? an[j] : bw[j]);
     }
-    }
     ++ck;
     if (ck == S.k1) {
       // ---- leave the tile: flush.  First drain the DMA queue (the slabs in flight were issued long ago), so that the counted waits
@@ -253,7 +250,6 @@ __device__ __forceinline__ void body(const KL kl, const int u0, const int u1, un
       const int ldc = S.ldc;
       const int vr = SWAP ? S.vw : S.vn, vc = SWAP ? S.vn : S.vw;      // valid D rows / columns
       float* Cl = S.C + (long long)(row0 + 4 * g) * ldc + col0 + p;
-      if (!(kl.kd->dbg & 2))
 #pragma unroll
       for (int a = 0; a < FA; ++a)
 #pragma unroll
@@ -398,7 +394,6 @@ extern "C" int stj_wgrad_group(const stj_wgrad_job* jobs, int njobs, int dtype, 
     if (total[1] == 0) g0 = G;
     if (g0 < 0 || (total[0] > 0 && g0 == 0)) { g0 = total[0] > 0 ? 1 : 0; if (G < g0 + (total[1] > 0 ? 1 : 0)) G = g0 + 1; }
     d.g0 = (int)g0;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("STJ_WGRAD_SK_DBG"); dbg = e ? atoi(e) : 0; } d.dbg = dbg; }
     if (dtype == STJ_BF16) hipLaunchKernelGGL(wsk::wgrad_sk_kernel<bf16>, dim3((unsigned)G), dim3(256), lds, stream, d);
     else hipLaunchKernelGGL(wsk::wgrad_sk_kernel<f16>, dim3((unsigned)G), dim3(256), lds, stream, d);
     int e = stj_check_launch("stj_wgrad_group");

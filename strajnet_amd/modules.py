@@ -224,13 +224,12 @@ class STrajNet:
         self._arena = ops._ZeroArena()    # this model's zeroed scratch (one fill per step)
         self._dctx = None
         self._side = torch.cuda.Stream(self.device) if (self.device.type == 'cuda' and os.environ.get('STJ_NO_SIDE_STREAM') != '1') else None
-        self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and os.environ.get('STJ_NO_SIDE_STREAM2') != '1') else None
+        self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and os.environ.get('STJ_NO_SIDE_STREAM') != '2') else None
         self._streams = (self._side, self._side2)
         self.serial = False              # True: everything on the current stream (per-kernel timing, debugging)
         self.taps = None                 # a dict: call() stores detached float copies of the stage boundaries in it (tools/bf16_attribution.py)
-        # fused Swin-block kernels (csrc/swin_fused.hip); STJ_FUSED_MLP=0 selects the layer-by-layer path (A/B runs, debugging)
-        self.fused_mlp = os.environ.get('STJ_FUSED_MLP', '1') != '0'
-        self.fused_attn = os.environ.get('STJ_FUSED_ATTN', '1') != '0'
+        # fused Swin-block kernels (csrc/swin_fused.hip); STJ_FUSED_SWIN=0 selects the layer-by-layer path (the one the f32 mode's C = 384 stage takes)
+        self.fused_mlp = self.fused_attn = os.environ.get('STJ_FUSED_SWIN', '1') != '0'
         # C = 384 (the 16x16 stage: 2048 rows = 32 row blocks / 32 windows at B = 8) runs the SPLIT variants of the fused kernels --
         # (row block | window) x (slice of the hidden dimension | of the heads) workgroups + a finishing launch -- in the 16-bit modes;
         # the f32 parity mode keeps that stage layer by layer

@@ -174,7 +174,7 @@ def zeros_f32(shape, device):
 _WG = {}
 # bit 0: dense layers, bit 1: up-convs.  Measured (B=8): up-convs on the side stream +1 %; dense layers -9 % (their 768-block
 # split-K kernels crowd the data-gradient chain out of the CUs), so only the up-convs use it by default.
-_WG_MODE = int(os.environ.get('STJ_WGRAD_STREAM', '2'))
+_WG_MODE = 2
 
 
 _SERIAL = False
@@ -337,7 +337,7 @@ class WJob:
              self.sdb[0], self.sdb[1], 0, 0, 0, ACT_NONE, 1.0, self.dt, 1, 1, 0, 1, 0, 0, _GROUP[0], _st())
 
 
-WG_BUDGET = int(os.environ.get('STJ_WGRAD_SK_WGS', '0'))       # workgroups of a grouped weight-gradient launch (0: one per CU)
+WG_BUDGET = 0       # workgroups of a grouped weight-gradient launch (0: one per CU; measured 128 / 192: 2 % / 0.5 % slower end to end)
 _WJ_LAST = [None]
 
 
@@ -442,7 +442,7 @@ def wgrad_queue_flush_point(x):
     return x
 
 
-WGRAD_SK_POINTS = os.environ.get('STJ_WGRAD_SK_POINTS', '1') != '0'
+WGRAD_SK_POINTS = True       # flush at the stage boundaries, not only at the end of the pass (end only: 1.5 % slower end to end)
 
 
 def _splitk(M_out, N_out, Kdim):
@@ -902,7 +902,7 @@ class _SwinAttnHalf(torch.autograd.Function):
         return (dx,) + (None,) * 13
 
 
-FUSED_ATTN_BWD = os.environ.get('STJ_FUSED_ATTN_BWD', '1') != '0'
+FUSED_ATTN_BWD = os.environ.get('STJ_FUSED_SWIN', '1') != '0'       # (STJ_FUSED_SWIN=0: the layer-by-layer Swin block, the form the f32 mode's C = 384 stage takes)
 
 
 def swin_attn_half(x, pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, eps, dctx=None, name=None, p_drop=0.0):
@@ -1714,7 +1714,7 @@ class _WgradFlushPoint(torch.autograd.Function):
 
 
 def wgrad_flush_point(x):
-    """Mark x as the input of the region whose up-conv weight gradients are deferred (no-op without autograd or with STJ_DEFER_UPWG=0).
+    """Mark x as the input of the region whose up-conv weight gradients are deferred (no-op without autograd).
     The region ends at wgrad_defer_end()."""
     _UPWG['on'] = DEFER_UPWG and x.requires_grad and torch.is_grad_enabled()
     _UPWG['items'] = []
@@ -1726,7 +1726,7 @@ def wgrad_defer_end():
     _UPWG['on'] = False
 
 
-DEFER_UPWG = os.environ.get('STJ_DEFER_UPWG', '1') != '0'
+DEFER_UPWG = True
 
 
 class _UpConv(torch.autograd.Function):
@@ -1769,7 +1769,7 @@ class _UpConvAdd(torch.autograd.Function):
     modules.py:750-765.  The ELU output itself is never stored; backward recovers ELU' from y - r1 (stj_elu_res_bwd), which also adds
     the two incoming gradients when there are two outputs."""
     @staticmethod
-    def forward(ctx, x, r1, r2, w_master, b_master, pw, pb, prep, in_epilogue=True):
+    def forward(ctx, x, r1, r2, w_master, b_master, pw, pb, prep):
         _req_cuda(x, r1)
         x, r1 = x.contiguous(), r1.contiguous()
         F_, Hi, Wi, Cin = x.shape
@@ -1781,14 +1781,8 @@ class _UpConvAdd(torch.autograd.Function):
         if r2 is not None:
             r2 = r2.contiguous()
             y2 = torch.empty_like(y)
-        if in_epilogue:
-            call('stj_upconv_fwd_res', _p(x), _p(wf), _p(pb.master), _p(y), _p(r1), _p(y2), _p(r2), F_, Hi, Wi, Cin, Cout, dt, _st())
-            ctx.save_for_backward(x, y, r1, wd)
-        else:       # the up-conv stores its ELU output (kept for ELU'), the sums are one pass of their own
-            ye = torch.empty_like(y)
-            call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(ye), F_, Hi, Wi, Cin, Cout, ACT_ELU, dt, _st())
-            call('stj_skip_add', _p(ye), _p(r1), _p(r2), _p(y), _p(y2), y.numel(), dt, _st())
-            ctx.save_for_backward(x, ye, None, wd)
+        call('stj_upconv_fwd_res', _p(x), _p(wf), _p(pb.master), _p(y), _p(r1), _p(y2), _p(r2), F_, Hi, Wi, Cin, Cout, dt, _st())
+        ctx.save_for_backward(x, y, r1, wd)
         ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
         ctx.x_is_elu_out, ctx.two = False, r2 is not None
         ctx.defer = _UPWG['on']
@@ -1807,15 +1801,16 @@ class _UpConvAdd(torch.autograd.Function):
         call('stj_elu_res_bwd', _p(dy), _p(dy2), _p(y), _p(r1), _p(dpre), _p(gsum), dy.numel(), dt, _st())
         dx = _upconv_backward_tail(ctx, x, dpre, wd, ctx.needs_input_grad[0])
         dr1 = gsum if gsum is not None else dy
-        return dx, dr1, (dy2 if ctx.two else None), None, None, None, None, None, None
+        return dx, dr1, (dy2 if ctx.two else None), None, None, None, None, None
 
 
-# (FUSED_SKIP = 2 in training recovers ELU' from y - r1 in 16-bit storage: for |ELU output| below the rounding step of y the
-# branch can flip -- one more reason it is not the training default.)
-# 0: never; 1 (default): in inference only; 2: always; 3: like 1, and in training the sums as one separate pass (see upconv_add).  Measured at B=8 bf16: the training step is 1.2 % SLOWER with the sums in the
-# epilogue (901 vs 912 scenes/s: a workgroup owns 32 of the 128 couts, so the skip operands are read and the sums written in 64-byte
-# pieces, 138 vs 92 us for the 192 -> 128 layer, while the separate adds stream whole lines at 5 TB/s), the B=32 fp16 forward 1.4 % faster.
-FUSED_SKIP = int(os.environ.get('STJ_FUSED_SKIP', '1'))
+# The skip sums ride in the up-conv epilogue in INFERENCE only.  Measured at B=8 bf16: the training step is 1.2 % SLOWER with them there
+# (901 vs 912 scenes/s: a workgroup owns 32 of the 128 couts, so the skip operands are read and the sums written in 64-byte pieces, 138 vs
+# 92 us for the 192 -> 128 layer, while the separate adds stream whole lines at 5 TB/s; and as one separate fused pass 0.5 % slower), the
+# B=32 fp16 forward 1.4 % faster.
+
+
+FUSED_SKIP_TRAIN = False       # (tests flip it: the fused form's backward, stj_elu_res_bwd, is the one a fine-tuning caller of the inference graph gets)
 
 
 def upconv_add(x, pw, pb, r1, r2=None, prep=None):
@@ -1823,14 +1818,8 @@ def upconv_add(x, pw, pb, r1, r2=None, prep=None):
     16-bit wide layers (Cin = 192, 384); otherwise the up-conv followed by elementwise adds."""
     Cin, Cout = pw.master.shape[2], pw.master.shape[3]
     oshape = (x.shape[0], 2 * x.shape[1], 2 * x.shape[2], Cout)
-    if (FUSED_SKIP == 2 or (FUSED_SKIP == 1 and not torch.is_grad_enabled())) and x.dtype != torch.float32 and Cin > 128 and Cin % 32 == 0 and Cout % 32 == 0 and os.environ.get('STJ_NO_PS') != '1' \
-            and os.environ.get('STJ_NO_WS') != '1':
+    if (FUSED_SKIP_TRAIN or not torch.is_grad_enabled()) and x.dtype != torch.float32 and Cin > 128 and Cin % 32 == 0 and Cout % 32 == 0 and os.environ.get('STJ_NO_WS') != '1':
         return _UpConvAdd.apply(x, r1.view(oshape), None if r2 is None else r2.view(oshape), pw.master, pb.master, pw, pb, prep)
-    if FUSED_SKIP == 3 and torch.is_grad_enabled() and (oshape[1] * oshape[2] * Cout) % 8 == 0:
-        # the sums as ONE pass over the stored ELU output (stj_skip_add), and in the backward the sum of the two incoming gradients
-        # together with ELU' (stj_elu_res_bwd) -- instead of two adds, an autograd accumulation pass and the ELU' pass: 4 launches and
-        # 0.2 GB of traffic less per step, but measured 0.5 % SLOWER end to end (1036 vs 1043 scenes/s), so not the default
-        return _UpConvAdd.apply(x, r1.view(oshape), None if r2 is None else r2.view(oshape), pw.master, pb.master, pw, pb, prep, False)
     y = upconv(x, pw, pb, prep=prep)
     y = y + r1.view(y.shape)
     return y if r2 is None else (y, y + r2.view(y.shape))
@@ -1859,7 +1848,7 @@ def _outconv_workspace(device):
     return _workspace(device, 'stj_outconv_bwd_workspace_bytes')
 
 
-PAIR_OUTCONV = os.environ.get('STJ_PAIR_OUTCONV', '1') != '0' and os.environ.get('STJ_NO_WS') != '1'     # (the paired kernel belongs to the MFMA / weight-stationary family)
+PAIR_OUTCONV = os.environ.get('STJ_NO_WS') != '1'     # (the paired kernel belongs to the MFMA / weight-stationary family)
 
 
 class _OutConvPair(torch.autograd.Function):

@@ -455,13 +455,13 @@ def test_odd_batch_b3(dtype):
     ref = np_ref.strajnet_forward(w, CFG128, x['ogm'], x['map_img'], x['obs'], x['occ'], x['flow'])
     err = np.abs(y.float().cpu().numpy() - ref).max()
     _report(f'fwd {dtype} B=3 128x128: max-abs err {err:.3e}')
-    assert err < (ABS_TOL_F32 if dtype == torch.float32 else 1.0)
+    assert err < (ABS_TOL_F32 if dtype == torch.float32 else 0.25)        # bf16: 2x the measured 0.115
     # scene 1 alone == scene 1 inside the batch (no cross-sample op anywhere; deterministic kernels in forward)
     assert torch.equal(y[1:2], y1)
 
 
 def test_bf16_mode_error_report():
-    """bf16-storage throughput mode: measured error vs the f64 oracle (reported, bounded loosely)."""
+    """bf16-storage throughput mode: measured error vs the f64 oracle (reported; bounded at twice the measured values)."""
     from oracle import np_ref
     model, w, x, xt = _setup(CFG128, 2, torch.bfloat16)
     with torch.no_grad():
@@ -473,7 +473,8 @@ def test_bf16_mode_error_report():
     _report(f'fwd bf16 128x128 B=2: max-abs err {err:.3e}, rms {rms:.3e} (ref scale {np.abs(ref).max():.2f}), |dPR-AUC| {dauc:.2e}')
     assert dauc < 2e-2
     assert np.isfinite(y).all()
-    assert rms < 0.1 and err < 1.0
+    # bounds = 2x what MI355X measures (0.123 max-abs, 0.0207 rms on logits of scale 9.7): a regression of the bf16 path shows up here
+    assert rms < 0.045 and err < 0.25, (rms, err)
 
 
 def test_fp16_inference_mode_error_report():
@@ -494,6 +495,7 @@ def test_fp16_inference_mode_error_report():
     _report(f'fwd fp16 128x128 B=2: max-abs err {e16[0]:.3e}, rms {e16[1]:.3e}, |dPR-AUC| {e16[2]:.2e}   '
             f'(bf16 on the same inputs: {eb[0]:.3e} / {eb[1]:.3e} / {eb[2]:.2e})')
     assert e16[1] < 0.35 * eb[1] and e16[0] < 0.5 * eb[0] and e16[2] < 5e-3
+    assert e16[0] < 0.03 and e16[1] < 0.006, e16            # 2x the measured 0.0145 max-abs / 0.0028 rms
     model, w, x, xt = _setup(CFG128, 1, torch.float16)
     model.zero_grad()
     out = model(xt['ogm'], xt['map_img'], training=True, obs=xt['obs'], occ=xt['occ'], mapt=xt['mapt'], flow=xt['flow'])
@@ -642,6 +644,35 @@ def test_golden_train_step_gradients_f32():
             got, want = model.params[k[5:]].grad.double().cpu().numpy(), g[k]
             assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 1e-9, k
     _report(f'golden train step 128x128 B=2 f32: worst relative error of the 299 gradient L2 norms {worst:.3e}')
+
+
+def test_golden_train_step_gradients_cfg256_b8_f32():
+    """BASELINE config 2's own geometry (cfg-256, B=8): one f32 train step of the HIP path against the committed fixture
+    tests/golden/strajnet_256_b8_grads.npz (make_golden_grads.py --cfg256, float64 oracle): the four losses and the L2 norm of each of
+    the 299 gradient tensors, plus three small gradients element by element."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'strajnet_256_b8_grads.npz'))
+    cfg = dict(CFG128, input_size=(256, 256))
+    model, w, x, xt = _setup(cfg, 8, torch.float32, seed=int(g['weight_seed']))
+    model.zero_grad()
+    out = _fwd(model, xt)
+    loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(256, 256, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+    d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+    sum(d.values()).backward()
+    for i, k in enumerate(('observed_xe', 'occluded_xe', 'flow', 'flow_warp_xe')):
+        assert abs(float(d[k].detach()) - float(g['loss'][i])) < 1e-4 * abs(float(g['loss'][i])) + 1e-5, (k, float(d[k].detach()), float(g['loss'][i]))
+    ref = dict(zip([str(n) for n in g['names']], g['grad_l2']))
+    gmax = float(g['grad_l2'].max())
+    worst = 0.0
+    for n, p in model.params.items():
+        e = abs(float(p.grad.double().norm()) - ref[n]) / (ref[n] + 1e-6 * gmax)
+        worst = max(worst, e)
+        assert e < 2e-3, (n, e)
+    for k in g.files:
+        if k.startswith('full:'):
+            got, want = model.params[k[5:]].grad.double().cpu().numpy(), g[k]
+            assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 1e-9, k
+    _report(f'golden train step cfg-256 B=8 f32: worst relative error of the 299 gradient L2 norms {worst:.3e}')
 
 
 def test_golden_cfg256_f32():

@@ -908,19 +908,19 @@ def test_upconv_add_fused_skip(dt, F_, Hi, Cin, Cout, two):
         x = x0.clone().requires_grad_(True)
         a = r1.clone().requires_grad_(True)
         b = r2.clone().requires_grad_(True) if two else None
-        keep, ops.FUSED_SKIP = ops.FUSED_SKIP, fused
+        keep, ops.FUSED_SKIP_TRAIN = ops.FUSED_SKIP_TRAIN, fused
         try:
             out = ops.upconv_add(x, pw, pb, a, b)
         finally:
-            ops.FUSED_SKIP = keep
+            ops.FUSED_SKIP_TRAIN = keep
         y, y2 = out if two else (out, None)
         loss = (y.float() * g1.float()).sum() + ((y2.float() * g2.float()).sum() if two else 0.0)
         loss.backward()
         ops.wgrad_join_now(torch.cuda.current_stream())
         torch.cuda.synchronize()
         return y, y2, x.grad, a.grad, (b.grad if two else None), pw.grad.clone(), pb.grad.clone()
-    u = run(0)
-    for mode in (2, 3):              # 2: sums in the up-conv epilogue; 3: one separate pass (stj_skip_add) + the fused backward
+    u = run(False)
+    for mode in (True,):             # sums in the up-conv epilogue + the fused backward
         f = run(mode)
         assert torch.equal(f[0], u[0])
         if two:

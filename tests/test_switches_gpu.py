@@ -2,7 +2,8 @@
 default (the generic kernels that f32 mode / odd shapes use, the guarded mover waves of ragged tiles, the layer-by-layer Swin path of
 the 16 x 16 stage, serial streams ...).  Each retained value is exercised here: the whole B = 8 cfg-256 training step in bf16 against
 the f32 mode (tests/test_timed_kernels_gpu.py: loss, gradient cosines, equal Dropout masks) in a fresh process with the variable
-set -- the switches are read once per process.  (Round 2's review: 43 switches, none tested.  Debug / tuning knobs are gone.)"""
+set -- the switches are read once per process.  (Round 2's review: 43 switches, none tested; round 3's: 21 switches keeping >= 10 superseded kernels compiled.  Now six: debug / tuning
+knobs and every kernel whose switch lost all its measurements are gone.)"""
 import os
 import subprocess
 import sys
@@ -12,35 +13,26 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# variable, value, relative loss gate of the bf16-vs-f32 comparison under it (1e-3 = the default path's own gate)
 SWITCHES = [
-    # csrc
-    ('STJ_NO_WS', '1'),            # generic conv kernels instead of the weight-stationary / wave-specialised ones
-    ('STJ_NO_PS', '1'),            # generic forward kernel for the wide up-convs
-    ('STJ_NO_DGRAD_PF', '1'),      # generic input gradient for the wide up-convs
-    ('STJ_WS2_GUARDED', '1'),      # guarded mover waves (the ragged-tile form) in the wave-specialised forward
-    ('STJ_DGRAD_WS2', '0'),        # single-role 96 <- 48 input gradient
-    ('STJ_DGRAD_WS2', '2'),        # guarded movers in the wave-specialised input gradient
-    ('STJ_WGRAD_V4', '0'),         # first transpose-read weight-gradient kernel for the two large layers
-    ('STJ_OUTCONV_V', '1'),        # first MFMA output-head forward
-    ('STJ_OUTCONV_BWD_V', '1'),    # first MFMA output-head backward
-    ('STJ_NO_RS', '1'),            # tile GEMM instead of the row-streaming linear kernel
-    ('STJ_GEMM_DEEPK', '0'),       # 64-element k-tiles everywhere
-    ('STJ_LN_V1', '1'),            # scalar-row LayerNorm kernels (the odd-width form)
-    # host side
-    ('STJ_FUSED_MLP', '0'), ('STJ_FUSED_ATTN', '0'), ('STJ_FUSED_ATTN_BWD', '0'),
-    ('STJ_GEMM_GROUP', '0'), ('STJ_WGRAD_STREAM', '0'), ('STJ_WGRAD_STREAM', '3'), ('STJ_DEFER_UPWG', '0'),
-    ('STJ_FUSED_SKIP', '0'), ('STJ_FUSED_SKIP', '2'), ('STJ_FUSED_SKIP', '3'), ('STJ_PAIR_OUTCONV', '0'),
-    ('STJ_NO_SIDE_STREAM', '1'), ('STJ_NO_SIDE_STREAM2', '1'),
+    # the generic conv kernels (what f32 mode and odd shapes run) instead of the weight-stationary / wave-specialised / pipelined ones and
+    # the paired output heads; they round a little differently from the default kernels: measured 1.4e-3 on this batch
+    ('STJ_NO_WS', '1', 2e-3),
+    ('STJ_NO_RS', '1', 1e-3),            # tile GEMM instead of the row-streaming linear kernel
+    ('STJ_FUSED_SWIN', '0', 1e-3),       # layer-by-layer Swin blocks (the form of the f32 mode's C = 384 stage) instead of the fused kernels
+    ('STJ_GEMM_GROUP', '0', 1e-3),       # every GEMM its own launch
+    ('STJ_WGRAD_SK', '0', 1e-3),         # split-K tile GEMMs (what unsupported shapes run) instead of the grouped stream-K weight gradients
+    ('STJ_NO_SIDE_STREAM', '1', 1e-3),   # one stream
+    ('STJ_NO_SIDE_STREAM', '2', 1e-3),   # no second side stream
 ]
 
 
-@pytest.mark.parametrize('var,val', SWITCHES, ids=[f'{a}={b}' for a, b in SWITCHES])
-def test_step_under_switch(var, val, lib_built):
+@pytest.mark.parametrize('var,val,gate', SWITCHES, ids=[f'{a}={b}' for a, b, _ in SWITCHES])
+def test_step_under_switch(var, val, gate, lib_built):
     env = dict(os.environ)
     env[var] = val
-    env['STJ_TEST_LOSS_GATE_SCALE'] = '3'
     r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_timed_kernels_gpu.py::test_bench_step_bf16_vs_f32_mode_cfg256_b8', '-x', '-q',
-                        '-p', 'no:cacheprovider'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        '-p', 'no:cacheprovider', f'--stj-loss-gate={gate}'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (var, val, r.stdout[-3000:], r.stderr[-1000:])
 
 
@@ -55,4 +47,5 @@ def test_switch_table_is_complete():
         if f.endswith('.py'):
             seen |= set(re.findall(r"os\.environ\.get\('([A-Z0-9_]+)'", open(os.path.join(ROOT, 'strajnet_amd', f)).read()))
     other = {'STJ_LIB_PATH', 'HIPCC'}
-    assert seen - other == {v for v, _ in SWITCHES}, (seen - other) ^ {v for v, _ in SWITCHES}
+    assert seen - other == {v for v, _, _ in SWITCHES}, (seen - other) ^ {v for v, _, _ in SWITCHES}
+    assert len(seen - other) <= 8

@@ -207,12 +207,9 @@ def _cmp_steps(tag, cfg, B, large_ogm, loss_gate=1e-3):
     err = float((o16 - o32).abs().max())
     print(f'{tag}: loss f32 {tot32:.6f} bf16 {tot16:.6f} (rel {rel:.2e}); gradient cosine: whole model {flat:.6f}, worst tensor {worst:.5f} '
           f'({worst_n}), {len(below)} of {len(cos)} tensors below 0.999: {below[:6]}; logits max-abs diff {err:.3e}')
-    # (tests/test_switches_gpu.py re-runs this under every retained STJ_* switch with a 3x wider loss gate: the superseded generic kernels
-    # round a little differently -- STJ_NO_WS=1 measured 1.4e-3 -- and what that run checks is that they are still CORRECT)
-    wide = float(os.environ.get('STJ_TEST_LOSS_GATE_SCALE', '1'))
-    assert rel < loss_gate * wide, (tot32, tot16)
+    assert rel < loss_gate, (tot32, tot16)
     for k in l32:
-        assert abs(l16[k] - l32[k]) < 2 * loss_gate * wide * abs(l32[k]) + 1e-4, (k, l16[k], l32[k])
+        assert abs(l16[k] - l32[k]) < 2 * loss_gate * abs(l32[k]) + 1e-4, (k, l16[k], l32[k])
     # Gate: the whole gradient and all but a handful of tensors at cosine >= 0.999.  The exceptions measured on MI355X are the
     # query / key kernels of the 11-token agent self-attention (tfa-MHA over time steps, trajNet.py:33,42): their gradient is the
     # small difference of softmax-weighted terms, which bf16 storage of P / dS resolves to ~2.5 digits; they stay above 0.99.
@@ -221,10 +218,12 @@ def _cmp_steps(tag, cfg, B, large_ogm, loss_gate=1e-3):
     assert len(below) <= max(3, len(cos) // 50), below
 
 
-def test_bench_step_bf16_vs_f32_mode_cfg256_b8():
-    """BASELINE config 2 (B=8 cfg-256, training=True): the timed bf16 step against the parity-mode f32 step."""
+def test_bench_step_bf16_vs_f32_mode_cfg256_b8(request):
+    """BASELINE config 2 (B=8 cfg-256, training=True): the timed bf16 step against the parity-mode f32 step.  (Loss gate 1e-3; a run
+    under a switch that selects other kernels states its own with --stj-loss-gate, tests/test_switches_gpu.py.)"""
     cfg = dict(input_size=(256, 256), window_size=8, embed_dim=96, depths=[2, 2, 2], num_heads=[3, 6, 12])
-    _cmp_steps('cfg-256 B=8 train step bf16 vs f32 mode', cfg, 8, False)
+    gate = request.config.getoption('--stj-loss-gate')
+    _cmp_steps('cfg-256 B=8 train step bf16 vs f32 mode', cfg, 8, False, loss_gate=float(gate) if gate else 1e-3)
 
 
 def test_bench_step_bf16_vs_f32_mode_cfg512_b2():
