@@ -167,7 +167,9 @@ __device__ __forceinline__ void body(const KL kl, const int u0, const int u1, un
     for (int s = 0; s < SLOTS; ++s) {
       const bool nar = (wave + 4 * s) < IMG_N / 1024;
       const int nvc = (nar ? L.vn : L.vw) >> 3;
-      voff[s] = srow[s] * (nar ? L.ldnb : L.ldwb) + min(scc[s], nvc - 1) * 16;     // pad / out-of-tile chunks re-read a valid one
+      // pad / out-of-tile chunks re-read a valid one (fetching them from a zero page instead measured 6 % slower grouped, 3.5x slower on
+      // one-problem launches)
+      voff[s] = srow[s] * (nar ? L.ldnb : L.ldwb) + min(scc[s], nvc - 1) * 16;
     }
   };
   set_voff();
