@@ -327,67 +327,46 @@ def run_extra_configs(steps=10, warmup=3):
 
 
 def input_feed(graphed, x, steps, finish_step, dev):
-    """The step WITH its input feed (reference train.py:85-103,319: every step consumes a new batch): the batch comes from pinned
-    host memory on a copy stream while the previous step runs, then lands in the captured step's static inputs.  Two host formats:
-    'f32' = the decoded float32 tensors; 'raw' = the TFRecord's own bytes (bool occupancy grids, int8 map, f32 flows) expanded on
-    the device by stj_decode_raw (strajnet_amd/data.py).  -> {'f32': {...}, 'raw': {...}} scenes/s including the feed."""
+    """The step WITH its input feed (reference train.py:85-103,319: every step consumes a new batch): strajnet_amd.data.HostFeed -- the
+    batch is uploaded from pinned host memory by a worker thread (1.5 MB pieces on a copy stream) while the previous step runs, then
+    lands in the captured step's static inputs.  Two host formats: 'f32' = the decoded float32 tensors; 'raw' = the TFRecord's own bytes
+    (bool occupancy grids, int8 map, f32 flows) expanded on the device by stj_decode_raw.  -> {'f32': {...}, 'raw': {...}} scenes/s
+    including the feed."""
     import torch
-    from strajnet_amd import ops
+    from strajnet_amd.data import HostFeed
     B = x['ogm'].shape[0]
     raw_kind = {'ogm': 'bool', 'gt_obs': 'bool', 'gt_occ': 'bool', 'map_img': 'int8'}
-    KIND = {'bool': 0, 'int8': 1}
-    copy = torch.cuda.Stream(dev)
     res = {}
     for mode in ('f32', 'raw'):
-        host, stage = {}, {}
+        host, raw = {}, {}
         for k, v in x.items():
             if k not in graphed.static:
                 continue
             if mode == 'raw' and k in raw_kind:
                 h = (v != 0).to(torch.uint8) if raw_kind[k] == 'bool' else torch.round(v * 256.0).to(torch.int8).view(torch.uint8)
-                host[k] = h.cpu().contiguous().pin_memory()
+                host[k], raw[k] = h.cpu().contiguous().pin_memory(), raw_kind[k]
             else:
                 host[k] = v.detach().float().cpu().contiguous().pin_memory()
-            stage[k] = torch.empty(host[k].shape, dtype=host[k].dtype, device=dev)
         nbytes = sum(h.numel() * h.element_size() for h in host.values())
-        up, landed = torch.cuda.Event(), torch.cuda.Event()
-
-        def upload():
-            with torch.cuda.stream(copy):
-                copy.wait_event(landed)              # the staging buffers are free once the previous batch left them
-                for k in host:
-                    stage[k].copy_(host[k], non_blocking=True)
-                up.record(copy)
-
-        def land():
-            main = torch.cuda.current_stream(dev)
-            main.wait_event(up)
-            for k, st in stage.items():
-                dst = graphed.static[k]
-                if mode == 'raw' and k in raw_kind:
-                    n = dst.numel()
-                    ops.call('stj_decode_raw', ops._p(st), KIND[raw_kind[k]], ops._p(dst), 1, 1, n, 1, 0, 0, 1, n,
-                             (1.0 / 256.0) if raw_kind[k] == 'int8' else 1.0, ops._st())
-                else:
-                    dst.copy_(st, non_blocking=True)
-            landed.record(main)
-        landed.record(torch.cuda.current_stream(dev))
-        upload()
+        feed = HostFeed(graphed.static, host, raw)
+        feed.start()
         for _ in range(2):
-            land(); upload(); graphed(); finish_step()
+            feed.land(); graphed(); finish_step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            land()
-            upload()                                  # the NEXT batch crosses PCIe under this step
+            feed.land()                               # this batch -> static inputs; the NEXT batch starts crossing PCIe under this step
             graphed()
             finish_step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        feed.wait_uploaded()
+        feed.close()
         res[mode] = {'value': round(B * steps / dt, 3), 'unit': 'scenes/s', 'ms_per_step': round(dt / steps * 1e3, 3),
                      'host_mbytes_per_step': round(nbytes / 1e6, 1)}
-    res['note'] = ('same captured step, every step preceded by a fresh batch from pinned host memory (upload on a copy stream under the '
-                   'previous step, then device copies / stj_decode_raw into the static inputs); `value` of the headline has the inputs resident')
+    res['note'] = ('same captured step, every step preceded by a fresh batch from pinned host memory (strajnet_amd.data.HostFeed: worker-thread '
+                   'upload in 1.5 MB pieces on a copy stream under the previous step, then device copies / stj_decode_raw into the static '
+                   'inputs); `value` of the headline has the inputs resident')
     return res
 
 

@@ -249,3 +249,116 @@ def decode_batch(examples, device='cuda', grid=512, out=256, test=False):
     if test and 'scenario/id' in examples[0]:
         res['scenario/id'] = [bytes(ex['scenario/id']) for ex in examples]
     return res
+
+
+# ---------------------------------------------------------------------------------------------------- per-step feed of a captured step
+_COPY_STREAMS = {}
+
+
+def _copy_stream(dev):
+    """ONE upload stream per device for every HostFeed (streams are multiplexed on a few hardware queues in creation order; a fresh
+    stream per feed lands on a different queue each time, and on the main chain's queue its SDMA barriers hold the step up)."""
+    key = str(dev)
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(dev)
+    return _COPY_STREAMS[key]
+
+
+class HostFeed:
+    """Feeds the static input tensors of a captured train step (graph.GraphedTrainStep.static) from PINNED host buffers, one batch
+    per step (reference train.py:85-103,319: every step consumes a new batch), without stretching the step:
+
+        feed = HostFeed(step.static, host, raw={'ogm': 'bool', ...})
+        feed.start()                       # upload of the first batch
+        for ...:
+            feed.land()                    # device: wait for the upload, staging -> static inputs (copies / stj_decode_raw, ~0.1 ms)
+                                           # host: the worker thread starts uploading what host[...] holds NOW (the next batch)
+            step(); optimizer.step()
+            feed.wait_uploaded()           # (a loader refills host[...] only after this returns)
+
+    host[k]: pinned tensors -- float32, or for the keys of `raw` the TFRecord's own bytes ('bool' / 'int8', expanded on the device).
+    Why a worker thread and 1.5 MB pieces (tools/probes/feed_probe.py, feed_probe3.py, feed_trace*.sh; B = 8: 77 MB of raw bytes per step):
+      * hipMemcpyAsync of a large pinned buffer BLOCKS its host thread for the duration of the transfer.  Issued from the thread that
+        replays the graph, no kernel runs until the last byte has arrived: the step grew by the full PCIe time (6.3 -> 8.4 ms),
+        whichever stream / priority / order, also as a memcpy node inside the graph;
+      * a kernel reading the pinned buffer over PCIe overlaps, but every kernel that runs beside it slows down 5-15x;
+      * from a second thread the SDMA transfer overlaps the step -- except that while ONE call is blocked the replaying thread's
+        launches stall too: a 33 MB tensor as one call left the GPU idle for 0.7 ms.  Measured by piece size (raw bytes, ms per step;
+        resident inputs 6.28): 32 MB 7.42, 8 MB 7.65, 4 MB 7.49, 2 MB 6.60, 1.5 MB 6.47, 1 MB 6.57, 0.5 MB 6.48, 0.25 MB 6.48 --
+        in 1.5 MB pieces the step keeps its resident-input time within 3 % (float32 host tensors, 141 MB: 7.2 ms)."""
+
+    def __init__(self, static, host, raw=None, chunk_bytes=3 << 19):
+        import threading
+        self.static, self.host, self.raw = static, {k: h for k, h in host.items() if k in static}, dict(raw or {})
+        dev = next(iter(static.values())).device
+        self.dev = dev
+        for k, h in self.host.items():
+            if not h.is_pinned():
+                raise ValueError(f'HostFeed: host[{k!r}] must be pinned memory')
+        self.stage = {k: torch.empty(h.shape, dtype=h.dtype, device=dev) for k, h in self.host.items()}
+        self.chunk = int(chunk_bytes)
+        self.copy = _copy_stream(dev)
+        self.up, self.landed = torch.cuda.Event(), torch.cuda.Event()
+        self._go, self._enqueued = threading.Event(), threading.Event()
+        self._stop = False
+        self._err = None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def _upload(self):
+        with torch.cuda.stream(self.copy):
+            self.copy.wait_event(self.landed)            # the staging buffers are free once the previous batch has left them
+            for k, h in self.host.items():
+                hs, ss = h.view(-1), self.stage[k].view(-1)
+                step = max(1, self.chunk // h.element_size())
+                for i in range(0, hs.numel(), step):
+                    ss[i:i + step].copy_(hs[i:i + step], non_blocking=True)
+            self.up.record(self.copy)
+
+    def _run(self):
+        torch.cuda.set_device(self.dev)
+        while True:
+            self._go.wait(); self._go.clear()
+            if self._stop:
+                return
+            try:
+                self._upload()
+            except Exception as e:       # surfaced by the next land() / wait_uploaded()
+                self._err = e
+            self._enqueued.set()
+
+    def _check(self):
+        if self._err is not None:
+            e, self._err = self._err, None
+            raise e
+
+    def start(self):
+        self.landed.record(torch.cuda.current_stream(self.dev))
+        self._go.set()
+
+    def land(self):
+        self._enqueued.wait(); self._enqueued.clear()       # the upload has been enqueued: its `up` event is recorded
+        self._check()
+        main = torch.cuda.current_stream(self.dev)
+        main.wait_event(self.up)
+        kind = {'bool': 0, 'int8': 1}
+        for k, st in self.stage.items():
+            dst = self.static[k]
+            if k in self.raw:
+                n = dst.numel()
+                call('stj_decode_raw', _p(st), kind[self.raw[k]], _p(dst), 1, 1, n, 1, 0, 0, 1, n, (1.0 / 256.0) if self.raw[k] == 'int8' else 1.0, _st())
+            else:
+                dst.copy_(st, non_blocking=True)
+        self.landed.record(main)
+        self._go.set()                                       # next batch: whatever host[...] holds now
+
+    def wait_uploaded(self):
+        """Host-side: returns once the upload kicked off by the last land() has left the host buffers (a loader may refill them)."""
+        self._enqueued.wait()
+        self._check()
+        self.up.synchronize()
+
+    def close(self):
+        self._stop = True
+        self._go.set()
+        self._thread.join(timeout=5)

@@ -98,3 +98,37 @@ def test_decode_batch_matches_oracle(lib_built, tmp_path, grid, out, test):
     with pytest.raises(ValueError):
         bad = dict(exs[0]); bad['actors'] = bad['actors'][:-8]
         D.decode_batch([bad], 'cuda', grid, out, test)
+
+
+@pytest.mark.gpu
+def test_host_feed_lands_every_batch(lib_built):
+    """data.HostFeed: three consecutive batches written into the pinned host buffers arrive bit-exactly in the static inputs (float32
+    tensors as they are, raw bool / int8 bytes expanded like _parse_image_function does), each one landing while the next is uploaded."""
+    import torch
+    from strajnet_amd.data import HostFeed
+    g = torch.Generator().manual_seed(0)
+    static = {'ogm': torch.zeros((2, 64, 64, 11, 2), device='cuda'), 'map_img': torch.zeros((2, 64, 64, 3), device='cuda'),
+              'flow': torch.zeros((2, 64, 64, 2), device='cuda'), 'big': torch.zeros((3, 1 << 20), device='cuda')}       # 12 MB: several pieces
+    host = {'ogm': torch.zeros((2, 64, 64, 11, 2), dtype=torch.uint8).pin_memory(), 'map_img': torch.zeros((2, 64, 64, 3), dtype=torch.uint8).pin_memory(),
+            'flow': torch.zeros((2, 64, 64, 2)).pin_memory(), 'big': torch.zeros((3, 1 << 20)).pin_memory(), 'ignored': torch.zeros(4).pin_memory()}
+    feed = HostFeed(static, host, raw={'ogm': 'bool', 'map_img': 'int8'})
+
+    def fill(seed):
+        g.manual_seed(seed)
+        host['ogm'].copy_((torch.rand(host['ogm'].shape, generator=g) < 0.3).to(torch.uint8) * 7)           # any non-zero byte is True
+        host['map_img'].copy_(torch.randint(-128, 128, host['map_img'].shape, generator=g, dtype=torch.int16).to(torch.int8).view(torch.uint8))
+        host['flow'].copy_(torch.randn(host['flow'].shape, generator=g))
+        host['big'].copy_(torch.randn(host['big'].shape, generator=g))
+        return {'ogm': (host['ogm'] != 0).float(), 'map_img': host['map_img'].view(torch.int8).float() / 256.0, 'flow': host['flow'].clone(), 'big': host['big'].clone()}
+    want = fill(1)
+    feed.start()
+    for step in range(3):
+        feed.wait_uploaded()              # the batch in flight has left the host buffers: refill them with the next one
+        nxt = fill(2 + step)
+        feed.land()                       # lands `want`, starts uploading `nxt`
+        torch.cuda.synchronize()
+        for k in want:
+            assert torch.equal(static[k].cpu(), want[k]), (step, k)
+        want = nxt
+    feed.wait_uploaded()
+    feed.close()
