@@ -285,6 +285,16 @@ int stj_outconv_fwd(const void* X, const float* W, const float* bias, float* Y, 
  * Tn = 8 only (STJ_EUNSUPPORTED otherwise: call stj_outconv_fwd per head). */
 int stj_outconv_pair_fwd(const void* X0, const void* X1, const float* W0, const float* W1, const float* bias0, const float* bias1,
                          float* Y, int B, int Tn, int H, int W, int C, int t_major, int dtype, hipStream_t stream);
+/* Inference form of the last decoder level + both heads (modules.py:746-748 at 96 -> 48, then :767-770,838) without the [F,H,W,48]
+ * tensor between them: out[p][o] = sum_taps z[p + tap][tap, o] with z[q][tap, o] = sum_c Whead[tap][c][o] ELU(upconv)[q][c].
+ * stj_upconv_fwd_head: the up-conv of stj_upconv_fwd (same X, Wf, bias) whose epilogue projects every output pixel onto the head kernel
+ * Whead f32 [3,3,48,2] and writes Z [F,2Hi,2Wi,24] (18 + 6 zero channels) in the activation dtype; stj_outconv_pair_gather: Y [B,H,W,32]
+ * f32, channel 4 t + 2 head + o = bias + the 9-neighbour sum of Z0 / Z1 (the two decoder branches; frames as in stj_outconv_pair_fwd).
+ * 16-bit dtypes, Cin = 96, Cout = 48, whole 8 x 16 tiles, Tn = 8; STJ_EUNSUPPORTED otherwise. */
+int stj_upconv_fwd_head(const void* X, const void* Wf, const float* bias, const float* Whead, void* Z, int F, int Hi, int Wi, int Cin,
+                        int Cout, int dtype, hipStream_t stream);
+int stj_outconv_pair_gather(const void* Z0, const void* Z1, const float* bias0, const float* bias1, float* Y, int B, int Tn, int H, int W,
+                            int t_major, int dtype, hipStream_t stream);
 int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, float* dW, float* db, int F, int Hh, int Ww,
                     int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int elu_in, void* ws,
                     long long ws_bytes, int dtype, hipStream_t stream);

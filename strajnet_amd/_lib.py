@@ -80,6 +80,8 @@ SIGNATURES = {
     'stj_upconv_dgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_upconv_wgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_pair_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
+    'stj_upconv_fwd_head': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    'stj_outconv_pair_gather': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
     'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp, cl, ci, vp],
     'stj_outconv_bwd_workspace_bytes': [],

@@ -884,6 +884,31 @@ extern "C" int stj_outconv_pair_fwd(const void* X0, const void* X1, const float*
   stj_set_error("outconv_pair: shape / dtype not covered by the paired kernel");
   return STJ_EUNSUPPORTED;
 }
+// Inference form of the last decoder level + the two output heads (no y48 tensor): stj_upconv_fwd_head writes the per-pixel projection
+// Z [F, 2 Hi, 2 Wi, 24] of ELU(up-conv) onto the head's 9 x 2 (tap, output) weights, stj_outconv_pair_gather sums the 9 neighbours of both
+// branches into [B, H, W, 32].  16-bit dtypes, the 96 -> 48 level, whole 8 x 16 tiles; STJ_EUNSUPPORTED otherwise (run stj_upconv_fwd +
+// stj_outconv_pair_fwd).
+bool upconv_fwd_head_try(const void* X, const void* Wf, const float* bias, const float* Wh, void* Z, int F, int Hi, int Wi, int Cin, int Cout, int dtype,
+                         hipStream_t st);
+bool outconv_pair_gather_try(const void* Z0, const void* Z1, const float* b0, const float* b1, float* Y, int B, int Tn, int Hh, int Ww, int t_major,
+                             int dtype, hipStream_t st);
+extern "C" int stj_upconv_fwd_head(const void* X, const void* Wf, const float* bias, const float* Whead, void* Z, int F, int Hi, int Wi, int Cin,
+                                   int Cout, int dtype, hipStream_t stream) {
+  int e = upconv_check(F, Hi, Wi, Cin, Cout, dtype);
+  if (e) return e;
+  if (stj_is16(dtype) && ws_enabled() && upconv_fwd_head_try(X, Wf, bias, Whead, Z, F, Hi, Wi, Cin, Cout, dtype, stream))
+    return stj_check_launch("stj_upconv_fwd_head");
+  stj_set_error("upconv_fwd_head: shape / dtype not covered (96 -> 48, whole 8 x 16 tiles, 16-bit)");
+  return STJ_EUNSUPPORTED;
+}
+extern "C" int stj_outconv_pair_gather(const void* Z0, const void* Z1, const float* bias0, const float* bias1, float* Y, int B, int Tn, int Hh,
+                                       int Ww, int t_major, int dtype, hipStream_t stream) {
+  if (B <= 0 || Tn <= 0) { stj_set_error("outconv_pair_gather: empty problem"); return STJ_EINVAL; }
+  if (stj_is16(dtype) && outconv_pair_gather_try(Z0, Z1, bias0, bias1, Y, B, Tn, Hh, Ww, t_major, dtype, stream))
+    return stj_check_launch("stj_outconv_pair_gather");
+  stj_set_error("outconv_pair_gather: shape / dtype not covered");
+  return STJ_EUNSUPPORTED;
+}
 // ws: caller-owned scratch of stj_outconv_bwd_workspace_bytes() bytes (need not be zeroed; per-block dW/db partials of the bf16
 // path live there between its two kernels); without it the slower generic kernel runs.
 extern "C" long long stj_outconv_bwd_workspace_bytes() { return outconv_bwd_ws_bytes(); }

@@ -196,14 +196,25 @@ static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y,
 // instead of one 57 KB tile stage), the halo at tile granularity; one workgroup barrier per step.  Both roles run on every SIMD (one
 // compute + one mover wave each), so global traffic, LDS staging and the epilogue's VALU work overlap the MFMAs of the other role.
 // =====================================================================================================
-template <typename T, int KS, int NF, bool EXACT>
+// HEAD = true (inference, the last level: Cout = 48 = one channel tile): the 3x3 48 -> 2 output head that follows (modules.py:767-770)
+// starts in this kernel's epilogue.  out[p][o] = sum_taps sum_c Wh[tap][c][o] y[p + tap][c] = sum_taps z[p + tap][tap, o] with the per-pixel
+// projection z[q][tap, o] = sum_c Wh[tap][c][o] y[q][c]: 18 numbers per pixel instead of 48, and no halo -- y never leaves the chip.  The
+// ELU outputs a lane holds after the main MFMAs (D layout: channels 16 n + 4 g + r of ITS pixel) ARE an MFMA B operand for pixel = column
+// if the head weights (A operand, rows = (tap, o)) are laid out with the same k order -- the contraction order is free -- so z costs 4 more
+// MFMAs per 16 pixels and no data movement.  Y is then the z tensor [F, 2 Hi, 2 Wi, 24] (18 + 6 zero channels: whole 16-byte pieces), which
+// stj_outconv_pair_gather sums over the 9 neighbours: 48 + 48 bytes per pixel of traffic instead of 96 + 96.
+template <typename T, int KS, int NF, bool EXACT, bool HEAD = false>
 __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
                                                              const float* __restrict__ bias, T* __restrict__ Y,
-                                                             int F, int Hi, int Wi, int Cout, int ntiles, int dbg) {
+                                                             int F, int Hi, int Wi, int Cout_, int ntiles, int dbg, const float* __restrict__ Wh) {
   constexpr int CIN = KS * 32;
   constexpr int LDK = CIN + 16;
   constexpr int CT = NF * 16;
-  constexpr int LDO = CT + 8;
+  constexpr int CTO = HEAD ? 24 : CT;                    // channels of a stage pixel / of the result
+  constexpr int LDO = HEAD ? 40 : CT + 8;
+  const int Cout = HEAD ? CT : Cout_;                    // channels of the convolution itself
+  const int Cres = HEAD ? 24 : Cout_;                    // channels of the tensor the movers write
+  static_assert(!HEAD || (NF == 3 && EXACT), "the head epilogue is written for the 48-channel level, whole tiles");
   constexpr int HPIX = WS_HH * WS_HW;
   constexpr int CPP = CIN / 8;
   constexpr int NCH = (HPIX * CPP + 255) / 256;          // halo chunks per mover thread
@@ -252,6 +263,25 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
         const int co = n0 + n * 16 + g * 4 + r;
         bv[n][r] = co < Cout ? bias[co] : 0.f;
       }
+    // head weights Wh f32 [9 taps][48][2] as MFMA A fragments: row t = 2 tap + o (t-fragment tf: t = 16 tf + ln, 18 rows used), k slot j
+    // of lane group g = channel 16 (j / 4) + 4 g + j % 4 (k-step 0: channels 0..31) / 32 + 4 g + j, j < 4 (k-step 1: channels 32..47)
+    s16x8 hw[2][2];
+    if constexpr (HEAD) {
+#pragma unroll
+      for (int tf = 0; tf < 2; ++tf) {
+        const int t = 16 * tf + ln;
+        float v0[8], v1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c0 = 16 * (j / 4) + 4 * g + j % 4, c1 = 32 + 4 * g + j;
+          v0[j] = t < 18 ? Wh[((t >> 1) * CT + c0) * 2 + (t & 1)] : 0.f;
+          v1[j] = (t < 18 && j < 4) ? Wh[((t >> 1) * CT + c1) * 2 + (t & 1)] : 0.f;
+        }
+        typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+        hw[tf][0] = __builtin_bit_cast(s16x8, (u4){pack2<T>(v0[0], v0[1]), pack2<T>(v0[2], v0[3]), pack2<T>(v0[4], v0[5]), pack2<T>(v0[6], v0[7])});
+        hw[tf][1] = __builtin_bit_cast(s16x8, (u4){pack2<T>(v1[0], v1[1]), pack2<T>(v1[2], v1[3]), 0u, 0u});
+      }
+    }
     __syncthreads();                                     // halo of the first tile committed by the movers
     int q = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -284,7 +314,29 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
                 for (int n = 0; n < NF; ++n) acc[j - 1][n] = Mma<T>::mma(wf[2 + s2][n][ks], xb, acc[j - 1][n]);
               }
             }
-        if (!(dbg & 2))
+        if constexpr (HEAD) {
+#pragma unroll
+          for (int m = 0; m < SR; ++m) {
+            uint32_t pk[NF][2];
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+              pk[n][0] = pack2<T>(elu_bf(acc[m][n][0] + bv[n][0]), elu_bf(acc[m][n][1] + bv[n][1]));
+              pk[n][1] = pack2<T>(elu_bf(acc[m][n][2] + bv[n][2]), elu_bf(acc[m][n][3] + bv[n][3]));
+            }
+            typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+            const s16x8 y0 = __builtin_bit_cast(s16x8, (u4){pk[0][0], pk[0][1], pk[1][0], pk[1][1]});     // channels 16 (j / 4) + 4 g + j % 4
+            const s16x8 y1 = __builtin_bit_cast(s16x8, (u4){pk[2][0], pk[2][1], 0u, 0u});                 // channels 32 + 4 g + j
+            T* zp = ost + ((2 * m + a) * (2 * WS_TW) + 2 * ln + b) * LDO;
+#pragma unroll
+            for (int tf = 0; tf < 2; ++tf) {
+              f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+              z = Mma<T>::mma(hw[tf][0], y0, z);
+              z = Mma<T>::mma(hw[tf][1], y1, z);
+              // D: row (tap, o) = 16 tf + 4 g + r, column = this lane's pixel.  Rows 18..23 are zero (zero weight rows); 24..31 are not stored.
+              if (tf == 0 || g < 2) *reinterpret_cast<uint2*>(zp + 16 * tf + 4 * g) = make_uint2(pack2<T>(z[0], z[1]), pack2<T>(z[2], z[3]));
+            }
+          }
+        } else if (!(dbg & 2))
 #pragma unroll
         for (int m = 0; m < SR; ++m)
 #pragma unroll
@@ -341,15 +393,15 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
         *reinterpret_cast<uint4*>(halo + (cgeo[i] & 0xffff) * LDK + (cgeo[i] >> 16) * 8) = v;
       }
     };
-    constexpr int SEG = CT / 8, NIT = 2 * SR * 2 * WS_TW * SEG;
+    constexpr int SEG = CTO / 8, NIT = 2 * SR * 2 * WS_TW * SEG;
     static_assert(NIT % 256 == 0, "whole rounds of 16-byte items per step");
     auto drain = [&](const T* ost, int f, int ty0, int tx0, int st) {
-      T* Yf = Y + (long long)f * Ho * Wo * Cout + ((long long)(2 * ty0 + 2 * SR * st) * Wo + 2 * tx0) * Cout + n0;
+      T* Yf = Y + (long long)f * Ho * Wo * Cres + ((long long)(2 * ty0 + 2 * SR * st) * Wo + 2 * tx0) * Cres + (HEAD ? 0 : n0);
 #pragma unroll
       for (int i = 0; i < NIT / 256; ++i) {
         const int c = mt + i * 256;
         const int sg = c % SEG, p = c / SEG;
-        *reinterpret_cast<uint4*>(Yf + ((p / (2 * WS_TW)) * Wo + p % (2 * WS_TW)) * Cout + sg * 8) = *reinterpret_cast<const uint4*>(ost + p * LDO + sg * 8);
+        *reinterpret_cast<uint4*>(Yf + ((p / (2 * WS_TW)) * Wo + p % (2 * WS_TW)) * Cres + sg * 8) = *reinterpret_cast<const uint4*>(ost + p * LDO + sg * 8);
       }
     };
     int tile = blockIdx.x;
@@ -451,8 +503,29 @@ static bool ws2_launch_t(const void* X, const void* Wf, const float* bias, void*
   if (nblk > ntiles) nblk = ntiles;
   if (nblk < 1) nblk = 1;
   const int dbg = 0;      // (role-ablation mask of the kernel; profiling builds only)
-  hipLaunchKernelGGL((upconv_fwd_ws2_kernel<T, KS, NF, EXACT>), dim3(nblk, ct), dim3(512), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y, F, Hi, Wi, Cout, ntiles, dbg);
+  hipLaunchKernelGGL((upconv_fwd_ws2_kernel<T, KS, NF, EXACT>), dim3(nblk, ct), dim3(512), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y, F, Hi, Wi, Cout, ntiles, dbg,
+                     (const float*)nullptr);
   return true;
+}
+// the 96 -> 48 level with the 48 -> 2 head's channel projection in its epilogue: Z [F, 2 Hi, 2 Wi, 24] instead of Y (whole tiles only)
+template <typename T>
+static bool ws2_head_launch(const void* X, const void* Wf, const float* bias, const float* Wh, void* Z, int F, int Hi, int Wi, hipStream_t st) {
+  constexpr int KS = 3, NF = 3, CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 8;
+  const size_t lds = (size_t)(2 * WS_HH * WS_HW * LDK + 2 * 8 * 2 * WS_TW * LDO) * 2;       // (the z stage is smaller than the y stage it replaces)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)upconv_fwd_ws2_kernel<T, KS, NF, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    attr_set = true;
+  }
+  const int ntiles = (Wi / WS_TW) * (Hi / WS_TH) * F;
+  const int nblk = ntiles < 256 ? ntiles : 256;
+  hipLaunchKernelGGL((upconv_fwd_ws2_kernel<T, KS, NF, true, true>), dim3(nblk, 1), dim3(512), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Z, F, Hi, Wi, CT, ntiles, 0, Wh);
+  return true;
+}
+bool upconv_fwd_head_try(const void* X, const void* Wf, const float* bias, const float* Wh, void* Z, int F, int Hi, int Wi, int Cin, int Cout, int dtype,
+                         hipStream_t st) {
+  if (Cin != 96 || Cout != 48 || Hi % WS_TH || Wi % WS_TW) return false;
+  return dtype == STJ_F16 ? ws2_head_launch<f16>(X, Wf, bias, Wh, Z, F, Hi, Wi, st) : ws2_head_launch<bf16>(X, Wf, bias, Wh, Z, F, Hi, Wi, st);
 }
 template <typename T, int KS, int NF>
 static bool ws2_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, hipStream_t st) {
@@ -1127,6 +1200,83 @@ bool outconv_pair_fwd_try(const void* X0, const void* X1, const float* W0, const
     hipLaunchKernelGGL((outconv_pair_fwd_kernel<f16, 48>), dim3(nb), dim3(256), 0, st, (const f16*)X0, (const f16*)X1, W0, W1, b0, b1, Y, B, Hh, Ww, t_major, nsp);
   else
     hipLaunchKernelGGL((outconv_pair_fwd_kernel<bf16, 48>), dim3(nb), dim3(256), 0, st, (const bf16*)X0, (const bf16*)X1, W0, W1, b0, b1, Y, B, Hh, Ww, t_major, nsp);
+  return true;
+}
+
+// Second half of the inference heads (first half: the HEAD epilogue of upconv_fwd_ws2_kernel): Y[b, y, x, 4 t + 2 h + o] = bias_h[o] +
+// sum over the 9 neighbours (ky, kx) of Z_h[f(b, t), y + ky - 1, x + kx - 1, 2 (3 ky + kx) + o] (zero outside the image), Z_h the projected
+// tensors [F, H, W, 24] of the two decoder branches.  A workgroup owns a 16 x 16 spatial tile of one scene and walks its 16 (waypoint,
+// head) planes through an 18 x 18 halo in LDS (next plane prefetched in registers); a thread keeps the 32 results of its pixel and writes
+// one full 128-byte line.
+template <typename T>
+__global__ __launch_bounds__(256) void outconv_pair_gather_kernel(const T* __restrict__ Z0, const T* __restrict__ Z1, const float* __restrict__ b0,
+                                                                  const float* __restrict__ b1, float* __restrict__ Y, int B, int Hh, int Ww,
+                                                                  int t_major, int nsp) {
+  constexpr int CZ = 24, LDZ = 24, NPX = OCM_H * OCM_H, NCHK = NPX * 3, NCH = (NCHK + 255) / 256;
+  __shared__ __attribute__((aligned(16))) T halo[NPX * LDZ];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T;
+  const float bias[2][2] = {{b0[0], b0[1]}, {b1[0], b1[1]}};
+  for (int sp = blockIdx.x; sp < nsp; sp += gridDim.x) {
+    const int tcx = sp % tiles_x, t2 = sp / tiles_x, tcy = t2 % tiles_y, b = t2 / tiles_y;
+    const int y0 = tcy * OCM_T - 1, x0 = tcx * OCM_T - 1;
+    uint4 pre[NCH];
+    auto fetch = [&](int plane) {
+      const int t = plane >> 1, h = plane & 1;
+      const int f = t_major ? t * B + b : b * 8 + t;
+      const T* Zf = (h ? Z1 : Z0) + (long long)f * Hh * Ww * CZ;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * 256;
+        const int px = c / 3, cc = c % 3;
+        const int gy = y0 + px / OCM_H, gx = x0 + px % OCM_H;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < NCHK && gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) v = *reinterpret_cast<const uint4*>(Zf + ((long long)gy * Ww + gx) * CZ + cc * 8);
+        pre[i] = v;
+      }
+    };
+    float out[32];
+    fetch(0);
+#pragma unroll 1
+    for (int plane = 0; plane < 16; ++plane) {
+      __syncthreads();                                   // the previous plane's reads are through
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * 256;
+        if (c < NCHK) *reinterpret_cast<uint4*>(halo + (c / 3) * LDZ + (c % 3) * 8) = pre[i];
+      }
+      __syncthreads();
+      if (plane + 1 < 16) fetch(plane + 1);
+      const int h = plane & 1;
+      float s0 = bias[h][0], s1 = bias[h][1];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(halo + ((ty + ky) * OCM_H + tx + kx) * LDZ + 2 * (3 * ky + kx));
+          float a0, a1;
+          unpack2<T>(w, a0, a1);
+          s0 += a0; s1 += a1;
+        }
+      // plane = 2 t + h -> channels 4 t + 2 h + {0, 1} = 2 plane + {0, 1}
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (q == plane) { out[2 * q] = s0; out[2 * q + 1] = s1; }
+    }
+    float* yp = Y + (((long long)b * Hh + tcy * OCM_T + ty) * Ww + tcx * OCM_T + tx) * 32;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(yp + 4 * q) = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+  }
+}
+bool outconv_pair_gather_try(const void* Z0, const void* Z1, const float* b0, const float* b1, float* Y, int B, int Tn, int Hh, int Ww, int t_major,
+                             int dtype, hipStream_t st) {
+  if (Tn != 8 || Hh % OCM_T || Ww % OCM_T || (((uintptr_t)Y | (uintptr_t)Z0 | (uintptr_t)Z1) & 15)) return false;
+  const int nsp = B * (Hh / OCM_T) * (Ww / OCM_T);
+  const int nb = nsp < 2048 ? nsp : 2048;
+  if (dtype == STJ_F16)
+    hipLaunchKernelGGL(outconv_pair_gather_kernel<f16>, dim3(nb), dim3(256), 0, st, (const f16*)Z0, (const f16*)Z1, b0, b1, Y, B, Hh, Ww, t_major, nsp);
+  else
+    hipLaunchKernelGGL(outconv_pair_gather_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)Z0, (const bf16*)Z1, b0, b1, Y, B, Hh, Ww, t_major, nsp);
   return true;
 }
 

@@ -708,6 +708,25 @@ class STrajNet:
         x, fx = up_add(x, 'decoder/upconv_2_0', s2, sf)                              # [F,4hb,4hb,128] x 2
         self._tap('decoder/level2', x)
         self._tap('decoder/level2_flow', fx)
+        oc = ('decoder/outconv/kernel', 'decoder/outconv/bias', 'decoder/outconv_f/kernel', 'decoder/outconv_f/bias')
+        if ops.upconv_head_ok(2 * x.shape[1], 2 * x.shape[2], self._p('decoder/upconv_0_0/kernel'), x.dtype, 8) and self.taps is None:
+            # inference: the last level's output never exists -- its epilogue projects it onto the heads' weights, the heads are a 9-neighbour sum
+            def last(t, n1, n0, head):
+                t = up(t, n1)
+                return ops.upconv_head(t, self._p(n0 + '/kernel'), self._p(n0 + '/bias'), self._p(head), prep=self._upconv_prep.get(n0))
+            if self._side2 is not None:
+                main = torch.cuda.current_stream(self.device)
+                self._side2.wait_stream(main)
+                fx.record_stream(self._side2)
+                with torch.cuda.stream(self._side2):
+                    zf = last(fx, 'decoder/upconvf_1_0', 'decoder/upconvf_0_0', oc[2])
+                zo = last(x, 'decoder/upconv_1_0', 'decoder/upconv_0_0', oc[0])
+                main.wait_stream(self._side2)
+                zf.record_stream(main)
+            else:
+                zo = last(x, 'decoder/upconv_1_0', 'decoder/upconv_0_0', oc[0])
+                zf = last(fx, 'decoder/upconvf_1_0', 'decoder/upconvf_0_0', oc[2])
+            return ops.heads_gather(zo, zf, self._p(oc[1]), self._p(oc[3]), B, 8, t_major=True)
         # the last two levels of each branch have a single consumer, whose backward folds ELU' into the gradient it returns
         if self._side2 is not None:      # the observed-occupancy and flow branches of the last two levels are independent
             main = torch.cuda.current_stream(self.device)

@@ -1892,6 +1892,32 @@ class _OutConvPair(torch.autograd.Function):
         return (dxo, dxf) + (None,) * 12
 
 
+def upconv_head_ok(Hi, Wi, pw, dtype, Tn):
+    """True when the inference form of the last level (kernel pw) applies to an input [F,Hi,Wi,96]: no autograd, 16-bit, 96 -> 48, whole
+    8 x 16 tiles, 8 waypoints."""
+    return (not torch.is_grad_enabled() and dtype != torch.float32 and tuple(pw.master.shape[2:]) == (96, 48) and Hi % 8 == 0 and Wi % 16 == 0
+            and Tn == 8 and os.environ.get('STJ_NO_WS') != '1')
+
+
+def upconv_head(x, pw, pb, phead, prep=None):
+    """Inference only: ELU(up-conv 96 -> 48) projected onto the 3x3 48 -> 2 head kernel `phead` inside the up-conv's epilogue ->
+    z [F,2Hi,2Wi,24] (stj_upconv_fwd_head); the [F,2Hi,2Wi,48] tensor is never written."""
+    _req_cuda(x)
+    F_, Hi, Wi, Cin = x.shape
+    wf, _ = prep if prep is not None else upconv_prep(pw, x.dtype)
+    z = torch.empty((F_, 2 * Hi, 2 * Wi, 24), dtype=x.dtype, device=x.device)
+    call('stj_upconv_fwd_head', _p(x.contiguous()), _p(wf), _p(pb.master), _p(phead.master), _p(z), F_, Hi, Wi, Cin, 48, _dt(x), _st())
+    return z
+
+
+def heads_gather(zo, zf, p1b, p2b, B, Tn, t_major=False):
+    """[B,H,W,4*Tn] f32 = bias + the 9-neighbour sums of the two projected tensors (stj_outconv_pair_gather)."""
+    F_, H, W, _ = zo.shape
+    out = torch.empty((B, H, W, 4 * Tn), dtype=torch.float32, device=zo.device)
+    call('stj_outconv_pair_gather', _p(zo), _p(zf), _p(p1b.master), _p(p2b.master), _p(out), B, Tn, H, W, 1 if t_major else 0, _dt(zo), _st())
+    return out
+
+
 def outconv_pair(xo, xf, p1w, p1b, p2w, p2b, B, Tn, t_major=False, x_is_elu_out=False):
     return _OutConvPair.apply(xo, xf, p1w.master, p1b.master, p2w.master, p2b.master, p1w, p1b, p2w, p2b, B, Tn, t_major, x_is_elu_out)
 

@@ -474,6 +474,56 @@ def test_outconv_pair(dt):
         assert rel_err(p.grad, r.grad) < tol(dt)
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('t_major', [True, False])
+def test_inference_heads_in_upconv_epilogue(dt, t_major):
+    """stj_upconv_fwd_head + stj_outconv_pair_gather (inference: the [F,H,W,48] level never exists) against the two-kernel path
+    (stj_upconv_fwd + stj_outconv_pair_fwd) and float64 (modules.py:746-748 at 96 -> 48, :767-770, :838).  The fused form rounds the nine
+    per-pixel projections z[q][tap, o] to the activation dtype before summing them; both paths see y and the head weights in the
+    activation dtype.  Gates per element, against sum |W| |y| over taps and channels, at twice the measured ratios: two-kernel <= 0.6 eps, fused <= 0.8 eps."""
+    from strajnet_amd import ops
+    B, Tn, Hi, Wi = 2, 8, 16, 32
+    pu = [[mk_param((3, 3, 96, 48), dt, 0.05, 3 + 10 * i), mk_param((48,), dt, 0.1, 4 + 10 * i)] for i in range(2)]
+    po = [mk_param((3, 3, 48, 2), dt, 0.1, 5), mk_param((2,), dt, 0.1, 6), mk_param((3, 3, 48, 2), dt, 0.1, 7), mk_param((2,), dt, 0.1, 8)]
+    xs = [rnd((Tn * B, Hi, Wi, 96), dt, 9 + i) for i in range(2)]
+    with torch.no_grad():
+        assert ops.upconv_head_ok(Hi, Wi, pu[0][0], dt, Tn)
+        ys = [ops.upconv(x, *p) for x, p in zip(xs, pu)]
+        two = ops.outconv_pair(ys[0], ys[1], *po, B, Tn, t_major=t_major)
+        zs = [ops.upconv_head(x, p[0], p[1], ph) for x, p, ph in zip(xs, pu, (po[0], po[2]))]
+        out = ops.heads_gather(zs[0], zs[1], po[1], po[3], B, Tn, t_major=t_major)
+    torch.cuda.synchronize()
+    assert out.shape == two.shape == (B, 2 * Hi, 2 * Wi, 4 * Tn)
+    assert float(zs[0][..., 18:].abs().max()) == 0.0 and float(zs[1][..., 18:].abs().max()) == 0.0       # the 6 padding channels
+
+    def upr(t, w, b):
+        u = F.interpolate(t.permute(0, 3, 1, 2), scale_factor=2, mode='nearest')
+        return F.elu(F.conv2d(u, w.permute(3, 2, 0, 1), b, padding=1)).permute(0, 2, 3, 1)
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    refs, bounds = [], []
+    for x, p, (pw, pb) in zip(xs, pu, ((po[0], po[1]), (po[2], po[3]))):
+        y = upr(x.double().cpu(), p[0].master.detach().double().cpu(), p[1].master.detach().double().cpu())                 # [F,H,W,48]
+        w = pw.master.detach().double().cpu()
+        z = torch.einsum('fhwc,ijco->fhwijo', y, w)                                                                          # z[q][tap, o]
+        zp = F.pad(z, (0, 0, 0, 0, 0, 0, 1, 1, 1, 1))
+        H, W = y.shape[1], y.shape[2]
+        o = sum(zp[:, i:i + H, j:j + W, i, j, :] for i in range(3) for j in range(3)) + pb.master.detach().double().cpu()
+        za = F.pad(torch.einsum('fhwc,ijco->fhwijo', y.abs(), w.abs()), (0, 0, 0, 0, 0, 0, 1, 1, 1, 1))                       # sum_c |W| |y| per tap
+        a = sum(za[:, i:i + H, j:j + W, i, j, :] for i in range(3) for j in range(3)) + pb.master.detach().double().cpu().abs()
+        refs.append(o); bounds.append(a)
+    def arrange(parts):
+        y = torch.cat(parts, -1)
+        y = y.view(Tn, B, *y.shape[1:]).permute(1, 0, 2, 3, 4) if t_major else y.view(B, Tn, *y.shape[1:])
+        return y.permute(0, 2, 3, 1, 4).reshape(B, y.shape[2], y.shape[3], 4 * Tn)
+    ref, bound = arrange(refs), arrange(bounds)
+    e_two = (two.double().cpu() - ref).abs()
+    e_fused = (out.double().cpu() - ref).abs()
+    # the two-kernel path sees y rounded to the activation dtype (relative eps / 2 per term); the fused one z rounded once more
+    assert float((e_two - 0.6 * eps * bound - 1e-6).max()) <= 0, float((e_two / (bound + 1e-30)).max())        # measured 0.30 eps
+    assert float((e_fused - 0.8 * eps * bound - 1e-6).max()) <= 0, float((e_fused / (bound + 1e-30)).max())    # measured 0.38-0.40 eps
+    print(f'inference heads {dt}: max |err| / sum|W||y|: two-kernel {float((e_two / bound).max()):.2e}, fused {float((e_fused / bound).max()):.2e} (eps {eps:.2e})')
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 def test_decoder_tail_fused_elu_bwd(dt):
     """up(128->96) -> up(96->48) -> output heads with the ELU' passes folded into the consumers' backward kernels
