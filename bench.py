@@ -587,6 +587,9 @@ def main():
         chk = torch.ones(1, device=dev)
         dist.all_reduce(chk)
         dist_info['ranks_seen_by_allreduce'] = int(chk.item())       # every rank contributed 1: proof the collective spans N ranks
+        lg = torch.tensor([loss_val], dtype=torch.float64, device=dev)
+        dist.all_reduce(lg)                                          # the replica-scaled losses add up to the loss of the global batch
+        dist_info['loss_global_batch'] = round(float(lg.item()), 4)
     # per-kernel HIP-event timing of EVERY C-ABI launch (strajnet_amd/prof.py): the same launches, issued eagerly with events
     # recorded on the launch stream -- under graph replay individual launches cannot carry events
     prof_ser = prof_conc = None

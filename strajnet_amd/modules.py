@@ -860,7 +860,9 @@ class STrajNet:
         # backward as well -- so that kernel has the GPU to itself -- measured 5 % SLOWER, 7.26 vs 6.88 ms: the 1.5 ms of half-GPU
         # weight-gradient launches then reach into the encoder's backward.)
         x = ops.wgrad_flush_point(x)
-        out = self._decoder(x, res_list, B, skips)
-        ops.wgrad_defer_end()
+        try:
+            out = self._decoder(x, res_list, B, skips)
+        finally:
+            ops.wgrad_defer_end()        # (also when the decoder raises: a stale "defer" flag would swallow the next stand-alone up-conv's weight gradient)
         self._tap('output', out)
         return ops.join_after_backward(out, (self._side, self._side2), fold)

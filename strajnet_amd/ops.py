@@ -8,6 +8,7 @@ routes activation gradients.
 import ctypes
 
 import os
+import threading
 
 import torch
 
@@ -23,12 +24,34 @@ def call(name, *args):
 
 
 GROUP_GEMMS = os.environ.get('STJ_GEMM_GROUP', '1') != '0'
-_GROUP = [None, None]       # [the open group's handle (None: stj_gemm launches at once), its host buffer]
+class _GroupState(threading.local):
+    """per host thread (the forward thread and autograd's device threads each record into their own group, as the C ABI's contract says)"""
+    def __init__(self):
+        self.h = [None, None]       # [the open group's handle (None: stj_gemm launches at once), its host buffer]
+        self.depth = [0]
+
+
+_GS = _GroupState()
+
+
+class _GroupProxy:
+    """_GROUP[i] / _GROUP_DEPTH[i] of the calling thread"""
+    def __init__(self, attr):
+        self.attr = attr
+
+    def __getitem__(self, i):
+        return getattr(_GS, self.attr)[i]
+
+    def __setitem__(self, i, v):
+        getattr(_GS, self.attr)[i] = v
+
+
+_GROUP = _GroupProxy('h')
 # Layers with at least this many rows launch their input and weight gradient separately: each then runs with 192-element k-tiles
 # (gemm_deepk_kernel: a third of the barrier-bound links), which the grouped kernel does not have.  Measured, scenes/s: no grouping
 # 943, limit 1024 rows 939, limit 16384 rows (every small layer grouped) 927.
 _GROUP_MAX_ROWS = 8192      # re-measured at the end of round 2: 1024 -> 1071, 4096 -> 1082, 8192 -> 1088, 16384 -> 1078, 65536 -> 1064 scenes/s
-_GROUP_DEPTH = [0]
+_GROUP_DEPTH = _GroupProxy('depth')
 
 
 class gemm_group:
@@ -750,8 +773,14 @@ def _swin_ws(x, M, C):
     the other widths take none."""
     if C != 384:
         return None
-    from ._lib import lib
-    return torch.empty(int(lib().stj_swin_split_workspace_bytes(M, C)) // 4, dtype=torch.float32, device=x.device)
+    # ONE buffer per (device, size), reused by every C = 384 block in stream order (the kernel and its finishing launch are through with it
+    # before the next block's kernel on the same stream starts): allocating it per call grew the graph's private pool by 25-100 MB per block
+    key = (str(x.device), 'swin_split', int(M), int(C), torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        from ._lib import lib
+        ws = _WS[key] = torch.empty(int(lib().stj_swin_split_workspace_bytes(M, C)) // 4, dtype=torch.float32, device=x.device)
+    return ws
 
 
 # ----------------------------------------------------------------------------------------------------

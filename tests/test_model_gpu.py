@@ -611,8 +611,11 @@ def test_bench_two_ranks_on_one_gpu():
         assert d['config']['optimizer_in_step'] and d['scaling'] == 'weak'
         assert d['distributed']['ranks'] == 2 and d['distributed']['ranks_seen_by_allreduce'] == 2
         assert d['distributed']['allreduce_overlapped_with_backward'] == (mode == 'overlap') == d['allreduce']['overlapped']
-    # same seeds, same draws: three Nadam steps on all-reduced gradients must land on the same loss whichever way they were exchanged
+    # same seeds, same draws: three Nadam steps on all-reduced gradients must land on the same loss whichever way they were exchanged --
+    # rank 0's own shard and the global batch (sum of the replica-scaled losses of both ranks)
     assert abs(res['overlap']['loss'] - res['one_bucket']['loss']) < 2e-3 * abs(res['one_bucket']['loss'])
+    lg = [res[m]['distributed']['loss_global_batch'] for m in ('overlap', 'one_bucket')]
+    assert abs(lg[0] - lg[1]) < 2e-3 * abs(lg[1]) and lg[1] > res['one_bucket']['loss']
 
 
 def test_golden_train_step_gradients_f32():
