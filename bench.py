@@ -587,9 +587,6 @@ def main():
         chk = torch.ones(1, device=dev)
         dist.all_reduce(chk)
         dist_info['ranks_seen_by_allreduce'] = int(chk.item())       # every rank contributed 1: proof the collective spans N ranks
-        lg = torch.tensor([loss_val], dtype=torch.float64, device=dev)
-        dist.all_reduce(lg)                                          # the replica-scaled losses add up to the loss of the global batch
-        dist_info['loss_global_batch'] = round(float(lg.item()), 4)
     # per-kernel HIP-event timing of EVERY C-ABI launch (strajnet_amd/prof.py): the same launches, issued eagerly with events
     # recorded on the launch stream -- under graph replay individual launches cannot carry events
     prof_ser = prof_conc = None
@@ -617,6 +614,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t.item())
     loss_val = float(last.detach())
+    if world > 1:
+        lg = torch.tensor([loss_val], dtype=torch.float64, device=dev)
+        dist.all_reduce(lg)                                          # the replica-scaled losses add up to the loss of the global batch
+        dist_info['loss_global_batch'] = round(float(lg.item()), 4)
     feed = None
     if rank == 0 and world == 1 and graphed is not None and not args.no_extra_configs and not args.no_kernel_timing:
         try:

@@ -904,6 +904,10 @@ static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* 
   //  128-pixel chunks: with 256 the register-staged prefetch spills)
   if (Hi % (256 / CW) == 0 && nchunks >= 2048) {
     if (Cout <= 48 && Cin <= 96) return wgrad_tr4_launch<3, 6, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, 1, wg_budget, st);
+    // 128 -> 96: ALL 96 couts x 64 cins per workgroup (24 accumulator fragments per wave).  As 64 x 64 channel tiles the layer is 4 tiles,
+    // the second cout tile half empty: every X slice staged twice, every dP slice twice, a quarter of the MFMAs on zero rows.
+    // (B = 8, 64 x 64: 153 vs 188 us alone on the GPU)
+    if (Cout == 96 && Cin % 64 == 0) return wgrad_tr4_launch<6, 4, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, Cin / 64, wg_budget, st);
     return wgrad_tr4_launch<4, 4, CW, 128>(X, dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, ((Cout + 63) / 64) * ((Cin + 63) / 64), wg_budget, st);
   }
   if (Cout <= 48 && Cin <= 96) {
