@@ -16,7 +16,10 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def tol(dt):
-    return {torch.float32: 2e-4, torch.bfloat16: 4e-2, torch.float16: 6e-3}[dt]
+    # bf16: 2e-2 of the tensor maximum (round 3: 4e-2).  Swept on MI355X: every op-level test passes at 2e-2; at 1e-2 only the three
+    # C = 384 fused attention-half cases fail (the kernels of the timed step have their own per-element bounds in
+    # test_timed_kernels_gpu.py, test_wgrad_sk_gpu.py and test_inference_heads_in_upconv_epilogue)
+    return {torch.float32: 2e-4, torch.bfloat16: 2e-2, torch.float16: 6e-3}[dt]
 
 
 def rel_err(a, ref):

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Deep PMC look at ONE micro-benchmark command (several rocprofv3 --pmc passes, --kernel-trace only), per kernel means.
+# (SQ counters only: a TCP_* set aborted rocprofv3 and hung the box's session for 20 minutes.)
 #   usage: tools/pmc_kernel.sh <tag> <kernel name substring> -- <command ...>      -> gpurun_out/<tag>_pmc_kernel.txt
 tag=$1; pat=$2; shift 3
 cd $GRAFT_REPO_ROOT 2>/dev/null || true
@@ -9,12 +10,9 @@ out=gpurun_out/${tag}_pmc_kernel.txt; : > $out
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_SCA" \
-           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" \
-           "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_ACCESSES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" \
-           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_BUSY_sum TCC_CYCLE_sum" \
-           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum"; do
+           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS"; do
   i=$((i+1)); rm -rf /tmp/pk_$i
-  rocprofv3 --kernel-trace --output-format csv --pmc $set -d /tmp/pk_$i -- "$@" > /dev/null 2>> gpurun_out/${tag}_pmc_kernel.err
+  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $set -d /tmp/pk_$i -- "$@" > /dev/null 2>> gpurun_out/${tag}_pmc_kernel.err
   c=$(find /tmp/pk_$i -name '*counter_collection.csv' | head -1); k=$(find /tmp/pk_$i -name '*kernel_trace.csv' | head -1)
   python - "$c" "$k" "$pat" >> $out <<'P'
 import csv, sys, collections
