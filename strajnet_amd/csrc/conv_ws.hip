@@ -1513,25 +1513,34 @@ bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* 
 // 96<-48 @128x128 (profiles/r01_b_*).
 // =====================================================================================================
 template <int KS, int NFI, bool ELU, int COUT>
-__global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ Wd,
+__global__ __launch_bounds__(512, 1) void upconv_dgrad_ws_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ Wd,
                                                                  bf16* __restrict__ dX, const bf16* __restrict__ Xelu, int F, int Hi,
                                                                  int Wi, int Cin, int ntiles) {
   constexpr int Cout = COUT;                       // compile time: the halo loader divides by Cout / 8 forty times per tile (a runtime
                                                    // divisor cost ~1400 VALU instructions per tile, a quarter of the tile's time)
   // halo pixel stride.  A fragment read takes every OTHER halo pixel (low-res pixel ln <-> high-res 2 ln + v), so consecutive lanes are
   // 2 * LDK apart: conflict-free b128 reads need 2 * LDK = 2 (mod 4) 16-byte slots, i.e. an ODD number of slots per pixel -> +8 elements
-  // (9 / 13 slots).  (+16 -- the right padding for the stride-1 reads of the forward kernel -- measured 36 % LDS bank-conflict cycles
-  // here for KS = 2; the kernel time did not move with the fix, so conflicts are not what bounds it.)  Channels >= Cout stay zero.
+  // (9 / 13 slots).  Channels >= Cout stay zero.
   constexpr int LDK = KS * 32 + 8;
   constexpr int HH = 2 * WS_TH + 2, HW = 2 * WS_TW + 2, HPIX = HH * HW;
   constexpr int CT = NFI * 16;                     // cin tile of this workgroup
-  constexpr int LDR = CT + 4;                      // reduction row stride (floats)
+  constexpr int LDR = CT + 4;                      // partial-tile row stride (bf16): 34 dwords (two stages + the halo = 158.4 KB of the 160)
+  constexpr int RED = 4 * 2 * 16 * LDR;            // one partial stage: [4 phases][2 rows][16 px][LDR]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16* halo = reinterpret_cast<bf16*>(smem_raw);                         // [HPIX][LDK] (+64 tail)
-  float* red = reinterpret_cast<float*>(smem_raw + (size_t)(HPIX * LDK + 64) * 2);   // [4 waves][2 rows][16 px][LDR]
+  bf16* red0 = reinterpret_cast<bf16*>(smem_raw + (size_t)(HPIX * LDK + 64) * 2);   // 2 stages
   constexpr int CPP = Cout / 8;                    // 16-byte chunks per halo pixel (Cout <= KS*32)
   static_assert(COUT % 8 == 0 && COUT <= KS * 32, "halo pixel holds KS*32 channels");
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // 8 waves: wave = (input phase (a,b), half of the cin tile), 96 weight VGPRs each, two waves per SIMD.  A pass (2 low-res rows) is ONE
+  // barrier interval holding three things that used to be three serial phases (measured by ablation, 128 <- 96 @64x64 F = 64: 68 us of
+  // MFMA + 37 us waiting for the halo prefetch + 14 us of phase reduction + 43 us of barriers and bookkeeping = the kernel's 154 us):
+  //   * the MFMAs of pass p -> this wave's partial tile (bf16) into stage p & 1;
+  //   * the phase reduction + ELU' + store of pass p - 1 from stage (p - 1) & 1 -- the waves of half 0 do it BEFORE their MFMAs, those
+  //     of half 1 AFTER, so on every SIMD one wave reduces / stores while the other feeds the matrix pipe;
+  //   * the next tile's halo rows for the rows this pass frees: loads issued at the top, written behind the barrier.
+  constexpr int NT = 512, NFW = NFI / 2;
+  static_assert(NFI % 2 == 0, "cin tile splits into two halves");
+  const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3, half = tid >> 8;
   const int a = w >> 1, b = w & 1;
   const int g = lane >> 4, ln = lane & 15;
   const int n0 = blockIdx.y * CT;
@@ -1539,14 +1548,14 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
   const int Ho = 2 * Hi, Wo = 2 * Wi;
 
   // stationary weights: A[m = cin][k = cout] = Wd[(u+1)*4 + (v+1)][cin][cout]
-  s16x8 wd[4][NFI][KS];
+  s16x8 wd[4][NFW][KS];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int r = t >> 1, s = t & 1;
     const int uv = (2 - a - 2 * r + 1) * 4 + (2 - b - 2 * s + 1);
 #pragma unroll
-    for (int n = 0; n < NFI; ++n) {
-      const int ci = n0 + n * 16 + ln;
+    for (int n = 0; n < NFW; ++n) {
+      const int ci = n0 + (half * NFW + n) * 16 + ln;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int co = ks * 32 + g * 8;
@@ -1555,141 +1564,157 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_ws_kernel(const bf16* __r
       }
     }
   }
-  for (int i = tid; i < (HPIX * LDK + 64) / 2; i += 256) reinterpret_cast<uint32_t*>(halo)[i] = 0u;
+  // the weights are complete HERE on every path: without this the waitcnt pass carries "weight loads may be pending" into the tile
+  // loop (through the path that skips the first tile's commit) and opens every pass's MFMA block with vmcnt(0) -- which also waits
+  // for the halo prefetch issued a few instructions earlier, i.e. exposes the whole HBM latency once per pass
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+  for (int i = tid; i < (HPIX * LDK + 64) / 2; i += NT) reinterpret_cast<uint32_t*>(halo)[i] = 0u;
   __syncthreads();
 
-  constexpr int NCH_MAX = (HPIX * CPP + 255) / 256;
-  uint4 pre[NCH_MAX];
+  // rolling halo: pass mf reads halo rows 2 mf .. 2 mf + 5, so rows 2 mf .. 2 mf + 3 are dead once its fragments are read (the last pass
+  // frees 6) and take the NEXT tile's rows: 5 uint4 of prefetch per thread instead of a whole tile's 15.
+  constexpr int NPRE = (6 * HW * CPP + NT - 1) / NT;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  u32x4 pre[NPRE];
   auto tile_coords = [&](int tile, int& f, int& ty0, int& tx0) {
     const int tx = tile % tiles_x; const int t2 = tile / tiles_x;
     ty0 = (t2 % tiles_y) * WS_TH; f = t2 / tiles_y; tx0 = tx * WS_TW;
   };
-  auto prefetch = [&](int tile) {
-    int f, ty0, tx0;
-    tile_coords(tile, f, ty0, tx0);
-    const bf16* Pf = dP + (long long)f * Ho * Wo * Cout;
+  // raw buffer loads: a pixel outside the image (or a thread beyond the row group) asks for an offset past the end and gets the zero
+  // padding from the hardware -- no guards, so the loads are straight-line code the waitcnt pass can count
+  const __amdgpu_buffer_rsrc_t dPr = __builtin_amdgcn_make_buffer_rsrc((void*)dP, 0, (unsigned)((long long)F * Ho * Wo * Cout * 2), 0x00020000);
+  auto prefetch = [&](int f, int ty0, int tx0, int r0, int nr) {
 #pragma unroll
-    for (int i = 0; i < NCH_MAX; ++i) {
-      const int q = tid + i * 256;
+    for (int i = 0; i < NPRE; ++i) {
+      const int q = tid + i * NT;
       const int px = q / CPP, ch = (q % CPP) * 8;
-      const int gy = 2 * ty0 + px / HW - 1, gx = 2 * tx0 + px % HW - 1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (q < HPIX * CPP && gy >= 0 && gy < Ho && gx >= 0 && gx < Wo) v = *reinterpret_cast<const uint4*>(Pf + ((long long)gy * Wo + gx) * Cout + ch);
-      pre[i] = v;
+      const int gy = 2 * ty0 + r0 + px / HW - 1, gx = 2 * tx0 + px % HW - 1;
+      const bool ok = q < nr * HW * CPP && gy >= 0 && gy < Ho && gx >= 0 && gx < Wo;
+      const unsigned off = ok ? (unsigned)((((f * Ho + gy) * Wo + gx) * Cout + ch) * 2) : 0xffffffe0u;
+      pre[i] = __builtin_amdgcn_raw_buffer_load_b128(dPr, off, 0, 0);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int r0, int nr) {
 #pragma unroll
-    for (int i = 0; i < NCH_MAX; ++i) {
-      const int q = tid + i * 256;
-      if (q < HPIX * CPP) *reinterpret_cast<uint4*>(halo + (q / CPP) * LDK + (q % CPP) * 8) = pre[i];
+    for (int i = 0; i < NPRE; ++i) {
+      const int q = tid + i * NT;
+      if (q < nr * HW * CPP) *reinterpret_cast<u32x4*>(halo + (r0 * HW + q / CPP) * LDK + (q % CPP) * 8) = pre[i];
     }
+  };
+  // phase reduction of one finished pass: thread = (row m, pixel, 4 cins); 4 x 8-byte partials -> f32 sum -> ELU' -> 8-byte store
+  static_assert(2 * 16 * (CT / 4) == NT, "one reduction item per thread");
+  const int rc4 = (tid % (CT / 4)) * 4, rp = tid / (CT / 4);            // rp = m * 16 + px
+  auto reduce = [&](const bf16* red, int f, int ty0, int tx0, int mf, uint2 xin) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const uint2 t = *reinterpret_cast<const uint2*>(red + (ww * 32 + rp) * LDR + rc4);
+      v[0] += __uint_as_float(t.x << 16); v[1] += __uint_as_float(t.x & 0xffff0000u);
+      v[2] += __uint_as_float(t.y << 16); v[3] += __uint_as_float(t.y & 0xffff0000u);
+    }
+    const int oy = ty0 + mf + (rp >> 4), ox = tx0 + (rp & 15), ci = n0 + rc4;
+    if (oy < Hi && ox < Wi && ci < Cin) {             // Cin % 8 == 0 (dispatch)
+      if constexpr (ELU) {      // layer input is an ELU output: return the gradient w.r.t. the producer's pre-activation
+        const uint32_t xw[2] = {xin.x, xin.y};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
+          v[2 * e] *= x0 > 0.f ? 1.f : x0 + 1.f;
+          v[2 * e + 1] *= x1 > 0.f ? 1.f : x1 + 1.f;
+        }
+      }
+      *reinterpret_cast<uint2*>(dX + ((long long)f * Hi * Wi + (long long)oy * Wi + ox) * Cin + ci) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+    }
+  };
+  auto load_xin = [&](int f, int ty0, int tx0, int mf) {
+    uint2 x = make_uint2(0x3f803f80u, 0x3f803f80u);
+    if constexpr (ELU) {
+      const int oy = ty0 + mf + (rp >> 4), ox = tx0 + (rp & 15), ci = n0 + rc4;
+      if (oy < Hi && ox < Wi && ci < Cin) x = *reinterpret_cast<const uint2*>(Xelu + ((long long)f * Hi * Wi + (long long)oy * Wi + ox) * Cin + ci);
+    }
+    return x;
+  };
+  f32x4 acc[2][NFW];
+  auto mfma_taps = [&](int mf, const int r) {      // the two taps (r, 0), (r, 1) of this wave's phase
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int u1 = 2 - a - 2 * r + 1, v1 = 2 - b - 2 * s + 1;      // halo offsets (u+1, v+1)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s16x8 xb[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          xb[m] = *reinterpret_cast<const s16x8*>(halo + ((2 * (mf + m) + u1) * HW + 2 * ln + v1) * LDK + ks * 32 + g * 8);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NFW; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wd[r * 2 + s][n][ks]),
+                                                                __builtin_bit_cast(bf16x8_t, xb[m]), acc[m][n], 0, 0, 0);
+      }
+    }
+  };
+  auto acc_zero = [&]() {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NFW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto acc_store = [&](bf16* red) {      // partial tile of this phase -> LDS: lane holds cins (half*NFW + n)*16 + g*4 + 0..3 of pixel (mf+m, ln)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NFW; ++n)
+        *reinterpret_cast<uint2*>(red + ((w * 2 + m) * 16 + ln) * LDR + (half * NFW + n) * 16 + g * 4) =
+            make_uint2(pack2bf(acc[m][n][0], acc[m][n][1]), pack2bf(acc[m][n][2], acc[m][n][3]));
   };
 
-  int tile = blockIdx.x;
-  if (tile < ntiles) { prefetch(tile); commit(); }
-  __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int next = tile + gridDim.x;
-    if (next < ntiles) prefetch(next);
+  int tile = blockIdx.x;              // < ntiles (launcher)
+  {
     int f, ty0, tx0;
     tile_coords(tile, f, ty0, tx0);
-    bf16* Xf = dX + (long long)f * Hi * Wi * Cin;
+    for (int r0 = 0; r0 < HH; r0 += 6) { prefetch(f, ty0, tx0, r0, 6); commit(r0, 6); }
+  }
+  __syncthreads();
+  int pf = 0, pty0 = 0, ptx0 = 0, pmf = -1, stage = 0;      // the pass waiting for its reduction (pmf < 0: none)
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    int f, ty0, tx0, nf = 0, nty0 = 0, ntx0 = 0;
+    tile_coords(tile, f, ty0, tx0);
+    if (next < ntiles) tile_coords(next, nf, nty0, ntx0);
 #pragma unroll 1
     for (int mf = 0; mf < WS_TH; mf += 2) {
-      // ELU' operand of the epilogue (layer input x): issued before the MFMA work so its latency is hidden.  The epilogue works
-      // in 8-channel (16-byte) items: 2 rows x 16 pixels x CT/8 of them per pass
-      constexpr int NIT = 2 * 16 * (CT / 8);
-      constexpr int NEP = (NIT + 255) / 256;
-      uint4 xin[ELU ? NEP : 1];
-      if constexpr (ELU) {
-#pragma unroll
-        for (int i = 0; i < NEP; ++i) {
-          const int q = tid + i * 256;
-          const int c8 = (q % (CT / 8)) * 8, p = q / (CT / 8);
-          const int oy = ty0 + mf + (p >> 4), ox = tx0 + (p & 15), ci = n0 + c8;
-          xin[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-          if (q < NIT && oy < Hi && ox < Wi && ci < Cin)
-            xin[i] = *reinterpret_cast<const uint4*>(Xelu + ((long long)f * Hi * Wi + (long long)oy * Wi + ox) * Cin + ci);
-        }
+      const int pr0 = 2 * mf, pnr = mf == WS_TH - 2 ? 6 : 4;
+      if (next < ntiles) prefetch(nf, nty0, ntx0, pr0, pnr);
+      uint2 xin = make_uint2(0x3f803f80u, 0x3f803f80u);
+      if (pmf >= 0) xin = load_xin(pf, pty0, ptx0, pmf);
+      bf16* rcur = red0 + stage * RED;
+      const bf16* rprev = red0 + (stage ^ 1) * RED;
+      // half 0 reduces first, half 1 between its two tap rows: one wave of a SIMD reduces while the other runs MFMAs, and every store
+      // is at least half a pass old when the commit behind the barrier waits for the prefetch (vmcnt(0) waits for stores too)
+      acc_zero();
+      if (half == 0) {
+        if (pmf >= 0) reduce(rprev, pf, pty0, ptx0, pmf, xin);
+        mfma_taps(mf, 0);
+        mfma_taps(mf, 1);
+      } else {
+        mfma_taps(mf, 0);
+        if (pmf >= 0) reduce(rprev, pf, pty0, ptx0, pmf, xin);
+        mfma_taps(mf, 1);
       }
-      f32x4 acc[2][NFI];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NFI; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int u1 = 2 - a - 2 * r + 1, v1 = 2 - b - 2 * s + 1;      // halo offsets (u+1, v+1)
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            s16x8 xb[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-              xb[m] = *reinterpret_cast<const s16x8*>(halo + ((2 * (mf + m) + u1) * HW + 2 * ln + v1) * LDK + ks * 32 + g * 8);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-              for (int n = 0; n < NFI; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wd[r * 2 + s][n][ks]),
-                                                                    __builtin_bit_cast(bf16x8_t, xb[m]), acc[m][n], 0, 0, 0);
-          }
-        }
-      // partial tile of this phase -> LDS: lane holds cins n*16 + g*4 + 0..3 of pixel (mf+m, ln)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NFI; ++n)
-          *reinterpret_cast<float4*>(red + ((w * 2 + m) * 16 + ln) * LDR + n * 16 + g * 4) = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+      acc_store(rcur);
       __syncthreads();
-      // the halo is dead once the last pass's fragments are read: the next tile goes in HERE, before this pass's stores are issued --
-      // after them, the commit's wait for the prefetched registers (vmcnt(0): the loads sit under guards, so the compiler cannot
-      // count) would also wait for those stores, once per tile
-      if (mf == WS_TH - 2 && next < ntiles) commit();
-      // sum the 4 phases, 8 channels per thread-iteration, coalesced 16-byte stores
-#pragma unroll
-      for (int i = 0; i < NEP; ++i) {
-        const int q = tid + i * 256;
-        if (q >= NIT) break;
-        const int c8 = (q % (CT / 8)) * 8, p = q / (CT / 8);      // p = m*16 + px
-        const int m = p >> 4, px = p & 15;
-        const float* rp = red + p * LDR + c8;
-        float v[8];
-        {
-          const float4 a0 = *reinterpret_cast<const float4*>(rp), a1 = *reinterpret_cast<const float4*>(rp + 4);
-          v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-        }
-#pragma unroll
-        for (int ww = 1; ww < 4; ++ww) {
-          const float4 t0 = *reinterpret_cast<const float4*>(rp + ww * 2 * 16 * LDR), t1 = *reinterpret_cast<const float4*>(rp + ww * 2 * 16 * LDR + 4);
-          v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
-        }
-        const int oy = ty0 + mf + m, ox = tx0 + px, ci = n0 + c8;
-        if (oy < Hi && ox < Wi && ci < Cin) {             // Cin % 8 == 0 (dispatch)
-          if constexpr (ELU) {      // layer input is an ELU output: return the gradient w.r.t. the producer's pre-activation
-            const uint32_t xw[4] = {xin[i].x, xin[i].y, xin[i].z, xin[i].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
-              v[2 * e] *= x0 > 0.f ? 1.f : x0 + 1.f;
-              v[2 * e + 1] *= x1 > 0.f ? 1.f : x1 + 1.f;
-            }
-          }
-          *reinterpret_cast<uint4*>(Xf + ((long long)oy * Wi + ox) * Cin + ci) =
-              make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-        }
-      }
-      __syncthreads();
+      if (next < ntiles) commit(pr0, pnr);
+      pf = f; pty0 = ty0; ptx0 = tx0; pmf = mf; stage ^= 1;
     }
   }
+  if (pmf >= 0) reduce(red0 + (stage ^ 1) * RED, pf, pty0, ptx0, pmf, load_xin(pf, pty0, ptx0, pmf));
 }
 
 template <int KS, int NFI, bool ELU, int COUT>
 static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   constexpr int LDK = KS * 32 + 8, HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), CT = NFI * 16, LDR = CT + 4;
-  const size_t lds = (size_t)(HPIX * LDK + 64) * 2 + (size_t)4 * 2 * 16 * LDR * 4;
+  const size_t lds = (size_t)(HPIX * LDK + 64) * 2 + (size_t)2 * 4 * 2 * 16 * LDR * 2;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)upconv_dgrad_ws_kernel<KS, NFI, ELU, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
@@ -1700,7 +1725,7 @@ static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const voi
   int nblk = 256 / ct;
   if (nblk > ntiles) nblk = ntiles;
   if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL((upconv_dgrad_ws_kernel<KS, NFI, ELU, COUT>), dim3(nblk, ct), dim3(256), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX,
+  hipLaunchKernelGGL((upconv_dgrad_ws_kernel<KS, NFI, ELU, COUT>), dim3(nblk, ct), dim3(512), lds, st, (const bf16*)dP, (const bf16*)Wd, (bf16*)dX,
                      (const bf16*)Xelu, F, Hi, Wi, Cin, ntiles);
   return true;
 }
