@@ -68,6 +68,9 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const T* __
       const int co = n0 + n * 16 + g * 4 + r;
       bv[n][r] = co < Cout ? bias[co] : 0.f;
     }
+  // weights and bias are complete HERE on every path (see upconv_dgrad_ws_kernel: otherwise every tile's MFMA block opens with a
+  // vmcnt(0) that also waits for the halo prefetch issued just before it)
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 
   auto tile_coords = [&](int tile, int& f, int& ty0, int& tx0) {
     const int tx = tile % tiles_x; const int t2 = tile / tiles_x;

@@ -364,14 +364,17 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
     const long long row = m0 + 16 * i + ln;
     if (row >= p.M) continue;
     const float dp = drop_path_scale(p.rng, p.site, row / p.rows_per_sample, p.p_drop);
+    float xs[NF][4];              // the shortcut row, read before the first store: y may alias x, so a load left in the store loop
+                                  // waits behind the previous store -- NF dependent round trips at the end of every wave
+    float4 bs[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { ld4(x + row * C + 16 * f + 4 * g, xs[f]); bs[f] = *reinterpret_cast<const float4*>(p.b2 + 16 * f + 4 * g); }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int col = 16 * f + 4 * g;
-      const float4 bv = *reinterpret_cast<const float4*>(p.b2 + col);
-      float xv[4];
-      ld4(x + row * C + col, xv);
-      const float v[4] = {xv[0] + dp * (acc2[i][f][0] + bv.x), xv[1] + dp * (acc2[i][f][1] + bv.y),
-                          xv[2] + dp * (acc2[i][f][2] + bv.z), xv[3] + dp * (acc2[i][f][3] + bv.w)};
+      const float4 bv = bs[f];
+      const float v[4] = {xs[f][0] + dp * (acc2[i][f][0] + bv.x), xs[f][1] + dp * (acc2[i][f][1] + bv.y),
+                          xs[f][2] + dp * (acc2[i][f][2] + bv.z), xs[f][3] + dp * (acc2[i][f][3] + bv.w)};
       st4(y + row * C + col, v);
     }
   }
@@ -520,7 +523,12 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
     const long long row = m0 + 16 * i + ln;
     const bool live = row < p.M;
     float xh[NF][4];
+    float dyv[NF][4];             // read up front: dx may alias dy, so loads left in the store loop below are serialised behind each store
     float s1 = 0.f, s2 = 0.f;
+    if (live) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) ld4(dy + row * C + 16 * f + 4 * g, dyv[f]);
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int col = 16 * f + 4 * g;
@@ -546,11 +554,9 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const int col = 16 * f + 4 * g;
-        float dv[4];
-        ld4(dy + row * C + col, dv);
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = dv[r] + rs[i] * (acc[i][f][r] - s1 - xh[f][r] * s2);
+        for (int r = 0; r < 4; ++r) v[r] = dyv[f][r] + rs[i] * (acc[i][f][r] - s1 - xh[f][r] * s2);
         st4(dx + row * C + col, v);
       }
     }
@@ -1049,13 +1055,15 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   const float dp = drop_path_scale(p.rng, p.site, b, p.p_drop);
   T* y = reinterpret_cast<T*>(p.y) + myrow * C;
   const T* xr = reinterpret_cast<const T*>(p.x) + myrow * C;
+  float xs[NF][4];                // shortcut row read before the first store (y may alias x: see swin_mlp_fwd_kernel)
+  float4 bs[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) { ld4(xr + 16 * f + 4 * g, xs[f]); bs[f] = *reinterpret_cast<const float4*>(p.bproj + 16 * f + 4 * g); }
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     const int col = 16 * f + 4 * g;
-    const float4 bv = *reinterpret_cast<const float4*>(p.bproj + col);
-    float xv[4];
-    ld4(xr + col, xv);
-    const float v[4] = {xv[0] + dp * (acco[f][0] + bv.x), xv[1] + dp * (acco[f][1] + bv.y), xv[2] + dp * (acco[f][2] + bv.z), xv[3] + dp * (acco[f][3] + bv.w)};
+    const float4 bv = bs[f];
+    const float v[4] = {xs[f][0] + dp * (acco[f][0] + bv.x), xs[f][1] + dp * (acco[f][1] + bv.y), xs[f][2] + dp * (acco[f][2] + bv.z), xs[f][3] + dp * (acco[f][3] + bv.w)};
     st4(y + col, v);
   }
 }
@@ -1478,7 +1486,10 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
     const T* dyr = reinterpret_cast<const T*>(p.dy) + myrow * C;
     T* dxr = reinterpret_cast<T*>(p.dx) + myrow * C;
     float xh[NF][4];
+    float dyv[NF][4];             // read up front: dx may alias dy, so loads left in the store loop below are serialised behind each store
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) ld4(dyr + 16 * f + 4 * g, dyv[f]);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int col = 16 * f + 4 * g;
@@ -1505,11 +1516,9 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int col = 16 * f + 4 * g;
-      float dv_[4];
-      ld4(dyr + col, dv_);
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = dv_[r] + rs * (dln[f][r] - s1 - xh[f][r] * s2);
+      for (int r = 0; r < 4; ++r) v[r] = dyv[f][r] + rs * (dln[f][r] - s1 - xh[f][r] * s2);
       st4(dxr + col, v);
     }
   }

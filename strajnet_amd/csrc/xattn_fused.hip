@@ -422,15 +422,21 @@ __global__ __launch_bounds__(256, 1) void xattn_fwd_kernel(Args p) {
   const float rstd = rsqrtf(q * (1.f / CB) + 1e-3f);
   T* y = reinterpret_cast<T*>(p.y) + zrow * CB;
   const T* xr = reinterpret_cast<const T*>(p.query) + zrow * CB;
+  float xs[CB / 16][4];           // the query row, read before the first store: y may alias it, and a load left in the store loop waits
+                                  // behind the previous store (24 dependent round trips at the end of every wave)
+  float4 gms[CB / 16], bts[CB / 16];
+#pragma unroll
+  for (int f = 0; f < CB / 16; ++f) {
+    ld4(xr + 16 * f + 4 * g, xs[f]);
+    gms[f] = *reinterpret_cast<const float4*>(p.g2 + zo + 16 * f + 4 * g);
+    bts[f] = *reinterpret_cast<const float4*>(p.be2 + zo + 16 * f + 4 * g);
+  }
 #pragma unroll
   for (int f = 0; f < CB / 16; ++f) {
     const int col = 16 * f + 4 * g;
-    const float4 gm = *reinterpret_cast<const float4*>(p.g2 + zo + col);
-    const float4 bt = *reinterpret_cast<const float4*>(p.be2 + zo + col);
-    float xv[4];
-    ld4(xr + col, xv);
-    const float v[4] = {(o2[f][0] - mean) * rstd * gm.x + bt.x + xv[0], (o2[f][1] - mean) * rstd * gm.y + bt.y + xv[1],
-                        (o2[f][2] - mean) * rstd * gm.z + bt.z + xv[2], (o2[f][3] - mean) * rstd * gm.w + bt.w + xv[3]};
+    const float4 gm = gms[f], bt = bts[f];
+    const float v[4] = {(o2[f][0] - mean) * rstd * gm.x + bt.x + xs[f][0], (o2[f][1] - mean) * rstd * gm.y + bt.y + xs[f][1],
+                        (o2[f][2] - mean) * rstd * gm.z + bt.z + xs[f][2], (o2[f][3] - mean) * rstd * gm.w + bt.w + xs[f][3]};
     st4(y + col, v);
   }
 }
@@ -884,11 +890,12 @@ __global__ __launch_bounds__(256, 1) void xattn_bwd_kernel(Args p) {
   {
     const T* dyr = reinterpret_cast<const T*>(p.dy) + zrow * CB + 4 * g;
     T* dqr = reinterpret_cast<T*>(p.dquery) + zrow * CB + 4 * g;
+    float dv[CB / 16][4];         // read before the first store (dquery may alias dy: see xattn_fwd_kernel)
+#pragma unroll
+    for (int f = 0; f < CB / 16; ++f) ld4(dyr + 16 * f, dv[f]);
 #pragma unroll
     for (int f = 0; f < CB / 16; ++f) {
-      float dv[4];
-      ld4(dyr + 16 * f, dv);
-      const float v[4] = {dv[0] + dqy[f][0], dv[1] + dqy[f][1], dv[2] + dqy[f][2], dv[3] + dqy[f][3]};
+      const float v[4] = {dv[f][0] + dqy[f][0], dv[f][1] + dqy[f][1], dv[f][2] + dqy[f][2], dv[f][3] + dqy[f][3]};
       st4(dqr + 16 * f, v);
     }
   }
