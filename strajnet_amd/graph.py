@@ -52,13 +52,19 @@ class GraphedTrainStep:
         m.zero_grad()
         tw = warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow'])
         main = torch.cuda.current_stream()
-        if hasattr(self.loss_fn, 'prepare'):         # the ground-truth-only part of the loss: side stream, under the forward pass
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                self.loss_fn.prepare(tw)
-        out = m(x['ogm'], x['map_img'], training=self.training, obs=x['obs'], occ=x['occ'], mapt=x.get('mapt'), flow=x['flow'])
+        if hasattr(self.loss_fn, 'prepare'):         # the ground-truth-only part of the loss: side stream, under the forward pass --
+            if self._side is None:                   # issued from the model's mid-forward hook (behind the encoder's first stage: at the
+                self._side = torch.cuda.Stream()     # head of the step its two launches delayed the first encoder kernel)
+
+            def prepare():
+                self._side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side):
+                    self.loss_fn.prepare(tw)
+            m.mid_forward_hook = prepare
+        try:
+            out = m(x['ogm'], x['map_img'], training=self.training, obs=x['obs'], occ=x['occ'], mapt=x.get('mapt'), flow=x['flow'])
+        finally:
+            m.mid_forward_hook = None
         if self._side is not None:
             main.wait_stream(self._side)
         d = self.loss_fn(get_pred_waypoint_logits(out), tw, None)

@@ -240,6 +240,7 @@ class STrajNet:
         # (the parity tests run both and compare)
         self.fused_xattn = True
         self.agent_issue_mode = 2
+        self.mid_forward_hook = None          # callable run once per forward pass behind the encoder's first stage (GraphedTrainStep: loss.prepare on its side stream)
         self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (16-bit modes, 8 x 8 / 16 x 16 maps)
         self._xattn_pack = None
         self.params = OrderedDict()
@@ -785,18 +786,20 @@ class STrajNet:
                  'decoder/upconvf_0_0')
         self._prep_event = None
         self._xattn_pack_stale = True
-        if self._side2 is not None:
-            self._side2.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self._side2):
+
+        def issue_prep():
+            if self._side2 is not None:
+                self._side2.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._side2):
+                    if self.fused_xattn:
+                        self._pack_xattn()
+                    self._upconv_prep = {n: ops.upconv_prep(self._p(n + '/kernel'), self.dtype) for n in names}
+                    self._prep_event = torch.cuda.Event()
+                    self._prep_event.record(self._side2)
+            else:
                 if self.fused_xattn:
                     self._pack_xattn()
                 self._upconv_prep = {n: ops.upconv_prep(self._p(n + '/kernel'), self.dtype) for n in names}
-                self._prep_event = torch.cuda.Event()
-                self._prep_event.record(self._side2)
-        else:
-            if self.fused_xattn:
-                self._pack_xattn()
-            self._upconv_prep = {n: ops.upconv_prep(self._p(n + '/kernel'), self.dtype) for n in names}
         # The agent branch (trajNet: a dependent chain of ~45 small launches that occupy a few CUs each, ~0.4 ms end to end) is
         # independent of the raster encoder up to the cross-attention: it runs on a side stream, forked HERE.  Its launches are ISSUED
         # after the encoder's first stage though: a replayed hipGraph starts branches roughly in node-creation order, and issued first
@@ -816,7 +819,22 @@ class STrajNet:
             issue_agent()
         elif mode < 0:
             agent.extend(self._traj_net(obs, occ))
-        res_list = self._encoder(ogm, map_img, flow, hook=issue_agent if mode == 2 else None)
+        # Side work that is not needed before the cross-attention / the decoder / the loss is ISSUED behind the encoder's first stage
+        # too: a replayed hipGraph starts its first ~20 nodes one after the other whatever their stream, so the seven packing /
+        # folding launches and the caller's mid_forward_hook (graph.py: the ground-truth half of the loss) at the head of the step kept
+        # the first encoder kernel waiting until 142 us (profiles/r04_b_timeline_concurrent.txt)
+        late = mode == 2 and self._side2 is not None
+        if not late:
+            issue_prep()
+
+        def hook():
+            if mode == 2:
+                issue_agent()
+            if late:
+                issue_prep()
+            if self.mid_forward_hook is not None:
+                self.mid_forward_hook()
+        res_list = self._encoder(ogm, map_img, flow, hook=hook)
         if mode == 1:
             issue_agent()
         key, tmask = agent
