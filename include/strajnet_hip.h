@@ -127,11 +127,11 @@ int stj_win_attn_bwd(const void* qkv, const float* table, const void* dout, void
  *        of the two weight gradients written once: h = gelu(pre) [M,4C], dpre [M,4C], ln = LN(x) [M,C], dys = dp*dy [M,C]
  *        (dys may be NULL when there is no DropPath: use dy).  dW1 = ln^T dpre, db1 = colsum(dpre), dW2 = h^T dys,
  *        db2 = colsum(dys) are stj_gemm split-K launches.
- * ws (C = 384 only; ignored for the other widths): f32 workspace of stj_swin_split_workspace_bytes(M, C) bytes.  With it the 2048-row
+ * ws (C = 384 only; ignored for the other widths): f32 workspace of stj_swin_split_workspace_bytes(M, C) bytes.  The 2048-row
  *   stage runs as (row block, 1/8 of the hidden dimension) workgroups -- 256 at B = 8 instead of 32, each streaming 1/8 of the weights
  *   -- whose partial sums [8][M][C] a second launch adds up and finishes (bias + DropPath + shortcut; LayerNorm backward + dgamma /
- *   dbeta).  NULL: one workgroup per row block.  The four stj_swin_* entry points share the workspace layout; stj_swin_attn_* at
- *   C = 384 REQUIRE it (and a 16-bit dtype): (window, 2 of the 12 heads) workgroups. */
+ *   dbeta).  REQUIRED at C = 384 (STJ_EINVAL without it).  The four stj_swin_* entry points share the workspace layout;
+ *   stj_swin_attn_* at C = 384 also need a 16-bit dtype: (window, 2 of the 12 heads) workgroups. */
 long long stj_swin_split_workspace_bytes(long long M, int C);
 int stj_swin_mlp_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
                      const float* b2, void* y, long long M, int C, float eps, const long long* rng_state, int site,

@@ -51,7 +51,7 @@ def build(force=False, verbose=True):
             if r.returncode != 0:
                 raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + r.stderr[-4000:])
     if jobs or force or _stale(OUT, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-s', '-o', OUT] + objs      # -s: no static symbol table (the C ABI is in .dynsym)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed: ' + r.stderr[-4000:])

@@ -653,16 +653,14 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, GroupState* gs,
   }
   constexpr int BK = 128 / sizeof(T);
   const long long nb = (long long)p.nb1 * p.nb2;
-  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nb;
   const long long tiles64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * nb;
   const int ktiles = ((p.K + BK - 1) / BK) * p.nkb;
   // Tile choice.  The hot-path GEMMs are skinny (K <= 1536, mostly 96..384) and latency / memory-parallelism bound, not
   // MFMA bound: measured on every Dense shape of the model, 64x64 tiles (4x the workgroups in flight) beat 128x128 by
   // 1.3-1.8x (profiles/r01_c_gemm_tiles.txt), so 64x64 is the default; 128x128 only pays for genuinely large problems.
-  int cfg;   // 0: 128x128, 2: 64x64, 3: 32x32
-  const double flops = 2.0 * p.M * p.N * (double)p.K * nb;
-  if (p.N > 64 && p.M > 64 && tiles128 >= 1024 && p.K >= 1024 && flops > 2e11) cfg = 0;
-  else cfg = 2;
+  // (a 128x128 configuration existed for problems beyond 2e11 FLOP with K >= 1024: no product of this model -- cfg-512 and batch-32
+  // inference included -- reached it, and its 12 instantiations were 0.3 MB of the library)
+  int cfg = 2;   // 2: 64x64, 3: 32x32
   // Few rows (the 16x16 Swin stage, the 64-agent encoder): 64x64 tiles leave most of the 256 CUs idle and a plain GEMM cannot
   // split K.  32x32 tiles quadruple the workgroups.
   if (!p.accumulate && tiles64 < 256 && p.M >= 32 && p.N >= 32) cfg = 3;
@@ -671,7 +669,7 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, GroupState* gs,
   // shape but two (e.g. [192x576] over 8192 rows 32.8 vs 18.8 us, [96x384] over 32768 rows 31.8 vs 28.7 us; 128x128: 38-47 us), 828
   // vs 860 scenes/s end to end: these launches are bound by how many workgroups are in flight, not by what one of them does.
   if (p.splitk == 0) {            // auto split-K (accumulating GEMMs only): aim at ~2 blocks per CU
-    const long long tiles = cfg == 0 ? tiles128 : tiles64;
+    const long long tiles = tiles64;
     const int tgt = 768, cap = 96;      // (swept repeatedly: within noise around these)
     long long s = (tgt + tiles - 1) / tiles;
     if (s > cap) s = cap;                 // bound same-address atomic contention
@@ -697,7 +695,6 @@ static int launch_gemm(GemmArgs& p, bool ta, bool tb, int dtype, GroupState* gs,
     }
   }
   if (cfg == 3) launch_tile<T, 32, 32, 2, 2>(p, ta, tb, st);
-  else if (cfg == 0) launch_tile<T, 128, 128, 2, 2>(p, ta, tb, st);
   else launch_tile<T, 64, 64, 2, 2>(p, ta, tb, st);
   return stj_check_launch("stj_gemm");
 }

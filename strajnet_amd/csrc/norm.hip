@@ -396,12 +396,9 @@ static int ln_launch(bool fwd, const void* x, const float* gamma, const float* b
     nb = (int)(nbt < nr * S ? nbt : nr * S);
     grid = G.ngroups * nb;
   }
-  if (npl <= 2) { LN_DISPATCH(2) }
-  else if (npl <= 3) { LN_DISPATCH(3) }
-  else if (npl <= 6) { LN_DISPATCH(6) }
-  else if (npl <= 8) { LN_DISPATCH(8) }
-  else if (npl <= 12) { LN_DISPATCH(12) }
-  else if (npl <= 24) { LN_DISPATCH(24) }
+  // ONE register width (24 values per lane, C <= 1536): this form serves the widths and alignments the chunked kernels refuse, not a
+  // timed path, and each instantiation is 50-100 KB of code (six widths x three storage types x forward / backward were 2 MB of the library)
+  if (npl <= 24) { LN_DISPATCH(24) }
   else { stj_set_error("layernorm: C=%d > 1536 unsupported", C); return STJ_EUNSUPPORTED; }
   return stj_check_launch("stj_layernorm");
 }

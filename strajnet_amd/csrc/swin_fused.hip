@@ -764,8 +764,9 @@ static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
     case 96: return two ? mlp_launch<T, 96, 2>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
     case 192: return two ? mlp_launch<T, 192, 2>(bwd, a, st) : mlp_launch<T, 192, 1>(bwd, a, st);
     case 384: {
-      if (a.part == nullptr) return mlp_launch<T, 384, 1>(bwd, a, st);
-      MlpArgs s = a;                 // with a workspace: (row block, hidden slice) workgroups + the finishing launch
+      // (a one-workgroup-per-row-block form without the workspace existed: 32 workgroups at B = 8, never taken by ops.py, 0.2 MB of code)
+      if (a.part == nullptr) { stj_set_error("swin_mlp: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
+      MlpArgs s = a;                 // (row block, hidden slice) workgroups + the finishing launch
       s.split = mlp_split_for(a.M);
       const int rc = mlp_launch<T, 384, 1, true>(bwd, s, st);
       if (rc != STJ_OK) return rc;
