@@ -1723,6 +1723,7 @@ static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const voi
     if (hipFuncSetAttribute((const void*)upconv_dgrad_ws_kernel<KS, NFI, ELU, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
   }
+  if ((long long)F * 4 * Hi * Wi * Cout * 2 >= (1LL << 31)) return false;      // the halo loader addresses dP through 32-bit (int) byte offsets
   const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
   const int ct = (Cin + CT - 1) / CT;
   int nblk = 256 / ct;

@@ -79,7 +79,8 @@ def _upconv_run(x, w, b, g, dt, grad_is_pre, x_is_elu_out):
     return y.detach(), xi.grad.detach(), pw.grad.detach().clone(), pb.grad.detach().clone()
 
 
-@pytest.mark.parametrize('F_,Hi,Cin,Cout', [(8, 128, 96, 48), (8, 64, 128, 96), (8, 32, 192, 128), (16, 16, 384, 192)])
+@pytest.mark.parametrize('F_,Hi,Cin,Cout', [(8, 128, 96, 48), (8, 64, 128, 96), (8, 32, 192, 128), (16, 16, 384, 192),
+                                            (12, 52, 128, 96)])     # ragged tiles in both directions, 2-3 tiles per workgroup: the rolling halo of upconv_dgrad_ws
 @pytest.mark.parametrize('x_is_elu_out', [False, True])
 def test_upconv_ws_bench_shapes_bf16(F_, Hi, Cin, Cout, x_is_elu_out):
     """upconv_fwd_ws / upconv_dgrad_ws (both ELU' variants) / upconv_wgrad_tr at the bench layer shapes, >= 8 frames: every
