@@ -300,7 +300,7 @@ def parity_extras(model, loss_fn, x, B, dev, with_cpu):
     return res
 
 
-def run_extra_configs(steps=10, warmup=3):
+def run_extra_configs(steps=30, warmup=10):        # (10 + 3 steps of a fresh process read 4 % low: 4823 vs 5011 scenes/s for config 4 in the same session)
     """BASELINE configs 4 and 5 measured in the SAME default run (the driver only runs `bench.py --gpus 1`): each is this file again,
     in a child process on the same GPU, with its own hipGraph capture, timed region and per-kernel roofline pass.  -> dict for the
     `extra_configs` field of the headline line (never the headline itself)."""

@@ -68,6 +68,22 @@ def _upconv(kind):
     return f
 
 
+def _upconv_head(a):
+    """stj_upconv_fwd_head(x, wf, bias, wh, z, F, Hi, Wi, Cin, Cout, dtype, stream): the 96 -> 48 up-conv whose epilogue projects onto the
+    two heads' 9 taps: reads x and the folded weights, writes z [F,2Hi,2Wi,24]; FLOPs = the up-conv + 18 x 48 MACs per output pixel."""
+    F, Hi, Wi, Cin, Cout, dt = a[5], a[6], a[7], a[8], a[9], a[10]
+    es = _es(dt)
+    fl = 2.0 * 9 * Cin * Cout * 4 * Hi * Wi * F + 2.0 * 18 * Cout * 4 * Hi * Wi * F
+    by = es * F * Hi * Wi * (Cin + 4 * 24) + es * 16 * Cin * Cout
+    return f'upconv_fwd_head[{Hi}x{Wi},{Cin}->{Cout}->18,F{F}]', 'upconv_fwd', fl, 2.0 * 4 * Cin * Cout * 4 * Hi * Wi * F + 2.0 * 32 * 64 * 4 * Hi * Wi * F, by
+
+
+def _pair_gather(a):
+    """stj_outconv_pair_gather(zo, zf, b0, b1, out, B, Tn, H, W, t_major, dtype, stream): 9-neighbour sums of two z tensors -> [B,H,W,4Tn] f32."""
+    B, Tn, H, W, dt = a[5], a[6], a[7], a[8], a[10]
+    return f'outconv_pair_gather[{H}x{W},F{B * Tn}x2]', 'outconv_fwd', 2.0 * 18 * 2 * B * Tn * H * W, 0.0, 2 * _es(dt) * B * Tn * H * W * 24 + 4 * B * H * W * 4 * Tn
+
+
 def _upconv_res(a):
     F, Hi, Wi, Cin, Cout, dt = a[7], a[8], a[9], a[10], a[11], a[12]
     es = _es(dt)
@@ -153,7 +169,7 @@ def _loss(fam, tens):
 
 MODELS = {
     'stj_gemm': _gemm,
-    'stj_upconv_fwd': _upconv('fwd'), 'stj_upconv_fwd_res': _upconv_res, 'stj_elu_res_bwd': _elu_res, 'stj_upconv_dgrad': _upconv('dgrad'), 'stj_upconv_wgrad': _upconv('wgrad'),
+    'stj_upconv_fwd': _upconv('fwd'), 'stj_upconv_fwd_head': _upconv_head, 'stj_outconv_pair_gather': _pair_gather, 'stj_upconv_fwd_res': _upconv_res, 'stj_elu_res_bwd': _elu_res, 'stj_upconv_dgrad': _upconv('dgrad'), 'stj_upconv_wgrad': _upconv('wgrad'),
     'stj_outconv_fwd': _outconv('fwd'), 'stj_outconv_pair_fwd': _outconv_pair, 'stj_outconv_bwd': _outconv('bwd'),
     'stj_layernorm_fwd': _ln('fwd'), 'stj_layernorm_bwd': _ln('bwd'), 'stj_layernorm_res_fwd': _ln('res_fwd'),
     'stj_win_attn_fwd': _win('fwd'), 'stj_win_attn_bwd': _win('bwd'),
