@@ -1,9 +1,4 @@
-run() { timeout 120 python tools/ab_ops.py $1 -- --steps 40 --warmup 5 --no-extra-configs --no-cpu-baseline --no-kernel-timing 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'])" || echo "$1 FAILED"; }
-run UPWG_BUDGET=128
-run UPWG_BUDGET=192
-run UPWG_BUDGET=256
-run UPWG_BUDGET=96
-run UPWG_BUDGET=128
-run DEFER_UPWG=False
-run WG_BUDGET=192
-run UPWG_BUDGET=128
+python tools/bench_conv.py --layer 3 --only fwd --iters 20 2>&1 | tail -1
+STJ_LIB_PATH=strajnet_amd/variants/lib_old.so python tools/bench_conv.py --layer 3 --only fwd --iters 20 2>&1 | tail -1
+python tools/bench_conv.py --layer 3 --only fwd --iters 20 2>&1 | tail -1
+timeout 300 python -m pytest tests/test_timed_kernels_gpu.py tests/test_ops_gpu.py -q -x -s -k "upconv" 2>&1 | grep "96->48\|passed\|failed\|Error\|assert" | head
