@@ -302,6 +302,18 @@ long long stj_outconv_bwd_workspace_bytes(void);   /* size of the caller-owned s
 /* PatchEmbed Conv2D k=4 s=4 VALID as im2col (+ f32->T cast, + stride-2 pick of ogm[...,0]; modules.py:430-431,572). */
 int stj_im2col_patch(const float* src, void* dst, int B, int H, int W, int Cin, long long pix_stride, int ch_stride,
                      int dtype, hipStream_t stream);
+/* Fused PatchEmbed + the stem's sums / norms (modules.py:430-446 PatchEmbed.call: Conv2D k=4 s=4 VALID -> reshape -> LayerNorm(1e-5);
+ * modules.py:572-590: patch_embed_vecicle(ogm[...,0]) + patch_embed_map(map) -> all_patch_norm; :576-578 patch_embed_flow -> flow_norm):
+ *   pre = cols(src) @ w + bias ; x2 = LN(pre; gamma, beta) [+ add] ; y = gamma2 ? LN(x2; gamma2, beta2) : x2
+ * src f32 rasters read as src[((b*H+y)*W+x)*pix_stride + c*ch_stride] (as stj_im2col_patch); w [16*Cin, Cout] type T (Keras kernel
+ * [4,4,Cin,Cout] flattened); bias / gamma / beta f32; add, pre, x2, y [B*(H/4)*(W/4), Cout] type T; cols [.., 16*Cin] type T.
+ * Optional outputs (NULL = not written): cols (the im2col rows, for dW = cols^T dpre), pre + mean + rstd, x2 + mean2 + rstd2 (what
+ * stj_layernorm_bwd needs).  pre and x2 are rounded to T before they are normalised.  Built for Cin in {11, 3, 2}, Cout = 96. */
+int stj_patch_embed_supported(int Cin, int Cout, int dtype);
+int stj_patch_embed_fwd(const float* src, const void* w, const float* bias, const float* gamma, const float* beta, const void* add,
+                        const float* gamma2, const float* beta2, void* cols, void* pre, void* x2, void* y, float* mean, float* rstd,
+                        float* mean2, float* rstd2, int B, int H, int W, int Cin, long long pix_stride, int ch_stride, int Cout,
+                        float eps, int dtype, hipStream_t stream);
 /* grouped 3x3 SAME conv of FG-MSA (FG_MSA.py:51) as im2col / col2im around the batched GEMM. */
 int stj_im2col3(const void* x, void* cols, int N, int H, int W, int G, int Cg, int dtype, hipStream_t stream);
 int stj_col2im3(const void* dcols, void* dx, int N, int H, int W, int G, int Cg, int dtype, hipStream_t stream);

@@ -41,6 +41,8 @@ SIGNATURES = {
     'stj_unary_bwd': [vp, vp, vp, cl, ci, cf, ci, vp],
     'stj_maxpool_fwd': [vp, vp, vp, cl, ci, ci, ci, vp],
     'stj_maxpool_bwd': [vp, vp, vp, vp, cl, ci, ci, ci, vp],
+    'stj_patch_embed_supported': [ci, ci, ci],
+    'stj_patch_embed_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cl, ci, ci, cf, ci, vp],
     'stj_layernorm_fwd': [vp, vp, vp, vp, vp, vp, cl, ci, cf, ci, ci, cl, ci, cl, ci, vp],
     'stj_layernorm_res_fwd': [vp, vp, vp, vp, vp, vp, vp, cl, ci, cf, cl, ci, cl, ci, vp],
     'stj_layernorm_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, cl, ci, cl, vp, ci, cl, ci, vp],

@@ -239,6 +239,7 @@ class STrajNet:
         # the 8 time-separated cross-attentions as one kernel per direction (csrc/xattn_fused.hip); False = the layer-by-layer chain
         # (the parity tests run both and compare)
         self.fused_xattn = True
+        self.fused_stem = True         # PatchEmbed + the stem's sums / norms as one launch per raster (csrc/patch_embed.hip); False = im2col + dense + LayerNorm launches
         self.agent_issue_mode = 2
         self.mid_forward_hook = None          # callable run once per forward pass behind the encoder's first stage (GraphedTrainStep: loss.prepare on its side stream)
         self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (16-bit modes, 8 x 8 / 16 x 16 maps)
@@ -449,13 +450,22 @@ class STrajNet:
             add = add()                                                      # join point of a branch computed on a side stream
         return self._dense(m, pre + '/downsample/reduction', bias=False, res=add), x
 
-    def _patch_embed(self, src, name, Cin, ch_stride, pix_stride, add=None):
-        """PatchEmbed.call (modules.py:437-446): conv4x4/s4 as im2col + dense, then LN(1e-5) (+ `add`, the other embedding the
-        caller sums it with, in the norm's epilogue)."""
+    def _patch_embed(self, src, name, Cin, ch_stride, pix_stride, add=None, norm2=None):
+        """PatchEmbed.call (modules.py:437-446): conv4x4/s4 + LN(1e-5) (+ `add`, the other embedding the caller sums it with)
+        (+ `norm2`, the LayerNorm the caller applies to that sum: all_patch_norm modules.py:590 / flow_norm :578) -- one launch
+        (csrc/patch_embed.hip); widths the fused kernel is not built for take im2col + dense + the LayerNorm kernels."""
         B, H = src.shape[0], src.shape[1]
+        pw = self._p(name + '/proj/kernel')
+        if self.fused_stem and ops.patch_embed_ok(Cin, pw.c.shape[-1], self.dtype):
+            y = ops.patch_embed(src, pw, self._p(name + '/proj/bias'), self._p(name + '/norm/gamma'), self._p(name + '/norm/beta'),
+                                Cin, ch_stride, pix_stride, self.dtype, 1e-5, add,
+                                self._p(norm2 + '/gamma') if norm2 else None, self._p(norm2 + '/beta') if norm2 else None)
+            return y.view(B, (H // 4) ** 2, -1)
         cols = ops.patch_im2col(src, Cin, ch_stride, pix_stride, self.dtype)
         y = self._dense(cols, name + '/proj')
         y = self._ln(y, name + '/norm', 1e-5, res=add.view(y.shape) if add is not None else None)
+        if norm2:
+            y = self._ln(y, norm2, 1e-5)
         return y.view(B, (H // 4) ** 2, -1)
 
     def _encoder(self, ogm, map_img, flow, hook=None):
@@ -464,8 +474,7 @@ class STrajNet:
         C, P = self.stage_dim[0], self.P
         depths, heads = self.cfg['depths'], self.cfg['num_heads']
         def flow_branch():
-            fl = self._patch_embed(flow, 'patch_embed_flow', 2, 1, 2)
-            fl = self._ln(fl, 'flow_norm', 1e-5)
+            fl = self._patch_embed(flow, 'patch_embed_flow', 2, 1, 2, norm2='flow_norm')
             return self._basic_layer(fl, 'flow_layers0', B, P, depths[0], heads[0], True)
         # the flow stage (2 Swin blocks at 64x64 tokens) and the vehicle/map stage 0 are independent until stage 0's PatchMerging
         # adds flow_x (modules.py:576-578,596-605): side stream, joined right before that GEMM
@@ -490,10 +499,9 @@ class STrajNet:
             Pm = self.map_size // 4
             pad = (P - Pm) // 2
             maps = torch.nn.functional.pad(maps.view(B, Pm, Pm, C), (0, 0, pad, pad, pad, pad)).reshape(B, P * P, C)
-            x = vec + maps
+            x = self._ln(vec + maps, 'all_patch_norm', 1e-5)
         else:
-            x = self._patch_embed(map_img, 'patch_embed_map', 3, 1, 3, add=vec)   # vec + maps (modules.py:589)
-        x = self._ln(x, 'all_patch_norm', 1e-5)
+            x = self._patch_embed(map_img, 'patch_embed_map', 3, 1, 3, add=vec, norm2='all_patch_norm')   # vec + maps (modules.py:589-590)
         self._tap('stem', x)
         res_list = []
 

@@ -1618,6 +1618,79 @@ def maxpool_time(x):
 # ----------------------------------------------------------------------------------------------------
 # patch embedding conv (4x4 stride 4) = im2col + dense
 # ----------------------------------------------------------------------------------------------------
+def _ln_bwd_plain(dy, x, mean, rstd, pg, pb, rows, C):
+    """stj_layernorm_bwd of a plain [rows, C] norm (no gather, one parameter set): -> dx; dgamma / dbeta accumulate."""
+    dx = torch.empty_like(x)
+    if pg.part is not None and pb.part is not None:
+        dg, db, nparts, pstride = pg.part[0], pb.part[0], pg.part[1], pg.part[2]
+    else:
+        dg, db, nparts, pstride = pg.grad, pb.grad, 1, 0
+    call('stj_layernorm_bwd', _p(dy), _p(x), _p(pg.master), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, C, 0, 0, 0, 1, 0,
+         _p(None), nparts, pstride, _dt(x), _st())
+    return dx
+
+
+class _PatchEmbed(torch.autograd.Function):
+    """PatchEmbed.call (modules.py:437-446) + what the stem does with it (modules.py:572-590), ONE launch (csrc/patch_embed.hip):
+    y = LN2(LN(cols(src) @ W + b) [+ add]).  Backward: the two LayerNorm backward launches on the saved pre-norm rows and the weight
+    gradient dW += cols^T dpre (queued for the grouped stream-K launch like every Dense layer's); the rasters are data, no dx."""
+    @staticmethod
+    def forward(ctx, src, trig, wc, gw, pbias, pg, pb, add, pg2, pb2, geo, dtype):
+        _req_cuda(src)
+        Cin, ch_stride, pix_stride, eps = geo
+        src = src.contiguous()
+        B, H, W = src.shape[0], src.shape[1], src.shape[2]
+        K, N = wc.shape
+        M = B * (H // 4) * (W // 4)
+        train = ctx.needs_input_grad[1] or (add is not None and ctx.needs_input_grad[7])     # (grad mode is off inside forward)
+        dev = src.device
+        y = torch.empty((M, N), dtype=dtype, device=dev)
+        cols = pre = x2 = mean = rstd = mean2 = rstd2 = None
+        if train:
+            cols = torch.empty((M, K), dtype=dtype, device=dev)
+            pre = torch.empty((M, N), dtype=dtype, device=dev)
+            mean, rstd = torch.empty(M, dtype=torch.float32, device=dev), torch.empty(M, dtype=torch.float32, device=dev)
+            if pg2 is not None:
+                x2 = torch.empty((M, N), dtype=dtype, device=dev)
+                mean2, rstd2 = torch.empty(M, dtype=torch.float32, device=dev), torch.empty(M, dtype=torch.float32, device=dev)
+        a2 = add.contiguous().view(M, N) if add is not None else None
+        call('stj_patch_embed_fwd', _p(src), _p(wc), _p(pbias.master), _p(pg.master), _p(pb.master), _p(a2),
+             _p(pg2.master if pg2 is not None else None), _p(pb2.master if pb2 is not None else None), _p(cols), _p(pre), _p(x2), _p(y),
+             _p(mean), _p(rstd), _p(mean2), _p(rstd2), B, H, W, Cin, pix_stride, ch_stride, N, float(eps), DTYPE_CODE[dtype], _st())
+        ctx.p = (gw, pbias, pg, pb, pg2, pb2)
+        ctx.has_add, ctx.add_shape = add is not None, (add.shape if add is not None else None)
+        ctx.save_for_backward(cols, pre, x2, mean, rstd, mean2, rstd2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, pre, x2, mean, rstd, mean2, rstd2 = ctx.saved_tensors
+        gw, pbias, pg, pb, pg2, pb2 = ctx.p
+        M, N = pre.shape
+        K = cols.shape[1]
+        dy = dy.contiguous().view(M, N)
+        if pg2 is not None:
+            dy = _ln_bwd_plain(dy, x2, mean2, rstd2, pg2, pb2, M, N)             # gradient of x2 = LN(pre) + add
+        dadd = dy.view(ctx.add_shape) if ctx.has_add else None
+        dpre = _ln_bwd_plain(dy, pre, mean, rstd, pg, pb, M, N)
+        with wgrad_stream(1, cols, dpre):
+            gemm(cols, dpre, gw, K, N, M, (0, 0, 1, K), (0, 0, N, 1), (0, 0, N), _dt(cols), c_f32=1, accumulate=1, splitk=0,
+                 colsum=pbias.grad)                                                # dW += cols^T dpre ; db += 1^T dpre
+        return (None,) * 7 + (dadd,) + (None,) * 4
+
+
+def patch_embed_ok(Cin, Cout, dtype):
+    from ._lib import lib
+    return bool(lib().stj_patch_embed_supported(Cin, Cout, DTYPE_CODE[dtype]))
+
+
+def patch_embed(src, pw, pbias, pg, pb, Cin, ch_stride, pix_stride, dtype, eps=1e-5, add=None, pg2=None, pb2=None):
+    """src: f32 raster [B,H,W,*] -> [B*(H/4)*(W/4), Cout] tokens: LN2(LN(conv4x4s4(src)) [+ add]) (LN2 only with pg2 / pb2)."""
+    N = pw.c.shape[-1]
+    return _PatchEmbed.apply(src, pw.master, pw.c.view(-1, N), pw.grad.view(-1, N), pbias, pg, pb, add, pg2, pb2,
+                             (Cin, ch_stride, pix_stride, eps), dtype)
+
+
 def patch_im2col(src, Cin, ch_stride, pix_stride, dtype):
     """src: f32 tensor viewed as [B,H,W,*]; returns [B*(H/4)*(W/4), 16*Cin] in `dtype` (no grad: inputs are data)."""
     _req_cuda(src)

@@ -605,6 +605,72 @@ def test_patch_im2col():
     assert rel_err(got, ref) < 1e-6
 
 
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('Cin,ch_stride,nch', [(11, 2, 22), (3, 1, 3), (2, 1, 2)])
+@pytest.mark.parametrize('with_add,with_norm2', [(False, False), (True, True), (False, True)])
+@pytest.mark.parametrize('B,H', [(2, 64), (1, 40)])            # 512 tokens = whole workgroups; 100 tokens = a ragged last one
+def test_patch_embed_fused(dt, Cin, ch_stride, nch, with_add, with_norm2, B, H):
+    """stj_patch_embed_fwd (PatchEmbed + LN [+ add] [+ LN2] in one launch, modules.py:437-446,572-590) and its backward (two LN
+    backward launches + the queued weight gradient) vs float64, and vs the im2col + dense + LayerNorm launches it replaces."""
+    from strajnet_amd import ops
+    assert ops.patch_embed_ok(Cin, 96, dt)
+    K, C = 16 * Cin, 96
+    src = rnd((B, H, H, nch), torch.float32, 1)
+    M = B * (H // 4) ** 2
+    add = rnd((M, C), dt, 2) if with_add else None
+    dy = rnd((M, C), dt, 3)
+
+    def params():
+        ps = dict(w=mk_param((4, 4, Cin, C), dt, 0.2, 4), b=mk_param((C,), dt, 0.1, 5), g=mk_param((C,), dt, 0.5, 6), be=mk_param((C,), dt, 0.1, 7))
+        ps['g'].master.data += 1.0
+        if with_norm2:
+            ps['g2'], ps['be2'] = mk_param((C,), dt, 0.5, 8), mk_param((C,), dt, 0.1, 9)
+            ps['g2'].master.data += 1.0
+        return ps
+
+    def run(fused):
+        ps = params()
+        a = add.clone().requires_grad_(True) if with_add else None
+        if fused:
+            y = ops.patch_embed(src, ps['w'], ps['b'], ps['g'], ps['be'], Cin, ch_stride, nch, dt, 1e-5, a, ps.get('g2'), ps.get('be2'))
+        else:
+            cols = ops.patch_im2col(src, Cin, ch_stride, nch, dt)
+            y = ops.layernorm(ops.linear(cols, ps['w'], ps['b']), ps['g'], ps['be'], 1e-5, res=a)
+            if with_norm2:
+                y = ops.layernorm(y, ps['g2'], ps['be2'], 1e-5)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        return y.detach(), (a.grad.detach() if with_add else None), {k: v.grad.detach().clone() for k, v in ps.items()}, ps
+
+    y1, da1, g1, ps = run(True)
+    y0, da0, g0, _ = run(False)
+    # float64 statement on the values the kernels saw (compute-dtype weights, f32 bias / gamma / beta masters)
+    x64 = src.double().cpu()[..., ::ch_stride][..., :Cin] if ch_stride > 1 else src.double().cpu()
+    w = ref_of(ps['w'].c)
+    leaves = {k: ref_of(ps[k].master) for k in ps if k != 'w'}
+    a64 = ref_of(add) if with_add else None
+    pre = F.conv2d(x64.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), stride=4).permute(0, 2, 3, 1).reshape(M, C) + leaves['b']
+    r = F.layer_norm(pre, (C,), leaves['g'], leaves['be'], 1e-5)
+    if with_add:
+        r = r + a64
+    if with_norm2:
+        r = F.layer_norm(r, (C,), leaves['g2'], leaves['be2'], 1e-5)
+    r.backward(dy.double().cpu())
+    t = tol(dt)
+    assert rel_err(y1, r) < t, rel_err(y1, r)
+    assert rel_err(y1, r) <= max(2.0 * rel_err(y0, r), 1e-6), (rel_err(y1, r), rel_err(y0, r))       # never further from float64 than the path it replaces
+    if with_add:
+        assert rel_err(da1, a64.grad) < t
+    assert rel_err(g1['w'], w.grad) < t, rel_err(g1['w'], w.grad)
+    for k, v in leaves.items():
+        assert rel_err(g1[k], v.grad) < t, (k, rel_err(g1[k], v.grad))
+    # against the launches it replaces: same roundings (pre and the sum are rounded to the storage type before they are
+    # normalised in both), only the f32 summation order of the product differs
+    assert rel_err(y1, y0) < (1e-5 if dt == torch.float32 else t)
+    for k in g1:
+        assert rel_err(g1[k], g0[k]) < (1e-4 if dt == torch.float32 else t), k
+
+
 def test_loss_and_gate():
     """Fused loss (fwd + d/dlogits) and the AUC gate vs the oracle restatements."""
     from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
