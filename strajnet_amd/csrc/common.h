@@ -131,6 +131,12 @@ __device__ __forceinline__ float elu_bf(float x) {
   const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.4426950408889634f) - 1.f;
   return x > 0.f ? x : e;
 }
+// ELU in four VALU instructions: max(x, min(exp(x), 1) - 1) -- for x > 0 the clamped exponential is 1 and the maximum is x, for x <= 0
+// exp(x) - 1 >= x.  fmed3(e, 0, 1) folds into the CLAMP output modifier of v_exp_f32 (v_mul, v_exp clamp, v_add, v_max).
+__device__ __forceinline__ float elu_c(float x) {
+  const float e = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x * 1.4426950408889634f), 0.f, 1.f);
+  return fmaxf(x, e - 1.f);
+}
 __device__ __forceinline__ float apply_act_fast(float x, int act) {
   return act == 2 ? elu_fast(x) : (act == 1 ? x * 0.5f * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))) : x);
 }

@@ -284,6 +284,14 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
         hw[tf][0] = __builtin_bit_cast(s16x8, (u4){pack2<T>(v0[0], v0[1]), pack2<T>(v0[2], v0[3]), pack2<T>(v0[4], v0[5]), pack2<T>(v0[6], v0[7])});
         hw[tf][1] = __builtin_bit_cast(s16x8, (u4){pack2<T>(v1[0], v1[1]), pack2<T>(v1[2], v1[3]), 0u, 0u});
       }
+      // the four fragments depend on the lane only: one copy in LDS behind the stage (the launcher sizes the stage for LDO = CT + 8; as 16
+      // stationary registers per lane they spilled once the fragment ring was added), read back where the projection runs
+      if (w == 0) {
+#pragma unroll
+        for (int tf = 0; tf < 2; ++tf)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) *reinterpret_cast<s16x8*>(ost0 + 2 * OST + ((tf * 2 + k) * 64 + lane) * 8) = hw[tf][k];
+      }
     }
     __syncthreads();                                     // halo of the first tile committed by the movers
     int q = 0;
@@ -293,38 +301,48 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
       for (int st = 0; st < STEPS; ++st, ++q) {
         const int mf = SR * st;
         T* ost = ost0 + (q & 1) * OST;
+        // the accumulators start at the bias (the MFMA's C operand: no add in the epilogue)
         f32x4 acc[SR][NF];
 #pragma unroll
         for (int m = 0; m < SR; ++m)
 #pragma unroll
-          for (int n = 0; n < NF; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int n = 0; n < NF; ++n) acc[m][n] = (f32x4){bv[n][0], bv[n][1], bv[n][2], bv[n][3]};
         // a halo row feeds tap row r = 0 of output row j and tap row r = 1 of output row j - 1: SR + 1 fragment reads per (s, ks)
-        // serve 2 SR row-taps (the tile-at-a-time kernel reads each twice) -- the B-fragment LDS traffic is what bounds this kernel
-        if (!(dbg & 1))
+        // serve 2 SR row-taps (the tile-at-a-time kernel reads each twice).  The reads are issued PF groups AHEAD of their MFMAs (ring of
+        // PF + 1 fragments): written as read-then-use, the ISA was ds_read, s_waitcnt lgkmcnt(0), 3-6 MFMAs, ds_read, ... -- the LDS
+        // latency exposed 30 times per step to a wave that is alone on its SIMD's matrix pipe (230 -> 208 us at F = 64, role ablation in DESIGN 4m)
+        if (!(dbg & 1)) {
+          constexpr int PF = 2, NG = 2 * KS * (SR + 1);
+          auto frag = [&](const int gi) -> s16x8 {
+            const int s2 = gi / (KS * (SR + 1)), ks = (gi / (SR + 1)) % KS, j = gi % (SR + 1);
+            return *reinterpret_cast<const s16x8*>(halo + ((mf + j + a) * WS_HW + ln + b + s2) * LDK + ks * 32 + g * 8);
+          };
+          s16x8 xr[PF + 1];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+          for (int i = 0; i < PF; ++i) xr[i] = frag(i);
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
+          for (int gi = 0; gi < NG; ++gi) {
+            if (gi + PF < NG) xr[(gi + PF) % (PF + 1)] = frag(gi + PF);
+            const int s2 = gi / (KS * (SR + 1)), ks = (gi / (SR + 1)) % KS, j = gi % (SR + 1);
+            const s16x8 xb = xr[gi % (PF + 1)];
+            if (j < SR) {
 #pragma unroll
-            for (int j = 0; j <= SR; ++j) {
-              const s16x8 xb = *reinterpret_cast<const s16x8*>(halo + ((mf + j + a) * WS_HW + ln + b + s2) * LDK + ks * 32 + g * 8);
-              if (j < SR) {
-#pragma unroll
-                for (int n = 0; n < NF; ++n) acc[j][n] = Mma<T>::mma(wf[s2][n][ks], xb, acc[j][n]);
-              }
-              if (j > 0) {
-#pragma unroll
-                for (int n = 0; n < NF; ++n) acc[j - 1][n] = Mma<T>::mma(wf[2 + s2][n][ks], xb, acc[j - 1][n]);
-              }
+              for (int n = 0; n < NF; ++n) acc[j][n] = Mma<T>::mma(wf[s2][n][ks], xb, acc[j][n]);
             }
+            if (j > 0) {
+#pragma unroll
+              for (int n = 0; n < NF; ++n) acc[j - 1][n] = Mma<T>::mma(wf[2 + s2][n][ks], xb, acc[j - 1][n]);
+            }
+          }
+        }
         if constexpr (HEAD) {
 #pragma unroll
           for (int m = 0; m < SR; ++m) {
             uint32_t pk[NF][2];
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
-              pk[n][0] = pack2<T>(elu_bf(acc[m][n][0] + bv[n][0]), elu_bf(acc[m][n][1] + bv[n][1]));
-              pk[n][1] = pack2<T>(elu_bf(acc[m][n][2] + bv[n][2]), elu_bf(acc[m][n][3] + bv[n][3]));
+              pk[n][0] = pack2<T>(elu_c(acc[m][n][0]), elu_c(acc[m][n][1]));
+              pk[n][1] = pack2<T>(elu_c(acc[m][n][2]), elu_c(acc[m][n][3]));
             }
             typedef __attribute__((ext_vector_type(4))) uint32_t u4;
             const s16x8 y0 = __builtin_bit_cast(s16x8, (u4){pk[0][0], pk[0][1], pk[1][0], pk[1][1]});     // channels 16 (j / 4) + 4 g + j % 4
@@ -333,8 +351,8 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
 #pragma unroll
             for (int tf = 0; tf < 2; ++tf) {
               f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-              z = Mma<T>::mma(hw[tf][0], y0, z);
-              z = Mma<T>::mma(hw[tf][1], y1, z);
+              z = Mma<T>::mma(*reinterpret_cast<const s16x8*>(ost0 + 2 * OST + ((tf * 2 + 0) * 64 + lane) * 8), y0, z);
+              z = Mma<T>::mma(*reinterpret_cast<const s16x8*>(ost0 + 2 * OST + ((tf * 2 + 1) * 64 + lane) * 8), y1, z);
               // D: row (tap, o) = 16 tf + 4 g + r, column = this lane's pixel.  Rows 18..23 are zero (zero weight rows); 24..31 are not stored.
               if (tf == 0 || g < 2) *reinterpret_cast<uint2*>(zp + 16 * tf + 4 * g) = make_uint2(pack2<T>(z[0], z[1]), pack2<T>(z[2], z[3]));
             }
@@ -344,8 +362,8 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
         for (int m = 0; m < SR; ++m)
 #pragma unroll
           for (int n = 0; n < NF; ++n) {
-            const uint32_t p0 = pack2<T>(elu_bf(acc[m][n][0] + bv[n][0]), elu_bf(acc[m][n][1] + bv[n][1]));
-            const uint32_t p1 = pack2<T>(elu_bf(acc[m][n][2] + bv[n][2]), elu_bf(acc[m][n][3] + bv[n][3]));
+            const uint32_t p0 = pack2<T>(elu_c(acc[m][n][0]), elu_c(acc[m][n][1]));
+            const uint32_t p1 = pack2<T>(elu_c(acc[m][n][2]), elu_c(acc[m][n][3]));
             *reinterpret_cast<uint2*>(ost + ((2 * m + a) * (2 * WS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
           }
         __syncthreads();                                 // step q's stage is complete; the movers drain it during step q + 1
