@@ -35,7 +35,10 @@ EPS_DENSE = 5.5e-3            # linear_rs forward / dgrad
 EPS_HEAD = 1.5e-3             # outconv forward
 EPS_WGRAD = 2.0 ** -22        # same operands in both runs: f32 summation order only
 EPS_WGRAD_ROUNDED = 2.0e-5    # output heads: dpre is bf16 in the 16-bit run
-BIAS_GATE = 5.0e-3            # (provisional: calibrated from the values printed with -s)
+# signed-error gate (second test of check()): |sum (got - ref)| / sum |ref| -- measured (printed with -s) <= 4.0e-5 for the conv / dense
+# forward and input-gradient kernels, <= 8.3e-8 for weight / bias gradients on identical operands, <= 3.7e-4 where the 16-bit run rounds
+# dpre.  Gates at ~5x / 12x / 4x of that: a 0.05 % systematic scale error of a forward kernel (5e-4) fails.
+BIAS_GATE, BIAS_GATE_WGRAD, BIAS_GATE_ROUNDED = 2.0e-4, 1.0e-6, 1.5e-3
 BIAS = []
 
 
@@ -70,10 +73,11 @@ def check(name, got, ref, bound, eps, slack=0.0):
     assert worst <= 0.0, f'{name}: worst excess {worst:.3e} over the bound (max |err|/sum|terms| = {ratio:.3e}, eps {eps:.3e})'
     # second gate, against SYSTEMATIC error: roundings are zero-mean, so the signed error summed over the whole tensor stays orders of
     # magnitude under the per-element bound, while a scale error of a fraction of a percent (a mis-weighted tap, a double-counted
-    # halo column) adds up coherently.  |sum (got - ref)| / sum |ref|; the gate BIAS_GATE is ~4x the largest value any case measures.
+    # halo column) adds up coherently.  |sum (got - ref)| / sum |ref|; gates: BIAS_GATE* above.
     bias = float((got - ref).double().sum().abs() / (ref.double().abs().sum() + 1e-30))
     BIAS.append((name, bias))
-    assert bias <= BIAS_GATE, f'{name}: signed error sum / sum |ref| = {bias:.3e} (gate {BIAS_GATE:.1e})'
+    gate = BIAS_GATE_WGRAD if eps == EPS_WGRAD else (BIAS_GATE_ROUNDED if eps in (EPS_WGRAD_ROUNDED, 6.4e-5) else BIAS_GATE)
+    assert bias <= gate, f'{name}: signed error sum / sum |ref| = {bias:.3e} (gate {gate:.1e})'
     return ratio
 
 
