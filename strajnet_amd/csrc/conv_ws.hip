@@ -114,27 +114,33 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const T* __
     // ---- MFMA main loop: two tile rows at a time ----
 #pragma unroll NW == 1 ? 4 : 1
     for (int mf = row0; mf < row0 + WS_TH / NW; mf += 2) {
+      // the accumulators start at the bias (the MFMA's C operand: no add in the epilogue)
       f32x4 acc[2][NF];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < NF; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NF; ++n) acc[m][n] = (f32x4){bv[n][0], bv[n][1], bv[n][2], bv[n][3]};
+      // fragment pairs read one (r, s, ks) group AHEAD of their MFMAs (read-then-use compiled to ds_read x 2, s_waitcnt lgkmcnt(0), 4 MFMAs,
+      // 16 times per block: see upconv_fwd_ws2_kernel)
+      {
+        constexpr int NG = 4 * KS;
+        auto frag = [&](const int gi, const int m) -> s16x8 {
+          const int r = gi / (2 * KS), s = (gi / KS) & 1, ks = gi % KS;
+          return *reinterpret_cast<const s16x8*>(halo + ((mf + m + a + r) * WS_HW + ln + b + s) * LDK + ks * 32 + g * 8);
+        };
+        s16x8 xr[2][2];
+        xr[0][0] = frag(0, 0); xr[0][1] = frag(0, 1);
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+        for (int gi = 0; gi < NG; ++gi) {
+          if (gi + 1 < NG) { xr[(gi + 1) & 1][0] = frag(gi + 1, 0); xr[(gi + 1) & 1][1] = frag(gi + 1, 1); }
+          const int r = gi / (2 * KS), s = (gi / KS) & 1, ks = gi % KS;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+          for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            s16x8 xb[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-              xb[m] = *reinterpret_cast<const s16x8*>(halo + ((mf + m + a + r) * WS_HW + ln + b + s) * LDK + ks * 32 + g * 8);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-              for (int n = 0; n < NF; ++n)
-                acc[m][n] = Mma<T>::mma(wf[r * 2 + s][n][ks], xb[m], acc[m][n]);
-          }
+            for (int n = 0; n < NF; ++n)
+              acc[m][n] = Mma<T>::mma(wf[r * 2 + s][n][ks], xr[gi & 1][m], acc[m][n]);
+        }
+      }
       // epilogue into the LDS stage: lane holds couts g*4..g*4+3 of pixel (2(mf+m)+a, 2 ln + b)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -142,8 +148,8 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const T* __
         for (int n = 0; n < NF; ++n) {
           // ELU only (the launcher routes other activations to the generic kernel): 6 VALU ops per value, no branches --
           // the runtime-selected activation cost ~7000 instructions per tile, more than the 288 MFMAs
-          const uint32_t p0 = pack2<T>(elu_bf(acc[m][n][0] + bv[n][0]), elu_bf(acc[m][n][1] + bv[n][1]));
-          const uint32_t p1 = pack2<T>(elu_bf(acc[m][n][2] + bv[n][2]), elu_bf(acc[m][n][3] + bv[n][3]));
+          const uint32_t p0 = pack2<T>(elu_c(acc[m][n][0]), elu_c(acc[m][n][1]));
+          const uint32_t p1 = pack2<T>(elu_c(acc[m][n][2]), elu_c(acc[m][n][3]));
           *reinterpret_cast<uint2*>(ostage + ((2 * (mf + m) + a) * (2 * WS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
         }
     }
