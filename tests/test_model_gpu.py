@@ -138,6 +138,34 @@ def test_train_step_parity_f32():
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_stem_matches_layerwise_whole_model(dtype):
+    """model.fused_stem (PatchEmbed + stem sums / norms as one launch per raster, csrc/patch_embed.hip) against the im2col + dense +
+    LayerNorm launches it replaces, through the WHOLE model: logits, and the gradients of every stem parameter for one output gradient."""
+    model, w, x, xt = _setup(CFG128, 2, dtype)
+    g = torch.randn(2, 128, 128, 32, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3))
+    res = {}
+    for fused in (True, False):
+        model.fused_stem = fused
+        model.zero_grad()
+        out = _fwd(model, xt)
+        out.backward(g)
+        torch.cuda.synchronize()
+        res[fused] = (out.detach().float().clone(), {n: p.grad.detach().clone() for n, p in model.params.items()
+                                                      if n.startswith(('patch_embed', 'flow_norm', 'all_patch_norm'))})
+    y1, g1 = res[True]
+    y0, g0 = res[False]
+    assert len(g1) == 16            # 3 x (kernel, bias, gamma, beta) + 2 x (gamma, beta)
+    scale = float(y0.abs().max())
+    err = float((y1 - y0).abs().max()) / scale
+    worst = max(float((g1[n] - g0[n]).norm() / (g0[n].norm() + 1e-30)) for n in g1)
+    _report(f'fused stem vs layer-by-layer stem ({dtype}): logits max-abs / scale {err:.2e}, worst stem parameter gradient rel-norm {worst:.2e}')
+    # f32: same arithmetic up to the f32 summation order of one K <= 176 product; bf16: the bf16 roundings are in the same places, but a
+    # flipped rounding of one token propagates through the network like any bf16 rounding
+    assert err < (2e-5 if dtype == torch.float32 else 2e-2)
+    assert worst < (2e-4 if dtype == torch.float32 else 5e-2)
+
+
 def _oracle_masks(model, B):
     from oracle.masks import masks_from_model
     return masks_from_model(model, B)
