@@ -1,16 +1,18 @@
 #!/usr/bin/env python
 """Dump the kernel timeline of ONE replayed step from a rocprofv3 rocpd database (start offset, duration, stream / queue, kernel name):
-which kernels overlap, where the GPU idles, what the critical chain is.   usage: tools/timeline.py results.db [step_index_from_end]"""
+which kernels overlap, where the GPU idles, what the critical chain is.   usage: tools/timeline.py results.db [step_index_from_end] [name of
+the step's LAST kernel: default 'nadam' (train step); 'outconv_pair_gather' for the inference forward]"""
 import sqlite3, sys
 db = sys.argv[1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+last = sys.argv[3] if len(sys.argv) > 3 else 'nadam'
 c = sqlite3.connect(db)
 cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
 sid = 'stream_id' if 'stream_id' in cols else ('queue_id' if 'queue_id' in cols else None)
 q = f"select start, end, {sid if sid else 0}, name from kernels order by start"
 rows = list(c.execute(q))
 # steps are separated by the Nadam kernel
-idx = [i for i, r in enumerate(rows) if 'nadam' in r[3]]
+idx = [i for i, r in enumerate(rows) if last in r[3]]
 if len(idx) < back + 1:
     print('not enough steps', len(idx)); sys.exit(1)
 a, b = idx[-back - 1] + 1, idx[-back] + 1
