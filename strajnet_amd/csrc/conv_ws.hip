@@ -1424,7 +1424,9 @@ __global__ __launch_bounds__(256, 3) void outconv_bwd_mfma2_kernel(const bf16* _
     oc_decode(tile, tiles_x, tiles_y, F, Tn, y_bs, y_ts, tx, ty, f);
     bf16* dXf = dX + (long long)f * Hh * Ww * C;
     // ---- dX rows 4w .. 4w+3 ----
-#pragma unroll 1
+    // (unrolled: with the 12 stores of a tile in a rolled loop the waitcnt pass cannot count them and the commit of the prefetched tile below
+    //  waits for most of the STORES to complete as well -- vmcnt(8..3) where 18 operations are younger than the first load)
+#pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int row = 4 * w + rr;
       float2 d[4];
