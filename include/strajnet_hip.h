@@ -103,6 +103,14 @@ int stj_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
                       void* dx, float* dgamma, float* dbeta, long long rows, int C, int gather_res, int C0,
                       long long group_rows, int ngroups, long long gstride, const void* dres, int nparts, long long part_stride,
                       int dtype, hipStream_t stream);
+/* Two LayerNorm backward passes in one launch, for y = LN2(LN1(x1) [+ add]) (the stem: modules.py:437-446 with :578 / :590): d2 = dLN2(dy)
+ * at x2 (written to d2 when non-NULL: the gradient of `add`), dx1 = dLN1(d2) at x1; d2 is rounded to T in between, as two stj_layernorm_bwd
+ * calls hand it over.  Plain [rows, C] tensors, one parameter set per norm, nparts / part_stride as in stj_layernorm_bwd (per norm). */
+int stj_layernorm_bwd_chain_supported(int C, int dtype);
+int stj_layernorm_bwd_chain(const void* dy, const void* x2, const float* gamma2, const float* mean2, const float* rstd2, const void* x1,
+                            const float* gamma1, const float* mean1, const float* rstd1, void* d2, void* dx1, float* dgamma2, float* dbeta2,
+                            float* dgamma1, float* dbeta1, long long rows, int C, int nparts2, long long part_stride2, int nparts1,
+                            long long part_stride1, int dtype, hipStream_t stream);
 /* dres (optional, x's layout, no gather): gradient arriving over the residual connection that bypasses the norm; dx += dres.
  * nparts / part_stride: dgamma and dbeta are "+=" into nparts copies that lie part_stride floats apart (workgroups rotate over
  * them: 256 same-address atomics per channel otherwise); the caller sums the copies.  nparts = 1: plain [C] buffers. */

@@ -46,6 +46,8 @@ SIGNATURES = {
     'stj_layernorm_fwd': [vp, vp, vp, vp, vp, vp, cl, ci, cf, ci, ci, cl, ci, cl, ci, vp],
     'stj_layernorm_res_fwd': [vp, vp, vp, vp, vp, vp, vp, cl, ci, cf, cl, ci, cl, ci, vp],
     'stj_layernorm_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, cl, ci, cl, vp, ci, cl, ci, vp],
+    'stj_layernorm_bwd_chain_supported': [ci, ci],
+    'stj_layernorm_bwd_chain': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, cl, ci, cl, ci, vp],
     'stj_win_attn_fwd': [vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_win_attn_bwd': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_swin_split_workspace_bytes': [cl, ci],

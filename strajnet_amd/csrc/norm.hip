@@ -403,6 +403,135 @@ static int ln_launch(bool fwd, const void* x, const float* gamma, const float* b
   return stj_check_launch("stj_layernorm");
 }
 
+// =====================================================================================================
+// Two LayerNorm backward passes in one launch: the stem's  y = LN2(LN1(x1) [+ add])  (modules.py:437-446 + :578 / :590; the forward is
+// csrc/patch_embed.hip).  d2 = dLN2(dy) at x2 = LN1(x1) [+ add]  (= the gradient of `add`, written when asked for);  dx1 = dLN1(d2) at x1.
+// d2 is rounded to the storage type before it is used, exactly as the two separate launches hand it over.  Rows are covered as in
+// ln_bwd2_kernel (LPR lanes x one 16-byte chunk, U rows per lane group in flight); plain [rows, C] tensors, one parameter set per norm.
+// =====================================================================================================
+template <typename T> __device__ __forceinline__ float ln_rnd(float x) { T t; stf(&t, x); return ldf(&t); }
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const T* __restrict__ dy, const T* __restrict__ x2, const float* __restrict__ gamma2,
+                                                           const float* __restrict__ mean2, const float* __restrict__ rstd2,
+                                                           const T* __restrict__ x1, const float* __restrict__ gamma1,
+                                                           const float* __restrict__ mean1, const float* __restrict__ rstd1,
+                                                           T* __restrict__ d2out, T* __restrict__ dx1, float* dg2, float* db2, float* dg1, float* db1,
+                                                           long long rows, int C, int np2, long long ps2, int np1, long long ps1) {
+  constexpr int VN = Vec<T>::N, RPW = 64 / LPR, U = 2;
+  __shared__ float red[4][LPR * VN];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sl = lane % LPR, rsub = lane / LPR;
+  for (int c = threadIdx.x; c < 4 * LPR * VN; c += 256) (&red[0][0])[c] = 0.f;
+  __syncthreads();
+  const int c0 = sl * VN;
+  const bool col = c0 < C;
+  const float invC = 1.f / C;
+  float g2[VN], g1[VN], a2[VN], b2[VN], a1[VN], b1[VN];
+#pragma unroll
+  for (int e = 0; e < VN; ++e) { g2[e] = col ? gamma2[c0 + e] : 0.f; g1[e] = col ? gamma1[c0 + e] : 0.f; a2[e] = b2[e] = a1[e] = b1[e] = 0.f; }
+  for (long long row0 = ((long long)blockIdx.x * 4 + w) * (U * RPW); row0 < rows; row0 += (long long)gridDim.x * 4 * (U * RPW)) {
+    float dv[U][VN], xa[U][VN], xb[U][VN], m2[U], r2[U], m1[U], r1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long row = row0 + u * RPW + rsub;
+      const bool ok = row < rows;
+      m2[u] = ok ? mean2[row] : 0.f; r2[u] = ok ? rstd2[row] : 0.f; m1[u] = ok ? mean1[row] : 0.f; r1[u] = ok ? rstd1[row] : 0.f;
+      if (ok && col) { ld16(dy + row * C + c0, dv[u]); ld16(x2 + row * C + c0, xa[u]); ld16(x1 + row * C + c0, xb[u]); }
+      else {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { dv[u][e] = 0.f; xa[u][e] = 0.f; xb[u][e] = 0.f; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long row = row0 + u * RPW + rsub;
+      const bool ok = row < rows;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float xh = col ? (xa[u][e] - m2[u]) * r2[u] : 0.f;              // r = 0 on rows past the end
+        const float gg = dv[u][e] * g2[e];
+        a2[e] += dv[u][e] * xh; b2[e] += dv[u][e];
+        xa[u][e] = xh; dv[u][e] = gg;
+        s1 += gg; s2 += gg * xh;
+      }
+      s1 = group_sum<LPR>(s1) * invC; s2 = group_sum<LPR>(s2) * invC;
+      float d[VN];
+#pragma unroll
+      for (int e = 0; e < VN; ++e) d[e] = ln_rnd<T>(r2[u] * (dv[u][e] - s1 - xa[u][e] * s2));      // as stored by a launch of its own
+      if (ok && col && d2out) st16(d2out + row * C + c0, d);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float dd = (ok && col) ? d[e] : 0.f;
+        const float xh = col ? (xb[u][e] - m1[u]) * r1[u] : 0.f;
+        const float gg = dd * g1[e];
+        a1[e] += dd * xh; b1[e] += dd;
+        xb[u][e] = xh; d[e] = gg;
+        t1 += gg; t2 += gg * xh;
+      }
+      t1 = group_sum<LPR>(t1) * invC; t2 = group_sum<LPR>(t2) * invC;
+      if (ok && col) {
+        float o[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) o[e] = r1[u] * (d[e] - t1 - xb[u][e] * t2);
+        st16(dx1 + row * C + c0, o);
+      }
+    }
+  }
+  // the four parameter gradients: row sub-groups of the wave, then the waves through LDS, then one atomic per column and block
+#pragma unroll
+  for (int e = 0; e < VN; ++e) {
+    float v[4] = {a2[e], b2[e], a1[e], b1[e]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) v[k] += __shfl_xor(v[k], o, 64);
+      if (rsub == 0) atomicAdd(&red[k][c0 + e], v[k]);
+    }
+  }
+  __syncthreads();
+  const long long o2 = (long long)(blockIdx.x % np2) * ps2, o1 = (long long)(blockIdx.x % np1) * ps1;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dg2 + o2 + c, red[0][c]); atomicAdd(db2 + o2 + c, red[1][c]);
+    atomicAdd(dg1 + o1 + c, red[2][c]); atomicAdd(db1 + o1 + c, red[3][c]);
+  }
+}
+template <typename T>
+static int ln_chain_launch(const void* dy, const void* x2, const float* gamma2, const float* mean2, const float* rstd2, const void* x1,
+                           const float* gamma1, const float* mean1, const float* rstd1, void* d2, void* dx1, float* dg2, float* db2, float* dg1,
+                           float* db1, long long rows, int C, int np2, long long ps2, int np1, long long ps1, hipStream_t st) {
+  constexpr int VN = Vec<T>::N;
+  const int chunks = C / VN;
+  const int lpr = chunks <= 16 ? 16 : (chunks <= 32 ? 32 : 64);
+  const long long per_pass = 4ll * 2 * (64 / lpr);                 // rows of one pass of a workgroup
+  long long nb = (rows + per_pass - 1) / per_pass;
+  if (nb > 256) nb = 256;                                          // (as stj_layernorm_bwd: more workgroups only share the parameter-gradient atomics)
+#define LNC(L) hipLaunchKernelGGL((ln_bwd_chain_kernel<T, L>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)dy, (const T*)x2, gamma2, mean2, rstd2, \
+                                  (const T*)x1, gamma1, mean1, rstd1, (T*)d2, (T*)dx1, dg2, db2, dg1, db1, rows, C, np2, ps2, np1, ps1)
+  if (lpr == 16) LNC(16); else if (lpr == 32) LNC(32); else LNC(64);
+#undef LNC
+  return stj_check_launch("stj_layernorm_bwd_chain");
+}
+extern "C" int stj_layernorm_bwd_chain_supported(int C, int dtype) {
+  const int vn = dtype == STJ_F32 ? 4 : 8;
+  return stj_dtype_ok(dtype) && C > 0 && C % vn == 0 && C / vn <= 64;
+}
+extern "C" int stj_layernorm_bwd_chain(const void* dy, const void* x2, const float* gamma2, const float* mean2, const float* rstd2, const void* x1,
+                                       const float* gamma1, const float* mean1, const float* rstd1, void* d2, void* dx1, float* dgamma2,
+                                       float* dbeta2, float* dgamma1, float* dbeta1, long long rows, int C, int nparts2, long long part_stride2,
+                                       int nparts1, long long part_stride1, int dtype, hipStream_t stream) {
+  if (rows <= 0) return STJ_OK;
+  if (!stj_layernorm_bwd_chain_supported(C, dtype)) { stj_set_error("layernorm_bwd_chain: C = %d / dtype %d not built (C a multiple of the 16-byte vector, at most 64 vectors)", C, dtype); return STJ_EUNSUPPORTED; }
+  if (!dy || !x2 || !x1 || !dx1 || !gamma2 || !gamma1 || !mean2 || !rstd2 || !mean1 || !rstd1 || !dgamma2 || !dbeta2 || !dgamma1 || !dbeta1 || nparts2 < 1 ||
+      nparts1 < 1 || (nparts2 > 1 && part_stride2 < C) || (nparts1 > 1 && part_stride1 < C) ||
+      (((uintptr_t)dy | (uintptr_t)x2 | (uintptr_t)x1 | (uintptr_t)dx1 | (uintptr_t)d2) & 15)) {
+    stj_set_error("layernorm_bwd_chain: bad arguments (null / unaligned pointer, nparts / part_stride)"); return STJ_EINVAL;
+  }
+  if (dtype == STJ_BF16) return ln_chain_launch<bf16>(dy, x2, gamma2, mean2, rstd2, x1, gamma1, mean1, rstd1, d2, dx1, dgamma2, dbeta2, dgamma1, dbeta1, rows, C, nparts2, part_stride2, nparts1, part_stride1, stream);
+  if (dtype == STJ_F16) return ln_chain_launch<f16>(dy, x2, gamma2, mean2, rstd2, x1, gamma1, mean1, rstd1, d2, dx1, dgamma2, dbeta2, dgamma1, dbeta1, rows, C, nparts2, part_stride2, nparts1, part_stride1, stream);
+  return ln_chain_launch<float>(dy, x2, gamma2, mean2, rstd2, x1, gamma1, mean1, rstd1, d2, dx1, dgamma2, dbeta2, dgamma1, dbeta1, rows, C, nparts2, part_stride2, nparts1, part_stride1, stream);
+}
+
 // group_rows/ngroups/gstride: parameter groups (ngroups <= 1: one gamma/beta for all rows).
 extern "C" int stj_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                  long long rows, int C, float eps, int gather_res, int C0, long long group_rows, int ngroups,

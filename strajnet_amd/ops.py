@@ -1630,6 +1630,21 @@ def _ln_bwd_plain(dy, x, mean, rstd, pg, pb, rows, C):
     return dx
 
 
+LN_CHAIN = True       # the stem's two LayerNorm backward passes as one launch (stj_layernorm_bwd_chain); False = two stj_layernorm_bwd launches
+
+
+def _ln_grad_targets(pg, pb):
+    """(dgamma, dbeta, nparts, part_stride) of a LayerNorm's parameters: the rotating partial copies when the model set them up."""
+    if pg.part is not None and pb.part is not None:
+        return pg.part[0], pb.part[0], pg.part[1], pg.part[2]
+    return pg.grad, pb.grad, 1, 0
+
+
+def _ln_chain_ok(C, dtype):
+    from ._lib import lib
+    return bool(lib().stj_layernorm_bwd_chain_supported(C, DTYPE_CODE[dtype]))
+
+
 class _PatchEmbed(torch.autograd.Function):
     """PatchEmbed.call (modules.py:437-446) + what the stem does with it (modules.py:572-590), ONE launch (csrc/patch_embed.hip):
     y = LN2(LN(cols(src) @ W + b) [+ add]).  Backward: the two LayerNorm backward launches on the saved pre-norm rows and the weight
@@ -1669,10 +1684,19 @@ class _PatchEmbed(torch.autograd.Function):
         M, N = pre.shape
         K = cols.shape[1]
         dy = dy.contiguous().view(M, N)
-        if pg2 is not None:
-            dy = _ln_bwd_plain(dy, x2, mean2, rstd2, pg2, pb2, M, N)             # gradient of x2 = LN(pre) + add
-        dadd = dy.view(ctx.add_shape) if ctx.has_add else None
-        dpre = _ln_bwd_plain(dy, pre, mean, rstd, pg, pb, M, N)
+        if pg2 is not None and LN_CHAIN and _ln_chain_ok(N, dy.dtype):
+            # both LayerNorm backward passes in one launch (the gradient of `add` is the intermediate, written only when there is an `add`)
+            dpre = torch.empty_like(pre)
+            d2 = torch.empty_like(pre) if ctx.has_add else None
+            (g2, b2, n2, s2), (g1, b1, n1, s1) = _ln_grad_targets(pg2, pb2), _ln_grad_targets(pg, pb)
+            call('stj_layernorm_bwd_chain', _p(dy), _p(x2), _p(pg2.master), _p(mean2), _p(rstd2), _p(pre), _p(pg.master), _p(mean), _p(rstd),
+                 _p(d2), _p(dpre), _p(g2), _p(b2), _p(g1), _p(b1), M, N, n2, s2, n1, s1, _dt(pre), _st())
+            dadd = d2.view(ctx.add_shape) if ctx.has_add else None
+        else:
+            if pg2 is not None:
+                dy = _ln_bwd_plain(dy, x2, mean2, rstd2, pg2, pb2, M, N)         # gradient of x2 = LN(pre) + add
+            dadd = dy.view(ctx.add_shape) if ctx.has_add else None
+            dpre = _ln_bwd_plain(dy, pre, mean, rstd, pg, pb, M, N)
         with wgrad_stream(1, cols, dpre):
             gemm(cols, dpre, gw, K, N, M, (0, 0, 1, K), (0, 0, N, 1), (0, 0, N), _dt(cols), c_f32=1, accumulate=1, splitk=0,
                  colsum=pbias.grad)                                                # dW += cols^T dpre ; db += 1^T dpre

@@ -669,6 +669,16 @@ def test_patch_embed_fused(dt, Cin, ch_stride, nch, with_add, with_norm2, B, H):
     assert rel_err(y1, y0) < (1e-5 if dt == torch.float32 else t)
     for k in g1:
         assert rel_err(g1[k], g0[k]) < (1e-4 if dt == torch.float32 else t), k
+    if with_norm2:      # the two LayerNorm backward passes as one launch (stj_layernorm_bwd_chain, the default) vs two stj_layernorm_bwd launches
+        ops.LN_CHAIN = False
+        try:
+            _, da2, g2, _ = run(True)
+        finally:
+            ops.LN_CHAIN = True
+        for k in g1:     # same arithmetic (the intermediate gradient is rounded to the storage type in both), f32 summation order of the parameter sums
+            assert rel_err(g1[k], g2[k]) < 1e-4, (k, rel_err(g1[k], g2[k]))
+        if with_add:     # the intermediate gradient: the row sums are taken in another order, an element may round to the neighbouring 16-bit value
+            assert rel_err(da1, da2) < (1e-6 if dt == torch.float32 else 2e-3)
 
 
 def test_loss_and_gate():
