@@ -374,6 +374,9 @@ int stj_agent_out_bwd(const void* dy, const void* out, const float* mean, const 
  * Wz T [8][n].  fold (backward): dW[j] += sum over the t whose window contains j of dWz[t]. */
 int stj_time_collapse(const float* W, void* Wz, long long n, int dtype, hipStream_t stream);
 int stj_time_fold(const float* dWz, float* dW, long long n, hipStream_t stream);
+/* g[idx[i]] += parts[i]; parts[i] = 0 for i < n: the partial-gradient copies some backward kernels rotate their atomics over
+ * (LayerNorm gamma / beta, bias tables, conv biases) folded into the flat gradient buffer and re-zeroed, one launch. */
+int stj_fold_parts(float* g, const long long* idx, float* parts, long long n, hipStream_t stream);
 
 /* Host-side CRC-32C (Castagnoli) for the two TensorFlow file formats on either side of the hot path: TFRecord framing
  * (train.py:75-78) and the checkpoint bundle written / read by save_weights / load_weights (train.py:358,366,372;

@@ -31,6 +31,7 @@ SIGNATURES = {
     'stj_agent_sum_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     'stj_agent_sum_bwd': [vp, vp, ci, ci, ci, ci, vp],
     'stj_time_fold': [vp, vp, cl, vp],
+    'stj_fold_parts': [vp, vp, vp, cl, vp],
     'stj_decode_raw': [vp, ci, vp, cl, ci, ci, ci, ci, ci, ci, ci, cf, vp],
     'stj_metrics': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_rng_advance': [vp, vp],

@@ -566,6 +566,22 @@ extern "C" int stj_time_fold(const float* dWz, float* dW, long long n, hipStream
   return stj_check_launch("stj_time_fold");
 }
 
+// Partial-gradient copies -> flat gradient buffer, and the copies re-zeroed for the next backward pass, in ONE launch (was index_add_ + a fill,
+// two dependent launches between the last weight-gradient launch and the optimizer): g[idx[i]] += parts[i]; parts[i] = 0.
+__global__ __launch_bounds__(256) void fold_parts_kernel(float* __restrict__ g, const long long* __restrict__ idx, float* __restrict__ parts, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+    const float v = parts[i];
+    parts[i] = 0.f;
+    if (v != 0.f) atomicAdd(g + idx[i], v);
+  }
+}
+extern "C" int stj_fold_parts(float* g, const long long* idx, float* parts, long long n, hipStream_t stream) {
+  if (n <= 0) return STJ_OK;
+  if (!g || !idx || !parts) { stj_set_error("stj_fold_parts: null pointer"); return STJ_EINVAL; }
+  hipLaunchKernelGGL(fold_parts_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, g, idx, parts, n);
+  return stj_check_launch("stj_fold_parts");
+}
+
 // ------------------------------------------------------------------------------------------------ host CRC-32C
 // TFRecord framing (train.py:75-78 tf.data.TFRecordDataset) and the TF checkpoint bundle (train.py:358,366,372
 // save_weights / load_weights) both checksum with CRC-32C (Castagnoli, reflected 0x82F63B78).  Slice-by-8 on the host: the

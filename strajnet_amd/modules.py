@@ -344,8 +344,7 @@ class STrajNet:
         k = self._parts_split
         lo, hi = {None: (0, self._parts.numel()), 'encoder': (0, k), 'tail': (k, self._parts.numel())}[which]
         if hi > lo:
-            self._gflat.index_add_(0, self._fold_index[lo:hi], self._parts[lo:hi])
-            self._parts[lo:hi].zero_()
+            ops.call('stj_fold_parts', ops._p(self._gflat), ops._p(self._fold_index[lo:hi]), ops._p(self._parts[lo:hi]), hi - lo, ops._st())
 
     def backward_encoder(self):
         """cut_encoder mode: the second half of backward -- from the gradients that backward() left on the encoder outputs down to
