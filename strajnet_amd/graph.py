@@ -70,6 +70,7 @@ class GraphedTrainStep:
         d = self.loss_fn(get_pred_waypoint_logits(out), tw, None)
         total = d.total                      # observed_xe + occluded_xe + flow + flow_warp_xe (train.py:221)
         total.backward()
+        self.total = total.detach()           # the sum the finalize kernel wrote (static across replays, like self.losses)
         return d.packed             # [observed_xe, occluded_xe, flow, flow_warp_xe], detached
 
     def load(self, batch):
