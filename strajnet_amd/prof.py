@@ -167,8 +167,27 @@ def _loss(fam, tens):
     return f
 
 
+def _patch_embed(a):
+    """stj_patch_embed_fwd(src, w, bias, gamma, beta, add, gamma2, beta2, cols, pre, x2, y, mean, rstd, mean2, rstd2, B, H, W, Cin, pix_stride,
+    ch_stride, Cout, eps, dtype, stream): reads the f32 raster lines once, writes the tokens (+ cols / pre / x2 in training, + add read)."""
+    B, H, W, Cin, pix, Cout, dt = a[16], a[17], a[18], a[19], a[20], a[22], a[24]
+    es = _es(dt)
+    M = B * (H // 4) * (W // 4)
+    nz = lambda i: bool(getattr(a[i], 'value', None))
+    by = 4.0 * B * H * W * pix + es * M * Cout * (1 + nz(5) + nz(9) + nz(10)) + es * M * 16 * Cin * nz(8)
+    fl = 2.0 * M * 16 * Cin * Cout
+    return f'patch_embed[{H}x{W},{Cin}->{Cout},B{B}]', 'patch_embed_fwd', fl, fl, by
+
+
+def _ln_chain(a):
+    """stj_layernorm_bwd_chain(dy, x2, g2, mean2, rstd2, x1, g1, mean1, rstd1, d2, dx1, ..., rows, C, ..., dtype, stream)"""
+    rows, C, dt = a[15], a[16], a[21]
+    return f'ln_bwd_chain[{rows}x{C}]', 'layernorm_bwd', 0.0, 0.0, _es(dt) * rows * C * (4 + bool(getattr(a[9], 'value', None)))
+
+
 MODELS = {
     'stj_gemm': _gemm,
+    'stj_patch_embed_fwd': _patch_embed, 'stj_layernorm_bwd_chain': _ln_chain,
     'stj_upconv_fwd': _upconv('fwd'), 'stj_upconv_fwd_head': _upconv_head, 'stj_outconv_pair_gather': _pair_gather, 'stj_upconv_fwd_res': _upconv_res, 'stj_elu_res_bwd': _elu_res, 'stj_upconv_dgrad': _upconv('dgrad'), 'stj_upconv_wgrad': _upconv('wgrad'),
     'stj_outconv_fwd': _outconv('fwd'), 'stj_outconv_pair_fwd': _outconv_pair, 'stj_outconv_bwd': _outconv('bwd'),
     'stj_layernorm_fwd': _ln('fwd'), 'stj_layernorm_bwd': _ln('bwd'), 'stj_layernorm_res_fwd': _ln('res_fwd'),
