@@ -1529,6 +1529,16 @@ bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* 
   const int nblk = min(ntiles, OCB_MAXBLK);          // 3 resident blocks per CU (168 VGPRs, 39 KB LDS): measured best of 512/768/1024
   hipLaunchKernelGGL(outconv_bwd_mfma2_kernel<48>, dim3(nblk), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, (float*)ws, F, Hh, Ww, Tn,
                      y_bs, y_ts, y_ps, elu_in);
+  // dW == db == NULL: the partials stay in ws; the caller sums them with outconv_bwd_reduce_launch wherever it likes (another stream:
+  // the 14 us sum is otherwise a dependent launch between the two heads' kernels on the backward pass's critical chain)
+  if (dW != nullptr || db != nullptr)
+    hipLaunchKernelGGL(outconv_bwd_reduce_kernel, dim3((OCB_PART + 63) / 64, 16), dim3(64), 0, st, (const float*)ws, nblk, dW, db);
+  return true;
+}
+bool outconv_bwd_reduce_launch(const void* ws, long long ws_bytes, int F, int Hh, int Ww, float* dW, float* db, hipStream_t st) {
+  if (Hh % OCM_T || Ww % OCM_T || !ws || ws_bytes < outconv_bwd_ws_bytes() || !dW || !db) return false;
+  const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
+  const int nblk = min(ntiles, OCB_MAXBLK);
   hipLaunchKernelGGL(outconv_bwd_reduce_kernel, dim3((OCB_PART + 63) / 64, 16), dim3(64), 0, st, (const float*)ws, nblk, dW, db);
   return true;
 }

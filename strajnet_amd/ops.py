@@ -1974,6 +1974,7 @@ def _outconv_workspace(device):
     return _workspace(device, 'stj_outconv_bwd_workspace_bytes')
 
 
+OUTCONV_REDUCE_ASIDE = os.environ.get('STJ_NO_WS') != '1'
 PAIR_OUTCONV = os.environ.get('STJ_NO_WS') != '1'     # (the paired kernel belongs to the MFMA / weight-stationary family)
 
 
@@ -2011,6 +2012,16 @@ class _OutConvPair(torch.autograd.Function):
         dt = _dt(xo)
         dxo, dxf = torch.empty_like(xo), torch.empty_like(xf)
         ws = _outconv_workspace(xo.device)
+        if OUTCONV_REDUCE_ASIDE and dt == 1 and not _SERIAL and prof.ACTIVE is None and C == 48 and H % 16 == 0 and W % 16 == 0:
+            # the sums of the per-workgroup dW / db partials (two 14 us launches) leave the chain head 1 -> head 2 -> decoder: they run on
+            # the weight-gradient side stream, each head with a workspace of its own
+            ws2 = _workspace(xo.device, 'stj_outconv_bwd_workspace_bytes', 1)
+            for x, pw, pb, dx, off, w_ in ((xo, p1w, p1b, dxo, 0, ws), (xf, p2w, p2b, dxf, 8, ws2)):
+                call('stj_outconv_bwd', _p(x), _p(pw.master), vp(dout.data_ptr() + off), _p(dx), _p(None), _p(None), F_, H, W, C, Tn,
+                     ybs, yts, yps, ctx.elu_in, _p(w_), w_.numel(), dt, _st())
+                with wgrad_stream(1, w_):
+                    call('stj_outconv_bwd_reduce', _p(w_), w_.numel(), F_, H, W, _p(pw.grad), _p(pb.grad), _st())
+            return (dxo, dxf) + (None,) * 12
         call('stj_outconv_bwd', _p(xo), _p(p1w.master), vp(dout.data_ptr()), _p(dxo), _p(p1w.grad), _p(p1b.grad), F_, H, W, C, Tn,
              ybs, yts, yps, ctx.elu_in, _p(ws), ws.numel(), dt, _st())
         call('stj_outconv_bwd', _p(xf), _p(p2w.master), vp(dout.data_ptr() + 8), _p(dxf), _p(p2w.grad), _p(p2b.grad), F_, H, W, C, Tn,
