@@ -1936,6 +1936,40 @@ class _UpConvAdd(torch.autograd.Function):
 # B=32 fp16 forward 1.4 % faster.
 
 
+SKIP_BWD_FUSED = True      # (False: the level's backward junction as an elementwise add + the ELU' pass; the f32 mode always)
+
+
+class _UpConvSkips(torch.autograd.Function):
+    """y1 = ELU(upconv(x)) + r1, y2 = y1 + r2 (the decoder level with two skips, modules.py:757-765) with the forward as the launches that measure
+    fastest in training (the up-conv, then two elementwise adds) and the backward's junction as ONE launch: the sum of the two incoming
+    gradients and its product with ELU'(ELU output) (stj_elu_res_bwd with r = NULL) instead of an elementwise add followed by the ELU' pass."""
+    @staticmethod
+    def forward(ctx, x, r1, r2, w_master, b_master, pw, pb, prep):
+        _req_cuda(x, r1, r2)
+        x = x.contiguous()
+        F_, Hi, Wi, Cin = x.shape
+        Cout = pw.master.shape[-1]
+        wf, wd = prep if prep is not None else upconv_prep(pw, x.dtype)
+        y = torch.empty((F_, 2 * Hi, 2 * Wi, Cout), dtype=x.dtype, device=x.device)
+        call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, _dt(x), _st())
+        y1 = y + r1
+        y2 = y1 + r2
+        ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
+        ctx.x_is_elu_out = False
+        ctx.defer = _UPWG['on']
+        ctx.save_for_backward(x, y, wd)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x, y, wd = ctx.saved_tensors
+        dy1, dy2 = dy1.contiguous(), dy2.contiguous()
+        dpre, gsum = torch.empty_like(dy1), torch.empty_like(dy1)
+        call('stj_elu_res_bwd', _p(dy1), _p(dy2), _p(y), _p(None), _p(dpre), _p(gsum), dy1.numel(), _dt(x), _st())
+        dx = _upconv_backward_tail(ctx, x, dpre, wd, ctx.needs_input_grad[0])
+        return dx, gsum, dy2, None, None, None, None, None
+
+
 FUSED_SKIP_TRAIN = False       # (tests flip it: the fused form's backward, stj_elu_res_bwd, is the one a fine-tuning caller of the inference graph gets)
 
 
@@ -1946,6 +1980,8 @@ def upconv_add(x, pw, pb, r1, r2=None, prep=None):
     oshape = (x.shape[0], 2 * x.shape[1], 2 * x.shape[2], Cout)
     if (FUSED_SKIP_TRAIN or not torch.is_grad_enabled()) and x.dtype != torch.float32 and Cin > 128 and Cin % 32 == 0 and Cout % 32 == 0 and os.environ.get('STJ_NO_WS') != '1':
         return _UpConvAdd.apply(x, r1.view(oshape), None if r2 is None else r2.view(oshape), pw.master, pb.master, pw, pb, prep)
+    if SKIP_BWD_FUSED and r2 is not None and x.dtype != torch.float32 and torch.is_grad_enabled():
+        return _UpConvSkips.apply(x, r1.view(oshape), r2.view(oshape), pw.master, pb.master, pw, pb, prep)
     y = upconv(x, pw, pb, prep=prep)
     y = y + r1.view(y.shape)
     return y if r2 is None else (y, y + r2.view(y.shape))
