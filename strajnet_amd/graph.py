@@ -24,6 +24,7 @@ class GraphedTrainStep:
         self.graph = self.graph_b = None
         self._side = None
         self.losses = None
+        self._one = None
         if split:
             model.cut_encoder = True
         side = torch.cuda.Stream()
@@ -69,7 +70,9 @@ class GraphedTrainStep:
             main.wait_stream(self._side)
         d = self.loss_fn(get_pred_waypoint_logits(out), tw, None)
         total = d.total                      # observed_xe + occluded_xe + flow + flow_warp_xe (train.py:221)
-        total.backward()
+        if self._one is None:                # (first warm-up pass, outside the capture: backward()'s implicit ones_like is a fill launch between
+            self._one = torch.ones_like(total)   #  the loss's forward and backward kernels on every replay)
+        total.backward(self._one)
         self.total = total.detach()           # the sum the finalize kernel wrote (static across replays, like self.losses)
         return d.packed             # [observed_xe, occluded_xe, flow, flow_warp_xe], detached
 
