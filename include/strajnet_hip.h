@@ -402,6 +402,8 @@ int stj_metrics(const float* pred, const float* gt_obs, const float* gt_occ, con
  * state = device int64[2] {seed, step} and `site`; backward calls stj_dropout on dY with the same (state, site).
  * stj_dropout_mask writes the keep bytes of the first ndraw draws (test hook: the oracle is fed the same masks). */
 int stj_rng_advance(long long* state, hipStream_t stream);
+/* stj_rng_advance that also writes the advanced {seed, step} to snap[2] (one launch instead of the advance + a device copy). */
+int stj_rng_advance_snap(long long* state, long long* snap, hipStream_t stream);
 int stj_dropout(const void* x, const void* res, void* y, long long n, long long inner, float p, const long long* state,
                 int site, int dtype, hipStream_t stream);
 int stj_dropout_mask(unsigned char* mask, long long ndraw, float p, const long long* state, int site, hipStream_t stream);

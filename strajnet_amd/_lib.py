@@ -35,6 +35,7 @@ SIGNATURES = {
     'stj_decode_raw': [vp, ci, vp, cl, ci, ci, ci, ci, ci, ci, ci, cf, vp],
     'stj_metrics': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_rng_advance': [vp, vp],
+    'stj_rng_advance_snap': [vp, vp, vp],
     'stj_dropout': [vp, vp, vp, cl, cl, cf, vp, ci, ci, vp],
     'stj_dropout_mask': [vp, cl, cf, vp, ci, vp],
     'stj_nadam_step': [vp, vp, vp, vp, cl, cf, cf, cf, cf, cf, cf, cf, cf, vp],

@@ -91,6 +91,14 @@ extern "C" int stj_rng_advance(long long* state, hipStream_t stream) {
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, stream, state);
   return stj_check_launch("stj_rng_advance");
 }
+// the same, and the advanced state copied to snap[2] (the snapshot a forward pass's backward kernels re-derive their masks from): one launch
+// instead of the advance + a device copy at the head of every step
+__global__ void rng_advance_snap_kernel(long long* state, long long* snap) { const long long s = state[1] + 1; state[1] = s; snap[0] = state[0]; snap[1] = s; }
+extern "C" int stj_rng_advance_snap(long long* state, long long* snap, hipStream_t stream) {
+  if (!state || !snap) { stj_set_error("stj_rng_advance_snap: null pointer"); return STJ_EINVAL; }
+  hipLaunchKernelGGL(rng_advance_snap_kernel, dim3(1), dim3(1), 0, stream, state, snap);
+  return stj_check_launch("stj_rng_advance_snap");
+}
 // y = (res ? res : 0) + keep(draw(i)) * x / (1 - p),  draw(i) = i / inner.  x, res, y: n elements of `dtype`; y may alias x.
 extern "C" int stj_dropout(const void* x, const void* res, void* y, long long n, long long inner, float p, const long long* state,
                            int site, int dtype, hipStream_t stream) {

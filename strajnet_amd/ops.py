@@ -1335,8 +1335,8 @@ class DropCtx:
         self.snap, self.n, self.sites = None, 0, {}
 
     def begin(self):
-        call('stj_rng_advance', _p(self.state), _st())
-        self.snap = self.state.clone()          # backward of THIS forward keeps reading this step, whatever runs in between
+        self.snap = torch.empty_like(self.state)  # backward of THIS forward keeps reading this step, whatever runs in between
+        call('stj_rng_advance_snap', _p(self.state), _p(self.snap), _st())
         self.n, self.sites = 0, {}
 
     def site(self, name, shape, p):
