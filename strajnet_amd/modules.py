@@ -205,7 +205,11 @@ class STrajNet:
                 for z in range(1, 8):
                     assert offs[n.replace('obs0', f'obs{z}')] - offs[n] == z * self._zstride
         self._flat = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self._gflat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        # the flat gradient buffer and the step's zeroed scratch (ops._ZeroArena) share ONE allocation: zero_grad() is one fill over the
+        # gradients + the used prefix of the arena instead of two launches at the head of every step
+        self._goff8 = (off + 7) // 8 * 8
+        self._gbuf = torch.zeros(self._goff8 + ops._ZeroArena.FLOATS, dtype=torch.float32, device=self.device)
+        self._gflat = self._gbuf[:off]
         self._cflat = self._flat if dtype == torch.float32 else torch.zeros(off, dtype=dtype, device=self.device)
         gen = torch.Generator().manual_seed(seed)
         # DropPath schedule (modules.py:507,527,548): rates linspace(0, .1, sum(depths)); the flow stage reuses the first depths[0]
@@ -222,6 +226,7 @@ class STrajNet:
         # (per replica: seed + rank, like MirroredStrategy's independent per-replica draws)
         self.dropctx = ops.DropCtx(self.device, seed if dropout_seed is None else dropout_seed)
         self._arena = ops._ZeroArena()    # this model's zeroed scratch (one fill per step)
+        self._arena.adopt(self._gbuf[self._goff8:])
         self._dctx = None
         self._side = torch.cuda.Stream(self.device) if (self.device.type == 'cuda' and os.environ.get('STJ_NO_SIDE_STREAM') != '1') else None
         self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and os.environ.get('STJ_NO_SIDE_STREAM') != '2') else None
@@ -334,8 +339,8 @@ class STrajNet:
         return self._flat
 
     def zero_grad(self):
-        self._gflat.zero_()
-        self._arena.arm(self.device)         # the step's zeroed scratch comes out of this model's arena, re-zeroed here
+        self._gbuf[:self._goff8 + self._arena.off].zero_()      # the gradients and what the last step took from the arena: one fill
+        self._arena.rearm()                  # the step's zeroed scratch comes out of this model's arena
         ops.use_arena(self._arena)
 
     def _fold_partials(self, which=None):

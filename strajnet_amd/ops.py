@@ -149,6 +149,14 @@ class _ZeroArena:
         d = torch.device(device)
         return self.buf is not None and self.buf.device.type == d.type and (d.index is None or d.index == self.buf.device.index)
 
+    def adopt(self, buf):
+        """Use `buf` (zeroed f32 storage the owner re-zeroes itself: see rearm) instead of an allocation of the arena's own."""
+        self.buf, self.off, self.armed, self.external = buf, 0, False, True
+
+    def rearm(self):
+        """Start of a step for an adopted buffer: the OWNER has just zeroed buf[:off] (one fill together with its own tensors)."""
+        self.off, self.armed = 0, True
+
     def arm(self, device):
         """Start of a step: everything handed out so far is dead; zero it again."""
         if not self._here(device):
