@@ -307,9 +307,6 @@ int stj_outconv_bwd(const void* X, const float* W, const float* dY, void* dX, fl
                     int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int elu_in, void* ws,
                     long long ws_bytes, int dtype, hipStream_t stream);
 long long stj_outconv_bwd_workspace_bytes(void);   /* size of the caller-owned scratch `ws` (not zeroed; may be NULL: slower path) */
-/* stj_outconv_bwd with dW = db = NULL (bf16, workspace given) leaves the weight / bias gradient as per-workgroup partials in ws;
- * stj_outconv_bwd_reduce adds their sum into dW / db -- on any stream ordered behind that call, e.g. beside the next head's kernel. */
-int stj_outconv_bwd_reduce(const void* ws, long long ws_bytes, int F, int Hh, int Ww, float* dW, float* db, hipStream_t stream);
 /* PatchEmbed Conv2D k=4 s=4 VALID as im2col (+ f32->T cast, + stride-2 pick of ogm[...,0]; modules.py:430-431,572). */
 int stj_im2col_patch(const float* src, void* dst, int B, int H, int W, int Cin, long long pix_stride, int ch_stride,
                      int dtype, hipStream_t stream);

@@ -90,7 +90,6 @@ SIGNATURES = {
     'stj_outconv_pair_gather': [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp],
     'stj_outconv_bwd': [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cl, cl, cl, ci, vp, cl, ci, vp],
-    'stj_outconv_bwd_reduce': [vp, cl, ci, ci, ci, vp, vp, vp],
     'stj_outconv_bwd_workspace_bytes': [],
     'stj_im2col_patch': [vp, vp, ci, ci, ci, ci, cl, ci, ci, vp],
     'stj_im2col3': [vp, vp, ci, ci, ci, ci, ci, ci, vp],

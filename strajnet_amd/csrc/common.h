@@ -282,3 +282,12 @@ static inline bool stj_is16(int dtype) { return dtype == STJ_BF16 || dtype == ST
 static inline bool stj_dtype_ok(int dtype) { return dtype == STJ_F32 || dtype == STJ_BF16 || dtype == STJ_F16; }
 void stj_set_error(const char* fmt, ...);
 int stj_check_launch(const char* what);
+
+// A launcher's once-per-process state that is really once per DEVICE (hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current
+// device's copy of the code object; the CU count is the current device's): one slot per device ordinal, read / written for the current one.
+template <typename V> struct PerDevice {
+  V v[64] = {};
+  V& ref() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0; return v[d]; }
+  operator V() { return ref(); }
+  PerDevice& operator=(V x) { ref() = x; return *this; }
+};

@@ -448,7 +448,7 @@ static bool upconv_dgrad_pf_try(const void* dP, const void* Wd, void* dX, const 
   if (!on || Hi % TILE_H || Wi % TILE_W || Cin % 64 || Cout % KC || Cin <= 128) return false;
   constexpr int FN = 4, BN = FN * 16, LDK = KC + 8;
   const size_t lds = (size_t)((2 * TILE_H + 2) * (2 * TILE_W + 2) * LDK + 16 * BN * LDK) * sizeof(T);
-  static bool attr_set = false;
+  static PerDevice<bool> attr_set;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)upconv_dgrad_pf_kernel<T, FN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
@@ -918,12 +918,9 @@ extern "C" int stj_outconv_bwd(const void* X, const float* W, const float* dY, v
                                int C, int Tn, long long y_bstride, long long y_tstride, long long y_pstride, int elu_in, void* ws,
                                long long ws_bytes, int dtype, hipStream_t stream) {
   if (Hh % OC_T || Ww % OC_T || C % 8) { stj_set_error("outconv: H,W must be multiples of 16 and C of 8"); return STJ_EINVAL; }
+  if (dW == nullptr || db == nullptr) { stj_set_error("stj_outconv_bwd: dW / db must not be NULL"); return STJ_EINVAL; }
   if (dtype == STJ_BF16 && ws_enabled() && outconv_bwd_mfma_try(X, W, dY, dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, elu_in, ws, ws_bytes, stream))
     return stj_check_launch("stj_outconv_bwd(mfma)");
-  if (dW == nullptr || db == nullptr) {
-    stj_set_error("stj_outconv_bwd: the deferred-reduction form (dW = db = NULL) needs the bf16 MFMA kernel and its workspace");
-    return STJ_EUNSUPPORTED;
-  }
   const size_t lds = (size_t)(18 * 18 * (C + 1) + 9 * C * 2 + 18 * 18 * 2) * 4;
   if (lds > 160 * 1024 || 9 * C > 1024) { stj_set_error("outconv: C=%d too large", C); return STJ_EUNSUPPORTED; }
   const int grid = min(1024, F * (Hh / OC_T) * (Ww / OC_T));
@@ -938,13 +935,6 @@ extern "C" int stj_outconv_bwd(const void* X, const float* W, const float* dY, v
     hipLaunchKernelGGL(outconv_bwd_kernel<float>, dim3(grid), dim3(256), lds, stream, (const float*)X, W, dY, (float*)dX, dW, db, F, Hh, Ww, C, Tn, y_bstride, y_tstride, y_pstride, elu_in);
   }
   return stj_check_launch("stj_outconv_bwd");
-}
-
-bool outconv_bwd_reduce_launch(const void* ws, long long ws_bytes, int F, int Hh, int Ww, float* dW, float* db, hipStream_t st);
-// second half of stj_outconv_bwd called with dW = db = NULL: dW / db += the per-workgroup partials that call left in ws
-extern "C" int stj_outconv_bwd_reduce(const void* ws, long long ws_bytes, int F, int Hh, int Ww, float* dW, float* db, hipStream_t stream) {
-  if (!outconv_bwd_reduce_launch(ws, ws_bytes, F, Hh, Ww, dW, db, stream)) { stj_set_error("stj_outconv_bwd_reduce: bad arguments"); return STJ_EINVAL; }
-  return stj_check_launch("stj_outconv_bwd_reduce");
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -185,7 +185,7 @@ static bool fwd_ps_launch(const void* X, const void* Wf, const float* bias, void
   constexpr int LDK = PS_KC + 16, CT = FN * 16, LDO = CT + 8;
   const size_t lds_h = (size_t)2 * PS_HH * PS_HW * LDK * 2, lds_o = (size_t)2 * PS_TH * 2 * PS_TW * LDO * 2;
   const size_t lds = lds_h > lds_o ? lds_h : lds_o;
-  static bool attr_set = false;
+  static PerDevice<bool> attr_set;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)upconv_fwd_ps_kernel<T, FN, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;

@@ -176,7 +176,7 @@ template <typename T, int KS, int NF, int NW>
 static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, int act, hipStream_t st) {
   constexpr int CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 8;
   const size_t lds = (size_t)(2 * WS_HH * WS_HW * LDK + 2 * WS_TH * 2 * WS_TW * LDO) * 2;
-  static bool attr_set = false;
+  static PerDevice<bool> attr_set;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)upconv_fwd_ws_kernel<T, KS, NF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
@@ -519,7 +519,7 @@ template <typename T, int KS, int NF, bool EXACT>
 static bool ws2_launch_t(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, hipStream_t st) {
   constexpr int CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 8;
   const size_t lds = (size_t)(2 * WS_HH * WS_HW * LDK + 2 * 8 * 2 * WS_TW * LDO) * 2;
-  static bool attr_set = false;
+  static PerDevice<bool> attr_set;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)upconv_fwd_ws2_kernel<T, KS, NF, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
@@ -539,7 +539,7 @@ template <typename T>
 static bool ws2_head_launch(const void* X, const void* Wf, const float* bias, const float* Wh, void* Z, int F, int Hi, int Wi, hipStream_t st) {
   constexpr int KS = 3, NF = 3, CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 8;
   const size_t lds = (size_t)(2 * WS_HH * WS_HW * LDK + 2 * 8 * 2 * WS_TW * LDO) * 2;       // (the z stage is smaller than the y stage it replaces)
-  static bool attr_set = false;
+  static PerDevice<bool> attr_set;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)upconv_fwd_ws2_kernel<T, KS, NF, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
@@ -903,7 +903,7 @@ static bool wgrad_tr4_launch(const void* X, const void* dP, float* dWeff, float*
                              int tiles, int wg_budget, hipStream_t st) {
   constexpr int CR = NPIX / CW, BO = FO * 16, BI = FI * 16;
   const size_t lds = (size_t)2 * (CR * 2 * CW * (BO + 8) + (CR + 1) * (CW + 2) * ((BI / 16) % 2 ? BI : BI + 16)) * 2;
-  static bool attr_set = false;
+  static PerDevice<bool> attr_set;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)upconv_wgrad_tr4_kernel<FO, FI, CW, NPIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
@@ -1529,20 +1529,9 @@ bool outconv_bwd_mfma_try(const void* X, const float* W, const float* dY, void* 
   const int nblk = min(ntiles, OCB_MAXBLK);          // 3 resident blocks per CU (168 VGPRs, 39 KB LDS): measured best of 512/768/1024
   hipLaunchKernelGGL(outconv_bwd_mfma2_kernel<48>, dim3(nblk), dim3(256), 0, st, (const bf16*)X, W, dY, (bf16*)dX, (float*)ws, F, Hh, Ww, Tn,
                      y_bs, y_ts, y_ps, elu_in);
-  // dW == db == NULL: the partials stay in ws; the caller sums them with outconv_bwd_reduce_launch wherever it likes (another stream:
-  // the 14 us sum is otherwise a dependent launch between the two heads' kernels on the backward pass's critical chain)
-  if (dW != nullptr || db != nullptr)
-    hipLaunchKernelGGL(outconv_bwd_reduce_kernel, dim3((OCB_PART + 63) / 64, 16), dim3(64), 0, st, (const float*)ws, nblk, dW, db);
-  return true;
-}
-bool outconv_bwd_reduce_launch(const void* ws, long long ws_bytes, int F, int Hh, int Ww, float* dW, float* db, hipStream_t st) {
-  if (Hh % OCM_T || Ww % OCM_T || !ws || ws_bytes < outconv_bwd_ws_bytes() || !dW || !db) return false;
-  const int ntiles = F * (Hh / OCM_T) * (Ww / OCM_T);
-  const int nblk = min(ntiles, OCB_MAXBLK);
   hipLaunchKernelGGL(outconv_bwd_reduce_kernel, dim3((OCB_PART + 63) / 64, 16), dim3(64), 0, st, (const float*)ws, nblk, dW, db);
   return true;
 }
-
 // =====================================================================================================
 // Input gradient of the folded up-conv, v2 (bf16): weight-stationary per INPUT phase + LDS reduction.
 //   dX[f,i,j,:] = sum_{a,b} sum_{r,s} dP[f, 2i+u, 2j+v, :] . Weff[a,b,r,s]^T ,  u = 2-a-2r, v = 2-b-2s
@@ -1754,7 +1743,7 @@ template <int KS, int NFI, bool ELU, int COUT>
 static bool dgrad_ws_launch2(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   constexpr int LDK = KS * 32 + 8, HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), CT = NFI * 16, LDR = CT + 4;
   const size_t lds = (size_t)(HPIX * LDK + 64) * 2 + (size_t)2 * 4 * 2 * 16 * LDR * 2;
-  static bool attr_set = false;
+  static PerDevice<bool> attr_set;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)upconv_dgrad_ws_kernel<KS, NFI, ELU, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
@@ -2146,7 +2135,7 @@ template <bool ELU, bool V3>
 static bool dgrad_ws2_launch(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, hipStream_t st) {
   constexpr int LDK = 56, HPIX = (2 * WS_TH + 2) * (2 * WS_TW + 2), LDR = 104;
   const size_t lds = (size_t)(HPIX * LDK + 2 * 4 * 2 * 16 * LDR) * 2;
-  static bool attr_set = false;
+  static PerDevice<bool> attr_set;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)upconv_dgrad_ws2_kernel<ELU, V3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;

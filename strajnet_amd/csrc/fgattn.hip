@@ -400,7 +400,7 @@ template <typename T, int NKF> static int launch(bool bwd, const Args& a, hipStr
   const int tt = (2 * a.Hh - 1) * (2 * a.Ww - 1);
   const int lds = bwd ? Lds<T, NKF>::bwd_bytes(tt) : Lds<T, NKF>::fwd_bytes(tt);
   const void* fn = bwd ? (const void*)fgattn_bwd_kernel<T, NKF> : (const void*)fgattn_fwd_kernel<T, NKF>;
-  static int reserved[2] = {0, 0};           // per (T, NKF) instantiation and direction: the attribute is set once per size, not per launch
+  static PerDevice<int> reserved[2];           // per (T, NKF) instantiation and direction: the attribute is set once per size, not per launch
   if (lds > 160 * 1024) { stj_set_error("fg_attn: %d bytes of LDS", lds); return STJ_ELAUNCH; }
   if (lds > reserved[bwd]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {

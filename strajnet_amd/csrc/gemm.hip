@@ -514,7 +514,7 @@ template <typename T, int KS, int NC, bool TB>
 static bool rs_launch2(const GemmArgs& p, hipStream_t st) {
   constexpr int K = KS * 32;
   constexpr size_t lds = (size_t)(TB ? K * (NC + 4) : NC * (K + 16)) * 2;
-  static bool attr_set = false;
+  static PerDevice<bool> attr_set;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)linear_rs_kernel<T, KS, NC, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(Args a) {
 
 template <typename T, int CIN>
 static int launch(const Args& a, hipStream_t stream) {
-  static bool attr = false;
+  static PerDevice<bool> attr;
   const size_t lds = Geo<T>::lds_bytes(16 * CIN);
   if (!attr) {
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)patch_embed_fwd_kernel<T, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

@@ -119,6 +119,42 @@ template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
   }
 }
 
+
+// ---- SPLIT == 2: the slices of one unit (row block / window) hand their partial sums over INSIDE the launch ------------------------
+// Every slice workgroup writes its accumulators as one slab (write-through 16-byte stores, fragment order: each store instruction of
+// the workgroup is one contiguous 4 KB piece), drains them, and draws a ticket from the unit's counter; the workgroup that draws the
+// last ticket adds the other slabs to its own accumulators (sc1 loads: the producers stored sc1, MI355X_MICROARCH.md "Workgroup
+// dispatch, XCD placement & inter-workgroup visibility") and runs the epilogue.  No dispatch-order, residency or placement assumption:
+// nobody waits for anybody.  With two slices the sum is own + other in either arrival order: bitwise reproducible.
+// ws = [FIX_CNT_BYTES of int counters, zeroed ONCE by the caller (the last arriver re-arms its counter)] [slabs [unit][slice][NFR][256] f32x4]
+constexpr int FIX_CNT_BYTES = 16384;                 // up to 4096 units per launch
+template <int NFR>
+__device__ __forceinline__ bool slice_combine(f32x4* acc, void* ws, int unit, int sp, int S, int tid, int* s_ticket) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  int* cnt = reinterpret_cast<int*>(ws) + unit;
+  constexpr unsigned SLAB = 256u * NFR * 16u;        // bytes of one slab
+  char* base = reinterpret_cast<char*>(ws) + FIX_CNT_BYTES + (long long)unit * S * SLAB;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (unsigned)S * SLAB, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < NFR; ++j)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j]), rs, (unsigned)sp * SLAB + (unsigned)(j * 256 + tid) * 16u, 0, 16 /* sc1 */);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) *s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*s_ticket != S - 1) return false;
+  if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int s = 0; s < S; ++s) {
+    if (s == sp) continue;
+#pragma unroll
+    for (int j = 0; j < NFR; ++j) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)s * SLAB + (unsigned)(j * 256 + tid) * 16u, 0, 16 /* sc1 */);
+      acc[j] += __builtin_bit_cast(f32x4, v);
+    }
+  }
+  return true;
+}
+
 // ---- geometry ---------------------------------------------------------------------------------------------------
 template <typename T, int C, int RF_ = ((C <= 192) ? 2 : 1)> struct MlpCfg {
   static constexpr int KSTEP = Mma<T>::KSTEP;
@@ -269,7 +305,7 @@ __device__ __forceinline__ void ln_rows(typename Mma<T>::Frag (&xa)[RF][C / Mma<
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <typename T, int C, int RFP, bool SPLIT = false>
+template <typename T, int C, int RFP, int SPLIT = 0>
 __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs p) {
   typedef MlpCfg<T, C, RFP> G;
   constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP;
@@ -348,7 +384,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
   }
 
   // epilogue: y = x + dp * (acc + b2); the lane holds columns 16 f + 4 g .. +3 of row (m0 + 16 i + ln)
-  if constexpr (SPLIT) {          // this slice's share of the sum over the hidden dimension; swin_split_fwd_epi_kernel finishes the rows
+  if constexpr (SPLIT == 1) {     // this slice's share of the sum over the hidden dimension; swin_split_fwd_epi_kernel finishes the rows
 #pragma unroll
     for (int i = 0; i < RF; ++i) {
       const long long row = m0 + 16 * i + ln;
@@ -358,6 +394,10 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
       for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(pr + 16 * f) = acc2[i][f];
     }
     return;
+  }
+  if constexpr (SPLIT == 2) {     // the slices' sums meet in the workgroup that finishes last (slice_combine); it alone goes on
+    __shared__ int ticket;
+    if (!slice_combine<RF * NF>(&acc2[0][0], p.part, unit, sp, p.split, tid, &ticket)) return;
   }
   T* y = reinterpret_cast<T*>(p.y);
 #pragma unroll
@@ -384,7 +424,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
 // =====================================================================================================================
 // backward
 // =====================================================================================================================
-template <typename T, int C, int RFP, bool SPLIT = false>
+template <typename T, int C, int RFP, int SPLIT = 0>
 __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs p) {
   typedef MlpCfg<T, C, RFP> G;
   constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP, LK = Mma<T>::LANE_K;
@@ -501,7 +541,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
     }
   }
 
-  if constexpr (SPLIT) {          // this slice's share of d LN(x); swin_split_bwd_epi_kernel sums the slices and runs the LayerNorm backward
+  if constexpr (SPLIT == 1) {     // this slice's share of d LN(x); swin_split_bwd_epi_kernel sums the slices and runs the LayerNorm backward
 #pragma unroll
     for (int i = 0; i < RF; ++i) {
       const long long row = m0 + 16 * i + ln;
@@ -511,6 +551,10 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
       for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(pr + 16 * f) = acc[i][f];
     }
     return;
+  }
+  if constexpr (SPLIT == 2) {     // (see the forward kernel)
+    __shared__ int ticket;
+    if (!slice_combine<RF * NF>(&acc[0][0], p.part, unit, sp, p.split, tid, &ticket)) return;
   }
   // LayerNorm backward on the accumulator layout (lane: columns 16 f + 4 g .. +3 of row m0 + 16 i + ln) + the skip gradient
   T* dx = reinterpret_cast<T*>(p.dx);
@@ -742,11 +786,11 @@ constexpr int SPLIT_MAX = 8;         // slices of a split launch (the workspace 
 static int mlp_split_for(long long M) { const long long blocks = (M + 63) / 64; return blocks <= 32 ? 8 : (blocks <= 64 ? 4 : 2); }
 static int attn_split_for(long long windows) { return windows <= 48 ? 6 : 2; }
 
-template <typename T, int C, int RFP, bool SPLIT = false>
+template <typename T, int C, int RFP, int SPLIT = 0>
 static int mlp_launch(bool bwd, const MlpArgs& a, hipStream_t st) {
   typedef MlpCfg<T, C, RFP> G;
   const void* fn = bwd ? (const void*)swin_mlp_bwd_kernel<T, C, RFP, SPLIT> : (const void*)swin_mlp_fwd_kernel<T, C, RFP, SPLIT>;
-  static bool attr[2] = {false, false};
+  static PerDevice<bool> attr[2];
   if (!attr[bwd]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
       stj_set_error("swin_mlp: cannot reserve %d bytes of LDS", G::LDS_BYTES); return STJ_ELAUNCH;
@@ -765,13 +809,21 @@ static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
   const bool two = a.M >= 256 * 128;
   switch (C) {
     case 96: return two ? mlp_launch<T, 96, 2>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
-    case 192: return two ? mlp_launch<T, 192, 2>(bwd, a, st) : mlp_launch<T, 192, 1>(bwd, a, st);
+    case 192: {
+      // 8192 rows (cfg-256's 32 x 32 stage at B = 8) are 128 row blocks of 64: with the workspace the hidden dimension is cut in two, 256
+      // workgroups that each stage half of the weights and meet inside the launch (SPLIT == 2)
+      if (two) return mlp_launch<T, 192, 2>(bwd, a, st);
+      if (a.part == nullptr || sizeof(T) != 2 || (a.M + 63) / 64 > FIX_CNT_BYTES / 4) return mlp_launch<T, 192, 1>(bwd, a, st);
+      MlpArgs s = a;
+      s.split = 2;
+      return mlp_launch<T, 192, 1, 2>(bwd, s, st);
+    }
     case 384: {
       // (a one-workgroup-per-row-block form without the workspace existed: 32 workgroups at B = 8, never taken by ops.py, 0.2 MB of code)
       if (a.part == nullptr) { stj_set_error("swin_mlp: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
       MlpArgs s = a;                 // (row block, hidden slice) workgroups + the finishing launch
       s.split = mlp_split_for(a.M);
-      const int rc = mlp_launch<T, 384, 1, true>(bwd, s, st);
+      const int rc = mlp_launch<T, 384, 1, 1>(bwd, s, st);
       if (rc != STJ_OK) return rc;
       if (bwd) return split_bwd_epi<T>(a.x, a.dy, a.part, s.split, a.gamma, a.eps, nullptr, nullptr, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.M, st);
       return split_fwd_epi<T>(a.x, a.part, s.split, a.b2, a.y, a.M, C, a.rng, a.site, a.p_drop, a.rows_per_sample, st);
@@ -792,7 +844,11 @@ static int mlp_any(bool bwd, int C, int dtype, const MlpArgs& a, hipStream_t st)
 
 // bytes of the f32 workspace `ws` of the four stj_swin_* entry points at C = 384 (NULL: the one-workgroup-per-row-block kernels; other
 // C: ignored): the slices' partial sums [SPLIT_MAX][M][C]
-extern "C" long long stj_swin_split_workspace_bytes(long long M, int C) { return (long long)SPLIT_MAX * M * C * 4; }
+extern "C" long long stj_swin_split_workspace_bytes(long long M, int C) {
+  if (C == 384) return (long long)SPLIT_MAX * M * C * 4;
+  if (C == 192 && M < 256 * 128) return FIX_CNT_BYTES + 2 * ((M + 63) / 64 * 64) * C * 4;        // counters + two slabs per 64-row unit
+  return 0;
+}
 
 extern "C" int stj_swin_mlp_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
                                 const float* b2, void* y, long long M, int C, float eps, const long long* rng_state, int site,
@@ -1075,7 +1131,7 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
 template <typename T, int C, bool SPLIT = false>
 static int attn_launch(const AttnArgs& a, hipStream_t st) {
   typedef AttnCfg<T, C> G;
-  static bool attr = false;
+  static PerDevice<bool> attr;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)swin_attn_fwd_kernel<T, C, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
       stj_set_error("swin_attn: cannot reserve %d bytes of LDS", G::LDS_BYTES); return STJ_ELAUNCH;
@@ -1534,7 +1590,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
 template <typename T, int C, int NSPLIT = 1>
 static int attnb_launch(const AttnBArgs& a, hipStream_t st) {
   typedef AttnBCfg<T, C> G;
-  static bool attr = false;
+  static PerDevice<bool> attr;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel<T, C, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
       stj_set_error("swin_attn_bwd: cannot reserve %d bytes of LDS", G::LDS_BYTES); return STJ_ELAUNCH;

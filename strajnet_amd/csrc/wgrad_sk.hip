@@ -328,7 +328,7 @@ extern "C" int stj_wgrad_group(const stj_wgrad_job* jobs, int njobs, int dtype, 
   if (!jobs) { stj_set_error("stj_wgrad_group: NULL jobs"); return STJ_EINVAL; }
   for (int i = 0; i < njobs; ++i)
     if (!wsk_supported(jobs[i], dtype)) { stj_set_error("stj_wgrad_group: job %d is not supported (see stj_wgrad_job_supported)", i); return STJ_EUNSUPPORTED; }
-  static int attr_set = 0;
+  static PerDevice<int> attr_set;
   constexpr int lds = wsk::NS * wsk::STAGE;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)wsk::wgrad_sk_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
@@ -338,13 +338,13 @@ extern "C" int stj_wgrad_group(const stj_wgrad_job* jobs, int njobs, int dtype, 
     }
     attr_set = 1;
   }
-  static int ncu = 0;
+  static PerDevice<int> ncu;
   if (!ncu) {
     int dev = 0; hipDeviceProp_t pr;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) ncu = 256;
     else ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
   }
-  const int budget = wg_budget > 0 ? wg_budget : ncu;
+  const int budget = wg_budget > 0 ? wg_budget : (int)ncu;
   auto tiles = [](int w, int t) { return (w + t - 1) / t; };
   // orientation of a job: which operand is cut into 96-column slices.  Cost = operand columns staged per row of the problem.
   auto swapped = [&](const stj_wgrad_job& j) {

@@ -923,7 +923,7 @@ __global__ __launch_bounds__(256) void xattn_dkv_reduce_kernel(const float* dkp,
 }
 
 template <typename T> static int launch_bwd(const Args& a, hipStream_t st) {
-  static bool attr = false;
+  static PerDevice<bool> attr;
   const int lds = BGeo<T>::LDS_BYTES;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)xattn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -938,7 +938,7 @@ template <typename T> static int launch_bwd(const Args& a, hipStream_t st) {
 template <typename T> static int lds_bytes_fwd() { return (2 * NKEY * Geo<T>::LDK + 2 * Geo<T>::BUFE) * (int)sizeof(T) + NKEY * 4 + F1 * 4; }
 
 template <typename T> static int launch_fwd(const Args& a, hipStream_t st) {
-  static bool attr = false;
+  static PerDevice<bool> attr;
   const int lds = lds_bytes_fwd<T>();
   if (!attr) {
     if (hipFuncSetAttribute((const void*)xattn_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {

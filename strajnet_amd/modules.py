@@ -207,7 +207,7 @@ class STrajNet:
         self._flat = torch.zeros(off, dtype=torch.float32, device=self.device)
         # the flat gradient buffer and the step's zeroed scratch (ops._ZeroArena) share ONE allocation: zero_grad() is one fill over the
         # gradients + the used prefix of the arena instead of two launches at the head of every step
-        self._goff8 = (off + 7) // 8 * 8
+        self._goff8 = (off + ops._ZeroArena.ALIGN - 1) // ops._ZeroArena.ALIGN * ops._ZeroArena.ALIGN
         self._gbuf = torch.zeros(self._goff8 + ops._ZeroArena.FLOATS, dtype=torch.float32, device=self.device)
         self._gflat = self._gbuf[:off]
         self._cflat = self._flat if dtype == torch.float32 else torch.zeros(off, dtype=dtype, device=self.device)

@@ -141,6 +141,10 @@ def _workspace(device, size_fn, which=0):
 # ----------------------------------------------------------------------------------------------------
 class _ZeroArena:
     FLOATS = 8 << 20           # 32 MB: ~2x what a cfg-512 step takes
+    # floats; every region starts on a multiple of it.  256 bytes: the f32 atomics of the decoder weight-gradient kernels retire 15-40 %
+    # slower into a buffer that starts on an odd multiple of 32 bytes (tools/probes/wgrad_align.py: 105 -> 147 us for 192 -> 128,
+    # 213 -> 243 us for 96 -> 48; any multiple of 64 bytes is as good as 4 KB)
+    ALIGN = 64
 
     def __init__(self):
         self.buf, self.off, self.armed = None, 0, False
@@ -166,7 +170,8 @@ class _ZeroArena:
         self.off, self.armed = 0, True
 
     def take(self, n, device):
-        n8 = (n + 7) // 8 * 8                     # keep every region 32-byte aligned
+        A = self.ALIGN
+        n8 = (n + A - 1) // A * A                 # keep every region aligned (>= 32 bytes)
         if not self.armed or not self._here(device) or self.off + n8 > self.buf.numel():
             return None
         v = self.buf[self.off:self.off + n]
@@ -319,7 +324,7 @@ def gemm(A, B, C, M, N, K, sA, sB, sC, dt, bias=None, sBias=(0, 0), res=None, sR
     post: callable that consumes C; it travels with a DEFERRED weight gradient and runs behind the flush that carries it.
     Returns True when the product was queued (post will run), False when it was launched (or recorded in the open group): the
     caller then runs its post-processing itself, after closing the group."""
-    if (accumulate and _WQ['on'] and splitk == 0 and c_f32 and kseg[0] == 1 and sA[2] == 1 and sB[3] == 1 and bias is None
+    if (accumulate and _wq()['on'] and splitk == 0 and c_f32 and kseg[0] == 1 and sA[2] == 1 and sB[3] == 1 and bias is None
             and res is None and alpha == 1.0 and isinstance(A, torch.Tensor) and isinstance(B, torch.Tensor)):
         # a weight gradient dW += x^T dY inside a model's backward pass: queued for the grouped stream-K launch of the next flush
         j = WJob(A, B, C, colsum, K, M, N, sA[3], sB[2], sC[2], dt, nb=nb, sx=sA[:2], sdy=sB[:2], sdw=sC[:2], sdb=sBias)
@@ -406,18 +411,32 @@ def wgrad_group(jobs, budget=None):
 # the caching allocator cannot recycle them before the flush is enqueued; operands produced on another stream are ordered in front of
 # the flush with an event and recorded on the flush stream.
 WGRAD_SK = os.environ.get('STJ_WGRAD_SK', '1') != '0'
-_WQ = {'on': False, 'jobs': []}
+class _WQueues(dict):
+    """One queue per device (the autograd engine runs a device's backward nodes on that device's worker thread with the device
+    current): two models stepping on two GPUs of one process keep their queued jobs apart."""
+    def __missing__(self, dev):
+        q = self[dev] = {'on': False, 'jobs': []}
+        return q
+
+
+_WQS = _WQueues()
+
+
+def _wq():
+    return _WQS[torch.cuda.current_device() if torch.cuda.is_available() else -1]
 
 
 def wgrad_queue_begin():
-    _WQ['on'] = WGRAD_SK
-    _WQ['jobs'] = []
+    q = _wq()
+    assert not q['jobs'], 'wgrad_queue_begin: jobs of another backward pass are still queued on this device'
+    q['on'] = WGRAD_SK
 
 
 def wgrad_queue_reset():
     """Start of a forward pass: whatever an aborted backward pass left behind is dropped."""
-    _WQ['on'] = False
-    _WQ['jobs'] = []
+    q = _wq()
+    q['on'] = False
+    q['jobs'] = []
 
 
 def wgrad_queue_push(job, post=None):
@@ -426,12 +445,16 @@ def wgrad_queue_push(job, post=None):
     if not _SERIAL:
         ev = torch.cuda.Event()
         ev.record(st)
-    _WQ['jobs'].append((job, post, st, ev))
+    _wq()['jobs'].append((job, post, st, ev))
 
 
 def wgrad_queue_flush():
-    """Launch everything queued, on the current stream."""
-    items, _WQ['jobs'] = _WQ['jobs'], []
+    """Launch everything queued, on the current stream.  (Round 5: the flush-point launches on the weight-gradient side stream instead,
+    so that the next stage's backward need not wait for them, measured 1286-1291 scenes/s with all CUs as the launch's budget, 1270-1276
+    with 128 workgroups, 1234-1246 with 96, against 1296-1305 on the main stream: the Swin backward kernels they would run beside fill
+    the CUs they are given, and the join before the optimizer waits for the slowed-down last flush.)"""
+    q = _wq()
+    items, q['jobs'] = q['jobs'], []
     if not items:
         return
     cur = torch.cuda.current_stream()
@@ -452,7 +475,7 @@ def wgrad_queue_flush():
 
 def wgrad_queue_end():
     wgrad_queue_flush()
-    _WQ['on'] = False
+    _wq()['on'] = False
 
 
 class _WgradQueueFlush(torch.autograd.Function):
@@ -777,17 +800,19 @@ def layernorm_skip(x, pg, pb, eps):
 
 
 def _swin_ws(x, M, C):
-    """f32 workspace of the fused Swin kernels at C = 384 (partial sums of the hidden / head slices: stj_swin_split_workspace_bytes);
-    the other widths take none."""
-    if C != 384:
+    """f32 workspace of the fused Swin kernels where they split a row block / window over several workgroups (C = 384; C = 192 below
+    32768 rows): partial sums of the hidden / head slices (stj_swin_split_workspace_bytes; 0 bytes = none needed)."""
+    from ._lib import lib
+    nbytes = int(lib().stj_swin_split_workspace_bytes(M, C))
+    if nbytes == 0:
         return None
     # ONE buffer per (device, size), reused by every C = 384 block in stream order (the kernel and its finishing launch are through with it
     # before the next block's kernel on the same stream starts): allocating it per call grew the graph's private pool by 25-100 MB per block
     key = (str(x.device), 'swin_split', int(M), int(C), torch.cuda.current_stream(x.device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
-        from ._lib import lib
-        ws = _WS[key] = torch.empty(int(lib().stj_swin_split_workspace_bytes(M, C)) // 4, dtype=torch.float32, device=x.device)
+        # zeroed ONCE: it starts with the arrival counters of the kernels whose slices meet inside the launch (they re-arm themselves)
+        ws = _WS[key] = torch.zeros(nbytes // 4, dtype=torch.float32, device=x.device)
     return ws
 
 
@@ -850,6 +875,13 @@ def swin_mlp(x, pg, pb, pw1, pb1, pw2, pb2, eps, dctx=None, name=None, p_drop=0.
     return _SwinMlp.apply(x, pg.master, pg, pb, pw1, pb1, pw2, pb2, eps, drop, rps)
 
 
+def _trig(t):
+    """The 'some parameter requires grad' trigger argument of the fused ops.  ctx.needs_input_grad stays True under torch.no_grad()
+    for a tensor that requires grad (and grad mode reads as off inside every forward()), so with grad mode off the ops get a detached
+    alias: `train` is then False and nothing is saved for a backward pass that cannot happen."""
+    return t if torch.is_grad_enabled() else t.detach()
+
+
 class _SwinAttnHalf(torch.autograd.Function):
     """x -> x + DropPath(proj(W-MSA / SW-MSA(LN(x)))): forward is ONE kernel (stj_swin_attn_fwd); backward runs the proj / qkv
     input and weight gradients as GEMMs around the window-attention backward kernel, on the operands the forward kernel saved."""
@@ -860,7 +892,7 @@ class _SwinAttnHalf(torch.autograd.Function):
         C = x.shape[-1]
         N = res * res
         y = torch.empty_like(x)
-        train = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])     # False under torch.no_grad(): nothing is saved
+        train = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])     # False under torch.no_grad() (see _trig): nothing is saved
         qkv = a = ln = mean = rstd = None
         if train:
             qkv = torch.empty((B, N, 3 * C), dtype=x.dtype, device=x.device)
@@ -947,7 +979,7 @@ def swin_attn_half(x, pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, eps, dctx=N
     drop = None
     if dctx is not None and p_drop > 0.0:
         drop = (float(p_drop), dctx.snap, dctx.site(name, (B,), p_drop))
-    return _SwinAttnHalf.apply(x, pg.master, pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, eps, drop)
+    return _SwinAttnHalf.apply(x, _trig(pg.master), pg, pb, pwq, pbq, pt, pwp, pbp, B, res, shift, eps, drop)
 
 
 def _attn_cost(a):
@@ -1190,7 +1222,7 @@ def fg_attn_ok(dtype, Hh, Ww, gc):
 
 
 def fg_attn(q, k, v, off, pt, Hh, Ww, scale):
-    return _FgAttn.apply(q, k, v, off, pt.master, pt, Hh, Ww, scale)
+    return _FgAttn.apply(q, k, v, off, _trig(pt.master), pt, Hh, Ww, scale)
 
 
 def _fgattn_cost(kind):
@@ -1305,7 +1337,7 @@ def xattn(query, k, v, kvalid, pack, ps, zstride, dctx=None, names=None, p_drop=
         sites = (dctx.site(names[0], (Z, B, 3, HW, 64), p_drop), dctx.site(names[1], (Z, B * HW, 512), p_drop),
                  dctx.site(names[2], (Z, B * HW, 384), p_drop))
         drop = (float(p_drop), dctx.snap, sites)
-    return _XAttn.apply(query, k, v, ps['wq'].master, kvalid, pack, ps, zstride, drop)
+    return _XAttn.apply(query, k, v, _trig(ps['wq'].master), kvalid, pack, ps, zstride, drop)
 
 
 def _xattn_cost(kind):
@@ -1660,12 +1692,14 @@ class _PatchEmbed(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, trig, wc, gw, pbias, pg, pb, add, pg2, pb2, geo, dtype):
         _req_cuda(src)
-        Cin, ch_stride, pix_stride, eps = geo
+        Cin, ch_stride, pix_stride, eps, grad_on = geo
         src = src.contiguous()
         B, H, W = src.shape[0], src.shape[1], src.shape[2]
         K, N = wc.shape
         M = B * (H // 4) * (W // 4)
-        train = ctx.needs_input_grad[1] or (add is not None and ctx.needs_input_grad[7])     # (grad mode is off inside forward)
+        # needs_input_grad stays True under torch.no_grad() (the master weights require grad); grad mode itself is off inside forward(), so
+        # the wrapper reads it and hands it in: inference saves nothing
+        train = grad_on and (ctx.needs_input_grad[1] or (add is not None and ctx.needs_input_grad[7]))
         dev = src.device
         y = torch.empty((M, N), dtype=dtype, device=dev)
         cols = pre = x2 = mean = rstd = mean2 = rstd2 = None
@@ -1720,7 +1754,7 @@ def patch_embed(src, pw, pbias, pg, pb, Cin, ch_stride, pix_stride, dtype, eps=1
     """src: f32 raster [B,H,W,*] -> [B*(H/4)*(W/4), Cout] tokens: LN2(LN(conv4x4s4(src)) [+ add]) (LN2 only with pg2 / pb2)."""
     N = pw.c.shape[-1]
     return _PatchEmbed.apply(src, pw.master, pw.c.view(-1, N), pw.grad.view(-1, N), pbias, pg, pb, add, pg2, pb2,
-                             (Cin, ch_stride, pix_stride, eps), dtype)
+                             (Cin, ch_stride, pix_stride, eps, torch.is_grad_enabled()), dtype)
 
 
 def patch_im2col(src, Cin, ch_stride, pix_stride, dtype):
@@ -2018,7 +2052,6 @@ def _outconv_workspace(device):
     return _workspace(device, 'stj_outconv_bwd_workspace_bytes')
 
 
-OUTCONV_REDUCE_ASIDE = os.environ.get('STJ_NO_WS') != '1'
 PAIR_OUTCONV = os.environ.get('STJ_NO_WS') != '1'     # (the paired kernel belongs to the MFMA / weight-stationary family)
 
 
@@ -2056,16 +2089,8 @@ class _OutConvPair(torch.autograd.Function):
         dt = _dt(xo)
         dxo, dxf = torch.empty_like(xo), torch.empty_like(xf)
         ws = _outconv_workspace(xo.device)
-        if OUTCONV_REDUCE_ASIDE and dt == 1 and not _SERIAL and prof.ACTIVE is None and C == 48 and H % 16 == 0 and W % 16 == 0:
-            # the sums of the per-workgroup dW / db partials (two 14 us launches) leave the chain head 1 -> head 2 -> decoder: they run on
-            # the weight-gradient side stream, each head with a workspace of its own
-            ws2 = _workspace(xo.device, 'stj_outconv_bwd_workspace_bytes', 1)
-            for x, pw, pb, dx, off, w_ in ((xo, p1w, p1b, dxo, 0, ws), (xf, p2w, p2b, dxf, 8, ws2)):
-                call('stj_outconv_bwd', _p(x), _p(pw.master), vp(dout.data_ptr() + off), _p(dx), _p(None), _p(None), F_, H, W, C, Tn,
-                     ybs, yts, yps, ctx.elu_in, _p(w_), w_.numel(), dt, _st())
-                with wgrad_stream(1, w_):
-                    call('stj_outconv_bwd_reduce', _p(w_), w_.numel(), F_, H, W, _p(pw.grad), _p(pb.grad), _st())
-            return (dxo, dxf) + (None,) * 12
+        # (round 5: leaving the partial sums' reduction to two launches of their own measured inside the noise on the main stream, 1288 vs
+        #  1285 scenes/s, and -9 % on the weight-gradient side stream -- the fork at the head of backward reorders the graph's branches)
         call('stj_outconv_bwd', _p(xo), _p(p1w.master), vp(dout.data_ptr()), _p(dxo), _p(p1w.grad), _p(p1b.grad), F_, H, W, C, Tn,
              ybs, yts, yps, ctx.elu_in, _p(ws), ws.numel(), dt, _st())
         call('stj_outconv_bwd', _p(xf), _p(p2w.master), vp(dout.data_ptr() + 8), _p(dxf), _p(p2w.grad), _p(p2b.grad), F_, H, W, C, Tn,
