@@ -58,6 +58,15 @@
 #define STJ_ATTN_HG96 1         // heads per pass of the attention kernel at C = 96 (16-bit types); 1: 1059 vs 1052 scenes/s for 3 (less LDS per window)
 #endif
 
+#ifdef STJ_STAMP   // A/B builds only (tools/build_variant.sh): per-workgroup cycle stamps of wave 0 at the kernels' phase boundaries
+__device__ unsigned long long g_stamp[8 * 2048];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_stamp[blockIdx.x * 8 + (i)] = (i) == 0 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int stj_dbg_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(g_stamp)); }
+extern "C" int stj_dbg_clear() { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamp)) != hipSuccess) return 1; return (int)hipMemset(p, 0, sizeof(g_stamp)); }
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 // ---- chained-operand fragments -------------------------------------------------------------------------------
 template <typename T> struct Chain;
 template <> struct Chain<float> {
@@ -328,6 +337,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
   // FFN1 bias in LDS: a global load inside the chunk loop sits BEHIND the prefetched weight chunk in the in-order vmcnt queue, so waiting
   // for it waited for the whole prefetch -- every chunk paid a full memory round trip (found on the C = 384 split kernels: 6 chunks, 32 us)
   __shared__ float b1s[4 * C];
+  STAMP(0); STAMP(1);
   for (int c = hs0 + tid; c < hs1; c += 256) b1s[c] = p.b1[c];
   MlpStage<T, C> stg;
   stg.issue(w1, w2, hs0, tid);                        // first weight chunk in flight under the row loads + LayerNorm
@@ -335,6 +345,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
   load_rows<T, C, RF>(xa, x, m0, p.M, lane);
   float mu[RF], rs[RF];
   ln_rows<T, C, RF>(xa, p.gamma, p.beta, p.eps, mu, rs, lane);
+  STAMP(2);
 
   f32x4 acc2[RF][NF];
 #pragma unroll
@@ -347,6 +358,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
     if (!STJ_MLP_PREFETCH && hc0 > hs0) stg.issue(w1, w2, hc0, tid);
     stg.commit(W1s, W2s, tid);
     __syncthreads();
+    if (hc0 == hs0) STAMP(6);
     if (STJ_MLP_PREFETCH && hc0 + G::HC < hs1) stg.issue(w1, w2, hc0 + G::HC, tid);      // next chunk: global loads overlap this chunk's MFMAs
 #pragma unroll 1
     for (int s = 0; s < G::HC / KSTEP; ++s) {
@@ -383,6 +395,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
     }
   }
 
+  STAMP(3);
   // epilogue: y = x + dp * (acc + b2); the lane holds columns 16 f + 4 g .. +3 of row (m0 + 16 i + ln)
   if constexpr (SPLIT == 1) {     // this slice's share of the sum over the hidden dimension; swin_split_fwd_epi_kernel finishes the rows
 #pragma unroll
@@ -399,6 +412,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
     __shared__ int ticket;
     if (!slice_combine<RF * NF>(&acc2[0][0], p.part, unit, sp, p.split, tid, &ticket)) return;
   }
+  STAMP(4);
   T* y = reinterpret_cast<T*>(p.y);
 #pragma unroll
   for (int i = 0; i < RF; ++i) {
@@ -419,6 +433,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
       st4(y + row * C + col, v);
     }
   }
+  STAMP(5);
 }
 
 // =====================================================================================================================
@@ -890,10 +905,10 @@ extern "C" int stj_swin_mlp_bwd(const void* x, const void* dy, const float* gamm
 // rows of Wproj.  Training additionally writes what backward needs: qkv [M,3C], a = attention output [M,C], ln = LN(x) [M,C],
 // mean / rstd [M].
 // =====================================================================================================================
-template <typename T, int C> struct AttnCfg {
+template <typename T, int C, int HGP = 0> struct AttnCfg {
   static constexpr int KSTEP = Mma<T>::KSTEP;
   static constexpr int KS = C / KSTEP, NF = C / 16, HEADS = C / 32;
-  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? STJ_ATTN_HG96 : (C == 192 ? STJ_ATTN_HG192 : 1)) : 1;     // heads per pass
+  static constexpr int HG = HGP ? HGP : (sizeof(T) == 2 ? (C == 96 ? STJ_ATTN_HG96 : (C == 192 ? STJ_ATTN_HG192 : 1)) : 1);     // heads per pass
   static constexpr int GC = 32 * HG;                                   // q (= k = v) columns per pass
   static constexpr int LDT = 3 * GC + (sizeof(T) == 2 ? 16 : 8);       // token-major q|k|v tile [64][LDT]
   static constexpr int LDW = 3 * GC + 4;                               // Wqkv slice image [C][LDW] ([k = c][q seg | k seg | v seg])
@@ -913,8 +928,8 @@ struct AttnArgs {
 };
 
 // weight slices of one head group, global -> registers (issued ahead) -> LDS
-template <typename T, int C> struct AttnStage {
-  typedef AttnCfg<T, C> G;
+template <typename T, int C, int HGP = 0> struct AttnStage {
+  typedef AttnCfg<T, C, HGP> G;
   static constexpr int VN = Vec<T>::N, GC = G::GC;
   static constexpr int CPS = GC / VN, CPP = C / VN;
   static constexpr int NQ = (C * 3 * CPS + 255) / 256, NP = (GC * CPP + 255) / 256;
@@ -956,9 +971,9 @@ template <typename T, int C> struct AttnStage {
   }
 };
 
-template <typename T, int C, bool SPLIT = false>
+template <typename T, int C, int SPLIT = 0, int HGP = 0>
 __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnArgs p) {
-  typedef AttnCfg<T, C> G;
+  typedef AttnCfg<T, C, HGP> G;
   constexpr int KS = G::KS, NF = G::NF, HG = G::HG, GC = G::GC, KSTEP = G::KSTEP, ND = Chain<T>::ND, LK = Mma<T>::LANE_K;
   constexpr int VN = Vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) unsigned char at_smem[];
@@ -977,7 +992,7 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   const int hb0 = SPLIT ? sp * (G::HEADS / p.split) : 0, hb1 = SPLIT ? hb0 + G::HEADS / p.split : G::HEADS;
   __shared__ float bqs[3 * C];                       // qkv bias in LDS (a global load inside the head loop would wait for the prefetched weights)
   for (int c = tid; c < 3 * C; c += 256) bqs[c] = p.bqkv[c];
-  AttnStage<T, C> stg;
+  AttnStage<T, C, HGP> stg;
   stg.issue(wq, wp, hb0, tid);                       // first head group's weights in flight under the row gather + LayerNorm
   const int nwx = p.res / 8, nW = nwx * nwx;
   const int win = unit % nW, b = unit / nW;
@@ -1106,11 +1121,15 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   }
 
   // ---- epilogue: y = x + dp * (out + bproj)
-  if constexpr (SPLIT) {          // this head slice's share of the projection; swin_split_fwd_epi_kernel finishes the rows
+  if constexpr (SPLIT == 1) {     // this head slice's share of the projection; swin_split_fwd_epi_kernel finishes the rows
     float* pr = p.part + ((long long)sp * p.B * N + myrow) * C + 4 * g;
 #pragma unroll
     for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(pr + 16 * f) = acco[f];
     return;
+  }
+  if constexpr (SPLIT == 2) {     // the head slices' shares meet in the workgroup that finishes last (slice_combine); it alone goes on
+    __shared__ int ticket;
+    if (!slice_combine<NF>(acco, p.part, unit, sp, p.split, tid, &ticket)) return;
   }
   const float dp = drop_path_scale(p.rng, p.site, b, p.p_drop);
   T* y = reinterpret_cast<T*>(p.y) + myrow * C;
@@ -1128,18 +1147,18 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   }
 }
 
-template <typename T, int C, bool SPLIT = false>
+template <typename T, int C, int SPLIT = 0, int HGP = 0>
 static int attn_launch(const AttnArgs& a, hipStream_t st) {
-  typedef AttnCfg<T, C> G;
+  typedef AttnCfg<T, C, HGP> G;
   static PerDevice<bool> attr;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)swin_attn_fwd_kernel<T, C, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)swin_attn_fwd_kernel<T, C, SPLIT, HGP>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
       stj_set_error("swin_attn: cannot reserve %d bytes of LDS", G::LDS_BYTES); return STJ_ELAUNCH;
     }
     attr = true;
   }
   const int nW = (a.res / 8) * (a.res / 8);
-  hipLaunchKernelGGL((swin_attn_fwd_kernel<T, C, SPLIT>), dim3((unsigned)(a.B * nW * (SPLIT ? a.split : 1))), dim3(256), G::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((swin_attn_fwd_kernel<T, C, SPLIT, HGP>), dim3((unsigned)(a.B * nW * (SPLIT ? a.split : 1))), dim3(256), G::LDS_BYTES, st, a);
   return stj_check_launch("stj_swin_attn_fwd");
 }
 // C = 384 (the 16 x 16 stage: 32 windows at B = 8): (window, head slice) workgroups + the finishing launch; 16-bit types with a workspace
@@ -1151,7 +1170,7 @@ static int attn_split384(const AttnArgs& a, hipStream_t st) {
     AttnArgs s = a;
     const long long N = (long long)a.res * a.res;
     s.split = attn_split_for(a.B * (N / 64));          // 6 slices of 2 heads (32 windows at B = 8: 192 workgroups) or 2 of 6
-    const int rc = attn_launch<T, 384, true>(s, st);
+    const int rc = attn_launch<T, 384, 1>(s, st);
     if (rc != STJ_OK) return rc;
     return split_fwd_epi<T>(a.x, a.part, s.split, a.bproj, a.y, a.B * N, 384, a.rng, a.site, a.p_drop, N, st);
   } else {
@@ -1162,7 +1181,15 @@ template <typename T>
 static int attn_dispatch(int C, const AttnArgs& a, hipStream_t st) {
   switch (C) {
     case 96: return attn_launch<T, 96>(a, st);
-    case 192: return attn_launch<T, 192>(a, st);
+    case 192: {
+      // fewer than 256 windows (cfg-256's 32 x 32 stage at B = 8 has 128): two workgroups per window, three heads each, one head per pass
+      // (65 KB of LDS instead of 127), meeting inside the launch (SPLIT == 2)
+      const long long nwin = (long long)a.B * (a.res / 8) * (a.res / 8);
+      if constexpr (sizeof(T) == 2) {
+        if (a.part != nullptr && nwin < 256) { AttnArgs s = a; s.split = 2; return attn_launch<T, 192, 2, 1>(s, st); }
+      }
+      return attn_launch<T, 192>(a, st);
+    }
     case 384: return attn_split384<T>(a, st);
     default: stj_set_error("swin_attn: C must be 96, 192 or 384 (got %d)", C); return STJ_EUNSUPPORTED;
   }
@@ -1197,10 +1224,10 @@ extern "C" int stj_swin_attn_fwd(const void* x, const float* gamma, const float*
 // exactly as in the forward kernel.  The weight gradients stay split-K GEMMs on what this kernel writes once: dqkv [M,3C] and
 // dys [M,C] (next to the forward's saved a = attention output and ln = LN(x)).
 // =====================================================================================================================
-template <typename T, int C> struct AttnBCfg {
+template <typename T, int C, int HGP = 0> struct AttnBCfg {
   static constexpr int KSTEP = Mma<T>::KSTEP;
   static constexpr int KS = C / KSTEP, NF = C / 16, HEADS = C / 32;
-  static constexpr int HG = sizeof(T) == 2 ? (C == 96 ? STJ_ATTNB_HG96 : (C == 192 ? STJ_ATTNB_HG192 : 1)) : 1;    // heads per pass
+  static constexpr int HG = HGP ? HGP : (sizeof(T) == 2 ? (C == 96 ? STJ_ATTNB_HG96 : (C == 192 ? STJ_ATTNB_HG192 : 1)) : 1);    // heads per pass
   static constexpr int GC = 32 * HG;
   static constexpr int PADK = sizeof(T) == 2 ? 16 : 8;                 // pad of k-contiguous images read with 16-byte fragments
   static constexpr int LDT = 3 * GC + PADK;                            // q|k|v (then dq|dk|dv) tile [64][LDT]
@@ -1225,17 +1252,17 @@ struct AttnBArgs {
 
 // staging geometry of the backward kernel (chunks per thread).  (The first version copied each 16-byte piece load -> store in a loop:
 // 20 dependent round trips per 80 KB chunk, cold; now all loads of a chunk are in flight at once, issued a phase ahead.)
-template <typename T, int C> struct AttnBStage {
-  typedef AttnBCfg<T, C> G;
+template <typename T, int C, int HGP = 0> struct AttnBStage {
+  typedef AttnBCfg<T, C, HGP> G;
   static constexpr int VN = Vec<T>::N, GC = G::GC;
   static constexpr int CPS = GC / VN, CP1 = G::KC1 / VN;
   static constexpr int NWQ = (C * 3 * CPS + 255) / 256, NWP = (C * CP1 + 255) / 256;
   static constexpr int NT = (64 * 3 * CPS + 255) / 256;
 };
 
-template <typename T, int C, int NSPLIT = 1>
+template <typename T, int C, int NSPLIT = 1, int HGP = 0, bool FIX = false>
 __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(AttnBArgs p) {
-  typedef AttnBCfg<T, C> G;
+  typedef AttnBCfg<T, C, HGP> G;
   constexpr int KS = G::KS, NF = G::NF, HG = G::HG, GC = G::GC, KSTEP = G::KSTEP, ND = Chain<T>::ND, LK = Mma<T>::LANE_K;
   constexpr int VN = Vec<T>::N;
   // NSPLIT > 1 (C = 384: 32 windows at B = 8 cannot fill the chip): workgroup = (window, slice sp of the heads); it needs da only for
@@ -1286,7 +1313,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
   const T* qkvb = reinterpret_cast<const T*>(p.qkv) + (long long)b * N * 3 * C;
   T* dqkvb = reinterpret_cast<T*>(p.dqkv) + (long long)b * N * 3 * C;
   // staging registers: weight chunk / q|k|v tile, global -> registers (all loads of a chunk in flight at once, issued a phase ahead) -> LDS
-  typedef AttnBStage<T, C> SG;
+  typedef AttnBStage<T, C, HGP> SG;
   constexpr int NWP = (PR * SG::CP1 + 255) / 256;
   uint4 s_wp[NWP], s_wq[SG::NWQ], s_t[SG::NT];
   auto issue_wp = [&](int k0) __attribute__((always_inline)) {                      // Wproj[rows of the workgroup's heads, k0 .. k0+KC1]
@@ -1533,11 +1560,15 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
     }
   }
 
-  if constexpr (SPLIT) {          // this head slice's share of d LN(x)
+  if constexpr (SPLIT && !FIX) {  // this head slice's share of d LN(x)
     float* pr = p.part + ((long long)sp * p.B * N + myrow) * C + 4 * g;
 #pragma unroll
     for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(pr + 16 * f) = dln[f];
     return;
+  }
+  if constexpr (SPLIT && FIX) {   // the head slices' shares meet in the workgroup that finishes last (slice_combine); it alone goes on
+    __shared__ int ticket;
+    if (!slice_combine<NF>(dln, p.part, unit, sp, NSPLIT, tid, &ticket)) return;
   }
   // ---- LayerNorm backward on the accumulator layout + the shortcut gradient; gamma / beta partial sums
   {
@@ -1587,18 +1618,18 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
   for (int c = tid; c < C; c += 256) { atomicAdd(p.dgamma + po + c, red[c]); atomicAdd(p.dbeta + po + c, red[C + c]); }
 }
 
-template <typename T, int C, int NSPLIT = 1>
+template <typename T, int C, int NSPLIT = 1, int HGP = 0, bool FIX = false>
 static int attnb_launch(const AttnBArgs& a, hipStream_t st) {
-  typedef AttnBCfg<T, C> G;
+  typedef AttnBCfg<T, C, HGP> G;
   static PerDevice<bool> attr;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel<T, C, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)swin_attn_bwd_kernel<T, C, NSPLIT, HGP, FIX>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
       stj_set_error("swin_attn_bwd: cannot reserve %d bytes of LDS", G::LDS_BYTES); return STJ_ELAUNCH;
     }
     attr = true;
   }
   const int nW = (a.res / 8) * (a.res / 8);
-  hipLaunchKernelGGL((swin_attn_bwd_kernel<T, C, NSPLIT>), dim3((unsigned)(a.B * nW * NSPLIT)), dim3(256), G::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((swin_attn_bwd_kernel<T, C, NSPLIT, HGP, FIX>), dim3((unsigned)(a.B * nW * NSPLIT)), dim3(256), G::LDS_BYTES, st, a);
   return stj_check_launch("stj_swin_attn_bwd");
 }
 template <typename T>
@@ -1615,6 +1646,14 @@ static int attnb_split384(const AttnBArgs& a, hipStream_t st) {          // see 
   }
 }
 
+template <typename T>
+static int attnb_192(const AttnBArgs& a, hipStream_t st) {              // see attn_dispatch
+  if constexpr (sizeof(T) == 2) {
+    if (a.part != nullptr && (long long)a.B * (a.res / 8) * (a.res / 8) < 256) return attnb_launch<T, 192, 2, 1, true>(a, st);
+  }
+  return attnb_launch<T, 192>(a, st);
+}
+
 extern "C" int stj_swin_attn_bwd(const void* x, const void* dy, const void* qkv, const float* mean, const float* rstd, const float* gamma,
                                  const void* wqkv, const void* wproj, const float* table, void* dx, void* dqkv, void* dys,
                                  float* dtable, int tparts, float* dgamma, float* dbeta, int nparts, long long part_stride,
@@ -1629,7 +1668,7 @@ extern "C" int stj_swin_attn_bwd(const void* x, const void* dy, const void* qkv,
   p.dx = dx; p.dqkv = dqkv; p.dys = dys; p.dtable = dtable; p.tparts = tparts; p.dgamma = dgamma; p.dbeta = dbeta; p.nparts = nparts;
   p.pstride = part_stride; p.B = B; p.res = res; p.shift = shift; p.rng = rng_state; p.site = site; p.p_drop = p_drop;
   p.part = reinterpret_cast<float*>(ws);
-#define STJ_AB(TT) (C == 96 ? attnb_launch<TT, 96>(p, stream) : (C == 192 ? attnb_launch<TT, 192>(p, stream) : (C == 384 ? attnb_split384<TT>(p, stream) : (stj_set_error("swin_attn_bwd: C must be 96, 192 or 384 (got %d)", C), (int)STJ_EUNSUPPORTED))))
+#define STJ_AB(TT) (C == 96 ? attnb_launch<TT, 96>(p, stream) : (C == 192 ? attnb_192<TT>(p, stream) : (C == 384 ? attnb_split384<TT>(p, stream) : (stj_set_error("swin_attn_bwd: C must be 96, 192 or 384 (got %d)", C), (int)STJ_EUNSUPPORTED))))
   if (dtype == STJ_BF16) return STJ_AB(bf16);
   if (dtype == STJ_F16) return STJ_AB(f16);
   if (dtype == STJ_F32) return STJ_AB(float);

@@ -812,12 +812,12 @@ def test_dropout_op(dt):
 
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('B,N,C,p_drop', [(3, 64, 96, 0.0), (4, 256, 96, 0.3), (2, 128, 192, 0.3), (3, 64, 384, 0.0), (1, 80, 96, 0.0),
-                                          (8, 256, 384, 0.3), (1, 80, 384, 0.3), (8, 1024, 384, 0.3)])
+                                          (8, 256, 384, 0.3), (1, 80, 384, 0.3), (8, 1024, 384, 0.3), (1, 80, 192, 0.3), (8, 1024, 192, 0.3)])
 def test_swin_mlp_fused(dt, B, N, C, p_drop):
     """csrc/swin_fused.hip: x + DropPath(fc2(gelu(fc1(LN(x))))) in one kernel, and its backward (dx, LN gamma/beta, both weight
     and bias gradients) vs float64 autograd on the same statement (modules.py:260, :40-46, :18-29, :137-151).  Row counts that
     are not a multiple of the block's rows exercise the tail guards.  C = 384 runs the split form: (row block, hidden slice)
-    workgroups + the finishing launch."""
+    workgroups + the finishing launch; C = 192 below 32768 rows the form whose two hidden slices meet inside the launch."""
     from strajnet_amd import ops
     pg, pb = mk_param((C,), dt, 0.3, 1), mk_param((C,), dt, 0.3, 2)
     with torch.no_grad():
