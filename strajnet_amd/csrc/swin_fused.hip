@@ -39,6 +39,9 @@
 #ifndef STJ_MLP_HC192
 #define STJ_MLP_HC192 96
 #endif
+#ifndef STJ_MLP_HC192S
+#define STJ_MLP_HC192S 64       // C = 192 in the eight-wave workgroups (256 registers per wave: 128 columns spill in backward)
+#endif
 #ifndef STJ_MLP_HC384
 #define STJ_MLP_HC384 32        // C = 384 (the split kernels: 192 hidden columns per workgroup)
 #endif
@@ -63,8 +66,17 @@ __device__ unsigned long long g_stamp[8 * 2048];
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_stamp[blockIdx.x * 8 + (i)] = (i) == 0 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int stj_dbg_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(g_stamp)); }
 extern "C" int stj_dbg_clear() { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamp)) != hipSuccess) return 1; return (int)hipMemset(p, 0, sizeof(g_stamp)); }
+// per-wave-0 accumulated cycles between TICK(k-1) and TICK(k) inside the chunk loop -> g_tick[block][k]
+__device__ unsigned long long g_tick[8 * 2048];
+#define TICK_DECL unsigned long long tk_prev = __builtin_amdgcn_s_memtime(), tk_acc[5] = {0, 0, 0, 0, 0}
+#define TICK(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk_acc[k] += t_ - tk_prev; tk_prev = t_; } while (0)
+#define TICK_STORE do { if (threadIdx.x == 0 && blockIdx.x < 2048) for (int k_ = 0; k_ < 5; ++k_) g_tick[blockIdx.x * 8 + k_] = tk_acc[k_]; } while (0)
+extern "C" int stj_dbg_ticks(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tick), sizeof(g_tick)); }
 #else
 #define STAMP(i) do {} while (0)
+#define TICK_DECL
+#define TICK(k) do {} while (0)
+#define TICK_STORE do {} while (0)
 #endif
 
 // ---- chained-operand fragments -------------------------------------------------------------------------------
@@ -137,16 +149,20 @@ template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
 // nobody waits for anybody.  With two slices the sum is own + other in either arrival order: bitwise reproducible.
 // ws = [FIX_CNT_BYTES of int counters, zeroed ONCE by the caller (the last arriver re-arms its counter)] [slabs [unit][slice][NFR][256] f32x4]
 constexpr int FIX_CNT_BYTES = 16384;                 // up to 4096 units per launch
-template <int NFR>
+// Threads tid < NTA hold accumulators (the others only take part in the barriers).
+template <int NFR, int NTA = 256>
 __device__ __forceinline__ bool slice_combine(f32x4* acc, void* ws, int unit, int sp, int S, int tid, int* s_ticket) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   int* cnt = reinterpret_cast<int*>(ws) + unit;
-  constexpr unsigned SLAB = 256u * NFR * 16u;        // bytes of one slab
+  constexpr unsigned SLAB = (unsigned)NTA * NFR * 16u;        // bytes of one slab
+  const bool active = tid < NTA;
   char* base = reinterpret_cast<char*>(ws) + FIX_CNT_BYTES + (long long)unit * S * SLAB;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (unsigned)S * SLAB, 0x00020000);
+  if (active) {
 #pragma unroll
-  for (int j = 0; j < NFR; ++j)
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j]), rs, (unsigned)sp * SLAB + (unsigned)(j * 256 + tid) * 16u, 0, 16 /* sc1 */);
+    for (int j = 0; j < NFR; ++j)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j]), rs, (unsigned)sp * SLAB + (unsigned)(j * NTA + tid) * 16u, 0, 16 /* sc1 */);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) *s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -154,10 +170,10 @@ __device__ __forceinline__ bool slice_combine(f32x4* acc, void* ws, int unit, in
   if (*s_ticket != S - 1) return false;
   if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int s = 0; s < S; ++s) {
-    if (s == sp) continue;
+    if (s == sp || !active) continue;
 #pragma unroll
     for (int j = 0; j < NFR; ++j) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)s * SLAB + (unsigned)(j * 256 + tid) * 16u, 0, 16 /* sc1 */);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)s * SLAB + (unsigned)(j * NTA + tid) * 16u, 0, 16 /* sc1 */);
       acc[j] += __builtin_bit_cast(f32x4, v);
     }
   }
@@ -165,19 +181,25 @@ __device__ __forceinline__ bool slice_combine(f32x4* acc, void* ws, int unit, in
 }
 
 // ---- geometry ---------------------------------------------------------------------------------------------------
-template <typename T, int C, int RF_ = ((C <= 192) ? 2 : 1)> struct MlpCfg {
+// NW waves per workgroup in HS hidden groups of RG = NW / HS waves: wave (rg, hg) owns 16 RF rows and, of every staged chunk, the k-steps
+// s = hg, hg + HS, ...; the hidden groups' sums meet in LDS behind the chunk loop.  Eight waves = two per SIMD: one wave's GELU / LayerNorm
+// VALU work and LDS-read latencies run under the other's MFMAs (with four waves the chunk loop ran 75 cycles per MFMA: stamps).
+template <typename T, int C, int RF_ = ((C <= 192) ? 2 : 1), int NW_ = 4, int HS_ = 1> struct MlpCfg {
   static constexpr int KSTEP = Mma<T>::KSTEP;
   static constexpr int KS = C / KSTEP;                // k-steps over the model dimension
   static constexpr int NF = C / 16;                   // 16-column fragments of the model dimension
   static constexpr int RF = RF_;                      // 16-row fragments per wave
-  static constexpr int ROWS = 4 * RF * 16;            // rows per block
-  // hidden columns per staged chunk: as many as keep the two images under ~78 KB (two blocks per CU)
-  static constexpr int HC = sizeof(T) == 2 ? (C == 96 ? STJ_MLP_HC96 : (C == 192 ? STJ_MLP_HC192 : STJ_MLP_HC384)) : (C == 96 ? 96 : (C == 192 ? 48 : 16));
+  static constexpr int NW = NW_, HS = HS_, RG = NW / HS, NT = 64 * NW;
+  static constexpr int ROWS = RG * RF * 16;           // rows per block
+  // hidden columns per staged chunk: as many as keep the two images under ~78 KB (two blocks per CU); with two hidden groups an even number of k-steps
+  static constexpr int HC = sizeof(T) == 2 ? (C == 96 ? STJ_MLP_HC96 : (C == 192 ? (NW == 8 ? STJ_MLP_HC192S : STJ_MLP_HC192) : (HS == 2 ? 64 : STJ_MLP_HC384)))
+                                           : (C == 96 ? 96 : (C == 192 ? 48 : 16));
   static constexpr int P1 = 4;                        // W1 image [C][HC + P1]: rows 8-byte aligned (tr reads, 8-byte chain reads)
   static constexpr int P2 = sizeof(T) == 2 ? 8 : 4;   // W2 image [HC][C + P2]: rows 16-byte aligned (16-byte fragment reads in backward)
   static constexpr int LD1 = HC + P1, LD2 = C + P2;
   static constexpr int LDS_BYTES = (C * LD1 + HC * LD2) * (int)sizeof(T);
-  static_assert(C % KSTEP == 0 && HC % KSTEP == 0 && (4 * C) % HC == 0, "shape");
+  static_assert(C % KSTEP == 0 && HC % KSTEP == 0 && (4 * C) % HC == 0 && (HC / KSTEP) % HS == 0 && NW % HS == 0, "shape");
+  static_assert(HS == 1 || RG * RF * NF * 1024 <= LDS_BYTES, "the hidden groups' sums meet in the weight images' LDS");
 };
 
 struct MlpArgs {
@@ -193,23 +215,22 @@ struct MlpArgs {
 // "global -> registers" (issued one chunk AHEAD: the loads fly while the current chunk's MFMAs run -- with a synchronous copy every
 // chunk exposed a full L2 / HBM round trip per 16 KB in flight, and the weights are cold in the real step: 114 vs 53 us for the
 // 8192 x 192 forward) and "registers -> LDS".
-template <typename T, int C> struct MlpStage {
-  typedef MlpCfg<T, C, 1> G;
-  static constexpr int VN = Vec<T>::N;
+template <typename T, int C, typename G> struct MlpStage {
+  static constexpr int VN = Vec<T>::N, NT = G::NT;
   static constexpr int CP1 = G::HC / VN, CP2 = C / VN;
-  static constexpr int N1 = (C * CP1 + 255) / 256, N2 = (G::HC * CP2 + 255) / 256;
+  static constexpr int N1 = (C * CP1 + NT - 1) / NT, N2 = (G::HC * CP2 + NT - 1) / NT;
   uint4 r1[N1], r2[N2];
   __device__ __forceinline__ void issue(const T* w1, const T* w2, int hc0, int tid) {
 #pragma unroll
     for (int i = 0; i < N1; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       uint4 v = make_uint4(0, 0, 0, 0);          // (always store a selected value: a conditional store keeps the array in scratch memory)
       if (q < C * CP1) { const int k = q / CP1, c = (q % CP1) * VN; v = *reinterpret_cast<const uint4*>(w1 + (long long)k * (4 * C) + hc0 + c); }
       r1[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < N2; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (q < G::HC * CP2) { const int k = q / CP2, c = (q % CP2) * VN; v = *reinterpret_cast<const uint4*>(w2 + (long long)(hc0 + k) * C + c); }
       r2[i] = v;
@@ -218,7 +239,7 @@ template <typename T, int C> struct MlpStage {
   __device__ __forceinline__ void commit(T* W1s, T* W2s, int tid) const {
 #pragma unroll
     for (int i = 0; i < N1; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       if (q < C * CP1) {
         T* d = W1s + (q / CP1) * G::LD1 + (q % CP1) * VN;
         if constexpr (sizeof(T) == 2) { uint2* d2 = reinterpret_cast<uint2*>(d); d2[0] = make_uint2(r1[i].x, r1[i].y); d2[1] = make_uint2(r1[i].z, r1[i].w); }
@@ -227,7 +248,7 @@ template <typename T, int C> struct MlpStage {
     }
 #pragma unroll
     for (int i = 0; i < N2; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       if (q < G::HC * CP2) *reinterpret_cast<uint4*>(W2s + (q / CP2) * G::LD2 + (q % CP2) * VN) = r2[i];
     }
   }
@@ -314,14 +335,15 @@ __device__ __forceinline__ void ln_rows(typename Mma<T>::Frag (&xa)[RF][C / Mma<
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <typename T, int C, int RFP, int SPLIT = 0>
-__global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs p) {
-  typedef MlpCfg<T, C, RFP> G;
-  constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP;
+template <typename T, int C, int RFP, int SPLIT = 0, int NW = 4, int HS = 1>
+__global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs p) {
+  typedef MlpCfg<T, C, RFP, NW, HS> G;
+  constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];
   T* W1s = reinterpret_cast<T*>(mlp_smem);
   T* W2s = W1s + C * G::LD1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ln = lane & 15;
+  const int rg = wave % G::RG, hg = wave / G::RG;          // row group, hidden group of this wave
   // SPLIT (the 2048-row C = 384 stage: 32 row blocks cannot fill 256 CUs, and each would stream all 2.4 MB of weights): workgroup =
   // (row block, slice sp of the hidden dimension); consecutive workgroups take consecutive slices, so slice sp of the weights is
   // read by the workgroups of ONE XCD (blockIdx % 8 with 8 slices) and stays in that L2.  Where its 29 us go at 2048 rows (parts
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
   // fragment from LDS), the 25 MB of f32 partial sums 8 us, LayerNorm 2, launch + row loads + first chunk 6; layer by layer: 48 us
   const int unit = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x, sp = SPLIT ? (int)blockIdx.x % p.split : 0;
   const int hs0 = SPLIT ? sp * (4 * C / p.split) : 0, hs1 = SPLIT ? hs0 + 4 * C / p.split : 4 * C;
-  const long long m0 = (long long)unit * G::ROWS + wave * (RF * 16);
+  const long long m0 = (long long)unit * G::ROWS + rg * (RF * 16);
   const T* x = reinterpret_cast<const T*>(p.x);
   const T* w1 = reinterpret_cast<const T*>(p.w1);
   const T* w2 = reinterpret_cast<const T*>(p.w2);
@@ -338,8 +360,8 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
   // for it waited for the whole prefetch -- every chunk paid a full memory round trip (found on the C = 384 split kernels: 6 chunks, 32 us)
   __shared__ float b1s[4 * C];
   STAMP(0); STAMP(1);
-  for (int c = hs0 + tid; c < hs1; c += 256) b1s[c] = p.b1[c];
-  MlpStage<T, C> stg;
+  for (int c = hs0 + tid; c < hs1; c += NT) b1s[c] = p.b1[c];
+  MlpStage<T, C, G> stg;
   stg.issue(w1, w2, hs0, tid);                        // first weight chunk in flight under the row loads + LayerNorm
   typename Mma<T>::Frag xa[RF][KS];
   load_rows<T, C, RF>(xa, x, m0, p.M, lane);
@@ -353,15 +375,20 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc2[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  TICK_DECL;
   for (int hc0 = hs0; hc0 < hs1; hc0 += G::HC) {
+    TICK(0);
     __syncthreads();                                  // previous chunk's fragment reads are done
+    TICK(1);
     if (!STJ_MLP_PREFETCH && hc0 > hs0) stg.issue(w1, w2, hc0, tid);
     stg.commit(W1s, W2s, tid);
+    TICK(2);
     __syncthreads();
+    TICK(3);
     if (hc0 == hs0) STAMP(6);
     if (STJ_MLP_PREFETCH && hc0 + G::HC < hs1) stg.issue(w1, w2, hc0 + G::HC, tid);      // next chunk: global loads overlap this chunk's MFMAs
 #pragma unroll 1
-    for (int s = 0; s < G::HC / KSTEP; ++s) {
+    for (int s = hg; s < G::HC / KSTEP; s += HS) {
       f32x4 a1[RF][ND];
 #pragma unroll
       for (int d = 0; d < ND; ++d) {
@@ -393,11 +420,31 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
         for (int i = 0; i < RF; ++i) acc2[i][f] = Mma<T>::mma(wf, hf[i], acc2[i][f]);
       }
     }
+    TICK(4);
   }
+  TICK_STORE;
 
   STAMP(3);
+  if constexpr (HS > 1) {         // the hidden groups' sums meet in LDS (over the weight images): group 0 carries on with the total
+    __syncthreads();
+    f32x4* rb = reinterpret_cast<f32x4*>(mlp_smem) + (rg * RF * NF) * 64 + lane;
+    if (hg == 1) {
+#pragma unroll
+      for (int i = 0; i < RF; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) rb[(i * NF + f) * 64] = acc2[i][f];
+    }
+    __syncthreads();
+    if (hg == 0) {
+#pragma unroll
+      for (int i = 0; i < RF; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc2[i][f] += rb[(i * NF + f) * 64];
+    }
+  }
   // epilogue: y = x + dp * (acc + b2); the lane holds columns 16 f + 4 g .. +3 of row (m0 + 16 i + ln)
-  if constexpr (SPLIT == 1) {     // this slice's share of the sum over the hidden dimension; swin_split_fwd_epi_kernel finishes the rows
+  if constexpr (SPLIT == 1) {
+    if (hg != 0) return;     // this slice's share of the sum over the hidden dimension; swin_split_fwd_epi_kernel finishes the rows
 #pragma unroll
     for (int i = 0; i < RF; ++i) {
       const long long row = m0 + 16 * i + ln;
@@ -410,9 +457,10 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
   }
   if constexpr (SPLIT == 2) {     // the slices' sums meet in the workgroup that finishes last (slice_combine); it alone goes on
     __shared__ int ticket;
-    if (!slice_combine<RF * NF>(&acc2[0][0], p.part, unit, sp, p.split, tid, &ticket)) return;
+    if (!slice_combine<RF * NF, 64 * G::RG>(&acc2[0][0], p.part, unit, sp, p.split, tid, &ticket)) return;
   }
   STAMP(4);
+  if (hg != 0) return;
   T* y = reinterpret_cast<T*>(p.y);
 #pragma unroll
   for (int i = 0; i < RF; ++i) {
@@ -439,27 +487,28 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs
 // =====================================================================================================================
 // backward
 // =====================================================================================================================
-template <typename T, int C, int RFP, int SPLIT = 0>
-__global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs p) {
-  typedef MlpCfg<T, C, RFP> G;
-  constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP, LK = Mma<T>::LANE_K;
+template <typename T, int C, int RFP, int SPLIT = 0, int NW = 4, int HS = 1>
+__global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs p) {
+  typedef MlpCfg<T, C, RFP, NW, HS> G;
+  constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP, LK = Mma<T>::LANE_K, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];
   __shared__ float red[2][C];
   T* W1s = reinterpret_cast<T*>(mlp_smem);
   T* W2s = W1s + C * G::LD1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ln = lane & 15;
+  const int rg = wave % G::RG, hg = wave / G::RG;          // (see the forward kernel)
   const int unit = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x, sp = SPLIT ? (int)blockIdx.x % p.split : 0;     // see the forward kernel
   const int hs0 = SPLIT ? sp * (4 * C / p.split) : 0, hs1 = SPLIT ? hs0 + 4 * C / p.split : 4 * C;
-  const long long m0 = (long long)unit * G::ROWS + wave * (RF * 16);
+  const long long m0 = (long long)unit * G::ROWS + rg * (RF * 16);
   const T* x = reinterpret_cast<const T*>(p.x);
   const T* dy = reinterpret_cast<const T*>(p.dy);
   const T* w1 = reinterpret_cast<const T*>(p.w1);
   const T* w2 = reinterpret_cast<const T*>(p.w2);
-  for (int c = tid; c < 2 * C; c += 256) (&red[0][0])[c] = 0.f;
+  for (int c = tid; c < 2 * C; c += NT) (&red[0][0])[c] = 0.f;
   __shared__ float b1s[4 * C];                         // (see the forward kernel)
-  for (int c = hs0 + tid; c < hs1; c += 256) b1s[c] = p.b1[c];
+  for (int c = hs0 + tid; c < hs1; c += NT) b1s[c] = p.b1[c];
 
-  MlpStage<T, C> stg;
+  MlpStage<T, C, G> stg;
   stg.issue(w1, w2, hs0, tid);
   typename Mma<T>::Frag xa[RF][KS], da[RF][KS];
   load_rows<T, C, RF>(xa, x, m0, p.M, lane);
@@ -482,7 +531,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
         for (int e = 0; e < LK; ++e) v[e] *= dp[i];
         da[i][ks] = frag_pack<T>(v);
       }
-      if (row < p.M && sp == 0) {
+      if (row < p.M && sp == 0 && hg == 0) {
         const long long o = row * C + ks * KSTEP + LK * g;
         *reinterpret_cast<typename Mma<T>::Frag*>(lnq + o) = xa[i][ks];
         if (dysq) *reinterpret_cast<typename Mma<T>::Frag*>(dysq + o) = da[i][ks];
@@ -505,7 +554,7 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
     __syncthreads();
     if (STJ_MLP_PREFETCH && hc0 + G::HC < hs1) stg.issue(w1, w2, hc0 + G::HC, tid);
 #pragma unroll 1
-    for (int s = 0; s < G::HC / KSTEP; ++s) {
+    for (int s = hg; s < G::HC / KSTEP; s += HS) {
       f32x4 a1[RF][ND], a3[RF][ND];                    // pre^T and dh^T, [hidden][row]
 #pragma unroll
       for (int d = 0; d < ND; ++d) {
@@ -556,7 +605,25 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
     }
   }
 
+  if constexpr (HS > 1) {         // (see the forward kernel)
+    __syncthreads();
+    f32x4* rb = reinterpret_cast<f32x4*>(mlp_smem) + (rg * RF * NF) * 64 + lane;
+    if (hg == 1) {
+#pragma unroll
+      for (int i = 0; i < RF; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) rb[(i * NF + f) * 64] = acc[i][f];
+    }
+    __syncthreads();
+    if (hg == 0) {
+#pragma unroll
+      for (int i = 0; i < RF; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[i][f] += rb[(i * NF + f) * 64];
+    }
+  }
   if constexpr (SPLIT == 1) {     // this slice's share of d LN(x); swin_split_bwd_epi_kernel sums the slices and runs the LayerNorm backward
+    if (hg != 0) return;
 #pragma unroll
     for (int i = 0; i < RF; ++i) {
       const long long row = m0 + 16 * i + ln;
@@ -569,10 +636,11 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
   }
   if constexpr (SPLIT == 2) {     // (see the forward kernel)
     __shared__ int ticket;
-    if (!slice_combine<RF * NF>(&acc[0][0], p.part, unit, sp, p.split, tid, &ticket)) return;
+    if (!slice_combine<RF * NF, 64 * G::RG>(&acc[0][0], p.part, unit, sp, p.split, tid, &ticket)) return;
   }
   // LayerNorm backward on the accumulator layout (lane: columns 16 f + 4 g .. +3 of row m0 + 16 i + ln) + the skip gradient
   T* dx = reinterpret_cast<T*>(p.dx);
+  if (hg == 0) {                  // (the waves of the other hidden group only take part in the barrier below)
   float dgs[NF][4], dbs[NF][4];
 #pragma unroll
   for (int f = 0; f < NF; ++f)
@@ -632,9 +700,10 @@ __global__ __launch_bounds__(256, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs
       for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
       if (ln == 0) { atomicAdd(&red[0][16 * f + 4 * g + r], a); atomicAdd(&red[1][16 * f + 4 * g + r], b); }
     }
+  }
   __syncthreads();
   const long long po = (long long)(blockIdx.x % p.nparts) * p.pstride;
-  for (int c = tid; c < C; c += 256) { atomicAdd(p.dgamma + po + c, red[0][c]); atomicAdd(p.dbeta + po + c, red[1][c]); }
+  for (int c = tid; c < C; c += NT) { atomicAdd(p.dgamma + po + c, red[0][c]); atomicAdd(p.dbeta + po + c, red[1][c]); }
 }
 
 // ---- the second launch of the SPLIT kernels: sum the slices' partial sums and finish the rows -----------------------------------
@@ -801,10 +870,10 @@ constexpr int SPLIT_MAX = 8;         // slices of a split launch (the workspace 
 static int mlp_split_for(long long M) { const long long blocks = (M + 63) / 64; return blocks <= 32 ? 8 : (blocks <= 64 ? 4 : 2); }
 static int attn_split_for(long long windows) { return windows <= 48 ? 6 : 2; }
 
-template <typename T, int C, int RFP, int SPLIT = 0>
+template <typename T, int C, int RFP, int SPLIT = 0, int NW = 4, int HS = 1>
 static int mlp_launch(bool bwd, const MlpArgs& a, hipStream_t st) {
-  typedef MlpCfg<T, C, RFP> G;
-  const void* fn = bwd ? (const void*)swin_mlp_bwd_kernel<T, C, RFP, SPLIT> : (const void*)swin_mlp_fwd_kernel<T, C, RFP, SPLIT>;
+  typedef MlpCfg<T, C, RFP, NW, HS> G;
+  const void* fn = bwd ? (const void*)swin_mlp_bwd_kernel<T, C, RFP, SPLIT, NW, HS> : (const void*)swin_mlp_fwd_kernel<T, C, RFP, SPLIT, NW, HS>;
   static PerDevice<bool> attr[2];
   if (!attr[bwd]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
@@ -813,8 +882,8 @@ static int mlp_launch(bool bwd, const MlpArgs& a, hipStream_t st) {
     attr[bwd] = true;
   }
   dim3 grid((unsigned)((a.M + G::ROWS - 1) / G::ROWS) * (SPLIT ? a.split : 1));
-  if (bwd) hipLaunchKernelGGL((swin_mlp_bwd_kernel<T, C, RFP, SPLIT>), grid, dim3(256), G::LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((swin_mlp_fwd_kernel<T, C, RFP, SPLIT>), grid, dim3(256), G::LDS_BYTES, st, a);
+  if (bwd) hipLaunchKernelGGL((swin_mlp_bwd_kernel<T, C, RFP, SPLIT, NW, HS>), grid, dim3(G::NT), G::LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((swin_mlp_fwd_kernel<T, C, RFP, SPLIT, NW, HS>), grid, dim3(G::NT), G::LDS_BYTES, st, a);
   return stj_check_launch(bwd ? "stj_swin_mlp_bwd" : "stj_swin_mlp_fwd");
 }
 template <typename T>
@@ -823,15 +892,23 @@ static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
   // the 256 CUs (32768 rows: 256 blocks of 128; 8192 rows: 128 blocks of 64)
   const bool two = a.M >= 256 * 128;
   switch (C) {
-    case 96: return two ? mlp_launch<T, 96, 2>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
+    case 96:         // 128-row blocks of eight waves (f32: of four waves with two row fragments each) | 64-row blocks of four
+      if constexpr (sizeof(T) == 2) return two ? mlp_launch<T, 96, 1, 0, 8>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
+      else return two ? mlp_launch<T, 96, 2>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
     case 192: {
       // 8192 rows (cfg-256's 32 x 32 stage at B = 8) are 128 row blocks of 64: with the workspace the hidden dimension is cut in two, 256
       // workgroups that each stage half of the weights and meet inside the launch (SPLIT == 2)
-      if (two) return mlp_launch<T, 192, 2>(bwd, a, st);
-      if (a.part == nullptr || sizeof(T) != 2 || (a.M + 63) / 64 > FIX_CNT_BYTES / 4) return mlp_launch<T, 192, 1>(bwd, a, st);
-      MlpArgs s = a;
-      s.split = 2;
-      return mlp_launch<T, 192, 1, 2>(bwd, s, st);
+      if constexpr (sizeof(T) == 4) { if (two) return mlp_launch<T, 192, 2>(bwd, a, st); }
+      if constexpr (sizeof(T) == 2) {
+        if (two) return mlp_launch<T, 192, 1, 0, 8>(bwd, a, st);
+        if (a.part != nullptr && (a.M + 63) / 64 <= FIX_CNT_BYTES / 4) {
+          MlpArgs s = a;
+          s.split = 2;
+          return mlp_launch<T, 192, 1, 2, 8, 2>(bwd, s, st);       // 64-row blocks x 2 slices of the hidden dimension, eight waves: 2 hidden groups x 4 row groups
+        }
+      }
+      if constexpr (sizeof(T) == 2) return mlp_launch<T, 192, 1, 0, 8, 2>(bwd, a, st);       // no workspace: one workgroup per row block, its two hidden groups meet in LDS
+      return mlp_launch<T, 192, 1>(bwd, a, st);
     }
     case 384: {
       // (a one-workgroup-per-row-block form without the workspace existed: 32 workgroups at B = 8, never taken by ops.py, 0.2 MB of code)

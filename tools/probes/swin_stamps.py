@@ -31,6 +31,10 @@ for B, res, C in ((8, 64, 96), (8, 32, 192), (8, 16, 384)):
     t0 = (s[:, 0] - s[:, 0].min()) * 10.0 / 1e3           # memrealtime: 100 MHz -> us
     d = lambda a, b_: (s[:, a] - s[:, b_]) / 1e3
     fin = s[:, 5] != 0
+    tb = np.zeros(8 * 2048, dtype=np.uint64); assert L.stj_dbg_ticks(tb.ctypes.data_as(ctypes.c_void_p)) == 0
+    tk = tb.reshape(2048, 8).astype(np.int64)[:nb, :5] / 1e3
+    print('   chunk loop, kcycles summed over chunks (median over workgroups): loop-top', np.median(tk[:, 0]).round(2), ' wait barrier 1', np.median(tk[:, 1]).round(2), ' commit', np.median(tk[:, 2]).round(2), ' wait barrier 2', np.median(tk[:, 3]).round(2), ' k-steps', np.median(tk[:, 4]).round(2))
+    if not fin.any(): continue
     print(f'M={M} C={C}: {nb} workgroups; start spread {t0.max():.2f} us (median {np.median(t0):.2f}); kcycles median: prologue(rows+LN) {np.median(d(2, 1)):.2f}  '
           f'first chunk ready {np.median(d(6, 1)):.2f}  loop end {np.median(d(3, 1)):.2f}  combine {np.median(d(4, 3)[fin]):.2f}  epilogue {np.median(d(5, 4)[fin]):.2f}  '
           f'total {np.median(d(5, 1)[fin]):.2f} (max {d(5, 1)[fin].max():.2f}); finishing workgroups {int(fin.sum())}')
