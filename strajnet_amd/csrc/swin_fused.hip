@@ -147,16 +147,17 @@ template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
 // last ticket adds the other slabs to its own accumulators (sc1 loads: the producers stored sc1, MI355X_MICROARCH.md "Workgroup
 // dispatch, XCD placement & inter-workgroup visibility") and runs the epilogue.  No dispatch-order, residency or placement assumption:
 // nobody waits for anybody.  With two slices the sum is own + other in either arrival order: bitwise reproducible.
-// ws = [FIX_CNT_BYTES of int counters, zeroed ONCE by the caller (the last arriver re-arms its counter)] [slabs [unit][slice][NFR][256] f32x4]
+// ws = [slabs [unit][slice][NFR][NTA] f32x4 (the same region holds the [slice][M][C] partial sums of the SPLIT == 1 launches)]
+//      [FIX_CNT_BYTES of int counters, zeroed ONCE by the caller (the last arriver re-arms its counter)]
 constexpr int FIX_CNT_BYTES = 16384;                 // up to 4096 units per launch
 // Threads tid < NTA hold accumulators (the others only take part in the barriers).
 template <int NFR, int NTA = 256>
-__device__ __forceinline__ bool slice_combine(f32x4* acc, void* ws, int unit, int sp, int S, int tid, int* s_ticket) {
+__device__ __forceinline__ bool slice_combine(f32x4* acc, void* slabs, int* counters, int unit, int sp, int S, int tid, int* s_ticket) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-  int* cnt = reinterpret_cast<int*>(ws) + unit;
+  int* cnt = counters + unit;
   constexpr unsigned SLAB = (unsigned)NTA * NFR * 16u;        // bytes of one slab
   const bool active = tid < NTA;
-  char* base = reinterpret_cast<char*>(ws) + FIX_CNT_BYTES + (long long)unit * S * SLAB;
+  char* base = reinterpret_cast<char*>(slabs) + (long long)unit * S * SLAB;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (unsigned)S * SLAB, 0x00020000);
   if (active) {
 #pragma unroll
@@ -208,7 +209,7 @@ struct MlpArgs {
   const void* dy; void* dx; void* h; void* dpre; void* ln; void* dys; float* dgamma; float* dbeta; int nparts; long long pstride;
   long long M; float eps;
   const long long* rng; int site; float p_drop; long long rows_per_sample;
-  int split; float* part;        // SPLIT kernels: workgroup = (row block, slice of the hidden dimension); partial sums [split][M][C] f32
+  int split; float* part; int* cnt;   // SPLIT kernels: workgroup = (row block, slice of the hidden dimension); partial sums [split][M][C] f32 | slabs + arrival counters
 };
 
 // Staging of W1[:, hc0 : hc0+HC] ([C][4C] global, row stride 4C) and W2[hc0 : hc0+HC, :] ([4C][C] global) into LDS, split into
@@ -400,7 +401,11 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(Mlp
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
+#ifdef STJ_ABL_NOLDS1      // ablation builds (tools/probes/swin_ablate.sh): the fragment address does not depend on the step, the read is hoisted
+          const typename Mma<T>::Frag wf = Mma<T>::load_tr(W1s, G::LD1, 16 * d, ks * KSTEP, lane);
+#else
           const typename Mma<T>::Frag wf = Mma<T>::load_tr(W1s, G::LD1, s * KSTEP + 16 * d, ks * KSTEP, lane);
+#endif
 #pragma unroll
           for (int i = 0; i < RF; ++i) a1[i][d] = Mma<T>::mma(wf, xa[i][ks], a1[i][d]);
         }
@@ -410,12 +415,20 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(Mlp
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
+#ifndef STJ_ABL_NOGELU
           for (int r = 0; r < 4; ++r) a1[i][d][r] = gelu_fwd<T>(a1[i][d][r]);
+#else
+          for (int r = 0; r < 4; ++r) a1[i][d][r] = a1[i][d][r] * 0.5f;
+#endif
         hf[i] = Chain<T>::from_acc(a1[i]);
       }
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
+#ifdef STJ_ABL_NOLDS2
+        const typename Chain<T>::Frag wf = Chain<T>::ldA_tr(W2s, G::LD2, 16 * f, 0, lane);
+#else
         const typename Chain<T>::Frag wf = Chain<T>::ldA_tr(W2s, G::LD2, 16 * f, s * KSTEP, lane);
+#endif
 #pragma unroll
         for (int i = 0; i < RF; ++i) acc2[i][f] = Mma<T>::mma(wf, hf[i], acc2[i][f]);
       }
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(Mlp
   }
   if constexpr (SPLIT == 2) {     // the slices' sums meet in the workgroup that finishes last (slice_combine); it alone goes on
     __shared__ int ticket;
-    if (!slice_combine<RF * NF, 64 * G::RG>(&acc2[0][0], p.part, unit, sp, p.split, tid, &ticket)) return;
+    if (!slice_combine<RF * NF, 64 * G::RG>(&acc2[0][0], p.part, p.cnt, unit, sp, p.split, tid, &ticket)) return;
   }
   STAMP(4);
   if (hg != 0) return;
@@ -636,7 +649,7 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_bwd_kernel(Mlp
   }
   if constexpr (SPLIT == 2) {     // (see the forward kernel)
     __shared__ int ticket;
-    if (!slice_combine<RF * NF, 64 * G::RG>(&acc[0][0], p.part, unit, sp, p.split, tid, &ticket)) return;
+    if (!slice_combine<RF * NF, 64 * G::RG>(&acc[0][0], p.part, p.cnt, unit, sp, p.split, tid, &ticket)) return;
   }
   // LayerNorm backward on the accumulator layout (lane: columns 16 f + 4 g .. +3 of row m0 + 16 i + ln) + the skip gradient
   T* dx = reinterpret_cast<T*>(p.dx);
@@ -915,6 +928,9 @@ static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
       if (a.part == nullptr) { stj_set_error("swin_mlp: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
       MlpArgs s = a;                 // (row block, hidden slice) workgroups + the finishing launch
       s.split = mlp_split_for(a.M);
+      if constexpr (sizeof(T) == 2) {       // two slices (cfg-512's 8192 rows): they meet inside the launch, no finishing launch
+        if (s.split == 2 && (a.M + 63) / 64 <= FIX_CNT_BYTES / 4) return mlp_launch<T, 384, 1, 2>(bwd, s, st);
+      }
       const int rc = mlp_launch<T, 384, 1, 1>(bwd, s, st);
       if (rc != STJ_OK) return rc;
       if (bwd) return split_bwd_epi<T>(a.x, a.dy, a.part, s.split, a.gamma, a.eps, nullptr, nullptr, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.M, st);
@@ -936,17 +952,24 @@ static int mlp_any(bool bwd, int C, int dtype, const MlpArgs& a, hipStream_t st)
 
 // bytes of the f32 workspace `ws` of the four stj_swin_* entry points at C = 384 (NULL: the one-workgroup-per-row-block kernels; other
 // C: ignored): the slices' partial sums [SPLIT_MAX][M][C]
-extern "C" long long stj_swin_split_workspace_bytes(long long M, int C) {
-  if (C == 384) return (long long)SPLIT_MAX * M * C * 4;
-  if (C == 192 && M < 256 * 128) return FIX_CNT_BYTES + 2 * ((M + 63) / 64 * 64) * C * 4;        // counters + two slabs per 64-row unit
+// partial-sum / slab region of the workspace; the arrival counters follow it
+static long long split_region_bytes(long long M, int C) {
+  const long long Mp = (M + 63) / 64 * 64;
+  if (C == 384) return (long long)SPLIT_MAX * Mp * C * 4;
+  if (C == 192 && M < 256 * 128) return 2 * Mp * C * 4;        // two slabs per 64-row unit
   return 0;
+}
+static int* split_counters(void* ws, long long M, int C) { return ws ? reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + split_region_bytes(M, C)) : nullptr; }
+extern "C" long long stj_swin_split_workspace_bytes(long long M, int C) {
+  const long long r = split_region_bytes(M, C);
+  return r ? r + FIX_CNT_BYTES : 0;
 }
 
 extern "C" int stj_swin_mlp_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
                                 const float* b2, void* y, long long M, int C, float eps, const long long* rng_state, int site,
                                 float p_drop, long long rows_per_sample, int dtype, void* ws, hipStream_t stream) {
   MlpArgs a = {};
-  a.part = reinterpret_cast<float*>(ws);
+  a.part = reinterpret_cast<float*>(ws); a.cnt = split_counters(ws, M, C);
   a.x = x; a.gamma = gamma; a.beta = beta; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.M = M; a.eps = eps;
   a.rng = rng_state; a.site = site; a.p_drop = p_drop; a.rows_per_sample = rows_per_sample;
   return mlp_any(false, C, dtype, a, stream);
@@ -958,7 +981,7 @@ extern "C" int stj_swin_mlp_bwd(const void* x, const void* dy, const float* gamm
                                 float p_drop, long long rows_per_sample, int dtype, void* ws, hipStream_t stream) {
   if (nparts < 1) { stj_set_error("swin_mlp_bwd: nparts must be >= 1"); return STJ_EINVAL; }
   MlpArgs a = {};
-  a.part = reinterpret_cast<float*>(ws);
+  a.part = reinterpret_cast<float*>(ws); a.cnt = split_counters(ws, M, C);
   a.x = x; a.dy = dy; a.gamma = gamma; a.beta = beta; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.dx = dx; a.h = h; a.dpre = dpre; a.ln = ln;
   a.dys = dys; a.dgamma = dgamma; a.dbeta = dbeta; a.nparts = nparts; a.pstride = part_stride; a.M = M; a.eps = eps;
   a.rng = rng_state; a.site = site; a.p_drop = p_drop; a.rows_per_sample = rows_per_sample;
@@ -1001,7 +1024,7 @@ struct AttnArgs {
   void* qkv; void* a; void* ln; float* mean; float* rstd;         // training hand-offs (all NULL for inference)
   int B, res, shift; float eps;
   const long long* rng; int site; float p_drop;
-  int split; float* part;        // SPLIT kernel: workgroup = (window, slice of the heads); partial sums [split][M][C] f32 in token order
+  int split; float* part; int* cnt;   // SPLIT kernel: workgroup = (window, slice of the heads); partial sums [split][M][C] f32 in token order | slabs + arrival counters
 };
 
 // weight slices of one head group, global -> registers (issued ahead) -> LDS
@@ -1206,7 +1229,7 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   }
   if constexpr (SPLIT == 2) {     // the head slices' shares meet in the workgroup that finishes last (slice_combine); it alone goes on
     __shared__ int ticket;
-    if (!slice_combine<NF>(acco, p.part, unit, sp, p.split, tid, &ticket)) return;
+    if (!slice_combine<NF>(acco, p.part, p.cnt, unit, sp, p.split, tid, &ticket)) return;
   }
   const float dp = drop_path_scale(p.rng, p.site, b, p.p_drop);
   T* y = reinterpret_cast<T*>(p.y) + myrow * C;
@@ -1247,6 +1270,7 @@ static int attn_split384(const AttnArgs& a, hipStream_t st) {
     AttnArgs s = a;
     const long long N = (long long)a.res * a.res;
     s.split = attn_split_for(a.B * (N / 64));          // 6 slices of 2 heads (32 windows at B = 8: 192 workgroups) or 2 of 6
+    if (s.split == 2 && a.B * (N / 64) <= FIX_CNT_BYTES / 4) return attn_launch<T, 384, 2>(s, st);      // two slices meet inside the launch
     const int rc = attn_launch<T, 384, 1>(s, st);
     if (rc != STJ_OK) return rc;
     return split_fwd_epi<T>(a.x, a.part, s.split, a.bproj, a.y, a.B * N, 384, a.rng, a.site, a.p_drop, N, st);
@@ -1283,7 +1307,7 @@ extern "C" int stj_swin_attn_fwd(const void* x, const float* gamma, const float*
   AttnArgs p = {};
   p.x = x; p.gamma = gamma; p.beta = beta; p.wqkv = wqkv; p.bqkv = bqkv; p.table = table; p.wproj = wproj; p.bproj = bproj; p.y = y;
   p.qkv = qkv; p.a = a; p.ln = ln; p.mean = mean; p.rstd = rstd; p.B = B; p.res = res; p.shift = shift; p.eps = eps;
-  p.rng = rng_state; p.site = site; p.p_drop = p_drop; p.part = reinterpret_cast<float*>(ws);
+  p.rng = rng_state; p.site = site; p.p_drop = p_drop; p.part = reinterpret_cast<float*>(ws); p.cnt = split_counters(ws, (long long)B * res * res, C);
   if (dtype == STJ_BF16) return attn_dispatch<bf16>(C, p, stream);
   if (dtype == STJ_F16) return attn_dispatch<f16>(C, p, stream);
   if (dtype == STJ_F32) return attn_dispatch<float>(C, p, stream);
@@ -1324,7 +1348,7 @@ struct AttnBArgs {
   void* dx; void* dqkv; void* dys; float* dtable; int tparts; float* dgamma; float* dbeta; int nparts; long long pstride;
   int B, res, shift;
   const long long* rng; int site; float p_drop;
-  int split; float* part;        // SPLIT kernel: workgroup = (window, slice of the heads); partial d LN(x) [split][M][C] f32 in token order
+  int split; float* part; int* cnt;   // SPLIT kernel: workgroup = (window, slice of the heads); partial d LN(x) [split][M][C] f32 in token order | slabs + arrival counters
 };
 
 // staging geometry of the backward kernel (chunks per thread).  (The first version copied each 16-byte piece load -> store in a loop:
@@ -1645,7 +1669,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
   }
   if constexpr (SPLIT && FIX) {   // the head slices' shares meet in the workgroup that finishes last (slice_combine); it alone goes on
     __shared__ int ticket;
-    if (!slice_combine<NF>(dln, p.part, unit, sp, NSPLIT, tid, &ticket)) return;
+    if (!slice_combine<NF>(dln, p.part, p.cnt, unit, sp, NSPLIT, tid, &ticket)) return;
   }
   // ---- LayerNorm backward on the accumulator layout + the shortcut gradient; gamma / beta partial sums
   {
@@ -1715,6 +1739,7 @@ static int attnb_split384(const AttnBArgs& a, hipStream_t st) {          // see 
     if (a.part == nullptr) { stj_set_error("swin_attn_bwd: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
     const long long N = (long long)a.res * a.res;
     const int split = attn_split_for(a.B * (N / 64));
+    if (split == 2 && a.B * (N / 64) <= FIX_CNT_BYTES / 4) return attnb_launch<T, 384, 2, 0, true>(a, st);
     const int rc = split == 6 ? attnb_launch<T, 384, 6>(a, st) : attnb_launch<T, 384, 2>(a, st);
     if (rc != STJ_OK) return rc;
     return split_bwd_epi<T>(a.x, a.dy, a.part, split, a.gamma, 0.f, a.mean, a.rstd, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.B * N, st);
@@ -1744,7 +1769,7 @@ extern "C" int stj_swin_attn_bwd(const void* x, const void* dy, const void* qkv,
   p.x = x; p.dy = dy; p.qkv = qkv; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.wqkv = wqkv; p.wproj = wproj; p.table = table;
   p.dx = dx; p.dqkv = dqkv; p.dys = dys; p.dtable = dtable; p.tparts = tparts; p.dgamma = dgamma; p.dbeta = dbeta; p.nparts = nparts;
   p.pstride = part_stride; p.B = B; p.res = res; p.shift = shift; p.rng = rng_state; p.site = site; p.p_drop = p_drop;
-  p.part = reinterpret_cast<float*>(ws);
+  p.part = reinterpret_cast<float*>(ws); p.cnt = split_counters(ws, (long long)B * res * res, C);
 #define STJ_AB(TT) (C == 96 ? attnb_launch<TT, 96>(p, stream) : (C == 192 ? attnb_192<TT>(p, stream) : (C == 384 ? attnb_split384<TT>(p, stream) : (stj_set_error("swin_attn_bwd: C must be 96, 192 or 384 (got %d)", C), (int)STJ_EUNSUPPORTED))))
   if (dtype == STJ_BF16) return STJ_AB(bf16);
   if (dtype == STJ_F16) return STJ_AB(f16);

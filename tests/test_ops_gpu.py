@@ -851,7 +851,7 @@ def test_swin_mlp_fused(dt, B, N, C, p_drop):
 
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('B,res,C,shift,p_drop', [(2, 16, 96, 0, 0.0), (3, 16, 96, 4, 0.3), (2, 16, 192, 4, 0.3), (1, 32, 192, 0, 0.0), (2, 8, 96, 0, 0.0),
-                                                  (3, 16, 384, 4, 0.3), (1, 16, 384, 0, 0.0), (2, 8, 384, 0, 0.3)])
+                                                  (3, 16, 384, 4, 0.3), (1, 16, 384, 0, 0.0), (2, 8, 384, 0, 0.3), (1, 64, 384, 4, 0.3), (8, 32, 192, 4, 0.3)])
 def test_swin_attn_half_fused(dt, B, res, C, shift, p_drop):
     """csrc/swin_fused.hip: x + DropPath(proj(window_attention(LN(x) Wqkv + b))) in one kernel (modules.py:225-258,103-134,189-216)
     and its backward (GEMMs + window-attention backward on the saved operands) vs float64 autograd on the index formulation."""
