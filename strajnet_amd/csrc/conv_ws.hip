@@ -23,10 +23,15 @@
 template <typename T, int KS, int NF, int NW>
 __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
                                                                const float* __restrict__ bias, T* __restrict__ Y,
-                                                               int F, int Hi, int Wi, int Cout, int act, int ntiles) {
+                                                               int F, int Hi, int Wi, int Cout, int act, int ntiles, int ct) {
   constexpr int CIN = KS * 32;
   constexpr int LDK = CIN + 16;                    // halo pixel stride (elements): 2 (mod 4) 16-byte slots -> conflict-free b128 fragment reads
   constexpr int CT = NF * 16;                      // cout tile of this workgroup
+  // 1-D grid of 8 * ct * K workgroups.  The ct cout groups that walk the SAME tile sequence sit on ONE XCD (workgroup id % 8) and share
+  // the halo tiles through that XCD's L2: as a (tile walker, cout group) 2-D grid the three groups of the 128 -> 96 layer landed on three
+  // XCDs and X was fetched 266 MB per launch for a 67 MB input (profiles/r04_h_roofline_traffic.json).
+  const int xcd_ = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
+  const int bx = (slot_ / ct) * 8 + xcd_, by = slot_ % ct, gx_ = gridDim.x / ct;
   constexpr int LDO = CT + 8;                      // output-stage pixel stride (elements), 16-byte aligned rows
   constexpr int HPIX = WS_HH * WS_HW;              // 180 halo pixels
   constexpr int CPP = CIN / 8;                     // 16-byte chunks per halo pixel
@@ -41,7 +46,7 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const T* __
   const int a = (w & 3) >> 1, b = w & 1;           // this wave's output phase
   const int row0 = (w >> 2) * (WS_TH / NW);        // first tile row of this wave
   const int g = lane >> 4, ln = lane & 15;
-  const int n0 = blockIdx.y * CT;
+  const int n0 = by * CT;
   const int tiles_x = (Wi + WS_TW - 1) / WS_TW, tiles_y = (Hi + WS_TH - 1) / WS_TH;
   const int Ho = 2 * Hi, Wo = 2 * Wi;
 
@@ -100,13 +105,13 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const T* __
     }
   };
 
-  int tile = blockIdx.x;
+  int tile = bx;
   if (tile < ntiles) { prefetch(tile); commit(halo0); }
   __syncthreads();
   int buf = 0;
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < ntiles; tile += gx_) {
     const T* halo = buf ? halo1 : halo0;
-    const int next = tile + gridDim.x;
+    const int next = tile + gx_;
     if (next < ntiles) prefetch(next);
     int f, ty0, tx0;
     tile_coords(tile, f, ty0, tx0);
@@ -183,11 +188,13 @@ static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y,
   }
   const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
   const int ct = (Cout + CT - 1) / CT;
-  int nblk = 256 / ct;
-  if (nblk > ntiles) nblk = ntiles;
-  if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL((upconv_fwd_ws_kernel<T, KS, NF, NW>), dim3(nblk, ct), dim3(256 * NW), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y,
-                     F, Hi, Wi, Cout, act, ntiles);
+  // tile walkers: a multiple of 8 (see the kernel's workgroup map), and no more workgroups than CUs: the tiles are dealt out statically, so two
+  // workgroups sharing a CU set the launch's time (88 walkers x 3 groups = 264 workgroups: 224 us; 85 x 3 on three XCDs each: 141 us)
+  int nblk = 256 / ct / 8 * 8;
+  if (nblk < 8) nblk = 8;
+  while (nblk > 8 && nblk - 8 >= ntiles) nblk -= 8;
+  hipLaunchKernelGGL((upconv_fwd_ws_kernel<T, KS, NF, NW>), dim3(nblk * ct), dim3(256 * NW), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y,
+                     F, Hi, Wi, Cout, act, ntiles, ct);
   return true;
 }
 

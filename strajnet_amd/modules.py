@@ -236,11 +236,11 @@ class STrajNet:
         # fused Swin-block kernels (csrc/swin_fused.hip); STJ_FUSED_SWIN=0 selects the layer-by-layer path (the one the f32 mode's C = 384 stage takes)
         self.fused_mlp = self.fused_attn = os.environ.get('STJ_FUSED_SWIN', '1') != '0'
         # C = 384 (the 16x16 stage: 2048 rows = 32 row blocks / 32 windows at B = 8) runs the SPLIT variants of the fused kernels --
-        # (row block | window) x (slice of the hidden dimension | of the heads) workgroups + a finishing launch -- in the 16-bit modes;
-        # the f32 parity mode keeps that stage layer by layer
-        wide = (384,) if self.dtype != torch.float32 else ()
-        self.fused_attn_dims = (96, 192) + wide
-        self.fused_mlp_dims = (96, 192) + wide
+        # (row block | window) x (slice of the hidden dimension | of the heads) workgroups + a finishing launch.  The f32 parity mode runs the
+        # MLP half of that stage through the same split kernel (round 5: the oracle gate then covers its code too) and keeps only the
+        # attention half layer by layer (an f32 weight slice of one head does not fit LDS next to the window's q|k|v tile)
+        self.fused_attn_dims = (96, 192) + ((384,) if self.dtype != torch.float32 else ())
+        self.fused_mlp_dims = (96, 192, 384)
         # the 8 time-separated cross-attentions as one kernel per direction (csrc/xattn_fused.hip); False = the layer-by-layer chain
         # (the parity tests run both and compare)
         self.fused_xattn = True

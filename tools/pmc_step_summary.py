@@ -19,7 +19,10 @@ BENCH_KEY = {'upconv_dgrad_ws2_kernel<true, true>': 'upconv_dgrad[128x128,96->48
              'outconv_pair_fwd_kernel<bf16, 48>': 'outconv_pair_fwd[256x256,48->2,F64x2]',
              'outconv_fwd_mfma_kernel<bf16, 48>': 'outconv_fwd[256x256,48->2,F64]',
              'upconv_fwd_ws_kernel<bf16, 4, 2, 2>': 'upconv_fwd[64x64,128->96,F64]',
-             'upconv_dgrad_ws_kernel<3, 4, false, 96>': 'upconv_dgrad[64x64,128->96,F64]'}
+             'upconv_dgrad_ws_kernel<3, 4, false, 96>': 'upconv_dgrad[64x64,128->96,F64]',
+             # dominant kernels of the extra configurations (tools/pmc_step.sh <tag> --infer / --cfg512)
+             'upconv_fwd_ws2_kernel<f16, 3, 3, true, true>': 'upconv_fwd_head[128x128,96->48->18,F256]',
+             'swin_mlp_bwd_kernel<bf16, 384, 1, 2, 4, 1>': 'swin_mlp_bwd[8192x384]'}
 
 
 def short(n):
@@ -64,6 +67,6 @@ for t, k, n, us, rd, wr, sq in rows[:60]:
     wt = sq.get('SQ_WAIT_ANY', 0.0) / sq['SQ_WAVE_CYCLES'] * 100 if sq.get('SQ_WAVE_CYCLES') else 0.0
     print(f'{t / tot * 100:7.2f} {n:8d} {us:8.1f} {rd / 1e6:9.1f} {wr / 1e6:9.1f} {tb:6.2f} {tb / 8 * 100:5.0f} {mf:6.1f} {cf:6.1f} {wt:6.1f}  {k}')
     if k in BENCH_KEY:
-        out[BENCH_KEY[k]] = round(rd + wr)
+        out.setdefault(BENCH_KEY[k], round(rd + wr))
 if len(sys.argv) > 5:
     json.dump(out, open(sys.argv[5], 'w'), indent=1)
