@@ -227,6 +227,16 @@ template <> struct Mma<f16> : Mma16<f16> {
   }
 };
 
+// sum over the 16 lanes of a DPP row (the lanes of equal lane >> 4); every lane gets the total.  quad_perm xor 1, xor 2, then
+// row_half_mirror / row_mirror (the quads / halves already hold equal values)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
 // accumulate a (FM*16) x (FN*16) wave tile over kk in [0,KT) from K-contiguous LDS tiles
 template <typename T, int FM, int FN>
 __device__ __forceinline__ void mma_tile(const T* As, int lda, const T* Bs, int ldb, int KT, int lane, f32x4 (&acc)[FM][FN]) {

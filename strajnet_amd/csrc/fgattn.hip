@@ -59,16 +59,6 @@ __device__ __forceinline__ void load_kv(const T* k, const T* v, T* Kt, T* Vt, lo
   }
 }
 
-// sum over the 16 lanes of a DPP row (the lanes of equal lane >> 4); every lane gets the total.  quad_perm xor 1, xor 2, then
-// row_half_mirror / row_mirror (the quads / halves already hold equal values)
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
-  return v;
-}
-
 // the 8 logits (scaled product + sampled bias) a lane holds of key fragments 2s, 2s+1: v[e], keys 32 s + 16 (e / 4) + 4 g4 + e % 4
 template <typename T, int NKF>
 __device__ __forceinline__ void logits8(float (&v)[8], const T* Kt, const HeadOp<T>& qop, const float* tbl, const float* offs,

@@ -333,6 +333,14 @@ __device__ __forceinline__ void ln_rows(typename Mma<T>::Frag (&xa)[RF][C / Mma<
   }
 }
 
+// 4 consecutive elements of a row as loaded (unpacked where they are used: the loads are issued a phase early)
+template <typename T> struct Raw4 { typedef uint2 type; };
+template <> struct Raw4<float> { typedef float4 type; };
+template <typename T> __device__ __forceinline__ void raw4_unpack(const typename Raw4<T>::type& r, float* v) {
+  if constexpr (sizeof(T) == 4) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+  else { unpack2<T>(r.x, v[0], v[1]); unpack2<T>(r.y, v[2], v[3]); }
+}
+
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
@@ -361,11 +369,13 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(Mlp
   // for it waited for the whole prefetch -- every chunk paid a full memory round trip (found on the C = 384 split kernels: 6 chunks, 32 us)
   __shared__ float b1s[4 * C];
   STAMP(0); STAMP(1);
-  for (int c = hs0 + tid; c < hs1; c += NT) b1s[c] = p.b1[c];
   MlpStage<T, C, G> stg;
   stg.issue(w1, w2, hs0, tid);                        // first weight chunk in flight under the row loads + LayerNorm
   typename Mma<T>::Frag xa[RF][KS];
   load_rows<T, C, RF>(xa, x, m0, p.M, lane);
+  // (the bias loads go LAST: their LDS writes wait for everything issued before them, so bias, first weight chunk and rows are ONE memory
+  //  round trip; in front of the others they were a round trip of their own)
+  for (int c = hs0 + tid; c < hs1; c += NT) b1s[c] = p.b1[c];
   float mu[RF], rs[RF];
   ln_rows<T, C, RF>(xa, p.gamma, p.beta, p.eps, mu, rs, lane);
   STAMP(2);
@@ -375,6 +385,14 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(Mlp
   for (int i = 0; i < RF; ++i)
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc2[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the shortcut rows in the accumulator layout: fetched under the last chunk / in front of the hand-over (see swin_attn_bwd_kernel)
+  constexpr bool TAILPF = RF == 1 && SPLIT != 1;
+  typename Raw4<T>::type xraw[TAILPF ? NF : 1];
+  auto tail_prefetch = [&]() __attribute__((always_inline)) {
+    const long long row = m0 + ln < p.M ? m0 + ln : p.M - 1;
+#pragma unroll
+    for (int f = 0; f < (TAILPF ? NF : 1); ++f) xraw[f] = *reinterpret_cast<const typename Raw4<T>::type*>(x + row * C + 16 * f + 4 * g);
+  };
 
   TICK_DECL;
   for (int hc0 = hs0; hc0 < hs1; hc0 += G::HC) {
@@ -388,6 +406,7 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(Mlp
     TICK(3);
     if (hc0 == hs0) STAMP(6);
     if (STJ_MLP_PREFETCH && hc0 + G::HC < hs1) stg.issue(w1, w2, hc0 + G::HC, tid);      // next chunk: global loads overlap this chunk's MFMAs
+    if constexpr (TAILPF && HS == 1 && SPLIT == 0) { if (hc0 + G::HC >= hs1) tail_prefetch(); }
 #pragma unroll 1
     for (int s = hg; s < G::HC / KSTEP; s += HS) {
       f32x4 a1[RF][ND];
@@ -438,6 +457,7 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(Mlp
   TICK_STORE;
 
   STAMP(3);
+  if constexpr (TAILPF && (HS > 1 || SPLIT == 2)) tail_prefetch();
   if constexpr (HS > 1) {         // the hidden groups' sums meet in LDS (over the weight images): group 0 carries on with the total
     __syncthreads();
     f32x4* rb = reinterpret_cast<f32x4*>(mlp_smem) + (rg * RF * NF) * 64 + lane;
@@ -484,7 +504,11 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(Mlp
                                   // waits behind the previous store -- NF dependent round trips at the end of every wave
     float4 bs[NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) { ld4(x + row * C + 16 * f + 4 * g, xs[f]); bs[f] = *reinterpret_cast<const float4*>(p.b2 + 16 * f + 4 * g); }
+    for (int f = 0; f < NF; ++f) {
+      if constexpr (TAILPF) raw4_unpack<T>(xraw[f], xs[f]);
+      else ld4(x + row * C + 16 * f + 4 * g, xs[f]);
+      bs[f] = *reinterpret_cast<const float4*>(p.b2 + 16 * f + 4 * g);
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int col = 16 * f + 4 * g;
@@ -519,13 +543,13 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_bwd_kernel(Mlp
   const T* w2 = reinterpret_cast<const T*>(p.w2);
   for (int c = tid; c < 2 * C; c += NT) (&red[0][0])[c] = 0.f;
   __shared__ float b1s[4 * C];                         // (see the forward kernel)
-  for (int c = hs0 + tid; c < hs1; c += NT) b1s[c] = p.b1[c];
 
   MlpStage<T, C, G> stg;
   stg.issue(w1, w2, hs0, tid);
   typename Mma<T>::Frag xa[RF][KS], da[RF][KS];
   load_rows<T, C, RF>(xa, x, m0, p.M, lane);
   load_rows<T, C, RF>(da, dy, m0, p.M, lane);
+  for (int c = hs0 + tid; c < hs1; c += NT) b1s[c] = p.b1[c];      // (last: see the forward kernel)
   float mu[RF], rs[RF], dp[RF];
   ln_rows<T, C, RF>(xa, p.gamma, p.beta, p.eps, mu, rs, lane);
   // hand-off operands of the weight gradients: ln = LN(x) and dys = dp * dy, written from the B fragments (16-byte rows segments)
@@ -559,6 +583,18 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_bwd_kernel(Mlp
     for (int f = 0; f < NF; ++f) acc[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   T* hq = reinterpret_cast<T*>(p.h);
   T* dpq = reinterpret_cast<T*>(p.dpre);
+  // the LayerNorm backward's operands in the accumulator layout (x and dy of the wave's rows): fetched under the last chunk (or in front of the
+  // hand-over of the hidden groups / slices), not where the epilogue needs them (see swin_attn_bwd_kernel)
+  constexpr bool TAILPF = RF == 1 && SPLIT != 1;
+  typename Raw4<T>::type xraw[TAILPF ? NF : 1], dyraw[TAILPF ? NF : 1];
+  auto tail_prefetch = [&]() __attribute__((always_inline)) {
+    const long long row = m0 + ln < p.M ? m0 + ln : p.M - 1;
+#pragma unroll
+    for (int f = 0; f < (TAILPF ? NF : 1); ++f) {
+      xraw[f] = *reinterpret_cast<const typename Raw4<T>::type*>(x + row * C + 16 * f + 4 * g);
+      dyraw[f] = *reinterpret_cast<const typename Raw4<T>::type*>(dy + row * C + 16 * f + 4 * g);
+    }
+  };
 
   for (int hc0 = hs0; hc0 < hs1; hc0 += G::HC) {
     __syncthreads();
@@ -566,6 +602,7 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_bwd_kernel(Mlp
     stg.commit(W1s, W2s, tid);
     __syncthreads();
     if (STJ_MLP_PREFETCH && hc0 + G::HC < hs1) stg.issue(w1, w2, hc0 + G::HC, tid);
+    if constexpr (TAILPF && HS == 1 && SPLIT == 0) { if (hc0 + G::HC >= hs1) tail_prefetch(); }
 #pragma unroll 1
     for (int s = hg; s < G::HC / KSTEP; s += HS) {
       f32x4 a1[RF][ND], a3[RF][ND];                    // pre^T and dh^T, [hidden][row]
@@ -618,6 +655,7 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_bwd_kernel(Mlp
     }
   }
 
+  if constexpr (TAILPF && (HS > 1 || SPLIT == 2)) tail_prefetch();
   if constexpr (HS > 1) {         // (see the forward kernel)
     __syncthreads();
     f32x4* rb = reinterpret_cast<f32x4*>(mlp_smem) + (rg * RF * NF) * 64 + lane;
@@ -666,7 +704,10 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_bwd_kernel(Mlp
     float xh[NF][4];
     float dyv[NF][4];             // read up front: dx may alias dy, so loads left in the store loop below are serialised behind each store
     float s1 = 0.f, s2 = 0.f;
-    if (live) {
+    if constexpr (TAILPF) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) raw4_unpack<T>(dyraw[f], dyv[f]);
+    } else if (live) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) ld4(dy + row * C + 16 * f + 4 * g, dyv[f]);
     }
@@ -674,7 +715,8 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_bwd_kernel(Mlp
     for (int f = 0; f < NF; ++f) {
       const int col = 16 * f + 4 * g;
       float xv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (live) ld4(x + row * C + col, xv);
+      if constexpr (TAILPF) raw4_unpack<T>(xraw[f], xv);
+      else if (live) ld4(x + row * C + col, xv);
       const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
       const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
 #pragma unroll
@@ -1091,7 +1133,6 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   const int unit = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x, sp = SPLIT ? (int)blockIdx.x % p.split : 0;
   const int hb0 = SPLIT ? sp * (G::HEADS / p.split) : 0, hb1 = SPLIT ? hb0 + G::HEADS / p.split : G::HEADS;
   __shared__ float bqs[3 * C];                       // qkv bias in LDS (a global load inside the head loop would wait for the prefetched weights)
-  for (int c = tid; c < 3 * C; c += 256) bqs[c] = p.bqkv[c];
   AttnStage<T, C, HGP> stg;
   stg.issue(wq, wp, hb0, tid);                       // first head group's weights in flight under the row gather + LayerNorm
   const int nwx = p.res / 8, nW = nwx * nwx;
@@ -1118,6 +1159,7 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xa[0][ks] = Mma<T>::from_global(px + ks * KSTEP);
   }
+  for (int c = tid; c < 3 * C; c += 256) bqs[c] = p.bqkv[c];          // (behind the weight and row loads: one memory round trip for the three)
   float mu[1], rs[1];
   ln_rows<T, C, 1>(xa, p.gamma, p.beta, p.eps, mu, rs, lane);
   if (p.ln && sp == 0) {
@@ -1131,6 +1173,14 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
 #pragma unroll
   for (int f = 0; f < NF; ++f) acco[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float scale = 0.17677669529663687f;       // 32^-1/2
+  // the shortcut row in the accumulator layout: fetched under the last pass / in front of the hand-over (see swin_attn_bwd_kernel)
+  constexpr bool TAILPF = SPLIT != 1;
+  typename Raw4<T>::type xraw[TAILPF ? NF : 1];
+  auto tail_prefetch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < (TAILPF ? NF : 1); ++f)
+      xraw[f] = *reinterpret_cast<const typename Raw4<T>::type*>(reinterpret_cast<const T*>(p.x) + myrow * C + 16 * f + 4 * g);
+  };
 
   for (int h0 = hb0; h0 < hb1; h0 += HG) {
     // ---- weight slices of this head group (Wqkv[:, seg*C + 32 h0 .. +GC] for seg = q,k,v; Wproj[32 h0 .. +GC, :]): registers -> LDS
@@ -1210,6 +1260,7 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
         for (int jd = 0; jd < 2; ++jd) { const float v[4] = {of[2 * hh + jd][0], of[2 * hh + jd][1], of[2 * hh + jd][2], of[2 * hh + jd][3]}; st4(ao + 16 * jd, v); }
       }
     }
+    if constexpr (TAILPF && SPLIT == 0) { if (h0 + HG >= hb1) tail_prefetch(); }
     // ---- phase 3: out^T += Wproj[32 h0 .. +GC, :]^T O^T, O^T chained from the accumulators
 #pragma unroll
     for (int kk = 0; kk < GC / KSTEP; ++kk) {
@@ -1229,6 +1280,7 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   }
   if constexpr (SPLIT == 2) {     // the head slices' shares meet in the workgroup that finishes last (slice_combine); it alone goes on
     __shared__ int ticket;
+    tail_prefetch();
     if (!slice_combine<NF>(acco, p.part, p.cnt, unit, sp, p.split, tid, &ticket)) return;
   }
   const float dp = drop_path_scale(p.rng, p.site, b, p.p_drop);
@@ -1237,7 +1289,11 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   float xs[NF][4];                // shortcut row read before the first store (y may alias x: see swin_mlp_fwd_kernel)
   float4 bs[NF];
 #pragma unroll
-  for (int f = 0; f < NF; ++f) { ld4(xr + 16 * f + 4 * g, xs[f]); bs[f] = *reinterpret_cast<const float4*>(p.bproj + 16 * f + 4 * g); }
+  for (int f = 0; f < NF; ++f) {
+    if constexpr (TAILPF) raw4_unpack<T>(xraw[f], xs[f]);
+    else ld4(xr + 16 * f + 4 * g, xs[f]);
+    bs[f] = *reinterpret_cast<const float4*>(p.bproj + 16 * f + 4 * g);
+  }
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     const int col = 16 * f + 4 * g;
@@ -1401,11 +1457,12 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
     const int lx = rx < p.res - 8 ? 0 : (rx < p.res - p.shift ? 1 : 2);
     lab[t] = ly * 3 + lx;
   }
+  STAMP(0); STAMP(1);
   for (int c = tid; c < 2 * C; c += 256) red[c] = 0.f;
   // bias tables of the workgroup's heads in LDS up front: a global load inside the head loop sits behind the prefetched weight group in the
   // in-order vmcnt queue and made every head wait for the whole prefetch
+  // (loaded BEHIND the first weight chunk and the dy rows, below: one memory round trip for the three instead of two)
   __shared__ float tbv[NH * 225];
-  for (int q = tid; q < NH * 225; q += 256) tbv[q] = p.table[(q % 225) * G::HEADS + hb0 + q / 225];
   __syncthreads();
   const long long myrow = (long long)b * N + tok[16 * wv + ln];
   const T* wq = reinterpret_cast<const T*>(p.wqkv);
@@ -1487,6 +1544,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
       if (p.dys && sp == 0) *reinterpret_cast<typename Mma<T>::Frag*>(reinterpret_cast<T*>(p.dys) + myrow * C + ks * KSTEP + LK * g) = dya[ks];
     }
   }
+  for (int q = tid; q < NH * 225; q += 256) tbv[q] = p.table[(q % 225) * G::HEADS + hb0 + q / 225];      // (readers are behind the proj loop's barriers)
   // ---- phase 1: da^T[c][tok] = sum_oc Wproj[c][oc] dys^T[oc][tok]  (A = Wproj rows, k = oc contiguous: the natural layout)
   f32x4 da[DAF];
 #pragma unroll
@@ -1505,11 +1563,18 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
         da[f] = Mma<T>::mma(Mma<T>::load(Wb, G::LDW, 16 * f, kk * KSTEP, lane), dya[k0 / KSTEP + kk], da[f]);
   }
 
+  STAMP(2);
   f32x4 dln[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) dln[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int qi = 16 * wv + ln;
   const int mylab = lab[qi];
+  TICK_DECL;
+  // the LayerNorm backward's operands (x row, dy row, statistics): fetched under the LAST pass's dLN product -- loaded where they are used
+  // the epilogue was two dependent memory round trips on an otherwise finished workgroup (17.6 of its 79 kcycles at C = 96: stamps)
+  constexpr bool TAILPF = !SPLIT || FIX;       // (with slices meeting inside the launch: in front of the hand-over, by every slice)
+  typename Raw4<T>::type xraw[TAILPF ? NF : 1], dyraw[TAILPF ? NF : 1];
+  float mu_pf = 0.f, rs_pf = 0.f;
 
 #pragma unroll
   for (int hl = 0; hl < NH; hl += HG) {            // unrolled: the da[] fragments of a head are picked by a compile-time index
@@ -1517,9 +1582,11 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
     __syncthreads();                                  // previous pass done with the tile and the weight buffer
     // q|k|v of this head group -> tile (token-major, gathered); Wqkv[:, group columns] -> weight buffer (rows = c): fetched during
     // the previous phase, committed here; the next group's go in flight right away
+    TICK(0);
     commit_group();
     __syncthreads();
     if (hl + HG < NH) issue_group(h0 + HG);
+    TICK(1);
 #pragma unroll
     for (int hh = 0; hh < HG; ++hh) {
       const int h = h0 + hh, hd = hl + hh;             // head; its index among the da[] fragments
@@ -1645,7 +1712,20 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
       for (int bin = tid; bin < 225; bin += 256)
         atomicAdd(p.dtable + (long long)(unit % p.tparts) * 225 * G::HEADS + bin * G::HEADS + h, tbl[bin]);
     }
+    TICK(2);
     __syncthreads();                                  // dq | dk | dv of the whole group are in the tile
+    if constexpr (TAILPF && !FIX) {
+      if (hl + HG >= NH) {
+        const T* xr = reinterpret_cast<const T*>(p.x) + myrow * C + 4 * g;
+        const T* dyr = reinterpret_cast<const T*>(p.dy) + myrow * C + 4 * g;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          xraw[f] = *reinterpret_cast<const typename Raw4<T>::type*>(xr + 16 * f);
+          dyraw[f] = *reinterpret_cast<const typename Raw4<T>::type*>(dyr + 16 * f);
+        }
+        mu_pf = p.mean[myrow]; rs_pf = p.rstd[myrow];
+      }
+    }
     {   // copy-out for the qkv weight gradient (rows in original token order), then dLN^T += Wqkv[:, group] dqkv_group^T
       constexpr int CPS = GC / VN;
       for (int q = tid; q < 64 * 3 * CPS; q += 256) {
@@ -1659,7 +1739,10 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
 #pragma unroll
       for (int f = 0; f < NF; ++f) dln[f] = Mma<T>::mma(Mma<T>::load(Wb, G::LDW, 16 * f, kk * KSTEP, lane), bf, dln[f]);
     }
+    TICK(3);
   }
+  TICK_STORE;
+  STAMP(3);
 
   if constexpr (SPLIT && !FIX) {  // this head slice's share of d LN(x)
     float* pr = p.part + ((long long)sp * p.B * N + myrow) * C + 4 * g;
@@ -1669,11 +1752,21 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
   }
   if constexpr (SPLIT && FIX) {   // the head slices' shares meet in the workgroup that finishes last (slice_combine); it alone goes on
     __shared__ int ticket;
+    {
+      const T* xr = reinterpret_cast<const T*>(p.x) + myrow * C + 4 * g;
+      const T* dyr = reinterpret_cast<const T*>(p.dy) + myrow * C + 4 * g;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        xraw[f] = *reinterpret_cast<const typename Raw4<T>::type*>(xr + 16 * f);
+        dyraw[f] = *reinterpret_cast<const typename Raw4<T>::type*>(dyr + 16 * f);
+      }
+      mu_pf = p.mean[myrow]; rs_pf = p.rstd[myrow];
+    }
     if (!slice_combine<NF>(dln, p.part, p.cnt, unit, sp, NSPLIT, tid, &ticket)) return;
   }
   // ---- LayerNorm backward on the accumulator layout + the shortcut gradient; gamma / beta partial sums
   {
-    const float mu = p.mean[myrow], rs = p.rstd[myrow];
+    const float mu = TAILPF ? mu_pf : p.mean[myrow], rs = TAILPF ? rs_pf : p.rstd[myrow];
     const T* xr = reinterpret_cast<const T*>(p.x) + myrow * C;
     const T* dyr = reinterpret_cast<const T*>(p.dy) + myrow * C;
     T* dxr = reinterpret_cast<T*>(p.dx) + myrow * C;
@@ -1681,21 +1774,23 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
     float dyv[NF][4];             // read up front: dx may alias dy, so loads left in the store loop below are serialised behind each store
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) ld4(dyr + 16 * f + 4 * g, dyv[f]);
+    for (int f = 0; f < NF; ++f) {
+      if constexpr (TAILPF) raw4_unpack<T>(dyraw[f], dyv[f]);
+      else ld4(dyr + 16 * f + 4 * g, dyv[f]);
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int col = 16 * f + 4 * g;
       float xv[4];
-      ld4(xr + col, xv);
+      if constexpr (TAILPF) raw4_unpack<T>(xraw[f], xv);
+      else ld4(xr + col, xv);
       const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
       const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         xh[f][r] = (xv[r] - mu) * rs;
         const float d = dln[f][r];
-        float a = d * xh[f][r], bsum = d;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); bsum += __shfl_xor(bsum, o, 64); }
+        const float a = row16_sum(d * xh[f][r]), bsum = row16_sum(d);         // over the wave's 16 rows (DPP, no LDS crossbar)
         if (ln == 0) { atomicAdd(&red[col + r], a); atomicAdd(&red[C + col + r], bsum); }
         const float t = d * gmv[r];
         dln[f][r] = t;
@@ -1717,6 +1812,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
   __syncthreads();
   const long long po = (long long)(blockIdx.x % p.nparts) * p.pstride;
   for (int c = tid; c < C; c += 256) { atomicAdd(p.dgamma + po + c, red[c]); atomicAdd(p.dbeta + po + c, red[C + c]); }
+  STAMP(5);
 }
 
 template <typename T, int C, int NSPLIT = 1, int HGP = 0, bool FIX = false>

@@ -1262,6 +1262,9 @@ def xattn_pack(ps, zstride, Z, dtype, out=None):
     return out
 
 
+XATTN_WG_KIND = 1      # (2 = on the up-conv weight-gradient side stream: 1250 vs 1335 scenes/s, round 5 -- one more fork off the main chain and the graph executor serialises the deferred up-conv weight gradients with it)
+
+
 class _XAttn(torch.autograd.Function):
     """y = LN2(FFN(LN1(MHA(query, k, v)))) + query for Z weight sets (trajNet.py:224-234,305-317).  query [Z,B,HW,384]; k, v [Z,B*64,126]
     (projected keys / values: their projections stay autograd nodes of their own); ps: Params of set 0 (set z lies zstride elements
@@ -1316,7 +1319,7 @@ class _XAttn(torch.autograd.Function):
              _p(dpre), _p(du2), _p(n1), _p(dv1), _p(dq), _p(ps['g1'].grad), _p(ps['be1'].grad), _p(ps['bo'].grad), _p(ps['g2'].grad),
              _p(ps['be2'].grad), Z, B, HW, _p(state), sites[0], sites[1], sites[2], float(p_drop), dt, _st())
         # the four weight gradients of the Z sets, straight into the flat gradient buffer: one grouped launch
-        with wgrad_stream(1, hd, dpre, du2, n1, dv1, dq, so, query), gemm_group():
+        with wgrad_stream(XATTN_WG_KIND, hd, dpre, du2, n1, dv1, dq, so, query), gemm_group():
             gemm(hd, du2, ps['w2'].grad, 512, 384, R, (0, R * 512, 1, 512), (0, R * 384, 384, 1), (0, zs, 384), dt, nb=(1, Z), c_f32=1,
                  accumulate=1, splitk=0, colsum=ps['b2'].grad, sBias=(0, zs))                      # dW2 += hd^T du2 ; db2
             gemm(n1, dpre, ps['w1'].grad, 128, 512, R, (0, R * 128, 1, 128), (0, R * 512, 512, 1), (0, zs, 512), dt, nb=(1, Z), c_f32=1,
