@@ -369,13 +369,14 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(Mlp
   // for it waited for the whole prefetch -- every chunk paid a full memory round trip (found on the C = 384 split kernels: 6 chunks, 32 us)
   __shared__ float b1s[4 * C];
   STAMP(0); STAMP(1);
+  // (the bias loads go LAST: their LDS writes wait for everything issued before them, so bias, first weight chunk and rows are ONE memory
+  //  round trip; in front of the others they were a round trip of their own.  Not in the C = 384 split kernels: 36.5 -> 39.5 us there)
+  if constexpr (SPLIT == 1) { for (int c = hs0 + tid; c < hs1; c += NT) b1s[c] = p.b1[c]; }
   MlpStage<T, C, G> stg;
   stg.issue(w1, w2, hs0, tid);                        // first weight chunk in flight under the row loads + LayerNorm
   typename Mma<T>::Frag xa[RF][KS];
   load_rows<T, C, RF>(xa, x, m0, p.M, lane);
-  // (the bias loads go LAST: their LDS writes wait for everything issued before them, so bias, first weight chunk and rows are ONE memory
-  //  round trip; in front of the others they were a round trip of their own)
-  for (int c = hs0 + tid; c < hs1; c += NT) b1s[c] = p.b1[c];
+  if constexpr (SPLIT != 1) { for (int c = hs0 + tid; c < hs1; c += NT) b1s[c] = p.b1[c]; }
   float mu[RF], rs[RF];
   ln_rows<T, C, RF>(xa, p.gamma, p.beta, p.eps, mu, rs, lane);
   STAMP(2);
