@@ -135,11 +135,18 @@ int stj_win_attn_bwd(const void* qkv, const float* table, const void* dout, void
  *        of the two weight gradients written once: h = gelu(pre) [M,4C], dpre [M,4C], ln = LN(x) [M,C], dys = dp*dy [M,C]
  *        (dys may be NULL when there is no DropPath: use dy).  dW1 = ln^T dpre, db1 = colsum(dpre), dW2 = h^T dys,
  *        db2 = colsum(dys) are stj_gemm split-K launches.
- * ws (C = 384 only; ignored for the other widths): f32 workspace of stj_swin_split_workspace_bytes(M, C) bytes.  The 2048-row
- *   stage runs as (row block, 1/8 of the hidden dimension) workgroups -- 256 at B = 8 instead of 32, each streaming 1/8 of the weights
- *   -- whose partial sums [8][M][C] a second launch adds up and finishes (bias + DropPath + shortcut; LayerNorm backward + dgamma /
- *   dbeta).  REQUIRED at C = 384 (STJ_EINVAL without it).  The four stj_swin_* entry points share the workspace layout;
- *   stj_swin_attn_* at C = 384 also need a 16-bit dtype: (window, 2 of the 12 heads) workgroups. */
+ * ws: workspace of stj_swin_split_workspace_bytes(M, C) bytes (0 = this (M, C) takes none: pass NULL), ZERO-INITIALISED ONCE by the caller
+ *   and then left to the kernels: where a stage has fewer row blocks / windows than the chip has CUs, a unit is cut into slices of the hidden
+ *   dimension (MLP half) or of the heads (attention half) that run as separate workgroups:
+ *     C = 384, many slices (the 2048-row stage: (row block, 1/8 of the hidden dimension) workgroups, 256 at B = 8 instead of 32, each
+ *       streaming 1/8 of the weights): partial sums [slices][M][C] f32 that a second launch adds up and finishes (bias + DropPath +
+ *       shortcut; LayerNorm backward + dgamma / dbeta);
+ *     two slices (C = 192 below 32768 rows; C = 384 at 8192 rows): the slices meet INSIDE the launch -- each writes its accumulators as a
+ *       slab (write-through stores) and draws a ticket from the unit's arrival counter; the workgroup that draws the last one adds the
+ *       other slab and runs the epilogue.  The counters live behind the partial-sum region and re-arm themselves (hence "zeroed once").
+ *   REQUIRED at C = 384 (STJ_EINVAL without it); at C = 192 NULL selects one workgroup per unit.  The four stj_swin_* entry points share
+ *   the workspace layout (launches that share a workspace must be ordered on one stream); stj_swin_attn_* at C = 384 also need a 16-bit
+ *   dtype: (window, 2 of the 12 heads) workgroups. */
 long long stj_swin_split_workspace_bytes(long long M, int C);
 int stj_swin_mlp_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
                      const float* b2, void* y, long long M, int C, float eps, const long long* rng_state, int site,

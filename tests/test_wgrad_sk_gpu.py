@@ -124,7 +124,7 @@ def test_deferred_queue_in_a_backward_pass_matches_immediate_launches():
             y = ops.join_after_backward(y, (), lambda: None)      # the node a model's output passes through: opens / closes the queue
         y.backward(rnd((4096, 96), dt, 6))
         torch.cuda.synchronize()
-        assert not ops._WQ['on'] and not ops._WQ['jobs']
+        assert not ops._wq()['on'] and not ops._wq()['jobs']
         grads.append([t.grad.clone() for t in (pw, pb, pw2, pb2)] + [x.grad.float().clone()])
     for a, b in zip(*grads):
         assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item()), (a - b).abs().max().item()

@@ -11,5 +11,8 @@ python bench.py --dtype f32 --no-cpu-baseline --no-extra-configs --steps 5 --war
 bash tools/trace.sh $tag > /dev/null 2>&1
 bash tools/trace_infer.sh $tag > /dev/null 2>&1
 bash tools/pmc_step.sh $tag > /dev/null 2>&1
+bash tools/pmc_step.sh $tag --infer > /dev/null 2>&1
+bash tools/pmc_step.sh $tag --cfg512 > /dev/null 2>&1
+bash tools/trace.sh ${tag}_cfg512 --cfg512 > /dev/null 2>&1
 cat gpurun_out/${tag}_gputests.txt
 for f in bench_line bench_line_cfg512 bench_line_infer bench_line_f32; do python -c "import json,sys; d=json.loads(open('gpurun_out/${tag}_$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'])"; done
