@@ -951,7 +951,10 @@ static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* 
     hipLaunchKernelGGL((upconv_wgrad_tr_kernel<3, 6, CW>), dim3((strips + 7) / 8 * 8 * 4), dim3(256), 0, st, (const bf16*)X, (const bf16*)dP, dWeff, dbias, db_parts, F, Hi, Wi, Cin, Cout, cpb, strips, 1);
   } else {
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    const int tgt = 1024;      // workgroups (swept: more or fewer are equal or worse)
+    // workgroups (swept again in round 5, after the accumulation buffers' alignment fix: 256 / 512 / 768 / 1536 / 2048 = 209 / 110 / 123 / 124 /
+    // 136 us for 384 -> 192 and 152 / 137 / 112 / 130 / 139 for 192 -> 128, against 111 / 113 for 1024; full-cout x 64-cin tiles (<6,4> / <8,4>:
+    // 20 / 183 spilled registers at two workgroups per CU) 132-157 / 248-290 us)
+    const int tgt = 1024;
     int strips = (int)min(nchunks, (long long)max(1, tgt / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
     strips = (int)((nchunks + cpb - 1) / cpb);
