@@ -26,16 +26,26 @@
 
 namespace wsk {
 
-constexpr int TN_ = 96, TW_ = 384;            // tile: narrow x wide columns
+constexpr int TW_ = 384;                       // tile: wide columns
 constexpr int KU = 32;                         // rows per unit (one 16x16x32 MFMA k-step)
-constexpr int LDN = TN_ + 16, LDW = TW_ + 16;  // LDS row strides (elements): 56 / 200 dwords = 8 * odd
-constexpr int CHN = LDN / 8, CHW = LDW / 8;    // 16-byte chunks per image row: 14 / 50
-constexpr int IMG_N = KU * LDN * 2;            // 7168 bytes = 7 x 1 KB DMA instructions
-constexpr int STAGE = KU * (LDN + LDW) * 2;    // 32768 bytes = 32 DMA instructions, 8 per wave
-constexpr int NS = 4;                          // ring depth
-constexpr int SLOTS = STAGE / 1024 / 4;        // DMA instructions per wave and stage
+constexpr int LDW = TW_ + 16;                  // LDS row stride of the wide image (elements): 200 dwords = 8 * odd
+constexpr int CHW = LDW / 8;                   // 16-byte chunks per wide image row: 50
 constexpr int MAXJ = 28;                       // jobs per launch (descriptor lives in the kernarg segment: 4 KB)
-static_assert(IMG_N % 1024 == 0 && STAGE % 4096 == 0, "whole DMA instructions");
+// Two tile geometries (round 5).  TN = 96: 4 waves as 2 x 2 (the Swin widths of the 64 x 64 stage are whole problems).  TN = 192: 8 waves
+// as 4 x 2 on the same 48 x 192 wave tile, for launches whose problems are all at least 192 wide on both sides (the C = 192 / 384 stages,
+// cfg-512's 8192-row C = 384 stage): a 32-row slab of 192 + 384 columns feeds twice the MFMAs of one of 96 + 384 -- 128 instead of 77
+// FLOP per byte of the L2 -> LDS stream those launches are bound by (one launch of cfg-512's 24 wide jobs: 2.26 GB streamed in 613 us).
+template <int TN> struct Geo {
+  static constexpr int TN_ = TN;
+  static constexpr int NWV = TN == 96 ? 4 : 8;               // waves per workgroup
+  static constexpr int LDN = TN == 96 ? 112 : 240;           // LDS row stride of the narrow image (elements): 56 / 120 dwords = 8 * odd
+  static constexpr int CHN = LDN / 8;                        // 16-byte chunks per narrow image row (the pad chunks re-read a valid one)
+  static constexpr int IMG_N = KU * LDN * 2;                 // 7168 / 15360 bytes = 7 / 15 x 1 KB DMA instructions
+  static constexpr int STAGE = KU * (LDN + LDW) * 2;         // 32768 / 40960 bytes = 32 / 40 DMA instructions: 8 / 5 per wave
+  static constexpr int NS = TN == 96 ? 4 : 3;                // ring depth (96 / 80 KB in flight)
+  static constexpr int SLOTS = STAGE / 1024 / NWV;           // DMA instructions per wave and stage
+  static_assert(IMG_N % 1024 == 0 && STAGE % (1024 * NWV) == 0 && LDN % 16 == 0 && (LDN / 16) % 2 == 1 && LDN >= TN + 8, "whole DMA instructions, conflict-free stride");
+};
 
 struct Job {
   const void* nar; const void* wid; float* C; float* cs;      // narrow / wide operand, dW, db (or null)
@@ -68,7 +78,7 @@ typedef const __attribute__((address_space(4))) Desc* KD;
 struct KL { KD kd; int jb, je; };       // a job list
 
 // unit u of list kl -> its segment, cut at uend
-template <bool SWAP>
+template <bool SWAP, int TN_>
 __device__ __forceinline__ Seg decode(const KL& kl, int u, int uend) {
   KD kd = kl.kd;
   int j = kl.jb;
@@ -140,18 +150,20 @@ __device__ __forceinline__ s16x8 read_tr(uint32_t lds_byte_lo, uint32_t lds_byte
 //                 64-byte row segments of dW.
 //   SWAP = true : dY is the narrow operand; the MFMA operands are exchanged (A = wide = X), D rows = cin again.
 // (Flushing D^T instead -- 16-byte pieces -- measured 4x slower: the atomic units retire 64-byte segments, tools/probes/atomic_probe.hip.)
-template <typename T, bool SWAP>
+template <typename T, bool SWAP, int TN>
 __device__ __forceinline__ void body(const KL kl, const int u0, const int u1, unsigned char* ring) {
+  typedef Geo<TN> GE;
+  constexpr int NWV = GE::NWV, LDN = GE::LDN, CHN = GE::CHN, IMG_N = GE::IMG_N, STAGE = GE::STAGE, NS = GE::NS, SLOTS = GE::SLOTS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const uint32_t ring0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)ring);
 
-  // DMA slot geometry of this lane: instruction i = wave + 4 s of a stage covers chunks 64 i .. 64 i + 63 of the stage image
+  // DMA slot geometry of this lane: instruction i = wave + NWV s of a stage covers chunks 64 i .. 64 i + 63 of the stage image
   int srow[SLOTS], scc[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
-    const int i = wave + 4 * s;
+    const int i = wave + NWV * s;
     const bool nar = i < IMG_N / 1024;
     const int c = (nar ? i : i - IMG_N / 1024) * 64 + lane;
     srow[s] = nar ? c / CHN : c / CHW;
@@ -159,13 +171,13 @@ __device__ __forceinline__ void body(const KL kl, const int u0, const int u1, un
   }
 
   // ---- loader state ----
-  Seg L = decode<SWAP>(kl, u0, u1);
+  Seg L = decode<SWAP, TN>(kl, u0, u1);
   int lu = u0, lk = L.k0;
   int voff[SLOTS];
   auto set_voff = [&]() {
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-      const bool nar = (wave + 4 * s) < IMG_N / 1024;
+      const bool nar = (wave + NWV * s) < IMG_N / 1024;
       const int nvc = (nar ? L.vn : L.vw) >> 3;
       // pad / out-of-tile chunks re-read a valid one (fetching them from a zero page instead measured 6 % slower grouped, 3.5x slower on
       // one-problem launches)
@@ -179,15 +191,15 @@ __device__ __forceinline__ void body(const KL kl, const int u0, const int u1, un
     const char* bw = L.pw + (long long)lk * L.stepw;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-      const bool nar = (wave + 4 * s) < IMG_N / 1024;
-      glds16((nar ? bn : bw) + voff[s], dst + s * 4096);
+      const bool nar = (wave + NWV * s) < IMG_N / 1024;
+      glds16((nar ? bn : bw) + voff[s], dst + s * (NWV * 1024));
     }
     ++lu; ++lk;
-    if (lk == L.k1 && lu < u1) { L = decode<SWAP>(kl, lu, u1); lk = L.k0; set_voff(); }
+    if (lk == L.k1 && lu < u1) { L = decode<SWAP, TN>(kl, lu, u1); lk = L.k0; set_voff(); }
   };
 
   // ---- consumer state ----
-  Seg S = decode<SWAP>(kl, u0, u1);
+  Seg S = decode<SWAP, TN>(kl, u0, u1);
   int ck = S.k0;
   constexpr int FA = SWAP ? 12 : 3, FB = SWAP ? 3 : 12;       // D fragments: rows x columns
   constexpr int NCS = SWAP ? 3 : 12;                           // dY fragments of a wave = D column fragments either way
@@ -275,14 +287,14 @@ __device__ __forceinline__ void body(const KL kl, const int u0, const int u1, un
         for (int b = 0; b < FB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < NCS; ++j) csum[j] = 0.f;
-      if (cu + 1 < u1) { S = decode<SWAP>(kl, cu + 1, u1); ck = S.k0; }
+      if (cu + 1 < u1) { S = decode<SWAP, TN>(kl, cu + 1, u1); ck = S.k0; }
     }
   }
 }
 
 // Workgroups [0, g0) take the X-narrow jobs, the others the dY-narrow ones: one launch, two instruction streams.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void wgrad_sk_kernel(Desc dsc) {
+template <typename T, int TN>
+__global__ __launch_bounds__(64 * Geo<TN>::NWV, TN == 96 ? 2 : 1) void wgrad_sk_kernel(Desc dsc) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
   (void)dsc;
   KD kd = (KD)__builtin_amdgcn_kernarg_segment_ptr();
@@ -290,11 +302,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_sk_kernel(Desc dsc) {
   if (w < g0) {
     const int total = kd->total0;
     const int u0 = (int)((long long)total * w / g0), u1 = (int)((long long)total * (w + 1) / g0);
-    if (u0 < u1) body<T, false>(KL{kd, 0, kd->n0}, u0, u1, ring);
+    if (u0 < u1) body<T, false, TN>(KL{kd, 0, kd->n0}, u0, u1, ring);
   } else {
     const int total = kd->total1, g1 = gridDim.x - g0, w1 = w - g0;
     const int u0 = (int)((long long)total * w1 / g1), u1 = (int)((long long)total * (w1 + 1) / g1);
-    if (u0 < u1) body<T, true>(KL{kd, kd->n0, kd->n}, u0, u1, ring);
+    if (u0 < u1) body<T, true, TN>(KL{kd, kd->n0, kd->n}, u0, u1, ring);
   }
 }
 
@@ -329,11 +341,13 @@ extern "C" int stj_wgrad_group(const stj_wgrad_job* jobs, int njobs, int dtype, 
   for (int i = 0; i < njobs; ++i)
     if (!wsk_supported(jobs[i], dtype)) { stj_set_error("stj_wgrad_group: job %d is not supported (see stj_wgrad_job_supported)", i); return STJ_EUNSUPPORTED; }
   static PerDevice<int> attr_set;
-  constexpr int lds = wsk::NS * wsk::STAGE;
+  constexpr int lds96 = wsk::Geo<96>::NS * wsk::Geo<96>::STAGE, lds192 = wsk::Geo<192>::NS * wsk::Geo<192>::STAGE;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wsk::wgrad_sk_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)wsk::wgrad_sk_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      stj_set_error("stj_wgrad_group: cannot reserve %d bytes of LDS", lds);
+    if (hipFuncSetAttribute((const void*)wsk::wgrad_sk_kernel<bf16, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds96) != hipSuccess ||
+        hipFuncSetAttribute((const void*)wsk::wgrad_sk_kernel<f16, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds96) != hipSuccess ||
+        hipFuncSetAttribute((const void*)wsk::wgrad_sk_kernel<bf16, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, lds192) != hipSuccess ||
+        hipFuncSetAttribute((const void*)wsk::wgrad_sk_kernel<f16, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, lds192) != hipSuccess) {
+      stj_set_error("stj_wgrad_group: cannot reserve %d bytes of LDS", lds96 > lds192 ? lds96 : lds192);
       return STJ_ELAUNCH;
     }
     attr_set = 1;
@@ -346,15 +360,31 @@ extern "C" int stj_wgrad_group(const stj_wgrad_job* jobs, int njobs, int dtype, 
   }
   const int budget = wg_budget > 0 ? wg_budget : (int)ncu;
   auto tiles = [](int w, int t) { return (w + t - 1) / t; };
-  // orientation of a job: which operand is cut into 96-column slices.  Cost = operand columns staged per row of the problem.
-  auto swapped = [&](const stj_wgrad_job& j) {
-    const long long cost_ns = (long long)tiles(j.cout, wsk::TW_) * j.cin + (long long)tiles(j.cin, wsk::TN_) * j.cout;      // X narrow
-    const long long cost_sw = (long long)tiles(j.cin, wsk::TW_) * j.cout + (long long)tiles(j.cout, wsk::TN_) * j.cin;      // dY narrow
-    const long long nt_ns = (long long)tiles(j.cout, wsk::TW_) * tiles(j.cin, wsk::TN_), nt_sw = (long long)tiles(j.cin, wsk::TW_) * tiles(j.cout, wsk::TN_);
-    return cost_sw < cost_ns || (cost_sw == cost_ns && nt_sw < nt_ns);
-  };
   for (int j0 = 0; j0 < njobs; j0 += wsk::MAXJ) {
     const int n = njobs - j0 < wsk::MAXJ ? njobs - j0 : wsk::MAXJ;
+    // tile geometry of this launch: 192-column narrow slices (8 waves) when every problem is at least 192 wide on both sides
+    // AND the launch is long: at least 32 of the larger units per workgroup.  (Measured, hot loop, 256 workgroups, 96 / 192-column slices:
+    // cfg-512's 8192-row C = 384 stage, 24 jobs, 345 / 261 us; its 32768-row C = 192 stage 144 / 126 us; cfg-256's 2048-row C = 384 stage
+    // -- 12 units per workgroup -- 59 / 99 us, its 8192-row C = 192 stage 64 / 86 us: tools/probes/wgrad_sk_budget.py.)
+    int TN = 192;
+    long long units192 = 0;
+    for (int i = 0; i < n; ++i) {
+      const stj_wgrad_job& j = jobs[j0 + i];
+      if (j.cin < 192 || j.cout < 192) TN = 96;
+      const long long nt_ns = (long long)tiles(j.cout, wsk::TW_) * tiles(j.cin, 192), nt_sw = (long long)tiles(j.cin, wsk::TW_) * tiles(j.cout, 192);
+      units192 += (long long)j.nb1 * j.nb2 * (j.rows / wsk::KU) * (nt_ns < nt_sw ? nt_ns : nt_sw);
+    }
+    if (units192 < 32ll * budget) TN = 96;
+#ifdef STJ_WSK_FORCE_TN
+    TN = STJ_WSK_FORCE_TN;
+#endif
+    // orientation of a job: which operand is cut into TN-column slices.  Cost = operand columns staged per row of the problem.
+    auto swapped = [&](const stj_wgrad_job& j) {
+      const long long cost_ns = (long long)tiles(j.cout, wsk::TW_) * j.cin + (long long)tiles(j.cin, TN) * j.cout;      // X narrow
+      const long long cost_sw = (long long)tiles(j.cin, wsk::TW_) * j.cout + (long long)tiles(j.cout, TN) * j.cin;      // dY narrow
+      const long long nt_ns = (long long)tiles(j.cout, wsk::TW_) * tiles(j.cin, TN), nt_sw = (long long)tiles(j.cin, wsk::TW_) * tiles(j.cout, TN);
+      return cost_sw < cost_ns || (cost_sw == cost_ns && nt_sw < nt_ns);
+    };
     wsk::Desc d;
     long long total[2] = {0, 0}, cost[2] = {0, 0};
     int k = 0;
@@ -374,7 +404,7 @@ extern "C" int stj_wgrad_group(const stj_wgrad_job* jobs, int njobs, int dtype, 
         }
         o.C = j.dw; o.cs = j.db; o.ldc = (int)j.lddw;
         o.cb1s = j.sdw1; o.cb2s = j.sdw2; o.sb1s = j.sdb1; o.sb2s = j.sdb2;
-        o.t_nar = tiles(o.n_nar, wsk::TN_); o.t_wid = tiles(o.n_wid, wsk::TW_);
+        o.t_nar = tiles(o.n_nar, TN); o.t_wid = tiles(o.n_wid, wsk::TW_);
         o.ku = j.rows / wsk::KU; o.nb2 = j.nb2;
         o.ustart = (int)total[pass];
         const long long units = (long long)j.nb1 * j.nb2 * o.t_nar * o.t_wid * o.ku;
@@ -396,8 +426,13 @@ extern "C" int stj_wgrad_group(const stj_wgrad_job* jobs, int njobs, int dtype, 
     if (total[1] == 0) g0 = G;
     if (g0 < 0 || (total[0] > 0 && g0 == 0)) { g0 = total[0] > 0 ? 1 : 0; if (G < g0 + (total[1] > 0 ? 1 : 0)) G = g0 + 1; }
     d.g0 = (int)g0;
-    if (dtype == STJ_BF16) hipLaunchKernelGGL(wsk::wgrad_sk_kernel<bf16>, dim3((unsigned)G), dim3(256), lds, stream, d);
-    else hipLaunchKernelGGL(wsk::wgrad_sk_kernel<f16>, dim3((unsigned)G), dim3(256), lds, stream, d);
+    if (TN == 96) {
+      if (dtype == STJ_BF16) hipLaunchKernelGGL((wsk::wgrad_sk_kernel<bf16, 96>), dim3((unsigned)G), dim3(256), lds96, stream, d);
+      else hipLaunchKernelGGL((wsk::wgrad_sk_kernel<f16, 96>), dim3((unsigned)G), dim3(256), lds96, stream, d);
+    } else {
+      if (dtype == STJ_BF16) hipLaunchKernelGGL((wsk::wgrad_sk_kernel<bf16, 192>), dim3((unsigned)G), dim3(512), lds192, stream, d);
+      else hipLaunchKernelGGL((wsk::wgrad_sk_kernel<f16, 192>), dim3((unsigned)G), dim3(512), lds192, stream, d);
+    }
     int e = stj_check_launch("stj_wgrad_group");
     if (e) return e;
   }

@@ -81,6 +81,30 @@ def test_grouped_launch_accumulates_into_prefilled_gradients(budget):
         _check(j, dw0, db0)
 
 
+# problems at least 192 wide on both sides: the launches that take the 192-column / eight-wave tile geometry when they are long enough
+# (>= 32 units per workgroup: cfg-512's 8192-row C = 384 stage, its 32768-row C = 192 stage), incl. ragged widths and one-slab problems
+WIDE = [(8192, 384, 1152, 1, False), (8192, 384, 384, 1, False), (8192, 384, 1536, 1, False), (8192, 1536, 384, 1, False),
+        (32768, 192, 576, 1, False), (32768, 768, 192, 1, False), (2048, 200, 392, 2, False), (4096, 392, 200, 1, True), (32, 192, 192, 1, False),
+        (1024, 584, 776, 1, False)]
+
+
+@pytest.mark.parametrize('dt,budget', [(torch.bfloat16, 0), (torch.bfloat16, 7), (torch.float16, 64)])
+def test_wide_launches_take_the_192_column_tiles(dt, budget):
+    """One grouped launch of WIDE (pre-filled gradients, padded strides, some jobs without a bias gradient) -- long enough on every budget
+    here to select wgrad_sk_kernel<T, 192> -- and each problem of the cfg-512 kind alone on 7 workgroups."""
+    from strajnet_amd import ops
+    jobs = [_mk(r, ci, co, nb, sh, dt, 300 + i, bias=(i % 3 != 1), ldpad=8 * (i % 2), prefill=True) for i, (r, ci, co, nb, sh) in enumerate(WIDE)]
+    ops.wgrad_group([j for j, _, _ in jobs], budget=budget)
+    torch.cuda.synchronize()
+    for j, dw0, db0 in jobs:
+        _check(j, dw0, db0)
+    for i, (r, ci, co, nb, sh) in enumerate(WIDE[:6]):
+        j, dw0, db0 = _mk(r, ci, co, nb, sh, dt, 400 + i)
+        ops.wgrad_group([j], budget=7)
+        torch.cuda.synchronize()
+        _check(j, dw0, db0)
+
+
 def test_same_parameter_twice_and_unsupported_shapes_fall_back():
     """Two jobs adding into ONE gradient (a weight used twice), plus shapes the stream-K kernel refuses (width 42, rows % 32 != 0, f32):
     wgrad_group sends those through stj_gemm and the sum is still right."""
