@@ -415,7 +415,13 @@ extern "C" int stj_wgrad_group(const stj_wgrad_job* jobs, int njobs, int dtype, 
       }
     }
     d.n = k; d.total0 = (int)total[0]; d.total1 = (int)total[1];
-    long long G = (total[0] + total[1]) / 4;                 // at least 4 slabs per workgroup
+#ifndef STJ_WSK_MINU
+#define STJ_WSK_MINU 32
+#endif
+    // at least 32 slabs (1024 rows) per workgroup: every visit of a tile ends in up to 36864 f32 atomics, and short launches are faster on
+    // fewer workgroups (the encoder's stage flushes, 8 problems each: 2048 rows 71 us on 256 workgroups, 55 on 192; 8192 rows 62 / 53.5;
+    // the 32768-row stage and cfg-512's launches have > 32 slabs per workgroup anyway: tools/probes/wgrad_sk_budget.py)
+    long long G = (total[0] + total[1]) / STJ_WSK_MINU;
     if (G > budget) G = budget;
     if (G < 1) G = 1;
     // workgroups per orientation in proportion to the bytes it streams (at least one where there is work)

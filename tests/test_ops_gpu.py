@@ -22,10 +22,25 @@ def tol(dt):
     return {torch.float32: 2e-4, torch.bfloat16: 2e-2, torch.float16: 6e-3}[dt]
 
 
-def rel_err(a, ref):
+RMS_WEIGHT = 2.5
+
+
+def rel_err(a, ref, rms_weight=None):
+    """max( max |a - ref| / max |ref| ,  RMS_WEIGHT * rms(a - ref) / rms(ref) ): the worst element against the tensor's scale AND the
+    error of the tensor as a whole.  (Round 5: the first term alone lets every element be off by the tolerance x the tensor maximum; the
+    second holds the root-mean-square error to tol / 2.5 -- 8e-3 in bf16, 2.4e-3 in fp16, 8e-5 in f32 -- of the root-mean-square value, which a dropped tap, a wrong scale
+    or a systematically mis-rounded operand does not pass.  Measured on MI355X: the largest rms ratio of any bf16 case in this file is
+    printed by `pytest -s` through STJ_TEST_REPORT.)"""
     a = a.detach().double().cpu()
     ref = ref.detach().double().cpu()
-    return float((a - ref).abs().max() / (ref.abs().max() + 1e-12))
+    d = a - ref
+    e_max = float(d.abs().max() / (ref.abs().max() + 1e-12))
+    e_rms = float(d.pow(2).mean().sqrt() / (ref.pow(2).mean().sqrt() + 1e-12))
+    _SEEN.append((e_max, e_rms))
+    return max(e_max, (RMS_WEIGHT if rms_weight is None else rms_weight) * e_rms)
+
+
+_SEEN = []
 
 
 def mk_param(shape, dt, scale=0.1, seed=0):
@@ -880,7 +895,7 @@ def test_swin_attn_half_fused(dt, B, res, C, shift, p_drop):
     qkvr = F.layer_norm(xr, (C,), gr, br, 1e-5) @ wqr + bqr
     yr = xr + keep.view(B, 1, 1) * (_win_ref(qkvr, tr, B, res, heads, shift) @ wpr + bpr)
     t = tol(dt)
-    assert rel_err(y, yr) < t
+    assert rel_err(y, yr, 1.4 if (C == 384 and dt != torch.float32) else None) < t
     # inference form (no saved operands) gives the same result
     with torch.no_grad():
         if dctx is not None:
@@ -890,10 +905,13 @@ def test_swin_attn_half_fused(dt, B, res, C, shift, p_drop):
     g = rnd((B, N, C), dt, 9)
     y.backward(g)
     yr.backward(g.double().cpu())
-    assert rel_err(x.grad, xr.grad) < 2 * t
+    # the C = 384 kernels hold the window's q | k | v tile, P and dS in the 16-bit type in LDS over 12 heads: rms error up to 1.4e-2 of the
+    # rms value in bf16 (every other case of this file stays under 8e-3: RMS_WEIGHT)
+    rw = 1.4 if (C == 384 and dt != torch.float32) else None
+    assert rel_err(x.grad, xr.grad, rw) < 2 * t
     for nm, p_, r_ in (('gamma', pg, gr), ('beta', pb, br), ('wqkv', pwq, wqr), ('bqkv', pbq, bqr), ('table', pt, tr), ('wproj', pwp, wpr),
                        ('bproj', pbp, bpr)):
-        assert rel_err(p_.grad, r_.grad) < 2 * t, nm
+        assert rel_err(p_.grad, r_.grad, rw) < 2 * t, nm
 
 
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
@@ -1057,3 +1075,9 @@ def test_upconv_add_fused_skip(dt, F_, Hi, Cin, Cout, two):
             assert torch.equal(f[4], u[4])
         for i in (2, 3, 5, 6):
             assert rel_err(f[i], u[i]) < (2e-2 if dt == torch.bfloat16 else 3e-3), (mode, i)
+
+
+def test_zz_report_error_ratios():
+    """(runs last in this file) the largest max-norm and rms error ratios any comparison above produced, for the record in DESIGN 2a"""
+    if _SEEN:
+        print(f'\nop-level comparisons: {len(_SEEN)}; largest max-norm ratio {max(e for e, _ in _SEEN):.3e}, largest rms ratio {max(r for _, r in _SEEN):.3e}')
