@@ -806,9 +806,12 @@ def _swin_ws(x, M, C):
     nbytes = int(lib().stj_swin_split_workspace_bytes(M, C))
     if nbytes == 0:
         return None
-    # ONE buffer per (device, size), reused by every C = 384 block in stream order (the kernel and its finishing launch are through with it
-    # before the next block's kernel on the same stream starts): allocating it per call grew the graph's private pool by 25-100 MB per block
-    key = (str(x.device), 'swin_split', int(M), int(C), torch.cuda.current_stream(x.device).cuda_stream)
+    # ONE buffer per (device, size, model), reused by every block of that width in stream order (the kernel and its finishing launch are
+    # through with it before the next block's kernel starts: a model runs its encoder stages on one stream): allocating it per call grew the
+    # graph's private pool by 25-100 MB per block.  Keyed by the model's arena, NOT by the stream: the capture stream of a hipGraph is not
+    # the stream of the warm-up steps, and a first use inside the capture put the zero fill (49 + 9 us, in front of stages 1 and 2) into
+    # every replay (profiles/r05_b_timeline_concurrent.txt)
+    key = (str(x.device), 'swin_split', int(M), int(C), id(_ARENA))
     ws = _WS.get(key)
     if ws is None:
         # zeroed ONCE: it starts with the arrival counters of the kernels whose slices meet inside the launch (they re-arm themselves)
