@@ -141,11 +141,14 @@ def bench_infer(args, model, x, world, rank, dist):
     """BASELINE config 4: replicas only (no collective), one hipGraph replay of the eval forward per step."""
     import torch
     from strajnet_amd.graph import GraphedForward
-    gf = None if args.no_graph else GraphedForward(model, x)
+    pipe = not args.no_agent_pipeline
+    gf = None if args.no_graph else GraphedForward(model, x, pipeline_agents=pipe)
 
     def step():
         if gf is not None:
-            return gf()
+            out = gf()
+            gf.prefetch_agents()         # the NEXT batch's agent branch (its own graph, its own stream) runs under this batch's raster path
+            return out
         with torch.no_grad():
             return model(x['ogm'], x['map_img'], training=False, obs=x['obs'], occ=x['occ'], mapt=None, flow=x['flow'])
 
@@ -165,6 +168,14 @@ def bench_infer(args, model, x, world, rank, dist):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_s = float(t)
+    single = None
+    if gf is not None and pipe:          # the same graphs without the overlap: every step runs its own agent graph in front of the main one
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out = gf()
+        barrier()
+        single = (time.perf_counter() - t1) / args.steps * 1e3
     roof = families = None
     if not args.no_kernel_timing:        # every C-ABI launch of the forward timed alone (serial eager pass), as in the train leg
         from strajnet_amd import prof as kprof
@@ -192,7 +203,9 @@ def bench_infer(args, model, x, world, rank, dist):
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'STrajNet {"cfg-512" if args.cfg512 else "cfg-256"} inference forward (BASELINE config 4: extra measurement, not the headline metric), '
                                    f'batch {B}/GPU, fg_msa+fg, random-init weights', 'global_batch': B * world, 'parallelism': f'replicas x{world}',
-                       'hipgraph': gf is not None, 'finite': bool(torch.isfinite(out).all())},
+                       'hipgraph': gf is not None, 'finite': bool(torch.isfinite(out).all()),
+                       'agent_pipeline': ('the agent branch of batch i + 1 (a hipGraph of its own on a second stream) runs under the raster path of batch i; '
+                                          f'ms_per_step with every batch running its own agent graph first: {single:.3f}') if (gf is not None and pipe) else False},
             'roofline': roof, 'families': families}))
     if world > 1:
         dist.destroy_process_group()
@@ -384,6 +397,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU')
     ap.add_argument('--dtype', default=None, choices=['bf16', 'f32', 'f16'], help='default bf16 (train step) / f16 (--infer)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-agent-pipeline', action='store_true', help='inference: the agent branch inside the one captured graph (round 4 form)')
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip every extra pass after the timed region (per-kernel HIP-event timing, the optimizer-free repeat): the run then executes exactly warmup + steps steps (+ 2 capture warm-ups), which is what the rocprofv3 summaries divide by')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying the captured hipGraph')
     ap.add_argument('--cfg512', action='store_true', help='BASELINE config 5 instead of the metric config: 512x512 rasters, large_ogm, depths [2,2,6] (extra measurement, not the headline)')

@@ -95,11 +95,19 @@ class GraphedTrainStep:
 
 class GraphedForward:
     """hipGraph capture of the inference forward (training=False, no autograd): BASELINE config 4 (batch 32, one MI355X).
-    __call__(batch) copies the batch into the static inputs, replays, and returns the static [B,Hg,Hg,32] f32 output."""
+    __call__(batch) copies the batch into the static inputs, replays, and returns the static [B,Hg,Hg,32] f32 output.
 
-    def __init__(self, model, batch, warmup=2):
+    pipeline_agents=True: the agent branch (trajNet: ~30 dependent launches of a few microseconds that a replayed graph starts only when
+    the raster encoder is through -- 0.3 of the 6.3 ms B = 32 step with nothing beside them, profiles/r05_c_timeline_infer_b32_f16.txt) is a
+    graph of its OWN on a second stream.  prefetch_agents(next_batch), called right after __call__(batch), runs it for the NEXT batch under
+    this batch's raster path; __call__ then waits for it, copies its two small results into the main graph's static inputs and replays the
+    main graph, which no longer contains the branch.  Without a prefetch the agent graph runs in front of the main one (same result)."""
+
+    def __init__(self, model, batch, warmup=2, pipeline_agents=False):
         self.model = model
         self.static = {k: v.clone() for k, v in batch.items() if k in ('ogm', 'map_img', 'obs', 'occ', 'flow')}
+        self.pipeline_agents = pipeline_agents
+        self._prefetched = False
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -107,18 +115,58 @@ class GraphedForward:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.out = self._eager()
+        if pipeline_agents:
+            self.agent_stream = torch.cuda.Stream()
+            self.agent_done, self.agent_free = torch.cuda.Event(), torch.cuda.Event()
+            self.agent_graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.agent_graph, capture_error_mode='thread_local'):
+                self.agent_next = model.agent_encode(self.static['obs'], self.static['occ'])
+            self.agent_cur = tuple(t.clone() for t in self.agent_next)
+            torch.cuda.synchronize()
+            model.agent_override = self.agent_cur
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                self.out = self._eager()
+        finally:
+            model.agent_override = None
+        if pipeline_agents:
+            self.agent_free.record(torch.cuda.current_stream())
 
     def _eager(self):
         x = self.static
         return self.model(x['ogm'], x['map_img'], training=False, obs=x['obs'], occ=x['occ'], mapt=None, flow=x['flow'])
 
+    def prefetch_agents(self, batch=None):
+        """Start the agent graph for the NEXT batch (None: the static inputs as they are) on the agent stream, under whatever the main
+        stream is running."""
+        if not self.pipeline_agents:
+            return
+        st = self.agent_stream
+        st.wait_event(self.agent_free)               # the previous results have been copied out
+        with torch.cuda.stream(st):
+            if batch is not None:
+                for k in ('obs', 'occ'):
+                    if k in batch:
+                        self.static[k].copy_(batch[k], non_blocking=True)
+            self.agent_graph.replay()
+            self.agent_done.record(st)
+        self._prefetched = True
+
     def __call__(self, batch=None):
+        main = torch.cuda.current_stream()
+        if self.pipeline_agents and not self._prefetched:
+            self.agent_stream.wait_stream(main)
+            self.prefetch_agents(batch)
         if batch is not None:
             for k, v in batch.items():
-                if k in self.static:
+                if k in self.static and not (self.pipeline_agents and k in ('obs', 'occ')):
                     self.static[k].copy_(v, non_blocking=True)
+        if self.pipeline_agents:
+            main.wait_event(self.agent_done)
+            for d, s_ in zip(self.agent_cur, self.agent_next):
+                d.copy_(s_, non_blocking=True)
+            self.agent_free.record(main)
+            self._prefetched = False
         self.graph.replay()
         return self.out

@@ -246,6 +246,7 @@ class STrajNet:
         self.fused_xattn = True
         self.fused_stem = True         # PatchEmbed + the stem's sums / norms as one launch per raster (csrc/patch_embed.hip); False = im2col + dense + LayerNorm launches
         self.agent_issue_mode = 2
+        self.agent_override = None            # (key, mask) from agent_encode(): call() then skips the agent branch
         self.mid_forward_hook = None          # callable run once per forward pass behind the encoder's first stage (GraphedTrainStep: loss.prepare on its side stream)
         self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (16-bit modes, 8 x 8 / 16 x 16 maps)
         self._xattn_pack = None
@@ -588,6 +589,16 @@ class STrajNet:
         v = self._drop(self._dense(v, pre + '/FFN2'), pre + '/dropout2')
         return self._ln(v, pre + '/norm2', 1e-3)
 
+    def agent_encode(self, obs, occ):
+        """The agent branch alone (TrajNet.call, trajNet.py:125-187), eval semantics: obs [B,48,11,8], occ [B,16,11,8] -> (key [B,64,384],
+        mask [B,64]) as call() computes them.  For callers that run the branch apart from the raster path (set `agent_override` to the
+        result before call()): it depends on the agents' tracks and the weights only."""
+        ops.set_serial(self.serial)
+        ops.use_arena(self._arena)
+        self._sync_compute_weights()
+        self._dctx = None
+        return tuple(self._traj_net(obs, occ))
+
     def _traj_net(self, obs, occ):
         """TrajNet.call (trajNet.py:125-187) with the 64-way TrajEncoder loop batched.  -> key [B,64,384], mask [B,64]."""
         pre = 'traj_net/traj_encoder'
@@ -818,6 +829,9 @@ class STrajNet:
         # the chain ran alone on an idle GPU for 0.5 ms before the first Swin kernel started (profiles/r02_c_timeline_concurrent.txt).
         mode = self.agent_issue_mode if self._side is not None else -1       # (0: issued at the head of the step, 1: after the encoder -- both measured equal or worse)
         agent = []
+        if self.agent_override is not None:     # the caller ran agent_encode() itself (graph.GraphedForward: a graph of its own, a batch ahead)
+            agent.extend(self.agent_override)
+            mode = -2
 
         def issue_agent():
             self._side.wait_event(fork)
@@ -829,7 +843,7 @@ class STrajNet:
             fork.record(main)
         if mode == 0:
             issue_agent()
-        elif mode < 0:
+        elif mode == -1:
             agent.extend(self._traj_net(obs, occ))
         # Side work that is not needed before the cross-attention / the decoder / the loss is ISSUED behind the encoder's first stage
         # too: a replayed hipGraph starts its first ~20 nodes one after the other whatever their stream, so the seven packing /
@@ -876,7 +890,7 @@ class STrajNet:
             q, query = self._fgmsa(q)                                              # modules.py:825-831
         else:
             query = q.reshape(1, B, hb * hb, Cb).expand(8, B, hb * hb, Cb).contiguous()   # modules.py:827
-        if self._side is not None:       # join the agent branch
+        if self._side is not None and mode >= 0:       # join the agent branch
             main.wait_stream(self._side)
             key.record_stream(main)
             tmask.record_stream(main)
