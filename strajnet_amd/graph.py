@@ -101,7 +101,10 @@ class GraphedForward:
     the raster encoder is through -- 0.3 of the 6.3 ms B = 32 step with nothing beside them, profiles/r05_c_timeline_infer_b32_f16.txt) is a
     graph of its OWN on a second stream.  prefetch_agents(next_batch), called right after __call__(batch), runs it for the NEXT batch under
     this batch's raster path; __call__ then waits for it, copies its two small results into the main graph's static inputs and replays the
-    main graph, which no longer contains the branch.  Without a prefetch the agent graph runs in front of the main one (same result)."""
+    main graph, which no longer contains the branch.  Without a prefetch the agent graph runs in front of the main one (same result).
+    (Also tried: a replay that does not re-cast / re-pack / re-fold the constant weights -- one cast + seven side-stream launches less per step --
+    measured 1.3 % SLOWER in three same-box pairs, 5333 / 5118 / 5333 vs 5390 / 5206 / 5412 scenes/s: where those launches sit decides when the
+    executor starts the other branches, DESIGN 4e.  Not kept.)"""
 
     def __init__(self, model, batch, warmup=2, pipeline_agents=False):
         self.model = model
