@@ -2,8 +2,9 @@
 //     S = 48^-1/2 q k^T + bias ,   bias[q, k] = sample(warp_attn_rel_table[:, :, g])(drow - off1[k], dcol - off0[k])      (:150-172)
 //     a = softmax(S) v                                                                                                   (:173-176)
 // as ONE kernel per direction: the [B, 8, HW, HW] logits / bias / probabilities never exist in HBM (the layer-by-layer path wrote
-// S and the bias in f32 and P in the activation type: 3 x 17 MB per direction at B = 8, in 4 + 5 launches).  16-bit storage types;
-// the f32 parity mode keeps the layer-by-layer kernels (its K / V / P tiles would not fit LDS in the backward kernel).
+// S and the bias in f32 and P in the activation type: 3 x 17 MB per direction at B = 8, in 4 + 5 launches).  All three storage types
+// run the same code (round 5: the f32 parity mode too -- exact-f32 MFMA through Mma<float> / chain48.h, 16-deep k-steps; its backward
+// takes 16 instead of 64 queries per workgroup so that K, V, P and dS fit the 160 KB of LDS: the oracle gate covers this kernel).
 //
 // Work layout (the chained-operand scheme of xattn_fused.hip): a workgroup = 32 (forward) or 64 (backward) queries of one (b, g); a wave
 // = 16 queries against a quarter of the keys (Split<>; 4 waves per SIMD at B = 8).  K and V of the group ([HW][48], HW = 64 or 256) sit
@@ -46,11 +47,11 @@ __device__ __forceinline__ float bias_at(const float* tbl, int TH, int TW, int q
 // K / V rows of group g: global [B, HW, C] (48 contiguous channels at column 48 g) -> LDS tiles [HW][LDK]
 template <typename T, int NT>
 __device__ __forceinline__ void load_kv(const T* k, const T* v, T* Kt, T* Vt, long long row0, int HW, int C, int g, int tid) {
-  constexpr int VN = 8, CPR = D / VN;            // 16-byte pieces per row
+  constexpr int VN = 16 / (int)sizeof(T), CPR = D / VN;            // 16-byte pieces per row
   for (int i = tid; i < 2 * HW * CPR; i += NT) {
     const int t = i / (HW * CPR), rem = i % (HW * CPR), r = rem / CPR, c = (rem % CPR) * VN;
     const uint4 w = *reinterpret_cast<const uint4*>((t ? v : k) + (row0 + r) * C + D * g + c);
-    uint2* d = reinterpret_cast<uint2*>((t ? Vt : Kt) + r * LDK + c);          // rows are 8-byte aligned (104 bytes)
+    uint2* d = reinterpret_cast<uint2*>((t ? Vt : Kt) + r * LDK + c);          // rows are 8-byte aligned (104 bytes in the 16-bit types)
     d[0] = make_uint2(w.x, w.y); d[1] = make_uint2(w.z, w.w);
   }
   for (int i = tid; i < 2 * HW * (LDK - D); i += NT) {
@@ -79,9 +80,10 @@ __device__ __forceinline__ void logits8(float (&v)[8], const T* Kt, const HeadOp
 // The waves of a workgroup: QG groups of 16 queries x KS slices of the keys (a wave = 16 queries against HW / KS keys).  One wave per
 // 16 queries against all 256 keys left the chip at one wave per SIMD (8 x 8 x 16 waves at B = 8) with every LDS / transcendental
 // latency exposed: 35 us forward, 111 us backward; the key slices of one query group merge through LDS.
-template <int NKF, bool BWD> struct Split {
+template <int NKF, bool BWD, typename T = bf16> struct Split {
   static constexpr int KS = NKF == 16 ? 4 : 1;
-  static constexpr int QG = (NKF == 16 && !BWD) ? 2 : 4;
+  // (f32 backward on the 16 x 16 map: ONE query group, or P / dS [queries][256 keys] do not fit LDS next to K and V)
+  static constexpr int QG = NKF == 16 ? (BWD ? (sizeof(T) == 4 ? 1 : 4) : 2) : 4;
   static constexpr int NT = 64 * QG * KS;
   static constexpr int TQ = 16 * QG;               // queries per workgroup
   static constexpr int IT = NKF / 2 / KS;          // 32-key steps per wave
@@ -89,7 +91,7 @@ template <int NKF, bool BWD> struct Split {
 template <typename T, int NKF> struct Lds {
   static constexpr int HW = 16 * NKF;
   static constexpr int LDP = HW + 8;
-  static constexpr int TQB = Split<NKF, true>::TQ;
+  static constexpr int TQB = Split<NKF, true, T>::TQ;
   static int fwd_bytes(int tt) { return 2 * HW * LDK * (int)sizeof(T) + (tt + 2 * HW) * 4; }
   static int bwd_bytes(int tt) { return (2 * HW * LDK + 2 * TQB * LDP + 2 * TQB * LDT) * (int)sizeof(T) + (2 * tt + 4 * HW) * 4; }
 };
@@ -97,8 +99,9 @@ template <typename T, int NKF> struct Lds {
 // =====================================================================================================================
 // Forward: the keys are visited 32 at a time with a running maximum / sum (the logits of a query never exist all at once).
 template <typename T, int NKF>
-__global__ __launch_bounds__((Split<NKF, false>::NT)) void fgattn_fwd_kernel(Args p) {
-  typedef Split<NKF, false> W;
+__global__ __launch_bounds__((Split<NKF, false, T>::NT)) void fgattn_fwd_kernel(Args p) {
+  typedef Split<NKF, false, T> W;
+  constexpr int ND = Ch<T>::ND;
   constexpr int HW = 16 * NKF, Ww = NKF == 4 ? 8 : 16, NT = W::NT, QG = W::QG, KS = W::KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char fg_smem[];
   const int TH = 2 * p.Hh - 1, TW = 2 * p.Ww - 1, TT = TH * TW, C = p.G * D;
@@ -140,11 +143,13 @@ __global__ __launch_bounds__((Split<NKF, false>::NT)) void fgattn_fwd_kernel(Arg
     f32x4 e2[2];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float x = __expf(v[e] - mn); e2[e >> 2][e & 3] = x; l += x; }
-    const typename Ch<T>::Frag pf = Ch<T>::from_acc(e2);
 #pragma unroll
-    for (int jd = 0; jd < 3; ++jd) {
-      o[jd] *= alpha;
-      o[jd] = Mma<T>::mma(Ch<T>::ldA_tr(Vt, LDK, 16 * jd, 32 * s, lane), pf, o[jd]);
+    for (int jd = 0; jd < 3; ++jd) o[jd] *= alpha;
+#pragma unroll
+    for (int hf = 0; hf < 2 / ND; ++hf) {            // one 32-deep k-step (16-bit) or two 16-deep ones (f32) over the 32 keys
+      const typename Ch<T>::Frag pf = Ch<T>::from_acc(&e2[hf * ND]);
+#pragma unroll
+      for (int jd = 0; jd < 3; ++jd) o[jd] = Mma<T>::mma(Ch<T>::ldA_tr(Vt, LDK, 16 * jd, 32 * s + 16 * hf, lane), pf, o[jd]);
     }
   }
   l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
@@ -187,11 +192,12 @@ __global__ __launch_bounds__((Split<NKF, false>::NT)) void fgattn_fwd_kernel(Arg
 // =====================================================================================================================
 // Backward: P = exp(logit - lse) from the forward's log-sum-exp, the softmax's row term sum_k P dP = dO . O from the forward output.
 template <typename T, int NKF>
-__global__ __launch_bounds__((Split<NKF, true>::NT)) void fgattn_bwd_kernel(Args p) {
-  typedef Split<NKF, true> W;
+__global__ __launch_bounds__((Split<NKF, true, T>::NT)) void fgattn_bwd_kernel(Args p) {
+  typedef Split<NKF, true, T> W;
   constexpr int HW = 16 * NKF, LDP = HW + 8, Ww = NKF == 4 ? 8 : 16, NT = W::NT, QG = W::QG, KS = W::KS, TQ = W::TQ;
+  constexpr int ND = Ch<T>::ND, KSTEP = Mma<T>::KSTEP;
   constexpr int MW = NKF / (QG * KS);          // 16-key fragments each wave owns for dK / dV
-  static_assert(MW >= 1 && TQ == 64, "the dK / dV contraction runs over 64 queries");
+  static_assert(MW >= 1 && MW * QG * KS == NKF && TQ % KSTEP == 0, "the dK / dV contraction runs over the workgroup's queries, every key owned once");
   extern __shared__ __attribute__((aligned(16))) unsigned char fg_smem[];
   const int TH = 2 * p.Hh - 1, TW = 2 * p.Ww - 1, TT = TH * TW, C = p.G * D;
   T* Kt = reinterpret_cast<T*>(fg_smem);
@@ -298,9 +304,12 @@ __global__ __launch_bounds__((Split<NKF, true>::NT)) void fgattn_bwd_kernel(Args
     st4(prow + 32 * s, pv); st4(prow + 32 * s + 16, pv + 4);
     { const float x0[4] = {ds2[0][0], ds2[0][1], ds2[0][2], ds2[0][3]}, x1[4] = {ds2[1][0], ds2[1][1], ds2[1][2], ds2[1][3]};
       st4(srow + 32 * s, x0); st4(srow + 32 * s + 16, x1); }
-    const typename Ch<T>::Frag sf = Ch<T>::from_acc(ds2);            // dq^T += K^T dS^T (dS carries the 48^-1/2)
 #pragma unroll
-    for (int jd = 0; jd < 3; ++jd) dq[jd] = Mma<T>::mma(Ch<T>::ldA_tr(Kt, LDK, 16 * jd, 32 * s, lane), sf, dq[jd]);
+    for (int hf = 0; hf < 2 / ND; ++hf) {
+      const typename Ch<T>::Frag sf = Ch<T>::from_acc(&ds2[hf * ND]);            // dq^T += K^T dS^T (dS carries the 48^-1/2)
+#pragma unroll
+      for (int jd = 0; jd < 3; ++jd) dq[jd] = Mma<T>::mma(Ch<T>::ldA_tr(Kt, LDK, 16 * jd, 32 * s + 16 * hf, lane), sf, dq[jd]);
+    }
   }
   __syncthreads();
   float* mb = reinterpret_cast<float*>(fg_smem);                       // dq of the key slices [KS][QG][12][64], over the K / V tiles
@@ -318,14 +327,14 @@ __global__ __launch_bounds__((Split<NKF, true>::NT)) void fgattn_bwd_kernel(Args
 #pragma unroll
       for (int jd = 0; jd < 3; ++jd) { dv[m][jd] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[m][jd] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int s = 0; s < TQ / 32; ++s) {
+    for (int s = 0; s < TQ / KSTEP; ++s) {
       typename Mma<T>::Frag bo[3], bq[3];
 #pragma unroll
-      for (int jd = 0; jd < 3; ++jd) { bo[jd] = Mma<T>::load_tr(OT, LDT, 16 * jd, 32 * s, lane); bq[jd] = Mma<T>::load_tr(QT, LDT, 16 * jd, 32 * s, lane); }
+      for (int jd = 0; jd < 3; ++jd) { bo[jd] = Mma<T>::load_tr(OT, LDT, 16 * jd, KSTEP * s, lane); bq[jd] = Mma<T>::load_tr(QT, LDT, 16 * jd, KSTEP * s, lane); }
 #pragma unroll
       for (int m = 0; m < MW; ++m) {
-        const typename Mma<T>::Frag ap = Mma<T>::load_tr(PT, LDP, 16 * (MW * wv + m), 32 * s, lane);
-        const typename Mma<T>::Frag as = Mma<T>::load_tr(ST, LDP, 16 * (MW * wv + m), 32 * s, lane);
+        const typename Mma<T>::Frag ap = Mma<T>::load_tr(PT, LDP, 16 * (MW * wv + m), KSTEP * s, lane);
+        const typename Mma<T>::Frag as = Mma<T>::load_tr(ST, LDP, 16 * (MW * wv + m), KSTEP * s, lane);
 #pragma unroll
         for (int jd = 0; jd < 3; ++jd) { dv[m][jd] = Mma<T>::mma(ap, bo[jd], dv[m][jd]); dk[m][jd] = Mma<T>::mma(as, bq[jd], dk[m][jd]); }
       }
@@ -398,8 +407,8 @@ template <typename T, int NKF> static int launch(bool bwd, const Args& a, hipStr
     }
     reserved[bwd] = lds;
   }
-  if (bwd) hipLaunchKernelGGL((fgattn_bwd_kernel<T, NKF>), dim3((unsigned)(a.B * a.G * (16 * NKF / Split<NKF, true>::TQ))), dim3(Split<NKF, true>::NT), lds, st, a);
-  else hipLaunchKernelGGL((fgattn_fwd_kernel<T, NKF>), dim3((unsigned)(a.B * a.G * (16 * NKF / Split<NKF, false>::TQ))), dim3(Split<NKF, false>::NT), lds, st, a);
+  if (bwd) hipLaunchKernelGGL((fgattn_bwd_kernel<T, NKF>), dim3((unsigned)(a.B * a.G * (16 * NKF / Split<NKF, true, T>::TQ))), dim3(Split<NKF, true, T>::NT), lds, st, a);
+  else hipLaunchKernelGGL((fgattn_fwd_kernel<T, NKF>), dim3((unsigned)(a.B * a.G * (16 * NKF / Split<NKF, false, T>::TQ))), dim3(Split<NKF, false, T>::NT), lds, st, a);
   return stj_check_launch(bwd ? "stj_fg_attn_bwd" : "stj_fg_attn_fwd");
 }
 template <typename T> static int dispatch(bool bwd, const Args& a, hipStream_t st) {
@@ -410,7 +419,7 @@ template <typename T> static int dispatch(bool bwd, const Args& a, hipStream_t s
 }
 static int check(int B, int G, int Hh, int Ww, int dtype) {
   if (B <= 0) return 1;
-  if (!stj_is16(dtype)) { stj_set_error("fg_attn: 16-bit storage types only (f32 keeps the layer-by-layer kernels)"); return STJ_EUNSUPPORTED; }
+  if (!stj_dtype_ok(dtype)) { stj_set_error("fg_attn: bad dtype %d", dtype); return STJ_EINVAL; }
   if (G <= 0 || Hh <= 0 || Ww <= 0) { stj_set_error("fg_attn: bad geometry"); return STJ_EINVAL; }
   return 0;
 }
@@ -424,12 +433,12 @@ extern "C" int stj_fg_attn_fwd(const void* q, const void* k, const void* v, cons
   if (c) return c > 0 ? STJ_OK : c;
   fga::Args p = {};
   p.q = q; p.k = k; p.v = v; p.off = off; p.table = table; p.a = a; p.lse = lse; p.B = B; p.G = G; p.Hh = Hh; p.Ww = Ww; p.scale = scale;
-  return dtype == STJ_BF16 ? fga::dispatch<bf16>(false, p, stream) : fga::dispatch<f16>(false, p, stream);
+  return dtype == STJ_BF16 ? fga::dispatch<bf16>(false, p, stream) : (dtype == STJ_F16 ? fga::dispatch<f16>(false, p, stream) : fga::dispatch<float>(false, p, stream));
 }
 // bytes of each of the two partial-sum workspaces (dkp, dvp) of stj_fg_attn_bwd
 extern "C" long long stj_fg_attn_bwd_workspace_bytes(int B, int G, int Hh, int Ww) {
   const long long HW = (long long)Hh * Ww;
-  return (long long)B * G * (HW / fga::TOK) * HW * fga::D * 4;
+  return (long long)B * G * (HW / 16) * HW * fga::D * 4;         // sized for the smallest query tile any dtype uses (f32 on the 16 x 16 map: 16)
 }
 // Backward: a, lse as the forward wrote them, da [B,HW,G*48] -> dq, dk, dv (same shape, written; dk / dv via the f32 per-tile partials
 // dkp / dvp and a second launch), dtable f32 [2Hh-1,2Ww-1,G] "+=", doff f32 [B,G,HW,2]: written when Hh = 8, "+=" (caller zeroes it)
@@ -443,12 +452,15 @@ extern "C" int stj_fg_attn_bwd(const void* q, const void* k, const void* v, cons
   p.q = q; p.k = k; p.v = v; p.off = off; p.table = table; p.a = const_cast<void*>(a); p.lse = const_cast<float*>(lse); p.da = da; p.dq = dq;
   p.dkp = dkp; p.dvp = dvp; p.dtable = dtable; p.doff = doff;
   p.B = B; p.G = G; p.Hh = Hh; p.Ww = Ww; p.scale = scale;
-  int rc = dtype == STJ_BF16 ? fga::dispatch<bf16>(true, p, stream) : fga::dispatch<f16>(true, p, stream);
+  int rc = dtype == STJ_BF16 ? fga::dispatch<bf16>(true, p, stream) : (dtype == STJ_F16 ? fga::dispatch<f16>(true, p, stream) : fga::dispatch<float>(true, p, stream));
   if (rc != STJ_OK) return rc;
-  const int HW = Hh * Ww, tiles = HW / fga::TOK;
+  const int HW = Hh * Ww;
+  const int tq = Hh == 16 ? (dtype == STJ_F32 ? fga::Split<16, true, float>::TQ : fga::Split<16, true, bf16>::TQ) : fga::Split<4, true, bf16>::TQ;
+  const int tiles = HW / tq;
   const long long n = 2ll * B * HW * G * fga::D;
   const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
   if (dtype == STJ_BF16) hipLaunchKernelGGL(fga::fgattn_dkv_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, stream, dkp, dvp, (bf16*)dk, (bf16*)dv, B, G, HW, tiles);
-  else hipLaunchKernelGGL(fga::fgattn_dkv_reduce_kernel<f16>, dim3(grid), dim3(256), 0, stream, dkp, dvp, (f16*)dk, (f16*)dv, B, G, HW, tiles);
+  else if (dtype == STJ_F16) hipLaunchKernelGGL(fga::fgattn_dkv_reduce_kernel<f16>, dim3(grid), dim3(256), 0, stream, dkp, dvp, (f16*)dk, (f16*)dv, B, G, HW, tiles);
+  else hipLaunchKernelGGL(fga::fgattn_dkv_reduce_kernel<float>, dim3(grid), dim3(256), 0, stream, dkp, dvp, (float*)dk, (float*)dv, B, G, HW, tiles);
   return stj_check_launch("stj_fg_attn_dkv_reduce");
 }

@@ -9,6 +9,7 @@ The Dropout / DropPath stream advances inside the graph (stj_rng_advance bumps a
 """
 import torch
 
+from . import ops
 from .loss import get_pred_waypoint_logits, warpped_gt
 
 
@@ -27,7 +28,7 @@ class GraphedTrainStep:
         self._one = None
         if split:
             model.cut_encoder = True
-        side = torch.cuda.Stream()
+        side = ops.role_stream(torch.cuda.current_device(), 'warmup')
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
@@ -55,7 +56,7 @@ class GraphedTrainStep:
         main = torch.cuda.current_stream()
         if hasattr(self.loss_fn, 'prepare'):         # the ground-truth-only part of the loss: side stream, under the forward pass --
             if self._side is None:                   # issued from the model's mid-forward hook (behind the encoder's first stage: at the
-                self._side = torch.cuda.Stream()     # head of the step its two launches delayed the first encoder kernel)
+                self._side = ops.role_stream(torch.cuda.current_device(), 'loss_prep')     # head of the step its two launches delayed the first encoder kernel)
 
             def prepare():
                 self._side.wait_stream(torch.cuda.current_stream())
@@ -98,10 +99,10 @@ class GraphedForward:
     __call__(batch) copies the batch into the static inputs, replays, and returns the static [B,Hg,Hg,32] f32 output.
 
     pipeline_agents=True: the agent branch (trajNet: ~30 dependent launches of a few microseconds that a replayed graph starts only when
-    the raster encoder is through -- 0.3 of the 6.3 ms B = 32 step with nothing beside them, profiles/r05_c_timeline_infer_b32_f16.txt) is a
-    graph of its OWN on a second stream.  prefetch_agents(next_batch), called right after __call__(batch), runs it for the NEXT batch under
+    the raster encoder is through -- 0.3 of the 6.3 ms B = 32 step with nothing beside them, profiles/r05_c_timeline_infer_b32_f16.txt) is
+    taken OUT of the graph and launched on a second stream.  prefetch_agents(next_batch), called right after __call__(batch), runs it for the NEXT batch under
     this batch's raster path; __call__ then waits for it, copies its two small results into the main graph's static inputs and replays the
-    main graph, which no longer contains the branch.  Without a prefetch the agent graph runs in front of the main one (same result).
+    main graph, which no longer contains the branch.  Without a prefetch the agent branch runs in front of the main graph (same result).
     (Also tried: a replay that does not re-cast / re-pack / re-fold the constant weights -- one cast + seven side-stream launches less per step --
     measured 1.3 % SLOWER in three same-box pairs, 5333 / 5118 / 5333 vs 5390 / 5206 / 5412 scenes/s: where those launches sit decides when the
     executor starts the other branches, DESIGN 4e.  Not kept.)"""
@@ -111,7 +112,7 @@ class GraphedForward:
         self.static = {k: v.clone() for k, v in batch.items() if k in ('ogm', 'map_img', 'obs', 'occ', 'flow')}
         self.pipeline_agents = pipeline_agents
         self._prefetched = False
-        side = torch.cuda.Stream()
+        side = ops.role_stream(torch.cuda.current_device(), 'warmup')
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):
@@ -119,10 +120,14 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if pipeline_agents:
-            self.agent_stream = torch.cuda.Stream()
+            # the model's own agent-branch stream (idle in a main graph captured without the branch).  NOT one more stream: with a sixth
+            # side stream alive in the process a LATER, unrelated graph replay died in hip::Graph::UpdateStreams (ROCm 7.2; tests/test_model_gpu.py
+            # run as a whole: bisected to the number of distinct streams in use -- see ops.role_stream)
+            self.agent_stream = model._streams[0] if model._streams[0] is not None else ops.role_stream(torch.cuda.current_device(), 'side')
             self.agent_done, self.agent_free = torch.cuda.Event(), torch.cuda.Event()
-            self.agent_graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.agent_graph, capture_error_mode='thread_local'):
+            # (the branch is launched EAGERLY, ~30 small launches issued by the host while the GPU replays the main graph; as a hipGraph of its
+            #  own it ran as fast)
+            with torch.no_grad():
                 self.agent_next = model.agent_encode(self.static['obs'], self.static['occ'])
             self.agent_cur = tuple(t.clone() for t in self.agent_next)
             torch.cuda.synchronize()
@@ -141,7 +146,7 @@ class GraphedForward:
         return self.model(x['ogm'], x['map_img'], training=False, obs=x['obs'], occ=x['occ'], mapt=None, flow=x['flow'])
 
     def prefetch_agents(self, batch=None):
-        """Start the agent graph for the NEXT batch (None: the static inputs as they are) on the agent stream, under whatever the main
+        """Start the agent branch of the NEXT batch (None: the static inputs as they are) on the agent stream, under whatever the main
         stream is running."""
         if not self.pipeline_agents:
             return
@@ -152,7 +157,8 @@ class GraphedForward:
                 for k in ('obs', 'occ'):
                     if k in batch:
                         self.static[k].copy_(batch[k], non_blocking=True)
-            self.agent_graph.replay()
+            with torch.no_grad():
+                self.agent_next = self.model.agent_encode(self.static['obs'], self.static['occ'])
             self.agent_done.record(st)
         self._prefetched = True
 

@@ -228,8 +228,8 @@ class STrajNet:
         self._arena = ops._ZeroArena()    # this model's zeroed scratch (one fill per step)
         self._arena.adopt(self._gbuf[self._goff8:])
         self._dctx = None
-        self._side = torch.cuda.Stream(self.device) if (self.device.type == 'cuda' and os.environ.get('STJ_NO_SIDE_STREAM') != '1') else None
-        self._side2 = torch.cuda.Stream(self.device) if (self._side is not None and os.environ.get('STJ_NO_SIDE_STREAM') != '2') else None
+        self._side = ops.role_stream(self.device, 'side') if (self.device.type == 'cuda' and os.environ.get('STJ_NO_SIDE_STREAM') != '1') else None
+        self._side2 = ops.role_stream(self.device, 'side2') if (self._side is not None and os.environ.get('STJ_NO_SIDE_STREAM') != '2') else None
         self._streams = (self._side, self._side2)
         self.serial = False              # True: everything on the current stream (per-kernel timing, debugging)
         self.taps = None                 # a dict: call() stores detached float copies of the stage boundaries in it (tools/bf16_attribution.py)
@@ -248,7 +248,7 @@ class STrajNet:
         self.agent_issue_mode = 2
         self.agent_override = None            # (key, mask) from agent_encode(): call() then skips the agent branch
         self.mid_forward_hook = None          # callable run once per forward pass behind the encoder's first stage (GraphedTrainStep: loss.prepare on its side stream)
-        self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (16-bit modes, 8 x 8 / 16 x 16 maps)
+        self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (8 x 8 / 16 x 16 maps; all three storage types)
         self._xattn_pack = None
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():

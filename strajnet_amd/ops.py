@@ -148,6 +148,7 @@ class _ZeroArena:
 
     def __init__(self):
         self.buf, self.off, self.armed = None, 0, False
+        self.split_ws = {}        # the owner's Swin split workspaces (_swin_ws)
 
     def _here(self, device):
         d = torch.device(device)
@@ -207,6 +208,24 @@ def zeros_f32(shape, device):
 # (dY is complete) and is joined ONCE, when the autograd engine finishes the backward pass (queue_callback).  Operands stay
 # referenced until the join, so the caching allocator cannot hand their memory to later kernels of the main stream.
 # ----------------------------------------------------------------------------------------------------
+_ROLE_STREAMS = {}
+
+
+def role_stream(device, role):
+    """ONE stream per (device, role) for the whole process.  torch hands out side streams from a round-robin pool of 32 per device: a
+    process that builds many models / captured steps (the GPU test suite: a model per test) wraps the pool, and a new model's side stream
+    is then the SAME stream as some long-lived one (the capture stream, the weight-gradient stream).  And the number of DISTINCT streams a
+    process uses matters on ROCm 7.2: with one more side stream alive (a sixth: the inference agent pipeline's own, round 5) a later,
+    unrelated hipGraph replay died in hip::Graph::UpdateStreams (tests/test_model_gpu.py run as a whole; gone when that work moved onto an
+    existing stream).  Models on one device share their side streams: at worst a false dependency between two models."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _ROLE_STREAMS.get((idx, role))
+    if st is None:
+        st = _ROLE_STREAMS[(idx, role)] = torch.cuda.Stream(torch.device('cuda', idx))
+    return st
+
+
 _WG = {}
 # bit 0: dense layers, bit 1: up-convs.  Measured (B=8): up-convs on the side stream +1 %; dense layers -9 % (their 768-block
 # split-K kernels crowd the data-gradient chain out of the CUs), so only the up-convs use it by default.
@@ -254,7 +273,7 @@ def wgrad_stream(kind, *operands):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _WG.get(key)
     if st is None:
-        st = _WG[key] = {'side': torch.cuda.Stream(dev), 'keep': [], 'armed': False, 'main': None}
+        st = _WG[key] = {'side': role_stream(dev, 'wgrad'), 'keep': [], 'armed': False, 'main': None}
     main = torch.cuda.current_stream(dev)
     st['side'].wait_stream(main)
     st['keep'].extend(operands)
@@ -811,11 +830,11 @@ def _swin_ws(x, M, C):
     # graph's private pool by 25-100 MB per block.  Keyed by the model's arena, NOT by the stream: the capture stream of a hipGraph is not
     # the stream of the warm-up steps, and a first use inside the capture put the zero fill (49 + 9 us, in front of stages 1 and 2) into
     # every replay (profiles/r05_b_timeline_concurrent.txt)
-    key = (str(x.device), 'swin_split', int(M), int(C), id(_ARENA))
-    ws = _WS.get(key)
+    key = (str(x.device), int(M), int(C))
+    ws = _ARENA.split_ws.get(key)        # (owned by the arena = by the model: freed with it, never handed to another model)
     if ws is None:
         # zeroed ONCE: it starts with the arrival counters of the kernels whose slices meet inside the launch (they re-arm themselves)
-        ws = _WS[key] = torch.zeros(nbytes // 4, dtype=torch.float32, device=x.device)
+        ws = _ARENA.split_ws[key] = torch.zeros(nbytes // 4, dtype=torch.float32, device=x.device)
     return ws
 
 
@@ -1183,7 +1202,7 @@ def mha_core(q, k, v, H, d, scale, qvalid=None, kvalid=None, bias=None, drop=Non
 
 
 # ----------------------------------------------------------------------------------------------------
-# fused FG-MSA attention core (csrc/fgattn.hip): one kernel per direction, 16-bit storage types
+# fused FG-MSA attention core (csrc/fgattn.hip): one kernel per direction
 # ----------------------------------------------------------------------------------------------------
 class _FgAttn(torch.autograd.Function):
     """a = softmax(scale q k^T + bias(off, table)) v (FG_MSA.py:150-176) for q, k, v [B,HW,G*48], off [B,G,HW,2], table Param
@@ -1220,8 +1239,9 @@ class _FgAttn(torch.autograd.Function):
 
 
 def fg_attn_ok(dtype, Hh, Ww, gc):
-    """The geometries the fused FG-MSA kernel covers: 16-bit activations, 48-wide groups, an 8 x 8 or 16 x 16 map."""
-    return dtype != torch.float32 and gc == 48 and Hh == Ww and Hh in (8, 16)
+    """The geometries the fused FG-MSA kernel covers: 48-wide groups, an 8 x 8 or 16 x 16 map (every storage type: the f32 parity mode
+    runs the same kernel template with exact-f32 MFMA)."""
+    return gc == 48 and Hh == Ww and Hh in (8, 16)
 
 
 def fg_attn(q, k, v, off, pt, Hh, Ww, scale):

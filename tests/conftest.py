@@ -22,3 +22,20 @@ def lib_built():
     """Make sure the in-tree HIP library exists (cross-compiles without a GPU)."""
     from strajnet_amd import build
     return build.build(verbose=False)
+
+
+@pytest.fixture(autouse=True)
+def _release_device_objects():
+    """After every test: collect garbage and drain the GPU, so that captured hipGraphs (each holds internal streams of its own) and their
+    memory pools are destroyed where the test ends, not whenever Python's cycle collector gets to them -- with dozens of dead graphs still
+    alive in one process a LATER graph replay died inside hip::Graph::UpdateStreams (ROCm 7.2)."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+

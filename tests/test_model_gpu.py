@@ -269,10 +269,10 @@ def test_config4_inference_graph_b32(dtype):
     big2 = {k: torch.roll(v, 1, 0) for k, v in big.items()}
     out2 = gf(big2)
     assert torch.equal(out2, torch.roll(eager, 1, 0))
-    # the agent branch as a graph of its own, a batch ahead (GraphedForward(pipeline_agents=True)): same bits, with and without a prefetch,
+    # the agent branch out of the graph, a batch ahead (GraphedForward(pipeline_agents=True)): same bits, with and without a prefetch,
     # over a sequence of different batches
     gp = GraphedForward(model, big, pipeline_agents=True)
-    assert torch.equal(gp().clone(), eager)                     # no prefetch: the agent graph runs in front
+    assert torch.equal(gp().clone(), eager)                     # no prefetch: the agent branch runs in front
     seq = [big2, big, {k: torch.roll(v, 3, 0) for k, v in big.items()}, big2]
     exp = [torch.roll(eager, 1, 0), eager, torch.roll(eager, 3, 0), torch.roll(eager, 1, 0)]
     gp.prefetch_agents(seq[0])
@@ -282,6 +282,10 @@ def test_config4_inference_graph_b32(dtype):
             gp.prefetch_agents(seq[i + 1])                      # overlaps this batch's main graph
         assert torch.equal(o.clone(), ex), i
     assert model.agent_override is None
+    del gp, gf
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 def test_config5_cfg512_deeper_stage_f32():
