@@ -964,7 +964,7 @@ static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
         }
       }
       if constexpr (sizeof(T) == 2) return mlp_launch<T, 192, 1, 0, 8, 2>(bwd, a, st);       // no workspace: one workgroup per row block, its two hidden groups meet in LDS
-      return mlp_launch<T, 192, 1>(bwd, a, st);
+      else return mlp_launch<T, 192, 1>(bwd, a, st);
     }
     case 384: {
       // (a one-workgroup-per-row-block form without the workspace existed: 32 workgroups at B = 8, never taken by ops.py, 0.2 MB of code)
@@ -1836,8 +1836,11 @@ static int attnb_split384(const AttnBArgs& a, hipStream_t st) {          // see 
     if (a.part == nullptr) { stj_set_error("swin_attn_bwd: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
     const long long N = (long long)a.res * a.res;
     const int split = attn_split_for(a.B * (N / 64));
-    if (split == 2 && a.B * (N / 64) <= FIX_CNT_BYTES / 4) return attnb_launch<T, 384, 2, 0, true>(a, st);
-    const int rc = split == 6 ? attnb_launch<T, 384, 6>(a, st) : attnb_launch<T, 384, 2>(a, st);
+    if (split == 2) {
+      if (a.B * (N / 64) > FIX_CNT_BYTES / 4) { stj_set_error("swin_attn_bwd: more than %d windows in one launch", FIX_CNT_BYTES / 4); return STJ_EUNSUPPORTED; }
+      return attnb_launch<T, 384, 2, 0, true>(a, st);
+    }
+    const int rc = attnb_launch<T, 384, 6>(a, st);
     if (rc != STJ_OK) return rc;
     return split_bwd_epi<T>(a.x, a.dy, a.part, split, a.gamma, 0.f, a.mean, a.rstd, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.B * N, st);
   } else {
