@@ -42,6 +42,23 @@ def rel_err(a, ref, rms_weight=None):
 
 _SEEN = []
 
+# Per-element bound for the GEMM-shaped ops (round 5; the timed kernels have theirs in test_timed_kernels_gpu.py): every product term
+# carries at most four storage roundings the float64 reference does not have (an operand the kernel folds or rounds -- folded conv
+# weights, dpre --, up to two intermediates -- the output heads' input gradient passes its phase partials through LDS in 16 bits --, the
+# stored result), so |got - ref| <= 4 * 2^-p * sum_k |a_k b_k| per element (bf16: 2^-7, the EPS_ACT of the timed tests), with the sum evaluated
+# in float64 on |operands|; f32 storage: exact products, float32 accumulation over K <= 3456 terms.  A dropped tap, a halo column read
+# twice or one tile's flush lost moves single elements by whole terms and fails here whatever the tensor maximum is.
+EPS_ELEM = {torch.float32: 2.0 ** -17, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}
+_ELEM = []
+
+
+def elem_check(name, got, ref, bound, dt):
+    got, ref, bound = got.detach().double().cpu(), ref.detach().double().cpu(), bound.detach().double().cpu().abs()
+    ratio = float(((got - ref).abs() / (bound + 1e-300)).max())
+    _ELEM.append((dt, name, ratio))
+    assert ratio <= EPS_ELEM[dt], f'{name}: max |err| / sum |terms| = {ratio:.3e} over the per-element bound {EPS_ELEM[dt]:.3e}'
+
+
 
 def mk_param(shape, dt, scale=0.1, seed=0):
     from strajnet_amd.ops import Param
@@ -101,6 +118,12 @@ def test_linear(dt, M, K, N, act, use_res):
     assert rel_err(pb.grad, br.grad) < tol(dt)
     if use_res:
         assert rel_err(res.grad, rr.grad) < tol(dt)
+    # per element, against sum |terms| (ELU: |ELU(a)| <= |a|, 1-Lipschitz, ELU' <= 1)
+    xa, wa, ga = xr.detach().abs(), wr.detach().abs(), g.double().cpu().abs()
+    elem_check('linear y', y, yr, xa @ wa + br.detach().abs() + (rr.detach().abs() if use_res else 0.0), dt)
+    elem_check('linear dx', x.grad, xr.grad, ga @ wa.t(), dt)
+    elem_check('linear dw', pw.grad, wr.grad, xa.t() @ ga, dt)
+    elem_check('linear db', pb.grad, br.grad, ga.sum(0), dt)
 
 
 @pytest.mark.parametrize('dt', DTYPES)
@@ -465,6 +488,14 @@ def test_upconv(dt, F_, Hi, Cin, Cout):
     assert rel_err(x.grad, xr.grad) < tol(dt)
     assert rel_err(pw.grad, wr.grad) < tol(dt)
     assert rel_err(pb.grad, br.grad) < tol(dt)
+    # per element: the same graph on |operands| without the ELU (|ELU(a)| <= |a|, ELU' <= 1) gives sum |terms| of all four results
+    xa, wa, ba = ref_of(x.detach().abs()), ref_of(pw.master.detach().abs()), ref_of(pb.master.detach().abs())
+    ya = F.conv2d(F.interpolate(xa.permute(0, 3, 1, 2), scale_factor=2, mode='nearest'), wa.permute(3, 2, 0, 1), ba, padding=1).permute(0, 2, 3, 1)
+    ya.backward(g.double().cpu().abs())
+    elem_check('upconv y', y, yr, ya, dt)
+    elem_check('upconv dx', x.grad, xr.grad, xa.grad, dt)
+    elem_check('upconv dw', pw.grad, wr.grad, wa.grad, dt)
+    elem_check('upconv db', pb.grad, br.grad, ba.grad, dt)
 
 
 @pytest.mark.parametrize('dt', DTYPES)
@@ -490,6 +521,15 @@ def test_outconv_pair(dt):
     assert rel_err(xf.grad, xfr.grad) < tol(dt)
     for p, r in zip(ps, refs):
         assert rel_err(p.grad, r.grad) < tol(dt)
+    refa = [ref_of(p.master.detach().abs()) for p in ps]
+    xoa, xfa = ref_of(xo.detach().abs()), ref_of(xf.detach().abs())
+    ya = torch.cat([cv(xoa, refa[0], refa[1]), cv(xfa, refa[2], refa[3])], -1).view(B, Tn, H, H, 4).permute(0, 2, 3, 1, 4).reshape(B, H, H, 4 * Tn)
+    ya.backward(g.double().abs())
+    elem_check('outconv y', out, outr, ya, dt)
+    elem_check('outconv dxo', xo.grad, xor_.grad, xoa.grad, dt)
+    elem_check('outconv dxf', xf.grad, xfr.grad, xfa.grad, dt)
+    for i, (p, r, ra) in enumerate(zip(ps, refs, refa)):
+        elem_check(f'outconv dparam{i}', p.grad, r.grad, ra.grad, dt)
 
 
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
@@ -593,6 +633,13 @@ def test_grouped_conv3(dt):
     assert rel_err(x.grad, xr.grad) < tol(dt)
     assert rel_err(pw.grad, wr.grad) < tol(dt)
     assert rel_err(pb.grad, br.grad) < tol(dt)
+    xa, wa, ba = ref_of(x.detach().abs()), ref_of(pw.c.detach().abs()), ref_of(pb.master.detach().abs())
+    ya = F.conv2d(xa.permute(0, 3, 1, 2), wa.permute(3, 2, 0, 1), ba, padding=1, groups=G).permute(0, 2, 3, 1)
+    ya.backward(g.double().cpu().abs())
+    elem_check('grouped conv y', y, yr, ya, dt)
+    elem_check('grouped conv dx', x.grad, xr.grad, xa.grad, dt)
+    elem_check('grouped conv dw', pw.grad, wr.grad, wa.grad, dt)
+    elem_check('grouped conv db', pb.grad, br.grad, ba.grad, dt)
 
 
 @pytest.mark.parametrize('dt', DTYPES)
@@ -1081,3 +1128,8 @@ def test_zz_report_error_ratios():
     """(runs last in this file) the largest max-norm and rms error ratios any comparison above produced, for the record in DESIGN 2a"""
     if _SEEN:
         print(f'\nop-level comparisons: {len(_SEEN)}; largest max-norm ratio {max(e for e, _ in _SEEN):.3e}, largest rms ratio {max(r for _, r in _SEEN):.3e}')
+    for dt in DTYPES:
+        rs = [(r, n) for d, n, r in _ELEM if d == dt]
+        if rs:
+            r, n = max(rs)
+            print(f'per-element checks {str(dt):16s}: {len(rs)}; largest |err| / sum |terms| {r:.3e} ({n}), bound {EPS_ELEM[dt]:.3e}')
