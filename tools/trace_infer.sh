@@ -9,3 +9,4 @@ rocprofv3 --kernel-trace --output-format rocpd -d /tmp/prof_inf -- python bench.
 db=$(find /tmp/prof_inf -name '*.db' | head -1)
 python tools/rocpd_summary.py "$db" 9 > gpurun_out/${tag}_kernel_trace_infer_b32_f16.txt
 head -32 gpurun_out/${tag}_kernel_trace_infer_b32_f16.txt | cut -c1-160
+python tools/timeline.py "$db" 2 outconv_pair_gather > gpurun_out/${tag}_timeline_infer_b32_f16.txt 2>/dev/null
