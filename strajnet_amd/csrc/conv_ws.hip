@@ -953,7 +953,9 @@ static bool wgrad_tr_launch(const void* X, const void* dP, float* dWeff, float* 
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     // workgroups (swept again in round 5, after the accumulation buffers' alignment fix: 256 / 512 / 768 / 1536 / 2048 = 209 / 110 / 123 / 124 /
     // 136 us for 384 -> 192 and 152 / 137 / 112 / 130 / 139 for 192 -> 128, against 111 / 113 for 1024; full-cout x 64-cin tiles (<6,4> / <8,4>:
-    // 20 / 183 spilled registers at two workgroups per CU) 132-157 / 248-290 us)
+    // 20 / 183 spilled registers at two workgroups per CU) 132-157 / 248-290 us).  Inside the step (same-box A/B, two boxes): 512 workgroups for
+    // 384 -> 192 gave 1351-1353 vs 1330-1338 scenes/s on one box and 1332-1337 vs 1343-1348 on the other; 384 / 448 / 576 and 896 / 1280 / 1536
+    // for 192 -> 128 inside the noise or below: 1024 stays)
     const int tgt = 1024;
     int strips = (int)min(nchunks, (long long)max(1, tgt / (4 * tiles)));
     const int cpb = (int)((nchunks + strips - 1) / strips);
