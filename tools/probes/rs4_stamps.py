@@ -24,4 +24,4 @@ for _ in range(10):
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 100
 tot = np.median(t[:, :4].sum(1))
-print('kernel %.1f us; loop ticks per workgroup %.0f  ->  >= %.2f GHz if s_memtime counts shader cycles (the flush is outside the stamps)' % (us, tot, tot / us / 1e3))
+print('kernel %.1f us; loop ticks per workgroup %.0f  ->  %.2f ticks per ns (s_memtime is NOT a cycle counter: tools/probes/clock_probe.hip)' % (us, tot, tot / us / 1e3))
