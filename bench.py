@@ -33,6 +33,7 @@ ALGO_GFLOP_STEP_PER_SCENE_512 = 3 * 240.9   # cfg-512 with depths [2,2,6] (SURVE
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0                # HBM3E (MI355X_MICROARCH.md)
+MFMA_LOOP_RATE_TFLOPS = 1950.0        # what a bare 16x16x32 bf16 MFMA loop sustains, 8 waves per CU (tools/probes/clock_probe.hip): informational
 HBM_STREAM_CEILING_GBPS = 6750.0      # what a pure read stream reaches with every CU streaming (tools/probes/dma_lgkm_probe.hip): informational
 
 CFG256 = dict(input_size=(256, 256), window_size=8, embed_dim=96, depths=[2, 2, 2], num_heads=[3, 6, 12])
@@ -123,6 +124,7 @@ def build_roofline(prof_ser, prof_conc, nprof, value, B, world, algo_gflop_per_s
             'hbm_frac_pmc': round(traffic / t_s / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None,
             # (informational: the same two ratios against the read-stream rate measured on this part, not against the 8 TB/s peak `frac` uses)
             'hbm_frac_of_measured_stream_ceiling': round(gbps / HBM_STREAM_CEILING_GBPS, 4),
+            'mfma_frac_executed_of_measured_loop_rate': round(tf_exec / MFMA_LOOP_RATE_TFLOPS, 4) if peak >= 2000 else None,
             'hbm_frac_pmc_of_measured_stream_ceiling': round(traffic / t_s / 1e9 / HBM_STREAM_CEILING_GBPS, 4) if traffic else None,
             'executed_flop_per_byte': round(ai_exec, 1), 'machine_balance_flop_per_byte': round(balance, 1),
             'avg_launch_ms': round(d['avg_ms'], 4), 'launches_per_step': round(d['launches'], 1),
