@@ -738,18 +738,11 @@ class STrajNet:
             def last(t, n1, n0, head):
                 t = up(t, n1)
                 return ops.upconv_head(t, self._p(n0 + '/kernel'), self._p(n0 + '/bias'), self._p(head), prep=self._upconv_prep.get(n0))
-            if self._side2 is not None:
-                main = torch.cuda.current_stream(self.device)
-                self._side2.wait_stream(main)
-                fx.record_stream(self._side2)
-                with torch.cuda.stream(self._side2):
-                    zf = last(fx, 'decoder/upconvf_1_0', 'decoder/upconvf_0_0', oc[2])
-                zo = last(x, 'decoder/upconv_1_0', 'decoder/upconv_0_0', oc[0])
-                main.wait_stream(self._side2)
-                zf.record_stream(main)
-            else:
-                zo = last(x, 'decoder/upconv_1_0', 'decoder/upconv_0_0', oc[0])
-                zf = last(fx, 'decoder/upconvf_1_0', 'decoder/upconvf_0_0', oc[2])
+            # both branches on ONE stream: their persistent one-workgroup-per-CU kernels time-slice the CUs anyway, and the two cross-stream
+            # joins of the two-stream form cost more than its overlap gave (B = 32 fp16, alternating same-box runs in both orders:
+            # 5555 / 5539 / 5341 / 5422 vs 5482 / 5317 / 5320 / 5337 and 5338 / 5452 / 5459 vs 5274 / 5378 / 5444 scenes/s)
+            zo = last(x, 'decoder/upconv_1_0', 'decoder/upconv_0_0', oc[0])
+            zf = last(fx, 'decoder/upconvf_1_0', 'decoder/upconvf_0_0', oc[2])
             return ops.heads_gather(zo, zf, self._p(oc[1]), self._p(oc[3]), B, 8, t_major=True)
         # the last two levels of each branch have a single consumer, whose backward folds ELU' into the gradient it returns
         if self._side2 is not None:      # the observed-occupancy and flow branches of the last two levels are independent
