@@ -807,9 +807,10 @@ def _strajnet_forward(p, cfg, ogm, map_img, obs, occ, flow, fg_msa, fg, large_og
 # --------------------------------------------------------------------------- #
 # loss + AUC
 # --------------------------------------------------------------------------- #
-def keras_auc_pr(y_true, y_pred, num_thresholds=100):
-    """tf.keras.metrics.AUC(num_thresholds=100, curve='PR', summation_method='interpolation')
-    (App. C-7; call sites loss.py:41,134-136, occu_metric.py:165-174).  float32 thresholds."""
+def keras_auc_counts(y_true, y_pred, num_thresholds):
+    """The confusion counts Keras' AUC accumulates: thresholds [0 - 1e-7, i / (n - 1) ..., 1 + 1e-7] (float32), prediction > threshold
+    = positive.  -> (thresholds, tp, fp, fn).  Pinned by the published worked example of the tf.keras.metrics.AUC docstring
+    (tests/test_oracle_kat.py::test_published_vectors)."""
     eps = 1e-7
     thr = np.array([0.0 - eps] + [(i + 1) * 1.0 / (num_thresholds - 1) for i in range(num_thresholds - 2)] + [1.0 + eps],
                    np.float32)
@@ -819,6 +820,13 @@ def keras_auc_pr(y_true, y_pred, num_thresholds=100):
     tp = (pos & yt[None]).sum(1).astype(F64)
     fp = (pos & ~yt[None]).sum(1).astype(F64)
     fn = ((~pos) & yt[None]).sum(1).astype(F64)
+    return thr, tp, fp, fn
+
+
+def keras_auc_pr(y_true, y_pred, num_thresholds=100):
+    """tf.keras.metrics.AUC(num_thresholds=100, curve='PR', summation_method='interpolation')
+    (App. C-7; call sites loss.py:41,134-136, occu_metric.py:165-174).  float32 thresholds."""
+    thr, tp, fp, fn = keras_auc_counts(y_true, y_pred, num_thresholds)
 
     def dnn(a, b):
         return np.where(b != 0, a / np.where(b != 0, b, 1), 0.0)

@@ -112,6 +112,8 @@ class GraphedForward:
         self.static = {k: v.clone() for k, v in batch.items() if k in ('ogm', 'map_img', 'obs', 'occ', 'flow')}
         self.pipeline_agents = pipeline_agents
         self._prefetched = False
+        self._staged = None
+        self._weights_seen = -1
         side = ops.role_stream(torch.cuda.current_device(), 'warmup')
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -145,26 +147,47 @@ class GraphedForward:
         x = self.static
         return self.model(x['ogm'], x['map_img'], training=False, obs=x['obs'], occ=x['occ'], mapt=None, flow=x['flow'])
 
-    def prefetch_agents(self, batch=None):
+    def prefetch_agents(self, batch=None, ready=None):
         """Start the agent branch of the NEXT batch (None: the static inputs as they are) on the agent stream, under whatever the main
-        stream is running."""
+        stream is running.  `ready`: an event recorded behind whatever produced batch['obs'] / batch['occ'] (e.g. their host-to-device
+        copies on a feed stream); the agent stream waits for it.  Without one the agent stream is ordered behind everything the CALLER's
+        current stream has been given so far -- always safe, but when that stream is the one replaying the main graph the branch then runs
+        after the replay instead of under it: prefer `__call__(batch, next_batch=...)`, which stages the tracks in front of the replay."""
         if not self.pipeline_agents:
             return
         st = self.agent_stream
         st.wait_event(self.agent_free)               # the previous results have been copied out
+        if batch is not None:
+            if ready is not None:
+                st.wait_event(ready)
+            else:
+                st.wait_stream(torch.cuda.current_stream())
+        if self._staged is not None:                 # tracks staged on the main stream in front of the replay (__call__(next_batch=))
+            st.wait_event(self._staged)
+            self._staged = None
         with torch.cuda.stream(st):
             if batch is not None:
                 for k in ('obs', 'occ'):
                     if k in batch:
                         self.static[k].copy_(batch[k], non_blocking=True)
+                        batch[k].record_stream(st)
             with torch.no_grad():
-                self.agent_next = self.model.agent_encode(self.static['obs'], self.static['occ'])
+                # (no weight cast here: the main graph casts the same buffer at the head of every replay, and two casts of one buffer on two
+                #  streams are an unordered write / read pair)
+                self.agent_next = self.model.agent_encode(self.static['obs'], self.static['occ'], cast=False)
             self.agent_done.record(st)
         self._prefetched = True
+        self._weights_seen = self.model.weights_version
 
-    def __call__(self, batch=None):
+    def __call__(self, batch=None, next_batch=None):
+        """next_batch (pipeline_agents only): the batch of the NEXT call; its agent tracks are copied into the static inputs on the
+        current stream IN FRONT of this replay (ordered behind whatever produced them on this stream) and the agent branch for them
+        starts on the agent stream under the replay."""
         main = torch.cuda.current_stream()
+        if self.pipeline_agents and self._prefetched and self._weights_seen != self.model.weights_version:
+            self._prefetched = False                 # the prefetched encoding is of the OLD weights (load_weights since): run it again
         if self.pipeline_agents and not self._prefetched:
+            self.model._sync_compute_weights()       # (the branch runs in front of the replay: it needs the current compute copy now)
             self.agent_stream.wait_stream(main)
             self.prefetch_agents(batch)
         if batch is not None:
@@ -177,5 +200,13 @@ class GraphedForward:
                 d.copy_(s_, non_blocking=True)
             self.agent_free.record(main)
             self._prefetched = False
+            if next_batch is not None:               # the agent branch has read the static tracks (agent_done): they may be overwritten
+                for k in ('obs', 'occ'):
+                    if k in next_batch:
+                        self.static[k].copy_(next_batch[k], non_blocking=True)
+                self._staged = torch.cuda.Event()
+                self._staged.record(main)
         self.graph.replay()
+        if self.pipeline_agents and next_batch is not None:
+            self.prefetch_agents()
         return self.out

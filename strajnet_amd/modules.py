@@ -292,6 +292,7 @@ class STrajNet:
         self._upconv_prep = {}
         self._xattn_pack_stale = True
         self._prep_event = None
+        self.weights_version = 0          # bumped by load_weights (callers that cache results of the weights compare it)
         self._sync_compute_weights()
 
     # ------------------------------------------------------------------ weights
@@ -324,6 +325,7 @@ class STrajNet:
                 if tuple(w.shape) != p.shape:
                     raise ValueError(f'{n}: shape {tuple(w.shape)} != {p.shape}')
                 p.master.copy_(w.to(self.device))
+        self.weights_version += 1
         self._sync_compute_weights()
 
     def trainable_weights(self):
@@ -361,7 +363,7 @@ class STrajNet:
         src, leaf = self._cut_src, self._cut_leaf
         self._cut_src = self._cut_leaf = None
         pairs = [(s_, l.grad) for s_, l in zip(src, leaf) if l.grad is not None]
-        ops.wgrad_queue_begin()               # the encoder's dense weight gradients: queued, flushed at the stage boundaries and here
+        ops.wgrad_queue_begin(self.device)    # the encoder's dense weight gradients: queued, flushed at the stage boundaries and here
         try:
             torch.autograd.backward([a for a, _ in pairs], [g for _, g in pairs])
             main = torch.cuda.current_stream(self.device)
@@ -370,7 +372,7 @@ class STrajNet:
                     main.wait_stream(st)
         finally:
             with torch.no_grad():
-                ops.wgrad_queue_end()
+                ops.wgrad_queue_end(self.device)
         ops.wgrad_join_now(main)
         with torch.no_grad():
             self._fold_partials('encoder')
@@ -589,13 +591,14 @@ class STrajNet:
         v = self._drop(self._dense(v, pre + '/FFN2'), pre + '/dropout2')
         return self._ln(v, pre + '/norm2', 1e-3)
 
-    def agent_encode(self, obs, occ):
+    def agent_encode(self, obs, occ, cast=True):
         """The agent branch alone (TrajNet.call, trajNet.py:125-187), eval semantics: obs [B,48,11,8], occ [B,16,11,8] -> (key [B,64,384],
         mask [B,64]) as call() computes them.  For callers that run the branch apart from the raster path (set `agent_override` to the
         result before call()): it depends on the agents' tracks and the weights only."""
         ops.set_serial(self.serial)
         ops.use_arena(self._arena)
-        self._sync_compute_weights()
+        if cast:                       # (cast=False: the caller knows the compute copy is current -- graph.GraphedForward's pipeline)
+            self._sync_compute_weights()
         self._dctx = None
         return tuple(self._traj_net(obs, occ))
 
@@ -785,7 +788,7 @@ class STrajNet:
                 raise RuntimeError('inputs must be CUDA (ROCm) tensors: the HIP path has no CPU fallback')
         self._side, self._side2 = (None, None) if self.serial else self._streams
         ops.set_serial(self.serial)
-        ops.wgrad_queue_reset()
+        ops.wgrad_queue_reset(self.device)
         ops.use_arena(self._arena)
         self._sync_compute_weights()
         self._dctx = None

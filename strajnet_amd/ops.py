@@ -211,7 +211,7 @@ def zeros_f32(shape, device):
 _ROLE_STREAMS = {}
 
 
-def role_stream(device, role):
+def role_stream(device, role, priority=0):
     """ONE stream per (device, role) for the whole process.  torch hands out side streams from a round-robin pool of 32 per device: a
     process that builds many models / captured steps (the GPU test suite: a model per test) wraps the pool, and a new model's side stream
     is then the SAME stream as some long-lived one (the capture stream, the weight-gradient stream).  And the number of DISTINCT streams a
@@ -222,7 +222,7 @@ def role_stream(device, role):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _ROLE_STREAMS.get((idx, role))
     if st is None:
-        st = _ROLE_STREAMS[(idx, role)] = torch.cuda.Stream(torch.device('cuda', idx))
+        st = _ROLE_STREAMS[(idx, role)] = torch.cuda.Stream(torch.device('cuda', idx), priority=priority)
     return st
 
 
@@ -273,7 +273,7 @@ def wgrad_stream(kind, *operands):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _WG.get(key)
     if st is None:
-        st = _WG[key] = {'side': role_stream(dev, 'wgrad'), 'keep': [], 'armed': False, 'main': None}
+        st = _WG[key] = {'side': role_stream(dev, 'wgrad', priority=int(os.environ.get('STJ_WG_PRIO', '0'))), 'keep': [], 'armed': False, 'main': None}
     main = torch.cuda.current_stream(dev)
     st['side'].wait_stream(main)
     st['keep'].extend(operands)
@@ -297,13 +297,13 @@ class _JoinAfterBackward(torch.autograd.Function):
     def backward(ctx, g):
         streams, post = ctx.streams, ctx.post
         main = torch.cuda.current_stream(g.device)
-        wgrad_queue_begin()
+        wgrad_queue_begin(g.device)
 
         def join():
             for s in streams:
                 main.wait_stream(s)
             with torch.cuda.stream(main), torch.no_grad():
-                wgrad_queue_end()             # the dense weight gradients still queued (one grouped stream-K launch)
+                wgrad_queue_end(g.device)     # the dense weight gradients still queued (one grouped stream-K launch)
             # the weight-gradient side stream writes bias-gradient partials that `post` folds: it must be ordered before the fold
             # (its own join callback is queued later than this one and would run after it)
             key = g.device.index if g.device.index is not None else torch.cuda.current_device()
@@ -343,12 +343,12 @@ def gemm(A, B, C, M, N, K, sA, sB, sC, dt, bias=None, sBias=(0, 0), res=None, sR
     post: callable that consumes C; it travels with a DEFERRED weight gradient and runs behind the flush that carries it.
     Returns True when the product was queued (post will run), False when it was launched (or recorded in the open group): the
     caller then runs its post-processing itself, after closing the group."""
-    if (accumulate and _wq()['on'] and splitk == 0 and c_f32 and kseg[0] == 1 and sA[2] == 1 and sB[3] == 1 and bias is None
-            and res is None and alpha == 1.0 and isinstance(A, torch.Tensor) and isinstance(B, torch.Tensor)):
+    if (accumulate and isinstance(A, torch.Tensor) and isinstance(B, torch.Tensor) and _wq(A.device)['on'] and splitk == 0 and c_f32
+            and kseg[0] == 1 and sA[2] == 1 and sB[3] == 1 and bias is None and res is None and alpha == 1.0):
         # a weight gradient dW += x^T dY inside a model's backward pass: queued for the grouped stream-K launch of the next flush
         j = WJob(A, B, C, colsum, K, M, N, sA[3], sB[2], sC[2], dt, nb=nb, sx=sA[:2], sdy=sB[:2], sdw=sC[:2], sdb=sBias)
         if j.supported():
-            wgrad_queue_push(j, post)
+            wgrad_queue_push(j, post, A.device)
             return True
     _gemm_call(A, B, C, M, N, K, sA, sB, sC, dt, bias, sBias, res, sRes, nb, act, alpha, c_f32, accumulate, splitk, colsum, kseg)
     return False
@@ -441,42 +441,47 @@ class _WQueues(dict):
 _WQS = _WQueues()
 
 
-def _wq():
+def _wq(dev=None):
+    """The queue of `dev` (a torch.device / tensor device; None: the calling thread's current device).  Callers that know their model's or
+    tensor's device pass it: the forward thread's current device need not be the model's (several GPUs driven by one process), while
+    autograd's worker thread of a device always has that device current."""
+    if dev is not None and getattr(dev, 'type', 'cuda') == 'cuda' and getattr(dev, 'index', None) is not None:
+        return _WQS[dev.index]
     return _WQS[torch.cuda.current_device() if torch.cuda.is_available() else -1]
 
 
-def wgrad_queue_begin():
-    q = _wq()
+def wgrad_queue_begin(dev=None):
+    q = _wq(dev)
     assert not q['jobs'], 'wgrad_queue_begin: jobs of another backward pass are still queued on this device'
     q['on'] = WGRAD_SK
 
 
-def wgrad_queue_reset():
+def wgrad_queue_reset(dev=None):
     """Start of a forward pass: whatever an aborted backward pass left behind is dropped."""
-    q = _wq()
+    q = _wq(dev)
     q['on'] = False
     q['jobs'] = []
 
 
-def wgrad_queue_push(job, post=None):
-    st = torch.cuda.current_stream()
+def wgrad_queue_push(job, post=None, dev=None):
+    st = torch.cuda.current_stream(dev)
     ev = None
     if not _SERIAL:
         ev = torch.cuda.Event()
         ev.record(st)
-    _wq()['jobs'].append((job, post, st, ev))
+    _wq(dev)['jobs'].append((job, post, st, ev))
 
 
-def wgrad_queue_flush():
-    """Launch everything queued, on the current stream.  (Round 5: the flush-point launches on the weight-gradient side stream instead,
+def wgrad_queue_flush(dev=None):
+    """Launch everything queued (on `dev`; None: the current device), on the current stream.  (Round 5: the flush-point launches on the weight-gradient side stream instead,
     so that the next stage's backward need not wait for them, measured 1286-1291 scenes/s with all CUs as the launch's budget, 1270-1276
     with 128 workgroups, 1234-1246 with 96, against 1296-1305 on the main stream: the Swin backward kernels they would run beside fill
     the CUs they are given, and the join before the optimizer waits for the slowed-down last flush.)"""
-    q = _wq()
+    q = _wq(dev)
     items, q['jobs'] = q['jobs'], []
     if not items:
         return
-    cur = torch.cuda.current_stream()
+    cur = torch.cuda.current_stream(dev)
     last = {}
     for job, post, st, ev in items:
         if ev is not None and st != cur:
@@ -492,9 +497,9 @@ def wgrad_queue_flush():
             post()
 
 
-def wgrad_queue_end():
-    wgrad_queue_flush()
-    _wq()['on'] = False
+def wgrad_queue_end(dev=None):
+    wgrad_queue_flush(dev)
+    _wq(dev)['on'] = False
 
 
 class _WgradQueueFlush(torch.autograd.Function):
@@ -505,7 +510,7 @@ class _WgradQueueFlush(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        wgrad_queue_flush()
+        wgrad_queue_flush(g.device)
         return g
 
 
@@ -1884,10 +1889,20 @@ def _upconv_backward_tail(ctx, x, dpre, wd, need_dx):
 _UPWG = {'on': False, 'items': []}
 
 
+# Issue order of the deferred launches.  'bwd' = the order backward produced them (full-resolution layers first, the two wide layers
+# 192 -> 128 / 384 -> 192 last: those are 1024-workgroup non-persistent launches and land on Swin stage 2's backward); 'wide' = widest
+# Cin first, so that they run beside the thin FG-MSA / agent chain and only the budgeted persistent launches reach into the encoder.
+UPWG_ORDER = os.environ.get('STJ_UPWG_ORDER', 'wide')     # round 6, alternating same-box runs: bwd 1350 / 1363 / 1349, wide 1372 / 1365 / 1359, rev 1340 / 1351 / 1353 scenes/s
+
+
 def flush_upconv_wgrads():
     items, _UPWG['items'] = _UPWG['items'], []
     if not items:
         return
+    if UPWG_ORDER == 'wide':
+        items = sorted(items, key=lambda it: -it[1].shape[-1])        # (stable: equal widths keep their backward order)
+    elif UPWG_ORDER == 'rev':
+        items = items[::-1]
     with wgrad_stream(2, *[t for it in items for t in it[1:]]):
         for wg, _, _ in items:
             wg()
@@ -1903,7 +1918,7 @@ class _WgradFlushPoint(torch.autograd.Function):
     def backward(ctx, g):
         flush_upconv_wgrads()
         if WGRAD_SK_POINTS:
-            wgrad_queue_flush()             # the decoder's dense weight gradients (the three time-kernel skips)
+            wgrad_queue_flush(g.device)     # the decoder's dense weight gradients (the three time-kernel skips)
         return g
 
 

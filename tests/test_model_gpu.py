@@ -281,6 +281,21 @@ def test_config4_inference_graph_b32(dtype):
         if i + 1 < len(seq):
             gp.prefetch_agents(seq[i + 1])                      # overlaps this batch's main graph
         assert torch.equal(o.clone(), ex), i
+    # the staged form: the next batch's tracks are copied in front of this replay, the branch runs under it (`next_batch=`); fresh
+    # device tensors produced on the current stream right before the call (the case a stream-ordered upload makes)
+    for i, (bt, ex) in enumerate(zip(seq, exp)):
+        nxt = {k: v.clone() for k, v in seq[i + 1].items()} if i + 1 < len(seq) else None
+        o = gp(bt, next_batch=nxt)
+        assert torch.equal(o.clone(), ex), i
+    # weights changed between a prefetch and the call: the stale encoding is dropped
+    gp.prefetch_agents(big)
+    w2 = {k: (v * 1.01 if k.startswith('traj_net/') else v) for k, v in w.items()}
+    model.load_weights(w2)
+    o_new = gp(big).clone()
+    with torch.no_grad():
+        e_new = model(big['ogm'], big['map_img'], training=False, obs=big['obs'], occ=big['occ'], mapt=None, flow=big['flow'])
+    assert torch.equal(o_new, e_new) and not torch.equal(o_new, eager)
+    model.load_weights(w)
     assert model.agent_override is None
     del gp, gf
     import gc

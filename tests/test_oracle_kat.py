@@ -173,3 +173,44 @@ def test_focal_and_keras_bce_known_answers():
     assert abs(float(R.bce_prob(np.array(0.0), np.array(0.0))) + np.log(1 - eps + eps)) < 1e-12    # == 0 up to rounding
     # probability form of the focal term: y=1, q=.5 -> .25 * .25 * bce
     assert abs(float(R.focal_prob(np.array(1.0), np.array(0.5))) - 0.0625 * float(R.bce_prob(np.array(1.0), np.array(0.5)))) < 1e-15
+
+
+def test_published_vectors():
+    """PUBLISHED third-party vectors (docstring examples of the libraries the reference calls) -- the only outside pins available in
+    an image without TensorFlow; everything else in this file is hand-derived.  Each is quoted with its source."""
+    from oracle import np_ref as R
+    # (1) tensorflow_addons.losses.SigmoidFocalCrossEntropy docstring (alpha .25, gamma 2, probabilities in, reduction NONE):
+    #     y_true [[1],[1],[0]], y_pred [[0.97],[0.91],[0.03]] -> [6.8532745e-06, 1.9097870e-04, 2.0559824e-05]   (loss.py:32-38 constructs it)
+    y = np.array([1.0, 1.0, 0.0])
+    q = np.array([0.97, 0.91, 0.03])
+    pub = np.array([6.8532745e-06, 1.9097870e-04, 2.0559824e-05])
+    got = R.focal_prob(y, q)
+    assert np.abs(got / pub - 1).max() < 5e-6, got            # float64 evaluation vs figures published from a float32 evaluation ...
+    got32 = R.focal_prob(y.astype(np.float32), q.astype(np.float32))
+    assert got32.dtype == np.float32 and np.abs(got32 / pub - 1).max() < 2e-7, got32      # ... which the same formula in float32 reproduces digit for digit
+    # (2) tf.keras.metrics.AUC docstring worked example (num_thresholds=3, y_true [0,0,1,1], y_pred [0,0.5,0.3,0.9]): thresholds
+    #     [0 - 1e-7, 0.5, 1 + 1e-7], tp = [2,1,0], fp = [2,0,0], fn = [0,1,2], ROC AUC 0.75 -- pins the threshold construction and the
+    #     strict `>` comparison that keras_auc_pr (loss.py:41,134-136) shares with it
+    thr, tp, fp, fn = R.keras_auc_counts([0, 0, 1, 1], [0, 0.5, 0.3, 0.9], 3)
+    assert np.allclose(thr, [0 - 1e-7, 0.5, 1 + 1e-7], atol=1e-12 + 1e-7) and thr[0] < 0 and thr[2] > 1
+    assert tp.tolist() == [2, 1, 0] and fp.tolist() == [2, 0, 0] and fn.tolist() == [0, 1, 2]
+    tn = 2 - fp
+    recall, fpr = tp / (tp + fn), fp / (fp + tn)
+    roc = sum((recall[i] + recall[i + 1]) / 2 * (fpr[i] - fpr[i + 1]) for i in range(2))
+    assert abs(roc - 0.75) < 1e-12
+    # (3) tf.keras.activations.gelu docstring, approximate=True (the tanh form the reference's own Gelu class restates, modules.py:18-29):
+    #     x = [-3, -1, 0, 1, 3] -> [-0.00363752, -0.15880796, 0., 0.841192, 2.9963627]
+    pubg = np.array([-0.00363752, -0.15880796, 0.0, 0.841192, 2.9963627])
+    assert np.abs(R.gelu(np.array([-3.0, -1.0, 0.0, 1.0, 3.0])) - pubg).max() < 5e-7
+    # (4) tf.keras.layers.LayerNormalization docstring: data = arange(10).reshape(5, 2) * 10, axis = 1 -> every row prints [-1., 1.]
+    #     (biased variance over the last axis, eps 1e-3 inside the root: (0 - 5) / sqrt(25 + 1e-3) = -0.99998)
+    d = np.arange(10, dtype=np.float64).reshape(5, 2) * 10
+    ln = R.layer_norm(d, np.ones(2), np.zeros(2), 1e-3)
+    assert np.abs(ln - np.array([[-1.0, 1.0]] * 5)).max() < 3e-5
+    assert np.abs(ln[0, 0] + 5 / np.sqrt(25 + 1e-3)) < 1e-12
+    # (5) tf.nn.sigmoid_cross_entropy_with_logits docstring: logits [1., -1., 0., 1., -1., 0., 0.], labels [0., 0., 0., 1., 1., 1., 0.5]
+    #     -> [1.3132616, 0.3132617, 0.6931472, 0.3132617, 1.3132616, 0.6931472, 0.6931472]
+    lg = np.array([1.0, -1.0, 0.0, 1.0, -1.0, 0.0, 0.0])
+    lb = np.array([0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 0.5])
+    pubx = np.array([1.3132616, 0.3132617, 0.6931472, 0.3132617, 1.3132616, 0.6931472, 0.6931472])
+    assert np.abs(R.sigmoid_xe(lb, lg) - pubx).max() < 1e-7
