@@ -228,6 +228,59 @@ int stj_small_attn_fwd(const void* q, const void* k, const void* v, const int* q
 int stj_small_attn_bwd(const void* q, const void* k, const void* v, const int* qvalid, const int* kvalid, const void* dO, void* dq, void* dk,
                        void* dv, long long Bt, int N, int H, int d, float scale, const long long* rng_state, int site, float p_drop, int dtype,
                        hipStream_t stream);
+/* Fused agent branch (csrc/agent_fused.hip).
+ * stj_agent_pack: transposed copies ([N][K], K contiguous, activation dtype) of the branch's eleven Dense / tfa kernels -- the layout
+ * the forward kernels stream as MFMA A fragments -- into `out` (stj_agent_pack_workspace_bytes(dtype) bytes); once per step.
+ * stj_agent_enc_fwd / _bwd: TrajEncoder.call (trajNet.py:38-48) for all B (n_obs + n_occ) agents in ONE launch per direction: Conv1D(5 -> 64)
+ * + ELU, the 4-head tfa self-attention over the 11 steps with the (x != 0) mask and dropout on the coefficients, GlobalMaxPooling1D,
+ * Dense(3 -> 64) on the step-0 type one-hot, concat, Dense(384 -> 384) + ELU.  Forward writes enc and the agent mask cmi, and, when the
+ * five s_* pointers are given, what backward reads.  Backward writes the three dY tensors whose weight gradients are the CALLER's
+ * (dW += X^T dY through stj_wgrad_group / stj_gemm with X = s_cat / s_att / s_nodes) and accumulates the 5 x 64, 64 and 3 x 64 ones itself. */
+typedef struct stj_agent_weights {
+  const float* e_wq; const float* e_wk; const float* e_wv; const float* e_wo; const float* e_ws;
+  const float* i_wq; const float* i_wk; const float* i_wv; const float* i_wo; const float* i_w1; const float* i_w2;
+} stj_agent_weights;
+typedef struct stj_agent_enc_args {
+  const float* obs; const float* occ;
+  int n_obs, n_occ, B, dtype;
+  const void* pack;
+  const float* wn; const float* bn; const float* wv3; const float* bo; const float* bs;
+  void* enc; int* cmi;
+  void* s_nodes; void* s_qkv; void* s_att; void* s_pmask; void* s_cat;
+  const long long* rng_state; int site; float p_drop;
+  const void* d_enc; const void* wq; const void* wk; const void* wv; const void* wo; const void* ws;
+  void* dpre_s; void* dout; void* dqkv; float* dwn; float* dbn; float* dwv3;
+} stj_agent_enc_args;
+typedef struct stj_agent_int_args {
+  const void* enc; const int* cmi;
+  int n_obs, n_occ, B, dtype;
+  const void* pack;
+  const void* seg;
+  const float* bo; const float* g1; const float* be1; const float* b1; const float* b2; const float* g2; const float* be2;
+  const float* g_obs; const float* b_obs; const float* g_occ; const float* b_occ;
+  void* key;
+  void* s_concat; void* s_qin; void* s_q; void* s_k; void* s_v; void* s_att; void* s_v1; void* s_n1; void* s_h; void* s_u2; void* s_out;
+  const long long* rng_state; int site_a, site_1, site_2; float p_drop;
+  const void* dkey;
+  const void* wq; const void* wk; const void* wv; const void* wo; const void* w1; const void* w2;
+  void* d_enc;
+  void* dq; void* dk; void* dv; void* dv1; void* dpre1; void* dz2;
+  float* dseg; float* dg1; float* dbe1; float* dg2; float* dbe2; float* dg_obs; float* db_obs; float* dg_occ; float* db_occ;
+} stj_agent_int_args;
+long long stj_agent_pack_workspace_bytes(int dtype);
+int stj_agent_pack(const stj_agent_weights* w, void* out, int dtype, hipStream_t stream);
+int stj_agent_enc_supported(int n_obs, int n_occ, int Tn, int dtype);
+int stj_agent_enc_fwd(const stj_agent_enc_args* a, hipStream_t stream);
+int stj_agent_enc_bwd(const stj_agent_enc_args* a, hipStream_t stream);
+/* stj_agent_int_fwd / _bwd: the 64-agent interaction block of TrajNet.call (trajNet.py:135-187 with Cross_Attention.call :79-87) per scene in
+ * ONE launch per direction: masked concat, segment embedding, the 6-head tfa attention (mask cm (x) cm, dropout on the coefficients), output
+ * projection, LayerNorm(1e-3), Dense(1536, elu), Dropout, Dense(384), Dropout, LayerNorm(1e-3), enc + value + embed, obs_norm | occ_norm.
+ * 16-bit dtypes, 64 agents per scene (stj_agent_int_supported); the f32 parity mode keeps the layer-by-layer chain.  Forward writes key
+ * [B 64][384] and, when the eleven s_* pointers are given, what backward reads.  Backward writes d_enc and the six dY tensors whose weight
+ * gradients are the caller's (X = s_qin / s_concat / s_concat / s_att / s_n1 / s_h), and accumulates seg_embed and the LayerNorm parameters. */
+int stj_agent_int_supported(int n_obs, int n_occ, int dtype);
+int stj_agent_int_fwd(const stj_agent_int_args* a, hipStream_t stream);
+int stj_agent_int_bwd(const stj_agent_int_args* a, hipStream_t stream);
 /* FG-MSA relative-position bias: bilinear `sample` of rpe_table at (query - key - offset) displacements
  * (FG_MSA.py:150-172 via occu_metric.py:345-409 + tfa_image.py:87-173).  off [B,G,H*W,2], table f32 [2H-1,2W-1,G],
  * bias f32 [B,G,HW,HW]; bwd: dtable +=, doff f32 [B,G,HW,2] += (zeroed by the caller: query slices accumulate). */

@@ -71,6 +71,14 @@ SIGNATURES = {
     'stj_small_attn_supported': [ci, ci, ci, ci],
     'stj_small_attn_fwd': [vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, cf, vp, ci, cf, ci, vp],
     'stj_small_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, ci, ci, cf, vp, ci, cf, ci, vp],
+    'stj_agent_pack_workspace_bytes': [ci],
+    'stj_agent_pack': [vp, vp, ci, vp],
+    'stj_agent_enc_supported': [ci, ci, ci, ci],
+    'stj_agent_enc_fwd': [vp, vp],
+    'stj_agent_enc_bwd': [vp, vp],
+    'stj_agent_int_supported': [ci, ci, ci],
+    'stj_agent_int_fwd': [vp, vp],
+    'stj_agent_int_bwd': [vp, vp],
     'stj_agent_out_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp],
     'stj_agent_out_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
     'stj_fg_attn_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp],
@@ -106,6 +114,28 @@ class WgradJob(ctypes.Structure):
                 ('ldx', cl), ('lddy', cl), ('lddw', cl),
                 ('sx1', cl), ('sx2', cl), ('sdy1', cl), ('sdy2', cl), ('sdw1', cl), ('sdw2', cl), ('sdb1', cl), ('sdb2', cl)]
 
+
+class AgentWeights(ctypes.Structure):
+    """struct stj_agent_weights (include/strajnet_hip.h)"""
+    _fields_ = [(n, vp) for n in ('e_wq', 'e_wk', 'e_wv', 'e_wo', 'e_ws', 'i_wq', 'i_wk', 'i_wv', 'i_wo', 'i_w1', 'i_w2')]
+
+
+class AgentEncArgs(ctypes.Structure):
+    """struct stj_agent_enc_args (include/strajnet_hip.h)"""
+    _fields_ = ([('obs', vp), ('occ', vp), ('n_obs', ci), ('n_occ', ci), ('B', ci), ('dtype', ci), ('pack', vp)] +
+                [(n, vp) for n in ('wn', 'bn', 'wv3', 'bo', 'bs', 'enc', 'cmi', 's_nodes', 's_qkv', 's_att', 's_pmask', 's_cat', 'rng_state')] +
+                [('site', ci), ('p_drop', cf)] +
+                [(n, vp) for n in ('d_enc', 'wq', 'wk', 'wv', 'wo', 'ws', 'dpre_s', 'dout', 'dqkv', 'dwn', 'dbn', 'dwv3')])
+
+
+class AgentIntArgs(ctypes.Structure):
+    """struct stj_agent_int_args (include/strajnet_hip.h)"""
+    _fields_ = ([('enc', vp), ('cmi', vp), ('n_obs', ci), ('n_occ', ci), ('B', ci), ('dtype', ci)] +
+                [(n, vp) for n in ('pack', 'seg', 'bo', 'g1', 'be1', 'b1', 'b2', 'g2', 'be2', 'g_obs', 'b_obs', 'g_occ', 'b_occ', 'key',
+                                   's_concat', 's_qin', 's_q', 's_k', 's_v', 's_att', 's_v1', 's_n1', 's_h', 's_u2', 's_out', 'rng_state')] +
+                [('site_a', ci), ('site_1', ci), ('site_2', ci), ('p_drop', cf)] +
+                [(n, vp) for n in ('dkey', 'wq', 'wk', 'wv', 'wo', 'w1', 'w2', 'd_enc', 'dq', 'dk', 'dv', 'dv1', 'dpre1', 'dz2',
+                                   'dseg', 'dg1', 'dbe1', 'dg2', 'dbe2', 'dg_obs', 'db_obs', 'dg_occ', 'db_occ')])
 
 _lib = None
 

@@ -249,6 +249,10 @@ class STrajNet:
         self.agent_override = None            # (key, mask) from agent_encode(): call() then skips the agent branch
         self.mid_forward_hook = None          # callable run once per forward pass behind the encoder's first stage (GraphedTrainStep: loss.prepare on its side stream)
         self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (8 x 8 / 16 x 16 maps; all three storage types)
+        self.fused_agent = True        # TrajEncoder of all agents as one kernel per direction (csrc/agent_fused.hip); False = the layer-by-layer chain
+        self.fused_agent_int = True    # ... and the 64-agent interaction block (16-bit storage types)
+        self._agent_pack = None
+        self._agent_pack_stale = True
         self._xattn_pack = None
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():
@@ -599,8 +603,24 @@ class STrajNet:
         ops.use_arena(self._arena)
         if cast:                       # (cast=False: the caller knows the compute copy is current -- graph.GraphedForward's pipeline)
             self._sync_compute_weights()
+        self._agent_pack_stale = True
         self._dctx = None
         return tuple(self._traj_net(obs, occ))
+
+    def _agent_ws(self):
+        """the agent branch's Params under the names ops.agent_pack / agent_enc use"""
+        e, c = 'traj_net/traj_encoder', 'traj_net/cross_attention'
+        p = self._p
+        return {'wn': p(e + '/node_feature/kernel'), 'bn': p(e + '/node_feature/bias'), 'wv3': p(e + '/vector_feature/kernel'),
+                'e_wq': p(e + '/node_attention/query_kernel'), 'e_wk': p(e + '/node_attention/key_kernel'),
+                'e_wv': p(e + '/node_attention/value_kernel'), 'e_wo': p(e + '/node_attention/projection_kernel'),
+                'e_bo': p(e + '/node_attention/projection_bias'), 'e_ws': p(e + '/sublayer/kernel'), 'e_bs': p(e + '/sublayer/bias'),
+                'i_wq': p(c + '/mha/query_kernel'), 'i_wk': p(c + '/mha/key_kernel'), 'i_wv': p(c + '/mha/value_kernel'),
+                'i_wo': p(c + '/mha/projection_kernel'), 'i_w1': p(c + '/FFN1/kernel'), 'i_w2': p(c + '/FFN2/kernel'),
+                'i_bo': p(c + '/mha/projection_bias'), 'g1': p(c + '/norm1/gamma'), 'be1': p(c + '/norm1/beta'), 'b1': p(c + '/FFN1/bias'),
+                'b2': p(c + '/FFN2/bias'), 'g2': p(c + '/norm2/gamma'), 'be2': p(c + '/norm2/beta'), 'seg': p('traj_net/seg_embed/kernel'),
+                'g_obs': p('traj_net/obs_norm/gamma'), 'b_obs': p('traj_net/obs_norm/beta'), 'g_occ': p('traj_net/occ_norm/gamma'),
+                'b_occ': p('traj_net/occ_norm/beta')}
 
     def _traj_net(self, obs, occ):
         """TrajNet.call (trajNet.py:125-187) with the 64-way TrajEncoder loop batched.  -> key [B,64,384], mask [B,64]."""
@@ -609,13 +629,31 @@ class STrajNet:
         A = n_obs + occ.shape[1]
         # tr = cat(obs, occ) [B,64,11,8]; step valid = tr[...,0] != 0 (trajNet.py:127,131); agent valid = any step (trajNet.py:138):
         # one launch writes the two feature slices in the activation dtype and the masks
-        x5, v3, vt, cmi, cmf = ops.agent_prep(obs, occ, self.dtype)
-        nodes = ops.linear(x5, self._p(pre + '/node_feature/kernel'), self._p(pre + '/node_feature/bias'), act=ACT_ELU)   # Conv1D(64,1)+ELU
-        nodes = nodes.view(B * A, T, 64)
-        nodes = self._tfa_mha(pre + '/node_attention', nodes, nodes, 4, vt, vt)           # [B*A,T,320]
-        nodes = ops.maxpool_time(nodes).view(B, A, 320)
-        vec = ops.linear(v3.view(B, A, 3), self._p(pre + '/vector_feature/kernel'))
-        enc = ops.linear(torch.cat([nodes, vec], -1), self._p(pre + '/sublayer/kernel'), self._p(pre + '/sublayer/bias'), act=ACT_ELU)
+        if self.fused_agent and ops.agent_enc_ok(n_obs, occ.shape[1], T, self.dtype):
+            # the whole TrajEncoder (trajNet.py:38-48) for every agent: ONE launch (csrc/agent_fused.hip), straight from the raw tracks
+            if self._agent_pack_stale:
+                self._agent_pack = ops.agent_pack(self._agent_ws(), self.dtype, out=self._agent_pack)
+                self._agent_pack_stale = False
+            enc, cmi = ops.agent_enc(obs, occ, self._agent_ws(), self._agent_pack, self.dtype,
+                                     self._attn_drop(pre + '/node_attention/dropout', (B * A, 4, T, T)))
+            if self.fused_agent_int and ops.agent_int_ok(n_obs, occ.shape[1], self.dtype):
+                # ... and the 64-agent interaction block (trajNet.py:135-187) as ONE more launch: 16-bit storage types
+                drop = None
+                if self._dctx is not None:
+                    c = 'traj_net/cross_attention'
+                    d = self._dctx
+                    drop = (0.1, d.snap, (d.site(c + '/mha/dropout', (B, 6, A, A), 0.1), d.site(c + '/dropout1', (B, A, 1536), 0.1),
+                                          d.site(c + '/dropout2', (B, A, 384), 0.1)))
+                return ops.agent_int(enc, cmi, self._agent_ws(), self._agent_pack, n_obs, drop), cmi
+            cmf = cmi.to(self.dtype)
+        else:
+            x5, v3, vt, cmi, cmf = ops.agent_prep(obs, occ, self.dtype)
+            nodes = ops.linear(x5, self._p(pre + '/node_feature/kernel'), self._p(pre + '/node_feature/bias'), act=ACT_ELU)   # Conv1D(64,1)+ELU
+            nodes = nodes.view(B * A, T, 64)
+            nodes = self._tfa_mha(pre + '/node_attention', nodes, nodes, 4, vt, vt)           # [B*A,T,320]
+            nodes = ops.maxpool_time(nodes).view(B, A, 320)
+            vec = ops.linear(v3.view(B, A, 3), self._p(pre + '/vector_feature/kernel'))
+            enc = ops.linear(torch.cat([nodes, vec], -1), self._p(pre + '/sublayer/kernel'), self._p(pre + '/sublayer/bias'), act=ACT_ELU)
         onehot = self._seg_onehot.get((A, n_obs))
         if onehot is None:
             onehot = torch.zeros((A, 2), dtype=self.dtype, device=self.device)
@@ -805,6 +843,7 @@ class STrajNet:
                  'decoder/upconvf_0_0')
         self._prep_event = None
         self._xattn_pack_stale = True
+        self._agent_pack_stale = True
 
         def issue_prep():
             if self._side2 is not None:

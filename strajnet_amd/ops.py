@@ -1657,6 +1657,178 @@ def agent_out(enc, value, embed, pg0, pb0, pg1, pb1, n_obs, eps):
 
 
 # ----------------------------------------------------------------------------------------------------
+# fused agent branch (csrc/agent_fused.hip): TrajEncoder for all agents / the 64-agent interaction block, one launch per direction
+# ----------------------------------------------------------------------------------------------------
+AGENT_PACK_KEYS = ('e_wq', 'e_wk', 'e_wv', 'e_wo', 'e_ws', 'i_wq', 'i_wk', 'i_wv', 'i_wo', 'i_w1', 'i_w2')
+
+
+def _ip(t):
+    """integer device address for a ctypes struct field (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def agent_pack(ws, dtype, out=None):
+    """Transposed copies of the branch's eleven kernels in `dtype` (stj_agent_pack): what the fused forward kernels stream.  ws: dict
+    AGENT_PACK_KEYS -> Param.  Once per step (the weights change)."""
+    from ._lib import lib, AgentWeights
+    if out is None:
+        out = torch.empty(int(lib().stj_agent_pack_workspace_bytes(DTYPE_CODE[dtype])), dtype=torch.uint8, device=ws['e_wq'].master.device)
+    aw = AgentWeights(*[ws[k].master.data_ptr() for k in AGENT_PACK_KEYS])
+    call('stj_agent_pack', ctypes.byref(aw), _p(out), DTYPE_CODE[dtype], _st())
+    return out
+
+
+def agent_enc_ok(n_obs, n_occ, Tn, dtype):
+    from ._lib import lib
+    return bool(lib().stj_agent_enc_supported(int(n_obs), int(n_occ), int(Tn), DTYPE_CODE[dtype]))
+
+
+class _AgentEnc(torch.autograd.Function):
+    """enc [B,A,384], cmi [B,A] = TrajEncoder of every agent (trajNet.py:38-48,127-138) from the raw tracks obs [B,n_obs,11,8], occ
+    [B,n_occ,11,8].  ws: Params {wn, bn, wv3, e_wq, e_wk, e_wv, e_wo, e_bo, e_ws, e_bs}; pack: agent_pack(); drop: (p, state, site) or None."""
+    @staticmethod
+    def forward(ctx, obs, occ, trig, ws, pack, dtype, drop):
+        from ._lib import AgentEncArgs
+        _req_cuda(obs, occ)
+        obs, occ = obs.float().contiguous(), occ.float().contiguous()
+        B, n_obs, Tn, _ = obs.shape
+        n_occ = occ.shape[1]
+        A = n_obs + n_occ
+        dev = obs.device
+        enc = torch.empty((B, A, 384), dtype=dtype, device=dev)
+        cmi = torch.empty((B, A), dtype=torch.int32, device=dev)
+        train = bool(ctx.needs_input_grad[2])
+        sv = {}
+        if train:
+            rows = B * A * Tn
+            sv = dict(s_nodes=torch.empty((rows, 64), dtype=dtype, device=dev), s_qkv=torch.empty((rows, 768), dtype=dtype, device=dev),
+                      s_att=torch.empty((rows, 256), dtype=dtype, device=dev), s_pmask=torch.empty((B * A, 320), dtype=torch.int16, device=dev),
+                      s_cat=torch.empty((B * A, 384), dtype=dtype, device=dev))
+        p_drop, state, site = drop if drop is not None else (0.0, None, 0)
+        a = AgentEncArgs(obs=_ip(obs), occ=_ip(occ), n_obs=n_obs, n_occ=n_occ, B=B, dtype=DTYPE_CODE[dtype], pack=_ip(pack),
+                         wn=_ip(ws['wn'].master), bn=_ip(ws['bn'].master), wv3=_ip(ws['wv3'].master), bo=_ip(ws['e_bo'].master),
+                         bs=_ip(ws['e_bs'].master), enc=_ip(enc), cmi=_ip(cmi), rng_state=_ip(state), site=site, p_drop=float(p_drop),
+                         **{k: _ip(v) for k, v in sv.items()})
+        call('stj_agent_enc_fwd', ctypes.byref(a), _st())
+        ctx.ws, ctx.drop, ctx.geo, ctx.tdtype = ws, drop, (B, n_obs, n_occ, Tn), dtype
+        if train:
+            ctx.save_for_backward(obs, occ, enc, cmi, *[sv[k] for k in ('s_nodes', 's_qkv', 's_att', 's_pmask', 's_cat')])
+        ctx.mark_non_differentiable(cmi)
+        return enc, cmi
+
+    @staticmethod
+    def backward(ctx, denc, _dcmi):
+        from ._lib import AgentEncArgs
+        obs, occ, enc, cmi, s_nodes, s_qkv, s_att, s_pmask, s_cat = ctx.saved_tensors
+        ws, dtype = ctx.ws, ctx.tdtype
+        B, n_obs, n_occ, Tn = ctx.geo
+        A = n_obs + n_occ
+        rows = B * A * Tn
+        dev = enc.device
+        dt = DTYPE_CODE[dtype]
+        denc = denc.contiguous()
+        dpre_s = torch.empty((B * A, 384), dtype=dtype, device=dev)
+        dout = torch.empty((rows, 320), dtype=dtype, device=dev)
+        dqkv = torch.empty((rows, 768), dtype=dtype, device=dev)
+        p_drop, state, site = ctx.drop if ctx.drop is not None else (0.0, None, 0)
+        a = AgentEncArgs(obs=_ip(obs), occ=_ip(occ), n_obs=n_obs, n_occ=n_occ, B=B, dtype=dt, enc=_ip(enc), cmi=_ip(cmi),
+                         s_nodes=_ip(s_nodes), s_qkv=_ip(s_qkv), s_att=_ip(s_att), s_pmask=_ip(s_pmask), s_cat=_ip(s_cat),
+                         rng_state=_ip(state), site=site, p_drop=float(p_drop), d_enc=_ip(denc),
+                         wq=_ip(ws['e_wq'].c), wk=_ip(ws['e_wk'].c), wv=_ip(ws['e_wv'].c), wo=_ip(ws['e_wo'].c), ws=_ip(ws['e_ws'].c),
+                         dpre_s=_ip(dpre_s), dout=_ip(dout), dqkv=_ip(dqkv), dwn=_ip(ws['wn'].grad), dbn=_ip(ws['bn'].grad), dwv3=_ip(ws['wv3'].grad))
+        call('stj_agent_enc_bwd', ctypes.byref(a), _st())
+        # the three weight gradients on what the kernel wrote (queued on the grouped stream-K launch inside a model's backward pass)
+        zq = ws['e_wk'].grad.data_ptr() - ws['e_wq'].grad.data_ptr()
+        assert ws['e_wv'].grad.data_ptr() - ws['e_wk'].grad.data_ptr() == zq and zq % 4 == 0
+        with gemm_group(not (_WG_MODE & 1)), wgrad_stream(1, s_cat, dpre_s, s_att, dout, s_nodes, dqkv):
+            gemm(s_cat, dpre_s, ws['e_ws'].grad, 384, 384, B * A, (0, 0, 1, 384), (0, 0, 384, 1), (0, 0, 384), dt, c_f32=1, accumulate=1,
+                 splitk=0, colsum=ws['e_bs'].grad)
+            gemm(s_att, dout, ws['e_wo'].grad.view(256, 320), 256, 320, rows, (0, 0, 1, 256), (0, 0, 320, 1), (0, 0, 320), dt, c_f32=1,
+                 accumulate=1, splitk=0, colsum=ws['e_bo'].grad)
+            gemm(s_nodes, dqkv, ws['e_wq'].grad, 64, 64, rows, (0, 0, 1, 64), (256, 64, 768, 1), (zq // 4, 64 * 64, 64), dt, nb=(3, 4),
+                 c_f32=1, accumulate=1, splitk=0)               # dW_m[h] += nodes^T dqkv[:, m, h]  (the three tfa kernels lie zq apart)
+        return (None,) * 7
+
+
+def agent_enc(obs, occ, ws, pack, dtype, drop=None):
+    return _AgentEnc.apply(obs, occ, _trig(ws['e_ws'].master), ws, pack, dtype, drop)
+
+
+def agent_int_ok(n_obs, n_occ, dtype):
+    from ._lib import lib
+    return bool(lib().stj_agent_int_supported(int(n_obs), int(n_occ), DTYPE_CODE[dtype]))
+
+
+_INT_SAVES = ('s_concat', 's_qin', 's_q', 's_k', 's_v', 's_att', 's_v1', 's_n1', 's_h', 's_u2', 's_out')
+
+
+class _AgentInt(torch.autograd.Function):
+    """key [B,64,384] = the interaction block of TrajNet.call (trajNet.py:135-187) on enc [B,64,384], cmi [B,64].  ws: Params {seg, i_wq, i_wk,
+    i_wv, i_wo, i_bo, g1, be1, i_w1, b1, i_w2, b2, g2, be2, g_obs, b_obs, g_occ, b_occ}; drop: (p, state, (site_a, site_1, site_2)) or None."""
+    @staticmethod
+    def forward(ctx, enc, cmi, trig, ws, pack, n_obs, drop):
+        from ._lib import AgentIntArgs
+        _req_cuda(enc)
+        enc = enc.contiguous()
+        B, A, C = enc.shape
+        dev, ty = enc.device, enc.dtype
+        key = torch.empty_like(enc)
+        train = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
+        sv = {}
+        if train:
+            sv = {k: torch.empty((B * A, 1536 if k == 's_h' else C), dtype=ty, device=dev) for k in _INT_SAVES}
+        p_drop, state, sites = drop if drop is not None else (0.0, None, (0, 0, 0))
+        m = lambda k: _ip(ws[k].master)
+        a = AgentIntArgs(enc=_ip(enc), cmi=_ip(cmi), n_obs=n_obs, n_occ=A - n_obs, B=B, dtype=_dt(enc), pack=_ip(pack), seg=_ip(ws['seg'].c),
+                         bo=m('i_bo'), g1=m('g1'), be1=m('be1'), b1=m('b1'), b2=m('b2'), g2=m('g2'), be2=m('be2'), g_obs=m('g_obs'), b_obs=m('b_obs'),
+                         g_occ=m('g_occ'), b_occ=m('b_occ'), key=_ip(key), rng_state=_ip(state), site_a=sites[0], site_1=sites[1], site_2=sites[2],
+                         p_drop=float(p_drop), **{k: _ip(v) for k, v in sv.items()})
+        call('stj_agent_int_fwd', ctypes.byref(a), _st())
+        ctx.ws, ctx.drop, ctx.geo = ws, drop, (B, A, C, n_obs)
+        if train:
+            ctx.save_for_backward(enc, cmi, *[sv[k] for k in _INT_SAVES])
+        return key
+
+    @staticmethod
+    def backward(ctx, dkey):
+        from ._lib import AgentIntArgs
+        enc, cmi = ctx.saved_tensors[:2]
+        sv = dict(zip(_INT_SAVES, ctx.saved_tensors[2:]))
+        ws = ctx.ws
+        B, A, C, n_obs = ctx.geo
+        R = B * A
+        dev, ty, dt = enc.device, enc.dtype, _dt(enc)
+        dkey = dkey.contiguous()
+        d_enc = torch.empty_like(enc)
+        dY = {k: torch.empty((R, 1536 if k == 'dpre1' else C), dtype=ty, device=dev) for k in ('dq', 'dk', 'dv', 'dv1', 'dpre1', 'dz2')}
+        p_drop, state, sites = ctx.drop if ctx.drop is not None else (0.0, None, (0, 0, 0))
+        m, c, gr = (lambda k: _ip(ws[k].master)), (lambda k: _ip(ws[k].c)), (lambda k: _ip(ws[k].grad))
+        a = AgentIntArgs(enc=_ip(enc), cmi=_ip(cmi), n_obs=n_obs, n_occ=A - n_obs, B=B, dtype=dt, seg=c('seg'), g1=m('g1'), g2=m('g2'), g_obs=m('g_obs'),
+                         g_occ=m('g_occ'), rng_state=_ip(state), site_a=sites[0], site_1=sites[1], site_2=sites[2], p_drop=float(p_drop),
+                         dkey=_ip(dkey), wq=c('i_wq'), wk=c('i_wk'), wv=c('i_wv'), wo=c('i_wo'), w1=c('i_w1'), w2=c('i_w2'), d_enc=_ip(d_enc),
+                         dseg=gr('seg'), dg1=gr('g1'), dbe1=gr('be1'), dg2=gr('g2'), dbe2=gr('be2'), dg_obs=gr('g_obs'), db_obs=gr('b_obs'),
+                         dg_occ=gr('g_occ'), db_occ=gr('b_occ'), **{k: _ip(v) for k, v in sv.items()}, **{k: _ip(v) for k, v in dY.items()})
+        call('stj_agent_int_bwd', ctypes.byref(a), _st())
+        # the six weight gradients on what the kernel wrote (queued on the grouped stream-K launch inside a model's backward pass)
+        H, hs = 6, C // 6
+        keep = list(sv.values()) + list(dY.values())
+        with gemm_group(not (_WG_MODE & 1)), wgrad_stream(1, *keep):
+            for x, dy, w in ((sv['s_qin'], dY['dq'], 'i_wq'), (sv['s_concat'], dY['dk'], 'i_wk'), (sv['s_concat'], dY['dv'], 'i_wv')):
+                gemm(x, dy, ws[w].grad, C, hs, R, (0, 0, 1, C), (0, hs, C, 1), (0, C * hs, hs), dt, nb=(1, H), c_f32=1, accumulate=1, splitk=0)   # dW[h] += x^T dy[:, h]
+            gemm(sv['s_att'], dY['dv1'], ws['i_wo'].grad.view(C, C), C, C, R, (0, 0, 1, C), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1,
+                 splitk=0, colsum=ws['i_bo'].grad)
+            gemm(sv['s_n1'], dY['dpre1'], ws['i_w1'].grad, C, 1536, R, (0, 0, 1, C), (0, 0, 1536, 1), (0, 0, 1536), dt, c_f32=1, accumulate=1,
+                 splitk=0, colsum=ws['b1'].grad)
+            gemm(sv['s_h'], dY['dz2'], ws['i_w2'].grad, 1536, C, R, (0, 0, 1, 1536), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1,
+                 splitk=0, colsum=ws['b2'].grad)
+        return (d_enc,) + (None,) * 6
+
+
+def agent_int(enc, cmi, ws, pack, n_obs, drop=None):
+    return _AgentInt.apply(enc, cmi, _trig(ws['i_w1'].master), ws, pack, n_obs, drop)
+
+
+# ----------------------------------------------------------------------------------------------------
 # max over time (GlobalMaxPooling1D)
 # ----------------------------------------------------------------------------------------------------
 class _MaxPool(torch.autograd.Function):
