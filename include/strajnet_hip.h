@@ -248,7 +248,7 @@ typedef struct stj_agent_enc_args {
   void* enc; int* cmi;
   void* s_nodes; void* s_qkv; void* s_att; void* s_pmask; void* s_cat;
   const long long* rng_state; int site; float p_drop;
-  const void* d_enc; const void* wq; const void* wk; const void* wv; const void* wo; const void* ws;
+  const void* d_enc; int d_enc_f32; const void* wq; const void* wk; const void* wv; const void* wo; const void* ws;
   void* dpre_s; void* dout; void* dqkv; float* dwn; float* dbn; float* dwv3;
 } stj_agent_enc_args;
 typedef struct stj_agent_int_args {
@@ -259,11 +259,13 @@ typedef struct stj_agent_int_args {
   const float* bo; const float* g1; const float* be1; const float* b1; const float* b2; const float* g2; const float* be2;
   const float* g_obs; const float* b_obs; const float* g_occ; const float* b_occ;
   void* key;
+  float* ws_v1; float* ws_u2;
   void* s_concat; void* s_qin; void* s_q; void* s_k; void* s_v; void* s_att; void* s_v1; void* s_n1; void* s_h; void* s_u2; void* s_out;
   const long long* rng_state; int site_a, site_1, site_2; float p_drop;
   const void* dkey;
   const void* wq; const void* wk; const void* wv; const void* wo; const void* w1; const void* w2;
-  void* d_enc;
+  float* d_enc;
+  float* ws_dn1;
   void* dq; void* dk; void* dv; void* dv1; void* dpre1; void* dz2;
   float* dseg; float* dg1; float* dbe1; float* dg2; float* dbe2; float* dg_obs; float* db_obs; float* dg_occ; float* db_occ;
 } stj_agent_int_args;
@@ -275,6 +277,8 @@ int stj_agent_enc_bwd(const stj_agent_enc_args* a, hipStream_t stream);
 /* stj_agent_int_fwd / _bwd: the 64-agent interaction block of TrajNet.call (trajNet.py:135-187 with Cross_Attention.call :79-87) per scene in
  * ONE launch per direction: masked concat, segment embedding, the 6-head tfa attention (mask cm (x) cm, dropout on the coefficients), output
  * projection, LayerNorm(1e-3), Dense(1536, elu), Dropout, Dense(384), Dropout, LayerNorm(1e-3), enc + value + embed, obs_norm | occ_norm.
+ * Three launches per direction: (scene, head) workgroups for the attention, (scene, hidden chunk) workgroups for the FFN -- their partial
+ * sums meet in caller-ZEROED f32 workspaces (ws_v1, ws_u2 forward; ws_dn1 backward; [B 64][384] each) -- and a row-wise tail.  d_enc is f32.
  * 16-bit dtypes, 64 agents per scene (stj_agent_int_supported); the f32 parity mode keeps the layer-by-layer chain.  Forward writes key
  * [B 64][384] and, when the eleven s_* pointers are given, what backward reads.  Backward writes d_enc and the six dY tensors whose weight
  * gradients are the caller's (X = s_qin / s_concat / s_concat / s_att / s_n1 / s_h), and accumulates seg_embed and the LayerNorm parameters. */

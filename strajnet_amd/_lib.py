@@ -125,16 +125,17 @@ class AgentEncArgs(ctypes.Structure):
     _fields_ = ([('obs', vp), ('occ', vp), ('n_obs', ci), ('n_occ', ci), ('B', ci), ('dtype', ci), ('pack', vp)] +
                 [(n, vp) for n in ('wn', 'bn', 'wv3', 'bo', 'bs', 'enc', 'cmi', 's_nodes', 's_qkv', 's_att', 's_pmask', 's_cat', 'rng_state')] +
                 [('site', ci), ('p_drop', cf)] +
-                [(n, vp) for n in ('d_enc', 'wq', 'wk', 'wv', 'wo', 'ws', 'dpre_s', 'dout', 'dqkv', 'dwn', 'dbn', 'dwv3')])
+                [('d_enc', vp), ('d_enc_f32', ci)] +
+                [(n, vp) for n in ('wq', 'wk', 'wv', 'wo', 'ws', 'dpre_s', 'dout', 'dqkv', 'dwn', 'dbn', 'dwv3')])
 
 
 class AgentIntArgs(ctypes.Structure):
     """struct stj_agent_int_args (include/strajnet_hip.h)"""
     _fields_ = ([('enc', vp), ('cmi', vp), ('n_obs', ci), ('n_occ', ci), ('B', ci), ('dtype', ci)] +
-                [(n, vp) for n in ('pack', 'seg', 'bo', 'g1', 'be1', 'b1', 'b2', 'g2', 'be2', 'g_obs', 'b_obs', 'g_occ', 'b_occ', 'key',
+                [(n, vp) for n in ('pack', 'seg', 'bo', 'g1', 'be1', 'b1', 'b2', 'g2', 'be2', 'g_obs', 'b_obs', 'g_occ', 'b_occ', 'key', 'ws_v1', 'ws_u2',
                                    's_concat', 's_qin', 's_q', 's_k', 's_v', 's_att', 's_v1', 's_n1', 's_h', 's_u2', 's_out', 'rng_state')] +
                 [('site_a', ci), ('site_1', ci), ('site_2', ci), ('p_drop', cf)] +
-                [(n, vp) for n in ('dkey', 'wq', 'wk', 'wv', 'wo', 'w1', 'w2', 'd_enc', 'dq', 'dk', 'dv', 'dv1', 'dpre1', 'dz2',
+                [(n, vp) for n in ('dkey', 'wq', 'wk', 'wv', 'wo', 'w1', 'w2', 'd_enc', 'ws_dn1', 'dq', 'dk', 'dv', 'dv1', 'dpre1', 'dz2',
                                    'dseg', 'dg1', 'dbe1', 'dg2', 'dbe2', 'dg_obs', 'db_obs', 'dg_occ', 'db_occ')])
 
 _lib = None

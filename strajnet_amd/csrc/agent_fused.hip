@@ -92,10 +92,21 @@ __device__ __forceinline__ void gemm_cols(WP wp, const T* X, int ldx, int xk0, i
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // the activation fragments one k-step ahead, and no further (left alone the scheduler hoists every LDS read of the unit: 192 registers)
+    typename M::Frag bf[MT], bn[MT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+    for (int mt = 0; mt < MT; ++mt) bf[mt] = M::load(X, ldx, mt * 16, xk0 + kc * KS * M::KSTEP, lane);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = M::mma(a[s], M::load(X, ldx, mt * 16, xk0 + (kc * KS + s) * M::KSTEP, lane), acc[mt]);
+    for (int s = 0; s < KS; ++s) {
+      const int sn = s + 1 < KS ? s + 1 : s;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bn[mt] = M::load(X, ldx, mt * 16, xk0 + (kc * KS + sn) * M::KSTEP, lane);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = M::mma(a[s], bf[mt], acc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bf[mt] = bn[mt];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (kc == NKC - 1) ep(w0 + (u / NKC) * nw, acc);
 #pragma unroll
     for (int s = 0; s < KS; ++s) a[s] = an[s];
@@ -115,10 +126,20 @@ __device__ __forceinline__ void gemm_cols_acc(WP wp, const T* X, int ldx, int xk
     const int jn = j + 1 < NCT ? j + 1 : j;
 #pragma unroll
     for (int s = 0; s < KS; ++s) an[s] = M::from_global(wp((w0 + jn * nw) * 16 + ln, s) + M::LANE_K * g);
+    typename M::Frag bf[MT], bn[MT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+    for (int mt = 0; mt < MT; ++mt) bf[mt] = M::load(X, ldx, mt * 16, xk0, lane);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[j][mt] = M::mma(a[s], M::load(X, ldx, mt * 16, xk0 + s * M::KSTEP, lane), acc[j][mt]);
+    for (int s = 0; s < KS; ++s) {
+      const int sn = s + 1 < KS ? s + 1 : s;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bn[mt] = M::load(X, ldx, mt * 16, xk0 + sn * M::KSTEP, lane);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[j][mt] = M::mma(a[s], bf[mt], acc[j][mt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bf[mt] = bn[mt];
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) a[s] = an[s];
   }
@@ -176,7 +197,7 @@ struct EncArgs {
   void* s_nodes; void* s_qkv; void* s_att; unsigned short* s_pmask; void* s_cat;                // training: what backward reads (NULL: not written)
   const long long* rng; int site; float p_drop;
   // backward
-  const void* d_enc; const void* wq; const void* wk; const void* wv; const void* wo; const void* ws;      // natural-layout weights, activation dtype
+  const void* d_enc; int d_enc_f32; const void* wq; const void* wk; const void* wv; const void* wo; const void* ws;      // natural-layout weights, activation dtype
   void* dpre_s; void* dout; void* dqkv;                                                            // dY of the sublayer / projection / q|k|v layers
   float* dwn; float* dbn; float* dwv3;
 };
@@ -393,7 +414,10 @@ __global__ __launch_bounds__(256) void agent_enc_bwd_kernel(EncArgs p) {
   for (int i = tid; i < AG * (CB / V); i += 256) {
     const int ag = i / (CB / V), c = (i % (CB / V)) * V;
     float d[V], y[V];
-    ld16(reinterpret_cast<const T*>(p.d_enc) + (long long)(a0 + ag) * CB + c, d);
+    if (p.d_enc_f32) {
+#pragma unroll
+      for (int e = 0; e < V; e += 4) ld4(reinterpret_cast<const float*>(p.d_enc) + (long long)(a0 + ag) * CB + c + e, d + e);
+    } else ld16(reinterpret_cast<const T*>(p.d_enc) + (long long)(a0 + ag) * CB + c, d);
     ld16(reinterpret_cast<const T*>(p.enc) + (long long)(a0 + ag) * CB + c, y);
 #pragma unroll
     for (int e = 0; e < V; ++e) d[e] *= y[e] > 0.f ? 1.f : y[e] + 1.f;
@@ -522,8 +546,12 @@ template <typename T> static size_t enc_bwd_lds() {
 
 // =====================================================================================================================================
 // interaction block: Cross_Attention over the 64 agents of a scene + FFN + residual + obs_norm | occ_norm (trajNet.py:65-87,135-187)
-// 16-bit storage types only (the f32 tiles do not fit LDS: the parity mode keeps the layer-by-layer chain for this block).
-// One workgroup (8 waves) per scene.
+// 16-bit storage types only (the parity mode keeps the layer-by-layer chain for this block).
+// A first version ran ONE workgroup per scene through the whole block: correct, and 211 us forward / 265 us backward at B = 8 -- eight
+// CUs each streaming all 3.5 MB of weights behind ~45 dependent fetch -> multiply units per wave (profiles/r06_b_agent_fused_prof_v1.txt).
+// The block is therefore cut where its weights can be spread: (scene, head) workgroups for the attention (0.2 MB of weights each) whose
+// output-projection partials meet in an f32 accumulator (atomics), (scene, hidden chunk) workgroups for the FFN (0.6 MB each) whose FFN2
+// partials meet the same way, and a row-wise tail; three launches per direction, no workgroup waits for another.
 // =====================================================================================================================================
 template <typename T> struct IGeo {
   static constexpr int PAD = LdsPad<T>::P;
@@ -531,6 +559,7 @@ template <typename T> struct IGeo {
   static constexpr int LDH = IDH + PAD;               // per-head tiles [64][LDH]
   static constexpr int XR = NA + 16;                  // rows of the projection input: 64 agents + a tile holding the two segment-embedding rows
   static constexpr int NW = 8;
+  static constexpr int NC = FF / CB;                  // hidden chunks (workgroups per scene in the FFN kernels)
 };
 
 struct IntArgs {
@@ -539,11 +568,14 @@ struct IntArgs {
   const float* bo; const float* g1; const float* be1; const float* b1; const float* b2; const float* g2; const float* be2;
   const float* go; const float* beo; const float* gc; const float* bec;                      // obs_norm | occ_norm
   void* key;
-  void* s_concat; void* s_qin; void* s_q; void* s_k; void* s_v; void* s_att; void* s_v1; void* s_n1; void* s_h; void* s_u2; void* s_out;
+  float* v1acc; float* u2acc; void* n1;              // workspaces: [B 64][384] f32 x 2 (zeroed by the caller), n1 [B 64][384] (= s_n1 in training)
+  void* s_concat; void* s_qin; void* s_q; void* s_k; void* s_v; void* s_att; void* s_v1; void* s_h; void* s_u2; void* s_out;
   const long long* rng; int site_a, site_1, site_2; float p_drop;
   // backward
   const void* dkey; const void* wq; const void* wk; const void* wv; const void* wo; const void* w1; const void* w2;
-  void* d_enc; void* dq; void* dk; void* dv; void* dv1; void* dpre1; void* dz2;
+  float* d_enc;                                      // [B 64][384] f32: written by the tail kernel, accumulated by the attention kernel
+  float* dn1acc;                                     // [B 64][384] f32, zeroed by the caller
+  void* dq; void* dk; void* dv; void* dv1; void* dpre1; void* dz2;
   float* dseg; float* dg1; float* dbe1; float* dg2; float* dbe2; float* dgo; float* dbeo; float* dgc; float* dbec;
 };
 
@@ -613,26 +645,25 @@ __device__ __forceinline__ void int_probs(const T* HQ, const T* HK, int ldh, int
   }
 }
 
+// ---- forward 1: workgroup = (scene, head): concat / embed, q | k | v of the head, attention, the head's share of the output projection
 template <typename T>
-__global__ __launch_bounds__(512) void agent_int_fwd_kernel(IntArgs p) {
+__global__ __launch_bounds__(512) void agent_int_attn_fwd_kernel(IntArgs p) {
   typedef IGeo<T> G;
   typedef Mma<T> M;
   constexpr int LD = G::LD, LDH = G::LDH, NW = G::NW, V = Vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) unsigned char ag_smem[];
-  T* XC = reinterpret_cast<T*>(ag_smem);                          // [80][LD] concat rows + the two segment rows; later v1 / n1
+  T* XC = reinterpret_cast<T*>(ag_smem);                          // [80][LD] concat rows + the two segment rows
   T* HQ = XC + G::XR * LD;                                        // [64][LDH] x 3
   T* HK = HQ + NA * LDH;
   T* HV = HK + NA * LDH;
-  T* ATT = HV + NA * LDH;                                         // [64][LD] attention output; later the hidden chunk, then u2
-  int* kval = reinterpret_cast<int*>(ATT + NA * LD);              // [64]
+  T* OH = HV + NA * LDH;                                          // [64][LDH] attention output of the head
+  int* kval = reinterpret_cast<int*>(OH + NA * LDH);              // [64]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x / IH, h = blockIdx.x % IH;
   const long long r0 = (long long)b * NA;                         // first row of the scene in the [B 64][.] tensors
   const T* pk = reinterpret_cast<const T*>(p.pack);
   const T* enc = reinterpret_cast<const T*>(p.enc) + r0 * CB;
-  const bool train = p.s_q != nullptr;
-  const bool drop = p.rng != nullptr && p.p_drop > 0.f;
-  const float dsc = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  const bool train = p.s_q != nullptr, lead = train && h == 0;
 
   if (tid < NA) kval[tid] = p.cmi[r0 + tid];
   for (int i = tid; i < G::XR * (CB / V); i += 512) {
@@ -644,7 +675,7 @@ __global__ __launch_bounds__(512) void agent_int_fwd_kernel(IntArgs p) {
 #pragma unroll
       for (int e = 0; e < V; ++e) v[e] *= cm;
       st16(XC + row * LD + c, v);
-      if (train) {
+      if (lead) {
         st16(reinterpret_cast<T*>(p.s_concat) + (r0 + row) * CB + c, v);
         float em[V];
         ld16(reinterpret_cast<const T*>(p.seg) + (row < p.n_obs ? 0 : CB) + c, em);
@@ -660,287 +691,322 @@ __global__ __launch_bounds__(512) void agent_int_fwd_kernel(IntArgs p) {
     }
   }
   __syncthreads();
-
-  // ---- attention, head by head
-#pragma unroll 1
-  for (int h = 0; h < IH; ++h) {
-    // q = (concat + embed) Wq: the embedding's two distinct rows ride as a fifth token tile and are added per segment
-    gemm_cols<T, 5, CB, CB>([&](int row, int s) { return pk + P_IQKV + ((long long)(h * IDH + row)) * CB + s * M::KSTEP; }, XC, LD, 0, IDH / 16, wv, NW, lane,
-                            [&](int ct, f32x4 (&acc)[5]) {
+  // q | k | v of the head: 12 column tiles; q = (concat + embed) Wq -- the embedding's two distinct rows ride as a fifth token tile and are added per segment
+  gemm_cols<T, 5, CB, CB>(
+      [&](int row, int s) { return pk + P_IQKV + ((long long)((row >> 6) * CB + h * IDH + (row & 63))) * CB + s * M::KSTEP; }, XC, LD, 0, 3 * IDH / 16, wv, NW,
+      lane, [&](int ct, f32x4 (&acc)[5]) {
+        const int m = ct >> 2, c0 = (ct & 3) * 16 + 4 * g;
+        T* HT = HQ + m * (NA * LDH);                         // HQ | HK | HV are adjacent (a select between LDS pointers put the staging arrays in scratch)
+        T* sv = reinterpret_cast<T*>(m == 0 ? p.s_q : (m == 1 ? p.s_k : p.s_v));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int tok = mt * 16 + ln, src = (lane & 48) | (tok < p.n_obs ? 0 : 1);
+          f32x4 q = acc[mt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __shfl(acc[4][r], src, 64);
+            if (m == 0) q[r] += e;
+          }
+          st_acc(HT + tok * LDH + c0, q);
+          if (train) st_acc(sv + (r0 + tok) * CB + h * IDH + c0, q);
+        }
+      });
+  __syncthreads();
+  {
+    const int qt = wv & 3, half = wv >> 2;                     // the two waves of a query tile share its probabilities, each takes half of the head columns
+    f32x4 st[4];
+    float f[4][4];
+    int_probs<T>(HQ, HK, LDH, qt, kval, (long long)b * IH + h, p.rng, p.site_a, p.p_drop, lane, st, f);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[jt][r] *= f[jt][r];
+    f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < NA / M::KSTEP; ++s) {
+      const typename Ch<T>::Frag pf = Ch<T>::from_acc(&st[s * Ch<T>::ND]);       // O^T = V^T P^T, P^T chained from the accumulators
+#pragma unroll
+      for (int jd = 0; jd < 2; ++jd) o[jd] = M::mma(Ch<T>::ldA_tr(HV, LDH, 16 * (2 * half + jd), s * M::KSTEP, lane), pf, o[jd]);
+    }
+#pragma unroll
+    for (int jd = 0; jd < 2; ++jd) {
+      const int c0 = 16 * (2 * half + jd) + 4 * g;
+      st_acc(OH + (qt * 16 + ln) * LDH + c0, o[jd]);
+      if (train) st_acc(reinterpret_cast<T*>(p.s_att) + (r0 + qt * 16 + ln) * CB + h * IDH + c0, o[jd]);
+    }
+  }
+  __syncthreads();
+  // the head's share of v1 = att Wo: K = its 64 columns; the six heads meet in the f32 accumulator
+  gemm_cols<T, 4, IDH, IDH>([&](int row, int s) { return pk + P_IWO + (long long)row * CB + h * IDH + s * M::KSTEP; }, OH, LDH, 0, CB / 16, wv, NW, lane,
+                            [&](int ct, f32x4 (&acc)[4]) {
 #pragma unroll
                               for (int mt = 0; mt < 4; ++mt) {
-                                const int tok = mt * 16 + ln, src = (lane & 48) | (tok < p.n_obs ? 0 : 1);
-                                f32x4 q;
+                                float* d = p.v1acc + (r0 + mt * 16 + ln) * CB + ct * 16 + 4 * g;
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) q[r] = acc[mt][r] + __shfl(acc[4][r], src, 64);
-                                st_acc(HQ + tok * LDH + ct * 16 + 4 * g, q);
-                                if (train) st_acc(reinterpret_cast<T*>(p.s_q) + (r0 + tok) * CB + h * IDH + ct * 16 + 4 * g, q);
+                                for (int r = 0; r < 4; ++r) atomicAdd(d + r, acc[mt][r]);
                               }
                             });
-#pragma unroll
-    for (int m = 1; m < 3; ++m) {
-      T* HT = m == 1 ? HK : HV;
-      T* sv = reinterpret_cast<T*>(m == 1 ? p.s_k : p.s_v);
-      gemm_cols<T, 4, CB, CB>([&](int row, int s) { return pk + P_IQKV + ((long long)(m * CB + h * IDH + row)) * CB + s * M::KSTEP; }, XC, LD, 0, IDH / 16,
-                              (wv + 4) & 7, NW, lane, [&](int ct, f32x4 (&acc)[4]) {
-#pragma unroll
-                                for (int mt = 0; mt < 4; ++mt) {
-                                  const int tok = mt * 16 + ln;
-                                  st_acc(HT + tok * LDH + ct * 16 + 4 * g, acc[mt]);
-                                  if (train) st_acc(sv + (r0 + tok) * CB + h * IDH + ct * 16 + 4 * g, acc[mt]);
-                                }
-                              });
-    }
-    __syncthreads();
-    {
-      const int qt = wv & 3, half = wv >> 2;                     // the two waves of a query tile share its probabilities, each takes half of the head columns
-      f32x4 st[4];
-      float f[4][4];
-      int_probs<T>(HQ, HK, LDH, qt, kval, (long long)b * IH + h, p.rng, p.site_a, p.p_drop, lane, st, f);
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st[jt][r] *= f[jt][r];
-      f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int s = 0; s < NA / M::KSTEP; ++s) {
-        const typename Ch<T>::Frag pf = Ch<T>::from_acc(&st[s * Ch<T>::ND]);       // O^T = V^T P^T, P^T chained from the accumulators
-#pragma unroll
-        for (int jd = 0; jd < 2; ++jd) o[jd] = M::mma(Ch<T>::ldA_tr(HV, LDH, 16 * (2 * half + jd), s * M::KSTEP, lane), pf, o[jd]);
-      }
-#pragma unroll
-      for (int jd = 0; jd < 2; ++jd) st_acc(ATT + (qt * 16 + ln) * LD + h * IDH + 16 * (2 * half + jd) + 4 * g, o[jd]);
-    }
-    __syncthreads();
-  }
-  if (train) rows_to_global(ATT, LD, reinterpret_cast<T*>(p.s_att) + r0 * CB, CB, NA, CB, tid, 512);
+}
+template <typename T> static size_t int_attn_fwd_lds() {
+  typedef IGeo<T> G;
+  return sizeof(T) * ((size_t)G::XR * G::LD + 4 * NA * G::LDH) + NA * 4;
+}
 
-  // ---- v1 = att Wo + bo  (into the dead projection-input tile)
-  T* V1 = XC;
-  gemm_cols<T, 4, CB, CB>([&](int row, int s) { return pk + P_IWO + (long long)row * CB + s * M::KSTEP; }, ATT, LD, 0, CB / 16, wv, NW, lane,
+// ---- forward 2: workgroup = (scene, hidden chunk): v1 = acc + bo, n1 = LayerNorm(v1); the chunk's hidden columns; its share of FFN2
+template <typename T>
+__global__ __launch_bounds__(512) void agent_int_ffn_fwd_kernel(IntArgs p) {
+  typedef IGeo<T> G;
+  typedef Mma<T> M;
+  constexpr int LD = G::LD, NW = G::NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ag_smem[];
+  T* N1 = reinterpret_cast<T*>(ag_smem);                          // [64][LD]
+  T* HC = N1 + NA * LD;                                           // [64][LD] hidden chunk
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / G::NC, c = blockIdx.x % G::NC;
+  const long long r0 = (long long)b * NA;
+  const T* pk = reinterpret_cast<const T*>(p.pack);
+  const bool train = p.s_h != nullptr, lead = c == 0;
+  const bool drop = p.rng != nullptr && p.p_drop > 0.f;
+  const float dsc = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  for (int row = wv; row < NA; row += NW) {
+    float v[3][2], mu, rs;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int cc = rcol(j, lane, 0);
+      const float2 a = *reinterpret_cast<const float2*>(p.v1acc + (r0 + row) * CB + cc);
+      v[j][0] = rnd<T>(a.x + p.bo[cc]); v[j][1] = rnd<T>(a.y + p.bo[cc + 1]);
+      if (lead && train) *reinterpret_cast<uint32_t*>(reinterpret_cast<T*>(p.s_v1) + (r0 + row) * CB + cc) = pack2<T>(v[j][0], v[j][1]);
+    }
+    row_stats(v, 1e-3f, mu, rs);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int cc = rcol(j, lane, 0);
+      const uint32_t w = pack2<T>((v[j][0] - mu) * rs * p.g1[cc] + p.be1[cc], (v[j][1] - mu) * rs * p.g1[cc + 1] + p.be1[cc + 1]);
+      *reinterpret_cast<uint32_t*>(N1 + row * LD + cc) = w;
+      if (lead && p.n1) *reinterpret_cast<uint32_t*>(reinterpret_cast<T*>(p.n1) + (r0 + row) * CB + cc) = w;
+    }
+  }
+  __syncthreads();
+  gemm_cols<T, 4, CB, CB>([&](int row, int s) { return pk + P_IW1 + ((long long)(c * CB + row)) * CB + s * M::KSTEP; }, N1, LD, 0, CB / 16, wv, NW, lane,
                           [&](int ct, f32x4 (&acc)[4]) {
-                            const float4 b4 = *reinterpret_cast<const float4*>(p.bo + ct * 16 + 4 * g);
+                            const int col = c * CB + ct * 16 + 4 * g;
+                            const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + col);
+                            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                             for (int mt = 0; mt < 4; ++mt) {
-                              const f32x4 v = {acc[mt][0] + b4.x, acc[mt][1] + b4.y, acc[mt][2] + b4.z, acc[mt][3] + b4.w};
-                              st_acc(V1 + (mt * 16 + ln) * LD + ct * 16 + 4 * g, v);
+                              const int tok = mt * 16 + ln;
+                              float f[4] = {1.f, 1.f, 1.f, 1.f};
+                              if (drop) keep_scale4(p.rng, p.site_1, (r0 + tok) * FF + col, p.p_drop, dsc, f);
+                              f32x4 hv;
+#pragma unroll
+                              for (int r = 0; r < 4; ++r) hv[r] = rnd<T>(elu_t<T>(acc[mt][r] + bb[r])) * f[r];
+                              st_acc(HC + tok * LD + ct * 16 + 4 * g, hv);
+                              if (train) st_acc(reinterpret_cast<T*>(p.s_h) + (r0 + tok) * FF + col, hv);
                             }
                           });
   __syncthreads();
-  if (train) rows_to_global(V1, LD, reinterpret_cast<T*>(p.s_v1) + r0 * CB, CB, NA, CB, tid, 512);
-  __syncthreads();
-  // ---- n1 = LayerNorm(v1), in place
-  for (int row = wv; row < NA; row += NW) {
-    float v[3][2], mu, rs;
+  gemm_cols<T, 4, CB, CB>([&](int row, int s) { return pk + P_IW2 + (long long)row * FF + c * CB + s * M::KSTEP; }, HC, LD, 0, CB / 16, wv, NW, lane,
+                          [&](int ct, f32x4 (&acc)[4]) {
 #pragma unroll
-    AGF_ROW(j, e) v[j][e] = ldf(V1 + row * LD + rcol(j, lane, e));
-    row_stats(v, 1e-3f, mu, rs);
+                            for (int mt = 0; mt < 4; ++mt) {
+                              float* d = p.u2acc + (r0 + mt * 16 + ln) * CB + ct * 16 + 4 * g;
 #pragma unroll
-    AGF_ROW(j, e) { const int c = rcol(j, lane, e); stf(V1 + row * LD + c, (v[j][e] - mu) * rs * p.g1[c] + p.be1[c]); }
-  }
-  __syncthreads();
-  if (train) rows_to_global(V1, LD, reinterpret_cast<T*>(p.s_n1) + r0 * CB, CB, NA, CB, tid, 512);
+                              for (int r = 0; r < 4; ++r) atomicAdd(d + r, acc[mt][r]);
+                            }
+                          });
+}
+template <typename T> static size_t int_ffn_lds() { return sizeof(T) * (size_t)2 * NA * IGeo<T>::LD; }
 
-  // ---- FFN: u2 = dropout(dropout(elu(n1 W1 + b1)) W2 + b2), the hidden layer in four chunks of 384 columns
-  T* HC = ATT;
-  f32x4 u2[3][4];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) u2[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int c = 0; c < FF / CB; ++c) {
-    gemm_cols<T, 4, CB, CB>([&](int row, int s) { return pk + P_IW1 + ((long long)(c * CB + row)) * CB + s * M::KSTEP; }, V1, LD, 0, CB / 16, wv, NW, lane,
-                            [&](int ct, f32x4 (&acc)[4]) {
-                              const int col = c * CB + ct * 16 + 4 * g;
-                              const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + col);
-                              const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-                              for (int mt = 0; mt < 4; ++mt) {
-                                const int tok = mt * 16 + ln;
-                                float f[4] = {1.f, 1.f, 1.f, 1.f};
-                                if (drop) keep_scale4(p.rng, p.site_1, (r0 + tok) * FF + col, p.p_drop, dsc, f);
-                                f32x4 hv;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) hv[r] = rnd<T>(elu_t<T>(acc[mt][r] + bb[r])) * f[r];
-                                st_acc(HC + tok * LD + ct * 16 + 4 * g, hv);
-                                if (train) st_acc(reinterpret_cast<T*>(p.s_h) + (r0 + tok) * FF + col, hv);
-                              }
-                            });
-    __syncthreads();
-    gemm_cols_acc<T, 4, CB, 3>([&](int row, int s) { return pk + P_IW2 + (long long)row * FF + c * CB + s * M::KSTEP; }, HC, LD, 0, wv, NW, lane, u2);
-    __syncthreads();
-  }
-  T* U2 = ATT;
+// ---- forward 3 (row-wise, a wave per agent row): u2 = dropout(acc + b2); value = LayerNorm(u2); out = enc + value + embed; key = obs_norm | occ_norm (out)
+template <typename T>
+__global__ __launch_bounds__(256) void agent_int_out_fwd_kernel(IntArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (row >= (long long)p.B * NA) return;
+  const bool ob = (int)(row % NA) < p.n_obs;
+  const bool drop = p.rng != nullptr && p.p_drop > 0.f;
+  const float dsc = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  float v[3][2], mu, rs;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int col = (wv + j * NW) * 16 + 4 * g;
-    const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + col);
-    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int tok = mt * 16 + ln;
-      float f[4] = {1.f, 1.f, 1.f, 1.f};
-      if (drop) keep_scale4(p.rng, p.site_2, (r0 + tok) * CB + col, p.p_drop, dsc, f);
-      f32x4 uv;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) uv[r] = rnd<T>(u2[j][mt][r] + bb[r]) * f[r];
-      st_acc(U2 + tok * LD + col, uv);
+    const int c = rcol(j, lane, 0);
+    const float2 a = *reinterpret_cast<const float2*>(p.u2acc + row * CB + c);
+    float f0 = 1.f, f1 = 1.f;
+    if (drop) {
+      bool k4[4];
+      const long long idx = row * CB + c;
+      keep4(p.rng, p.site_2, idx >> 2, p.p_drop, k4);
+      f0 = k4[idx & 3] ? dsc : 0.f; f1 = k4[(idx & 3) + 1] ? dsc : 0.f;
     }
+    v[j][0] = rnd<T>(rnd<T>(a.x + p.b2[c]) * f0); v[j][1] = rnd<T>(rnd<T>(a.y + p.b2[c + 1]) * f1);
+    if (p.s_u2) *reinterpret_cast<uint32_t*>(reinterpret_cast<T*>(p.s_u2) + row * CB + c) = pack2<T>(v[j][0], v[j][1]);
   }
-  __syncthreads();
-  if (train) rows_to_global(U2, LD, reinterpret_cast<T*>(p.s_u2) + r0 * CB, CB, NA, CB, tid, 512);
-  // ---- value = LayerNorm(u2); out = enc + value + embed; key = obs_norm | occ_norm (out)
-  for (int row = wv; row < NA; row += NW) {
-    const bool ob = row < p.n_obs;
-    float v[3][2], mu, rs;
+  row_stats(v, 1e-3f, mu, rs);
 #pragma unroll
-    AGF_ROW(j, e) v[j][e] = ldf(U2 + row * LD + rcol(j, lane, e));
-    row_stats(v, 1e-3f, mu, rs);
+  AGF_ROW(j, e) {
+    const int c = rcol(j, lane, e);
+    const float val = rnd<T>((v[j][e] - mu) * rs * p.g2[c] + p.be2[c]);
+    const float t = rnd<T>(ldf(reinterpret_cast<const T*>(p.enc) + row * CB + c) + val);                      // (enc + value) rounded, then + embed: the order of the two adds
+    v[j][e] = rnd<T>(t + ldf(reinterpret_cast<const T*>(p.seg) + (ob ? 0 : CB) + c));
+    if (p.s_out) stf(reinterpret_cast<T*>(p.s_out) + row * CB + c, v[j][e]);
+  }
+  row_stats(v, 1e-3f, mu, rs);
+  const float* gm = ob ? p.go : p.gc;
+  const float* bt = ob ? p.beo : p.bec;
+#pragma unroll
+  AGF_ROW(j, e) { const int c = rcol(j, lane, e); stf(reinterpret_cast<T*>(p.key) + row * CB + c, (v[j][e] - mu) * rs * gm[c] + bt[c]); }
+}
+
+// ---- backward 1 (row-wise; a workgroup = 4 waves x 4 rows of ONE segment): obs_norm | occ_norm backward -> dout (d_enc's residual share, d_embed);
+// LayerNorm2 backward; dropout2 -> dz2
+template <typename T>
+__global__ __launch_bounds__(256) void agent_int_out_bwd_kernel(IntArgs p) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool drop = p.rng != nullptr && p.p_drop > 0.f;
+  const float dsc = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  float ag[2][3][2], ab[2][3][2], ae[2][3][2], ag2[3][2], ab2[3][2];          // gamma / beta of obs | occ, d_embed per segment, gamma2 / beta2
+#pragma unroll
+  AGF_ROW(j, e) { ag[0][j][e] = ag[1][j][e] = ab[0][j][e] = ab[1][j][e] = ae[0][j][e] = ae[1][j][e] = ag2[j][e] = ab2[j][e] = 0.f; }
+  const long long nrows = (long long)p.B * NA;
+  for (long long row = blockIdx.x * 16ll + wv; row < nrows && row < (blockIdx.x + 1) * 16ll; row += 4) {
+    const int sg = (int)(row % NA) < p.n_obs ? 0 : 1;
+    const float* gm = sg ? p.gc : p.go;
+    float x[3][2], xh[3][2], t[3][2], d[3][2], mu, rs;
+#pragma unroll
+    AGF_ROW(j, e) x[j][e] = ldf(reinterpret_cast<const T*>(p.s_out) + row * CB + rcol(j, lane, e));
+    row_stats(x, 1e-3f, mu, rs);
 #pragma unroll
     AGF_ROW(j, e) {
       const int c = rcol(j, lane, e);
-      const float val = rnd<T>((v[j][e] - mu) * rs * p.g2[c] + p.be2[c]);
-      const float t = rnd<T>(ldf(enc + (long long)row * CB + c) + val);                      // (enc + value) rounded, then + embed: the order of the two adds
-      v[j][e] = rnd<T>(t + ldf(reinterpret_cast<const T*>(p.seg) + (ob ? 0 : CB) + c));
-      if (train) stf(reinterpret_cast<T*>(p.s_out) + (r0 + row) * CB + c, v[j][e]);
+      const float dy = ldf(reinterpret_cast<const T*>(p.dkey) + row * CB + c);
+      xh[j][e] = (x[j][e] - mu) * rs;
+      ag[sg][j][e] += dy * xh[j][e]; ab[sg][j][e] += dy;
+      t[j][e] = dy * gm[c];
     }
-    row_stats(v, 1e-3f, mu, rs);
-    const float* gm = ob ? p.go : p.gc;
-    const float* bt = ob ? p.beo : p.bec;
+    row_ln_bwd(xh, t, rs, d);
 #pragma unroll
-    AGF_ROW(j, e) { const int c = rcol(j, lane, e); stf(reinterpret_cast<T*>(p.key) + (r0 + row) * CB + c, (v[j][e] - mu) * rs * gm[c] + bt[c]); }
+    for (int j = 0; j < 3; ++j) {
+      d[j][0] = rnd<T>(d[j][0]); d[j][1] = rnd<T>(d[j][1]);
+      ae[sg][j][0] += d[j][0]; ae[sg][j][1] += d[j][1];
+      *reinterpret_cast<float2*>(p.d_enc + row * CB + rcol(j, lane, 0)) = make_float2(d[j][0], d[j][1]);   // the residual's share; the attention kernel adds its own
+    }
+    // value = LayerNorm2(u2)
+#pragma unroll
+    AGF_ROW(j, e) x[j][e] = ldf(reinterpret_cast<const T*>(p.s_u2) + row * CB + rcol(j, lane, e));
+    row_stats(x, 1e-3f, mu, rs);
+#pragma unroll
+    AGF_ROW(j, e) {
+      const int c = rcol(j, lane, e);
+      xh[j][e] = (x[j][e] - mu) * rs;
+      ag2[j][e] += d[j][e] * xh[j][e]; ab2[j][e] += d[j][e];
+      t[j][e] = d[j][e] * p.g2[c];
+    }
+    float du[3][2];
+    row_ln_bwd(xh, t, rs, du);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c = rcol(j, lane, 0);
+      if (drop) {                                              // dropout2: the two columns of a lane share a draw group (c even; group of 4)
+        bool k4[4];
+        const long long idx = row * CB + c;
+        keep4(p.rng, p.site_2, idx >> 2, p.p_drop, k4);
+        du[j][0] *= k4[idx & 3] ? dsc : 0.f; du[j][1] *= k4[(idx & 3) + 1] ? dsc : 0.f;
+      }
+      *reinterpret_cast<uint32_t*>(reinterpret_cast<T*>(p.dz2) + row * CB + c) = pack2<T>(du[j][0], du[j][1]);
+    }
+  }
+  // the workgroup's 16 rows -> LDS -> one atomic per column and array
+  __shared__ float red[4][8][CB];
+#pragma unroll
+  AGF_ROW(j, e) {
+    const int c = rcol(j, lane, e);
+    red[wv][0][c] = ag[0][j][e]; red[wv][1][c] = ab[0][j][e]; red[wv][2][c] = ag[1][j][e]; red[wv][3][c] = ab[1][j][e];
+    red[wv][4][c] = ae[0][j][e]; red[wv][5][c] = ae[1][j][e]; red[wv][6][c] = ag2[j][e]; red[wv][7][c] = ab2[j][e];
+  }
+  __syncthreads();
+  float* const dst[8] = {p.dgo, p.dbeo, p.dgc, p.dbec, p.dseg, p.dseg + CB, p.dg2, p.dbe2};
+  for (int i = threadIdx.x; i < 8 * CB; i += 256) {
+    const int a = i / CB, c = i % CB;
+    const float s = red[0][a][c] + red[1][a][c] + red[2][a][c] + red[3][a][c];
+    if (s != 0.f) atomicAdd(dst[a] + c, s);
   }
 }
-template <typename T> static size_t int_fwd_lds() {
+
+// ---- backward 2: workgroup = (scene, hidden chunk): dh = dz2 W2^T ; dpre = dh * keep * ELU' ; its share of dn1 = dpre W1^T
+template <typename T>
+__global__ __launch_bounds__(512) void agent_int_ffn_bwd_kernel(IntArgs p) {
   typedef IGeo<T> G;
-  return sizeof(T) * ((size_t)G::XR * G::LD + 3 * NA * G::LDH + NA * G::LD) + NA * 4;
+  typedef Mma<T> M;
+  constexpr int LD = G::LD, NW = G::NW, V = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ag_smem[];
+  T* DZ = reinterpret_cast<T*>(ag_smem);                          // [64][LD]
+  T* DP = DZ + NA * LD;                                           // [64][LD]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / G::NC, c = blockIdx.x % G::NC;
+  const long long r0 = (long long)b * NA;
+  const bool drop = p.rng != nullptr && p.p_drop > 0.f;
+  const float dsc = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  for (int i = tid; i < NA * (CB / V); i += 512) {
+    const int row = i / (CB / V), cc = (i % (CB / V)) * V;
+    *reinterpret_cast<uint4*>(DZ + row * LD + cc) = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.dz2) + (r0 + row) * CB + cc);
+  }
+  __syncthreads();
+  gemm_cols<T, 4, CB, CB>([&](int row, int s) { return reinterpret_cast<const T*>(p.w2) + ((long long)(c * CB + row)) * CB + s * M::KSTEP; }, DZ, LD, 0, CB / 16,
+                          wv, NW, lane, [&](int ct, f32x4 (&acc)[4]) {
+                            const int col = c * CB + ct * 16 + 4 * g;
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) {
+                              const int tok = mt * 16 + ln;
+                              float hv[4], f[4] = {1.f, 1.f, 1.f, 1.f};
+                              ld4(reinterpret_cast<const T*>(p.s_h) + (r0 + tok) * FF + col, hv);      // dropout(elu(pre)): elu(pre) / (1 - p) where kept
+                              if (drop) keep_scale4(p.rng, p.site_1, (r0 + tok) * FF + col, p.p_drop, dsc, f);
+                              f32x4 dp;
+#pragma unroll
+                              for (int r = 0; r < 4; ++r) {
+                                const float y = drop ? hv[r] * (1.f - p.p_drop) : hv[r];                  // elu(pre)
+                                dp[r] = acc[mt][r] * f[r] * (y > 0.f ? 1.f : y + 1.f);
+                              }
+                              st_acc(DP + tok * LD + ct * 16 + 4 * g, dp);
+                              st_acc(reinterpret_cast<T*>(p.dpre1) + (r0 + tok) * FF + col, dp);
+                            }
+                          });
+  __syncthreads();
+  gemm_cols<T, 4, CB, CB>([&](int row, int s) { return reinterpret_cast<const T*>(p.w1) + (long long)row * FF + c * CB + s * M::KSTEP; }, DP, LD, 0, CB / 16, wv, NW,
+                          lane, [&](int ct, f32x4 (&acc)[4]) {
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) {
+                              float* d = p.dn1acc + (r0 + mt * 16 + ln) * CB + ct * 16 + 4 * g;
+#pragma unroll
+                              for (int r = 0; r < 4; ++r) atomicAdd(d + r, acc[mt][r]);
+                            }
+                          });
 }
 
-// ---- backward ---------------------------------------------------------------------------------------------------------------------------
+// ---- backward 3: workgroup = (scene, head): LayerNorm1 backward (every head for itself; head 0 publishes dv1 and the parameter gradients),
+// the head's datt = dv1 Wo[h]^T, attention backward, dq | dk | dv, and the head's share of d(qin), d(concat) -> d_enc, d_embed
 template <typename T>
-__global__ __launch_bounds__(512) void agent_int_bwd_kernel(IntArgs p) {
+__global__ __launch_bounds__(512) void agent_int_attn_bwd_kernel(IntArgs p) {
   typedef IGeo<T> G;
   typedef Mma<T> M;
   constexpr int LD = G::LD, LDH = G::LDH, NW = G::NW, V = Vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) unsigned char ag_smem[];
-  T* R1 = reinterpret_cast<T*>(ag_smem);                          // [64][LD]: dz2 -> dn1 -> dv1; then the per-head tiles q, k, v, dS^T, Pd^T
-  T* R2 = R1 + NA * LD;                                           // [64][LD]: the hidden-chunk gradient; then datt
-  T* DQh = R2 + NA * LD;                                          // [64][LDH] x 3: dq, dk, dv of the head
-  T* DKh = DQh + NA * LDH;
-  T* DVh = DKh + NA * LDH;
+  T* DV1 = reinterpret_cast<T*>(ag_smem);                         // [64][LD]
+  T* HQ = DV1 + NA * LD;                                          // [64][LDH] x 5: q, k, v, dS^T, Pd^T
+  T* HK = HQ + NA * LDH; T* HV = HK + NA * LDH; T* DST = HV + NA * LDH; T* PDT = DST + NA * LDH;
+  T* DAT = PDT + NA * LDH;                                        // [64][LDH] datt of the head
+  T* DQh = DAT + NA * LDH;                                        // [64][LDH] x 3
+  T* DKh = DQh + NA * LDH; T* DVh = DKh + NA * LDH;
   int* kval = reinterpret_cast<int*>(DVh + NA * LDH);
-  static_assert(5 * NA * G::LDH <= NA * G::LD, "the five per-head tiles fit one full-width tile");
-  T* HQ = R1; T* HK = HQ + NA * LDH; T* HV = HK + NA * LDH; T* DST = HV + NA * LDH; T* PDT = DST + NA * LDH;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ln = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x / IH, h = blockIdx.x % IH;
   const long long r0 = (long long)b * NA;
-  const bool drop = p.rng != nullptr && p.p_drop > 0.f;
-  const float dsc = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  const bool lead = h == 0;
   if (tid < NA) kval[tid] = p.cmi[r0 + tid];
-
-  // ---- obs_norm | occ_norm backward -> dout (residual: d_enc part, d_value, d_embed); LayerNorm2 backward; dropout2 -> dz2
-  {
-    float ag[2][3][2], ab[2][3][2], ae[2][3][2], ag2[3][2], ab2[3][2];          // gamma / beta of obs | occ, d_embed per segment, gamma2 / beta2
-#pragma unroll
-    AGF_ROW(j, e) { ag[0][j][e] = ag[1][j][e] = ab[0][j][e] = ab[1][j][e] = ae[0][j][e] = ae[1][j][e] = ag2[j][e] = ab2[j][e] = 0.f; }
-    for (int row = wv; row < NA; row += NW) {
-      const int sg = row < p.n_obs ? 0 : 1;
-      const float* gm = sg ? p.gc : p.go;
-      float x[3][2], xh[3][2], t[3][2], d[3][2], mu, rs;
-#pragma unroll
-      AGF_ROW(j, e) x[j][e] = ldf(reinterpret_cast<const T*>(p.s_out) + (r0 + row) * CB + rcol(j, lane, e));
-      row_stats(x, 1e-3f, mu, rs);
-#pragma unroll
-      AGF_ROW(j, e) {
-        const int c = rcol(j, lane, e);
-        const float dy = ldf(reinterpret_cast<const T*>(p.dkey) + (r0 + row) * CB + c);
-        xh[j][e] = (x[j][e] - mu) * rs;
-        ag[sg][j][e] += dy * xh[j][e]; ab[sg][j][e] += dy;
-        t[j][e] = dy * gm[c];
-      }
-      row_ln_bwd(xh, t, rs, d);
-#pragma unroll
-      AGF_ROW(j, e) {
-        d[j][e] = rnd<T>(d[j][e]);
-        ae[sg][j][e] += d[j][e];
-        stf(reinterpret_cast<T*>(p.d_enc) + (r0 + row) * CB + rcol(j, lane, e), d[j][e]);          // the residual's share; the attention's is added at the end
-      }
-      // value = LayerNorm2(u2)
-#pragma unroll
-      AGF_ROW(j, e) x[j][e] = ldf(reinterpret_cast<const T*>(p.s_u2) + (r0 + row) * CB + rcol(j, lane, e));
-      row_stats(x, 1e-3f, mu, rs);
-#pragma unroll
-      AGF_ROW(j, e) {
-        const int c = rcol(j, lane, e);
-        xh[j][e] = (x[j][e] - mu) * rs;
-        ag2[j][e] += d[j][e] * xh[j][e]; ab2[j][e] += d[j][e];
-        t[j][e] = d[j][e] * p.g2[c];
-      }
-      float du[3][2];
-      row_ln_bwd(xh, t, rs, du);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int c = rcol(j, lane, 0);
-        if (drop) {                                              // dropout2: the two columns of a lane share a draw group (c even; group of 4)
-          bool k4[4];
-          const long long idx = (r0 + row) * CB + c;
-          keep4(p.rng, p.site_2, idx >> 2, p.p_drop, k4);
-          du[j][0] *= k4[idx & 3] ? dsc : 0.f; du[j][1] *= k4[(idx & 3) + 1] ? dsc : 0.f;
-        }
-        const uint32_t w = pack2<T>(du[j][0], du[j][1]);
-        *reinterpret_cast<uint32_t*>(R1 + row * LD + c) = w;
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<T*>(p.dz2) + (r0 + row) * CB + c) = w;
-      }
-    }
-#pragma unroll
-    AGF_ROW(j, e) {
-      const int c = rcol(j, lane, e);
-      atomicAdd(p.dgo + c, ag[0][j][e]); atomicAdd(p.dbeo + c, ab[0][j][e]); atomicAdd(p.dgc + c, ag[1][j][e]); atomicAdd(p.dbec + c, ab[1][j][e]);
-      atomicAdd(p.dseg + c, ae[0][j][e]); atomicAdd(p.dseg + CB + c, ae[1][j][e]);
-      atomicAdd(p.dg2 + c, ag2[j][e]); atomicAdd(p.dbe2 + c, ab2[j][e]);
-    }
+  for (int i = tid; i < 3 * NA * (IDH / V); i += 512) {
+    const int m = i / (NA * (IDH / V)), rem = i % (NA * (IDH / V)), row = rem / (IDH / V), c = (rem % (IDH / V)) * V;
+    const T* src = reinterpret_cast<const T*>(m == 0 ? p.s_q : (m == 1 ? p.s_k : p.s_v)) + (r0 + row) * CB + h * IDH + c;
+    *reinterpret_cast<uint4*>((m == 0 ? HQ : (m == 1 ? HK : HV)) + row * LDH + c) = *reinterpret_cast<const uint4*>(src);
   }
-  __syncthreads();
-
-  // ---- FFN backward, hidden chunk by hidden chunk: dh = dz2 W2^T ; dpre = dh * keep * ELU' ; dn1 += dpre W1^T
-  f32x4 dn[3][4];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) dn[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int c = 0; c < FF / CB; ++c) {
-    gemm_cols<T, 4, CB, CB>([&](int row, int s) { return reinterpret_cast<const T*>(p.w2) + ((long long)(c * CB + row)) * CB + s * M::KSTEP; }, R1, LD, 0, CB / 16,
-                            wv, NW, lane, [&](int ct, f32x4 (&acc)[4]) {
-                              const int col = c * CB + ct * 16 + 4 * g;
-#pragma unroll
-                              for (int mt = 0; mt < 4; ++mt) {
-                                const int tok = mt * 16 + ln;
-                                float hv[4], f[4] = {1.f, 1.f, 1.f, 1.f};
-                                ld4(reinterpret_cast<const T*>(p.s_h) + (r0 + tok) * FF + col, hv);      // dropout(elu(pre)): elu(pre) / (1 - p) where kept
-                                if (drop) keep_scale4(p.rng, p.site_1, (r0 + tok) * FF + col, p.p_drop, dsc, f);
-                                f32x4 dp;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                  const float y = drop ? hv[r] * (1.f - p.p_drop) : hv[r];                  // elu(pre)
-                                  dp[r] = acc[mt][r] * f[r] * (y > 0.f ? 1.f : y + 1.f);
-                                }
-                                st_acc(R2 + tok * LD + ct * 16 + 4 * g, dp);
-                                st_acc(reinterpret_cast<T*>(p.dpre1) + (r0 + tok) * FF + col, dp);
-                              }
-                            });
-    __syncthreads();
-    gemm_cols_acc<T, 4, CB, 3>([&](int row, int s) { return reinterpret_cast<const T*>(p.w1) + (long long)row * FF + c * CB + s * M::KSTEP; }, R2, LD, 0, wv, NW,
-                               lane, dn);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) st_acc(R1 + (mt * 16 + ln) * LD + (wv + j * NW) * 16 + 4 * g, dn[j][mt]);
-  __syncthreads();
-  // ---- LayerNorm1 backward (in place): dv1
   {
     float ag1[3][2], ab1[3][2];
 #pragma unroll
@@ -951,119 +1017,106 @@ __global__ __launch_bounds__(512) void agent_int_bwd_kernel(IntArgs p) {
       AGF_ROW(j, e) x[j][e] = ldf(reinterpret_cast<const T*>(p.s_v1) + (r0 + row) * CB + rcol(j, lane, e));
       row_stats(x, 1e-3f, mu, rs);
 #pragma unroll
-      AGF_ROW(j, e) {
-        const int c = rcol(j, lane, e);
-        const float dy = ldf(R1 + row * LD + c);
-        xh[j][e] = (x[j][e] - mu) * rs;
-        ag1[j][e] += dy * xh[j][e]; ab1[j][e] += dy;
-        t[j][e] = dy * p.g1[c];
+      for (int j = 0; j < 3; ++j) {
+        const int c = rcol(j, lane, 0);
+        const float2 dy = *reinterpret_cast<const float2*>(p.dn1acc + (r0 + row) * CB + c);
+        xh[j][0] = (x[j][0] - mu) * rs; xh[j][1] = (x[j][1] - mu) * rs;
+        ag1[j][0] += dy.x * xh[j][0]; ab1[j][0] += dy.x; ag1[j][1] += dy.y * xh[j][1]; ab1[j][1] += dy.y;
+        t[j][0] = dy.x * p.g1[c]; t[j][1] = dy.y * p.g1[c + 1];
       }
       row_ln_bwd(xh, t, rs, d);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int c = rcol(j, lane, 0);
         const uint32_t w = pack2<T>(d[j][0], d[j][1]);
-        *reinterpret_cast<uint32_t*>(R1 + row * LD + c) = w;
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<T*>(p.dv1) + (r0 + row) * CB + c) = w;
+        *reinterpret_cast<uint32_t*>(DV1 + row * LD + c) = w;
+        if (lead) *reinterpret_cast<uint32_t*>(reinterpret_cast<T*>(p.dv1) + (r0 + row) * CB + c) = w;
       }
     }
+    if (lead) {
 #pragma unroll
-    AGF_ROW(j, e) { const int c = rcol(j, lane, e); atomicAdd(p.dg1 + c, ag1[j][e]); atomicAdd(p.dbe1 + c, ab1[j][e]); }
+      AGF_ROW(j, e) { const int c = rcol(j, lane, e); atomicAdd(p.dg1 + c, ag1[j][e]); atomicAdd(p.dbe1 + c, ab1[j][e]); }
+    }
   }
   __syncthreads();
-  // ---- datt = dv1 Wo^T
-  T* DATT = R2;
-  gemm_cols<T, 4, CB, CB>([&](int row, int s) { return reinterpret_cast<const T*>(p.wo) + (long long)row * CB + s * M::KSTEP; }, R1, LD, 0, CB / 16, wv, NW, lane,
-                          [&](int ct, f32x4 (&acc)[4]) {
+  // datt of the head = dv1 Wo[h]^T  (4 column tiles)
+  gemm_cols<T, 4, CB, CB>([&](int row, int s) { return reinterpret_cast<const T*>(p.wo) + ((long long)(h * IDH + row)) * CB + s * M::KSTEP; }, DV1, LD, 0, IDH / 16,
+                          wv, NW, lane, [&](int ct, f32x4 (&acc)[4]) {
 #pragma unroll
-                            for (int mt = 0; mt < 4; ++mt) st_acc(DATT + (mt * 16 + ln) * LD + ct * 16 + 4 * g, acc[mt]);
+                            for (int mt = 0; mt < 4; ++mt) st_acc(DAT + (mt * 16 + ln) * LDH + ct * 16 + 4 * g, acc[mt]);
                           });
   __syncthreads();
-  // ---- attention backward head by head; d(qin) and d(concat) accumulate in registers over the heads
+  {
+    const int qt = wv & 3, half = wv >> 2;
+    f32x4 st[4];
+    float f[4][4];
+    int_probs<T>(HQ, HK, LDH, qt, kval, (long long)b * IH + h, p.rng, p.site_a, p.p_drop, lane, st, f);
+    // dPd^T[key][query] = sum_c V[key][c] dO[query][c]
+    f32x4 ds[4];
+    float t = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < IDH / M::KSTEP; ++ks)
+        dp = M::mma(M::load(HV, LDH, jt * 16, ks * M::KSTEP, lane), M::load(DAT, LDH, qt * 16, ks * M::KSTEP, lane), dp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ds[jt][r] = dp[r] * f[jt][r]; t += st[jt][r] * ds[jt][r]; }
+    }
+    t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[jt][r] = st[jt][r] * (ds[jt][r] - t) * 0.125f;
+    // dS^T and Pd^T tiles [key][query] for the products that contract over the queries (the two waves of a query tile write half each)
+#pragma unroll
+    for (int jt = 2 * half; jt < 2 * half + 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * jt + 4 * g + r;
+        stf(DST + key * LDH + qt * 16 + ln, ds[jt][r]);
+        stf(PDT + key * LDH + qt * 16 + ln, st[jt][r] * f[jt][r]);
+      }
+    // dQ^T[c][query] = sum_key K[key][c] dS[query][key], dS chained from the registers (half of the head columns per wave)
+    f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < NA / M::KSTEP; ++s) {
+      const typename Ch<T>::Frag sf = Ch<T>::from_acc(&ds[s * Ch<T>::ND]);
+#pragma unroll
+      for (int jd = 0; jd < 2; ++jd) dq[jd] = M::mma(Ch<T>::ldA_tr(HK, LDH, 16 * (2 * half + jd), s * M::KSTEP, lane), sf, dq[jd]);
+    }
+#pragma unroll
+    for (int jd = 0; jd < 2; ++jd) {
+      const int col = 16 * (2 * half + jd) + 4 * g;
+      st_acc(DQh + (qt * 16 + ln) * LDH + col, dq[jd]);
+      st_acc(reinterpret_cast<T*>(p.dq) + (r0 + qt * 16 + ln) * CB + h * IDH + col, dq[jd]);
+    }
+  }
+  __syncthreads();
+  // dK^T[c][key] = sum_query Q[query][c] dS[query][key] ; dV^T[c][key] = sum_query dO[query][c] Pd[query][key]: 32 (matrix, c tile, key tile) units
+  for (int u = wv; u < 32; u += NW) {
+    const int mv = u >> 4, ct = (u >> 2) & 3, jt = u & 3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NA / M::KSTEP; ++ks)
+      acc = M::mma(M::load_tr(mv == 0 ? HQ : DAT, LDH, ct * 16, ks * M::KSTEP, lane), M::load(mv == 0 ? DST : PDT, LDH, jt * 16, ks * M::KSTEP, lane), acc);
+    const int key = jt * 16 + ln, col = ct * 16 + 4 * g;
+    st_acc((mv == 0 ? DKh : DVh) + key * LDH + col, acc);
+    st_acc(reinterpret_cast<T*>(mv == 0 ? p.dk : p.dv) + (r0 + key) * CB + h * IDH + col, acc);
+  }
+  __syncthreads();
+  // the head's share of d(qin) = dq_h Wq[h]^T and d(concat) = dk_h Wk[h]^T + dv_h Wv[h]^T
   f32x4 dqi[3][4], dco[3][4];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) dqi[j][mt] = dco[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int h = 0; h < IH; ++h) {
-    for (int i = tid; i < 3 * NA * (IDH / V); i += 512) {
-      const int m = i / (NA * (IDH / V)), rem = i % (NA * (IDH / V)), row = rem / (IDH / V), c = (rem % (IDH / V)) * V;
-      const T* src = reinterpret_cast<const T*>(m == 0 ? p.s_q : (m == 1 ? p.s_k : p.s_v)) + (r0 + row) * CB + h * IDH + c;
-      *reinterpret_cast<uint4*>((m == 0 ? HQ : (m == 1 ? HK : HV)) + row * LDH + c) = *reinterpret_cast<const uint4*>(src);
-    }
-    __syncthreads();
-    {
-      const int qt = wv & 3, half = wv >> 2;
-      f32x4 st[4];
-      float f[4][4];
-      int_probs<T>(HQ, HK, LDH, qt, kval, (long long)b * IH + h, p.rng, p.site_a, p.p_drop, lane, st, f);
-      // dPd^T[key][query] = sum_c V[key][c] dO[query][c]
-      f32x4 ds[4];
-      float t = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < IDH / M::KSTEP; ++ks)
-          dp = M::mma(M::load(HV, LDH, jt * 16, ks * M::KSTEP, lane), M::load(DATT, LD, qt * 16, h * IDH + ks * M::KSTEP, lane), dp);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { ds[jt][r] = dp[r] * f[jt][r]; t += st[jt][r] * ds[jt][r]; }
-      }
-      t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ds[jt][r] = st[jt][r] * (ds[jt][r] - t) * 0.125f;
-      // dS^T and Pd^T tiles [key][query] for the products that contract over the queries (the two waves of a query tile write half each)
-#pragma unroll
-      for (int jt = 2 * half; jt < 2 * half + 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * jt + 4 * g + r;
-          stf(DST + key * LDH + qt * 16 + ln, ds[jt][r]);
-          stf(PDT + key * LDH + qt * 16 + ln, st[jt][r] * f[jt][r]);
-        }
-      // dQ^T[c][query] = sum_key K[key][c] dS[query][key], dS chained from the registers (half of the head columns per wave)
-      f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int s = 0; s < NA / M::KSTEP; ++s) {
-        const typename Ch<T>::Frag sf = Ch<T>::from_acc(&ds[s * Ch<T>::ND]);
-#pragma unroll
-        for (int jd = 0; jd < 2; ++jd) dq[jd] = M::mma(Ch<T>::ldA_tr(HK, LDH, 16 * (2 * half + jd), s * M::KSTEP, lane), sf, dq[jd]);
-      }
-#pragma unroll
-      for (int jd = 0; jd < 2; ++jd) {
-        const int col = 16 * (2 * half + jd) + 4 * g;
-        st_acc(DQh + (qt * 16 + ln) * LDH + col, dq[jd]);
-        st_acc(reinterpret_cast<T*>(p.dq) + (r0 + qt * 16 + ln) * CB + h * IDH + col, dq[jd]);
-      }
-    }
-    __syncthreads();
-    // dK^T[c][key] = sum_query Q[query][c] dS[query][key] ; dV^T[c][key] = sum_query dO[query][c] Pd[query][key]: 32 (matrix, c tile, key tile) units
-    for (int u = wv; u < 32; u += NW) {
-      const int mv = u >> 4, ct = (u >> 2) & 3, jt = u & 3;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < NA / M::KSTEP; ++ks) {
-        const typename M::Frag a = mv == 0 ? M::load_tr(HQ, LDH, ct * 16, ks * M::KSTEP, lane) : M::load_tr(DATT, LD, h * IDH + ct * 16, ks * M::KSTEP, lane);
-        acc = M::mma(a, M::load(mv == 0 ? DST : PDT, LDH, jt * 16, ks * M::KSTEP, lane), acc);
-      }
-      const int key = jt * 16 + ln, col = ct * 16 + 4 * g;
-      st_acc((mv == 0 ? DKh : DVh) + key * LDH + col, acc);
-      st_acc(reinterpret_cast<T*>(mv == 0 ? p.dk : p.dv) + (r0 + key) * CB + h * IDH + col, acc);
-    }
-    __syncthreads();
-    // d(qin) += dq_h Wq[h]^T ; d(concat) += dk_h Wk[h]^T + dv_h Wv[h]^T
-    gemm_cols_acc<T, 4, IDH, 3>([&](int row, int s) { return reinterpret_cast<const T*>(p.wq) + ((long long)h * CB + row) * IDH + s * M::KSTEP; }, DQh, LDH, 0, wv,
-                                NW, lane, dqi);
-    gemm_cols_acc<T, 4, IDH, 3>([&](int row, int s) { return reinterpret_cast<const T*>(p.wk) + ((long long)h * CB + row) * IDH + s * M::KSTEP; }, DKh, LDH, 0, wv,
-                                NW, lane, dco);
-    gemm_cols_acc<T, 4, IDH, 3>([&](int row, int s) { return reinterpret_cast<const T*>(p.wv) + ((long long)h * CB + row) * IDH + s * M::KSTEP; }, DVh, LDH, 0, wv,
-                                NW, lane, dco);
-    __syncthreads();
-  }
-  // ---- d_enc = dout + cm (d(qin) + d(concat)) ; d_embed += d(qin) summed over the segment's agents
+  gemm_cols_acc<T, 4, IDH, 3>([&](int row, int s) { return reinterpret_cast<const T*>(p.wq) + ((long long)h * CB + row) * IDH + s * M::KSTEP; }, DQh, LDH, 0, wv, NW,
+                              lane, dqi);
+  gemm_cols_acc<T, 4, IDH, 3>([&](int row, int s) { return reinterpret_cast<const T*>(p.wk) + ((long long)h * CB + row) * IDH + s * M::KSTEP; }, DKh, LDH, 0, wv, NW,
+                              lane, dco);
+  gemm_cols_acc<T, 4, IDH, 3>([&](int row, int s) { return reinterpret_cast<const T*>(p.wv) + ((long long)h * CB + row) * IDH + s * M::KSTEP; }, DVh, LDH, 0, wv, NW,
+                              lane, dco);
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int col = (wv + j * NW) * 16 + 4 * g;
@@ -1071,17 +1124,13 @@ __global__ __launch_bounds__(512) void agent_int_bwd_kernel(IntArgs p) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int tok = mt * 16 + ln;
-      T* de = reinterpret_cast<T*>(p.d_enc) + (r0 + tok) * CB + col;
-      float dv[4];
-      ld4(de, dv);
-      const float cm = kval[tok] ? 1.f : 0.f;
+      const bool cm = kval[tok] != 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float q = rnd<T>(dqi[j][mt][r]);
+        const float q = dqi[j][mt][r];
         if (tok < p.n_obs) e0[r] += q; else e1[r] += q;
-        dv[r] += cm * (q + rnd<T>(dco[j][mt][r]));
+        if (cm) atomicAdd(p.d_enc + (r0 + tok) * CB + col + r, q + dco[j][mt][r]);
       }
-      st4(de, dv);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1091,9 +1140,9 @@ __global__ __launch_bounds__(512) void agent_int_bwd_kernel(IntArgs p) {
     }
   }
 }
-template <typename T> static size_t int_bwd_lds() {
+template <typename T> static size_t int_attn_bwd_lds() {
   typedef IGeo<T> G;
-  return sizeof(T) * ((size_t)2 * NA * G::LD + 3 * NA * G::LDH) + NA * 4;
+  return sizeof(T) * ((size_t)NA * G::LD + 9 * NA * G::LDH) + NA * 4;
 }
 
 }  // namespace agf
@@ -1164,7 +1213,7 @@ static int enc_args(const stj_agent_enc_args* s, agf::EncArgs& a, bool bwd) {
   a.wn = s->wn; a.bn = s->bn; a.wv3 = s->wv3; a.bo = s->bo; a.bs = s->bs; a.enc = s->enc; a.cmi = s->cmi;
   a.s_nodes = s->s_nodes; a.s_qkv = s->s_qkv; a.s_att = s->s_att; a.s_pmask = (unsigned short*)s->s_pmask; a.s_cat = s->s_cat;
   a.rng = s->rng_state; a.site = s->site; a.p_drop = s->p_drop;
-  a.d_enc = s->d_enc; a.wq = s->wq; a.wk = s->wk; a.wv = s->wv; a.wo = s->wo; a.ws = s->ws;
+  a.d_enc = s->d_enc; a.d_enc_f32 = s->d_enc_f32; a.wq = s->wq; a.wk = s->wk; a.wv = s->wv; a.wo = s->wo; a.ws = s->ws;
   a.dpre_s = s->dpre_s; a.dout = s->dout; a.dqkv = s->dqkv; a.dwn = s->dwn; a.dbn = s->dbn; a.dwv3 = s->dwv3;
   if (!bwd) {
     if (!s->pack || !s->wn || !s->bn || !s->wv3 || !s->bo || !s->bs) { stj_set_error("stj_agent_enc_fwd: null weight pointer"); return STJ_EINVAL; }
@@ -1200,15 +1249,25 @@ template <typename T, bool BWD> static int int_launch(const agf::IntArgs& a, hip
   using namespace agf;
   static PerDevice<int> attr_set;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)agent_int_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)int_fwd_lds<T>()) != hipSuccess ||
-        hipFuncSetAttribute((const void*)agent_int_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)int_bwd_lds<T>()) != hipSuccess) {
-      stj_set_error("stj_agent_int: cannot reserve %zu bytes of LDS", BWD ? int_bwd_lds<T>() : int_fwd_lds<T>());
+    if (hipFuncSetAttribute((const void*)agent_int_attn_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)int_attn_fwd_lds<T>()) != hipSuccess ||
+        hipFuncSetAttribute((const void*)agent_int_ffn_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)int_ffn_lds<T>()) != hipSuccess ||
+        hipFuncSetAttribute((const void*)agent_int_ffn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)int_ffn_lds<T>()) != hipSuccess ||
+        hipFuncSetAttribute((const void*)agent_int_attn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)int_attn_bwd_lds<T>()) != hipSuccess) {
+      stj_set_error("stj_agent_int: cannot reserve %zu bytes of LDS", int_attn_bwd_lds<T>());
       return STJ_ELAUNCH;
     }
     attr_set = 1;
   }
-  if (BWD) hipLaunchKernelGGL(agent_int_bwd_kernel<T>, dim3(a.B), dim3(512), int_bwd_lds<T>(), stream, a);
-  else hipLaunchKernelGGL(agent_int_fwd_kernel<T>, dim3(a.B), dim3(512), int_fwd_lds<T>(), stream, a);
+  const int rows = a.B * NA;
+  if (!BWD) {
+    hipLaunchKernelGGL(agent_int_attn_fwd_kernel<T>, dim3(a.B * IH), dim3(512), int_attn_fwd_lds<T>(), stream, a);
+    hipLaunchKernelGGL(agent_int_ffn_fwd_kernel<T>, dim3(a.B * IGeo<T>::NC), dim3(512), int_ffn_lds<T>(), stream, a);
+    hipLaunchKernelGGL(agent_int_out_fwd_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(agent_int_out_bwd_kernel<T>, dim3((rows + 15) / 16), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(agent_int_ffn_bwd_kernel<T>, dim3(a.B * IGeo<T>::NC), dim3(512), int_ffn_lds<T>(), stream, a);
+    hipLaunchKernelGGL(agent_int_attn_bwd_kernel<T>, dim3(a.B * IH), dim3(512), int_attn_bwd_lds<T>(), stream, a);
+  }
   return stj_check_launch(BWD ? "stj_agent_int_bwd" : "stj_agent_int_fwd");
 }
 
@@ -1221,7 +1280,8 @@ static int int_args(const stj_agent_int_args* s, agf::IntArgs& a, bool bwd) {
   a.enc = s->enc; a.cmi = s->cmi; a.n_obs = s->n_obs; a.B = s->B; a.pack = s->pack; a.seg = s->seg;
   a.bo = s->bo; a.g1 = s->g1; a.be1 = s->be1; a.b1 = s->b1; a.b2 = s->b2; a.g2 = s->g2; a.be2 = s->be2;
   a.go = s->g_obs; a.beo = s->b_obs; a.gc = s->g_occ; a.bec = s->b_occ; a.key = s->key;
-  a.s_concat = s->s_concat; a.s_qin = s->s_qin; a.s_q = s->s_q; a.s_k = s->s_k; a.s_v = s->s_v; a.s_att = s->s_att; a.s_v1 = s->s_v1; a.s_n1 = s->s_n1;
+  a.v1acc = s->ws_v1; a.u2acc = s->ws_u2; a.n1 = s->s_n1; a.dn1acc = s->ws_dn1;
+  a.s_concat = s->s_concat; a.s_qin = s->s_qin; a.s_q = s->s_q; a.s_k = s->s_k; a.s_v = s->s_v; a.s_att = s->s_att; a.s_v1 = s->s_v1;
   a.s_h = s->s_h; a.s_u2 = s->s_u2; a.s_out = s->s_out;
   a.rng = s->rng_state; a.site_a = s->site_a; a.site_1 = s->site_1; a.site_2 = s->site_2; a.p_drop = s->p_drop;
   a.dkey = s->dkey; a.wq = s->wq; a.wk = s->wk; a.wv = s->wv; a.wo = s->wo; a.w1 = s->w1; a.w2 = s->w2;
@@ -1232,11 +1292,11 @@ static int int_args(const stj_agent_int_args* s, agf::IntArgs& a, bool bwd) {
   for (const void* q : saves) nset += q != nullptr;
   if (!s->seg || !s->g1 || !s->g2 || !s->g_obs || !s->g_occ) { stj_set_error("stj_agent_int: null parameter pointer"); return STJ_EINVAL; }
   if (!bwd) {
-    if (!s->pack || !s->key || !s->bo || !s->be1 || !s->b1 || !s->b2 || !s->be2 || !s->b_obs || !s->b_occ) { stj_set_error("stj_agent_int_fwd: null pointer"); return STJ_EINVAL; }
+    if (!s->pack || !s->key || !s->bo || !s->be1 || !s->b1 || !s->b2 || !s->be2 || !s->b_obs || !s->b_occ || !s->ws_v1 || !s->ws_u2) { stj_set_error("stj_agent_int_fwd: null pointer"); return STJ_EINVAL; }
     if (nset != 0 && nset != 11) { stj_set_error("stj_agent_int_fwd: the eleven saved tensors go together"); return STJ_EINVAL; }
   } else {
     const void* need[] = {s->dkey, s->wq, s->wk, s->wv, s->wo, s->w1, s->w2, s->d_enc, s->dq, s->dk, s->dv, s->dv1, s->dpre1, s->dz2, s->dseg, s->dg1, s->dbe1,
-                          s->dg2, s->dbe2, s->dg_obs, s->db_obs, s->dg_occ, s->db_occ};
+                          s->dg2, s->dbe2, s->dg_obs, s->db_obs, s->dg_occ, s->db_occ, s->ws_dn1};
     for (const void* q : need)
       if (!q) { stj_set_error("stj_agent_int_bwd: null pointer"); return STJ_EINVAL; }
     if (nset != 11) { stj_set_error("stj_agent_int_bwd: needs the eleven saved tensors"); return STJ_EINVAL; }

@@ -634,17 +634,16 @@ class STrajNet:
             if self._agent_pack_stale:
                 self._agent_pack = ops.agent_pack(self._agent_ws(), self.dtype, out=self._agent_pack)
                 self._agent_pack_stale = False
-            enc, cmi = ops.agent_enc(obs, occ, self._agent_ws(), self._agent_pack, self.dtype,
-                                     self._attn_drop(pre + '/node_attention/dropout', (B * A, 4, T, T)))
+            drop_e = self._attn_drop(pre + '/node_attention/dropout', (B * A, 4, T, T))
             if self.fused_agent_int and ops.agent_int_ok(n_obs, occ.shape[1], self.dtype):
-                # ... and the 64-agent interaction block (trajNet.py:135-187) as ONE more launch: 16-bit storage types
+                # ... followed by the 64-agent interaction block (trajNet.py:135-187) as three more launches: 16-bit storage types
                 drop = None
                 if self._dctx is not None:
-                    c = 'traj_net/cross_attention'
-                    d = self._dctx
-                    drop = (0.1, d.snap, (d.site(c + '/mha/dropout', (B, 6, A, A), 0.1), d.site(c + '/dropout1', (B, A, 1536), 0.1),
+                    c, d = 'traj_net/cross_attention', self._dctx
+                    drop = (0.1, d.snap, (drop_e[2], d.site(c + '/mha/dropout', (B, 6, A, A), 0.1), d.site(c + '/dropout1', (B, A, 1536), 0.1),
                                           d.site(c + '/dropout2', (B, A, 384), 0.1)))
-                return ops.agent_int(enc, cmi, self._agent_ws(), self._agent_pack, n_obs, drop), cmi
+                return ops.agent_branch(obs, occ, self._agent_ws(), self._agent_pack, self.dtype, drop)
+            enc, cmi = ops.agent_enc(obs, occ, self._agent_ws(), self._agent_pack, self.dtype, drop_e)
             cmf = cmi.to(self.dtype)
         else:
             x5, v3, vt, cmi, cmf = ops.agent_prep(obs, occ, self.dtype)
@@ -863,6 +862,9 @@ class STrajNet:
         # after the encoder's first stage though: a replayed hipGraph starts branches roughly in node-creation order, and issued first
         # the chain ran alone on an idle GPU for 0.5 ms before the first Swin kernel started (profiles/r02_c_timeline_concurrent.txt).
         mode = self.agent_issue_mode if self._side is not None else -1       # (0: issued at the head of the step, 1: after the encoder -- both measured equal or worse)
+        main_pos = None
+        if mode in (3, 4, 5):           # on the MAIN stream: 4 = at the head of the step, 3 = behind the encoder, 5 = behind FG-MSA (in front of the cross-attention)
+            main_pos, mode = mode, -3
         agent = []
         if self.agent_override is not None:     # the caller ran agent_encode() itself (graph.GraphedForward: a graph of its own, a batch ahead)
             agent.extend(self.agent_override)
@@ -878,7 +880,7 @@ class STrajNet:
             fork.record(main)
         if mode == 0:
             issue_agent()
-        elif mode == -1:
+        elif mode == -1 or main_pos == 4:
             agent.extend(self._traj_net(obs, occ))
         # Side work that is not needed before the cross-attention / the decoder / the loss is ISSUED behind the encoder's first stage
         # too: a replayed hipGraph starts its first ~20 nodes one after the other whatever their stream, so the seven packing /
@@ -898,7 +900,8 @@ class STrajNet:
         res_list = self._encoder(ogm, map_img, flow, hook=hook)
         if mode == 1:
             issue_agent()
-        key, tmask = agent
+        if main_pos == 3:
+            agent.extend(self._traj_net(obs, occ))
         fold = self._fold_partials
         if self.cut_encoder and torch.is_grad_enabled():
             # data-parallel overlap: detach here; backward() then ends at these leaves (the tail bucket is complete and can be
@@ -925,6 +928,9 @@ class STrajNet:
             q, query = self._fgmsa(q)                                              # modules.py:825-831
         else:
             query = q.reshape(1, B, hb * hb, Cb).expand(8, B, hb * hb, Cb).contiguous()   # modules.py:827
+        if main_pos == 5:
+            agent.extend(self._traj_net(obs, occ))
+        key, tmask = agent
         if self._side is not None and mode >= 0:       # join the agent branch
             main.wait_stream(self._side)
             key.record_stream(main)

@@ -1759,73 +1759,111 @@ def agent_int_ok(n_obs, n_occ, dtype):
     return bool(lib().stj_agent_int_supported(int(n_obs), int(n_occ), DTYPE_CODE[dtype]))
 
 
+_ENC_SAVES = ('s_nodes', 's_qkv', 's_att', 's_pmask', 's_cat')
 _INT_SAVES = ('s_concat', 's_qin', 's_q', 's_k', 's_v', 's_att', 's_v1', 's_n1', 's_h', 's_u2', 's_out')
 
 
-class _AgentInt(torch.autograd.Function):
-    """key [B,64,384] = the interaction block of TrajNet.call (trajNet.py:135-187) on enc [B,64,384], cmi [B,64].  ws: Params {seg, i_wq, i_wk,
-    i_wv, i_wo, i_bo, g1, be1, i_w1, b1, i_w2, b2, g2, be2, g_obs, b_obs, g_occ, b_occ}; drop: (p, state, (site_a, site_1, site_2)) or None."""
+class _AgentBranch(torch.autograd.Function):
+    """key [B,64,384], cmi [B,64] = TrajNet.call (trajNet.py:125-187) from the raw tracks: the fused TrajEncoder kernel followed by the three
+    interaction-block kernels (16-bit storage types); backward = three interaction kernels + the encoder kernel + nine queued weight-gradient
+    products.  ws: the Params of STrajNet._agent_ws(); drop: (p, state, (site of the encoder attention, site_a, site_1, site_2)) or None."""
     @staticmethod
-    def forward(ctx, enc, cmi, trig, ws, pack, n_obs, drop):
-        from ._lib import AgentIntArgs
-        _req_cuda(enc)
-        enc = enc.contiguous()
-        B, A, C = enc.shape
-        dev, ty = enc.device, enc.dtype
+    def forward(ctx, obs, occ, trig, ws, pack, dtype, drop):
+        from ._lib import AgentEncArgs, AgentIntArgs
+        _req_cuda(obs, occ)
+        obs, occ = obs.float().contiguous(), occ.float().contiguous()
+        B, n_obs, Tn, _ = obs.shape
+        n_occ = occ.shape[1]
+        A, C = n_obs + n_occ, 384
+        dev, dt = obs.device, DTYPE_CODE[dtype]
+        enc = torch.empty((B, A, C), dtype=dtype, device=dev)
         key = torch.empty_like(enc)
-        train = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
-        sv = {}
+        cmi = torch.empty((B, A), dtype=torch.int32, device=dev)
+        train = bool(ctx.needs_input_grad[2])
+        se, si = {}, {}
         if train:
-            sv = {k: torch.empty((B * A, 1536 if k == 's_h' else C), dtype=ty, device=dev) for k in _INT_SAVES}
-        p_drop, state, sites = drop if drop is not None else (0.0, None, (0, 0, 0))
+            rows = B * A * Tn
+            se = dict(s_nodes=torch.empty((rows, 64), dtype=dtype, device=dev), s_qkv=torch.empty((rows, 768), dtype=dtype, device=dev),
+                      s_att=torch.empty((rows, 256), dtype=dtype, device=dev), s_pmask=torch.empty((B * A, 320), dtype=torch.int16, device=dev),
+                      s_cat=torch.empty((B * A, C), dtype=dtype, device=dev))
+            si = {k: torch.empty((B * A, 1536 if k == 's_h' else C), dtype=dtype, device=dev) for k in _INT_SAVES}
+        p_drop, state, sites = drop if drop is not None else (0.0, None, (0, 0, 0, 0))
         m = lambda k: _ip(ws[k].master)
-        a = AgentIntArgs(enc=_ip(enc), cmi=_ip(cmi), n_obs=n_obs, n_occ=A - n_obs, B=B, dtype=_dt(enc), pack=_ip(pack), seg=_ip(ws['seg'].c),
-                         bo=m('i_bo'), g1=m('g1'), be1=m('be1'), b1=m('b1'), b2=m('b2'), g2=m('g2'), be2=m('be2'), g_obs=m('g_obs'), b_obs=m('b_obs'),
-                         g_occ=m('g_occ'), b_occ=m('b_occ'), key=_ip(key), rng_state=_ip(state), site_a=sites[0], site_1=sites[1], site_2=sites[2],
-                         p_drop=float(p_drop), **{k: _ip(v) for k, v in sv.items()})
-        call('stj_agent_int_fwd', ctypes.byref(a), _st())
-        ctx.ws, ctx.drop, ctx.geo = ws, drop, (B, A, C, n_obs)
+        a = AgentEncArgs(obs=_ip(obs), occ=_ip(occ), n_obs=n_obs, n_occ=n_occ, B=B, dtype=dt, pack=_ip(pack), wn=m('wn'), bn=m('bn'), wv3=m('wv3'),
+                         bo=m('e_bo'), bs=m('e_bs'), enc=_ip(enc), cmi=_ip(cmi), rng_state=_ip(state), site=sites[0], p_drop=float(p_drop),
+                         **{k: _ip(v) for k, v in se.items()})
+        call('stj_agent_enc_fwd', ctypes.byref(a), _st())
+        acc = zeros_f32((2, B * A, C), dev)              # where the heads' / hidden chunks' partial sums meet
+        ai = AgentIntArgs(enc=_ip(enc), cmi=_ip(cmi), n_obs=n_obs, n_occ=n_occ, B=B, dtype=dt, pack=_ip(pack), seg=_ip(ws['seg'].c),
+                          bo=m('i_bo'), g1=m('g1'), be1=m('be1'), b1=m('b1'), b2=m('b2'), g2=m('g2'), be2=m('be2'), g_obs=m('g_obs'), b_obs=m('b_obs'),
+                          g_occ=m('g_occ'), b_occ=m('b_occ'), key=_ip(key), ws_v1=_ip(acc[0]), ws_u2=_ip(acc[1]), rng_state=_ip(state),
+                          site_a=sites[1], site_1=sites[2], site_2=sites[3], p_drop=float(p_drop), **{k: _ip(v) for k, v in si.items()})
+        call('stj_agent_int_fwd', ctypes.byref(ai), _st())
+        ctx.ws, ctx.drop, ctx.geo, ctx.tdtype = ws, drop, (B, n_obs, n_occ, Tn), dtype
         if train:
-            ctx.save_for_backward(enc, cmi, *[sv[k] for k in _INT_SAVES])
-        return key
+            ctx.save_for_backward(obs, occ, enc, cmi, *[se[k] for k in _ENC_SAVES], *[si[k] for k in _INT_SAVES])
+        ctx.mark_non_differentiable(cmi)
+        return key, cmi
 
     @staticmethod
-    def backward(ctx, dkey):
-        from ._lib import AgentIntArgs
-        enc, cmi = ctx.saved_tensors[:2]
-        sv = dict(zip(_INT_SAVES, ctx.saved_tensors[2:]))
-        ws = ctx.ws
-        B, A, C, n_obs = ctx.geo
-        R = B * A
-        dev, ty, dt = enc.device, enc.dtype, _dt(enc)
+    def backward(ctx, dkey, _dcmi):
+        from ._lib import AgentEncArgs, AgentIntArgs
+        t = ctx.saved_tensors
+        obs, occ, enc, cmi = t[:4]
+        se = dict(zip(_ENC_SAVES, t[4:9]))
+        si = dict(zip(_INT_SAVES, t[9:]))
+        ws, dtype = ctx.ws, ctx.tdtype
+        B, n_obs, n_occ, Tn = ctx.geo
+        A, C = n_obs + n_occ, 384
+        R, rows = B * A, B * A * Tn
+        dev, dt = enc.device, DTYPE_CODE[dtype]
         dkey = dkey.contiguous()
-        d_enc = torch.empty_like(enc)
-        dY = {k: torch.empty((R, 1536 if k == 'dpre1' else C), dtype=ty, device=dev) for k in ('dq', 'dk', 'dv', 'dv1', 'dpre1', 'dz2')}
-        p_drop, state, sites = ctx.drop if ctx.drop is not None else (0.0, None, (0, 0, 0))
+        d_enc = torch.empty((R, C), dtype=torch.float32, device=dev)
+        dn1acc = zeros_f32((R, C), dev)
+        dY = {k: torch.empty((R, 1536 if k == 'dpre1' else C), dtype=dtype, device=dev) for k in ('dq', 'dk', 'dv', 'dv1', 'dpre1', 'dz2')}
+        p_drop, state, sites = ctx.drop if ctx.drop is not None else (0.0, None, (0, 0, 0, 0))
         m, c, gr = (lambda k: _ip(ws[k].master)), (lambda k: _ip(ws[k].c)), (lambda k: _ip(ws[k].grad))
-        a = AgentIntArgs(enc=_ip(enc), cmi=_ip(cmi), n_obs=n_obs, n_occ=A - n_obs, B=B, dtype=dt, seg=c('seg'), g1=m('g1'), g2=m('g2'), g_obs=m('g_obs'),
-                         g_occ=m('g_occ'), rng_state=_ip(state), site_a=sites[0], site_1=sites[1], site_2=sites[2], p_drop=float(p_drop),
-                         dkey=_ip(dkey), wq=c('i_wq'), wk=c('i_wk'), wv=c('i_wv'), wo=c('i_wo'), w1=c('i_w1'), w2=c('i_w2'), d_enc=_ip(d_enc),
-                         dseg=gr('seg'), dg1=gr('g1'), dbe1=gr('be1'), dg2=gr('g2'), dbe2=gr('be2'), dg_obs=gr('g_obs'), db_obs=gr('b_obs'),
-                         dg_occ=gr('g_occ'), db_occ=gr('b_occ'), **{k: _ip(v) for k, v in sv.items()}, **{k: _ip(v) for k, v in dY.items()})
-        call('stj_agent_int_bwd', ctypes.byref(a), _st())
-        # the six weight gradients on what the kernel wrote (queued on the grouped stream-K launch inside a model's backward pass)
+        ai = AgentIntArgs(enc=_ip(enc), cmi=_ip(cmi), n_obs=n_obs, n_occ=n_occ, B=B, dtype=dt, seg=c('seg'), g1=m('g1'), g2=m('g2'), g_obs=m('g_obs'),
+                          g_occ=m('g_occ'), rng_state=_ip(state), site_a=sites[1], site_1=sites[2], site_2=sites[3], p_drop=float(p_drop),
+                          dkey=_ip(dkey), wq=c('i_wq'), wk=c('i_wk'), wv=c('i_wv'), wo=c('i_wo'), w1=c('i_w1'), w2=c('i_w2'), d_enc=_ip(d_enc),
+                          ws_dn1=_ip(dn1acc), dseg=gr('seg'), dg1=gr('g1'), dbe1=gr('be1'), dg2=gr('g2'), dbe2=gr('be2'), dg_obs=gr('g_obs'),
+                          db_obs=gr('b_obs'), dg_occ=gr('g_occ'), db_occ=gr('b_occ'), **{k: _ip(v) for k, v in si.items()},
+                          **{k: _ip(v) for k, v in dY.items()})
+        call('stj_agent_int_bwd', ctypes.byref(ai), _st())
+        dpre_s = torch.empty((R, C), dtype=dtype, device=dev)
+        dout = torch.empty((rows, 320), dtype=dtype, device=dev)
+        dqkv = torch.empty((rows, 768), dtype=dtype, device=dev)
+        a = AgentEncArgs(obs=_ip(obs), occ=_ip(occ), n_obs=n_obs, n_occ=n_occ, B=B, dtype=dt, enc=_ip(enc), cmi=_ip(cmi),
+                         rng_state=_ip(state), site=sites[0], p_drop=float(p_drop), d_enc=_ip(d_enc), d_enc_f32=1,
+                         wq=c('e_wq'), wk=c('e_wk'), wv=c('e_wv'), wo=c('e_wo'), ws=c('e_ws'),
+                         dpre_s=_ip(dpre_s), dout=_ip(dout), dqkv=_ip(dqkv), dwn=gr('wn'), dbn=gr('bn'), dwv3=gr('wv3'),
+                         **{k: _ip(v) for k, v in se.items()})
+        call('stj_agent_enc_bwd', ctypes.byref(a), _st())
+        # the nine weight gradients on what the kernels wrote (queued on the grouped stream-K launch inside a model's backward pass)
         H, hs = 6, C // 6
-        keep = list(sv.values()) + list(dY.values())
+        zq = ws['e_wk'].grad.data_ptr() - ws['e_wq'].grad.data_ptr()
+        assert ws['e_wv'].grad.data_ptr() - ws['e_wk'].grad.data_ptr() == zq and zq % 4 == 0
+        keep = list(si.values()) + list(dY.values()) + list(se.values()) + [dpre_s, dout, dqkv]
         with gemm_group(not (_WG_MODE & 1)), wgrad_stream(1, *keep):
-            for x, dy, w in ((sv['s_qin'], dY['dq'], 'i_wq'), (sv['s_concat'], dY['dk'], 'i_wk'), (sv['s_concat'], dY['dv'], 'i_wv')):
+            for x, dy, w in ((si['s_qin'], dY['dq'], 'i_wq'), (si['s_concat'], dY['dk'], 'i_wk'), (si['s_concat'], dY['dv'], 'i_wv')):
                 gemm(x, dy, ws[w].grad, C, hs, R, (0, 0, 1, C), (0, hs, C, 1), (0, C * hs, hs), dt, nb=(1, H), c_f32=1, accumulate=1, splitk=0)   # dW[h] += x^T dy[:, h]
-            gemm(sv['s_att'], dY['dv1'], ws['i_wo'].grad.view(C, C), C, C, R, (0, 0, 1, C), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1,
+            gemm(si['s_att'], dY['dv1'], ws['i_wo'].grad.view(C, C), C, C, R, (0, 0, 1, C), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1,
                  splitk=0, colsum=ws['i_bo'].grad)
-            gemm(sv['s_n1'], dY['dpre1'], ws['i_w1'].grad, C, 1536, R, (0, 0, 1, C), (0, 0, 1536, 1), (0, 0, 1536), dt, c_f32=1, accumulate=1,
+            gemm(si['s_n1'], dY['dpre1'], ws['i_w1'].grad, C, 1536, R, (0, 0, 1, C), (0, 0, 1536, 1), (0, 0, 1536), dt, c_f32=1, accumulate=1,
                  splitk=0, colsum=ws['b1'].grad)
-            gemm(sv['s_h'], dY['dz2'], ws['i_w2'].grad, 1536, C, R, (0, 0, 1, 1536), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1,
+            gemm(si['s_h'], dY['dz2'], ws['i_w2'].grad, 1536, C, R, (0, 0, 1, 1536), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1,
                  splitk=0, colsum=ws['b2'].grad)
-        return (d_enc,) + (None,) * 6
+            gemm(se['s_cat'], dpre_s, ws['e_ws'].grad, C, C, R, (0, 0, 1, C), (0, 0, C, 1), (0, 0, C), dt, c_f32=1, accumulate=1, splitk=0,
+                 colsum=ws['e_bs'].grad)
+            gemm(se['s_att'], dout, ws['e_wo'].grad.view(256, 320), 256, 320, rows, (0, 0, 1, 256), (0, 0, 320, 1), (0, 0, 320), dt, c_f32=1,
+                 accumulate=1, splitk=0, colsum=ws['e_bo'].grad)
+            gemm(se['s_nodes'], dqkv, ws['e_wq'].grad, 64, 64, rows, (0, 0, 1, 64), (256, 64, 768, 1), (zq // 4, 64 * 64, 64), dt, nb=(3, 4),
+                 c_f32=1, accumulate=1, splitk=0)
+        return (None,) * 7
 
 
-def agent_int(enc, cmi, ws, pack, n_obs, drop=None):
-    return _AgentInt.apply(enc, cmi, _trig(ws['i_w1'].master), ws, pack, n_obs, drop)
+def agent_branch(obs, occ, ws, pack, dtype, drop=None):
+    return _AgentBranch.apply(obs, occ, _trig(ws['e_ws'].master), ws, pack, dtype, drop)
 
 
 # ----------------------------------------------------------------------------------------------------
