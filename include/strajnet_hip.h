@@ -278,7 +278,8 @@ int stj_agent_enc_bwd(const stj_agent_enc_args* a, hipStream_t stream);
  * ONE launch per direction: masked concat, segment embedding, the 6-head tfa attention (mask cm (x) cm, dropout on the coefficients), output
  * projection, LayerNorm(1e-3), Dense(1536, elu), Dropout, Dense(384), Dropout, LayerNorm(1e-3), enc + value + embed, obs_norm | occ_norm.
  * Three launches per direction: (scene, head) workgroups for the attention, (scene, hidden chunk) workgroups for the FFN -- their partial
- * sums meet in caller-ZEROED f32 workspaces (ws_v1, ws_u2 forward; ws_dn1 backward; [B 64][384] each) -- and a row-wise tail.  d_enc is f32.
+ * sums are written as f32 slabs (ws_v1 [6][B 64][384], ws_u2 [4][..] forward; ws_dn1 [4][..], d_enc [7][..] backward) that the next launch adds
+ * in a fixed order (no atomics on activations: bitwise reproducible) -- and a row-wise tail.  stj_agent_enc_bwd takes d_enc with d_enc_f32 = 7.
  * 16-bit dtypes, 64 agents per scene (stj_agent_int_supported); the f32 parity mode keeps the layer-by-layer chain.  Forward writes key
  * [B 64][384] and, when the eleven s_* pointers are given, what backward reads.  Backward writes d_enc and the six dY tensors whose weight
  * gradients are the caller's (X = s_qin / s_concat / s_concat / s_att / s_n1 / s_h), and accumulates seg_embed and the LayerNorm parameters. */

@@ -414,9 +414,16 @@ __global__ __launch_bounds__(256) void agent_enc_bwd_kernel(EncArgs p) {
   for (int i = tid; i < AG * (CB / V); i += 256) {
     const int ag = i / (CB / V), c = (i % (CB / V)) * V;
     float d[V], y[V];
-    if (p.d_enc_f32) {
+    if (p.d_enc_f32) {                 // d_enc_f32 slabs [B A][384] f32 (the interaction kernels' shares), added in a fixed order
 #pragma unroll
-      for (int e = 0; e < V; e += 4) ld4(reinterpret_cast<const float*>(p.d_enc) + (long long)(a0 + ag) * CB + c + e, d + e);
+      for (int e = 0; e < V; ++e) d[e] = 0.f;
+      for (int sl = 0; sl < p.d_enc_f32; ++sl) {
+        float t4[V];
+#pragma unroll
+        for (int e = 0; e < V; e += 4) ld4(reinterpret_cast<const float*>(p.d_enc) + ((long long)sl * p.B * (p.n_obs + p.n_occ) + a0 + ag) * CB + c + e, t4 + e);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] += t4[e];
+      }
     } else ld16(reinterpret_cast<const T*>(p.d_enc) + (long long)(a0 + ag) * CB + c, d);
     ld16(reinterpret_cast<const T*>(p.enc) + (long long)(a0 + ag) * CB + c, y);
 #pragma unroll
@@ -568,13 +575,13 @@ struct IntArgs {
   const float* bo; const float* g1; const float* be1; const float* b1; const float* b2; const float* g2; const float* be2;
   const float* go; const float* beo; const float* gc; const float* bec;                      // obs_norm | occ_norm
   void* key;
-  float* v1acc; float* u2acc; void* n1;              // workspaces: [B 64][384] f32 x 2 (zeroed by the caller), n1 [B 64][384] (= s_n1 in training)
+  float* v1acc; float* u2acc; void* n1;              // workspaces: slabs [6][B 64][384] / [4][B 64][384] f32 (per head / hidden chunk partial sums), n1 [B 64][384] (= s_n1 in training)
   void* s_concat; void* s_qin; void* s_q; void* s_k; void* s_v; void* s_att; void* s_v1; void* s_h; void* s_u2; void* s_out;
   const long long* rng; int site_a, site_1, site_2; float p_drop;
   // backward
   const void* dkey; const void* wq; const void* wk; const void* wv; const void* wo; const void* w1; const void* w2;
-  float* d_enc;                                      // [B 64][384] f32: written by the tail kernel, accumulated by the attention kernel
-  float* dn1acc;                                     // [B 64][384] f32, zeroed by the caller
+  float* d_enc;                                      // slabs [7][B 64][384] f32: the residual's share (tail kernel) + one per head
+  float* dn1acc;                                     // slabs [4][B 64][384] f32
   void* dq; void* dk; void* dv; void* dv1; void* dpre1; void* dz2;
   float* dseg; float* dg1; float* dbe1; float* dg2; float* dbe2; float* dgo; float* dbeo; float* dgc; float* dbec;
 };
@@ -740,11 +747,8 @@ __global__ __launch_bounds__(512) void agent_int_attn_fwd_kernel(IntArgs p) {
   gemm_cols<T, 4, IDH, IDH>([&](int row, int s) { return pk + P_IWO + (long long)row * CB + h * IDH + s * M::KSTEP; }, OH, LDH, 0, CB / 16, wv, NW, lane,
                             [&](int ct, f32x4 (&acc)[4]) {
 #pragma unroll
-                              for (int mt = 0; mt < 4; ++mt) {
-                                float* d = p.v1acc + (r0 + mt * 16 + ln) * CB + ct * 16 + 4 * g;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) atomicAdd(d + r, acc[mt][r]);
-                              }
+                              for (int mt = 0; mt < 4; ++mt)      // the head's slab (plain 16-byte stores; the FFN kernel adds the six in a fixed order)
+                                *reinterpret_cast<f32x4*>(p.v1acc + ((long long)h * p.B * NA + r0 + mt * 16 + ln) * CB + ct * 16 + 4 * g) = acc[mt];
                             });
 }
 template <typename T> static size_t int_attn_fwd_lds() {
@@ -773,8 +777,13 @@ __global__ __launch_bounds__(512) void agent_int_ffn_fwd_kernel(IntArgs p) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int cc = rcol(j, lane, 0);
-      const float2 a = *reinterpret_cast<const float2*>(p.v1acc + (r0 + row) * CB + cc);
-      v[j][0] = rnd<T>(a.x + p.bo[cc]); v[j][1] = rnd<T>(a.y + p.bo[cc + 1]);
+      float2 a = make_float2(p.bo[cc], p.bo[cc + 1]);
+#pragma unroll
+      for (int hh = 0; hh < IH; ++hh) {
+        const float2 t = *reinterpret_cast<const float2*>(p.v1acc + ((long long)hh * p.B * NA + r0 + row) * CB + cc);
+        a.x += t.x; a.y += t.y;
+      }
+      v[j][0] = rnd<T>(a.x); v[j][1] = rnd<T>(a.y);
       if (lead && train) *reinterpret_cast<uint32_t*>(reinterpret_cast<T*>(p.s_v1) + (r0 + row) * CB + cc) = pack2<T>(v[j][0], v[j][1]);
     }
     row_stats(v, 1e-3f, mu, rs);
@@ -808,11 +817,8 @@ __global__ __launch_bounds__(512) void agent_int_ffn_fwd_kernel(IntArgs p) {
   gemm_cols<T, 4, CB, CB>([&](int row, int s) { return pk + P_IW2 + (long long)row * FF + c * CB + s * M::KSTEP; }, HC, LD, 0, CB / 16, wv, NW, lane,
                           [&](int ct, f32x4 (&acc)[4]) {
 #pragma unroll
-                            for (int mt = 0; mt < 4; ++mt) {
-                              float* d = p.u2acc + (r0 + mt * 16 + ln) * CB + ct * 16 + 4 * g;
-#pragma unroll
-                              for (int r = 0; r < 4; ++r) atomicAdd(d + r, acc[mt][r]);
-                            }
+                            for (int mt = 0; mt < 4; ++mt)
+                              *reinterpret_cast<f32x4*>(p.u2acc + ((long long)c * p.B * NA + r0 + mt * 16 + ln) * CB + ct * 16 + 4 * g) = acc[mt];
                           });
 }
 template <typename T> static size_t int_ffn_lds() { return sizeof(T) * (size_t)2 * NA * IGeo<T>::LD; }
@@ -830,7 +836,12 @@ __global__ __launch_bounds__(256) void agent_int_out_fwd_kernel(IntArgs p) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int c = rcol(j, lane, 0);
-    const float2 a = *reinterpret_cast<const float2*>(p.u2acc + row * CB + c);
+    float2 a = make_float2(p.b2[c], p.b2[c + 1]);
+#pragma unroll
+    for (int cc = 0; cc < FF / CB; ++cc) {
+      const float2 t = *reinterpret_cast<const float2*>(p.u2acc + ((long long)cc * p.B * NA + row) * CB + c);
+      a.x += t.x; a.y += t.y;
+    }
     float f0 = 1.f, f1 = 1.f;
     if (drop) {
       bool k4[4];
@@ -838,7 +849,7 @@ __global__ __launch_bounds__(256) void agent_int_out_fwd_kernel(IntArgs p) {
       keep4(p.rng, p.site_2, idx >> 2, p.p_drop, k4);
       f0 = k4[idx & 3] ? dsc : 0.f; f1 = k4[(idx & 3) + 1] ? dsc : 0.f;
     }
-    v[j][0] = rnd<T>(rnd<T>(a.x + p.b2[c]) * f0); v[j][1] = rnd<T>(rnd<T>(a.y + p.b2[c + 1]) * f1);
+    v[j][0] = rnd<T>(rnd<T>(a.x) * f0); v[j][1] = rnd<T>(rnd<T>(a.y) * f1);
     if (p.s_u2) *reinterpret_cast<uint32_t*>(reinterpret_cast<T*>(p.s_u2) + row * CB + c) = pack2<T>(v[j][0], v[j][1]);
   }
   row_stats(v, 1e-3f, mu, rs);
@@ -974,11 +985,8 @@ __global__ __launch_bounds__(512) void agent_int_ffn_bwd_kernel(IntArgs p) {
   gemm_cols<T, 4, CB, CB>([&](int row, int s) { return reinterpret_cast<const T*>(p.w1) + (long long)row * FF + c * CB + s * M::KSTEP; }, DP, LD, 0, CB / 16, wv, NW,
                           lane, [&](int ct, f32x4 (&acc)[4]) {
 #pragma unroll
-                            for (int mt = 0; mt < 4; ++mt) {
-                              float* d = p.dn1acc + (r0 + mt * 16 + ln) * CB + ct * 16 + 4 * g;
-#pragma unroll
-                              for (int r = 0; r < 4; ++r) atomicAdd(d + r, acc[mt][r]);
-                            }
+                            for (int mt = 0; mt < 4; ++mt)
+                              *reinterpret_cast<f32x4*>(p.dn1acc + ((long long)c * p.B * NA + r0 + mt * 16 + ln) * CB + ct * 16 + 4 * g) = acc[mt];
                           });
 }
 
@@ -1019,7 +1027,12 @@ __global__ __launch_bounds__(512) void agent_int_attn_bwd_kernel(IntArgs p) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int c = rcol(j, lane, 0);
-        const float2 dy = *reinterpret_cast<const float2*>(p.dn1acc + (r0 + row) * CB + c);
+        float2 dy = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int cc = 0; cc < FF / CB; ++cc) {
+          const float2 t2 = *reinterpret_cast<const float2*>(p.dn1acc + ((long long)cc * p.B * NA + r0 + row) * CB + c);
+          dy.x += t2.x; dy.y += t2.y;
+        }
         xh[j][0] = (x[j][0] - mu) * rs; xh[j][1] = (x[j][1] - mu) * rs;
         ag1[j][0] += dy.x * xh[j][0]; ab1[j][0] += dy.x; ag1[j][1] += dy.y * xh[j][1]; ab1[j][1] += dy.y;
         t[j][0] = dy.x * p.g1[c]; t[j][1] = dy.y * p.g1[c + 1];
@@ -1124,13 +1137,15 @@ __global__ __launch_bounds__(512) void agent_int_attn_bwd_kernel(IntArgs p) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int tok = mt * 16 + ln;
-      const bool cm = kval[tok] != 0;
+      const float cm = kval[tok] != 0 ? 1.f : 0.f;
+      f32x4 de;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float q = dqi[j][mt][r];
         if (tok < p.n_obs) e0[r] += q; else e1[r] += q;
-        if (cm) atomicAdd(p.d_enc + (r0 + tok) * CB + col + r, q + dco[j][mt][r]);
+        de[r] = cm * (q + dco[j][mt][r]);
       }
+      *reinterpret_cast<f32x4*>(p.d_enc + ((long long)(1 + h) * p.B * NA + r0 + tok) * CB + col) = de;      // slab 1 + h (slab 0: the residual's share)
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -23,7 +23,7 @@ typedef struct stj_agent_enc_args {
   void* s_nodes; void* s_qkv; void* s_att; void* s_pmask; void* s_cat;     // saved for backward ([rows 11][64], [rows 11][768], [rows 11][256], uint16 [agents][320], [agents][384]); all NULL: inference
   const long long* rng_state; int site; float p_drop;                    // attention dropout, drawn as stj_dropout draws [agents][4][11][11]
   /* backward only */
-  const void* d_enc; int d_enc_f32;          // [agents][384], activation dtype or (d_enc_f32 != 0) f32
+  const void* d_enc; int d_enc_f32;          // [agents][384] in the activation dtype (d_enc_f32 = 0), or d_enc_f32 f32 slabs [d_enc_f32][agents][384] to be added
   const void* wq; const void* wk; const void* wv; const void* wo; const void* ws;      // the kernels in the activation dtype, natural layouts
   void* dpre_s; void* dout; void* dqkv;      // written: dY of sublayer [agents][384], projection [rows 11][320], q|k|v [rows 11][768]
   float* dwn; float* dbn; float* dwv3;       // += (atomics)
@@ -37,14 +37,14 @@ typedef struct stj_agent_int_args {
   const float* bo; const float* g1; const float* be1; const float* b1; const float* b2; const float* g2; const float* be2;     // cross_attention: projection_bias, norm1, FFN1 / FFN2 bias, norm2 (f32 masters)
   const float* g_obs; const float* b_obs; const float* g_occ; const float* b_occ;                                             // obs_norm | occ_norm
   void* key;                                 // out [B 64][384]
-  float* ws_v1; float* ws_u2;                // forward workspaces [B 64][384] f32 each, ZEROED by the caller: the heads' / hidden chunks' partial sums meet here
+  float* ws_v1; float* ws_u2;                // forward workspaces: [6][B 64][384] and [4][B 64][384] f32 (per head / per hidden chunk partial sums, added in a fixed order: no atomics)
   void* s_concat; void* s_qin; void* s_q; void* s_k; void* s_v; void* s_att; void* s_v1; void* s_n1; void* s_h; void* s_u2; void* s_out;   // saved for backward ([B 64][384]; s_h [B 64][1536]); all NULL: inference
   const long long* rng_state; int site_a, site_1, site_2; float p_drop;      // dropout sites: coefficients [B][6][64][64], after FFN1 [B 64][1536], after FFN2 [B 64][384]
   /* backward only */
   const void* dkey;
   const void* wq; const void* wk; const void* wv; const void* wo; const void* w1; const void* w2;      // natural layouts, activation dtype
-  float* d_enc;                              // written: gradient of enc, [B 64][384] f32
-  float* ws_dn1;                             // backward workspace [B 64][384] f32, ZEROED by the caller
+  float* d_enc;                              // written: gradient of enc as 7 slabs [7][B 64][384] f32 (stj_agent_enc_bwd with d_enc_f32 = 7 adds them)
+  float* ws_dn1;                             // backward workspace [4][B 64][384] f32
   void* dq; void* dk; void* dv; void* dv1; void* dpre1; void* dz2;          // written: dY of the q / k / v projections, the output projection, FFN1, FFN2
   float* dseg; float* dg1; float* dbe1; float* dg2; float* dbe2; float* dg_obs; float* db_obs; float* dg_occ; float* db_occ;      // += (atomics)
 } stj_agent_int_args;

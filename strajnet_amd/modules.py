@@ -249,9 +249,12 @@ class STrajNet:
         self.agent_override = None            # (key, mask) from agent_encode(): call() then skips the agent branch
         self.mid_forward_hook = None          # callable run once per forward pass behind the encoder's first stage (GraphedTrainStep: loss.prepare on its side stream)
         self.fused_fgattn = True       # FG-MSA attention core as one kernel per direction (8 x 8 / 16 x 16 maps; all three storage types)
+        self.kv_in_agent_branch = False # (measured neutral: 1333-1338 either way) the cross-attention's key / value projections of the agent encoding issued on the agent branch's stream
+        self._xattn_kv_pre = None
         self.fused_agent = True        # TrajEncoder of all agents as one kernel per direction (csrc/agent_fused.hip); False = the layer-by-layer chain
         self.fused_agent_int = True    # ... and the 64-agent interaction block (16-bit storage types)
         self._agent_pack = None
+        self._agent_pack_event = None
         self._agent_pack_stale = True
         self._xattn_pack = None
         self.params = OrderedDict()
@@ -700,6 +703,15 @@ class STrajNet:
         self._xattn_pack = ops.xattn_pack(self._xattn_params(), self._zstride, 8, self.dtype, out=self._xattn_pack)
         self._xattn_pack_stale = False
 
+    def _xattn_kv(self, key):
+        """key [B,64,Cb] -> (k, v) [8, B*64, 126]: the 8 sets' tfa key / value projections (kernels [3,384,42], addressed in place), one grouped launch."""
+        zs = self._zstride
+        with ops.gemm_group():
+            pk, pv = self._zp('mha/key_kernel'), self._zp('mha/value_kernel')
+            k = ops.linear_heads_in_z(key, pk.master, pk.c, pk.grad, zs, 8, True)
+            v = ops.linear_heads_in_z(key, pv.master, pv.c, pv.grad, zs, 8, True)
+        return k, v
+
     def _cross_attention_z(self, query, key, tmask):
         """8 x Cross_AttentionT (trajNet.py:224-234) + query residual in one batched pass, waypoint-major:
         query [8,B,HW,Cb], key [B,64,Cb] -> [8,B,HW,Cb]."""
@@ -714,14 +726,13 @@ class STrajNet:
         if self.fused_xattn and A == 64 and HW % 64 == 0 and Cb == 384:
             # ONE kernel: q projection, masked softmax attention, out projection, LN, FFN, LN, + query (csrc/xattn_fused.hip);
             # only the projections of the 64 agent keys / values stay GEMMs (one grouped launch)
-            with ops.gemm_group():
-                k = proj_in(key, 'mha/key_kernel', True)                         # [8, B*64, 126]
-                v = proj_in(key, 'mha/value_kernel', True)
+            pre, self._xattn_kv_pre = self._xattn_kv_pre, None
+            k, v = pre if pre is not None else self._xattn_kv(key)
             ps = self._xattn_params()
             if self._xattn_pack_stale:
                 self._pack_xattn()
             return ops.xattn(query, k, v, tmask, self._xattn_pack, ps, zs, self._dctx,
-                             ('cross_attn_obs/mha/dropout', 'cross_attn_obs/dropout1', 'cross_attn_obs/dropout2'))
+                             ('cross_attn_obs/mha/dropout', 'cross_attn_obs/dropout1', 'cross_attn_obs/dropout2'), defer_wg=pre is not None)
         with ops.gemm_group():
             q = proj_in(query, 'mha/query_kernel', False)                    # [8, B*HW, 126]
             k = proj_in(key, 'mha/key_kernel', True)                         # [8, B*64, 126]
@@ -843,11 +854,17 @@ class STrajNet:
         self._prep_event = None
         self._xattn_pack_stale = True
         self._agent_pack_stale = True
+        self._agent_pack_event = None
 
         def issue_prep():
             if self._side2 is not None:
                 self._side2.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self._side2):
+                    if self.fused_agent and self._agent_pack_stale:      # the agent branch's weight pack: with the other preparations, not on its chain
+                        self._agent_pack = ops.agent_pack(self._agent_ws(), self.dtype, out=self._agent_pack)
+                        self._agent_pack_stale = False
+                        self._agent_pack_event = torch.cuda.Event()
+                        self._agent_pack_event.record(self._side2)
                     if self.fused_xattn:
                         self._pack_xattn()
                     self._upconv_prep = {n: ops.upconv_prep(self._p(n + '/kernel'), self.dtype) for n in names}
@@ -870,10 +887,20 @@ class STrajNet:
             agent.extend(self.agent_override)
             mode = -2
 
+        self._xattn_kv_pre = None
+
         def issue_agent():
             self._side.wait_event(fork)
+            if self._agent_pack_event is not None:
+                self._side.wait_event(self._agent_pack_event)
             with torch.cuda.stream(self._side):
                 agent.extend(self._traj_net(obs, occ))
+                if self.kv_in_agent_branch and self.fused_xattn and agent[0].shape[1] == 64 and Cb == 384:
+                    # the 8 sets' key / value projections of the agent encoding belong to the cross-attention (trajNet.py:225) but depend on
+                    # the agent branch only: issued HERE, on its stream, their backward (two grouped launches, ~80 us in the step) runs beside
+                    # the FG-MSA backward instead of in front of it on the main stream -- and autograd, which runs the most recently
+                    # created nodes first, reaches FG-MSA's nodes before these
+                    self._xattn_kv_pre = self._xattn_kv(agent[0])
         if mode >= 0:
             main = torch.cuda.current_stream(self.device)
             fork = torch.cuda.Event()
@@ -891,10 +918,10 @@ class STrajNet:
             issue_prep()
 
         def hook():
-            if mode == 2:
-                issue_agent()
             if late:
                 issue_prep()
+            if mode == 2:
+                issue_agent()
             if self.mid_forward_hook is not None:
                 self.mid_forward_hook()
         res_list = self._encoder(ogm, map_img, flow, hook=hook)
@@ -935,6 +962,9 @@ class STrajNet:
             main.wait_stream(self._side)
             key.record_stream(main)
             tmask.record_stream(main)
+            if self._xattn_kv_pre is not None:
+                for t in self._xattn_kv_pre:
+                    t.record_stream(main)
         self._tap('agent_key', key)
         self._tap('query', query)
         if self._prep_event is not None:                 # the packed cross-attention weights come from the side stream

@@ -273,7 +273,7 @@ def wgrad_stream(kind, *operands):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _WG.get(key)
     if st is None:
-        st = _WG[key] = {'side': role_stream(dev, 'wgrad', priority=int(os.environ.get('STJ_WG_PRIO', '0'))), 'keep': [], 'armed': False, 'main': None}
+        st = _WG[key] = {'side': role_stream(dev, 'wgrad')      # (a low-priority stream measured nothing: 1341 / 1360 / 1345 vs 1350 / 1363 / 1349 scenes/s), 'keep': [], 'armed': False, 'main': None}
     main = torch.cuda.current_stream(dev)
     st['side'].wait_stream(main)
     st['keep'].extend(operands)
@@ -309,6 +309,8 @@ class _JoinAfterBackward(torch.autograd.Function):
             key = g.device.index if g.device.index is not None else torch.cuda.current_device()
             st = _WG.get(key)
             flush_upconv_wgrads()             # (leftovers: a flush point whose backward did not run)
+            with torch.cuda.stream(main), torch.no_grad():
+                run_pending_wg(g.device)      # (handed-over weight gradients nobody took)
             st = _WG.get(key)
             if st is not None and st['armed']:
                 main.wait_stream(st['side'])
@@ -593,6 +595,25 @@ def linear(x, pw, pb=None, act=ACT_NONE, res=None):
                          pb.grad if pb is not None else None, act, res, None)
 
 
+# Weight-gradient launches handed from one backward node to another that runs on a different stream (the fused cross-attention's four
+# products -> the key / value projections' backward on the agent branch's stream): (closure, event behind the producer, operands).
+_PENDING_WG = {}
+
+
+def run_pending_wg(dev=None):
+    """Launch the handed-over weight gradients on the CURRENT stream of `dev` (ordered behind their producers)."""
+    idx = dev.index if dev is not None and dev.index is not None else torch.cuda.current_device()
+    items = _PENDING_WG.pop(idx, [])
+    if not items:
+        return
+    cur = torch.cuda.current_stream(dev)
+    for wg, ev, operands in items:
+        cur.wait_event(ev)
+        for t in operands:
+            t.record_stream(cur)
+        wg()
+
+
 class _HeadsIn(torch.autograd.Function):
     """tfa-MHA query / key / value projection for Z weight sets at once: y[z, r, h*hs + o] = sum_i x[(z|shared), r, i] W[z][h, i, o].
     The kernels [H, in, hs] are read and their gradients written IN PLACE in the flat buffers: every product is a batched GEMM over
@@ -617,6 +638,7 @@ class _HeadsIn(torch.autograd.Function):
         Z, R, H, I, hs, zstride, shared_x, xshape = ctx.dims
         dt = _dt(x)
         dy = dy.contiguous()
+        run_pending_wg(dy.device)
         dx = acc = None
         with gemm_group(R < _GROUP_MAX_ROWS and not (_WG_MODE & 1)):          # input and weight gradient: independent products
             if ctx.needs_input_grad[0]:
@@ -1299,7 +1321,7 @@ class _XAttn(torch.autograd.Function):
     further in the flat buffers).  Backward = ONE kernel + the dk / dv tile reduction + one grouped launch of the four weight-gradient
     GEMMs, on operands the backward kernel writes once."""
     @staticmethod
-    def forward(ctx, query, k, v, trig, kvalid, pack, ps, zstride, drop):
+    def forward(ctx, query, k, v, trig, kvalid, pack, ps, zstride, drop, defer_wg=False):
         _req_cuda(query, k, v)
         query, k, v = query.contiguous(), k.contiguous(), v.contiguous()
         Z, B, HW, Cb = query.shape
@@ -1316,7 +1338,7 @@ class _XAttn(torch.autograd.Function):
         call('stj_xattn_fwd', _p(query), _p(k), _p(v), _p(kvalid), _p(pack), _p(ps['bo'].master), _p(ps['g1'].master), _p(ps['be1'].master),
              _p(ps['b1'].master), _p(ps['b2'].master), _p(ps['g2'].master), _p(ps['be2'].master), zstride, _p(y), _p(sq), _p(so), _p(sv1),
              _p(su2), Z, B, HW, _p(state), sites[0], sites[1], sites[2], float(p_drop), dt, _st())
-        ctx.ps, ctx.zstride, ctx.drop, ctx.pack = ps, zstride, drop, pack
+        ctx.ps, ctx.zstride, ctx.drop, ctx.pack, ctx.defer_wg = ps, zstride, drop, pack, defer_wg
         ctx.save_for_backward(query, k, v, kvalid, sq, so, sv1, su2)
         return y
 
@@ -1346,8 +1368,10 @@ class _XAttn(torch.autograd.Function):
              _p(ps['b1'].master), _p(ps['g2'].master), zs, _p(sq), _p(sv1), _p(su2), _p(dquery), _p(dk), _p(dv), _p(dkp), _p(dvp), _p(hd),
              _p(dpre), _p(du2), _p(n1), _p(dv1), _p(dq), _p(ps['g1'].grad), _p(ps['be1'].grad), _p(ps['bo'].grad), _p(ps['g2'].grad),
              _p(ps['be2'].grad), Z, B, HW, _p(state), sites[0], sites[1], sites[2], float(p_drop), dt, _st())
-        # the four weight gradients of the Z sets, straight into the flat gradient buffer: one grouped launch
-        with wgrad_stream(XATTN_WG_KIND, hd, dpre, du2, n1, dv1, dq, so, query), gemm_group():
+        # the four weight gradients of the Z sets, straight into the flat gradient buffer: one grouped launch -- here, or (defer_wg) handed to
+        # the key / value projections' backward, which runs on the agent branch's stream: nobody on the main chain waits for them
+        def wg():
+          with wgrad_stream(XATTN_WG_KIND, hd, dpre, du2, n1, dv1, dq, so, query), gemm_group():
             gemm(hd, du2, ps['w2'].grad, 512, 384, R, (0, R * 512, 1, 512), (0, R * 384, 384, 1), (0, zs, 384), dt, nb=(1, Z), c_f32=1,
                  accumulate=1, splitk=0, colsum=ps['b2'].grad, sBias=(0, zs))                      # dW2 += hd^T du2 ; db2
             gemm(n1, dpre, ps['w1'].grad, 128, 512, R, (0, R * 128, 1, 128), (0, R * 512, 512, 1), (0, zs, 512), dt, nb=(1, Z), c_f32=1,
@@ -1356,10 +1380,16 @@ class _XAttn(torch.autograd.Function):
                  c_f32=1, accumulate=1, splitk=0)                                                  # dWo[z,h] += O_h^T dv1
             gemm(query, dq, ps['wq'].grad, 384, 42, R, (R * 384, 0, 1, 384), (R * 144, 48, 144, 1), (zs, 384 * 42, 42), dt, nb=(Z, 3),
                  c_f32=1, accumulate=1, splitk=0)                                                  # dWq[z,h] += query^T dq_h
-        return dquery, dk, dv, None, None, None, None, None, None
+        if ctx.defer_wg:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            _PENDING_WG.setdefault(dev.index, []).append((wg, ev, (hd, dpre, du2, n1, dv1, dq, so, query)))
+        else:
+            wg()
+        return dquery, dk, dv, None, None, None, None, None, None, None
 
 
-def xattn(query, k, v, kvalid, pack, ps, zstride, dctx=None, names=None, p_drop=0.1):
+def xattn(query, k, v, kvalid, pack, ps, zstride, dctx=None, names=None, p_drop=0.1, defer_wg=False):
     """Fused Cross_AttentionT x Z.  ps: dict of set-0 Params {wq, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2}; dctx / names: the three
     dropout sites of a training step (attention coefficients, after FFN1, after FFN2), registered with the unfused draw shapes."""
     Z, B, HW, _ = query.shape
@@ -1368,7 +1398,7 @@ def xattn(query, k, v, kvalid, pack, ps, zstride, dctx=None, names=None, p_drop=
         sites = (dctx.site(names[0], (Z, B, 3, HW, 64), p_drop), dctx.site(names[1], (Z, B * HW, 512), p_drop),
                  dctx.site(names[2], (Z, B * HW, 384), p_drop))
         drop = (float(p_drop), dctx.snap, sites)
-    return _XAttn.apply(query, k, v, _trig(ps['wq'].master), kvalid, pack, ps, zstride, drop)
+    return _XAttn.apply(query, k, v, _trig(ps['wq'].master), kvalid, pack, ps, zstride, drop, defer_wg and not _SERIAL)
 
 
 def _xattn_cost(kind):
@@ -1793,10 +1823,10 @@ class _AgentBranch(torch.autograd.Function):
                          bo=m('e_bo'), bs=m('e_bs'), enc=_ip(enc), cmi=_ip(cmi), rng_state=_ip(state), site=sites[0], p_drop=float(p_drop),
                          **{k: _ip(v) for k, v in se.items()})
         call('stj_agent_enc_fwd', ctypes.byref(a), _st())
-        acc = zeros_f32((2, B * A, C), dev)              # where the heads' / hidden chunks' partial sums meet
+        acc = torch.empty((10, B * A, C), dtype=torch.float32, device=dev)       # slabs of the six heads' / four hidden chunks' partial sums
         ai = AgentIntArgs(enc=_ip(enc), cmi=_ip(cmi), n_obs=n_obs, n_occ=n_occ, B=B, dtype=dt, pack=_ip(pack), seg=_ip(ws['seg'].c),
                           bo=m('i_bo'), g1=m('g1'), be1=m('be1'), b1=m('b1'), b2=m('b2'), g2=m('g2'), be2=m('be2'), g_obs=m('g_obs'), b_obs=m('b_obs'),
-                          g_occ=m('g_occ'), b_occ=m('b_occ'), key=_ip(key), ws_v1=_ip(acc[0]), ws_u2=_ip(acc[1]), rng_state=_ip(state),
+                          g_occ=m('g_occ'), b_occ=m('b_occ'), key=_ip(key), ws_v1=_ip(acc[0]), ws_u2=_ip(acc[6]), rng_state=_ip(state),
                           site_a=sites[1], site_1=sites[2], site_2=sites[3], p_drop=float(p_drop), **{k: _ip(v) for k, v in si.items()})
         call('stj_agent_int_fwd', ctypes.byref(ai), _st())
         ctx.ws, ctx.drop, ctx.geo, ctx.tdtype = ws, drop, (B, n_obs, n_occ, Tn), dtype
@@ -1818,8 +1848,8 @@ class _AgentBranch(torch.autograd.Function):
         R, rows = B * A, B * A * Tn
         dev, dt = enc.device, DTYPE_CODE[dtype]
         dkey = dkey.contiguous()
-        d_enc = torch.empty((R, C), dtype=torch.float32, device=dev)
-        dn1acc = zeros_f32((R, C), dev)
+        d_enc = torch.empty((7, R, C), dtype=torch.float32, device=dev)          # slabs: the residual's share + one per head
+        dn1acc = torch.empty((4, R, C), dtype=torch.float32, device=dev)         # one per hidden chunk
         dY = {k: torch.empty((R, 1536 if k == 'dpre1' else C), dtype=dtype, device=dev) for k in ('dq', 'dk', 'dv', 'dv1', 'dpre1', 'dz2')}
         p_drop, state, sites = ctx.drop if ctx.drop is not None else (0.0, None, (0, 0, 0, 0))
         m, c, gr = (lambda k: _ip(ws[k].master)), (lambda k: _ip(ws[k].c)), (lambda k: _ip(ws[k].grad))
@@ -1834,7 +1864,7 @@ class _AgentBranch(torch.autograd.Function):
         dout = torch.empty((rows, 320), dtype=dtype, device=dev)
         dqkv = torch.empty((rows, 768), dtype=dtype, device=dev)
         a = AgentEncArgs(obs=_ip(obs), occ=_ip(occ), n_obs=n_obs, n_occ=n_occ, B=B, dtype=dt, enc=_ip(enc), cmi=_ip(cmi),
-                         rng_state=_ip(state), site=sites[0], p_drop=float(p_drop), d_enc=_ip(d_enc), d_enc_f32=1,
+                         rng_state=_ip(state), site=sites[0], p_drop=float(p_drop), d_enc=_ip(d_enc), d_enc_f32=7,
                          wq=c('e_wq'), wk=c('e_wk'), wv=c('e_wv'), wo=c('e_wo'), ws=c('e_ws'),
                          dpre_s=_ip(dpre_s), dout=_ip(dout), dqkv=_ip(dqkv), dwn=gr('wn'), dbn=gr('bn'), dwv3=gr('wv3'),
                          **{k: _ip(v) for k, v in se.items()})
@@ -2102,7 +2132,7 @@ _UPWG = {'on': False, 'items': []}
 # Issue order of the deferred launches.  'bwd' = the order backward produced them (full-resolution layers first, the two wide layers
 # 192 -> 128 / 384 -> 192 last: those are 1024-workgroup non-persistent launches and land on Swin stage 2's backward); 'wide' = widest
 # Cin first, so that they run beside the thin FG-MSA / agent chain and only the budgeted persistent launches reach into the encoder.
-UPWG_ORDER = os.environ.get('STJ_UPWG_ORDER', 'wide')     # round 6, alternating same-box runs: bwd 1350 / 1363 / 1349, wide 1372 / 1365 / 1359, rev 1340 / 1351 / 1353 scenes/s
+UPWG_ORDER = 'wide'     # round 6, alternating same-box runs: bwd 1350 / 1363 / 1349, wide 1372 / 1365 / 1359, rev 1340 / 1351 / 1353 scenes/s
 
 
 def flush_upconv_wgrads():

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, first GPU session: deferred up-conv weight-gradient order / stream priority A/B on the training bench (alternating same-box runs)
+# round 6, first GPU session (the two switches were environment variables then; UPWG_ORDER is a module constant of ops.py now): deferred up-conv weight-gradient order / stream priority A/B on the training bench (alternating same-box runs)
 cd $GRAFT_REPO_ROOT 2>/dev/null || true
 mkdir -p gpurun_out
 line() { python -c "
