@@ -15,20 +15,22 @@
 #include "common.h"
 #include <stdlib.h>
 
-#define PS_TH 8
 #define PS_TW 16
 #define PS_HW (PS_TW + 2)
-#define PS_HH (PS_TH + 2)
 #define PS_KC 32
 
-template <typename T, int FN, int MINB>
+// TH = rows of the low-res tile.  16 (round 6): the workgroup's weight stream -- every workgroup reads all 16 tap matrices of its cout block,
+// 393 KB at Cin = 384, and with 8-row tiles that was 302 of the 400 MB the 384 -> 192 launch pulls out of L2, the level this kernel saturates
+// (~6 TB/s) -- is amortised over twice the pixels; the epilogue goes through the LDS stage in two halves so that two workgroups still share a CU.
+template <typename T, int FN, int MINB, int TH>
 __global__ __launch_bounds__(256, MINB) void upconv_fwd_ps_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
                                                                   const float* __restrict__ bias, T* __restrict__ Y,
                                                                   const T* __restrict__ R1, T* __restrict__ Y2, const T* __restrict__ R2,
                                                                   int F, int Hi, int Wi, int Cin, int Cout) {
   constexpr int LDK = PS_KC + 16;                  // 96-byte pixel stride: 2 (mod 4) 16-byte slots, conflict-free b128 fragment reads
   constexpr int CT = FN * 16, LDO = CT + 8;
-  constexpr int HPIX = PS_HH * PS_HW;              // 180
+  constexpr int PS_TH = TH, PS_HH = TH + 2;
+  constexpr int HPIX = PS_HH * PS_HW;              // 180 / 324
   constexpr int NCH = (HPIX * 4 + 255) / 256;      // 16-byte chunks per thread per halo chunk (3)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* halo0 = reinterpret_cast<T*>(smem_raw);
@@ -53,14 +55,14 @@ __global__ __launch_bounds__(256, MINB) void upconv_fwd_ps_kernel(const T* __res
     for (int n = 0; n < FN; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // per-thread halo chunk geometry (does not depend on the channel chunk)
-  long long hoff[NCH]; bool hin[NCH]; int hlds[NCH];
+  int hoff[NCH]; bool hin[NCH]; int hlds[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int q = tid + i * 256;
     const int px = q >> 2, ch = (q & 3) * 8;
     const int gy = ty0 + px / PS_HW - 1, gx = tx0 + px % PS_HW - 1;
     hin[i] = q < HPIX * 4 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
-    hoff[i] = hin[i] ? ((long long)gy * Wi + gx) * Cin + ch : 0;      // out-of-image pixels load pixel 0 and are zeroed on the way to LDS
+    hoff[i] = hin[i] ? (gy * Wi + gx) * Cin + ch : 0;      // out-of-image pixels load pixel 0 and are zeroed on the way to LDS
     hlds[i] = q < HPIX * 4 ? px * LDK + ch : -1;
   }
   long long woff[FN];
@@ -80,77 +82,76 @@ __global__ __launch_bounds__(256, MINB) void upconv_fwd_ps_kernel(const T* __res
     for (int i = 0; i < NCH; ++i)
       if (hlds[i] >= 0) *reinterpret_cast<uint4*>(h + hlds[i]) = hin[i] ? pre[i] : make_uint4(0, 0, 0, 0);
   };
-  auto ld_w = [&](int c0, s16x8 (&wv)[4][FN]) {
+  // the chunk's tap matrices of tap column s: [0] = tap row 0, [1] = tap row 1 -- half a chunk's weights at a time (with 16-row tiles the
+  // accumulators take 128 registers: a whole chunk in flight next to a whole chunk in use spilled)
+  auto ld_w = [&](int c0, int sh, s16x8 (&wv)[2][FN]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int n = 0; n < FN; ++n) {
-        wv[t][n] = *reinterpret_cast<const s16x8*>(Wf + woff[n] + t * wtap + c0);
-      }
+      for (int n = 0; n < FN; ++n) wv[r][n] = *reinterpret_cast<const s16x8*>(Wf + woff[n] + (2 * r + sh) * wtap + c0);
   };
-  auto compute = [&](const T* h, const s16x8 (&wv)[4][FN]) {
+  auto compute = [&](const T* h, int sh, const s16x8 (&wv)[2][FN]) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int hr = 0; hr <= PS_TH; ++hr) {
+      const s16x8 xb = *reinterpret_cast<const s16x8*>(h + ((hr + a) * PS_HW + ln + b + sh) * LDK + g * 8);
+      if (hr < PS_TH) {
 #pragma unroll
-      for (int hr = 0; hr <= PS_TH; ++hr) {
-        const s16x8 xb = *reinterpret_cast<const s16x8*>(h + ((hr + a) * PS_HW + ln + b + s) * LDK + g * 8);
-        if (hr < PS_TH) {
-#pragma unroll
-          for (int n = 0; n < FN; ++n) acc[hr][n] = Mma<T>::mma(wv[s][n], xb, acc[hr][n]);                 // r = 0: D[cout][pixel]
-        }
-        if (hr >= 1) {
-#pragma unroll
-          for (int n = 0; n < FN; ++n) acc[hr - 1][n] = Mma<T>::mma(wv[2 + s][n], xb, acc[hr - 1][n]);     // r = 1
-        }
+        for (int n = 0; n < FN; ++n) acc[hr][n] = Mma<T>::mma(wv[0][n], xb, acc[hr][n]);                 // r = 0: D[cout][pixel]
       }
+      if (hr >= 1) {
+#pragma unroll
+        for (int n = 0; n < FN; ++n) acc[hr - 1][n] = Mma<T>::mma(wv[1][n], xb, acc[hr - 1][n]);         // r = 1
+      }
+    }
   };
 
-  s16x8 w0[4][FN], w1[4][FN];
-  ld_w(0, w0);
+  s16x8 wA[2][FN], wB[2][FN];
+  ld_w(0, 0, wA);
   ld_halo(0);
   st_halo(halo0);
   __syncthreads();
-  for (int c = 0; c < nch; c += 2) {
-    int cn = min(c + 1, nch - 1) * PS_KC;          // (the last prefetch re-reads the last chunk: unconditional loads keep the
-    ld_w(cn, w1);                                  //  register arrays out of scratch)
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    const T* hc = halo0 + (c & 1) * (HPIX * LDK);
+    T* hn = halo0 + ((c + 1) & 1) * (HPIX * LDK);
+    const int cn = min(c + 1, nch - 1) * PS_KC;    // (the last prefetch re-reads the last chunk: unconditional loads keep the register arrays out of scratch)
+    ld_w(c * PS_KC, 1, wB);
     ld_halo(cn);
-    compute(halo0, w0);
-    st_halo(halo1);
-    __syncthreads();
-    if (c + 1 >= nch) break;
-    cn = min(c + 2, nch - 1) * PS_KC;
-    ld_w(cn, w0);
-    ld_halo(cn);
-    compute(halo1, w1);
-    st_halo(halo0);
+    compute(hc, 0, wA);
+    ld_w(cn, 0, wA);
+    compute(hc, 1, wB);
+    st_halo(hn);
     __syncthreads();
   }
   __syncthreads();                                 // (halo stores of the dangling prefetch are done: the stage may overwrite them)
 
-  // ---- bias + ELU into the stage: lane holds couts n*16 + 4g .. +3 of output pixel (2j + a, 2 ln + b) ----
+  // ---- bias + ELU into the stage (8 tile rows at a time): lane holds couts n*16 + 4g .. +3 of output pixel (2j + a, 2 ln + b) ----
+  float bv[FN][4];
 #pragma unroll
-  for (int n = 0; n < FN; ++n) {
-    float bv[4];
+  for (int n = 0; n < FN; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = n0 + n * 16 + g * 4 + r;
-      bv[r] = co < Cout ? bias[co] : 0.f;
+      bv[n][r] = co < Cout ? bias[co] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < PS_TH; ++j) {
-      const uint32_t p0 = pack2<T>(elu_bf(acc[j][n][0] + bv[0]), elu_bf(acc[j][n][1] + bv[1]));
-      const uint32_t p1 = pack2<T>(elu_bf(acc[j][n][2] + bv[2]), elu_bf(acc[j][n][3] + bv[3]));
-      *reinterpret_cast<uint2*>(ostage + ((2 * j + a) * (2 * PS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
-    }
-  }
-  __syncthreads();
-  {
+  for (int hj = 0; hj < PS_TH; hj += 8) {
+    if (hj) __syncthreads();                         // the previous half has left the stage
+#pragma unroll
+    for (int n = 0; n < FN; ++n)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t p0 = pack2<T>(elu_bf(acc[hj + j][n][0] + bv[n][0]), elu_bf(acc[hj + j][n][1] + bv[n][1]));
+        const uint32_t p1 = pack2<T>(elu_bf(acc[hj + j][n][2] + bv[n][2]), elu_bf(acc[hj + j][n][3] + bv[n][3]));
+        *reinterpret_cast<uint2*>(ostage + ((2 * j + a) * (2 * PS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
+      }
+    __syncthreads();
     constexpr int SEG = CT / 8;
     const int Ho = 2 * Hi, Wo = 2 * Wi;
     T* Yf = Y + (long long)f * Ho * Wo * Cout;
-    for (int q = tid; q < 2 * PS_TH * 2 * PS_TW * SEG; q += 256) {
+    for (int q = tid; q < 2 * 8 * 2 * PS_TW * SEG; q += 256) {
       const int sg = q % SEG, p = q / SEG;
-      const int oy = 2 * ty0 + p / (2 * PS_TW), ox = 2 * tx0 + p % (2 * PS_TW), co = n0 + sg * 8;
+      const int oy = 2 * (ty0 + hj) + p / (2 * PS_TW), ox = 2 * tx0 + p % (2 * PS_TW), co = n0 + sg * 8;
       if (oy < Ho && ox < Wo && co < Cout) {
         const long long o = ((long long)oy * Wo + ox) * Cout + co;
         if (R1 == nullptr) {
@@ -180,18 +181,18 @@ __global__ __launch_bounds__(256, MINB) void upconv_fwd_ps_kernel(const T* __res
   }
 }
 
-template <typename T, int FN, int MINB>
+template <typename T, int FN, int MINB, int TH>
 static bool fwd_ps_launch(const void* X, const void* Wf, const float* bias, void* Y, const void* R1, void* Y2, const void* R2, int F, int Hi, int Wi, int Cin, int Cout, hipStream_t st) {
   constexpr int LDK = PS_KC + 16, CT = FN * 16, LDO = CT + 8;
-  const size_t lds_h = (size_t)2 * PS_HH * PS_HW * LDK * 2, lds_o = (size_t)2 * PS_TH * 2 * PS_TW * LDO * 2;
+  const size_t lds_h = (size_t)2 * (TH + 2) * PS_HW * LDK * 2, lds_o = (size_t)2 * 8 * 2 * PS_TW * LDO * 2;
   const size_t lds = lds_h > lds_o ? lds_h : lds_o;
   static PerDevice<bool> attr_set;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)upconv_fwd_ps_kernel<T, FN, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)upconv_fwd_ps_kernel<T, FN, MINB, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     attr_set = true;
   }
-  const int tiles = ((Wi + PS_TW - 1) / PS_TW) * ((Hi + PS_TH - 1) / PS_TH) * F;
-  hipLaunchKernelGGL((upconv_fwd_ps_kernel<T, FN, MINB>), dim3(tiles, (Cout + CT - 1) / CT), dim3(256), lds, st, (const T*)X, (const T*)Wf, bias,
+  const int tiles = ((Wi + PS_TW - 1) / PS_TW) * ((Hi + TH - 1) / TH) * F;
+  hipLaunchKernelGGL((upconv_fwd_ps_kernel<T, FN, MINB, TH>), dim3(tiles, (Cout + CT - 1) / CT), dim3(256), lds, st, (const T*)X, (const T*)Wf, bias,
                      (T*)Y, (const T*)R1, (T*)Y2, (const T*)R2, F, Hi, Wi, Cin, Cout);
   return true;
 }
@@ -202,7 +203,10 @@ static bool fwd_ps_try_t(const void* X, const void* Wf, const float* bias, void*
   // per CU: 64 / 93;  FN = 3: 84 / 137;  FN = 4 (one wave per SIMD): 105 / 128.  At FN = 2 the kernel moves ~6 TB/s from L2 (each
   // workgroup streams 32 KB of weights + 11.5 KB of halo per 4.2 MFLOP chunk), which is where the 64x64 GEMM tiles saturate too.
   if (Cout % 32) return false;
-  return fwd_ps_launch<T, 2, 2>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
+  static int th = -1;
+  if (th < 0) { const char* e = getenv("STJ_PS_TH"); th = e ? atoi(e) : 16; }
+  if (th == 16 && Hi % 16 == 0) return fwd_ps_launch<T, 2, 2, 16>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
+  return fwd_ps_launch<T, 2, 2, 8>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
 }
 // true when this kernel took the problem: 16-bit, ELU, Cin a multiple of 32 above the weight-stationary range
 bool upconv_fwd_ps_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,

@@ -273,7 +273,8 @@ def wgrad_stream(kind, *operands):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _WG.get(key)
     if st is None:
-        st = _WG[key] = {'side': role_stream(dev, 'wgrad')      # (a low-priority stream measured nothing: 1341 / 1360 / 1345 vs 1350 / 1363 / 1349 scenes/s), 'keep': [], 'armed': False, 'main': None}
+        # (a low-priority side stream measured nothing: 1341 / 1360 / 1345 vs 1350 / 1363 / 1349 scenes/s)
+        st = _WG[key] = {'side': role_stream(dev, 'wgrad'), 'keep': [], 'armed': False, 'main': None}
     main = torch.cuda.current_stream(dev)
     st['side'].wait_stream(main)
     st['keep'].extend(operands)
