@@ -203,9 +203,9 @@ static bool fwd_ps_try_t(const void* X, const void* Wf, const float* bias, void*
   // per CU: 64 / 93;  FN = 3: 84 / 137;  FN = 4 (one wave per SIMD): 105 / 128.  At FN = 2 the kernel moves ~6 TB/s from L2 (each
   // workgroup streams 32 KB of weights + 11.5 KB of halo per 4.2 MFLOP chunk), which is where the 64x64 GEMM tiles saturate too.
   if (Cout % 32) return false;
-  static int th = -1;
-  if (th < 0) { const char* e = getenv("STJ_PS_TH"); th = e ? atoi(e) : 16; }
-  if (th == 16 && Hi % 16 == 0) return fwd_ps_launch<T, 2, 2, 16>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
+  // round 6 (half-chunk weight staging: 152 registers at 8-row tiles, 253 at 16): 8-row tiles 54.8 / 83.9 us, 16-row tiles 55.0 / 69.5 us;
+  // end to end (alternating same-box runs, 16 vs 8 rows) inference 5533 / 5535 / 5414 vs 5515 / 5387 / 5349, training 1377 / 1373 / 1372 vs 1368 / 1374 / 1375
+  if (Hi % 16 == 0) return fwd_ps_launch<T, 2, 2, 16>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
   return fwd_ps_launch<T, 2, 2, 8>(X, Wf, bias, Y, R1, Y2, R2, F, Hi, Wi, Cin, Cout, st);
 }
 // true when this kernel took the problem: 16-bit, ELU, Cin a multiple of 32 above the weight-stationary range
