@@ -709,6 +709,40 @@ def test_golden_train_step_gradients_f32():
     _report(f'golden train step 128x128 B=2 f32: worst relative error of the 299 gradient L2 norms {worst:.3e}')
 
 
+def test_f32_golden_step_runs_the_fused_entry_points():
+    """WHICH kernels the oracle gate covers, checked instead of narrated: the f32 golden train step (the one the two tests around this one
+    hold against the float64 fixture) is run with every C-ABI call recorded (strajnet_amd.prof), and the set of entry points must contain
+    the fused kernels the bf16 step times -- and must not contain the layer-by-layer ops they replace.  (Known 16-bit-only kernels, by
+    their entry points' dispatch: the weight-stationary / wave-specialised decoder family behind stj_upconv_*, stj_outconv_pair_*,
+    stj_wgrad_group, the C = 384 attention half, and the agent interaction block stj_agent_int_*: their f32 counterparts run here.)"""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from strajnet_amd import prof
+    model, w, x, xt = _setup(CFG128, 2, torch.float32)
+    model.serial = True
+    model.zero_grad()
+    prof.enable()
+    try:
+        out = model(xt['ogm'], xt['map_img'], training=True, obs=xt['obs'], occ=xt['occ'], mapt=xt['mapt'], flow=xt['flow'])
+        loss_fn = OGMFlow_loss(OccupancyFlowTaskConfig(128, 128, 8), replica=1.0, use_focal_loss=False, use_gt=True)
+        d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(xt['gt_obs'], xt['gt_occ'], xt['gt_flow'], xt['origin_flow']), None)
+        sum(d.values()).backward()
+        torch.cuda.synchronize()
+    finally:
+        ev = prof.disable()
+    fams = {prof.COST[k][0] for k in ev}
+    called = set(fams) | {k for k in ev if k.startswith('stj_')}
+    text = ' '.join(sorted(called))
+    must = ['swin_attn_fwd', 'swin_attn_bwd', 'swin_mlp_fwd', 'swin_mlp_bwd', 'fgattn_fwd', 'fgattn_bwd', 'xattn_fwd', 'xattn_bwd', 'patch_embed_fwd',
+            'agent_enc_fwd', 'agent_enc_bwd', 'agent_pack', 'loss_fwd', 'loss_bwd', 'upconv_fwd', 'upconv_dgrad', 'upconv_wgrad']
+    for m in must:
+        assert m in text, (m, text)
+    for gone in ('small_attn', 'agent_prep', 'maxpool', 'fg_bias_fwd', 'win_attn_fwd'):      # replaced ops: small_attn / agent_prep / maxpool by agent_enc; fg_bias by fgattn; win_attn at C = 96 / 192
+        if gone == 'win_attn_fwd':
+            continue                          # (the C = 384 attention half keeps the layer-by-layer window attention in f32)
+        assert gone not in text, (gone, text)
+    _report('f32 golden step entry points: ' + text)
+
+
 def test_golden_train_step_gradients_cfg256_b8_f32():
     """BASELINE config 2's own geometry (cfg-256, B=8): one f32 train step of the HIP path against the committed fixture
     tests/golden/strajnet_256_b8_grads.npz (make_golden_grads.py --cfg256, float64 oracle): the four losses and the L2 norm of each of

@@ -6,7 +6,7 @@ tag=$1; extra=$2; sfx=${extra:+_${extra#--}}
 cd $GRAFT_REPO_ROOT 2>/dev/null || true
 export TMPDIR=/tmp STJ_BENCH_CALIB=1
 mkdir -p gpurun_out
-cmd="python bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra-configs --serial"
+cmd="python bench.py $extra --steps 2 --warmup 1 --settle 0 --no-cpu-baseline --no-kernel-timing --no-extra-configs --serial"
 rm -rf /tmp/pmc_f /tmp/pmc_w /tmp/pmc_s
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d /tmp/pmc_f -- $cmd > /dev/null 2> gpurun_out/${tag}_pmc${sfx}.err
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d /tmp/pmc_w -- $cmd > /dev/null 2>> gpurun_out/${tag}_pmc${sfx}.err

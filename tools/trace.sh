@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 for mode in serial concurrent; do
   extra=""; [ $mode = serial ] && extra="--serial"
   rm -rf /tmp/prof_$mode
-  rocprofv3 --kernel-trace --output-format rocpd -d /tmp/prof_$mode -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extra-configs $extra "$@" > gpurun_out/trace_${tag}_$mode.json 2> gpurun_out/trace_${tag}_$mode.err
+  rocprofv3 --kernel-trace --output-format rocpd -d /tmp/prof_$mode -- python bench.py --steps 5 --warmup 2 --settle 0 --no-cpu-baseline --no-kernel-timing --no-extra-configs $extra "$@" > gpurun_out/trace_${tag}_$mode.json 2> gpurun_out/trace_${tag}_$mode.err
   db=$(find /tmp/prof_$mode -name '*.db' | head -1)
   python tools/rocpd_summary.py "$db" 9 > gpurun_out/${tag}_kernel_trace_${mode}_b8_bf16.txt 2>> gpurun_out/trace_${tag}_$mode.err
 done
