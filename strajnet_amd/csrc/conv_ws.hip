@@ -1336,6 +1336,7 @@ bool outconv_pair_gather_try(const void* Z0, const void* Z1, const float* b0, co
 // the X tile shifted per tap) needs 14 + 8 + 7 in each of its four waves -- and X needs no halo any more (256 instead of 324 pixels per
 // tile).  A wave owns two of the eight k-steps (the four tile rows it also produces dX for); the four partial sums meet in LDS once,
 // at the end of the kernel.
+#define OCB_CH(mf, m) (12 * ((m) >> 2) + 4 * (mf) + ((m) & 3))
 template <int C>
 __global__ __launch_bounds__(256, 3) void outconv_bwd_mfma2_kernel(const bf16* __restrict__ X, const float* __restrict__ W,
                                                                    const float* __restrict__ dY, bf16* __restrict__ dX,
@@ -1358,7 +1359,9 @@ __global__ __launch_bounds__(256, 3) void outconv_bwd_mfma2_kernel(const bf16* _
   for (int mf = 0; mf < 3; ++mf) {
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; v[j] = k < 18 ? W[((k >> 1) * C + mf * 16 + ln) * 2 + (k & 1)] : 0.f; }
+    // row m = ln of fragment mf is channel 12 (ln >> 2) + 4 mf + (ln & 3): the three accumulator fragments of a lane are then 12 CONSECUTIVE
+    // channels (12 g + 4 mf + r) of its pixel -- 24 contiguous bytes per lane, 96 per 4 lanes -- instead of three 8-byte pieces 32 bytes apart
+    for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; v[j] = k < 18 ? W[((k >> 1) * C + OCB_CH(mf, ln)) * 2 + (k & 1)] : 0.f; }
     ax[mf] = __builtin_bit_cast(s16x8, make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])));
   }
   f32x4 wacc[3][2];
@@ -1448,19 +1451,23 @@ __global__ __launch_bounds__(256, 3) void outconv_bwd_mfma2_kernel(const bf16* _
         d[j] = t < 9 ? *reinterpret_cast<const float2*>(dys + 2 * ((row + 2 - t / 3) * OCM_H + ln + 2 - t % 3)) : make_float2(0.f, 0.f);
       }
       const s16x8 bx = __builtin_bit_cast(s16x8, make_uint4(pack2bf(d[0].x, d[0].y), pack2bf(d[1].x, d[1].y), pack2bf(d[2].x, d[2].y), pack2bf(d[3].x, d[3].y)));
-      bf16* orow = dXf + ((long long)(ty * OCM_T + row) * Ww + tx * OCM_T + ln) * C + 4 * g;
+      bf16* orow = dXf + ((long long)(ty * OCM_T + row) * Ww + tx * OCM_T + ln) * C + 12 * g;      // 24 bytes of the lane: channels 12 g .. 12 g + 11
+      uint32_t ow[6];
 #pragma unroll
       for (int mf = 0; mf < 3; ++mf) {
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax[mf]), __builtin_bit_cast(bf16x8_t, bx), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         if (elu_in) {        // X is the ELU output of the producing conv: fold ELU'(x) = (x > 0 ? 1 : x + 1) into the input gradient
-          const uint2 xv = *reinterpret_cast<const uint2*>(Xs + (row * OCM_T + ln) * LDH + mf * 16 + 4 * g);
+          const uint2 xv = *reinterpret_cast<const uint2*>(Xs + (row * OCM_T + ln) * LDH + 12 * g + 4 * mf);
           const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
           const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
           acc[0] *= x0 > 0.f ? 1.f : x0 + 1.f; acc[1] *= x1 > 0.f ? 1.f : x1 + 1.f;
           acc[2] *= x2 > 0.f ? 1.f : x2 + 1.f; acc[3] *= x3 > 0.f ? 1.f : x3 + 1.f;
         }
-        *reinterpret_cast<uint2*>(orow + mf * 16) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+        ow[2 * mf] = pack2bf(acc[0], acc[1]); ow[2 * mf + 1] = pack2bf(acc[2], acc[3]);
       }
+      // 24 bytes at an 8-byte aligned address: three 8-byte stores to consecutive addresses (the compiler may merge them; 96 contiguous bytes per 4 lanes either way)
+      uint2* o2 = reinterpret_cast<uint2*>(orow);
+      o2[0] = make_uint2(ow[0], ow[1]); o2[1] = make_uint2(ow[2], ow[3]); o2[2] = make_uint2(ow[4], ow[5]);
     }
     // ---- dW: this wave's k-steps 2w, 2w+1 (tile rows 4w .. 4w+3, 32 pixels each) ----
 #pragma unroll
