@@ -286,6 +286,32 @@ int stj_agent_enc_bwd(const stj_agent_enc_args* a, hipStream_t stream);
 int stj_agent_int_supported(int n_obs, int n_occ, int dtype);
 int stj_agent_int_fwd(const stj_agent_int_args* a, hipStream_t stream);
 int stj_agent_int_bwd(const stj_agent_int_args* a, hipStream_t stream);
+/* Fused FG-MSA offset head (csrc/fgoff_fused.hip): offset = tanh(conv_offset(q)) * (H / 2) with conv_offset = grouped 3x3 conv
+ * (8 groups of 48 channels, SAME) -> LayerNorm(eps) -> gelu -> per-group 1x1 conv 48 -> 2 without bias (FG_MSA.py:84-92,109-123), ONE launch
+ * per direction instead of stj_im2col3 + stj_gemm + stj_layernorm_fwd + stj_unary_fwd + stj_fg_offset_fwd (and their backward).  One workgroup
+ * per 16 or 32 pixels of whole image rows; the conv is an implicit GEMM over an LDS halo tile with the weights streamed as MFMA A fragments from the pack.
+ * stj_fgoff_pack: w = conv_offset_0/kernel [3][3][48][384] f32 -> both directions' fragments (stj_fgoff_pack_workspace_bytes(dtype)
+ * bytes), once per step.  Training (cols / c / mean / rstd given) also writes the im2col matrix and the saved tensors; the
+ * backward writes dq and dc and ADDS the small parameter gradients; the conv kernel's gradient cols^T dc is the caller's GEMM.
+ * C = 384, 8 groups; W = 16 (any dtype), W = 8 with even H (any dtype), W = 32 (16-bit dtypes): stj_fgoff_supported. */
+typedef struct stj_fgoff_args {
+  int B, H, W, dtype;
+  float scale, eps;                          /* offset range H / 2 (FG_MSA.py:139); LayerNorm epsilon */
+  const void* q;                             /* [B][H][W][384], activation dtype */
+  const void* pack;                          /* stj_fgoff_pack output */
+  const float* bias; const float* gamma; const float* beta;   /* conv_offset_0/bias, conv_norm gamma / beta: f32 masters [384] */
+  const void* w1;                            /* conv_offset_proj/kernel [48][2], ACTIVATION dtype */
+  void* off;                                 /* [B][8][H W][2] (forward: out; backward: in) */
+  void* cols; void* c; float* mean; float* rstd;     /* training: [B H W][8][432], [B H W][384], [B H W], [B H W]; all NULL: inference */
+  const void* doff;                          /* backward: gradient of off */
+  void* dc; void* dq;                        /* written: gradient of the conv output [B H W][384], of q [B][H][W][384] */
+  float* d_w1; float* d_gamma; float* d_beta; float* d_bias;     /* += (atomics) */
+} stj_fgoff_args;
+int stj_fgoff_supported(int H, int W, int C, int G, int dtype);
+long long stj_fgoff_pack_workspace_bytes(int dtype);
+int stj_fgoff_pack(const float* w, void* out, int dtype, hipStream_t stream);
+int stj_fgoff_fwd(const stj_fgoff_args* a, hipStream_t stream);
+int stj_fgoff_bwd(const stj_fgoff_args* a, hipStream_t stream);
 /* FG-MSA relative-position bias: bilinear `sample` of rpe_table at (query - key - offset) displacements
  * (FG_MSA.py:150-172 via occu_metric.py:345-409 + tfa_image.py:87-173).  off [B,G,H*W,2], table f32 [2H-1,2W-1,G],
  * bias f32 [B,G,HW,HW]; bwd: dtable +=, doff f32 [B,G,HW,2] += (zeroed by the caller: query slices accumulate). */

@@ -81,6 +81,11 @@ SIGNATURES = {
     'stj_agent_int_bwd': [vp, vp],
     'stj_agent_out_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp],
     'stj_agent_out_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    'stj_fgoff_supported': [ci, ci, ci, ci, ci],
+    'stj_fgoff_pack_workspace_bytes': [ci],
+    'stj_fgoff_pack': [vp, vp, ci, vp],
+    'stj_fgoff_fwd': [vp, vp],
+    'stj_fgoff_bwd': [vp, vp],
     'stj_fg_attn_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp],
     'stj_fg_attn_bwd_workspace_bytes': [ci, ci, ci, ci],
     'stj_fg_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp],
@@ -137,6 +142,13 @@ class AgentIntArgs(ctypes.Structure):
                 [('site_a', ci), ('site_1', ci), ('site_2', ci), ('p_drop', cf)] +
                 [(n, vp) for n in ('dkey', 'wq', 'wk', 'wv', 'wo', 'w1', 'w2', 'd_enc', 'ws_dn1', 'dq', 'dk', 'dv', 'dv1', 'dpre1', 'dz2',
                                    'dseg', 'dg1', 'dbe1', 'dg2', 'dbe2', 'dg_obs', 'db_obs', 'dg_occ', 'db_occ')])
+
+class FgOffArgs(ctypes.Structure):
+    """struct stj_fgoff_args (include/strajnet_hip.h)"""
+    _fields_ = ([('B', ci), ('H', ci), ('W', ci), ('dtype', ci), ('scale', cf), ('eps', cf)] +
+                [(n, vp) for n in ('q', 'pack', 'bias', 'gamma', 'beta', 'w1', 'off', 'cols', 'c', 'mean', 'rstd', 'doff', 'dc', 'dq',
+                                   'd_w1', 'd_gamma', 'd_beta', 'd_bias')])
+
 
 _lib = None
 

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libstrajnet_hip.so')
-SOURCES = ['util.hip', 'gemm.hip', 'wgrad_sk.hip', 'norm.hip', 'patch_embed.hip', 'swin_attn.hip', 'swin_fused.hip', 'xattn_fused.hip', 'fgattn.hip', 'agent_fused.hip', 'attn.hip', 'conv.hip', 'conv_ws.hip', 'conv_ps.hip', 'loss.hip', 'rng.hip']
+SOURCES = ['util.hip', 'gemm.hip', 'wgrad_sk.hip', 'norm.hip', 'patch_embed.hip', 'swin_attn.hip', 'swin_fused.hip', 'xattn_fused.hip', 'fgattn.hip', 'agent_fused.hip', 'fgoff_fused.hip', 'attn.hip', 'conv.hip', 'conv_ws.hip', 'conv_ps.hip', 'loss.hip', 'rng.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result', '-Wno-unused-value',
          '-ffp-contract=fast']
 

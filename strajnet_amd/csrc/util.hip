@@ -48,32 +48,9 @@ extern "C" int stj_cast(const void* src, int sdtype, void* dst, int ddtype, long
 }
 
 // ---- unary activations ----------------------------------------------------------------------
-// op: 1 gelu (saved = x), 2 elu (saved = y), 3 tanh*scale (saved = y)
-enum { U_GELU = 1, U_ELU = 2, U_TANHS = 3 };
+// op: 1 gelu (saved = x), 2 elu (saved = y), 3 tanh*scale (saved = y)   (enum U_*: common.h)
 
-// The op is a template parameter (no per-element selection) and the bf16 kernels use a v_exp_f32 based tanh (abs error ~2e-7,
-// two decades below bf16 resolution); the f32 parity mode keeps libm tanhf / expm1f.
-template <bool FAST> __device__ __forceinline__ float tanh_sel(float u) {
-  if constexpr (FAST) {
-    const float e = __builtin_amdgcn_exp2f(fminf(u, 15.f) * 2.885390081777927f);       // e^(2u), clamped: tanh(15) == 1 in f32
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-  } else return tanhf(u);
-}
-template <int OP, bool FAST> __device__ __forceinline__ float unary_f(float x, float p0) {
-  if constexpr (OP == U_GELU) {
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.f + tanh_sel<FAST>(u));
-  } else if constexpr (OP == U_ELU) return FAST ? elu_bf(x) : elu_f(x);
-  else return tanh_sel<FAST>(x) * p0;
-}
-template <int OP, bool FAST> __device__ __forceinline__ float unary_g(float dy, float s, float p0) {
-  if constexpr (OP == U_GELU) {
-    const float k = 0.7978845608028654f, x2 = s * s;
-    const float t = tanh_sel<FAST>(k * (s + 0.044715f * s * x2));
-    return dy * (0.5f * (1.f + t) + 0.5f * s * (1.f - t * t) * (k * (1.f + 3.f * 0.044715f * x2)));
-  } else if constexpr (OP == U_ELU) return s > 0.f ? dy : dy * (s + 1.f);
-  else { const float t = s / p0; return dy * p0 * (1.f - t * t); }
-}
+// (tanh_sel / unary_f / unary_g: common.h -- the fused FG-MSA offset head evaluates the same expressions)
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void unary_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float p0) {
   constexpr int VN = Vec<T>::N;

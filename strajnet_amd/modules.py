@@ -253,9 +253,13 @@ class STrajNet:
         self._xattn_kv_pre = None
         self.fused_agent = True        # TrajEncoder of all agents as one kernel per direction (csrc/agent_fused.hip); False = the layer-by-layer chain
         self.fused_agent_int = True    # ... and the 64-agent interaction block (16-bit storage types)
+        self.fused_fgoff = True        # FG-MSA's offset head (conv_offset -> tanh * range) as one kernel per direction (csrc/fgoff_fused.hip)
         self._agent_pack = None
         self._agent_pack_event = None
         self._agent_pack_stale = True
+        self._fgoff_pack = None
+        self._fgoff_pack_event = None
+        self._fgoff_pack_stale = True
         self._xattn_pack = None
         self.params = OrderedDict()
         for n, (s, kind) in spec.items():
@@ -545,10 +549,22 @@ class STrajNet:
             q = self._dense(x, 'fg_msa/proj_q')
             k = self._dense(x, 'fg_msa/proj_k')
             v = self._dense(x, 'fg_msa/proj_v')
-        o = ops.grouped_conv3(q, self._p('fg_msa/conv_offset_0/kernel'), self._p('fg_msa/conv_offset_0/bias'), G)
-        o = ops.gelu(self._ln(o, 'fg_msa/conv_norm', 1e-3))
-        # per group: 1x1 conv gc->2 (no bias), tanh * (H/2); the kernel reads o in place ([B,H,W,G,gc]) and writes [B,G,HW,2]
-        off = ops.fg_offset(o, self._p('fg_msa/conv_offset_proj/kernel'), Hh / 2.0, G)
+        if self.fused_fgoff and ops.fgoff_ok(self.dtype, Hh, Ww, C, G):
+            # conv_offset (grouped 3x3 conv -> LayerNorm -> gelu -> 1x1 conv gc->2) and tanh * (H/2) as ONE launch per direction (csrc/fgoff_fused.hip)
+            pw = self._p('fg_msa/conv_offset_0/kernel')
+            if self._fgoff_pack_stale:                   # (no second side stream: packed here)
+                self._fgoff_pack = ops.fgoff_pack(pw, self.dtype, out=self._fgoff_pack)
+                self._fgoff_pack_stale = False
+            elif self._fgoff_pack_event is not None:     # packed with the other per-step preparations on the second side stream
+                torch.cuda.current_stream(self.device).wait_event(self._fgoff_pack_event)
+                self._fgoff_pack_event = None
+            off = ops.fgoff_chain(q, pw, self._p('fg_msa/conv_offset_0/bias'), self._p('fg_msa/conv_norm/gamma'), self._p('fg_msa/conv_norm/beta'),
+                                  self._p('fg_msa/conv_offset_proj/kernel'), self._fgoff_pack, Hh / 2.0, 1e-3)
+        else:
+            o = ops.grouped_conv3(q, self._p('fg_msa/conv_offset_0/kernel'), self._p('fg_msa/conv_offset_0/bias'), G)
+            o = ops.gelu(self._ln(o, 'fg_msa/conv_norm', 1e-3))
+            # per group: 1x1 conv gc->2 (no bias), tanh * (H/2); the kernel reads o in place ([B,H,W,G,gc]) and writes [B,G,HW,2]
+            off = ops.fg_offset(o, self._p('fg_msa/conv_offset_proj/kernel'), Hh / 2.0, G)
         # the sampled relative-position bias is built from `off` inside the attention op
         if self.fused_fgattn and ops.fg_attn_ok(self.dtype, Hh, Ww, gc):      # one kernel per direction (csrc/fgattn.hip)
             a = ops.fg_attn(q.view(B, HW, C), k.view(B, HW, C), v.view(B, HW, C), off, self._p('fg_msa/warp_attn_rel_table'), Hh, Ww, gc ** -0.5)
@@ -855,11 +871,18 @@ class STrajNet:
         self._xattn_pack_stale = True
         self._agent_pack_stale = True
         self._agent_pack_event = None
+        self._fgoff_pack_stale = True
+        self._fgoff_pack_event = None
 
         def issue_prep():
             if self._side2 is not None:
                 self._side2.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self._side2):
+                    if self.fused_fgoff and self.fg_msa and ops.fgoff_ok(self.dtype, hb, hb, Cb, 8):
+                        self._fgoff_pack = ops.fgoff_pack(self._p('fg_msa/conv_offset_0/kernel'), self.dtype, out=self._fgoff_pack)
+                        self._fgoff_pack_stale = False
+                        self._fgoff_pack_event = torch.cuda.Event()
+                        self._fgoff_pack_event.record(self._side2)
                     if self.fused_agent and self._agent_pack_stale:      # the agent branch's weight pack: with the other preparations, not on its chain
                         self._agent_pack = ops.agent_pack(self._agent_ws(), self.dtype, out=self._agent_pack)
                         self._agent_pack_stale = False

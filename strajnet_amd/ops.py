@@ -1542,6 +1542,71 @@ def fg_offset(o, p1, scale, G):
     return _FgOffset.apply(o, p1.master, p1, scale, G)
 
 
+def fgoff_ok(dtype, Hh, Ww, C, G):
+    from ._lib import lib
+    return bool(lib().stj_fgoff_supported(int(Hh), int(Ww), int(C), int(G), DTYPE_CODE[dtype]))
+
+
+def fgoff_pack(pw, dtype, out=None):
+    """MFMA-fragment-ordered copies (both directions) of FG-MSA's offset conv kernel in `dtype` (stj_fgoff_pack).  Once per step."""
+    from ._lib import lib
+    if out is None:
+        out = torch.empty(int(lib().stj_fgoff_pack_workspace_bytes(DTYPE_CODE[dtype])), dtype=torch.uint8, device=pw.master.device)
+    call('stj_fgoff_pack', _p(pw.master), _p(out), DTYPE_CODE[dtype], _st())
+    return out
+
+
+class _FgOffsetChain(torch.autograd.Function):
+    """off [B,G,HW,2] = tanh(conv_offset(q)) * scale with conv_offset = grouped 3x3 conv -> LayerNorm(eps) -> gelu -> per-group 1x1 conv 48 -> 2
+    (FG_MSA.py:84-92,109-123) as one launch per direction (csrc/fgoff_fused.hip) in place of grouped_conv3 + layernorm + gelu + fg_offset.
+    ps: Params (conv kernel, conv bias, gamma, beta, proj kernel); pack: fgoff_pack()."""
+    @staticmethod
+    def forward(ctx, q, trig, ps, pack, scale, eps):
+        from ._lib import FgOffArgs
+        _req_cuda(q)
+        q = q.contiguous()
+        B, Hh, Ww, C = q.shape
+        G, M = 8, B * Hh * Ww
+        pw, pb, pg, pbe, p1 = ps
+        dev, dt = q.device, q.dtype
+        off = torch.empty((B, G, Hh * Ww, 2), dtype=dt, device=dev)
+        train = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        sv = {}
+        if train:
+            sv = dict(cols=torch.empty((M, G, 9 * (C // G)), dtype=dt, device=dev), c=torch.empty((M, C), dtype=dt, device=dev),
+                      mean=torch.empty((M,), dtype=torch.float32, device=dev), rstd=torch.empty((M,), dtype=torch.float32, device=dev))
+        a = FgOffArgs(B=B, H=Hh, W=Ww, dtype=DTYPE_CODE[dt], scale=float(scale), eps=float(eps), q=_ip(q), pack=_ip(pack), bias=_ip(pb.master),
+                      gamma=_ip(pg.master), beta=_ip(pbe.master), w1=_ip(p1.c), off=_ip(off), **{k: _ip(v) for k, v in sv.items()})
+        call('stj_fgoff_fwd', ctypes.byref(a), _st())
+        if train:
+            ctx.ps, ctx.pack, ctx.geo = ps, pack, (B, Hh, Ww, C, G, float(scale), float(eps))
+            ctx.save_for_backward(off, sv['cols'], sv['c'], sv['mean'], sv['rstd'])
+        return off
+
+    @staticmethod
+    def backward(ctx, doff):
+        from ._lib import FgOffArgs
+        off, cols, c, mean, rstd = ctx.saved_tensors
+        B, Hh, Ww, C, G, scale, eps = ctx.geo
+        pw, pb, pg, pbe, p1 = ctx.ps
+        M, Cg = B * Hh * Ww, C // G
+        K = 9 * Cg
+        doff = doff.contiguous()
+        dc = torch.empty_like(c)
+        dq = torch.empty((B, Hh, Ww, C), dtype=c.dtype, device=c.device)
+        a = FgOffArgs(B=B, H=Hh, W=Ww, dtype=DTYPE_CODE[c.dtype], scale=scale, eps=eps, pack=_ip(ctx.pack), gamma=_ip(pg.master), beta=_ip(pbe.master),
+                      w1=_ip(p1.c), off=_ip(off), c=_ip(c), mean=_ip(mean), rstd=_ip(rstd), doff=_ip(doff), dc=_ip(dc), dq=_ip(dq),
+                      d_w1=_ip(p1.grad), d_gamma=_ip(pg.grad), d_beta=_ip(pbe.grad), d_bias=_ip(pb.grad))
+        call('stj_fgoff_bwd', ctypes.byref(a), _st())
+        # dW[k, g*cog+n] += sum_m cols[m,g,k] dc[m, g*cog+n]   (as _GroupedConv3.backward; queued on the grouped weight-gradient launch)
+        gemm(cols, dc, pw.grad, K, Cg, M, (0, K, 1, G * K), (0, Cg, C, 1), (0, Cg, C), _dt(cols), nb=(1, G), c_f32=1, accumulate=1, splitk=0)
+        return dq, None, None, None, None, None
+
+
+def fgoff_chain(q, pw, pb, pg, pbe, p1, pack, scale, eps):
+    return _FgOffsetChain.apply(q, pw.master, (pw, pb, pg, pbe, p1), pack, scale, eps)
+
+
 class _FgQuery(torch.autograd.Function):
     """Second half: fh = off . W2 + b2 (1x1 conv 2 -> C2), [B,G,HW,C2]; with qres [B,HW,C2] the output is the group-major decoder
     query [G,B,HW,C2] = qres (broadcast over the groups) + fh  (modules.py:827-831), written once."""

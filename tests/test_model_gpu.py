@@ -733,10 +733,10 @@ def test_f32_golden_step_runs_the_fused_entry_points():
     called = set(fams) | {k for k in ev if k.startswith('stj_')}
     text = ' '.join(sorted(called))
     must = ['swin_attn_fwd', 'swin_attn_bwd', 'swin_mlp_fwd', 'swin_mlp_bwd', 'fgattn_fwd', 'fgattn_bwd', 'xattn_fwd', 'xattn_bwd', 'patch_embed_fwd',
-            'agent_enc_fwd', 'agent_enc_bwd', 'agent_pack', 'loss_fwd', 'loss_bwd', 'upconv_fwd', 'upconv_dgrad', 'upconv_wgrad']
+            'agent_enc_fwd', 'agent_enc_bwd', 'agent_pack', 'fgoff_fwd', 'fgoff_bwd', 'fgoff_pack', 'loss_fwd', 'loss_bwd', 'upconv_fwd', 'upconv_dgrad', 'upconv_wgrad']
     for m in must:
         assert m in text, (m, text)
-    for gone in ('small_attn', 'agent_prep', 'maxpool', 'fg_bias_fwd', 'win_attn_fwd'):      # replaced ops: small_attn / agent_prep / maxpool by agent_enc; fg_bias by fgattn; win_attn at C = 96 / 192
+    for gone in ('small_attn', 'agent_prep', 'maxpool', 'fg_bias_fwd', 'im2col3', 'col2im3', 'win_attn_fwd'):      # replaced ops: small_attn / agent_prep / maxpool by agent_enc; fg_bias by fgattn; im2col3 / col2im3 (+ LayerNorm, gelu, the offset kernel's first half) by fgoff; win_attn at C = 96 / 192
         if gone == 'win_attn_fwd':
             continue                          # (the C = 384 attention half keeps the layer-by-layer window attention in f32)
         assert gone not in text, (gone, text)
