@@ -362,6 +362,12 @@ int stj_upconv_fwd_res(const void* X, const void* Wf, const float* bias, void* Y
                        int Wi, int Cin, int Cout, int dtype, hipStream_t stream);
 int stj_elu_res_bwd(const void* dy, const void* dy2, const void* y, const void* r, void* dpre, void* gsum, long long n, int dtype,
                     hipStream_t stream);
+/* Backward junction of a decoder level whose skips R1 / R2 are ELU outputs themselves (the time-collapsed Conv3D + ELU of an encoder stage,
+ * modules.py:750-765), one pass: g = dy1 (+ dy2, rounded), dpre = g ELU'(y) (y = the up-conv's ELU output), dr1 = g ELU'(r1) and
+ * dr2 = dy2 ELU'(r2) -- the gradients of the skips' PRE-activations -- in place of stj_elu_res_bwd + one stj_unary_bwd per skip.
+ * dy2 / r2 / dr2 all NULL: a level with one skip. */
+int stj_skip_junction_bwd(const void* dy1, const void* dy2, const void* y, const void* r1, const void* r2, void* dpre, void* dr1,
+                          void* dr2, long long n, int dtype, hipStream_t stream);
 int stj_upconv_dgrad(const void* dP, const void* Wd, void* dX, const void* Xelu, int F, int Hi, int Wi, int Cin, int Cout,
                      int dtype, hipStream_t stream);
 /* wg_budget: workgroups the two large weight-gradient launches (>= 64x64 inputs) may occupy.  0 = 128: half the CUs, because in a

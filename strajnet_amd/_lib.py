@@ -96,6 +96,7 @@ SIGNATURES = {
     'stj_upconv_fwd': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     'stj_upconv_fwd_res': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_elu_res_bwd': [vp, vp, vp, vp, vp, vp, cl, ci, vp],
+    'stj_skip_junction_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, cl, ci, vp],
     'stj_upconv_dgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     'stj_upconv_wgrad': [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     'stj_outconv_pair_fwd': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp],

@@ -152,6 +152,56 @@ extern "C" int stj_elu_res_bwd(const void* dy, const void* dy2, const void* y, c
   return stj_check_launch("stj_elu_res_bwd");
 }
 
+// Backward junction of a decoder level whose skips are ELU outputs themselves (modules.py:750-765: y1 = ELU(upconv(x)) + r1, y2 = y1 + r2,
+// r = ELU(time-collapsed Conv3D of an encoder stage)): g = dy1 (+ dy2, rounded like the separate add), and ALL THREE ELU' products in the
+// one pass -- dpre = g ELU'(y), dr1 = g ELU'(r1), dr2 = dy2 ELU'(r2) -- instead of stj_elu_res_bwd followed by one stj_unary_bwd per skip
+// (three more passes over [F,H,W,C] tensors at the two-skip level, one more launch per skip).  Same values as that sequence, bit for bit.
+template <typename T>
+__global__ __launch_bounds__(256) void skip_junction_bwd_kernel(const T* __restrict__ dy1, const T* __restrict__ dy2, const T* __restrict__ y,
+                                                                const T* __restrict__ r1, const T* __restrict__ r2, T* __restrict__ dpre,
+                                                                T* __restrict__ dr1, T* __restrict__ dr2, long long n) {
+  constexpr int VN = Vec<T>::N;
+  const long long nv = n / VN;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += gridDim.x * 256ll) {
+    float g[VN], b[VN], s[VN], o[VN];
+    ld16(dy1 + i * VN, g);
+    if (dy2) {
+      ld16(dy2 + i * VN, b);
+      ld16(r2 + i * VN, s);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) { g[e] += b[e]; o[e] = b[e] * (s[e] > 0.f ? 1.f : s[e] + 1.f); }
+      st16(dr2 + i * VN, o);
+      __attribute__((aligned(16))) T rounded[VN];
+      st16(rounded, g);
+      ld16(rounded, g);                              // the rounded sum, as the consumers of a separate add would see it
+    }
+    ld16(y + i * VN, s);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) o[e] = g[e] * (s[e] > 0.f ? 1.f : s[e] + 1.f);
+    st16(dpre + i * VN, o);
+    ld16(r1 + i * VN, s);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) o[e] = g[e] * (s[e] > 0.f ? 1.f : s[e] + 1.f);
+    st16(dr1 + i * VN, o);
+  }
+}
+extern "C" int stj_skip_junction_bwd(const void* dy1, const void* dy2, const void* y, const void* r1, const void* r2, void* dpre, void* dr1,
+                                     void* dr2, long long n, int dtype, hipStream_t stream) {
+  if (n <= 0) return STJ_OK;
+  if (n % 8) { stj_set_error("stj_skip_junction_bwd: n must be a multiple of 8"); return STJ_EINVAL; }
+  if (!dy1 || !y || !r1 || !dpre || !dr1) { stj_set_error("stj_skip_junction_bwd: null pointer"); return STJ_EINVAL; }
+  if ((dy2 == nullptr) != (r2 == nullptr) || (dy2 == nullptr) != (dr2 == nullptr)) { stj_set_error("stj_skip_junction_bwd: dy2, r2 and dr2 go together"); return STJ_EINVAL; }
+  if (((uintptr_t)dy1 | (uintptr_t)dy2 | (uintptr_t)y | (uintptr_t)r1 | (uintptr_t)r2 | (uintptr_t)dpre | (uintptr_t)dr1 | (uintptr_t)dr2) & 15) {
+    stj_set_error("stj_skip_junction_bwd: pointers must be 16-byte aligned"); return STJ_EINVAL;
+  }
+  if (!stj_dtype_ok(dtype)) { stj_set_error("stj_skip_junction_bwd: bad dtype %d", dtype); return STJ_EINVAL; }
+  const int g = ew_grid(n / 8);
+#define SJ_GO(TT) hipLaunchKernelGGL(skip_junction_bwd_kernel<TT>, dim3(g), dim3(256), 0, stream, (const TT*)dy1, (const TT*)dy2, (const TT*)y, (const TT*)r1, (const TT*)r2, (TT*)dpre, (TT*)dr1, (TT*)dr2, n)
+  if (dtype == STJ_BF16) SJ_GO(bf16); else if (dtype == STJ_F16) SJ_GO(f16); else SJ_GO(float);
+#undef SJ_GO
+  return stj_check_launch("stj_skip_junction_bwd");
+}
+
 // ---- max over a middle axis: x[outer][T][C] -> y[outer][C], idx (argmax, int8-in-int32) ---------
 // GlobalMaxPooling1D over the 11 time steps (reference trajNet.py:34,44).
 template <typename T>

@@ -701,8 +701,9 @@ class STrajNet:
 
         def fold():
             ops.call('stj_time_fold', ops._p(gwz), ops._p(pw.grad), Ci * Co, ops._st())
+        # (16-bit training: the decoder level that adds this skip returns its gradient times ELU' -- ops.upconv_add(skips_pre=True))
         return ops.linear_z(skip, pw.master, wz[0], Ci * Co, pb.master.detach(), 0, gwz[0], Ci * Co, pb.grad, 8,
-                            act=ACT_ELU, shared_x=True, fold=fold)    # [8, B*HW, Co]  (time-major)
+                            act=ACT_ELU, shared_x=True, fold=fold, grad_is_pre=ops.skips_pre_ok(self.dtype))    # [8, B*HW, Co]  (time-major)
 
     # ---- the 8 time-separated cross-attentions, batched over the waypoint axis z (trajNet.py:305-314) ----
     def _zp(self, suffix):
@@ -793,7 +794,8 @@ class STrajNet:
                           self._resconv(flow_res, 'decoder/resconv_f'))
 
         def up_add(t, name, ra, rb=None):        # up-conv with the skip sum(s) in its epilogue (modules.py:750-765)
-            return ops.upconv_add(t, self._p(name + '/kernel'), self._p(name + '/bias'), ra, rb, prep=self._upconv_prep.get(name))
+            return ops.upconv_add(t, self._p(name + '/kernel'), self._p(name + '/bias'), ra, rb, prep=self._upconv_prep.get(name),
+                                  skips_pre=ops.skips_pre_ok(self.dtype))
         x = up_add(x, 'decoder/upconv_3_0', s3)                                      # [F,2hb,2hb,192]
         self._tap('decoder/level3', x)
         x, fx = up_add(x, 'decoder/upconv_2_0', s2, sf)                              # [F,4hb,4hb,128] x 2

@@ -687,10 +687,11 @@ def linear_heads_out(x, pw, pb):
 # ----------------------------------------------------------------------------------------------------
 class _LinearZ(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, trig, w0, wstride, b0, bstride, gw0, gwstride, gb0, Z, act, shared_x, fold):
+    def forward(ctx, x, trig, w0, wstride, b0, bstride, gw0, gwstride, gb0, Z, act, shared_x, fold, grad_is_pre=False):
         _req_cuda(x)
         K, N = w0.shape
         x = x.contiguous()
+        ctx.grad_is_pre = grad_is_pre
         R = x.numel() // K if shared_x else x.numel() // (K * Z)
         dt = _dt(x)
         y = torch.empty((Z, R, N), dtype=x.dtype, device=x.device)
@@ -707,7 +708,7 @@ class _LinearZ(torch.autograd.Function):
         Z, R, K, N, shared_x, act, wstride, bstride, gwstride, xshape = ctx.dims
         dt = _dt(x)
         dy = dy.contiguous()
-        if act == ACT_ELU:
+        if act == ACT_ELU and not ctx.grad_is_pre:      # (grad_is_pre: the consumer folded ELU'(y) into the gradient it returned -- upconv_add(skips_pre=True))
             dpre = torch.empty_like(dy)
             call('stj_unary_bwd', _p(dy), _p(y), _p(dpre), dy.numel(), U_ELU, 0.0, dt, _st())
         else:
@@ -734,11 +735,13 @@ class _LinearZ(torch.autograd.Function):
         if ctx.fold is not None and not queued:
             with wgrad_stream(1, x, dpre):
                 ctx.fold()
-        return (dx,) + (None,) * 12
+        return (dx,) + (None,) * 13
 
 
-def linear_z(x, trig, w0, wstride, b0, bstride, gw0, gwstride, gb0, Z, act=ACT_NONE, shared_x=False, fold=None):
-    return _LinearZ.apply(x, trig, w0, wstride, b0, bstride, gw0, gwstride, gb0, Z, act, shared_x, fold)
+def linear_z(x, trig, w0, wstride, b0, bstride, gw0, gwstride, gb0, Z, act=ACT_NONE, shared_x=False, fold=None, grad_is_pre=False):
+    """grad_is_pre (act = ELU): contract with the single consumer of the output -- it returns the gradient already multiplied by ELU'(y)
+    (upconv_add(skips_pre=True)), so the separate ELU' pass is skipped."""
+    return _LinearZ.apply(x, trig, w0, wstride, b0, bstride, gw0, gwstride, gb0, Z, act, shared_x, fold, grad_is_pre)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -2326,15 +2329,19 @@ class _UpConvAdd(torch.autograd.Function):
 
 
 SKIP_BWD_FUSED = True      # (False: the level's backward junction as an elementwise add + the ELU' pass; the f32 mode always)
+SKIP_JUNCTION = True       # the junction also applies the SKIPS' ELU' (stj_skip_junction_bwd); False: one stj_unary_bwd per skip, as up to round 5
 
 
 class _UpConvSkips(torch.autograd.Function):
-    """y1 = ELU(upconv(x)) + r1, y2 = y1 + r2 (the decoder level with two skips, modules.py:757-765) with the forward as the launches that measure
-    fastest in training (the up-conv, then two elementwise adds) and the backward's junction as ONE launch: the sum of the two incoming
-    gradients and its product with ELU'(ELU output) (stj_elu_res_bwd with r = NULL) instead of an elementwise add followed by the ELU' pass."""
+    """y1 = ELU(upconv(x)) + r1 [, y2 = y1 + r2] (a decoder level with its skips, modules.py:750-765) with the forward as the launches that
+    measure fastest in training (the up-conv, then the elementwise adds) and the backward's junction as ONE launch:
+      skips_pre = False  the sum of the two incoming gradients and its product with ELU'(ELU output) (stj_elu_res_bwd with r = NULL) instead of an
+                         elementwise add followed by the ELU' pass (two skips only);
+      skips_pre = True   r1 / r2 are ELU outputs of producers called with grad_is_pre = True (linear_z): stj_skip_junction_bwd also returns THEIR
+                         gradients times ELU'(r) -- the three (one skip: two) ELU' passes of the level in the one launch."""
     @staticmethod
-    def forward(ctx, x, r1, r2, w_master, b_master, pw, pb, prep):
-        _req_cuda(x, r1, r2)
+    def forward(ctx, x, r1, r2, w_master, b_master, pw, pb, prep, skips_pre):
+        _req_cuda(x, r1)
         x = x.contiguous()
         F_, Hi, Wi, Cin = x.shape
         Cout = pw.master.shape[-1]
@@ -2342,35 +2349,58 @@ class _UpConvSkips(torch.autograd.Function):
         y = torch.empty((F_, 2 * Hi, 2 * Wi, Cout), dtype=x.dtype, device=x.device)
         call('stj_upconv_fwd', _p(x), _p(wf), _p(pb.master), _p(y), F_, Hi, Wi, Cin, Cout, ACT_ELU, _dt(x), _st())
         y1 = y + r1
-        y2 = y1 + r2
+        y2 = y1 + r2 if r2 is not None else None
         ctx.pw, ctx.pb, ctx.geo = pw, pb, (F_, Hi, Wi, Cin, Cout)
         ctx.x_is_elu_out = False
         ctx.defer = _UPWG['on']
-        ctx.save_for_backward(x, y, wd)
-        return y1, y2
+        ctx.skips_pre, ctx.two = skips_pre, r2 is not None
+        if skips_pre:
+            ctx.save_for_backward(x, y, wd, r1.contiguous(), r2.contiguous() if r2 is not None else None)
+        else:
+            ctx.save_for_backward(x, y, wd)
+        return (y1, y2) if r2 is not None else y1
 
     @staticmethod
-    def backward(ctx, dy1, dy2):
-        x, y, wd = ctx.saved_tensors
-        dy1, dy2 = dy1.contiguous(), dy2.contiguous()
-        dpre, gsum = torch.empty_like(dy1), torch.empty_like(dy1)
-        call('stj_elu_res_bwd', _p(dy1), _p(dy2), _p(y), _p(None), _p(dpre), _p(gsum), dy1.numel(), _dt(x), _st())
+    def backward(ctx, dy1, dy2=None):
+        x, y, wd = ctx.saved_tensors[:3]
+        dy1 = dy1.contiguous()
+        dy2 = dy2.contiguous() if ctx.two else None
+        dpre = torch.empty_like(dy1)
+        if ctx.skips_pre:
+            r1, r2 = ctx.saved_tensors[3:]
+            dr1 = torch.empty_like(dy1)
+            dr2 = torch.empty_like(dy1) if ctx.two else None
+            call('stj_skip_junction_bwd', _p(dy1), _p(dy2), _p(y), _p(r1), _p(r2), _p(dpre), _p(dr1), _p(dr2), dy1.numel(), _dt(x), _st())
+        else:
+            dr1, dr2 = torch.empty_like(dy1), dy2
+            call('stj_elu_res_bwd', _p(dy1), _p(dy2), _p(y), _p(None), _p(dpre), _p(dr1), dy1.numel(), _dt(x), _st())
         dx = _upconv_backward_tail(ctx, x, dpre, wd, ctx.needs_input_grad[0])
-        return dx, gsum, dy2, None, None, None, None, None
+        return dx, dr1, dr2, None, None, None, None, None, None
 
 
 FUSED_SKIP_TRAIN = False       # (tests flip it: the fused form's backward, stj_elu_res_bwd, is the one a fine-tuning caller of the inference graph gets)
 
 
-def upconv_add(x, pw, pb, r1, r2=None, prep=None):
+def skips_pre_ok(dtype):
+    """Will upconv_add(skips_pre=True) take the gradients' ELU' products on itself (so the skips' producers are to be called with
+    grad_is_pre=True)?  The training form of the 16-bit modes; decided HERE for both sides of the contract."""
+    return SKIP_BWD_FUSED and SKIP_JUNCTION and not FUSED_SKIP_TRAIN and dtype != torch.float32 and torch.is_grad_enabled()
+
+
+def upconv_add(x, pw, pb, r1, r2=None, prep=None, skips_pre=False):
     """ELU(upconv(x)) + r1 -> y, and y + r2 -> y2 when r2 is given (returns y or (y, y2)).  Fused into the up-conv epilogue for the
-    16-bit wide layers (Cin = 192, 384); otherwise the up-conv followed by elementwise adds."""
+    16-bit wide layers (Cin = 192, 384); otherwise the up-conv followed by elementwise adds.
+    skips_pre=True (only where skips_pre_ok()): r1 / r2 are ELU outputs whose producers were told grad_is_pre=True."""
     Cin, Cout = pw.master.shape[2], pw.master.shape[3]
     oshape = (x.shape[0], 2 * x.shape[1], 2 * x.shape[2], Cout)
+    if skips_pre:
+        if not skips_pre_ok(x.dtype):
+            raise RuntimeError('upconv_add(skips_pre=True) outside skips_pre_ok(): the skips would lose their ELU\' factor')
+        return _UpConvSkips.apply(x, r1.view(oshape), None if r2 is None else r2.view(oshape), pw.master, pb.master, pw, pb, prep, True)
     if (FUSED_SKIP_TRAIN or not torch.is_grad_enabled()) and x.dtype != torch.float32 and Cin > 128 and Cin % 32 == 0 and Cout % 32 == 0 and os.environ.get('STJ_NO_WS') != '1':
         return _UpConvAdd.apply(x, r1.view(oshape), None if r2 is None else r2.view(oshape), pw.master, pb.master, pw, pb, prep)
     if SKIP_BWD_FUSED and r2 is not None and x.dtype != torch.float32 and torch.is_grad_enabled():
-        return _UpConvSkips.apply(x, r1.view(oshape), r2.view(oshape), pw.master, pb.master, pw, pb, prep)
+        return _UpConvSkips.apply(x, r1.view(oshape), r2.view(oshape), pw.master, pb.master, pw, pb, prep, False)
     y = upconv(x, pw, pb, prep=prep)
     y = y + r1.view(y.shape)
     return y if r2 is None else (y, y + r2.view(y.shape))

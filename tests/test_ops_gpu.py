@@ -1124,6 +1124,56 @@ def test_upconv_add_fused_skip(dt, F_, Hi, Cin, Cout, two):
             assert rel_err(f[i], u[i]) < (2e-2 if dt == torch.bfloat16 else 3e-3), (mode, i)
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('F_,Hi,Cin,Cout,two', [(3, 16, 192, 128, True), (2, 8, 384, 192, False)])
+def test_upconv_add_skips_pre_junction(dt, F_, Hi, Cin, Cout, two):
+    """The decoder level whose skips are ELU outputs of linear_z (the time-collapsed Conv3D skips): upconv_add(skips_pre=True) + linear_z(grad_is_pre=True)
+    -- ONE stj_skip_junction_bwd for the level's three ELU' products -- against the forms it replaces (stj_elu_res_bwd / the plain adds, then one
+    stj_unary_bwd per skip): outputs and every gradient BIT-identical (the junction rounds where the separate passes rounded)."""
+    from strajnet_amd import ops
+    Ci = 96
+    R = F_ // (F_) * (2 * Hi) * (2 * Hi)            # rows per time slice: the skips are [Z = F_, R, Cout] (shared input [R, Ci])
+    x0 = rnd((F_, Hi, Hi, Cin), dt, 1)
+    s0 = rnd((R, Ci), dt, 2)
+    g1 = rnd((F_, 2 * Hi, 2 * Hi, Cout), dt, 4)
+    g2 = rnd((F_, 2 * Hi, 2 * Hi, Cout), dt, 5)
+
+    def run(junction):
+        pw, pb = mk_param((3, 3, Cin, Cout), dt, 0.03, seed=7), mk_param((Cout,), dt, 0.1, seed=8)
+        ws = [mk_param((F_, Ci, Cout), dt, 0.1, seed=20 + i) for i in range(2 if two else 1)]
+        bs = [mk_param((Cout,), dt, 0.1, seed=30 + i) for i in range(len(ws))]
+        x = x0.clone().requires_grad_(True)
+        skin = [s0.clone().requires_grad_(True) for _ in ws]
+        keep, ops.SKIP_JUNCTION = ops.SKIP_JUNCTION, junction
+        try:
+            pre = ops.skips_pre_ok(dt)
+            assert pre == junction
+            sk = [ops.linear_z(si, w.master, w.c[0], Ci * Cout, b.master.detach(), 0, w.grad[0], Ci * Cout, b.grad, F_, act=ops.ACT_ELU, shared_x=True,
+                               grad_is_pre=pre) for si, w, b in zip(skin, ws, bs)]
+            out = ops.upconv_add(x, pw, pb, sk[0], sk[1] if two else None, skips_pre=pre)
+        finally:
+            ops.SKIP_JUNCTION = keep
+        y, y2 = out if two else (out, None)
+        loss = (y.float() * g1.float()).sum() + ((y2.float() * g2.float()).sum() if two else 0.0)
+        loss.backward()
+        ops.wgrad_join_now(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        return [y, y2, x.grad, pw.grad.clone(), pb.grad.clone()] + [t.grad for t in skin] + [w.grad.clone() for w in ws] + [b.grad.clone() for b in bs]
+    a, b = run(True), run(False)
+    names = ['y', 'y2', 'dx', 'dW', 'db', 'dskip_in', 'dskip_in2', 'dWs', 'dWs2', 'dbs', 'dbs2']
+    if not two:
+        names = [n for n in names if not n.endswith('2') or n == 'y2']
+    for n, u, v in zip(names, a, b):
+        if u is not None:
+            # activations / input gradients: the same arithmetic; weight gradients: f32 atomics of the stream-K launch (order-dependent last bits)
+            if n in ('dW', 'db', 'dWs', 'dWs2', 'dbs', 'dbs2'):
+                assert rel_err(u, v) < 1e-5, n
+            elif n.startswith('dskip_in'):        # (few rows: linear_z sums the Z slices' input gradients with f32 atomics, then rounds)
+                assert rel_err(u, v) < (1e-2 if dt == torch.bfloat16 else 2e-3), n
+            else:
+                assert torch.equal(u, v), n
+
+
 def test_zz_report_error_ratios():
     """(runs last in this file) the largest max-norm and rms error ratios any comparison above produced, for the record in DESIGN 2a"""
     if _SEEN:
