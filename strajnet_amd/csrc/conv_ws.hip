@@ -1518,6 +1518,13 @@ __global__ __launch_bounds__(256, 3) void outconv_bwd_mfma2_kernel(const bf16* _
 #undef OCB2_PREFETCH
 #undef OCB2_COMMIT
 
+// (Round 6 built a v3 of this kernel in short-lived workgroups -- one 4 x 16 pixel strip per wave, all loads in flight first, no barrier between a
+// wave's loads and its stores, the last wave of a workgroup writing the partial -- because a bare copy of the tensor streams 5.8 TB/s in that
+// form and 4.1-4.5 in this kernel's persistent one (tools/probes/tile_stream_probe.hip, profiles/r06_m_tile_stream_probe*.txt).  Measured at
+// F = 64, 256 x 256: 614 us with the cross-wave sum as LDS float atomics (24 ds_add_f32 per lane cost ~23 us per wave there), 249 us with
+// plain LDS stores, 220 us with no cross-wave sum at all, against 209 us for this kernel: per WAVE the strided dY halo (8 bytes of every
+// 128-byte line: -35 us without it, -18 us with a compact dY) and the 24 weight loads (-18 us) are paid 65536 times instead of 3072.
+// Not kept; profiles/r06_m_outconv_bwd_v3.txt.)
 // sums the per-block partials: grid (ceil(866 / 64), 16 row groups) x 64 threads
 __global__ __launch_bounds__(64) void outconv_bwd_reduce_kernel(const float* __restrict__ part, int nblk, float* dW, float* db) {
   const int idx = blockIdx.x * 64 + threadIdx.x;

@@ -22,7 +22,8 @@ else:
 dy = torch.randn_like(y)
 dx = torch.empty_like(x)
 dw, db = torch.zeros_like(w), torch.zeros_like(b)
-ws = torch.empty(768 * 866 * 4, dtype=torch.uint8, device='cuda')
+from strajnet_amd._lib import lib
+ws = torch.empty(int(lib().stj_outconv_bwd_workspace_bytes()), dtype=torch.uint8, device='cuda')
 
 
 def run(name, fn, nbytes):
