@@ -1524,7 +1524,9 @@ __global__ __launch_bounds__(256, 3) void outconv_bwd_mfma2_kernel(const bf16* _
 // F = 64, 256 x 256: 614 us with the cross-wave sum as LDS float atomics (24 ds_add_f32 per lane cost ~23 us per wave there), 249 us with
 // plain LDS stores, 220 us with no cross-wave sum at all, against 209 us for this kernel: per WAVE the strided dY halo (8 bytes of every
 // 128-byte line: -35 us without it, -18 us with a compact dY) and the 24 weight loads (-18 us) are paid 65536 times instead of 3072.
-// Not kept; profiles/r06_m_outconv_bwd_v3.txt.)
+// The same strips in a LOOP (a wave walks strips gw, gw + GW, ...; weights through LDS once per workgroup, eight loads in flight behind an
+// operand-barrier asm statement, sums as plain LDS stores added up by the last wave): 205-214 us at 768 .. 3072 workgroups -- this
+// kernel's time.  Not kept; profiles/r06_m_outconv_bwd_v3.txt.)
 // sums the per-block partials: grid (ceil(866 / 64), 16 row groups) x 64 threads
 __global__ __launch_bounds__(64) void outconv_bwd_reduce_kernel(const float* __restrict__ part, int nblk, float* dW, float* db) {
   const int idx = blockIdx.x * 64 + threadIdx.x;
