@@ -18,6 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAST_TOUCHED = [
     ('agf::agent_', 6, 'new: fused agent branch (csrc/agent_fused.hip)'),
     ('fgo::fgoff_', 6, 'new: fused FG-MSA offset head (csrc/fgoff_fused.hip)'),
+    ('skip_junction_bwd_kernel', 6, 'new: the decoder level\'s three ELU\' products in one pass'),
+    ('unary_', 6, 'one vector per thread'), ('elu_res_bwd', 6, 'one vector per thread'), ('cast_kernel', 6, 'one vector per thread'),
     ('upconv_fwd_ps_kernel', 6, 'half-chunk weight staging, 16-row tiles'),
     ('wsk::wgrad_sk_kernel', 5, 'second tile geometry (192-column slices)'),
     ('upconv_wgrad_tr4_kernel', 5, 'accumulation-buffer alignment'),
@@ -80,6 +82,8 @@ def read_trace(path):
             continue
         f = ln.split(None, 6)
         if len(f) < 7:
+            continue
+        if '__amd_rocclr' in f[6]:        # runtime blit kernels of the bench's input-feed measurement (host -> device pieces), not of the step
             continue
         try:
             rows[short(f[6])] = dict(us_step=float(f[1]), calls=float(f[2]), avg=float(f[3]))
