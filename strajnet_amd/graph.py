@@ -19,7 +19,9 @@ class GraphedTrainStep:
     backward; `__call__(between=f)` runs f between the two replays (dp.OverlappedGradSync.tail: the tail bucket's all-reduce then
     overlaps graph B).  Both graphs share one private memory pool: B reads the activations A saved."""
 
-    def __init__(self, model, loss_fn, batch, warmup=2, training=True, split=False):
+    def __init__(self, model, loss_fn, batch, warmup=2, training=True, split=False, keep_graph=False):
+        """keep_graph: leave the captured hipGraph_t un-instantiated (torch.cuda.CUDAGraph(keep_graph=True)) so that a caller can edit it
+        (self.graph.raw_cuda_graph(): e.g. kernel-node attributes, tools/probes/graph_node_priority.py) before self.graph.instantiate()."""
         self.model, self.loss_fn, self.training, self.split = model, loss_fn, training, split
         self.static = {k: v.clone() for k, v in batch.items()}
         self.graph = self.graph_b = None
@@ -37,7 +39,7 @@ class GraphedTrainStep:
                     model.backward_encoder()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
         # thread_local: calls that are illegal during capture only count against THIS thread -- a process-group watchdog thread
         # (RCCL, data parallel runs) querying its events must not invalidate the capture
         with torch.cuda.graph(g, capture_error_mode='thread_local'):

@@ -149,6 +149,8 @@ class _ZeroArena:
     def __init__(self):
         self.buf, self.off, self.armed = None, 0, False
         self.split_ws = {}        # the owner's Swin split workspaces (_swin_ws)
+        self.split_ws_stream = {}     # ... the stream that used each last, and whether that use was inside a graph capture
+        self.split_ws_captured = {}
 
     def _here(self, device):
         d = torch.device(device)
@@ -866,6 +868,16 @@ def _swin_ws(x, M, C):
     if ws is None:
         # zeroed ONCE: it starts with the arrival counters of the kernels whose slices meet inside the launch (they re-arm themselves)
         ws = _ARENA.split_ws[key] = torch.zeros(nbytes // 4, dtype=torch.float32, device=x.device)
+    # Two launches of one (M, C) on DIFFERENT streams would share slabs and tickets: a stream that takes the buffer over is ordered behind
+    # everything the previous user has been given.  (STrajNet never needs it -- its concurrent branches are C = 96, which takes no
+    # workspace -- but direct users of ops.* on two streams do.  Not across a capture boundary: the warm-up stream is synchronised before
+    # the capture starts, and a capturing stream cannot wait for a stream outside its graph.)
+    cur = torch.cuda.current_stream(x.device)
+    last = _ARENA.split_ws_stream.get(key)
+    if last is not None and last != cur and not torch.cuda.is_current_stream_capturing() and not _ARENA.split_ws_captured.get(key, False):
+        cur.wait_stream(last)
+    _ARENA.split_ws_stream[key] = cur
+    _ARENA.split_ws_captured[key] = torch.cuda.is_current_stream_capturing()
     return ws
 
 
