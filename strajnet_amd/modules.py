@@ -253,6 +253,9 @@ class STrajNet:
         self._xattn_kv_pre = None
         self.fused_agent = True        # TrajEncoder of all agents as one kernel per direction (csrc/agent_fused.hip); False = the layer-by-layer chain
         self.fused_agent_int = True    # ... and the 64-agent interaction block (16-bit storage types)
+        # stage 0: the last block's weight gradients leave on the side stream under the first block's backward, so that the pass's final launch (122 us with
+        # nothing left to run beside it) halves.  Measured 1362 / 1365 / 1363 / 1365 with against 1366 / 1366 / 1368 / 1363 without: off
+        self.wg_mid_flush = False
         self.fused_fgoff = True        # FG-MSA's offset head (conv_offset -> tanh * range) as one kernel per direction (csrc/fgoff_fused.hip)
         self._agent_pack = None
         self._agent_pack_event = None
@@ -456,9 +459,13 @@ class STrajNet:
         if self.taps is not None:
             self.taps[name] = t.detach().float().clone()
 
-    def _basic_layer(self, x, pre, B, res, depth, heads, downsample, add=None):
+    def _basic_layer(self, x, pre, B, res, depth, heads, downsample, add=None, mid_flush=False):
         """BasicLayer.call (modules.py:351-364) -> (downsampled, pre-merge tokens)."""
         for i in range(depth):
+            if mid_flush and i == depth - 1:
+                # backward: the LAST block's weight gradients (and whatever else is queued) leave on the side stream while the blocks in front
+                # of it still run backward -- the final launch of the pass, which nothing can hide, is then half as long
+                x = ops.wgrad_queue_flush_point(x, side=True)
             x = self._swin_block(x, f'{pre}/blocks{i}', B, res, heads, 0 if i % 2 == 0 else 4)
             self._tap(f'{pre}/block{i}', x)
         if not downsample:
@@ -528,7 +535,8 @@ class STrajNet:
             return t.view(B, r, r, c)[:, q:q + r // 2, q:q + r // 2].reshape(B, (r // 2) ** 2, c)
         for i in range(3):
             r, c = self.stage_res[i], self.stage_dim[i]
-            x, res = self._basic_layer(x, f'layers{i}', B, r, depths[i], heads[i], i < 2, add=joined_flow_x if i == 0 else None)
+            x, res = self._basic_layer(x, f'layers{i}', B, r, depths[i], heads[i], i < 2, add=joined_flow_x if i == 0 else None,
+                                       mid_flush=self.wg_mid_flush and i == 0)
             if i < 2:       # in backward: stage i + 1 is through -> its weight gradients (and whatever else is queued) leave as one launch
                 x = ops.wgrad_queue_flush_point(x)
             if i == 0:

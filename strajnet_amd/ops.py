@@ -477,15 +477,25 @@ def wgrad_queue_push(job, post=None, dev=None):
     _wq(dev)['jobs'].append((job, post, st, ev))
 
 
-def wgrad_queue_flush(dev=None):
+def wgrad_queue_flush(dev=None, side=False):
     """Launch everything queued (on `dev`; None: the current device), on the current stream.  (Round 5: the flush-point launches on the weight-gradient side stream instead,
     so that the next stage's backward need not wait for them, measured 1286-1291 scenes/s with all CUs as the launch's budget, 1270-1276
     with 128 workgroups, 1234-1246 with 96, against 1296-1305 on the main stream: the Swin backward kernels they would run beside fill
-    the CUs they are given, and the join before the optimizer waits for the slowed-down last flush.)"""
+    the CUs they are given, and the join before the optimizer waits for the slowed-down last flush.)
+    side=True: this one launch on the weight-gradient side stream (ordered behind the current stream, joined at the end of the pass)."""
     q = _wq(dev)
     items, q['jobs'] = q['jobs'], []
     if not items:
         return
+    if side and not _SERIAL:
+        keep = [t for job, _, _, _ in items for t in (job.x, job.dy) if isinstance(t, torch.Tensor)]
+        with wgrad_stream(1, *keep):
+            _wgrad_launch(items, dev)
+    else:
+        _wgrad_launch(items, dev)
+
+
+def _wgrad_launch(items, dev):
     cur = torch.cuda.current_stream(dev)
     last = {}
     for job, post, st, ev in items:
@@ -510,18 +520,19 @@ def wgrad_queue_end(dev=None):
 class _WgradQueueFlush(torch.autograd.Function):
     """Identity whose backward flushes the weight-gradient queue: everything downstream of it in the forward pass has been through."""
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, side):
+        ctx.side = side
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        wgrad_queue_flush(g.device)
-        return g
+        wgrad_queue_flush(g.device, side=ctx.side)
+        return g, None
 
 
-def wgrad_queue_flush_point(x):
+def wgrad_queue_flush_point(x, side=False):
     if WGRAD_SK and WGRAD_SK_POINTS and x.requires_grad and torch.is_grad_enabled():
-        return _WgradQueueFlush.apply(x)
+        return _WgradQueueFlush.apply(x, side)
     return x
 
 
