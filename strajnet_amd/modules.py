@@ -837,7 +837,8 @@ class STrajNet:
         self._tap('decoder/level0', x)
         self._tap('decoder/level0_flow', fx)
         return ops.outconv_pair(x, fx, self._p('decoder/outconv/kernel'), self._p('decoder/outconv/bias'),
-                                self._p('decoder/outconv_f/kernel'), self._p('decoder/outconv_f/bias'), B, 8, t_major=True, x_is_elu_out=True)
+                                self._p('decoder/outconv_f/kernel'), self._p('decoder/outconv_f/bias'), B, 8, t_major=True, x_is_elu_out=True,
+                                side=self._side2)
 
     # ------------------------------------------------------------------ call
     def __call__(self, ogm, map_img, training=True, obs=None, occ=None, mapt=None, flow=None, dense_vec=None, dense_map=None):

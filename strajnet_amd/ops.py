@@ -2227,6 +2227,8 @@ _UPWG = {'on': False, 'items': []}
 UPWG_ORDER = 'wide'     # round 6, alternating same-box runs: bwd 1350 / 1363 / 1349, wide 1372 / 1365 / 1359, rev 1340 / 1351 / 1353 scenes/s
 
 
+# (Releasing the OLDEST deferred launches -- the 256 x 256 level's -- already at the two-skip level's junction, beside the junction and the two wide input-gradient
+#  kernels that run alone there: 1 / 2 / 4 launches early 1352 / 1362 / 1355 scenes/s against 1380 with all of them deferred, profiles/r06_t_ab_upwg_early.txt.)
 def flush_upconv_wgrads():
     items, _UPWG['items'] = _UPWG['items'], []
     if not items:
@@ -2458,7 +2460,8 @@ PAIR_OUTCONV = os.environ.get('STJ_NO_WS') != '1'     # (the paired kernel belon
 class _OutConvPair(torch.autograd.Function):
     """Two 3x3 C->2 heads written straight into the [B,H,W,32] f32 model output (channel 4t+{0,1} and 4t+{2,3})."""
     @staticmethod
-    def forward(ctx, xo, xf, w1m, b1m, w2m, b2m, p1w, p1b, p2w, p2b, B, Tn, t_major, x_is_elu_out):
+    def forward(ctx, xo, xf, w1m, b1m, w2m, b2m, p1w, p1b, p2w, p2b, B, Tn, t_major, x_is_elu_out, side=None):
+        ctx.side = side
         _req_cuda(xo, xf)
         xo, xf = xo.contiguous(), xf.contiguous()
         F_, H, W, C = xo.shape
@@ -2493,9 +2496,22 @@ class _OutConvPair(torch.autograd.Function):
         #  1285 scenes/s, and -9 % on the weight-gradient side stream -- the fork at the head of backward reorders the graph's branches)
         call('stj_outconv_bwd', _p(xo), _p(p1w.master), vp(dout.data_ptr()), _p(dxo), _p(p1w.grad), _p(p1b.grad), F_, H, W, C, Tn,
              ybs, yts, yps, ctx.elu_in, _p(ws), ws.numel(), dt, _st())
-        call('stj_outconv_bwd', _p(xf), _p(p2w.master), vp(dout.data_ptr() + 8), _p(dxf), _p(p2w.grad), _p(p2b.grad), F_, H, W, C, Tn,
-             ybs, yts, yps, ctx.elu_in, _p(ws), ws.numel(), dt, _st())
-        return (dxo, dxf) + (None,) * 12
+        side = ctx.side if (OUTCONV_BWD_TWO_STREAMS and not _SERIAL) else None
+        if side is not None:
+            # the second head on the stream its branch's backward continues on (the model's second side stream): the first branch's input
+            # gradient then starts behind ITS head instead of behind both
+            main = torch.cuda.current_stream(xo.device)
+            side.wait_stream(main)
+            ws2 = _workspace(xo.device, 'stj_outconv_bwd_workspace_bytes', 1)
+            with torch.cuda.stream(side):
+                call('stj_outconv_bwd', _p(xf), _p(p2w.master), vp(dout.data_ptr() + 8), _p(dxf), _p(p2w.grad), _p(p2b.grad), F_, H, W, C, Tn,
+                     ybs, yts, yps, ctx.elu_in, _p(ws2), ws2.numel(), dt, _st())
+            for t in (dxf, dout, xf):
+                t.record_stream(side)
+        else:
+            call('stj_outconv_bwd', _p(xf), _p(p2w.master), vp(dout.data_ptr() + 8), _p(dxf), _p(p2w.grad), _p(p2b.grad), F_, H, W, C, Tn,
+                 ybs, yts, yps, ctx.elu_in, _p(ws), ws.numel(), dt, _st())
+        return (dxo, dxf) + (None,) * 13
 
 
 def upconv_head_ok(Hi, Wi, pw, dtype, Tn):
@@ -2524,8 +2540,12 @@ def heads_gather(zo, zf, p1b, p2b, B, Tn, t_major=False):
     return out
 
 
-def outconv_pair(xo, xf, p1w, p1b, p2w, p2b, B, Tn, t_major=False, x_is_elu_out=False):
-    return _OutConvPair.apply(xo, xf, p1w.master, p1b.master, p2w.master, p2b.master, p1w, p1b, p2w, p2b, B, Tn, t_major, x_is_elu_out)
+OUTCONV_BWD_TWO_STREAMS = True     # round 6, alternating same-box runs: 1383 / 1383 / 1382 / 1385 against 1376 / 1376 / 1379 / 1365 scenes/s on one stream
+
+
+def outconv_pair(xo, xf, p1w, p1b, p2w, p2b, B, Tn, t_major=False, x_is_elu_out=False, side=None):
+    """side: the stream the second branch (xf) was computed on, when the caller runs the two branches on two streams."""
+    return _OutConvPair.apply(xo, xf, p1w.master, p1b.master, p2w.master, p2b.master, p1w, p1b, p2w, p2b, B, Tn, t_major, x_is_elu_out, side)
 
 
 # ----------------------------------------------------------------------------------------------------
