@@ -437,6 +437,24 @@ int stj_loss_fwd(const float* logits, const float* gt_obs, const float* gt_occ, 
                  float flow_origin_w, float replica, int flags, hipStream_t stream);
 int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                  const float* coef, const float* upstream, float* dlogits, int B, int H, int W, int flags, hipStream_t stream);
+/* The same two passes as ONE (round 6): every backward coefficient of loss.py:161-170 under train.py:221-223 (unit gradient on the sum of
+ * the four terms) depends on the ground truth alone -- weights, pixel count, the AUC gate, the per-waypoint count of pixels with a
+ * non-zero true flow (loss.py:279-291) -- so
+ * coef:    coef f32[32] = what stj_loss_fwd would write, from gt_flow and the gate (cnt int[8] scratch, zero on entry);
+ * fwd_bwd: loss f32[5], coef_out f32[32] as stj_loss_fwd, AND dlogits as stj_loss_bwd with upstream == 1 (flag bit 3), on one read of
+ *          the logits and the ground truth; coef_in = coef's output; sums f32[128*40] scratch, zero on entry.  loss == NULL: the pass
+ *          alone; stj_loss_finalize (any stream behind it) then writes loss and coef_out from sums. */
+int stj_loss_coef(const float* gt_flow, const float* gate, int* cnt, float* coef, int B, int H, int W, float ogm_w, float occ_w,
+                  float flow_origin_w, float replica, int flags, hipStream_t stream);
+int stj_loss_finalize(const float* sums, const float* gate, float* loss, float* coef_out, int B, int H, int W, float ogm_w,
+                      float occ_w, float flow_origin_w, float replica, int flags, hipStream_t stream);
+/* auc_gate + coef on one pass over the ground truth: hist int[8*202 + 8] scratch (zero on entry; the last 8 collect the flow counts) */
+int stj_loss_gate_coef(const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin, int* hist, float* gate,
+                       float* auc_out, float* coef, int B, int H, int W, float ogm_w, float occ_w, float flow_origin_w,
+                       float replica, int flags, hipStream_t stream);
+int stj_loss_fwd_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
+                     const float* gate, const float* coef_in, float* sums, float* loss, float* coef_out, float* dlogits,
+                     int B, int H, int W, float ogm_w, float occ_w, float flow_origin_w, float replica, int flags, hipStream_t stream);
 
 /* TFRecord feature decode (train.py:87-103, inference.py:84-96 _parse_image_function: tf.io.decode_raw + reshape + centre crop
  * + cast).  src: the raw feature bytes of a batch, [n_outer][H][W][C] elements of kind 0 bool/uint8 (v != 0), 1 int8,

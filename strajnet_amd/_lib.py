@@ -111,6 +111,10 @@ SIGNATURES = {
     'stj_loss_auc_gate': [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp],
     'stj_loss_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp],
     'stj_loss_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    'stj_loss_coef': [vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp],
+    'stj_loss_finalize': [vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp],
+    'stj_loss_gate_coef': [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp],
+    'stj_loss_fwd_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp],
 }
 
 class WgradJob(ctypes.Structure):

@@ -100,12 +100,14 @@ __device__ __forceinline__ int auc_bucket(float pred) {
 
 // ---- AUC gate ----------------------------------------------------------------------------------------
 // hist [NWP][2][101] (int): bucket = #thresholds strictly below pred; class 1 = label true.
+// cnt (optional): int[NWP], += the pixels of waypoint k with a non-zero true flow (the flow term's denominator: loss_coef_kernel)
 __global__ __launch_bounds__(256) void auc_hist_kernel(const float* gt_obs, const float* gt_occ, const float* gt_flow,
-                                                       const float* origin, int* hist, int B, int H, int W) {
-  __shared__ int sh[2 * 101];
+                                                       const float* origin, int* hist, int* cnt, int B, int H, int W) {
+  __shared__ int sh[2 * 101 + 1];
   const int k = blockIdx.y;
-  for (int i = threadIdx.x; i < 202; i += 256) sh[i] = 0;
+  for (int i = threadIdx.x; i < 203; i += 256) sh[i] = 0;
   __syncthreads();
+  int nex = 0;
   const long long npix = (long long)B * H * W;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += gridDim.x * 256ll) {
     const int x = (int)(i % W); long long t = i / W;
@@ -113,14 +115,22 @@ __global__ __launch_bounds__(256) void auc_hist_kernel(const float* gt_obs, cons
     const long long g = ((b * NWP + k) * H + y) * W + x;
     const float ta = fminf(fmaxf(gt_obs[g] + gt_occ[g], 0.f), 1.f);
     const float* img = origin + (b * NWP + k) * (long long)H * W;
-    const float wp = warp_sample(img, H, W, (float)x + gt_flow[2 * g], (float)y + gt_flow[2 * g + 1], nullptr, nullptr);
+    const float fx = gt_flow[2 * g], fy = gt_flow[2 * g + 1];
+    nex += (fx != 0.f || fy != 0.f) ? 1 : 0;
+    const float wp = warp_sample(img, H, W, (float)x + fx, (float)y + fy, nullptr, nullptr);
     const float pred = wp * ta;
     const int bk = auc_bucket(pred);
     atomicAdd(&sh[(ta != 0.f ? 101 : 0) + bk], 1);
   }
+  if (cnt) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nex += __shfl_xor(nex, o, 64);
+    if ((threadIdx.x & 63) == 0 && nex) atomicAdd(&sh[202], nex);
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < 202; i += 256)
     if (sh[i]) atomicAdd(hist + k * 202 + i, sh[i]);
+  if (cnt && threadIdx.x == 0 && sh[202]) atomicAdd(cnt + k, sh[202]);
 }
 // one 128-thread block per waypoint, thread i = threshold i: Keras interpolate_pr_auc from the histogram; gate[k] = auc > 0;
 // auc_out optional.  (v0 ran the whole recurrence in ONE thread per waypoint with 1.6 KB of f64 scratch arrays: 82 us.)
@@ -218,12 +228,21 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* logits, cons
 struct LossCfg { float ogm_w, occ_w, fow, replica; int use_warp; };
 
 // loss[5] = observed_xe, occluded_xe, flow, flow_warp_xe, their sum ; coef [NWP][4] per-waypoint backward coefficients (before upstream grads)
-__global__ void loss_finalize_kernel(const float* sums_parts, const float* gate, float* loss, float* coef, float npix, LossCfg c) {
-  __shared__ float sums[NWP * S_N];
-  if (threadIdx.x < NWP * S_N) {
+__global__ void loss_finalize_kernel(const float* sums_parts, int nparts, const float* gate, float* loss, float* coef, float npix, LossCfg c) {
+  // 240 threads: six per accumulator, each over every sixth copy (a serial walk of 128 copies by 40 threads was 36 us of dependent loads
+  // on the step's critical path); the six partial sums are added in a fixed order
+  __shared__ float sums[NWP * S_N], part[6][NWP * S_N];
+  if (threadIdx.x < 6 * NWP * S_N) {
+    const int slot = threadIdx.x % (NWP * S_N), j = threadIdx.x / (NWP * S_N);
     float a = 0.f;
-    for (int q = 0; q < LOSS_PARTS; ++q) a += sums_parts[q * (NWP * S_N) + threadIdx.x];
-    sums[threadIdx.x] = a;
+#pragma unroll 8
+    for (int q = j; q < nparts; q += 6) a += sums_parts[q * (NWP * S_N) + slot];
+    part[j][slot] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < NWP * S_N) {
+    const int t = threadIdx.x;
+    sums[t] = ((((part[0][t] + part[1][t]) + part[2][t]) + part[3][t]) + part[4][t]) + part[5][t];
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -299,13 +318,133 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* logits, cons
   }
 }
 
+// ---- forward sums AND d(total)/d(logits) in one pass --------------------------------------------------
+// Every backward coefficient (loss_finalize_kernel: coef[k][0..3]) depends on the GROUND TRUTH alone -- the weights, the pixel count, the
+// AUC gate and, for the flow term, the number of pixels with a non-zero true flow (loss.py:279-291) -- so a step that differentiates
+// the sum of the four terms with a unit upstream gradient (train.py:221-223) does not need the forward sums before it can write
+// d/dlogits: loss_coef (below, issued with the gate on the loss-preparation stream, under the model's forward pass) produces the
+// coefficients, and this kernel is loss_fwd_kernel + loss_bwd_kernel on ONE read of the logits and the ground truth.  In the captured
+// train step the two passes and the finalize launch between them ran alone on the machine between the last forward and the first
+// backward kernel (69 + 8 + 59 us of a 5.9 ms step, profiles/r06_p_timeline_concurrent.txt).
+#define LOSS_PARTS_FUSED 128
+#ifndef LOSS_FB_MAXG
+#define LOSS_FB_MAXG 16384
+#endif
+template <bool FOCAL, bool PRED>
+__global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const float* logits, const float* gt_obs, const float* gt_occ,
+                                                           const float* gt_flow, const float* origin, const float* coef,
+                                                           float* sums, float* dlogits, int B, int H, int W, int use_warp) {
+  __shared__ float red[4][NWP * S_N];
+  const float inv_hw = 1.f / ((float)H * (float)W);
+  float acc[S_N];
+#pragma unroll
+  for (int i = 0; i < S_N; ++i) acc[i] = 0.f;
+  const long long nitem = (long long)B * H * W * NWP;
+  const int k = threadIdx.x & 7;
+  const float c0 = coef[4 * k], c1 = coef[4 * k + 1], c2 = coef[4 * k + 2], c3 = coef[4 * k + 3];
+  for (long long it = blockIdx.x * 256ll + threadIdx.x; it < nitem; it += gridDim.x * 256ll) {
+    const long long i = it >> 3;
+    const int x = (int)(i % W); long long t = i / W;
+    const int y = (int)(t % H); const long long b = t / H;
+    const float4 lg = reinterpret_cast<const float4*>(logits)[it];
+    const long long g = ((b * NWP + k) * H + y) * W + x;
+    const float to = gt_obs[g], tc = gt_occ[g];
+    const float2 fl = reinterpret_cast<const float2*>(gt_flow)[g];
+    const float fx = fl.x, fy = fl.y;
+    float g0, g1;
+    if (FOCAL) { acc[S_OBS] += xe_focal_logits(to, lg.x, &g0); acc[S_OCC] += xe_focal_logits(tc, lg.y, &g1); }
+    else {
+      acc[S_OBS] += xe_logits(to, lg.x); acc[S_OCC] += xe_logits(tc, lg.y);
+      g0 = sigmoidf(lg.x) - to; g1 = sigmoidf(lg.y) - tc;
+    }
+    g0 *= c0; g1 *= c1;
+    const float ex = (fx != 0.f || fy != 0.f) ? 1.f : 0.f;
+    const float d0 = fx - lg.z, d1 = fy - lg.w;
+    acc[S_L1] += (fabsf(d0) + fabsf(d1)) * ex;
+    acc[S_EX] += ex;
+    float g2 = -c2 * ex * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+    float g3 = -c2 * ex * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+    if (use_warp) {
+      const float* img = origin + (b * NWP + k) * (long long)H * W;
+      float ddx, ddy;
+      const float wp = warp_sample(img, H, W, (float)x + lg.z, (float)y + lg.w, &ddx, &ddy);
+      const float sa = sigmoidf(PRED ? lg.x : to), sb = sigmoidf(PRED ? lg.y : tc);
+      const float ssum = sa + sb;
+      const float sg = fminf(fmaxf(ssum, 0.f), 1.f);
+      const float ta = fminf(fmaxf(to + tc, 0.f), 1.f);
+      float dq;
+      acc[S_WARP] += warp_term<FOCAL, PRED>(ta, sg * wp, inv_hw, &dq);
+      if (c3 != 0.f) {
+        dq *= c3;
+        g2 += dq * sg * ddx;
+        g3 += dq * sg * ddy;
+        if (PRED && ssum <= 1.f) {
+          g0 += dq * wp * sa * (1.f - sa);
+          g1 += dq * wp * sb * (1.f - sb);
+        }
+      }
+    }
+    reinterpret_cast<float4*>(dlogits)[it] = make_float4(g0, g1, g2, g3);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < S_N; ++i) {
+    float v = acc[i];
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if (lane < 8) red[w][lane * S_N + i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NWP * S_N)
+    atomicAdd(sums + (blockIdx.x % LOSS_PARTS_FUSED) * (NWP * S_N) + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// pixels with a non-zero true flow, per waypoint (the denominator of the flow term, loss.py:279-291): cnt int[8], zero on entry
+template <bool VEC4>
+__global__ __launch_bounds__(256) void loss_flow_count_kernel(const float* gt_flow, int* cnt, long long plane) {
+  __shared__ int red[4];
+  const int k = blockIdx.y % NWP;
+  const float* fp = gt_flow + (long long)blockIdx.y * plane * 2;
+  int n = 0;
+  if (VEC4) {       // two pixels per 16-byte load
+    const float4* f = reinterpret_cast<const float4*>(fp);
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < plane / 2; i += gridDim.x * 256ll) {
+      const float4 v = f[i];
+      n += ((v.x != 0.f || v.y != 0.f) ? 1 : 0) + ((v.z != 0.f || v.w != 0.f) ? 1 : 0);
+    }
+  } else {
+    const float2* f = reinterpret_cast<const float2*>(fp);
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < plane; i += gridDim.x * 256ll) {
+      const float2 v = f[i];
+      n += (v.x != 0.f || v.y != 0.f) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) { const int s = red[0] + red[1] + red[2] + red[3]; if (s) atomicAdd(cnt + k, s); }
+}
+// the coefficients loss_finalize_kernel derives from the forward sums, from the count instead (bit-identical: the float sum of ones is exact)
+__global__ void loss_coef_kernel(const int* cnt, const float* gate, float* coef, float npix, LossCfg c) {
+  if (threadIdx.x != 0) return;
+  float fc = 0.f;
+  for (int k = 0; k < NWP; ++k) fc += gate[k];
+  for (int k = 0; k < NWP; ++k) {
+    const float den = (float)cnt[k] * c.replica / 2.f;
+    coef[k * 4 + 0] = c.ogm_w / (npix * c.replica) / NWP;
+    coef[k * 4 + 1] = c.occ_w / (npix * c.replica) / NWP;
+    coef[k * 4 + 2] = den != 0.f ? gate[k] / fc / den : 0.f;
+    coef[k * 4 + 3] = c.use_warp ? gate[k] / fc * c.fow / (npix * c.replica) : 0.f;
+  }
+}
+
 // gate: f32[8] out.  hist: int[8*202] scratch, MUST BE ZERO on entry (no memset node here: hipMemsetAsync inside a captured
 // hipGraph replayed with stale contents on ROCm 7.2 -- tools/probes/dbg_graph2.py).  auc_out optional f32[8].
 extern "C" int stj_loss_auc_gate(const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
                                  int* hist, float* gate, float* auc_out, int B, int H, int W, hipStream_t stream) {
   const long long npix = (long long)B * H * W;
   const int gx = (int)min(256ll, (npix + 255) / 256);
-  hipLaunchKernelGGL(auc_hist_kernel, dim3(gx, NWP), dim3(256), 0, stream, gt_obs, gt_occ, gt_flow, origin, hist, B, H, W);
+  hipLaunchKernelGGL(auc_hist_kernel, dim3(gx, NWP), dim3(256), 0, stream, gt_obs, gt_occ, gt_flow, origin, hist, (int*)nullptr, B, H, W);
   hipLaunchKernelGGL(auc_gate_kernel, dim3(NWP), dim3(128), 0, stream, hist, gate, auc_out);
   return stj_check_launch("stj_loss_auc_gate");
 }
@@ -323,7 +462,7 @@ extern "C" int stj_loss_fwd(const float* logits, const float* gt_obs, const floa
   if (focal && pred) LOSS_FWD(true, true); else if (focal) LOSS_FWD(true, false); else if (pred) LOSS_FWD(false, true); else LOSS_FWD(false, false);
 #undef LOSS_FWD
   LossCfg c; c.ogm_w = ogm_w; c.occ_w = occ_w; c.fow = flow_origin_w; c.replica = replica; c.use_warp = use_warp;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, gate, loss, coef, (float)npix, c);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, sums, LOSS_PARTS, gate, loss, coef, (float)npix, c);
   return stj_check_launch("stj_loss_fwd");
 }
 extern "C" int stj_loss_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
@@ -338,6 +477,72 @@ extern "C" int stj_loss_bwd(const float* logits, const float* gt_obs, const floa
   if (focal && pred) LOSS_BWD(true, true); else if (focal) LOSS_BWD(true, false); else if (pred) LOSS_BWD(false, true); else LOSS_BWD(false, false);
 #undef LOSS_BWD
   return stj_check_launch("stj_loss_bwd");
+}
+
+// coef f32[32]: the backward coefficients from the ground truth alone (see loss_fwd_bwd_kernel); cnt int[8] scratch, MUST BE ZERO on entry
+extern "C" int stj_loss_coef(const float* gt_flow, const float* gate, int* cnt, float* coef, int B, int H, int W, float ogm_w, float occ_w,
+                             float flow_origin_w, float replica, int flags, hipStream_t stream) {
+  if (((uintptr_t)gt_flow) & 7) { stj_set_error("loss: gt_flow must be 8-byte aligned"); return STJ_EINVAL; }
+  if (flags & ~7) { stj_set_error("loss: unknown flag bits %d", flags); return STJ_EINVAL; }
+  const long long plane = (long long)H * W;
+  if (B > 0 && plane > 0) {
+    // 16 workgroups per (sample, waypoint) plane at 256 x 256: 8 pixels per thread; one atomic per workgroup (128 per counter at B = 8)
+    const int gx = (int)min(16ll, (plane / 2 + 255) / 256);
+    if (plane % 2 == 0 && (((uintptr_t)gt_flow) & 15) == 0)
+      hipLaunchKernelGGL(loss_flow_count_kernel<true>, dim3(gx, B * NWP), dim3(256), 0, stream, gt_flow, cnt, plane);
+    else
+      hipLaunchKernelGGL(loss_flow_count_kernel<false>, dim3(gx, B * NWP), dim3(256), 0, stream, gt_flow, cnt, plane);
+  }
+  LossCfg c; c.ogm_w = ogm_w; c.occ_w = occ_w; c.fow = flow_origin_w; c.replica = replica; c.use_warp = flags & 1;
+  hipLaunchKernelGGL(loss_coef_kernel, dim3(1), dim3(64), 0, stream, cnt, gate, coef, (float)((long long)B * H * W), c);
+  return stj_check_launch("stj_loss_coef");
+}
+// stj_loss_auc_gate + stj_loss_coef on ONE pass over the ground truth (the histogram kernel reads gt_flow anyway): hist int[8*202 + 8]
+// scratch, MUST BE ZERO on entry (the last 8: the flow counts)
+extern "C" int stj_loss_gate_coef(const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin, int* hist, float* gate,
+                                  float* auc_out, float* coef, int B, int H, int W, float ogm_w, float occ_w, float flow_origin_w,
+                                  float replica, int flags, hipStream_t stream) {
+  if (flags & ~7) { stj_set_error("loss: unknown flag bits %d", flags); return STJ_EINVAL; }
+  const long long npix = (long long)B * H * W;
+  const int gx = (int)min(256ll, (npix + 255) / 256);
+  int* cnt = hist + NWP * 202;
+  if (gx > 0) hipLaunchKernelGGL(auc_hist_kernel, dim3(gx, NWP), dim3(256), 0, stream, gt_obs, gt_occ, gt_flow, origin, hist, cnt, B, H, W);
+  hipLaunchKernelGGL(auc_gate_kernel, dim3(NWP), dim3(128), 0, stream, hist, gate, auc_out);
+  LossCfg c; c.ogm_w = ogm_w; c.occ_w = occ_w; c.fow = flow_origin_w; c.replica = replica; c.use_warp = flags & 1;
+  hipLaunchKernelGGL(loss_coef_kernel, dim3(1), dim3(64), 0, stream, cnt, gate, coef, (float)npix, c);
+  return stj_check_launch("stj_loss_gate_coef");
+}
+// stj_loss_fwd and stj_loss_bwd with a unit upstream gradient on the sum of the four terms, as one pass: coef_in = stj_loss_coef's output;
+// sums f32[128*40] scratch, MUST BE ZERO on entry; loss f32[5] and coef_out f32[32] as stj_loss_fwd writes them (coef_out == coef_in)
+extern "C" int stj_loss_fwd_bwd(const float* logits, const float* gt_obs, const float* gt_occ, const float* gt_flow, const float* origin,
+                                const float* gate, const float* coef_in, float* sums, float* loss, float* coef_out, float* dlogits,
+                                int B, int H, int W, float ogm_w, float occ_w, float flow_origin_w, float replica, int flags,
+                                hipStream_t stream) {
+  if ((((uintptr_t)logits) | ((uintptr_t)dlogits)) & 15) { stj_set_error("loss: logits / dlogits must be 16-byte aligned"); return STJ_EINVAL; }
+  if (((uintptr_t)gt_flow) & 7) { stj_set_error("loss: gt_flow must be 8-byte aligned"); return STJ_EINVAL; }
+  if (flags & ~7) { stj_set_error("loss: unknown flag bits %d", flags); return STJ_EINVAL; }
+  const long long npix = (long long)B * H * W;
+  // one (pixel, waypoint) item per thread up to 16384 workgroups: waves that load, store and end (the streaming probe)
+  const int gx = (int)min((long long)LOSS_FB_MAXG, (npix * NWP + 255) / 256);
+  const int use_warp = flags & 1, focal = (flags >> 1) & 1, pred = (flags >> 2) & 1;
+  if (gx > 0) {
+#define LOSS_FB(FO, PR) hipLaunchKernelGGL((loss_fwd_bwd_kernel<FO, PR>), dim3(gx), dim3(256), 0, stream, logits, gt_obs, gt_occ, gt_flow, origin, coef_in, sums, dlogits, B, H, W, use_warp)
+    if (focal && pred) LOSS_FB(true, true); else if (focal) LOSS_FB(true, false); else if (pred) LOSS_FB(false, true); else LOSS_FB(false, false);
+#undef LOSS_FB
+  }
+  if (loss == nullptr) return stj_check_launch("stj_loss_fwd_bwd");        // the caller finishes with stj_loss_finalize (e.g. on another stream)
+  LossCfg c; c.ogm_w = ogm_w; c.occ_w = occ_w; c.fow = flow_origin_w; c.replica = replica; c.use_warp = use_warp;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, sums, LOSS_PARTS_FUSED, gate, loss, coef_out, (float)npix, c);
+  return stj_check_launch("stj_loss_fwd_bwd");
+}
+// the last launch of stj_loss_fwd_bwd on its own (loss == NULL there): nothing on the backward path reads what it writes, so a caller may
+// issue it on a side stream behind the pass; sums = the pass's f32[128*40]
+extern "C" int stj_loss_finalize(const float* sums, const float* gate, float* loss, float* coef_out, int B, int H, int W, float ogm_w,
+                                 float occ_w, float flow_origin_w, float replica, int flags, hipStream_t stream) {
+  if (flags & ~7) { stj_set_error("loss: unknown flag bits %d", flags); return STJ_EINVAL; }
+  LossCfg c; c.ogm_w = ogm_w; c.occ_w = occ_w; c.fow = flow_origin_w; c.replica = replica; c.use_warp = flags & 1;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, sums, LOSS_PARTS_FUSED, gate, loss, coef_out, (float)((long long)B * H * W), c);
+  return stj_check_launch("stj_loss_finalize");
 }
 
 

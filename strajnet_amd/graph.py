@@ -27,7 +27,11 @@ class GraphedTrainStep:
         self.graph = self.graph_b = None
         self._side = None
         self.losses = None
-        self._one = None
+        # the gradient `total` is differentiated with: created up front and announced to the loss, which then writes d(total)/d(logits)
+        # in its forward pass (OGMFlow_loss.unit_grad, ops.LOSS_FUSED_BWD)
+        self._one = torch.ones((), dtype=torch.float32, device=next(iter(batch.values())).device)
+        if hasattr(loss_fn, 'unit_grad'):
+            loss_fn.unit_grad = self._one
         if split:
             model.cut_encoder = True
         side = ops.role_stream(torch.cuda.current_device(), 'warmup')
@@ -59,6 +63,8 @@ class GraphedTrainStep:
         if hasattr(self.loss_fn, 'prepare'):         # the ground-truth-only part of the loss: side stream, under the forward pass --
             if self._side is None:                   # issued from the model's mid-forward hook (behind the encoder's first stage: at the
                 self._side = ops.role_stream(torch.cuda.current_device(), 'loss_prep')     # head of the step its two launches delayed the first encoder kernel)
+                if hasattr(self.loss_fn, 'finalize_stream'):
+                    self.loss_fn.finalize_stream = self._side
 
             def prepare():
                 self._side.wait_stream(torch.cuda.current_stream())
@@ -73,9 +79,9 @@ class GraphedTrainStep:
             main.wait_stream(self._side)
         d = self.loss_fn(get_pred_waypoint_logits(out), tw, None)
         total = d.total                      # observed_xe + occluded_xe + flow + flow_warp_xe (train.py:221)
-        if self._one is None:                # (first warm-up pass, outside the capture: backward()'s implicit ones_like is a fill launch between
-            self._one = torch.ones_like(total)   #  the loss's forward and backward kernels on every replay)
-        total.backward(self._one)
+        total.backward(self._one)             # (an explicit tensor: backward()'s implicit ones_like is a fill launch on every replay)
+        if self._side is not None:
+            main.wait_stream(self._side)      # the loss values' finalize launch (issued behind the loss pass on the side stream)
         self.total = total.detach()           # the sum the finalize kernel wrote (static across replays, like self.losses)
         return d.packed             # [observed_xe, occluded_xe, flow, flow_warp_xe], detached
 

@@ -86,6 +86,15 @@ class OGMFlow_loss:
         self.replica = replica
         self.flow_origin_weight = flow_origin_weight
         self.no_use_warp, self.use_gt = no_use_warp, use_gt
+        # Not in the reference: a caller that will differentiate `.total` with a known all-ones gradient tensor (GraphedTrainStep:
+        # `total.backward(one)`) announces that tensor here; together with prepare() the loss then writes d(total)/d(logits) in its
+        # forward pass (stj_loss_fwd_bwd) and backward hands it over when it is called with exactly that tensor -- any other
+        # upstream gradient takes the general kernel.
+        self.unit_grad = None
+        self.finalize_stream = None     # with unit_grad: a side stream for the launch that writes the loss VALUES (the caller joins it)
+
+    def _flags(self):
+        return (0 if self.no_use_warp else 1) | (2 if self.use_focal_loss else 0) | (4 if self.use_pred else 0)
 
     @staticmethod
     def _ground_truth(true_waypoints):
@@ -101,8 +110,17 @@ class OGMFlow_loss:
         the model's forward pass, e.g. on a side stream; the next __call__ with the SAME true_waypoints object then skips it.  In
         the train step the gate (37 us) otherwise sits between the last forward and the first backward kernel, where nothing overlaps it."""
         self._prepared = None
-        if self.use_gt:
-            self._prepared = (true_waypoints, ops.auc_gate(*self._ground_truth(true_waypoints)))
+        if self.use_gt or self.unit_grad is not None:
+            gt = self._ground_truth(true_waypoints)
+            w = (self.ogm_weight, self.occ_weight, self.flow_origin_weight, self.replica, self._flags())
+            coef = None
+            if self.use_gt and self.unit_grad is not None:      # the backward coefficients depend on the ground truth alone as well:
+                gate, coef = ops.auc_gate_coef(*gt, *w)         # the gate's histogram pass counts the flow term's denominator on the way
+            else:
+                gate = ops.auc_gate(*gt) if self.use_gt else torch.ones(8, dtype=torch.float32, device=gt[0].device)
+                if self.unit_grad is not None:
+                    coef = ops.loss_coef(gt[2], gate, *w)
+            self._prepared = (true_waypoints, gate, coef)
 
     def __call__(self, pred_waypoint_logits, true_waypoints, curr_ogm=None):
         n = self.config.num_waypoints
@@ -122,15 +140,16 @@ class OGMFlow_loss:
         if tuple(gt_obs.shape) != (B, 8, H, W, 1) or tuple(gt_flow.shape) != (B, 8, H, W, 2):
             raise ValueError('ground truth must be [B,8,H,W,{1,1,2,1}]')
         cached, self._prepared = getattr(self, '_prepared', None), None
-        if self.use_gt and cached is not None and cached[0] is true_waypoints:
-            gate = cached[1]                 # computed by prepare() (it depends on the ground truth only)
+        coef = None
+        if cached is not None and cached[0] is true_waypoints:
+            gate, coef = cached[1], cached[2]            # computed by prepare() (they depend on the ground truth only)
         elif self.use_gt:
             gate = ops.auc_gate(gt_obs, gt_occ, gt_flow, origin)
         else:
             gate = torch.ones(8, dtype=torch.float32, device=logits.device)
         loss = ops.ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin, gate, self.ogm_weight, self.occ_weight,
-                                 self.flow_origin_weight, self.replica,
-                                 (0 if self.no_use_warp else 1) | (2 if self.use_focal_loss else 0) | (4 if self.use_pred else 0))
+                                 self.flow_origin_weight, self.replica, self._flags(),
+                                 coef=coef, unit=self.unit_grad if coef is not None else None, fin_stream=self.finalize_stream)
         d = LossDict({'observed_xe': loss[0], 'occluded_xe': loss[1], 'flow': loss[2],
                       'flow_warp_xe': loss[3] if not self.no_use_warp else 0.0})
         d.total, d.packed = loss[4], loss[5]       # the sum (differentiable) and the 4 values as one detached vector

@@ -2555,16 +2555,39 @@ class _OgmFlowLoss(torch.autograd.Function):
     """-> (observed_xe, occluded_xe, flow, flow_warp_xe, total): five 0-dim tensors.  `total` (their sum, train.py:221) is an output
     of its own so that a step which only differentiates the sum runs no select / add / zeros glue around the two loss kernels."""
     @staticmethod
-    def forward(ctx, logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, flags):
+    def forward(ctx, logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, flags, coef_pre=None, unit=None, fin_stream=None):
         _req_cuda(logits)
         logits = logits.contiguous().float()
         B, H, W, _ = logits.shape
         dev = logits.device
-        sums = zeros_f32(32 * 40, dev)       # 32 copies of the 40 accumulators (stj_loss_fwd)
         loss = torch.empty(5, dtype=torch.float32, device=dev)      # the four terms + their sum
         coef = torch.empty(32, dtype=torch.float32, device=dev)
-        call('stj_loss_fwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(sums), _p(loss), _p(coef),
-             B, H, W, float(ogm_w), float(occ_w), float(fow), float(replica), int(flags), _st())
+        ctx.unit_grad = None
+        if coef_pre is not None and unit is not None and LOSS_FUSED_BWD:
+            # the caller announced the unit gradient it will differentiate `total` with, and the backward coefficients are there already
+            # (loss_coef: they depend on the ground truth alone): forward sums and d(total)/d(logits) in one pass over the logits
+            sums = zeros_f32(128 * 40, dev)
+            dlogits = torch.empty_like(logits)
+            w = (B, H, W, float(ogm_w), float(occ_w), float(fow), float(replica), int(flags))
+            ctx.fin_stream = fin_stream if (LOSS_FIN_SIDE and not _SERIAL) else None
+            if ctx.fin_stream is None:
+                call('stj_loss_fwd_bwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(coef_pre), _p(sums), _p(loss),
+                     _p(coef), _p(dlogits), *w, _st())
+            else:
+                # the loss VALUES are read by nobody on the backward path: their 1-workgroup finalize launch goes behind the pass on the
+                # caller's side stream (the caller joins it: GraphedTrainStep, after backward) instead of in front of the first backward kernel
+                call('stj_loss_fwd_bwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(coef_pre), _p(sums), None,
+                     None, _p(dlogits), *w, _st())
+                ctx.fin_stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(ctx.fin_stream):
+                    call('stj_loss_finalize', _p(sums), _p(gate), _p(loss), _p(coef), *w, _st())
+                for t in (sums, gate, loss, coef):
+                    t.record_stream(ctx.fin_stream)
+            ctx.unit_grad, ctx.dlogits = unit, dlogits
+        else:
+            sums = zeros_f32(32 * 40, dev)       # 32 copies of the 40 accumulators (stj_loss_fwd)
+            call('stj_loss_fwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(gate), _p(sums), _p(loss), _p(coef),
+                 B, H, W, float(ogm_w), float(occ_w), float(fow), float(replica), int(flags), _st())
         ctx.geo = (B, H, W, int(flags))
         ctx.set_materialize_grads(False)     # a step that differentiates only `total` gets None for the four terms: one-scalar path below
         ctx.save_for_backward(logits, gt_obs, gt_occ, gt_flow, origin, coef)
@@ -2578,7 +2601,16 @@ class _OgmFlowLoss(torch.autograd.Function):
         B, H, W, flags = ctx.geo
         parts = (g0, g1, g2, g3)
         if all(g is None for g in parts) and gt is None:
-            return (None,) * 11
+            return (None,) * 14
+        if ctx.unit_grad is not None and all(g is None for g in parts) and gt.data_ptr() == ctx.unit_grad.data_ptr():
+            LOSS_FUSED_STATS['hits'] += 1          # the announced unit gradient: d/dlogits was written by the forward pass
+            dl, ctx.dlogits = ctx.dlogits, None
+            return (dl,) + (None,) * 13
+        if ctx.unit_grad is not None:
+            LOSS_FUSED_STATS['misses'] += 1        # some other upstream gradient: the general kernel (the forward's d/dlogits is dropped)
+            ctx.dlogits = None
+            if ctx.fin_stream is not None:         # (its coefficients come from the finalize launch)
+                torch.cuda.current_stream(logits.device).wait_stream(ctx.fin_stream)
         if all(g is None for g in parts):
             up = gt.float().contiguous()             # one value for the four terms (flag bit 3): no expand / copy launch
             flags |= 8
@@ -2590,7 +2622,36 @@ class _OgmFlowLoss(torch.autograd.Function):
         dlogits = torch.empty_like(logits)
         call('stj_loss_bwd', _p(logits), _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(coef), _p(up), _p(dlogits), B, H, W,
              flags, _st())
-        return (dlogits,) + (None,) * 10
+        return (dlogits,) + (None,) * 13
+
+
+LOSS_FUSED_BWD = True      # OGMFlow_loss with an announced unit gradient (loss_fn.unit_grad, set by GraphedTrainStep) + prepare(): stj_loss_fwd_bwd
+LOSS_FIN_SIDE = False      # ... with the launch that writes the loss VALUES on the caller's side stream (loss_fn.finalize_stream) instead of in front of the first backward kernel: 1355 / 1360 / 1357 against 1379 / 1380 / 1380 scenes/s on the main stream (a fork / join more in the replayed graph), profiles/r06_u_loss_one_pass.txt
+LOSS_FUSED_STATS = {'hits': 0, 'misses': 0}
+
+
+def loss_coef(gt_flow, gate, ogm_w, occ_w, fow, replica, flags):
+    """The backward coefficients of the loss from the ground truth alone -> f32[32] (stj_loss_coef; what stj_loss_fwd writes as `coef`)."""
+    _req_cuda(gt_flow)
+    B, _, H, W, _ = gt_flow.shape
+    cnt = zeros_f32(8, gt_flow.device).view(torch.int32)
+    coef = torch.empty(32, dtype=torch.float32, device=gt_flow.device)
+    call('stj_loss_coef', _p(gt_flow), _p(gate), _p(cnt), _p(coef), B, H, W, float(ogm_w), float(occ_w), float(fow), float(replica),
+         int(flags) & 7, _st())
+    return coef
+
+
+def auc_gate_coef(gt_obs, gt_occ, gt_flow, origin, ogm_w, occ_w, fow, replica, flags):
+    """auc_gate + loss_coef on one pass over the ground truth (stj_loss_gate_coef) -> (gate f32[8], coef f32[32])."""
+    _req_cuda(gt_obs)
+    B, _, H, W, _ = gt_obs.shape
+    dev = gt_obs.device
+    hist = zeros_f32(8 * 202 + 8, dev).view(torch.int32)
+    gate = torch.empty(8, dtype=torch.float32, device=dev)
+    coef = torch.empty(32, dtype=torch.float32, device=dev)
+    call('stj_loss_gate_coef', _p(gt_obs), _p(gt_occ), _p(gt_flow), _p(origin), _p(hist), _p(gate), None, _p(coef), B, H, W,
+         float(ogm_w), float(occ_w), float(fow), float(replica), int(flags) & 7, _st())
+    return gate, coef
 
 
 def auc_gate(gt_obs, gt_occ, gt_flow, origin, return_auc=False):
@@ -2605,5 +2666,7 @@ def auc_gate(gt_obs, gt_occ, gt_flow, origin, return_auc=False):
     return (gate, auc) if return_auc else gate
 
 
-def ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, use_warp):
-    return _OgmFlowLoss.apply(logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, use_warp)
+def ogm_flow_loss(logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, use_warp, coef=None, unit=None, fin_stream=None):
+    """coef + unit: the prepared backward coefficients (loss_coef) and the unit gradient tensor `total` will be differentiated with;
+    fin_stream: a side stream for the launch that turns the sums into the loss values (the caller waits for it before reading them)."""
+    return _OgmFlowLoss.apply(logits, gt_obs, gt_occ, gt_flow, origin, gate, ogm_w, occ_w, fow, replica, use_warp, coef, unit, fin_stream)

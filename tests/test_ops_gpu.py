@@ -806,6 +806,80 @@ def test_loss_and_gate():
     assert rel_err(lt.grad2, lt.grad) < 1e-6
 
 
+def test_loss_forward_writes_the_gradient_for_an_announced_unit_upstream():
+    """stj_loss_coef + stj_loss_fwd_bwd (OGMFlow_loss.unit_grad + prepare(), the captured train step's path) against the two-pass path
+    stj_loss_fwd / stj_loss_bwd: same coefficients (bit for bit), same loss values, same d/dlogits; another upstream gradient than the
+    announced tensor takes the general kernel."""
+    from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
+    from strajnet_amd import ops
+    from oracle import np_ref
+    cfg = dict(input_size=(128, 128), window_size=8, embed_dim=96, depths=[2, 2, 2], num_heads=[3, 6, 12])
+    x = np_ref.make_inputs(cfg, 3)
+    Hg = x['gt_obs'].shape[2]
+    rng = np.random.default_rng(1)
+    logits = rng.normal(0, 2, (3, Hg, Hg, 32)).astype(np.float32)
+    x['gt_obs'][:, 3] = 0
+    x['gt_occ'][:, 3] = 0                        # waypoint 3: gate 0
+    x['gt_flow'][:, 5] = 0                       # waypoint 5: no pixel with a true flow (denominator 0: coefficient 0)
+    gt = {k: torch.as_tensor(x[k]).cuda() for k in ('gt_obs', 'gt_occ', 'gt_flow', 'origin_flow')}
+    lt = torch.as_tensor(logits).cuda().requires_grad_(True)
+    one = torch.ones((), dtype=torch.float32, device='cuda')
+    combos = [dict(use_focal_loss=False), dict(use_focal_loss=True), dict(use_focal_loss=False, use_pred=True),
+              dict(use_focal_loss=True, use_pred=True), dict(use_focal_loss=True, no_use_warp=True)]
+    for flags in combos:
+        for use_gt in (True, False):
+            tw = warpped_gt(gt['gt_obs'], gt['gt_occ'], gt['gt_flow'], gt['origin_flow'])
+            ref_fn = OGMFlow_loss(OccupancyFlowTaskConfig(Hg, Hg, 8), replica=2.0, use_gt=use_gt, **flags)
+            lt.grad = None
+            d0 = ref_fn(get_pred_waypoint_logits(lt), tw, None)
+            d0.total.backward(one)
+            g_two = lt.grad.clone()
+            fn = OGMFlow_loss(OccupancyFlowTaskConfig(Hg, Hg, 8), replica=2.0, use_gt=use_gt, **flags)
+            fn.unit_grad = one
+            # the coefficients from the ground truth alone are the ones the forward sums give
+            gate = ops.auc_gate(*(gt[k] for k in ('gt_obs', 'gt_occ', 'gt_flow', 'origin_flow'))) if use_gt else torch.ones(8, device='cuda')
+            coef = ops.loss_coef(gt['gt_flow'], gate, fn.ogm_weight, fn.occ_weight, fn.flow_origin_weight, fn.replica, fn._flags())
+            sums, loss, coef2 = torch.zeros(32 * 40, device='cuda'), torch.empty(5, device='cuda'), torch.empty(32, device='cuda')
+            ops.call('stj_loss_fwd', ops._p(lt.detach()), ops._p(gt['gt_obs']), ops._p(gt['gt_occ']), ops._p(gt['gt_flow']), ops._p(gt['origin_flow']),
+                     ops._p(gate), ops._p(sums), ops._p(loss), ops._p(coef2), 3, Hg, Hg, fn.ogm_weight, fn.occ_weight, fn.flow_origin_weight,
+                     fn.replica, fn._flags(), ops._st())
+            assert torch.equal(coef, coef2), (flags, use_gt, coef, coef2)
+            if use_gt:       # the gate's histogram pass counting the flow pixels on the way: the same gate, the same coefficients
+                gate3, coef3 = ops.auc_gate_coef(gt['gt_obs'], gt['gt_occ'], gt['gt_flow'], gt['origin_flow'], fn.ogm_weight, fn.occ_weight,
+                                                 fn.flow_origin_weight, fn.replica, fn._flags())
+                assert torch.equal(gate3, gate) and torch.equal(coef3, coef)
+            assert float(coef[4 * 5 + 2]) == 0.0 and (not use_gt or float(coef[4 * 3 + 3]) == 0.0)
+            hits = ops.LOSS_FUSED_STATS['hits']
+            side = torch.cuda.Stream() if use_gt else None     # the loss values' finalize launch on a side stream (the caller joins it) | on the caller's
+            fn.finalize_stream = side
+            fn.prepare(tw)
+            lt.grad = None
+            ops.LOSS_FIN_SIDE, keep = True, ops.LOSS_FIN_SIDE        # (the switch is off in the shipped step: measured slower there)
+            try:
+                d1 = fn(get_pred_waypoint_logits(lt), tw, None)
+            finally:
+                ops.LOSS_FIN_SIDE = keep
+            d1.total.backward(one)
+            assert ops.LOSS_FUSED_STATS['hits'] == hits + 1
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            for k in ('observed_xe', 'occluded_xe', 'flow', 'flow_warp_xe'):
+                a, b = float(d1[k]), float(d0[k])
+                assert abs(a - b) <= 2e-6 * abs(b) + 1e-9, (flags, use_gt, k, a, b)          # f32 summation order of the partial sums
+            assert rel_err(lt.grad, g_two) < 1e-6, (flags, use_gt)
+            # not the announced tensor: the general kernel
+            miss = ops.LOSS_FUSED_STATS['misses']
+            fn.prepare(tw)
+            lt.grad = None
+            (3.0 * fn(get_pred_waypoint_logits(lt), tw, None).total).backward()
+            assert ops.LOSS_FUSED_STATS['misses'] == miss + 1
+            assert rel_err(lt.grad, 3.0 * g_two) < 1e-6
+            # no prepare(): the two-pass path, whatever was announced
+            lt.grad = None
+            fn(get_pred_waypoint_logits(lt), tw, None).total.backward(one)
+            assert ops.LOSS_FUSED_STATS['hits'] == hits + 1 and rel_err(lt.grad, g_two) < 1e-6
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('rows,C', [(1000, 96), (257, 384), (64, 100)])
 def test_layernorm_skip(dt, rows, C):
