@@ -1066,7 +1066,10 @@ template <typename T, int C, int HGP = 0> struct AttnCfg {
   static constexpr int LDT = 3 * GC + (sizeof(T) == 2 ? 16 : 8);       // token-major q|k|v tile [64][LDT]
   static constexpr int LDW = 3 * GC + 4;                               // Wqkv slice image [C][LDW] ([k = c][q seg | k seg | v seg])
   static constexpr int LDP = C + 4;                                    // Wproj slice image [GC][LDP] ([k = c of the group][oc])
-  static constexpr int TILE = 64 * LDT, WQ = C * LDW, WP = GC * LDP;
+  // f32 at C = 384: the Wqkv slice of one head is 150 KB; it is staged in KH = 2 halves of the contraction (model) dimension, the q|k|v
+  // accumulators of the wave's 16 tokens kept across the two (round 6: the f32 parity mode then runs the fused kernel at every width)
+  static constexpr int KH = (sizeof(T) == 4 && C == 384) ? 2 : 1;
+  static constexpr int TILE = 64 * LDT, WQ = (C / KH) * LDW, WP = GC * LDP;
   static constexpr int LDS_BYTES = (TILE + WQ + WP) * (int)sizeof(T) + HG * 225 * 4 + 2 * 64 * 4;
   static_assert(HEADS % HG == 0, "head groups");
 };
@@ -1145,7 +1148,7 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
   const int hb0 = SPLIT ? sp * (G::HEADS / p.split) : 0, hb1 = SPLIT ? hb0 + G::HEADS / p.split : G::HEADS;
   __shared__ float bqs[3 * C];                       // qkv bias in LDS (a global load inside the head loop would wait for the prefetched weights)
   AttnStage<T, C, HGP> stg;
-  stg.issue(wq, wp, hb0, tid);                       // first head group's weights in flight under the row gather + LayerNorm
+  if constexpr (G::KH == 1) stg.issue(wq, wp, hb0, tid);      // first head group's weights in flight under the row gather + LayerNorm
   const int nwx = p.res / 8, nW = nwx * nwx;
   const int win = unit % nW, b = unit / nW;
   const int wy = win / nwx, wx = win % nwx;
@@ -1195,6 +1198,7 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
 
   for (int h0 = hb0; h0 < hb1; h0 += HG) {
     // ---- weight slices of this head group (Wqkv[:, seg*C + 32 h0 .. +GC] for seg = q,k,v; Wproj[32 h0 .. +GC, :]): registers -> LDS
+    if constexpr (G::KH == 1) {
     stg.commit(Wqs, Wps, tid);
     for (int q = tid; q < HG * 225; q += 256) tbl[q] = p.table[(q % 225) * G::HEADS + h0 + q / 225];
     __syncthreads();
@@ -1209,6 +1213,43 @@ __global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnA
       for (int ks = 0; ks < KS; ++ks) a = Mma<T>::mma(Mma<T>::load_tr(Wqs, G::LDW, 16 * f, ks * KSTEP, lane), xa[0][ks], a);
       const float v[4] = {a[0], a[1], a[2], a[3]};
       st4(tile + (16 * wv + ln) * G::LDT + 16 * f + 4 * g, v);
+    }
+    } else {
+      // KH halves of the contraction dimension (see AttnCfg): the Wproj slice and the table first, then per half: rows [kh C / KH, +C / KH) of
+      // the Wqkv slice -> LDS (straight copies: this is the parity mode's path), the q|k|v accumulators carried across the halves
+      constexpr int CPS = GC / VN, CPP = C / VN, CH = C / G::KH, NQF = 3 * GC / 16;
+      for (int q = tid; q < GC * CPP; q += 256)
+        *reinterpret_cast<uint4*>(Wps + (q / CPP) * G::LDP + (q % CPP) * VN) = *reinterpret_cast<const uint4*>(wp + (long long)(32 * h0 + q / CPP) * C + (q % CPP) * VN);
+      for (int q = tid; q < HG * 225; q += 256) tbl[q] = p.table[(q % 225) * G::HEADS + h0 + q / 225];
+      f32x4 qa[NQF];
+#pragma unroll
+      for (int f = 0; f < NQF; ++f) {
+        const int seg = (16 * f) / GC, within = (16 * f) % GC;
+        const float4 bv = *reinterpret_cast<const float4*>(bqs + seg * C + 32 * h0 + within + 4 * g);
+        qa[f] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+      }
+#pragma unroll 1
+      for (int kh = 0; kh < G::KH; ++kh) {
+        if (kh > 0) __syncthreads();                 // the previous half's readers are done
+        for (int q = tid; q < CH * 3 * CPS; q += 256) {
+          const int k = q / (3 * CPS), r = q % (3 * CPS), seg = r / CPS, c = (r % CPS) * VN;
+          *reinterpret_cast<uint4*>(Wqs + k * G::LDW + seg * GC + c) = *reinterpret_cast<const uint4*>(wq + (long long)(kh * CH + k) * (3 * C) + seg * C + 32 * h0 + c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < NQF; ++f)
+#pragma unroll
+          for (int ks = 0; ks < KS / G::KH; ++ks) {
+            // (xa indexed by a runtime half: both candidates are registers, picked by a select)
+            const typename Mma<T>::Frag xb = kh == 0 ? xa[0][ks] : xa[0][KS / G::KH + ks];
+            qa[f] = Mma<T>::mma(Mma<T>::load_tr(Wqs, G::LDW, 16 * f, ks * KSTEP, lane), xb, qa[f]);
+          }
+      }
+#pragma unroll
+      for (int f = 0; f < NQF; ++f) {
+        const float v[4] = {qa[f][0], qa[f][1], qa[f][2], qa[f][3]};
+        st4(tile + (16 * wv + ln) * G::LDT + 16 * f + 4 * g, v);
+      }
     }
     __syncthreads();
     if (p.qkv) {                                     // coalesced copy of the tile to qkv[M, 3C] (rows in original token order)
@@ -1342,7 +1383,15 @@ static int attn_split384(const AttnArgs& a, hipStream_t st) {
     if (rc != STJ_OK) return rc;
     return split_fwd_epi<T>(a.x, a.part, s.split, a.bproj, a.y, a.B * N, 384, a.rng, a.site, a.p_drop, N, st);
   } else {
-    stj_set_error("swin_attn: C = 384 is built for the 16-bit storage types"); return STJ_EUNSUPPORTED;
+    // f32 (parity mode): (window, slice of 2 heads) workgroups, the Wqkv slice of a head staged in two halves of the model dimension
+    // (AttnCfg::KH), partial sums + the finishing launch
+    if (a.part == nullptr) { stj_set_error("swin_attn: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
+    AttnArgs s = a;
+    const long long N = (long long)a.res * a.res;
+    s.split = 6;
+    const int rc = attn_launch<T, 384, 1>(s, st);
+    if (rc != STJ_OK) return rc;
+    return split_fwd_epi<T>(a.x, a.part, s.split, a.bproj, a.y, a.B * N, 384, a.rng, a.site, a.p_drop, N, st);
   }
 }
 template <typename T>
@@ -1404,7 +1453,9 @@ template <typename T, int C, int HGP = 0> struct AttnBCfg {
   static constexpr int KC1 = C <= KW ? C : 96;                         // K-chunk of the proj product
   static constexpr int LDP = 64 + (sizeof(T) == 2 ? 8 : 4);            // P / dS tiles [64][LDP]
   static constexpr int LDO = 32 + (sizeof(T) == 2 ? 8 : 4);            // dO tile of one head [64][LDO]
-  static constexpr int TILE = 64 * LDT, WB = C * LDW, PT = 64 * LDP, DO = 64 * LDO;
+  // f32 at C = 384: the Wqkv slice of a head (rows = the C outputs of d LN(x)) is staged in KH = 2 halves of its ROWS (see AttnCfg::KH)
+  static constexpr int KH = (sizeof(T) == 4 && C == 384) ? 2 : 1;
+  static constexpr int TILE = 64 * LDT, WB = (C / KH) * LDW, PT = 64 * LDP, DO = 64 * LDO;
   static constexpr int LDS_BYTES = (TILE + WB + 2 * PT + DO) * (int)sizeof(T) + 225 * 4 + 2 * 64 * 4 + 2 * C * 4;
   static_assert(HEADS % HG == 0 && C % KC1 == 0, "shape");
 };
@@ -1424,7 +1475,8 @@ template <typename T, int C, int HGP = 0> struct AttnBStage {
   typedef AttnBCfg<T, C, HGP> G;
   static constexpr int VN = Vec<T>::N, GC = G::GC;
   static constexpr int CPS = GC / VN, CP1 = G::KC1 / VN;
-  static constexpr int NWQ = (C * 3 * CPS + 255) / 256, NWP = (C * CP1 + 255) / 256;
+  static constexpr int CH = C / G::KH;                // rows of the Wqkv slice staged at a time
+  static constexpr int NWQ = (CH * 3 * CPS + 255) / 256, NWP = (C * CP1 + 255) / 256;
   static constexpr int NT = (64 * 3 * CPS + 255) / 256;
 };
 
@@ -1506,7 +1558,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
     for (int i = 0; i < SG::NWQ; ++i) {
       const int q = tid + i * 256;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (q < C * 3 * SG::CPS) {
+      if (q < SG::CH * 3 * SG::CPS) {
         const int r0 = q / (3 * SG::CPS), r = q % (3 * SG::CPS);
         v = *reinterpret_cast<const uint4*>(wq + (long long)r0 * (3 * C) + (r / SG::CPS) * C + 32 * h0 + (r % SG::CPS) * VN);
       }
@@ -1527,7 +1579,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
 #pragma unroll
     for (int i = 0; i < SG::NWQ; ++i) {
       const int q = tid + i * 256;
-      if (q < C * 3 * SG::CPS) { const int r0 = q / (3 * SG::CPS), r = q % (3 * SG::CPS); *reinterpret_cast<uint4*>(Wb + r0 * G::LDW + (r / SG::CPS) * GC + (r % SG::CPS) * VN) = s_wq[i]; }
+      if (q < SG::CH * 3 * SG::CPS) { const int r0 = q / (3 * SG::CPS), r = q % (3 * SG::CPS); *reinterpret_cast<uint4*>(Wb + r0 * G::LDW + (r / SG::CPS) * GC + (r % SG::CPS) * VN) = s_wq[i]; }
     }
 #pragma unroll
     for (int i = 0; i < SG::NT; ++i) {
@@ -1744,11 +1796,35 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
         *reinterpret_cast<uint4*>(dqkvb + (long long)tok[t] * 3 * C + seg * C + 32 * h0 + c) = *reinterpret_cast<const uint4*>(tile + t * G::LDT + seg * GC + c);
       }
     }
+    if constexpr (G::KH == 1) {
 #pragma unroll 1
     for (int kk = 0; kk < G::KW / KSTEP; ++kk) {
       const typename Mma<T>::Frag bf = Mma<T>::load(tile, G::LDT, 16 * wv, kk * KSTEP, lane);
 #pragma unroll
       for (int f = 0; f < NF; ++f) dln[f] = Mma<T>::mma(Mma<T>::load(Wb, G::LDW, 16 * f, kk * KSTEP, lane), bf, dln[f]);
+    }
+    } else {
+      // the weight buffer holds rows [0, C / 2) of the slice (commit_group); rows [C / 2, C) replace them for the second half of d LN(x)
+      static_assert(G::KH == 2 && NF % 2 == 0, "two halves");
+#pragma unroll 1
+      for (int kk = 0; kk < G::KW / KSTEP; ++kk) {
+        const typename Mma<T>::Frag bf = Mma<T>::load(tile, G::LDT, 16 * wv, kk * KSTEP, lane);
+#pragma unroll
+        for (int f = 0; f < NF / 2; ++f) dln[f] = Mma<T>::mma(Mma<T>::load(Wb, G::LDW, 16 * f, kk * KSTEP, lane), bf, dln[f]);
+      }
+      __syncthreads();
+      for (int q = tid; q < SG::CH * 3 * SG::CPS; q += 256) {
+        const int r0 = q / (3 * SG::CPS), r = q % (3 * SG::CPS);
+        *reinterpret_cast<uint4*>(Wb + r0 * G::LDW + (r / SG::CPS) * GC + (r % SG::CPS) * VN) =
+            *reinterpret_cast<const uint4*>(wq + (long long)(SG::CH + r0) * (3 * C) + (r / SG::CPS) * C + 32 * h0 + (r % SG::CPS) * VN);
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int kk = 0; kk < G::KW / KSTEP; ++kk) {
+        const typename Mma<T>::Frag bf = Mma<T>::load(tile, G::LDT, 16 * wv, kk * KSTEP, lane);
+#pragma unroll
+        for (int f = 0; f < NF / 2; ++f) dln[NF / 2 + f] = Mma<T>::mma(Mma<T>::load(Wb, G::LDW, 16 * f, kk * KSTEP, lane), bf, dln[NF / 2 + f]);
+      }
     }
     TICK(3);
   }
@@ -1854,7 +1930,13 @@ static int attnb_split384(const AttnBArgs& a, hipStream_t st) {          // see 
     if (rc != STJ_OK) return rc;
     return split_bwd_epi<T>(a.x, a.dy, a.part, split, a.gamma, 0.f, a.mean, a.rstd, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.B * N, st);
   } else {
-    stj_set_error("swin_attn_bwd: C = 384 is built for the 16-bit storage types"); return STJ_EUNSUPPORTED;
+    // f32 (parity mode): six slices of two heads, the Wqkv slice of a head staged in two halves of its rows (AttnBCfg::KH), partial sums +
+    // the finishing launch
+    if (a.part == nullptr) { stj_set_error("swin_attn_bwd: C = 384 needs the workspace (stj_swin_split_workspace_bytes)"); return STJ_EINVAL; }
+    const long long N = (long long)a.res * a.res;
+    const int rc = attnb_launch<T, 384, 6>(a, st);
+    if (rc != STJ_OK) return rc;
+    return split_bwd_epi<T>(a.x, a.dy, a.part, 6, a.gamma, 0.f, a.mean, a.rstd, a.dx, a.dgamma, a.dbeta, a.nparts, a.pstride, a.B * N, st);
   }
 }
 

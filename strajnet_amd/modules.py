@@ -239,7 +239,7 @@ class STrajNet:
         # (row block | window) x (slice of the hidden dimension | of the heads) workgroups + a finishing launch.  The f32 parity mode runs the
         # MLP half of that stage through the same split kernel (round 5: the oracle gate then covers its code too) and keeps only the
         # attention half layer by layer (an f32 weight slice of one head does not fit LDS next to the window's q|k|v tile)
-        self.fused_attn_dims = (96, 192) + ((384,) if self.dtype != torch.float32 else ())
+        self.fused_attn_dims = (96, 192, 384)      # (f32 at C = 384 since round 6: the Wqkv slice of a head staged in two halves, csrc/swin_fused.hip AttnCfg::KH)
         self.fused_mlp_dims = (96, 192, 384)
         # the 8 time-separated cross-attentions as one kernel per direction (csrc/xattn_fused.hip); False = the layer-by-layer chain
         # (the parity tests run both and compare)

@@ -714,7 +714,7 @@ def test_f32_golden_step_runs_the_fused_entry_points():
     hold against the float64 fixture) is run with every C-ABI call recorded (strajnet_amd.prof), and the set of entry points must contain
     the fused kernels the bf16 step times -- and must not contain the layer-by-layer ops they replace.  (Known 16-bit-only kernels, by
     their entry points' dispatch: the weight-stationary / wave-specialised decoder family behind stj_upconv_*, stj_outconv_pair_*,
-    stj_wgrad_group, the C = 384 attention half, and the agent interaction block stj_agent_int_*: their f32 counterparts run here.)"""
+    stj_wgrad_group, and the agent interaction block stj_agent_int_*: their f32 counterparts run here.)"""
     from strajnet_amd import OGMFlow_loss, OccupancyFlowTaskConfig, get_pred_waypoint_logits, warpped_gt
     from strajnet_amd import prof
     model, w, x, xt = _setup(CFG128, 2, torch.float32)
@@ -736,10 +736,8 @@ def test_f32_golden_step_runs_the_fused_entry_points():
             'agent_enc_fwd', 'agent_enc_bwd', 'agent_pack', 'fgoff_fwd', 'fgoff_bwd', 'fgoff_pack', 'loss_fwd', 'loss_bwd', 'upconv_fwd', 'upconv_dgrad', 'upconv_wgrad']
     for m in must:
         assert m in text, (m, text)
-    for gone in ('small_attn', 'agent_prep', 'maxpool', 'fg_bias_fwd', 'im2col3', 'col2im3', 'win_attn_fwd'):      # replaced ops: small_attn / agent_prep / maxpool by agent_enc; fg_bias by fgattn; im2col3 / col2im3 (+ LayerNorm, gelu, the offset kernel's first half) by fgoff; win_attn at C = 96 / 192
-        if gone == 'win_attn_fwd':
-            continue                          # (the C = 384 attention half keeps the layer-by-layer window attention in f32)
-        assert gone not in text, (gone, text)
+    for gone in ('small_attn', 'agent_prep', 'maxpool', 'fg_bias_fwd', 'im2col3', 'col2im3', 'win_attn_fwd', 'win_attn_bwd'):      # replaced ops: small_attn / agent_prep / maxpool by agent_enc; fg_bias by fgattn; im2col3 / col2im3 (+ LayerNorm, gelu, the offset kernel's first half) by fgoff; win_attn at every width (C = 384 in f32 since round 6: AttnCfg::KH)
+        assert not any(k == gone or k.startswith(gone + '[') or k == 'stj_' + gone or k.startswith('stj_' + gone + '_') for k in called), (gone, text)      # (whole names: 'win_attn_fwd' is inside 'swin_attn_fwd')
     _report('f32 golden step entry points: ' + text)
 
 
