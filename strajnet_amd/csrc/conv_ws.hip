@@ -349,6 +349,14 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
           }
         }
         if constexpr (HEAD) {
+          // the four head-weight fragments once per step (they are the same for the step's SR rows; the stage writes between the rows keep the
+          // compiler from merging the reads itself: 16 ds_read_b128 per step instead of 4 next to the main loop's 30; inference B = 32 in
+          // alternating same-box runs 5636 / 5627 / 5418 against 5587 / 5575 / 5360 scenes/s, profiles/r06_x_ws2_head_hoist.txt)
+          s16x8 hwr[2][2];
+#pragma unroll
+          for (int tf = 0; tf < 2; ++tf)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) hwr[tf][k] = *reinterpret_cast<const s16x8*>(ost0 + 2 * OST + ((tf * 2 + k) * 64 + lane) * 8);
 #pragma unroll
           for (int m = 0; m < SR; ++m) {
             uint32_t pk[NF][2];
@@ -364,8 +372,8 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
 #pragma unroll
             for (int tf = 0; tf < 2; ++tf) {
               f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-              z = Mma<T>::mma(*reinterpret_cast<const s16x8*>(ost0 + 2 * OST + ((tf * 2 + 0) * 64 + lane) * 8), y0, z);
-              z = Mma<T>::mma(*reinterpret_cast<const s16x8*>(ost0 + 2 * OST + ((tf * 2 + 1) * 64 + lane) * 8), y1, z);
+              z = Mma<T>::mma(hwr[tf][0], y0, z);
+              z = Mma<T>::mma(hwr[tf][1], y1, z);
               // D: row (tap, o) = 16 tf + 4 g + r, column = this lane's pixel.  Rows 18..23 are zero (zero weight rows); 24..31 are not stored.
               if (tf == 0 || g < 2) *reinterpret_cast<uint2*>(zp + 16 * tf + 4 * g) = make_uint2(pack2<T>(z[0], z[1]), pack2<T>(z[2], z[3]));
             }
