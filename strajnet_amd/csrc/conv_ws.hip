@@ -117,6 +117,9 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const T* __
     tile_coords(tile, f, ty0, tx0);
 
     // ---- MFMA main loop: two tile rows at a time ----
+    // (Round 6: the wave's four tile rows as ONE block with every halo row read once for the two tap rows it feeds -- 40 instead of 64
+    //  ds_read_b128 per wave and tile for the same 128 MFMAs, as upconv_fwd_ws2_kernel does -- measured 147 / 141 us against 144 / 147 alone
+    //  and +0.2 / +0.2 / 0.0 % on the train step: the kernel is not bound by its fragment reads.  profiles/r06_y_ws_rowreuse.txt)
 #pragma unroll NW == 1 ? 4 : 1
     for (int mf = row0; mf < row0 + WS_TH / NW; mf += 2) {
       // the accumulators start at the bias (the MFMA's C operand: no add in the epilogue)
