@@ -15,6 +15,12 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef DG_PF
+#define DG_PF 3         // fragment groups in flight ahead of their MFMAs, upconv_dgrad_ws2_kernel (2 / 3 / 5: 230 / 227 / 229 us; old order 244)
+#endif
+#ifndef WS2_PF
+#define WS2_PF 6        // ... upconv_fwd_ws2_kernel (2 / 4 / 6: 209 / 199 / 194 us; 7 spills)
+#endif
 #define WS_TH 8
 #define WS_TW 16
 #define WS_HW (WS_TW + 2)
@@ -326,42 +332,23 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
         // a halo row feeds tap row r = 0 of output row j and tap row r = 1 of output row j - 1: SR + 1 fragment reads per (s, ks)
         // serve 2 SR row-taps (the tile-at-a-time kernel reads each twice).  The reads are issued PF groups AHEAD of their MFMAs (ring of
         // PF + 1 fragments): written as read-then-use, the ISA was ds_read, s_waitcnt lgkmcnt(0), 3-6 MFMAs, ds_read, ... -- the LDS
-        // latency exposed 30 times per step to a wave that is alone on its SIMD's matrix pipe (230 -> 208 us at F = 64, role ablation in DESIGN 4m)
-        if (!(dbg & 1)) {
-          constexpr int PF = 2, NG = 2 * KS * (SR + 1);
-          auto frag = [&](const int gi) -> s16x8 {
-            const int s2 = gi / (KS * (SR + 1)), ks = (gi / (SR + 1)) % KS, j = gi % (SR + 1);
-            return *reinterpret_cast<const s16x8*>(halo + ((mf + j + a) * WS_HW + ln + b + s2) * LDK + ks * 32 + g * 8);
-          };
-          s16x8 xr[PF + 1];
-#pragma unroll
-          for (int i = 0; i < PF; ++i) xr[i] = frag(i);
-#pragma unroll
-          for (int gi = 0; gi < NG; ++gi) {
-            if (gi + PF < NG) xr[(gi + PF) % (PF + 1)] = frag(gi + PF);
-            const int s2 = gi / (KS * (SR + 1)), ks = (gi / (SR + 1)) % KS, j = gi % (SR + 1);
-            const s16x8 xb = xr[gi % (PF + 1)];
-            if (j < SR) {
-#pragma unroll
-              for (int n = 0; n < NF; ++n) acc[j][n] = Mma<T>::mma(wf[s2][n][ks], xb, acc[j][n]);
-            }
-            if (j > 0) {
-#pragma unroll
-              for (int n = 0; n < NF; ++n) acc[j - 1][n] = Mma<T>::mma(wf[2 + s2][n][ks], xb, acc[j - 1][n]);
-            }
-          }
-        }
+        // latency exposed 30 times per step to a wave that is alone on its SIMD's matrix pipe (230 -> 208 us at F = 64, role ablation in DESIGN 4m).
+        // Round 6: the groups in HALO-ROW-MAJOR order (below) with the ring 6 deep: 210 -> 194 us alone in a hot loop (2 deep: 209; the old
+        // (s, ks, row) order 4 deep: 214), profiles/r06_z2_ws2_pf.txt.  (The role-ablation bits 1 and 2 of `dbg` went with the old order.)
+        // Halo-row-major order: after the 2 KS fragments of halo row hr, output row hr - 1 is COMPLETE (its r = 1 taps were the last it
+        // was waiting for), so its epilogue -- 12 ELUs per lane, a quarter-rate v_exp each, the packs, the stage writes (HEAD: + the
+        // projection MFMAs) -- is issued THERE, in front of halo row hr + 1's 36 MFMAs, whose matrix-pipe time covers its VALU work.  In
+        // the (s, ks, row) order every accumulator finished at the very end of the step and the whole epilogue ran with the matrix pipe idle
+        // (role ablation: 44 of the kernel's 218 us).
+        s16x8 hwr[2][2];
         if constexpr (HEAD) {
-          // the four head-weight fragments once per step (they are the same for the step's SR rows; the stage writes between the rows keep the
-          // compiler from merging the reads itself: 16 ds_read_b128 per step instead of 4 next to the main loop's 30; inference B = 32 in
-          // alternating same-box runs 5636 / 5627 / 5418 against 5587 / 5575 / 5360 scenes/s, profiles/r06_x_ws2_head_hoist.txt)
-          s16x8 hwr[2][2];
 #pragma unroll
           for (int tf = 0; tf < 2; ++tf)
 #pragma unroll
             for (int k = 0; k < 2; ++k) hwr[tf][k] = *reinterpret_cast<const s16x8*>(ost0 + 2 * OST + ((tf * 2 + k) * 64 + lane) * 8);
-#pragma unroll
-          for (int m = 0; m < SR; ++m) {
+        }
+        auto epi = [&](const int m) __attribute__((always_inline)) {
+          if constexpr (HEAD) {
             uint32_t pk[NF][2];
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
@@ -369,27 +356,50 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
               pk[n][1] = pack2<T>(elu_c(acc[m][n][2]), elu_c(acc[m][n][3]));
             }
             typedef __attribute__((ext_vector_type(4))) uint32_t u4;
-            const s16x8 y0 = __builtin_bit_cast(s16x8, (u4){pk[0][0], pk[0][1], pk[1][0], pk[1][1]});     // channels 16 (j / 4) + 4 g + j % 4
-            const s16x8 y1 = __builtin_bit_cast(s16x8, (u4){pk[2][0], pk[2][1], 0u, 0u});                 // channels 32 + 4 g + j
+            const s16x8 y0 = __builtin_bit_cast(s16x8, (u4){pk[0][0], pk[0][1], pk[1][0], pk[1][1]});
+            const s16x8 y1 = __builtin_bit_cast(s16x8, (u4){pk[2][0], pk[2][1], 0u, 0u});
             T* zp = ost + ((2 * m + a) * (2 * WS_TW) + 2 * ln + b) * LDO;
 #pragma unroll
             for (int tf = 0; tf < 2; ++tf) {
               f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
               z = Mma<T>::mma(hwr[tf][0], y0, z);
               z = Mma<T>::mma(hwr[tf][1], y1, z);
-              // D: row (tap, o) = 16 tf + 4 g + r, column = this lane's pixel.  Rows 18..23 are zero (zero weight rows); 24..31 are not stored.
               if (tf == 0 || g < 2) *reinterpret_cast<uint2*>(zp + 16 * tf + 4 * g) = make_uint2(pack2<T>(z[0], z[1]), pack2<T>(z[2], z[3]));
             }
-          }
-        } else if (!(dbg & 2))
+          } else {
 #pragma unroll
-        for (int m = 0; m < SR; ++m)
-#pragma unroll
-          for (int n = 0; n < NF; ++n) {
-            const uint32_t p0 = pack2<T>(elu_c(acc[m][n][0]), elu_c(acc[m][n][1]));
-            const uint32_t p1 = pack2<T>(elu_c(acc[m][n][2]), elu_c(acc[m][n][3]));
-            *reinterpret_cast<uint2*>(ost + ((2 * m + a) * (2 * WS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
+            for (int n = 0; n < NF; ++n) {
+              const uint32_t p0 = pack2<T>(elu_c(acc[m][n][0]), elu_c(acc[m][n][1]));
+              const uint32_t p1 = pack2<T>(elu_c(acc[m][n][2]), elu_c(acc[m][n][3]));
+              *reinterpret_cast<uint2*>(ost + ((2 * m + a) * (2 * WS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
+            }
           }
+        };
+        {
+          constexpr int PF = WS2_PF, NG = 2 * KS * (SR + 1);
+          auto frag = [&](const int gi) -> s16x8 {
+            const int hr = gi / (2 * KS), s2 = (gi / KS) & 1, ks = gi % KS;
+            return *reinterpret_cast<const s16x8*>(halo + ((mf + hr + a) * WS_HW + ln + b + s2) * LDK + ks * 32 + g * 8);
+          };
+          s16x8 xr[PF + 1];
+#pragma unroll
+          for (int i = 0; i < PF; ++i) xr[i] = frag(i);
+#pragma unroll
+          for (int gi = 0; gi < NG; ++gi) {
+            if (gi + PF < NG) xr[(gi + PF) % (PF + 1)] = frag(gi + PF);
+            const int hr = gi / (2 * KS), s2 = (gi / KS) & 1, ks = gi % KS;
+            const s16x8 xb = xr[gi % (PF + 1)];
+            if (hr < SR) {
+#pragma unroll
+              for (int n = 0; n < NF; ++n) acc[hr][n] = Mma<T>::mma(wf[s2][n][ks], xb, acc[hr][n]);
+            }
+            if (hr > 0) {
+#pragma unroll
+              for (int n = 0; n < NF; ++n) acc[hr - 1][n] = Mma<T>::mma(wf[2 + s2][n][ks], xb, acc[hr - 1][n]);
+            }
+            if (gi % (2 * KS) == 2 * KS - 1 && hr > 0) epi(hr - 1);
+          }
+        }
         __syncthreads();                                 // step q's stage is complete; the movers drain it during step q + 1
       }
     }
@@ -1863,32 +1873,49 @@ __global__ __launch_bounds__(512, 1) void upconv_dgrad_ws2_kernel(const bf16* __
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int n = 0; n < NFI; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 1))
+        // Halo-row-major order (as upconv_fwd_ws2_kernel): the step's two low-res rows take their four taps from THREE hi-res halo rows of this
+        // wave's parity -- row 2 mf + 1 - a (row 0's r = 1 taps), 2 mf + 3 - a (row 0's r = 0 and row 1's r = 1 taps: read ONCE), 2 mf + 5 - a
+        // (row 1's r = 0 taps) -- 6 fragment pairs instead of 8, fetched DG_PF groups ahead of their MFMAs through a ring; row 0's partial
+        // tile is packed and staged in front of the last halo row's MFMAs.
+        {
+          constexpr int PF = DG_PF, NG = 6;
+          auto fragp = [&](const int gi) { return halo + ((2 * mf + 2 * (gi >> 1) + 1 - a) * HW + 2 * ln + (2 - b - 2 * (gi & 1) + 1)) * LDK; };
+          s16x8 x32r[PF + 1];
+          ws_bf16x4 x16r[PF + 1];
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+          for (int i = 0; i < PF; ++i) { x32r[i] = *reinterpret_cast<const s16x8*>(fragp(i) + g * 8); x16r[i] = *reinterpret_cast<const ws_bf16x4*>(fragp(i) + 32 + g * 4); }
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const int u1 = 2 - a - 2 * r + 1, v1 = 2 - b - 2 * s2 + 1;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              const bf16* hp = halo + ((2 * (mf + m) + u1) * HW + 2 * ln + v1) * LDK;
-              const s16x8 x32 = *reinterpret_cast<const s16x8*>(hp + g * 8);
-              const ws_bf16x4 x16 = *reinterpret_cast<const ws_bf16x4*>(hp + 32 + g * 4);
-#pragma unroll
-              for (int n = 0; n < NFI; ++n)      // the six 32-deep MFMAs, then the six 16-deep ones: no back-to-back dependent pair
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w32[r * 2 + s2][n]), __builtin_bit_cast(bf16x8_t, x32), acc[m][n], 0, 0, 0);
+          for (int gi = 0; gi < NG; ++gi) {
+            if (gi + PF < NG) {
+              x32r[(gi + PF) % (PF + 1)] = *reinterpret_cast<const s16x8*>(fragp(gi + PF) + g * 8);
+              x16r[(gi + PF) % (PF + 1)] = *reinterpret_cast<const ws_bf16x4*>(fragp(gi + PF) + 32 + g * 4);
+            }
+            const int hr = gi >> 1, s2 = gi & 1;
+            const s16x8 x32 = x32r[gi % (PF + 1)];
+            const ws_bf16x4 x16 = x16r[gi % (PF + 1)];
+            if (hr >= 1) {            // tap row r = 0 of low-res row hr - 1
 #pragma unroll
               for (int n = 0; n < NFI; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w16[r * 2 + s2][n], x16, acc[m][n], 0, 0, 0);
+                acc[hr - 1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w32[s2][n]), __builtin_bit_cast(bf16x8_t, x32), acc[hr - 1][n], 0, 0, 0);
+#pragma unroll
+              for (int n = 0; n < NFI; ++n) acc[hr - 1][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w16[s2][n], x16, acc[hr - 1][n], 0, 0, 0);
+            }
+            if (hr <= 1) {            // tap row r = 1 of low-res row hr
+#pragma unroll
+              for (int n = 0; n < NFI; ++n)
+                acc[hr][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w32[2 + s2][n]), __builtin_bit_cast(bf16x8_t, x32), acc[hr][n], 0, 0, 0);
+#pragma unroll
+              for (int n = 0; n < NFI; ++n) acc[hr][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w16[2 + s2][n], x16, acc[hr][n], 0, 0, 0);
+            }
+            if (gi == 3 || gi == 5) {
+              const int m = gi == 3 ? 0 : 1;
+#pragma unroll
+              for (int n = 0; n < NFI; ++n)
+                *reinterpret_cast<uint2*>(red + ((w * 2 + m) * 16 + ln) * LDR + n * 16 + g * 4) =
+                    make_uint2(pack2bf(acc[m][n][0], acc[m][n][1]), pack2bf(acc[m][n][2], acc[m][n][3]));
             }
           }
-        if (!(dbg & 2))
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < NFI; ++n)
-            *reinterpret_cast<uint2*>(red + ((w * 2 + m) * 16 + ln) * LDR + n * 16 + g * 4) =
-                make_uint2(pack2bf(acc[m][n][0], acc[m][n][1]), pack2bf(acc[m][n][2], acc[m][n][3]));
+        }
         __syncthreads();
       }
     }
