@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const T* __
     // ---- MFMA main loop: two tile rows at a time ----
     // (Round 6: the wave's four tile rows as ONE block with every halo row read once for the two tap rows it feeds -- 40 instead of 64
     //  ds_read_b128 per wave and tile for the same 128 MFMAs, as upconv_fwd_ws2_kernel does -- measured 147 / 141 us against 144 / 147 alone
-    //  and +0.2 / +0.2 / 0.0 % on the train step: the kernel is not bound by its fragment reads.  profiles/r06_y_ws_rowreuse.txt)
+    //  and +0.2 / +0.2 / 0.0 % on the train step: the kernel is not bound by its fragment reads.  profiles/r06_y_ws_rowreuse.txt.  The
+    //  halo-row-major order with a 2 / 4 / 6 / 8 deep fragment ring that upconv_fwd_ws2_kernel gained 7 % from: 158 / 153 / 154 / 158 us
+    //  against 156 here, profiles/r06_z5_ws_rowmajor.txt -- this kernel's waves also prefetch, commit and store, and wait there.)
 #pragma unroll NW == 1 ? 4 : 1
     for (int mf = row0; mf < row0 + WS_TH / NW; mf += 2) {
       // the accumulators start at the bias (the MFMA's C operand: no add in the epilogue)
