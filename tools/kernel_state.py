@@ -26,8 +26,10 @@ LAST_TOUCHED = [
     ('upconv_wgrad_tr_kernel', 4, 'k-permutation / conflict-free strides'),
     ('outconv_bwd_mfma2_kernel', 4, 'partials + reduce'),
     ('outconv_bwd_reduce_kernel', 4, ''),
-    ('upconv_dgrad_ws2_kernel', 3, 'wave-specialised roles'),
-    ('upconv_fwd_ws2_kernel', 4, 'fragment ring'),
+    ('upconv_dgrad_ws2_kernel', 6, 'halo-row-major fragment order, 3-deep ring'),
+    ('upconv_fwd_ws2_kernel', 6, 'halo-row-major fragment order, epilogue under the next row\'s MFMAs, 6-deep ring'),
+    ('loss_fwd_bwd_kernel', 6, 'new: forward sums and d/dlogits in one pass'),
+    ('loss_flow_count_kernel', 6, ''), ('loss_coef_kernel', 6, ''),
     ('upconv_dgrad_ws_kernel', 4, 'rolling halo, one barrier per pass'),
     ('upconv_fwd_ws_kernel', 5, 'XCD-aware cout groups'),
     ('outconv_pair_fwd_kernel', 2, ''),
