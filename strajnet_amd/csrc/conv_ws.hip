@@ -18,6 +18,9 @@
 #ifndef DG_PF
 #define DG_PF 3         // fragment groups in flight ahead of their MFMAs, upconv_dgrad_ws2_kernel (2 / 3 / 5: 230 / 227 / 229 us; old order 244)
 #endif
+#ifndef WS2_PF_K4
+#define WS2_PF_K4 6
+#endif
 #ifndef WS2_PF
 #define WS2_PF 6        // ... upconv_fwd_ws2_kernel (2 / 4 / 6: 209 / 199 / 194 us; 7 spills)
 #endif
@@ -26,191 +29,9 @@
 #define WS_HW (WS_TW + 2)
 #define WS_HH (WS_TH + 2)
 
-template <typename T, int KS, int NF, int NW>
-__global__ __launch_bounds__(256 * NW, NW) void upconv_fwd_ws_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
-                                                               const float* __restrict__ bias, T* __restrict__ Y,
-                                                               int F, int Hi, int Wi, int Cout, int act, int ntiles, int ct) {
-  constexpr int CIN = KS * 32;
-  constexpr int LDK = CIN + 16;                    // halo pixel stride (elements): 2 (mod 4) 16-byte slots -> conflict-free b128 fragment reads
-  constexpr int CT = NF * 16;                      // cout tile of this workgroup
-  // 1-D grid of 8 * ct * K workgroups.  The ct cout groups that walk the SAME tile sequence sit on ONE XCD (workgroup id % 8) and share
-  // the halo tiles through that XCD's L2: as a (tile walker, cout group) 2-D grid the three groups of the 128 -> 96 layer landed on three
-  // XCDs and X was fetched 266 MB per launch for a 67 MB input (profiles/r04_h_roofline_traffic.json).
-  const int xcd_ = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
-  const int bx = (slot_ / ct) * 8 + xcd_, by = slot_ % ct, gx_ = gridDim.x / ct;
-  constexpr int LDO = CT + 8;                      // output-stage pixel stride (elements), 16-byte aligned rows
-  constexpr int HPIX = WS_HH * WS_HW;              // 180 halo pixels
-  constexpr int CPP = CIN / 8;                     // 16-byte chunks per halo pixel
-  constexpr int NT = 256 * NW;                     // threads: NW waves per output phase, each owning WS_TH/NW tile rows
-  constexpr int NCH = (HPIX * CPP + NT - 1) / NT;  // chunks per thread
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* halo0 = reinterpret_cast<T*>(smem_raw);
-  T* halo1 = halo0 + HPIX * LDK;
-  T* ostage = halo1 + HPIX * LDK;               // [16][32][LDO]
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int a = (w & 3) >> 1, b = w & 1;           // this wave's output phase
-  const int row0 = (w >> 2) * (WS_TH / NW);        // first tile row of this wave
-  const int g = lane >> 4, ln = lane & 15;
-  const int n0 = by * CT;
-  const int tiles_x = (Wi + WS_TW - 1) / WS_TW, tiles_y = (Hi + WS_TH - 1) / WS_TH;
-  const int Ho = 2 * Hi, Wo = 2 * Wi;
-
-  // ---- stationary weights: wf[tap][n][ks] = Weff[a,b,r,s][n0 + n*16 + ln][ks*32 + g*8 .. +8] ----
-  s16x8 wf[4][NF][KS];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int pt = a * 8 + b * 4 + t;
-#pragma unroll
-    for (int n = 0; n < NF; ++n) {
-      const int co = n0 + n * 16 + ln;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (co < Cout) wf[t][n][ks] = *reinterpret_cast<const s16x8*>(Wf + ((long long)pt * Cout + co) * CIN + ks * 32 + g * 8);
-        else wf[t][n][ks] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      }
-    }
-  }
-  float bv[NF][4];
-#pragma unroll
-  for (int n = 0; n < NF; ++n)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = n0 + n * 16 + g * 4 + r;
-      bv[n][r] = co < Cout ? bias[co] : 0.f;
-    }
-  // weights and bias are complete HERE on every path (see upconv_dgrad_ws_kernel: otherwise every tile's MFMA block opens with a
-  // vmcnt(0) that also waits for the halo prefetch issued just before it)
-  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-
-  auto tile_coords = [&](int tile, int& f, int& ty0, int& tx0) {
-    const int tx = tile % tiles_x; const int t2 = tile / tiles_x;
-    ty0 = (t2 % tiles_y) * WS_TH; f = t2 / tiles_y; tx0 = tx * WS_TW;
-  };
-  uint4 pre[NCH];
-  auto prefetch = [&](int tile) {                  // global -> registers (asynchronous until first use)
-    int f, ty0, tx0;
-    tile_coords(tile, f, ty0, tx0);
-    const T* Xf = X + (long long)f * Hi * Wi * CIN;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int q = tid + i * NT;
-      const int px = q / CPP, ch = (q % CPP) * 8;
-      const int gy = ty0 + px / WS_HW - 1, gx = tx0 + px % WS_HW - 1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (q < HPIX * CPP && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
-        v = *reinterpret_cast<const uint4*>(Xf + ((long long)gy * Wi + gx) * CIN + ch);
-      pre[i] = v;
-    }
-  };
-  auto commit = [&](T* halo) {                  // registers -> LDS
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int q = tid + i * NT;
-      if (q < HPIX * CPP) *reinterpret_cast<uint4*>(halo + (q / CPP) * LDK + (q % CPP) * 8) = pre[i];
-    }
-  };
-
-  int tile = bx;
-  if (tile < ntiles) { prefetch(tile); commit(halo0); }
-  __syncthreads();
-  int buf = 0;
-  for (; tile < ntiles; tile += gx_) {
-    const T* halo = buf ? halo1 : halo0;
-    const int next = tile + gx_;
-    if (next < ntiles) prefetch(next);
-    int f, ty0, tx0;
-    tile_coords(tile, f, ty0, tx0);
-
-    // ---- MFMA main loop: two tile rows at a time ----
-    // (Round 6: the wave's four tile rows as ONE block with every halo row read once for the two tap rows it feeds -- 40 instead of 64
-    //  ds_read_b128 per wave and tile for the same 128 MFMAs, as upconv_fwd_ws2_kernel does -- measured 147 / 141 us against 144 / 147 alone
-    //  and +0.2 / +0.2 / 0.0 % on the train step: the kernel is not bound by its fragment reads.  profiles/r06_y_ws_rowreuse.txt.  The
-    //  halo-row-major order with a 2 / 4 / 6 / 8 deep fragment ring that upconv_fwd_ws2_kernel gained 7 % from: 158 / 153 / 154 / 158 us
-    //  against 156 here, profiles/r06_z5_ws_rowmajor.txt -- this kernel's waves also prefetch, commit and store, and wait there.)
-#pragma unroll NW == 1 ? 4 : 1
-    for (int mf = row0; mf < row0 + WS_TH / NW; mf += 2) {
-      // the accumulators start at the bias (the MFMA's C operand: no add in the epilogue)
-      f32x4 acc[2][NF];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NF; ++n) acc[m][n] = (f32x4){bv[n][0], bv[n][1], bv[n][2], bv[n][3]};
-      // fragment pairs read one (r, s, ks) group AHEAD of their MFMAs (read-then-use compiled to ds_read x 2, s_waitcnt lgkmcnt(0), 4 MFMAs,
-      // 16 times per block: see upconv_fwd_ws2_kernel)
-      {
-        constexpr int NG = 4 * KS;
-        auto frag = [&](const int gi, const int m) -> s16x8 {
-          const int r = gi / (2 * KS), s = (gi / KS) & 1, ks = gi % KS;
-          return *reinterpret_cast<const s16x8*>(halo + ((mf + m + a + r) * WS_HW + ln + b + s) * LDK + ks * 32 + g * 8);
-        };
-        s16x8 xr[2][2];
-        xr[0][0] = frag(0, 0); xr[0][1] = frag(0, 1);
-#pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
-          if (gi + 1 < NG) { xr[(gi + 1) & 1][0] = frag(gi + 1, 0); xr[(gi + 1) & 1][1] = frag(gi + 1, 1); }
-          const int r = gi / (2 * KS), s = (gi / KS) & 1, ks = gi % KS;
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < NF; ++n)
-              acc[m][n] = Mma<T>::mma(wf[r * 2 + s][n][ks], xr[gi & 1][m], acc[m][n]);
-        }
-      }
-      // epilogue into the LDS stage: lane holds couts g*4..g*4+3 of pixel (2(mf+m)+a, 2 ln + b)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NF; ++n) {
-          // ELU only (the launcher routes other activations to the generic kernel): 6 VALU ops per value, no branches --
-          // the runtime-selected activation cost ~7000 instructions per tile, more than the 288 MFMAs
-          const uint32_t p0 = pack2<T>(elu_c(acc[m][n][0]), elu_c(acc[m][n][1]));
-          const uint32_t p1 = pack2<T>(elu_c(acc[m][n][2]), elu_c(acc[m][n][3]));
-          *reinterpret_cast<uint2*>(ostage + ((2 * (mf + m) + a) * (2 * WS_TW) + 2 * ln + b) * LDO + n * 16 + g * 4) = make_uint2(p0, p1);
-        }
-    }
-    if (next < ntiles) commit(buf ? halo0 : halo1);
-    __syncthreads();
-    // ---- coalesced store of the 16 x 32 x CT output tile (8-byte segments) ----
-    {
-      constexpr int SEG = CT / 8;                  // 16-byte segments per pixel
-      T* Yf = Y + (long long)f * Ho * Wo * Cout;
-      for (int q = tid; q < 2 * WS_TH * 2 * WS_TW * SEG; q += NT) {
-        const int sg = q % SEG, p = q / SEG;
-        const int hr = p / (2 * WS_TW), hc = p % (2 * WS_TW);
-        const int oy = 2 * ty0 + hr, ox = 2 * tx0 + hc, co = n0 + sg * 8;
-        if (oy < Ho && ox < Wo && co < Cout)         // Cout % 8 == 0 (dispatch)
-          *reinterpret_cast<uint4*>(Yf + ((long long)oy * Wo + ox) * Cout + co) = *reinterpret_cast<const uint4*>(ostage + p * LDO + sg * 8);
-      }
-    }
-    __syncthreads();
-    buf ^= 1;
-  }
-}
-
-template <typename T, int KS, int NF, int NW>
-static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cout, int act, hipStream_t st) {
-  constexpr int CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 8;
-  const size_t lds = (size_t)(2 * WS_HH * WS_HW * LDK + 2 * WS_TH * 2 * WS_TW * LDO) * 2;
-  static PerDevice<bool> attr_set;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)upconv_fwd_ws_kernel<T, KS, NF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-    attr_set = true;
-  }
-  const int ntiles = ((Wi + WS_TW - 1) / WS_TW) * ((Hi + WS_TH - 1) / WS_TH) * F;
-  const int ct = (Cout + CT - 1) / CT;
-  // tile walkers: a multiple of 8 (see the kernel's workgroup map), and no more workgroups than CUs: the tiles are dealt out statically, so two
-  // workgroups sharing a CU set the launch's time (88 walkers x 3 groups = 264 workgroups: 224 us; 85 x 3 on three XCDs each: 141 us)
-  int nblk = 256 / ct / 8 * 8;
-  if (nblk < 8) nblk = 8;
-  while (nblk > 8 && nblk - 8 >= ntiles) nblk -= 8;
-  hipLaunchKernelGGL((upconv_fwd_ws_kernel<T, KS, NF, NW>), dim3(nblk * ct), dim3(256 * NW), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y,
-                     F, Hi, Wi, Cout, act, ntiles, ct);
-  return true;
-}
-
 // =====================================================================================================
-// Wave-specialised variant of the forward kernel (round 2).  rocprof PMC on the kernel above: MFMA busy 22 %, HBM 27 %, one wave
+// Wave-specialised forward kernel (round 2).  The first weight-stationary kernel (`upconv_fwd_ws_kernel`: every wave prefetched, ran its MFMAs, applied
+// the ELU, committed the next halo and stored; removed in round 6, see upconv_fwd_ws_try_t) measured by rocprof PMC: MFMA busy 22 %, HBM 27 %, one wave
 // per SIMD -- the phases of a tile (prefetch issue, MFMA + LDS fragment reads, ELU epilogue, LDS commit of the next halo, barrier,
 // coalesced store loop, barrier) add up serially inside each wave because nothing else is resident on the SIMD to overlap them.
 // Here a workgroup has EIGHT waves with two roles:
@@ -230,11 +51,12 @@ static bool ws_launch(const void* X, const void* Wf, const float* bias, void* Y,
 // if the head weights (A operand, rows = (tap, o)) are laid out with the same k order -- the contraction order is free -- so z costs 4 more
 // MFMAs per 16 pixels and no data movement.  Y is then the z tensor [F, 2 Hi, 2 Wi, 24] (18 + 6 zero channels: whole 16-byte pieces), which
 // stj_outconv_pair_gather sums over the 9 neighbours: 48 + 48 bytes per pixel of traffic instead of 96 + 96.
-template <typename T, int KS, int NF, bool EXACT, bool HEAD = false>
+template <typename T, int KS, int NF, bool EXACT, bool HEAD = false, int XCT = 0>
 __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
                                                              const float* __restrict__ bias, T* __restrict__ Y,
                                                              int F, int Hi, int Wi, int Cout_, int ntiles, int dbg, const float* __restrict__ Wh) {
   constexpr int CIN = KS * 32;
+  constexpr bool XMAP = XCT > 1;
   constexpr int LDK = CIN + 16;
   constexpr int CT = NF * 16;
   constexpr int CTO = HEAD ? 24 : CT;                    // channels of a stage pixel / of the result
@@ -257,7 +79,13 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
   const bool mover = w >= 4;
   const int mt = tid - 256;                              // mover thread index 0..255
   const int g = lane >> 4, ln = lane & 15;
-  const int n0 = blockIdx.y * CT;
+  // Workgroup map: 1-D grid of (walkers x cout groups).  With several cout groups (the 128 -> 96 layer: 3) the groups that walk the SAME
+  // tile sequence sit on ONE XCD (workgroup id % 8) and share the halo tiles through that XCD's L2: as a (walker, group) 2-D grid they
+  // landed on three XCDs and X was fetched 266 MB per launch for a 67 MB input (profiles/r04_h_roofline_traffic.json, the one-role kernel).
+  const int BX = XMAP ? ((int)(blockIdx.x >> 3) / XCT) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;
+  const int BY = XMAP ? (int)(blockIdx.x >> 3) % XCT : (int)blockIdx.y;
+  const int GX = XMAP ? (int)gridDim.x / XCT : (int)gridDim.x;
+  const int n0 = BY * CT;
   const int tiles_x = (Wi + WS_TW - 1) / WS_TW, tiles_y = (Hi + WS_TH - 1) / WS_TH;
   const int Ho = 2 * Hi, Wo = 2 * Wi;
   auto tile_coords = [&](int tile, int& f, int& ty0, int& tx0) {
@@ -319,8 +147,8 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
     }
     __syncthreads();                                     // halo of the first tile committed by the movers
     int q = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      const T* halo = ((tile - blockIdx.x) / gridDim.x) & 1 ? halo1 : halo0;
+    for (int tile = BX; tile < ntiles; tile += GX) {
+      const T* halo = ((tile - BX) / GX) & 1 ? halo1 : halo0;
 #pragma unroll 1
       for (int st = 0; st < STEPS; ++st, ++q) {
         const int mf = SR * st;
@@ -378,7 +206,7 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
           }
         };
         {
-          constexpr int PF = WS2_PF, NG = 2 * KS * (SR + 1);
+          constexpr int PF = KS == 4 ? WS2_PF_K4 : WS2_PF, NG = 2 * KS * (SR + 1);
           auto frag = [&](const int gi) -> s16x8 {
             const int hr = gi / (2 * KS), s2 = (gi / KS) & 1, ks = gi % KS;
             return *reinterpret_cast<const s16x8*>(halo + ((mf + hr + a) * WS_HW + ln + b + s2) * LDK + ks * 32 + g * 8);
@@ -461,21 +289,21 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
         *reinterpret_cast<uint4*>(Yf + ((p / (2 * WS_TW)) * Wo + p % (2 * WS_TW)) * Cres + sg * 8) = *reinterpret_cast<const uint4*>(ost + p * LDO + sg * 8);
       }
     };
-    int tile = blockIdx.x;
+    int tile = BX;
     prefetch(tile); commit(halo0);
     __syncthreads();
     int lt = 0, f, ty0, tx0, pf, pty, ptx;
     // first tile: no previous stage at its first step
     tile_coords(tile, f, ty0, tx0);
-    prefetch(tile + gridDim.x);                           // loads fly for the whole tile
+    prefetch(tile + GX);                           // loads fly for the whole tile
     __syncthreads();
     drain(ost0, f, ty0, tx0, 0);
     commit(halo1);
     pf = f; pty = ty0; ptx = tx0; lt = 1;
     __syncthreads();
-    for (tile += gridDim.x; tile < ntiles; tile += gridDim.x, ++lt) {
+    for (tile += GX; tile < ntiles; tile += GX, ++lt) {
       tile_coords(tile, f, ty0, tx0);
-      prefetch(tile + gridDim.x);
+      prefetch(tile + GX);
       drain(ost0 + OST, pf, pty, ptx, 1);                 // stage of the previous tile's second step (odd q)
       __syncthreads();
       drain(ost0, f, ty0, tx0, 0);
@@ -521,14 +349,14 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
           *reinterpret_cast<uint4*>(Yf + ((long long)oy * Wo + ox) * Cout + co) = *reinterpret_cast<const uint4*>(ost + p * LDO + sg * 8);
       }
     };
-    int tile = blockIdx.x;
+    int tile = BX;
     if (tile < ntiles) { prefetch(tile); commit(halo0); }
     __syncthreads();
     int q = 0, pf = 0, pty = 0, ptx = 0, pst = 0;       // coordinates of the step whose stage is drained next
     bool have = false;
-    for (; tile < ntiles; tile += gridDim.x) {
-      const int nbuf = (((tile - blockIdx.x) / gridDim.x) & 1) ^ 1;
-      const int next = tile + gridDim.x;
+    for (; tile < ntiles; tile += GX) {
+      const int nbuf = (((tile - BX) / GX) & 1) ^ 1;
+      const int next = tile + GX;
       int f, ty0, tx0;
       tile_coords(tile, f, ty0, tx0);
 #pragma unroll 1
@@ -560,6 +388,21 @@ static bool ws2_launch_t(const void* X, const void* Wf, const float* bias, void*
   if (nblk > ntiles) nblk = ntiles;
   if (nblk < 1) nblk = 1;
   const int dbg = 0;      // (role-ablation mask of the kernel; profiling builds only)
+  if constexpr (NF == 2) {
+    // three cout groups of 32 (the 128 -> 96 layer): 1-D grid, the groups of a walker on one XCD (XCT = 3); walkers a multiple of 8
+    if (ct == 3 && ntiles >= 8) {
+      static PerDevice<bool> attr3;
+      if (!attr3) {
+        if (hipFuncSetAttribute((const void*)upconv_fwd_ws2_kernel<T, KS, NF, EXACT, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        attr3 = true;
+      }
+      int nw = 256 / 3 / 8 * 8;                        // 80 walkers x 3 groups = 240 workgroups
+      while (nw > 8 && nw - 8 >= ntiles) nw -= 8;
+      hipLaunchKernelGGL((upconv_fwd_ws2_kernel<T, KS, NF, EXACT, false, 3>), dim3(nw * 3), dim3(512), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y, F, Hi, Wi, Cout,
+                         ntiles, dbg, (const float*)nullptr);
+      return true;
+    }
+  }
   hipLaunchKernelGGL((upconv_fwd_ws2_kernel<T, KS, NF, EXACT>), dim3(nblk, ct), dim3(512), lds, st, (const T*)X, (const T*)Wf, bias, (T*)Y, F, Hi, Wi, Cout, ntiles, dbg,
                      (const float*)nullptr);
   return true;
@@ -596,10 +439,15 @@ template <typename T>
 static bool upconv_fwd_ws_try_t(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,
                        hipStream_t st) {
   if (Cout % 8 || act != ACT_ELU) return false;
-  // Cin = 96: the wave-specialised kernel (compute + mover waves).  Cin = 128: one role, two workgroups per CU (the wave-specialised
-  // form measured 139 vs 142 us there; the single-workgroup variants 386 vs 432 us: superseded, removed)
+  // Cin = 96 and, since round 6, Cin = 128: the wave-specialised kernel (compute + mover waves).  In round 2 the 128 -> 96 layer measured
+  // 139 (wave-specialised) vs 142 us (one role, eight waves that each prefetch, compute, commit and store) and kept the one-role kernel;
+  // with the halo-row-major fragment order and the 6-deep ring the wave-specialised form runs it in 126-132 us against 147-153
+  // (profiles/r06_z6_ws2_for_128.txt; ring 4 / 8 / 10 deep: 135 / 128 / 127), inference +0.5-1.2 % in alternating same-box runs
+  // (profiles/r06_z7_ws2_for_128_step.txt).  The one-role kernel is gone with it; what was tried on it in round 6 and bought nothing:
+  // every halo row read once (40 instead of 64 fragment reads per tile: 147 / 141 vs 144 / 147 us), the row-major order with a 2-8 deep
+  // ring (153-158 vs 156): its waves waited in their prefetch / commit / store phases, not on fragments (profiles/r06_y_*, r06_z5_*).
   if (Cin == 96) return ws2_launch<T, 3, 3>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
-  if (Cin == 128) return ws_launch<T, 4, 2, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, act, st);
+  if (Cin == 128) return ws2_launch<T, 4, 2>(X, Wf, bias, Y, F, Hi, Wi, Cout, st);
   return false;
 }
 bool upconv_fwd_ws_try(const void* X, const void* Wf, const float* bias, void* Y, int F, int Hi, int Wi, int Cin, int Cout, int act,

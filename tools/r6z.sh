@@ -21,4 +21,4 @@ for i in 1 2 3; do
   STJ_LIB_PATH=$V python bench.py $B --steps 200 --warmup 10 2>/dev/null | line "train variant"
   python bench.py $B --steps 200 --warmup 10 2>/dev/null | line "train base"
 done
-} 2>&1 | tee gpurun_out/r06_z4_rowmajor_both.txt
+} 2>&1 | tee gpurun_out/r06_z7_ws2_for_128_step.txt
