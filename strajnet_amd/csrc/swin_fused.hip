@@ -949,6 +949,10 @@ static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
   const bool two = a.M >= 256 * 128;
   switch (C) {
     case 96:         // 128-row blocks of eight waves (f32: of four waves with two row fragments each) | 64-row blocks of four
+      // (Round 6, at >= 131072 rows -- cfg-512's stage 0, the B = 32 inference forward: 4 rounds of 128-row workgroups --: two / four 16-row
+      //  fragments per wave, i.e. the staged weight chunks and their fragment reads serving 2 / 4 x the rows in 2 / 1 rounds (forward 158 / 250
+      //  registers; backward 242, four fragments spill): cfg-512 776 / 778 against 779 scenes/s, inference inside its noise
+      //  (profiles/r06_zb_mlp96_rf.txt): the kernel's time is its per-row-fragment latency chain, not staging or rounds.  Not kept.)
       if constexpr (sizeof(T) == 2) return two ? mlp_launch<T, 96, 1, 0, 8>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
       else return two ? mlp_launch<T, 96, 2>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
     case 192: {
