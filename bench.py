@@ -489,10 +489,17 @@ def main():
 
         def step():
             model.zero_grad()
+            tw = warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow'])
+            unit = getattr(loss_fn, 'unit_grad', None)       # announced by GraphedTrainStep: the eager passes (per-kernel timing) then run the
+            if unit is not None:                             # same one-pass loss the replayed step does
+                loss_fn.prepare(tw)
             out = model(x['ogm'], x['map_img'], training=True, obs=x['obs'], occ=x['occ'], mapt=x['mapt'], flow=x['flow'])
-            d = loss_fn(get_pred_waypoint_logits(out), warpped_gt(x['gt_obs'], x['gt_occ'], x['gt_flow'], x['origin_flow']), None)
+            d = loss_fn(get_pred_waypoint_logits(out), tw, None)
             total = d.total                      # observed_xe + occluded_xe + flow + flow_warp_xe (train.py:221)
-            total.backward()
+            if unit is not None:
+                total.backward(unit)
+            else:
+                total.backward()
             if overlap:
                 sync.tail()
                 model.backward_encoder()

@@ -161,7 +161,7 @@ def _elem(fam, n_idx, dt_idx, tensors, f32=False):
 
 def _loss(fam, tens):
     def f(a):
-        B, H, W = (a[9], a[10], a[11]) if fam == 'loss_fwd' else (a[8], a[9], a[10])
+        B, H, W = (a[9], a[10], a[11]) if fam == 'loss_fwd' else ((a[11], a[12], a[13]) if fam == 'loss_fwd_bwd' else (a[8], a[9], a[10]))
         by = 4.0 * B * H * W * (32 * tens + 8 * 5)
         return f'{fam}[B{B} {H}x{W}]', fam, 0.0, 0.0, by
     return f
@@ -194,7 +194,7 @@ MODELS = {
     'stj_win_attn_fwd': _win('fwd'), 'stj_win_attn_bwd': _win('bwd'),
     'stj_unary_fwd': _elem('unary_fwd', 2, 5, 2), 'stj_unary_bwd': _elem('unary_bwd', 3, 6, 3),
     'stj_dropout': _elem('dropout', 3, 8, 2),
-    'stj_loss_fwd': _loss('loss_fwd', 1), 'stj_loss_bwd': _loss('loss_bwd', 2),
+    'stj_loss_fwd': _loss('loss_fwd', 1), 'stj_loss_bwd': _loss('loss_bwd', 2), 'stj_loss_fwd_bwd': _loss('loss_fwd_bwd', 2),
     'stj_nadam_step': _elem('nadam', 4, 0, 7, f32=True),
 }
 EXTRA_MODELS = {}        # fused kernels register their models here (ops.py)
