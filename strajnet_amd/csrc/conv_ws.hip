@@ -1108,6 +1108,7 @@ bool outconv_pair_fwd_try(const void* X0, const void* X1, const float* W0, const
   if (C != 48 || Tn != 8 || Hh % OCM_T || Ww % OCM_T || (((uintptr_t)Y) & 15)) return false;
   const int nsp = B * (Hh / OCM_T) * (Ww / OCM_T);
   // OCP_MINB resident workgroups per CU; an equal number of spatial tiles for (nearly) every workgroup
+  // (one / two spatial tiles per workgroup instead of four, i.e. 2048 / 1024 shorter-lived workgroups: 187-193 / 172-179 us against 172-175 in a hot loop)
   const int per = (nsp + 256 * OCP_MINB - 1) / (256 * OCP_MINB);
   const int nb = (nsp + per - 1) / per;
   if (dtype == STJ_F16)

@@ -41,3 +41,9 @@ run('outconv_fwd', lambda: call('stj_outconv_fwd', _p(x), _p(w), _p(b), _p(y), F
 for e in (0, 1):
     run(f'outconv_bwd e{e}', lambda: call('stj_outconv_bwd', _p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), F, H, H, C, Tn, ybs, yts, yps, e, _p(ws), ws.numel(), 1, _st()),
         x.numel() * 4 + F * H * H * 8)
+# both heads in one launch (the training forward's stj_outconv_pair_fwd): two branch tensors in, whole 128-byte output lines out
+x2 = torch.randn(F, H, H, C, device='cuda').bfloat16()
+w2 = torch.randn(3, 3, C, 2, device='cuda') * 0.1
+yp = torch.zeros(B, H, H, 4 * Tn, device='cuda')
+run('pair_fwd', lambda: call('stj_outconv_pair_fwd', _p(x), _p(x2), _p(w), _p(w2), _p(b), _p(b), _p(yp), B, Tn, H, H, C, 1, 1, _st()),
+    2 * x.numel() * 2 + yp.numel() * 4)
