@@ -1658,9 +1658,9 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
     for (int hh = 0; hh < HG; ++hh) {
       const int h = h0 + hh, hd = hl + hh;             // head; its index among the da[] fragments
       if (hh > 0) __syncthreads();                    // previous head's P / dS / dO / table readers are done
-#ifndef STJ_ATTNB_TBV
+      // (reading tbv in place -- no copy, one barrier per head less: 1400 / 1398 / 1401 against 1399 / 1402 / 1399 scenes/s, cfg-512 780.8 / 780.2
+      //  against 779.8 / 779.7: nothing, profiles/r06_zd_attnb_tbv.txt)
       for (int q = tid; q < 225; q += 256) tbl[q] = tbv[hd * 225 + q];
-#endif
       {   // dO of this head (this wave's 16 queries) -> LDS, token-major
 #pragma unroll
         for (int jd = 0; jd < 2; ++jd) {
@@ -1669,9 +1669,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
           st4(dOt + qi * G::LDO + 16 * jd + 4 * g, v);
         }
       }
-#ifndef STJ_ATTNB_TBV
       __syncthreads();                                // table staged
-#endif
       // S^T = K Q^T, P^T = softmax over keys (as in the forward kernel)
       f32x4 st[4], dpt[4];
 #pragma unroll
@@ -1687,11 +1685,7 @@ __global__ __launch_bounds__(256, STJ_ATTNB_MINB) void swin_attn_bwd_kernel(Attn
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = 16 * j + 4 * g + r;
-#ifdef STJ_ATTNB_TBV
-          float v = st[j][r] * scale + tbv[hd * 225 + ((qi >> 3) - (key >> 3) + 7) * 15 + ((qi & 7) - (key & 7) + 7)];
-#else
           float v = st[j][r] * scale + tbl[((qi >> 3) - (key >> 3) + 7) * 15 + ((qi & 7) - (key & 7) + 7)];
-#endif
           if (p.shift > 0 && lab[key] != mylab) v += -100.0f;
           st[j][r] = v;
           m = fmaxf(m, v);
