@@ -2602,11 +2602,11 @@ class _OgmFlowLoss(torch.autograd.Function):
         parts = (g0, g1, g2, g3)
         if all(g is None for g in parts) and gt is None:
             return (None,) * 14
-        if ctx.unit_grad is not None and all(g is None for g in parts) and gt.data_ptr() == ctx.unit_grad.data_ptr():
+        if ctx.unit_grad is not None and ctx.dlogits is not None and all(g is None for g in parts) and gt.data_ptr() == ctx.unit_grad.data_ptr():
             LOSS_FUSED_STATS['hits'] += 1          # the announced unit gradient: d/dlogits was written by the forward pass
             dl, ctx.dlogits = ctx.dlogits, None
             return (dl,) + (None,) * 13
-        if ctx.unit_grad is not None:
+        if ctx.unit_grad is not None:              # (also a second backward through a retained graph: the stored gradient was handed over once)
             LOSS_FUSED_STATS['misses'] += 1        # some other upstream gradient: the general kernel (the forward's d/dlogits is dropped)
             ctx.dlogits = None
             if ctx.fin_stream is not None:         # (its coefficients come from the finalize launch)

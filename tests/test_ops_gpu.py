@@ -874,10 +874,17 @@ def test_loss_forward_writes_the_gradient_for_an_announced_unit_upstream():
             (3.0 * fn(get_pred_waypoint_logits(lt), tw, None).total).backward()
             assert ops.LOSS_FUSED_STATS['misses'] == miss + 1
             assert rel_err(lt.grad, 3.0 * g_two) < 1e-6
+            # a second backward through a retained graph: the stored gradient was handed over once, the general kernel answers
+            fn.prepare(tw)
+            lt.grad = None
+            tot = fn(get_pred_waypoint_logits(lt), tw, None).total
+            tot.backward(one, retain_graph=True)
+            tot.backward(one)
+            assert rel_err(lt.grad, 2.0 * g_two) < 1e-6
             # no prepare(): the two-pass path, whatever was announced
             lt.grad = None
             fn(get_pred_waypoint_logits(lt), tw, None).total.backward(one)
-            assert ops.LOSS_FUSED_STATS['hits'] == hits + 1 and rel_err(lt.grad, g_two) < 1e-6
+            assert ops.LOSS_FUSED_STATS['hits'] == hits + 2 and rel_err(lt.grad, g_two) < 1e-6
 
 
 @pytest.mark.parametrize('dt', DTYPES)
