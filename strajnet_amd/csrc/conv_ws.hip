@@ -720,7 +720,9 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_tr4_kernel(const bf16* __
   };
   // (Round 6: a SECOND register set, so that the chunk after next is in flight while this one is computed -- a chunk's loads then have a whole
   //  chunk period to land: 128-pixel chunks spill (588 us); 64-pixel chunks, one k-step unrolled: 334 us against 270 for 64-pixel chunks with one
-  //  set and 240 for this kernel: the staging is not waiting on its prefetch distance.  profiles/r06_zf_tr4_deep_prefetch.txt)
+  //  set and 240 for this kernel: the staging is not waiting on its prefetch distance.  profiles/r06_zf_tr4_deep_prefetch.txt.  The k-steps
+  //  software-pipelined inside the wave -- the next k-step's 18 transpose reads under this one's 18 MFMAs, two fragment sets, 222 registers --:
+  //  242 / 246 / 245 us against 244 / 246 / 242: the SIMD's other wave already covers the reads.  profiles/r06_zg_tr4_swp.txt)
   if (c_begin < c_end) { prefetch(c_begin); commit(0); }
   __syncthreads();
   const int kpx = 4 * g + (p >> 2), kch = 4 * (p & 3);        // pixels 4g + p/4 and 16 + 4g + p/4 of a 32-pixel k-step (see upconv_wgrad_tr_kernel)
