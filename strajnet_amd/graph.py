@@ -80,8 +80,8 @@ class GraphedTrainStep:
         d = self.loss_fn(get_pred_waypoint_logits(out), tw, None)
         total = d.total                      # observed_xe + occluded_xe + flow + flow_warp_xe (train.py:221)
         total.backward(self._one)             # (an explicit tensor: backward()'s implicit ones_like is a fill launch on every replay)
-        if self._side is not None:
-            main.wait_stream(self._side)      # the loss values' finalize launch (issued behind the loss pass on the side stream)
+        if self._side is not None and ops.LOSS_FIN_SIDE:
+            main.wait_stream(self._side)      # the loss values' finalize launch (issued behind the loss pass on the side stream: off, see ops.LOSS_FIN_SIDE)
         self.total = total.detach()           # the sum the finalize kernel wrote (static across replays, like self.losses)
         return d.packed             # [observed_xe, occluded_xe, flow, flow_warp_xe], detached
 
