@@ -18,6 +18,7 @@
 #define PS_TW 16
 #define PS_HW (PS_TW + 2)
 #define PS_KC 32
+#define PS_RES_BATCH 4      // skip-sum items whose operands are in flight together (item by item: 5691 / 5889 / 5678 against 5729 / 5912 / 5711 scenes/s, B = 32 inference; 8: 5788 / 5731 / 5716; profiles/r06_zi_ps_res_batch.txt)
 
 // TH = rows of the low-res tile.  16 (round 6): the workgroup's weight stream -- every workgroup reads all 16 tap matrices of its cout block,
 // 393 KB at Cin = 384, and with 8-row tiles that was 302 of the 400 MB the 384 -> 192 launch pulls out of L2, the level this kernel saturates
@@ -149,33 +150,54 @@ __global__ __launch_bounds__(256, MINB) void upconv_fwd_ps_kernel(const T* __res
     constexpr int SEG = CT / 8;
     const int Ho = 2 * Hi, Wo = 2 * Wi;
     T* Yf = Y + (long long)f * Ho * Wo * Cout;
-    for (int q = tid; q < 2 * 8 * 2 * PS_TW * SEG; q += 256) {
-      const int sg = q % SEG, p = q / SEG;
-      const int oy = 2 * (ty0 + hj) + p / (2 * PS_TW), ox = 2 * tx0 + p % (2 * PS_TW), co = n0 + sg * 8;
-      if (oy < Ho && ox < Wo && co < Cout) {
-        const long long o = ((long long)oy * Wo + ox) * Cout + co;
-        if (R1 == nullptr) {
-          *reinterpret_cast<uint4*>(Yf + o) = *reinterpret_cast<const uint4*>(ostage + p * LDO + sg * 8);
-        } else {
-          // decoder skips (reference modules.py:750-765): Y = ELU(conv) + R1 and, optionally, Y2 = Y + R2 -- each sum rounded to the
-          // storage type exactly as a separate elementwise add of the stored tensors would round it
-          const long long fo = (long long)f * Ho * Wo * Cout + o;
+    constexpr int NIT = 2 * 8 * 2 * PS_TW * SEG / 256;          // 16-byte items per thread and half (8 at FN = 2)
+    if (R1 != nullptr) {
+      // decoder skips (reference modules.py:750-765): Y = ELU(conv) + R1 and, optionally, Y2 = Y + R2 -- each sum rounded to the storage type
+      // exactly as a separate elementwise add of the stored tensors would round it.  The skip operands of PS_RES_BATCH items at a time are
+      // fetched before any of them is used: item by item every item was two dependent memory round trips (R1 -> store Y -> R2 -> store Y2) on
+      // a workgroup that has nothing else left to do
+      static_assert(NIT % PS_RES_BATCH == 0, "whole batches");
+#pragma unroll 1
+      for (int q0 = tid; q0 < 256 * NIT; q0 += 256 * PS_RES_BATCH) {
+        uint4 r1v[PS_RES_BATCH], r2v[PS_RES_BATCH];
+        long long fo[PS_RES_BATCH];
+        bool ok[PS_RES_BATCH];
+#pragma unroll
+        for (int k = 0; k < PS_RES_BATCH; ++k) {
+          const int q = q0 + 256 * k, sg = q % SEG, p = q / SEG;
+          const int oy = 2 * (ty0 + hj) + p / (2 * PS_TW), ox = 2 * tx0 + p % (2 * PS_TW), co = n0 + sg * 8;
+          ok[k] = oy < Ho && ox < Wo && co < Cout;
+          fo[k] = ok[k] ? (long long)f * Ho * Wo * Cout + ((long long)oy * Wo + ox) * Cout + co : 0;
+          r1v[k] = *reinterpret_cast<const uint4*>(R1 + fo[k]);
+          r2v[k] = R2 != nullptr ? *reinterpret_cast<const uint4*>(R2 + fo[k]) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < PS_RES_BATCH; ++k) {
+          const int q = q0 + 256 * k, sg = q % SEG, p = q / SEG;
+          if (!ok[k]) continue;
           float u[8], r[8];
           ld16<T>(ostage + p * LDO + sg * 8, u);
-          ld16<T>(R1 + fo, r);
+          ld16<T>(reinterpret_cast<const T*>(&r1v[k]), r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) u[e] += r[e];
           __attribute__((aligned(16))) T rounded[8];
           st16<T>(rounded, u);
-          *reinterpret_cast<uint4*>(Yf + o) = *reinterpret_cast<const uint4*>(rounded);
+          *reinterpret_cast<uint4*>(Y + fo[k]) = *reinterpret_cast<const uint4*>(rounded);
           if (Y2 != nullptr) {
             ld16<T>(rounded, u);                   // the rounded sum, as a separate add would read it back
-            ld16<T>(R2 + fo, r);
+            ld16<T>(reinterpret_cast<const T*>(&r2v[k]), r);
 #pragma unroll
             for (int e = 0; e < 8; ++e) u[e] += r[e];
-            st16<T>(Y2 + fo, u);
+            st16<T>(Y2 + fo[k], u);
           }
         }
+      }
+    } else {
+      for (int q = tid; q < 2 * 8 * 2 * PS_TW * SEG; q += 256) {
+        const int sg = q % SEG, p = q / SEG;
+        const int oy = 2 * (ty0 + hj) + p / (2 * PS_TW), ox = 2 * tx0 + p % (2 * PS_TW), co = n0 + sg * 8;
+        if (oy < Ho && ox < Wo && co < Cout)
+          *reinterpret_cast<uint4*>(Yf + ((long long)oy * Wo + ox) * Cout + co) = *reinterpret_cast<const uint4*>(ostage + p * LDO + sg * 8);
       }
     }
   }
