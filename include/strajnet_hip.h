@@ -393,7 +393,7 @@ int stj_outconv_pair_fwd(const void* X0, const void* X1, const float* W0, const 
 /* Inference form of the last decoder level + both heads (modules.py:746-748 at 96 -> 48, then :767-770,838) without the [F,H,W,48]
  * tensor between them: out[p][o] = sum_taps z[p + tap][tap, o] with z[q][tap, o] = sum_c Whead[tap][c][o] ELU(upconv)[q][c].
  * stj_upconv_fwd_head: the up-conv of stj_upconv_fwd (same X, Wf, bias) whose epilogue projects every output pixel onto the head kernel
- * Whead f32 [3,3,48,2] and writes Z [F,2Hi,2Wi,24] (18 + 6 zero channels) in the activation dtype; stj_outconv_pair_gather: Y [B,H,W,32]
+ * Whead f32 [3,3,48,2] and writes Z [F,2Hi,2Wi,20] (18 + 2 zero channels; 24 until round 6) in the activation dtype; stj_outconv_pair_gather: Y [B,H,W,32]
  * f32, channel 4 t + 2 head + o = bias + the 9-neighbour sum of Z0 / Z1 (the two decoder branches; frames as in stj_outconv_pair_fwd).
  * 16-bit dtypes, Cin = 96, Cout = 48, whole 8 x 16 tiles, Tn = 8; STJ_EUNSUPPORTED otherwise. */
 int stj_upconv_fwd_head(const void* X, const void* Wf, const float* bias, const float* Whead, void* Z, int F, int Hi, int Wi, int Cin,

@@ -24,6 +24,7 @@
 #ifndef WS2_PF
 #define WS2_PF 6        // ... upconv_fwd_ws2_kernel (2 / 4 / 6: 209 / 199 / 194 us; 7 spills)
 #endif
+#define HEAD_CZ 20         // channels of the inference heads' projected tensor z: 18 (9 taps x 2 outputs) + 2 zero channels = whole 8-byte pieces (24 until round 6: 17 % more z traffic)
 #define WS_TH 8
 #define WS_TW 16
 #define WS_HW (WS_TW + 2)
@@ -49,7 +50,7 @@
 // projection z[q][tap, o] = sum_c Wh[tap][c][o] y[q][c]: 18 numbers per pixel instead of 48, and no halo -- y never leaves the chip.  The
 // ELU outputs a lane holds after the main MFMAs (D layout: channels 16 n + 4 g + r of ITS pixel) ARE an MFMA B operand for pixel = column
 // if the head weights (A operand, rows = (tap, o)) are laid out with the same k order -- the contraction order is free -- so z costs 4 more
-// MFMAs per 16 pixels and no data movement.  Y is then the z tensor [F, 2 Hi, 2 Wi, 24] (18 + 6 zero channels: whole 16-byte pieces), which
+// MFMAs per 16 pixels and no data movement.  Y is then the z tensor [F, 2 Hi, 2 Wi, HEAD_CZ = 20] (18 + 2 zero channels: whole 8-byte pieces), which
 // stj_outconv_pair_gather sums over the 9 neighbours: 48 + 48 bytes per pixel of traffic instead of 96 + 96.
 template <typename T, int KS, int NF, bool EXACT, bool HEAD = false, int XCT = 0>
 __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restrict__ X, const T* __restrict__ Wf,
@@ -59,10 +60,10 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
   constexpr bool XMAP = XCT > 1;
   constexpr int LDK = CIN + 16;
   constexpr int CT = NF * 16;
-  constexpr int CTO = HEAD ? 24 : CT;                    // channels of a stage pixel / of the result
+  constexpr int CTO = HEAD ? HEAD_CZ : CT;               // channels of a stage pixel / of the result
   constexpr int LDO = HEAD ? 40 : CT + 8;
   const int Cout = HEAD ? CT : Cout_;                    // channels of the convolution itself
-  const int Cres = HEAD ? 24 : Cout_;                    // channels of the tensor the movers write
+  const int Cres = HEAD ? HEAD_CZ : Cout_;               // channels of the tensor the movers write
   static_assert(!HEAD || (NF == 3 && EXACT), "the head epilogue is written for the 48-channel level, whole tiles");
   constexpr int HPIX = WS_HH * WS_HW;
   constexpr int CPP = CIN / 8;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
               f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
               z = Mma<T>::mma(hwr[tf][0], y0, z);
               z = Mma<T>::mma(hwr[tf][1], y1, z);
-              if (tf == 0 || g < 2) *reinterpret_cast<uint2*>(zp + 16 * tf + 4 * g) = make_uint2(pack2<T>(z[0], z[1]), pack2<T>(z[2], z[3]));
+              if (tf == 0 || 16 + 4 * g < HEAD_CZ) *reinterpret_cast<uint2*>(zp + 16 * tf + 4 * g) = make_uint2(pack2<T>(z[0], z[1]), pack2<T>(z[2], z[3]));
             }
           } else {
 #pragma unroll
@@ -278,15 +279,19 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_ws2_kernel(const T* __restr
         *reinterpret_cast<uint4*>(halo + (cgeo[i] & 0xffff) * LDK + (cgeo[i] >> 16) * 8) = v;
       }
     };
-    constexpr int SEG = CTO / 8, NIT = 2 * SR * 2 * WS_TW * SEG;
-    static_assert(NIT % 256 == 0, "whole rounds of 16-byte items per step");
+    constexpr int IE = HEAD ? 4 : 8;                       // elements per drained item: 8-byte pieces of the 40-byte z pixels | 16-byte pieces
+    constexpr int SEG = CTO / IE, NIT = 2 * SR * 2 * WS_TW * SEG;
+    static_assert(NIT % 256 == 0, "whole rounds of items per step");
     auto drain = [&](const T* ost, int f, int ty0, int tx0, int st) {
       T* Yf = Y + (long long)f * Ho * Wo * Cres + ((long long)(2 * ty0 + 2 * SR * st) * Wo + 2 * tx0) * Cres + (HEAD ? 0 : n0);
 #pragma unroll
       for (int i = 0; i < NIT / 256; ++i) {
         const int c = mt + i * 256;
         const int sg = c % SEG, p = c / SEG;
-        *reinterpret_cast<uint4*>(Yf + ((p / (2 * WS_TW)) * Wo + p % (2 * WS_TW)) * Cres + sg * 8) = *reinterpret_cast<const uint4*>(ost + p * LDO + sg * 8);
+        if constexpr (HEAD)
+          *reinterpret_cast<uint2*>(Yf + ((p / (2 * WS_TW)) * Wo + p % (2 * WS_TW)) * Cres + sg * IE) = *reinterpret_cast<const uint2*>(ost + p * LDO + sg * IE);
+        else
+          *reinterpret_cast<uint4*>(Yf + ((p / (2 * WS_TW)) * Wo + p % (2 * WS_TW)) * Cres + sg * 8) = *reinterpret_cast<const uint4*>(ost + p * LDO + sg * 8);
       }
     };
     int tile = BX;
@@ -407,7 +412,7 @@ static bool ws2_launch_t(const void* X, const void* Wf, const float* bias, void*
                      (const float*)nullptr);
   return true;
 }
-// the 96 -> 48 level with the 48 -> 2 head's channel projection in its epilogue: Z [F, 2 Hi, 2 Wi, 24] instead of Y (whole tiles only)
+// the 96 -> 48 level with the 48 -> 2 head's channel projection in its epilogue: Z [F, 2 Hi, 2 Wi, HEAD_CZ] instead of Y (whole tiles only)
 template <typename T>
 static bool ws2_head_launch(const void* X, const void* Wf, const float* bias, const float* Wh, void* Z, int F, int Hi, int Wi, hipStream_t st) {
   constexpr int KS = 3, NF = 3, CIN = KS * 32, LDK = CIN + 16, CT = NF * 16, LDO = CT + 8;
@@ -1125,14 +1130,14 @@ bool outconv_pair_fwd_try(const void* X0, const void* X1, const float* W0, const
 
 // Second half of the inference heads (first half: the HEAD epilogue of upconv_fwd_ws2_kernel): Y[b, y, x, 4 t + 2 h + o] = bias_h[o] +
 // sum over the 9 neighbours (ky, kx) of Z_h[f(b, t), y + ky - 1, x + kx - 1, 2 (3 ky + kx) + o] (zero outside the image), Z_h the projected
-// tensors [F, H, W, 24] of the two decoder branches.  A workgroup owns a 16 x 16 spatial tile of one scene and walks its 16 (waypoint,
+// tensors [F, H, W, HEAD_CZ = 20] of the two decoder branches.  A workgroup owns a 16 x 16 spatial tile of one scene and walks its 16 (waypoint,
 // head) planes through an 18 x 18 halo in LDS (next plane prefetched in registers); a thread keeps the 32 results of its pixel and writes
 // one full 128-byte line.
 template <typename T>
 __global__ __launch_bounds__(256) void outconv_pair_gather_kernel(const T* __restrict__ Z0, const T* __restrict__ Z1, const float* __restrict__ b0,
                                                                   const float* __restrict__ b1, float* __restrict__ Y, int B, int Hh, int Ww,
                                                                   int t_major, int nsp) {
-  constexpr int CZ = 24, LDZ = 24, NPX = OCM_H * OCM_H, NCHK = NPX * 3, NCH = (NCHK + 255) / 256;
+  constexpr int CZ = HEAD_CZ, LDZ = HEAD_CZ, CPP = CZ / 4, NPX = OCM_H * OCM_H, NCHK = NPX * CPP, NCH = (NCHK + 255) / 256;      // 8-byte pieces
   __shared__ __attribute__((aligned(16))) T halo[NPX * LDZ];
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   const int tiles_x = Ww / OCM_T, tiles_y = Hh / OCM_T;
@@ -1140,7 +1145,7 @@ __global__ __launch_bounds__(256) void outconv_pair_gather_kernel(const T* __res
   for (int sp = blockIdx.x; sp < nsp; sp += gridDim.x) {
     const int tcx = sp % tiles_x, t2 = sp / tiles_x, tcy = t2 % tiles_y, b = t2 / tiles_y;
     const int y0 = tcy * OCM_T - 1, x0 = tcx * OCM_T - 1;
-    uint4 pre[NCH];
+    uint2 pre[NCH];
     auto fetch = [&](int plane) {
       const int t = plane >> 1, h = plane & 1;
       const int f = t_major ? t * B + b : b * 8 + t;
@@ -1148,10 +1153,10 @@ __global__ __launch_bounds__(256) void outconv_pair_gather_kernel(const T* __res
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int c = tid + i * 256;
-        const int px = c / 3, cc = c % 3;
+        const int px = c / CPP, cc = c % CPP;
         const int gy = y0 + px / OCM_H, gx = x0 + px % OCM_H;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < NCHK && gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) v = *reinterpret_cast<const uint4*>(Zf + ((long long)gy * Ww + gx) * CZ + cc * 8);
+        uint2 v = make_uint2(0, 0);
+        if (c < NCHK && gy >= 0 && gy < Hh && gx >= 0 && gx < Ww) v = *reinterpret_cast<const uint2*>(Zf + ((long long)gy * Ww + gx) * CZ + cc * 4);
         pre[i] = v;
       }
     };
@@ -1163,7 +1168,7 @@ __global__ __launch_bounds__(256) void outconv_pair_gather_kernel(const T* __res
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int c = tid + i * 256;
-        if (c < NCHK) *reinterpret_cast<uint4*>(halo + (c / 3) * LDZ + (c % 3) * 8) = pre[i];
+        if (c < NCHK) *reinterpret_cast<uint2*>(halo + (c / CPP) * LDZ + (c % CPP) * 4) = pre[i];
       }
       __syncthreads();
       if (plane + 1 < 16) fetch(plane + 1);

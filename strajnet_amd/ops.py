@@ -2521,13 +2521,16 @@ def upconv_head_ok(Hi, Wi, pw, dtype, Tn):
             and Tn == 8 and os.environ.get('STJ_NO_WS') != '1')
 
 
+HEAD_CZ = 20       # channels of the projected tensor z: 9 taps x 2 outputs + 2 zero channels (csrc/conv_ws.hip HEAD_CZ)
+
+
 def upconv_head(x, pw, pb, phead, prep=None):
     """Inference only: ELU(up-conv 96 -> 48) projected onto the 3x3 48 -> 2 head kernel `phead` inside the up-conv's epilogue ->
-    z [F,2Hi,2Wi,24] (stj_upconv_fwd_head); the [F,2Hi,2Wi,48] tensor is never written."""
+    z [F,2Hi,2Wi,HEAD_CZ] (stj_upconv_fwd_head); the [F,2Hi,2Wi,48] tensor is never written."""
     _req_cuda(x)
     F_, Hi, Wi, Cin = x.shape
     wf, _ = prep if prep is not None else upconv_prep(pw, x.dtype)
-    z = torch.empty((F_, 2 * Hi, 2 * Wi, 24), dtype=x.dtype, device=x.device)
+    z = torch.empty((F_, 2 * Hi, 2 * Wi, HEAD_CZ), dtype=x.dtype, device=x.device)
     call('stj_upconv_fwd_head', _p(x.contiguous()), _p(wf), _p(pb.master), _p(phead.master), _p(z), F_, Hi, Wi, Cin, 48, _dt(x), _st())
     return z
 

@@ -70,18 +70,18 @@ def _upconv(kind):
 
 def _upconv_head(a):
     """stj_upconv_fwd_head(x, wf, bias, wh, z, F, Hi, Wi, Cin, Cout, dtype, stream): the 96 -> 48 up-conv whose epilogue projects onto the
-    two heads' 9 taps: reads x and the folded weights, writes z [F,2Hi,2Wi,24]; FLOPs = the up-conv + 18 x 48 MACs per output pixel."""
+    two heads' 9 taps: reads x and the folded weights, writes z [F,2Hi,2Wi,20]; FLOPs = the up-conv + 18 x 48 MACs per output pixel."""
     F, Hi, Wi, Cin, Cout, dt = a[5], a[6], a[7], a[8], a[9], a[10]
     es = _es(dt)
     fl = 2.0 * 9 * Cin * Cout * 4 * Hi * Wi * F + 2.0 * 18 * Cout * 4 * Hi * Wi * F
-    by = es * F * Hi * Wi * (Cin + 4 * 24) + es * 16 * Cin * Cout
+    by = es * F * Hi * Wi * (Cin + 4 * 20) + es * 16 * Cin * Cout
     return f'upconv_fwd_head[{Hi}x{Wi},{Cin}->{Cout}->18,F{F}]', 'upconv_fwd', fl, 2.0 * 4 * Cin * Cout * 4 * Hi * Wi * F + 2.0 * 32 * 64 * 4 * Hi * Wi * F, by
 
 
 def _pair_gather(a):
     """stj_outconv_pair_gather(zo, zf, b0, b1, out, B, Tn, H, W, t_major, dtype, stream): 9-neighbour sums of two z tensors -> [B,H,W,4Tn] f32."""
     B, Tn, H, W, dt = a[5], a[6], a[7], a[8], a[10]
-    return f'outconv_pair_gather[{H}x{W},F{B * Tn}x2]', 'outconv_fwd', 2.0 * 18 * 2 * B * Tn * H * W, 0.0, 2 * _es(dt) * B * Tn * H * W * 24 + 4 * B * H * W * 4 * Tn
+    return f'outconv_pair_gather[{H}x{W},F{B * Tn}x2]', 'outconv_fwd', 2.0 * 18 * 2 * B * Tn * H * W, 0.0, 2 * _es(dt) * B * Tn * H * W * 20 + 4 * B * H * W * 4 * Tn
 
 
 def _upconv_res(a):
