@@ -234,6 +234,10 @@ class STrajNet:
         self.serial = False              # True: everything on the current stream (per-kernel timing, debugging)
         self.taps = None                 # a dict: call() stores detached float copies of the stage boundaries in it (tools/bf16_attribution.py)
         # fused Swin-block kernels (csrc/swin_fused.hip); STJ_FUSED_SWIN=0 selects the layer-by-layer path (the one the f32 mode's C = 384 stage takes)
+        # where the decoder's three skip GEMMs are issued on the side stream: 0 behind the encoder, 1 behind FG-MSA, 2 behind the cross-attention (round 6, the B = 32
+        # inference timeline has `fgattn_fwd` at 290 us beside them against 64 alone: 0 / 1 / 2 = 5803-5962 / 5854-5889 / 5741-5771 scenes/s, training 1407 / 1389-1418 / 1210:
+        # moving them moves the contention, profiles/r06_zk_skips_issue.txt)
+        self.skips_issue = 0
         self.fused_mlp = self.fused_attn = os.environ.get('STJ_FUSED_SWIN', '1') != '0'
         # C = 384 (the 16x16 stage: 2048 rows = 32 row blocks / 32 windows at B = 8) runs the SPLIT variants of the fused kernels --
         # (row block | window) x (slice of the hidden dimension | of the heads) workgroups + a finishing launch.  The f32 parity mode runs the
@@ -974,14 +978,17 @@ class STrajNet:
         # the three time-kernel skips (Conv3D collapsed to per-waypoint 1x1 GEMMs) only need the encoder outputs: side stream,
         # overlapping FG-MSA / the cross-attentions / the first up-convs; joined in the decoder where they are added
         skips = None
-        if self._side2 is not None:
+
+        def issue_skips():
             main2 = torch.cuda.current_stream(self.device)
             self._side2.wait_stream(main2)
             for t in res_list[:3]:
                 t.record_stream(self._side2)
             with torch.cuda.stream(self._side2):
-                skips = (self._resconv(res_list[2], 'decoder/resconv_3'), self._resconv(res_list[1], 'decoder/resconv_2'),
-                         self._resconv(res_list[0], 'decoder/resconv_f'))
+                return (self._resconv(res_list[2], 'decoder/resconv_3'), self._resconv(res_list[1], 'decoder/resconv_2'),
+                        self._resconv(res_list[0], 'decoder/resconv_f'))
+        if self._side2 is not None and self.skips_issue == 0:
+            skips = issue_skips()
         q = ops.wgrad_queue_flush_point(res_list[-1]).reshape(B, hb, hb, Cb)     # backward: FG-MSA / cross-attention / agent branch are through
         # waypoint-major [8,B,HW,Cb] (the reference's [B,8,...] transposed): every per-waypoint product downstream is then a
         # plain batched GEMM and the decoder frames are t-major; the output kernel undoes it when writing [B,H,W,32]
@@ -989,6 +996,8 @@ class STrajNet:
             q, query = self._fgmsa(q)                                              # modules.py:825-831
         else:
             query = q.reshape(1, B, hb * hb, Cb).expand(8, B, hb * hb, Cb).contiguous()   # modules.py:827
+        if self._side2 is not None and self.skips_issue == 1:       # behind FG-MSA: beside the cross-attention
+            skips = issue_skips()
         if main_pos == 5:
             agent.extend(self._traj_net(obs, occ))
         key, tmask = agent
@@ -1009,6 +1018,8 @@ class STrajNet:
         # backward as well -- so that kernel has the GPU to itself -- measured 5 % SLOWER, 7.26 vs 6.88 ms: the 1.5 ms of half-GPU
         # weight-gradient launches then reach into the encoder's backward.)
         x = ops.wgrad_flush_point(x)
+        if self._side2 is not None and self.skips_issue == 2:       # behind the cross-attention: beside the first up-conv
+            skips = issue_skips()
         try:
             out = self._decoder(x, res_list, B, skips)
         finally:
