@@ -391,7 +391,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         fetch(tile_of(nk), nc);                        // in flight during the 128 MFMAs below (past the end: fetched, never used)
         if (t == 0) fetch_w(more ? c0 + KC : 0);       // the NEXT chunk's tap matrices: four steps to arrive
         // one wave per SIMD: nothing else hides the LDS latency, so the fragments of tap q + 1 are read before the MFMAs of tap q
-        // are issued (left to the compiler the reads came two MFMAs ahead, with an lgkmcnt wait in front of every second MFMA)
+        // are issued (left to the compiler the reads came two MFMAs ahead, with an lgkmcnt wait in front of every second MFMA).
+        // (Two / three / four taps ahead, round 6: 68.9 / 70.2 / 71.8 us against 67.6 at 384 -> 192 and 94.5 / 97.0 / 99.7 against 93.6 at
+        //  192 -> 128: one tap ahead is the depth, profiles/r06_zl_pf_depth.txt.)
         typedef typename Mma<T>::Frag Frag;
         Frag af[2][2], bf[2][FN];
         auto load_tap = [&](int q, Frag (&a)[2], Frag (&b)[FN]) {
