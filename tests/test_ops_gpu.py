@@ -472,7 +472,8 @@ def test_fg_offset_head(dt, B, Hh, G, gc, C2):
 
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('F_,Hi,Cin,Cout', [(2, 8, 384, 192), (2, 16, 192, 128), (1, 32, 128, 96), (1, 32, 96, 48), (3, 16, 96, 48),
-                                            (2, 24, 96, 48)])      # 24 x 24: ragged tiles (guarded movers of the 96 <- 48 input gradient)
+                                            (2, 24, 96, 48),       # 24 x 24: ragged tiles (guarded movers of the 96 <- 48 input gradient)
+                                            (2, 24, 128, 96), (1, 8, 128, 96)])    # the wave-specialised forward at 128 -> 96 (round 6): ragged tiles; fewer tiles than one walker set (2-D grid)
 def test_upconv(dt, F_, Hi, Cin, Cout):
     from strajnet_amd import ops
     pw, pb = mk_param((3, 3, Cin, Cout), dt, 0.05, 1), mk_param((Cout,), dt, 0.1, 2)
