@@ -175,7 +175,9 @@ def bench_infer(args, model, x, world, rank, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_s = float(t)
     single = None
-    if gf is not None and pipe:          # the same without the overlap: every step runs its own agent branch in front of the main graph
+    # (not under --no-kernel-timing: that run executes exactly warmup + steps replays, which is what the rocprofv3 summaries divide by and what
+    #  tools/timeline.py takes its step from)
+    if gf is not None and pipe and not args.no_kernel_timing:          # the same without the overlap: every step runs its own agent branch in front of the main graph
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -211,7 +213,7 @@ def bench_infer(args, model, x, world, rank, dist):
                                    f'batch {B}/GPU, fg_msa+fg, random-init weights', 'global_batch': B * world, 'parallelism': f'replicas x{world}',
                        'hipgraph': gf is not None, 'finite': bool(torch.isfinite(out).all()),
                        'agent_pipeline': ('the agent branch of batch i + 1 (taken out of the captured forward, launched on the model\'s agent-branch stream) runs under the raster '
-                                          f'path of batch i; ms_per_step with every batch running its own agent branch first: {single:.3f}') if (gf is not None and pipe) else False},
+                                          'path of batch i' + (f'; ms_per_step with every batch running its own agent branch first: {single:.3f}' if single is not None else '')) if (gf is not None and pipe) else False},
             'roofline': roof, 'families': families}))
     if world > 1:
         dist.destroy_process_group()
