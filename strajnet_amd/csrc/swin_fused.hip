@@ -58,7 +58,7 @@
 #define STJ_ATTN_MINB 1
 #endif
 #ifndef STJ_ATTN_HG96
-#define STJ_ATTN_HG96 1         // heads per pass of the attention kernel at C = 96 (16-bit types); 1: 1059 vs 1052 scenes/s for 3 (less LDS per window)
+#define STJ_ATTN_HG96 1         // heads per pass of the attention kernel at C = 96 (16-bit types); 1: 1059 vs 1052 scenes/s for 3 (less LDS per window); at 131072 rows (round 6): inference 5813-5889 vs 5596-5665, cfg-512 773-774 vs 761 (profiles/r06_zn_attn_hg96.txt)
 #endif
 
 #ifdef STJ_STAMP   // A/B builds only (tools/build_variant.sh): per-workgroup cycle stamps of wave 0 at the kernels' phase boundaries
