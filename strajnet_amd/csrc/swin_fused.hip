@@ -185,7 +185,7 @@ __device__ __forceinline__ bool slice_combine(f32x4* acc, void* slabs, int* coun
 // NW waves per workgroup in HS hidden groups of RG = NW / HS waves: wave (rg, hg) owns 16 RF rows and, of every staged chunk, the k-steps
 // s = hg, hg + HS, ...; the hidden groups' sums meet in LDS behind the chunk loop.  Eight waves = two per SIMD: one wave's GELU / LayerNorm
 // VALU work and LDS-read latencies run under the other's MFMAs (with four waves the chunk loop ran 75 cycles per MFMA: stamps).
-template <typename T, int C, int RF_ = ((C <= 192) ? 2 : 1), int NW_ = 4, int HS_ = 1> struct MlpCfg {
+template <typename T, int C, int RF_ = ((C <= 192) ? 2 : 1), int NW_ = 4, int HS_ = 1, int HCX = 0> struct MlpCfg {
   static constexpr int KSTEP = Mma<T>::KSTEP;
   static constexpr int KS = C / KSTEP;                // k-steps over the model dimension
   static constexpr int NF = C / 16;                   // 16-column fragments of the model dimension
@@ -193,7 +193,7 @@ template <typename T, int C, int RF_ = ((C <= 192) ? 2 : 1), int NW_ = 4, int HS
   static constexpr int NW = NW_, HS = HS_, RG = NW / HS, NT = 64 * NW;
   static constexpr int ROWS = RG * RF * 16;           // rows per block
   // hidden columns per staged chunk: as many as keep the two images under ~78 KB (two blocks per CU); with two hidden groups an even number of k-steps
-  static constexpr int HC = sizeof(T) == 2 ? (C == 96 ? STJ_MLP_HC96 : (C == 192 ? (NW == 8 ? STJ_MLP_HC192S : STJ_MLP_HC192) : (HS == 2 ? 64 : STJ_MLP_HC384)))
+  static constexpr int HC = HCX ? HCX : sizeof(T) == 2 ? (C == 96 ? STJ_MLP_HC96 : (C == 192 ? (NW == 8 ? STJ_MLP_HC192S : STJ_MLP_HC192) : (HS == 2 ? 64 : STJ_MLP_HC384)))
                                            : (C == 96 ? 96 : (C == 192 ? 48 : 16));
   static constexpr int P1 = 4;                        // W1 image [C][HC + P1]: rows 8-byte aligned (tr reads, 8-byte chain reads)
   static constexpr int P2 = sizeof(T) == 2 ? 8 : 4;   // W2 image [HC][C + P2]: rows 16-byte aligned (16-byte fragment reads in backward)
@@ -344,9 +344,9 @@ template <typename T> __device__ __forceinline__ void raw4_unpack(const typename
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <typename T, int C, int RFP, int SPLIT = 0, int NW = 4, int HS = 1>
+template <typename T, int C, int RFP, int SPLIT = 0, int NW = 4, int HS = 1, int HCX = 0>
 __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(MlpArgs p) {
-  typedef MlpCfg<T, C, RFP, NW, HS> G;
+  typedef MlpCfg<T, C, RFP, NW, HS, HCX> G;
   constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];
   T* W1s = reinterpret_cast<T*>(mlp_smem);
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_fwd_kernel(Mlp
 // =====================================================================================================================
 // backward
 // =====================================================================================================================
-template <typename T, int C, int RFP, int SPLIT = 0, int NW = 4, int HS = 1>
+template <typename T, int C, int RFP, int SPLIT = 0, int NW = 4, int HS = 1, int HCX = 0>
 __global__ __launch_bounds__(64 * NW, STJ_MLP_MINB) void swin_mlp_bwd_kernel(MlpArgs p) {
-  typedef MlpCfg<T, C, RFP, NW, HS> G;
+  typedef MlpCfg<T, C, RFP, NW, HS, HCX> G;
   constexpr int KS = G::KS, NF = G::NF, RF = G::RF, ND = Chain<T>::ND, KSTEP = G::KSTEP, LK = Mma<T>::LANE_K, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];
   __shared__ float red[2][C];
@@ -926,10 +926,10 @@ constexpr int SPLIT_MAX = 8;         // slices of a split launch (the workspace 
 static int mlp_split_for(long long M) { const long long blocks = (M + 63) / 64; return blocks <= 32 ? 8 : (blocks <= 64 ? 4 : 2); }
 static int attn_split_for(long long windows) { return windows <= 48 ? 6 : 2; }
 
-template <typename T, int C, int RFP, int SPLIT = 0, int NW = 4, int HS = 1>
+template <typename T, int C, int RFP, int SPLIT = 0, int NW = 4, int HS = 1, int HCX = 0>
 static int mlp_launch(bool bwd, const MlpArgs& a, hipStream_t st) {
-  typedef MlpCfg<T, C, RFP, NW, HS> G;
-  const void* fn = bwd ? (const void*)swin_mlp_bwd_kernel<T, C, RFP, SPLIT, NW, HS> : (const void*)swin_mlp_fwd_kernel<T, C, RFP, SPLIT, NW, HS>;
+  typedef MlpCfg<T, C, RFP, NW, HS, HCX> G;
+  const void* fn = bwd ? (const void*)swin_mlp_bwd_kernel<T, C, RFP, SPLIT, NW, HS, HCX> : (const void*)swin_mlp_fwd_kernel<T, C, RFP, SPLIT, NW, HS, HCX>;
   static PerDevice<bool> attr[2];
   if (!attr[bwd]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
@@ -938,8 +938,8 @@ static int mlp_launch(bool bwd, const MlpArgs& a, hipStream_t st) {
     attr[bwd] = true;
   }
   dim3 grid((unsigned)((a.M + G::ROWS - 1) / G::ROWS) * (SPLIT ? a.split : 1));
-  if (bwd) hipLaunchKernelGGL((swin_mlp_bwd_kernel<T, C, RFP, SPLIT, NW, HS>), grid, dim3(G::NT), G::LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((swin_mlp_fwd_kernel<T, C, RFP, SPLIT, NW, HS>), grid, dim3(G::NT), G::LDS_BYTES, st, a);
+  if (bwd) hipLaunchKernelGGL((swin_mlp_bwd_kernel<T, C, RFP, SPLIT, NW, HS, HCX>), grid, dim3(G::NT), G::LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((swin_mlp_fwd_kernel<T, C, RFP, SPLIT, NW, HS, HCX>), grid, dim3(G::NT), G::LDS_BYTES, st, a);
   return stj_check_launch(bwd ? "stj_swin_mlp_bwd" : "stj_swin_mlp_fwd");
 }
 template <typename T>
@@ -953,7 +953,13 @@ static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
       //  fragments per wave, i.e. the staged weight chunks and their fragment reads serving 2 / 4 x the rows in 2 / 1 rounds (forward 158 / 250
       //  registers; backward 242, four fragments spill): cfg-512 776 / 778 against 779 scenes/s, inference inside its noise
       //  (profiles/r06_zb_mlp96_rf.txt): the kernel's time is its per-row-fragment latency chain, not staging or rounds.  Not kept.)
-      if constexpr (sizeof(T) == 2) return two ? mlp_launch<T, 96, 1, 0, 8>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
+      // weight chunks of 192 hidden columns (two per block instead of four: half the barriers and commits) at 32768 rows: train step 1420 / 1413 /
+      // 1414 / 1409 against 1411 / 1407 / 1406 / 1408 scenes/s with 96; at 131072 rows (B = 32 inference, cfg-512) 96 stays: inference 5744-5757
+      // against 5790-5820, cfg-512 equal (profiles/r06_zo_mlp_hc96.txt)
+      if constexpr (sizeof(T) == 2) {
+        if (two && a.M < 4LL * 256 * 128) return mlp_launch<T, 96, 1, 0, 8, 1, 192>(bwd, a, st);
+        return two ? mlp_launch<T, 96, 1, 0, 8>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
+      }
       else return two ? mlp_launch<T, 96, 2>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
     case 192: {
       // 8192 rows (cfg-256's 32 x 32 stage at B = 8) are 128 row blocks of 64: with the workspace the hidden dimension is cut in two, 256
