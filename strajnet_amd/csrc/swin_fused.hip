@@ -30,6 +30,9 @@
 #ifndef STJ_MLP_PREFETCH
 #define STJ_MLP_PREFETCH 1      // next weight chunk's global loads issued before the current chunk's MFMAs
 #endif
+#ifndef STJ_ATTN_MINB96
+#define STJ_ATTN_MINB96 3       // swin_attn_fwd at C = 96 (16-bit) compiled for three waves per SIMD (158 registers, no spill; 40 KB of LDS per window: three windows per CU
+#endif                          // instead of two): inference +0.4 %, cfg-512 +0.2 %, train step equal; four (128 registers, 24 spilled) loses 0.7 % (profiles/r06_zr_attn_occ3.txt)
 #ifndef STJ_ATTN_HG192
 #define STJ_ATTN_HG192 2
 #endif
@@ -1138,7 +1141,7 @@ template <typename T, int C, int HGP = 0> struct AttnStage {
 };
 
 template <typename T, int C, int SPLIT = 0, int HGP = 0>
-__global__ __launch_bounds__(256, STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (C == 96 && sizeof(T) == 2) ? STJ_ATTN_MINB96 : STJ_ATTN_MINB) void swin_attn_fwd_kernel(AttnArgs p) {
   typedef AttnCfg<T, C, HGP> G;
   constexpr int KS = G::KS, NF = G::NF, HG = G::HG, GC = G::GC, KSTEP = G::KSTEP, ND = Chain<T>::ND, LK = Mma<T>::LANE_K;
   constexpr int VN = Vec<T>::N;
