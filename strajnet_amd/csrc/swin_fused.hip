@@ -30,6 +30,9 @@
 #ifndef STJ_MLP_PREFETCH
 #define STJ_MLP_PREFETCH 1      // next weight chunk's global loads issued before the current chunk's MFMAs
 #endif
+#ifndef STJ_MLP_HC96W
+#define STJ_MLP_HC96W 192      // C = 96 MLP kernels at 32768 rows: hidden columns per weight chunk (96: -0.6 %; 384 = everything resident, 154 KB of LDS: -0.3 %, profiles/r06_zo_*, r06_zt_*)
+#endif
 #ifndef STJ_ATTN_MINB96
 #define STJ_ATTN_MINB96 3       // swin_attn_fwd at C = 96 (16-bit) compiled for three waves per SIMD (158 registers, no spill; 40 KB of LDS per window: three windows per CU
 #endif                          // instead of two): inference +0.4 %, cfg-512 +0.2 %, train step equal; four (128 registers, 24 spilled) loses 0.7 % (profiles/r06_zr_attn_occ3.txt)
@@ -960,7 +963,7 @@ static int mlp_dispatch(bool bwd, int C, const MlpArgs& a, hipStream_t st) {
       // 1414 / 1409 against 1411 / 1407 / 1406 / 1408 scenes/s with 96; at 131072 rows (B = 32 inference, cfg-512) 96 stays: inference 5744-5757
       // against 5790-5820, cfg-512 equal (profiles/r06_zo_mlp_hc96.txt)
       if constexpr (sizeof(T) == 2) {
-        if (two && a.M < 4LL * 256 * 128) return mlp_launch<T, 96, 1, 0, 8, 1, 192>(bwd, a, st);
+        if (two && a.M < 4LL * 256 * 128) return mlp_launch<T, 96, 1, 0, 8, 1, STJ_MLP_HC96W>(bwd, a, st);
         return two ? mlp_launch<T, 96, 1, 0, 8>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
       }
       else return two ? mlp_launch<T, 96, 2>(bwd, a, st) : mlp_launch<T, 96, 1>(bwd, a, st);
