@@ -993,6 +993,13 @@ def test_swin_mlp_fused(dt, B, N, C, p_drop):
         assert rel_err(p_.grad, r_.grad) < 2 * t, nm
 
 
+@pytest.mark.parametrize('B,N', [(8, 4096), (32, 4096)])
+def test_swin_mlp_fused_c96_wide_row_counts(B, N):
+    """The eight-wave 128-row form of the C = 96 MLP kernels, which the op-level test above never reaches: 32768 rows (the bench's stage 0:
+    192-column weight chunks since round 6) and 131072 rows (B = 32 inference / cfg-512: 96-column chunks), bf16 against float64."""
+    test_swin_mlp_fused(torch.bfloat16, B, N, 96, 0.3)
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('B,res,C,shift,p_drop', [(2, 16, 96, 0, 0.0), (3, 16, 96, 4, 0.3), (2, 16, 192, 4, 0.3), (1, 32, 192, 0, 0.0), (2, 8, 96, 0, 0.0),
                                                   (3, 16, 384, 4, 0.3), (1, 16, 384, 0, 0.0), (2, 8, 384, 0, 0.3), (1, 64, 384, 4, 0.3), (8, 32, 192, 4, 0.3)])
